@@ -1,0 +1,404 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU oracle for the spin-weighted Legendre stage of the HEALPix SHTs.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.  The
+ * product path (plancklens_amd/csrc, HIP) never links or calls it.
+ *
+ * What is restated.  The reference (plancklens/shts.py:12-35) delegates alm2map / map2alm /
+ * alm2map_spin / map2alm_spin to third-party healpy (C++ libsharp; un-vendored, un-pinned:
+ * pyproject.toml:11-16).  Its published algorithm (Reinecke & Seljebotn 2013, "Libsharp - spherical
+ * harmonic transforms revisited") is: per azimuthal order m, a three-term recursion in l of the
+ * normalised spin-weighted Legendre functions on every iso-latitude ring, accumulated into per-ring
+ * Fourier coefficients F_m(ring), followed by one FFT per ring.  This file is the Legendre stage; the
+ * ring FFTs and the HEALPix geometry are in oracle/sht_oracle.py (numpy pocketfft).
+ *
+ * Conventions (plancklens/utils_spin.py:1-16):
+ *   spin 0 :  F_m(theta)         = sum_l a_lm lambda_lm(theta),  Y_lm = lambda_lm e^{i m phi}
+ *   spin s>0: _{+-s}a_lm = -(+-1)^s (G_lm +- i C_lm),  _sf = Q + iU = sum _sa_lm _sY_lm
+ *             _sY_lm(theta,0) = (-1)^s sqrt((2l+1)/4pi) d^l_{m,-s}(theta)
+ *             Fp = -( _slam + (-1)^s _{-s}lam )/2 ,  Fm = -( _slam - (-1)^s _{-s}lam )/2
+ *             Q_m = sum_l (G Fp + i C Fm) ,  U_m = sum_l (C Fp - i G Fm)
+ *   analysis is the exact adjoint: G_lm = sum_rings (Q_m Fp + i U_m Fm), C_lm = sum_rings (U_m Fp - i Q_m Fm)
+ *   (ring quadrature weights and e^{-i m phi0} are applied by the FFT stage).
+ *
+ * Two arithmetic modes:
+ *   mode 0: x87 long double, unscaled textbook Wigner-d recursion seeded from lgamma -- slow,
+ *           obviously correct, used to pin mode 1 and the HIP kernels at small sizes.
+ *   mode 1: double with libsharp-style 2^(+-512) block scaling, ring-blocked and OpenMP-threaded over m;
+ *           this is the "port" CPU baseline timed by bench.py.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_PI 3.14159265358979323846264338327950288L
+
+static inline int64_t alm_index(int lmax, int l, int m) { return (int64_t)m * (2 * lmax + 1 - m) / 2 + l; }
+
+/* ------------------------------------------------------------------------------------------- */
+/* mode 0: long double                                                                         */
+/* ------------------------------------------------------------------------------------------- */
+
+/* Normalised Wigner small-d: out[l] = sqrt((2l+1)/4pi) d^l_{m,n}(theta), l = 0..lmax (0 below max(|m|,|n|)). */
+static void ld_wigd(int m, int n, int lmax, long double theta, long double *out)
+{
+    int am = m < 0 ? -m : m, an = n < 0 ? -n : n;
+    int j = am > an ? am : an;
+    for (int l = 0; l <= lmax; ++l) out[l] = 0.0L;
+    if (j > lmax) return;
+    long double x = cosl(theta), c = cosl(0.5L * theta), s = sinl(0.5L * theta);
+    /* map d^j_{m,n} onto sign * d^j_{j,k} with the symmetries d_{m,n} = (-1)^{m-n} d_{n,m} = d_{-n,-m} */
+    int k; long double sign = 1.0L;
+    if (j == m)       { k = n; }
+    else if (j == n)  { k = m;  if ((j - m) & 1) sign = -1.0L; }        /* d_{m,j} = (-1)^{m-j} d_{j,m} */
+    else if (j == -n) { k = -m; }                                       /* d_{m,-j} = d_{j,-m}          */
+    else              { k = -n; if ((j + n) & 1) sign = -1.0L; }        /* m = -j: d_{-j,n} = (-1)^{n+j} d_{j,-n} */
+    /* d^j_{j,k} = sqrt((2j)!/((j+k)!(j-k)!)) cos^{j+k}(theta/2) (-sin(theta/2))^{j-k} */
+    long double lg = 0.5L * (lgammal(2.0L * j + 1) - lgammal((long double)(j + k) + 1) - lgammal((long double)(j - k) + 1));
+    long double seed;
+    if ((j + k > 0 && c <= 0.0L) || (j - k > 0 && s <= 0.0L)) seed = 0.0L;
+    else {
+        if (j + k > 0) lg += (j + k) * logl(c);
+        if (j - k > 0) lg += (j - k) * logl(s);
+        seed = (lg < -11300.0L) ? 0.0L : expl(lg);
+    }
+    if ((j - k) & 1) sign = -sign;
+    long double dm1 = 0.0L, d0 = sign * seed;
+    out[j] = sqrtl((2.0L * j + 1) / (4.0L * ORC_PI)) * d0;
+    for (int l = j; l < lmax; ++l) {
+        long double d1;
+        if (l == 0) d1 = x * d0; /* m = n = 0 */
+        else {
+            long double L = l, L1 = l + 1;
+            long double num1 = (2 * L + 1) * (L * L1 * x - (long double)m * n);
+            long double num2 = L1 * sqrtl((L * L - (long double)m * m) * (L * L - (long double)n * n));
+            long double den = L * sqrtl((L1 * L1 - (long double)m * m) * (L1 * L1 - (long double)n * n));
+            d1 = (num1 * d0 - num2 * dm1) / den;
+        }
+        dm1 = d0; d0 = d1;
+        out[l + 1] = sqrtl((2.0L * (l + 1) + 1) / (4.0L * ORC_PI)) * d0;
+    }
+}
+
+/* fp[l], fm[l], l = 0..lmax for spin s >= 0 and order m >= 0 at colatitude theta. */
+static void ld_lam(int s, int m, int lmax, long double theta, long double *fp, long double *fm, long double *tmp)
+{
+    if (s == 0) {
+        ld_wigd(m, 0, lmax, theta, fp);
+        for (int l = 0; l <= lmax; ++l) fm[l] = 0.0L;
+        return;
+    }
+    long double sg = (s & 1) ? -1.0L : 1.0L;
+    ld_wigd(m, -s, lmax, theta, fp);   /* -> _slam  = sg * this  */
+    ld_wigd(m, +s, lmax, theta, tmp);  /* -> _-slam = sg * this  */
+    for (int l = 0; l <= lmax; ++l) {
+        long double lp = sg * fp[l], lm = sg * tmp[l];
+        fp[l] = -0.5L * (lp + sg * lm);
+        fm[l] = -0.5L * (lp - sg * lm);
+    }
+}
+
+/* Exported for tests: double copies of Fp, Fm (or lambda_lm for s = 0). */
+void orc_lambda(int s, int m, int lmax, double cth, double sth, double *fp, double *fm)
+{
+    long double *a = malloc(3 * (size_t)(lmax + 1) * sizeof(long double));
+    long double theta = atan2l((long double)sth, (long double)cth);
+    ld_lam(s, m, lmax, theta, a, a + (lmax + 1), a + 2 * (lmax + 1));
+    for (int l = 0; l <= lmax; ++l) { fp[l] = (double)a[l]; fm[l] = (double)a[lmax + 1 + l]; }
+    free(a);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* mode 1: double, scaled                                                                      */
+/* ------------------------------------------------------------------------------------------- */
+#define NV 8                    /* rings per block (vector direction)        */
+#define SCALE_BITS 512
+static const double F_BIG = 0x1p+512, F_SMALL = 0x1p-512, T_BIG = 0x1p+256, T_SMALL = 0x1p-256;
+
+/* value = v * 2^(512 sc); keep |v| in [2^-256, 2^256] */
+static inline void renorm(double *v, int *sc)
+{
+    double a = fabs(*v);
+    if (a > T_BIG) { *v *= F_SMALL; *sc += 1; }
+    else if (a < T_SMALL && a != 0.0) { *v *= F_BIG; *sc -= 1; }
+}
+
+/* b^e (e >= 0, 0 < b <= 1 typically) as scaled number */
+static void scaled_pow(double b, int e, double *v, int *sc)
+{
+    double r = 1.0, bb = b; int rs = 0, bs = 0;
+    while (e) {
+        if (e & 1) { r *= bb; rs += bs; renorm(&r, &rs); }
+        bb *= bb; bs *= 2; renorm(&bb, &bs);
+        e >>= 1;
+    }
+    *v = r; *sc = rs;
+}
+
+/* Per-m tables of the one-step recursion  R_{l+1} = (x a_l - b_l) R_l - c_l R_{l-1}  for the
+ * normalised function  sqrt((2l+1)/4pi) d^l_{m,n}.  (b = 0 for n = 0.)  Computed in long double. */
+typedef struct { double *a, *b, *c; double seedfac; int l0; int psin, phalf, usecos; double seedsign; } rectab;
+
+static void rectab_build(rectab *t, int m, int n, int lmax)
+{
+    int an = n < 0 ? -n : n;
+    int j = m > an ? m : an;
+    t->l0 = j;
+    if (j > lmax) return;
+    for (int l = j; l < lmax; ++l) {
+        long double L = l, L1 = l + 1, M = m, N = n;
+        if (l == 0) { t->a[l] = (double)sqrtl(3.0L); t->b[l] = 0; t->c[l] = 0; continue; }
+        long double den = L * sqrtl((L1 * L1 - M * M) * (L1 * L1 - N * N));
+        long double nrm1 = sqrtl((2 * L1 + 1) / (2 * L + 1));
+        long double nrm2 = sqrtl((2 * L1 + 1) / (2 * L - 1));
+        t->a[l] = (double)(nrm1 * (2 * L + 1) * L * L1 / den);
+        t->b[l] = (double)(nrm1 * (2 * L + 1) * M * N / den);
+        t->c[l] = (l == j) ? 0.0 : (double)(nrm2 * L1 * sqrtl((L * L - M * M) * (L * L - N * N)) / den);
+    }
+    /* seed: sqrt((2j+1)/4pi) * sign * sqrt((2j)!/((j+k)!(j-k)!)) * cos^{j+k}(th/2) * sin^{j-k}(th/2)
+     *     = sign * [sqrt((2j+1)/4pi) sqrt(C(2j,j+k)) 2^-(j-|k|)] * sin^{j-|k|}(th) * (cos or sin)^{2|k|}(th/2) */
+    int k; long double sign = 1.0L;
+    if (j == m)       { k = n; }
+    else if (j == n)  { k = m;  if ((j - m) & 1) sign = -1.0L; }
+    else              { k = -m; }
+    if ((j - k) & 1) sign = -sign;
+    int ak = k < 0 ? -k : k;
+    long double lg = 0.5L * (lgammal(2.0L * j + 1) - lgammal((long double)(j + k) + 1) - lgammal((long double)(j - k) + 1))
+                     - (long double)(j - ak) * logl(2.0L);
+    t->seedfac = (double)(sqrtl((2.0L * j + 1) / (4.0L * ORC_PI)) * expl(lg));
+    t->seedsign = (double)sign;
+    t->psin = j - ak; t->phalf = 2 * ak; t->usecos = k > 0;
+}
+
+/* Fill lam[l*NV + v] (l = l0..lmax) with the IEEE-range values of the function (0 while still below 2^-256),
+ * for NV rings.  Returns the first l with a non-zero entry (lmax + 1 if none). */
+static int rec_fill(const rectab *t, int lmax, const double *x, const double *st, const double *ch, const double *sh, int nv, double *lam)
+{
+    double v1[NV], v2[NV]; int sc[NV];
+    int l0 = t->l0;
+    for (int v = 0; v < NV; ++v) { v1[v] = 0; v2[v] = 0; sc[v] = 0; }
+    for (int v = 0; v < nv; ++v) {
+        double pv, qv; int ps_, qs_;
+        scaled_pow(st[v], t->psin, &pv, &ps_);
+        scaled_pow(t->usecos ? ch[v] : sh[v], t->phalf, &qv, &qs_);
+        double r = pv * qv; int rs = ps_ + qs_;
+        renorm(&r, &rs);
+        r *= t->seedfac * t->seedsign; renorm(&r, &rs);
+        if (r == 0.0) rs = -1000000;
+        v2[v] = r; sc[v] = rs;
+    }
+    for (int v = nv; v < NV; ++v) sc[v] = 0;
+    int l = l0, first = lmax + 1;
+    /* scaled phase: at least one ring still below the IEEE window */
+    for (; l <= lmax; ++l) {
+        int allin = 1;
+        for (int v = 0; v < NV; ++v) allin &= (sc[v] == 0);
+        if (allin) break;
+        int any = 0;
+        for (int v = 0; v < NV; ++v) { double o = (sc[v] == 0) ? v2[v] : 0.0; lam[(size_t)l * NV + v] = o; any |= (sc[v] == 0); }
+        if (any && first > lmax) first = l;
+        if (l == lmax) { ++l; break; }
+        double a = t->a[l], b = t->b[l], c = t->c[l];
+        for (int v = 0; v < NV; ++v) {
+            double nw = (x[v] * a - b) * v2[v] - c * v1[v];
+            v1[v] = v2[v]; v2[v] = nw;
+            if (sc[v] < 0 && fabs(nw) > T_BIG) { v1[v] *= F_SMALL; v2[v] *= F_SMALL; sc[v] += 1; }
+        }
+    }
+    if (l <= lmax && first > lmax) first = l;
+    /* IEEE phase */
+    for (; l <= lmax; ++l) {
+        for (int v = 0; v < NV; ++v) lam[(size_t)l * NV + v] = v2[v];
+        if (l == lmax) break;
+        double a = t->a[l], b = t->b[l], c = t->c[l];
+#pragma omp simd
+        for (int v = 0; v < NV; ++v) {
+            double nw = (x[v] * a - b) * v2[v] - c * v1[v];
+            v1[v] = v2[v]; v2[v] = nw;
+        }
+    }
+    return first;
+}
+
+/* libsharp's polar-optimisation bound: orders m above this contribute < ~1e-30 on the ring */
+static int mlim_ring(int lmax, int spin, double sth, double cth)
+{
+    double ofs = lmax * 0.01;
+    if (ofs < 100.) ofs = 100.;
+    double b = -2 * spin * fabs(cth);
+    double t1 = lmax * sth + ofs;
+    double c = (double)spin * spin - t1 * t1;
+    double discr = b * b - 4 * c;
+    if (discr <= 0) return lmax;
+    double res = (-b + sqrt(discr)) / 2.;
+    if (res > lmax) res = lmax;
+    return (int)(res + 0.5);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* drivers                                                                                     */
+/* ------------------------------------------------------------------------------------------- */
+/* Ring list: nring rings with cos/sin(theta).  If pair[r] != 0 the ring has a mirror partner at
+ * pi - theta whose phases are stored right after the ring's own (slot index 2*r and 2*r + 1 in the
+ * phase array); otherwise slot 2*r + 1 is unused.
+ *
+ * phase layout: [comp][slot = 2*nring][m = 0..mmax] complex (interleaved re, im)
+ * alm layout:   [comp][healpy index] complex interleaved; ncomp = 1 (spin 0) or 2 (G, C).
+ */
+
+static void get_lam_ld(int spin, int m, int lmax, double cth, double sth, double *fp, double *fm, long double *scr)
+{
+    long double theta = atan2l((long double)sth, (long double)cth);
+    ld_lam(spin, m, lmax, theta, scr, scr + (lmax + 1), scr + 2 * (lmax + 1));
+    for (int l = 0; l <= lmax; ++l) { fp[l] = (double)scr[l]; fm[l] = (double)scr[lmax + 1 + l]; }
+}
+
+/* generic kernel given tables of Fp/Fm for one (m, ring): synthesis of both hemispheres */
+static inline void synth_one(int spin, int lmax, int m, int l0, const double *fp, const double *fm, int stride,
+                             const double *almG, const double *almC, /* pointers to (l = 0) of this m, interleaved */
+                             double *qn, double *un, double *qs, double *us)
+{
+    /* accumulate even / odd (l + m + s) parities separately: mirror ring flips the odd Fp and even Fm parts */
+    double qe[2] = {0, 0}, qo[2] = {0, 0}, ue[2] = {0, 0}, uo[2] = {0, 0};
+    for (int l = l0; l <= lmax; ++l) {
+        double p = fp[(size_t)l * stride], q = fm ? fm[(size_t)l * stride] : 0.0;
+        double gr = almG[2 * l], gi = almG[2 * l + 1];
+        double cr = almC ? almC[2 * l] : 0.0, ci = almC ? almC[2 * l + 1] : 0.0;
+        /* Q += G p + i C q ; U += C p - i G q */
+        double tq_p[2] = {gr * p, gi * p}, tq_m[2] = {-ci * q, cr * q};
+        double tu_p[2] = {cr * p, ci * p}, tu_m[2] = {gi * q, -gr * q};
+        if (((l + m + spin) & 1) == 0) { /* Fp even under mirror, Fm odd */
+            qe[0] += tq_p[0]; qe[1] += tq_p[1]; qo[0] += tq_m[0]; qo[1] += tq_m[1];
+            ue[0] += tu_p[0]; ue[1] += tu_p[1]; uo[0] += tu_m[0]; uo[1] += tu_m[1];
+        } else {
+            qo[0] += tq_p[0]; qo[1] += tq_p[1]; qe[0] += tq_m[0]; qe[1] += tq_m[1];
+            uo[0] += tu_p[0]; uo[1] += tu_p[1]; ue[0] += tu_m[0]; ue[1] += tu_m[1];
+        }
+    }
+    qn[0] = qe[0] + qo[0]; qn[1] = qe[1] + qo[1];
+    un[0] = ue[0] + uo[0]; un[1] = ue[1] + uo[1];
+    if (qs) { qs[0] = qe[0] - qo[0]; qs[1] = qe[1] - qo[1]; us[0] = ue[0] - uo[0]; us[1] = ue[1] - uo[1]; }
+}
+
+static inline void anal_one(int spin, int lmax, int m, int l0, const double *fp, const double *fm, int stride,
+                            double *almG, double *almC,
+                            const double *qn, const double *un, const double *qs, const double *us)
+{
+    double qe[2], qo[2], ue[2] = {0, 0}, uo[2] = {0, 0};
+    double z[2] = {0, 0};
+    if (!qs) { qs = z; us = z; }
+    if (!un) { un = z; us = z; }
+    qe[0] = qn[0] + qs[0]; qe[1] = qn[1] + qs[1]; qo[0] = qn[0] - qs[0]; qo[1] = qn[1] - qs[1];
+    ue[0] = un[0] + us[0]; ue[1] = un[1] + us[1]; uo[0] = un[0] - us[0]; uo[1] = un[1] - us[1];
+    for (int l = l0; l <= lmax; ++l) {
+        double p = fp[(size_t)l * stride], q = fm ? fm[(size_t)l * stride] : 0.0;
+        const double *qp, *qm, *up, *um;
+        if (((l + m + spin) & 1) == 0) { qp = qe; qm = qo; up = ue; um = uo; }
+        else { qp = qo; qm = qe; up = uo; um = ue; }
+        /* G += Q p + i U q ; C += U p - i Q q */
+        almG[2 * l] += qp[0] * p - um[1] * q;
+        almG[2 * l + 1] += qp[1] * p + um[0] * q;
+        if (almC) {
+            almC[2 * l] += up[0] * p + qm[1] * q;
+            almC[2 * l + 1] += up[1] * p - qm[0] * q;
+        }
+    }
+}
+
+/* direction: 0 = synthesis (alm -> phase), 1 = analysis (phase -> alm, accumulating into zeroed alm).
+ * mode: 0 long double, 1 scaled double.  Returns 0. */
+int orc_legendre(int direction, int mode, int spin, int lmax, int mmax, int nring,
+                 const double *cth, const double *sth, const int *pair,
+                 double *alm, double *phase, int nthreads)
+{
+    const int ncomp = spin == 0 ? 1 : 2;
+    const int64_t nalm = alm_index(lmax, lmax, mmax) + 1;
+    const int64_t nslot = 2 * (int64_t)nring, mstride = mmax + 1;
+    if (direction == 1) memset(alm, 0, sizeof(double) * 2 * nalm * ncomp);
+    else memset(phase, 0, sizeof(double) * 2 * nslot * mstride * ncomp);
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    int *mlim = malloc(sizeof(int) * nring);
+    for (int r = 0; r < nring; ++r) mlim[r] = mode == 0 ? mmax : mlim_ring(lmax, spin, sth[r], cth[r]);
+
+#pragma omp parallel
+    {
+        double *fp = malloc(sizeof(double) * (size_t)(lmax + 1) * NV);
+        double *fm = malloc(sizeof(double) * (size_t)(lmax + 1) * NV);
+        double *tm = malloc(sizeof(double) * (size_t)(lmax + 1) * NV);
+        long double *scr = malloc(sizeof(long double) * 3 * (size_t)(lmax + 1));
+        rectab tp, tn;
+        tp.a = malloc(sizeof(double) * 3 * (size_t)(lmax + 2)); tp.b = tp.a + lmax + 2; tp.c = tp.b + lmax + 2;
+        tn.a = malloc(sizeof(double) * 3 * (size_t)(lmax + 2)); tn.b = tn.a + lmax + 2; tn.c = tn.b + lmax + 2;
+#pragma omp for schedule(dynamic, 1)
+        for (int m = 0; m <= mmax; ++m) {
+            double *aG = alm + 2 * alm_index(lmax, 0, m);
+            double *aC = ncomp == 2 ? alm + 2 * nalm + 2 * alm_index(lmax, 0, m) : NULL;
+            int l0 = m > spin ? m : spin;
+            if (mode == 1) {
+                rectab_build(&tp, m, -spin, lmax);
+                if (spin) rectab_build(&tn, m, spin, lmax);
+            }
+            for (int r0 = 0; r0 < nring; r0 += (mode == 1 ? NV : 1)) {
+                int nv = 1, first = l0, stride = 1;
+                if (mode == 0) {
+                    get_lam_ld(spin, m, lmax, cth[r0], sth[r0], fp, fm, scr);
+                } else {
+                    nv = nring - r0 < NV ? nring - r0 : NV;
+                    int anyact = 0;
+                    for (int v = 0; v < nv; ++v) anyact |= (m <= mlim[r0 + v]);
+                    if (!anyact) continue;
+                    double x[NV], st[NV], ch[NV], sh[NV];
+                    for (int v = 0; v < NV; ++v) {
+                        int r = r0 + (v < nv ? v : 0);
+                        x[v] = cth[r]; st[v] = sth[r];
+                        /* half-angle functions without cancellation: cos(th/2)^2 = (1+x)/2, sin(th/2) = sin(th) / (2 cos(th/2)) */
+                        if (cth[r] >= 0) { ch[v] = sqrt(0.5 * (1.0 + cth[r])); sh[v] = 0.5 * sth[r] / ch[v]; }
+                        else { sh[v] = sqrt(0.5 * (1.0 - cth[r])); ch[v] = 0.5 * sth[r] / sh[v]; }
+                    }
+                    stride = NV;
+                    int f1 = rec_fill(&tp, lmax, x, st, ch, sh, nv, fp);
+                    first = f1;
+                    if (spin) {
+                        int f2 = rec_fill(&tn, lmax, x, st, ch, sh, nv, tm);
+                        first = f1 < f2 ? f1 : f2;
+                        double sg = (spin & 1) ? -1.0 : 1.0;
+                        for (int l = first; l <= lmax; ++l)
+                            for (int v = 0; v < NV; ++v) {
+                                double lp = sg * fp[(size_t)l * NV + v], lm_ = sg * tm[(size_t)l * NV + v];
+                                if (l < f1) lp = 0; if (l < f2) lm_ = 0;
+                                fp[(size_t)l * NV + v] = -0.5 * (lp + sg * lm_);
+                                fm[(size_t)l * NV + v] = -0.5 * (lp - sg * lm_);
+                            }
+                    }
+                    if (first > lmax) continue;
+                }
+                for (int v = 0; v < nv; ++v) {
+                    int r = r0 + v;
+                    if (mode == 1 && m > mlim[r]) continue;
+                    double *pq_n = phase + 2 * ((2 * (int64_t)r) * mstride + m);
+                    double *pq_s = pair[r] ? phase + 2 * ((2 * (int64_t)r + 1) * mstride + m) : NULL;
+                    double *pu_n = ncomp == 2 ? pq_n + 2 * nslot * mstride : NULL;
+                    double *pu_s = (ncomp == 2 && pq_s) ? pq_s + 2 * nslot * mstride : NULL;
+                    double dum[2];
+                    if (direction == 0) {
+                        double du[2], dus[2];
+                        synth_one(spin, lmax, m, first, fp + v, spin ? fm + v : NULL, stride, aG, aC,
+                                  pq_n, pu_n ? pu_n : du, pq_s ? pq_s : NULL, pq_s ? (pu_s ? pu_s : dus) : NULL);
+                    } else {
+                        anal_one(spin, lmax, m, first, fp + v, spin ? fm + v : NULL, stride, aG, aC,
+                                 pq_n, pu_n, pq_s, pu_s);
+                    }
+                    (void)dum;
+                }
+            }
+        }
+        free(fp); free(fm); free(tm); free(scr); free(tp.a); free(tn.a);
+    }
+    free(mlim);
+    return 0;
+}

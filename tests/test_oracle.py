@@ -1,0 +1,153 @@
+"""Pins the CPU oracle (test infrastructure) -- SURVEY.md section 8(c) substitutes (i)-(iii).
+
+The reference has no SHT test, so the oracle is pinned by closed-form known answers, by the reference's
+own Fortran Wigner module (built from /root/reference into oracle/_ref/ when present), by a brute-force
+pixel-by-pixel evaluation of the definition, by adjointness, and by long-double vs scaled-double agreement.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from plancklens_amd import hp
+from helpers import random_alm, alm_dot, relrms, alm_size
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFSO = os.path.join(os.path.dirname(HERE), 'oracle', '_ref', 'libwigners_ref.so')
+
+
+def test_monopole_dipole(oracle):
+    """a_00 = sqrt(4pi) -> 1; xyz_to_alm dipole (template_removal.py:153-158)."""
+    nside, lmax = 8, 16
+    for mode in (0, 1):
+        alm = np.zeros(alm_size(lmax), complex)
+        alm[0] = np.sqrt(4 * np.pi)
+        assert np.abs(oracle.alm2map(alm, nside, mode=mode) - 1).max() < 1e-14
+        x, y, z = 0.3, -0.7, 1.1
+        alm[:] = 0
+        alm[1] = z * np.sqrt(4 * np.pi / 3)
+        alm[hp.Alm.getidx(lmax, 1, 1)] = (-x + 1j * y) * np.sqrt(2 * np.pi / 3)
+        vx, vy, vz = hp.pix2vec(nside)
+        assert np.abs(oracle.alm2map(alm, nside, mode=mode) - (x * vx + y * vy + z * vz)).max() < 1e-14
+    # A.5 (iii): equal-area pixels -> map2alm of the constant map gives exactly sqrt(4pi)
+    a = oracle.map2alm(np.ones(12 * nside ** 2), lmax)
+    assert abs(a[0] - np.sqrt(4 * np.pi)) < 1e-14
+
+
+@pytest.mark.parametrize('spin', [0, 1, 2, 3])
+def test_brute_force_and_modes(oracle, spin):
+    """Definition (pixel by pixel) == separable long double == scaled double."""
+    rng = np.random.default_rng(10 + spin)
+    nside, lmax = 4, 11
+    g, c = random_alm(rng, lmax, spin), random_alm(rng, lmax, spin)
+    if spin == 0:
+        ref = oracle.brute_alm2map_spin([g], nside, 0, lmax)
+        m0 = oracle.alm2map(g, nside, mode=0, use_pairs=False)
+        m1 = oracle.alm2map(g, nside, mode=1)
+        assert relrms(m0, ref) < 1e-13 and relrms(m1, ref) < 1e-13
+    else:
+        ref = oracle.brute_alm2map_spin([g, c], nside, spin, lmax)
+        m0 = oracle.alm2map_spin([g, c], nside, spin, lmax, mode=0, use_pairs=False)
+        m1 = oracle.alm2map_spin([g, c], nside, spin, lmax, mode=1)
+        for i in range(2):
+            assert relrms(m0[i], ref[i]) < 1e-13 and relrms(m1[i], ref[i]) < 1e-13
+
+
+@pytest.mark.parametrize('spin', [0, 1, 2, 3])
+def test_adjointness(oracle, spin):
+    """<map, alm2map(a)> = npix/4pi <map2alm(map), a>  (opfilt_tt.py:190)."""
+    rng = np.random.default_rng(20 + spin)
+    nside, lmax = 8, 20
+    npix = 12 * nside ** 2
+    for mode in (0, 1):
+        if spin == 0:
+            a = random_alm(rng, lmax)
+            t = rng.standard_normal(npix)
+            lhs = np.sum(t * oracle.alm2map(a, nside, mode=mode))
+            rhs = npix / (4 * np.pi) * alm_dot(oracle.map2alm(t, lmax, mode=mode), a, lmax)
+        else:
+            g, c = random_alm(rng, lmax, spin), random_alm(rng, lmax, spin)
+            q, u = rng.standard_normal(npix), rng.standard_normal(npix)
+            mq, mu = oracle.alm2map_spin([g, c], nside, spin, lmax, mode=mode)
+            ga, ca = oracle.map2alm_spin([q, u], spin, lmax, mode=mode)
+            lhs = np.sum(q * mq + u * mu)
+            rhs = npix / (4 * np.pi) * (alm_dot(ga, g, lmax) + alm_dot(ca, c, lmax))
+        assert abs(lhs - rhs) < 1e-12 * abs(lhs)
+
+
+@pytest.mark.parametrize('spin', [0, 1, 2, 3])
+def test_scaled_vs_longdouble_high_m(oracle, spin):
+    """Scaled double arithmetic (mode 1) in the regime where sin^m(theta) underflows IEEE double."""
+    rng = np.random.default_rng(30 + spin)
+    nside, lmax = 16, 47
+    cth, sth, nphi, phi0, ofs = oracle.ring_geometry(nside)
+    # long lmax on few rings: rings near the pole, lmax = 1500 -> sin^m underflows for m > ~ 400
+    lmax = 1500
+    rings = np.array([0, 1, 2, 5, 9, 15, 23, 31])
+    ncomp = 1 if spin == 0 else 2
+    alm = np.stack([random_alm(rng, lmax, spin) for _ in range(ncomp)])
+    pair = np.ones(rings.size, dtype=np.int32)
+    p0 = oracle.legendre(0, 0, spin, lmax, lmax, cth[rings], sth[rings], pair, alm=alm)
+    p1 = oracle.legendre(0, 1, spin, lmax, lmax, cth[rings], sth[rings], pair, alm=alm)
+    assert relrms(p1, p0) < 1e-12
+    a0 = oracle.legendre(1, 0, spin, lmax, lmax, cth[rings], sth[rings], pair, phase=p0)
+    a1 = oracle.legendre(1, 1, spin, lmax, lmax, cth[rings], sth[rings], pair, phase=p0)
+    assert relrms(a1, a0) < 1e-12
+
+
+@pytest.mark.skipif(not os.path.exists(REFSO), reason='oracle/_ref not built (needs /root/reference + amdflang)')
+@pytest.mark.parametrize('spin', [0, 1, 2, 3])
+def test_against_reference_fortran_wigners(oracle, spin):
+    """_slambda_lm from the reference's wigners.f90 (wigners.f90:566-624),
+    _sY_lm(theta, 0) = (-1)^s sqrt((2l+1)/4pi) d^l_{m,-s}(theta); wignerpos(cl, x, s1, s2) returns
+    sum_l cl_l (2l+1)/(4pi) d^l_{s1 s2}(x)."""
+    lib = ctypes.CDLL(REFSO)
+    dp = ctypes.POINTER(ctypes.c_double)
+    ip = ctypes.POINTER(ctypes.c_int)
+
+    def wigd(l, m, n, x, lmax):
+        cl = np.zeros(lmax + 1)
+        cl[l] = 1.
+        xi = np.zeros(x.size)
+        nx, lm_, s1, s2 = (ctypes.c_int(v) for v in (x.size, lmax, m, n))
+        lib.wignerpos_(xi.ctypes.data_as(dp), ctypes.byref(nx), ctypes.byref(lm_), cl.ctypes.data_as(dp),
+                       x.ctypes.data_as(dp), ctypes.byref(s1), ctypes.byref(s2))
+        return xi * 4 * np.pi / (2 * l + 1)
+
+    lmax = 24
+    x = np.array([-0.93, -0.41, 0.07, 0.55, 0.88])
+    sg = (-1.) ** spin
+    for m in (0, 1, 2, 5, 17):
+        for l in range(max(m, spin), lmax, 5):  # wignerpos needs lmax > lmin (SURVEY.md 8(c) caveat)
+            nrm = np.sqrt((2 * l + 1) / (4 * np.pi))
+            lam_p = sg * nrm * wigd(l, m, -spin, x, lmax)
+            lam_m = sg * nrm * wigd(l, m, spin, x, lmax)
+            for ix, xx in enumerate(x):
+                fp, fm = oracle.lambda_lm(spin, m, lmax, xx, np.sqrt(1 - xx * xx))
+                if spin == 0:
+                    assert abs(fp[l] - lam_p[ix]) < 1e-13
+                else:
+                    assert abs(fp[l] - (-0.5) * (lam_p[ix] + sg * lam_m[ix])) < 1e-13
+                    assert abs(fm[l] - (-0.5) * (lam_p[ix] - sg * lam_m[ix])) < 1e-13
+
+
+def test_gradient_spin1(oracle):
+    """with _1X_lm = -(G + iC) and the Goldberg edth, edth T = -(d_theta + i/sin d_phi) T
+    = sum sqrt(l(l+1)) T_lm _1Y_lm, so alm2map_spin([-sqrt(l(l+1)) T_lm, 0], 1) (qest.py:592-593) is edth T
+    = -(d_theta T, d_phi T / sin theta); equivalently G = +sqrt(l(l+1)) phi_lm gives +grad(phi), the lensing
+    deflection convention.  For the dipole T = cos(theta): (+sin theta, 0)."""
+    nside, lmax = 8, 4
+    alm = np.zeros(alm_size(lmax), complex)
+    alm[1] = np.sqrt(4 * np.pi / 3)  # T = cos(theta)
+    fl = -np.sqrt(np.arange(lmax + 1.) * np.arange(1, lmax + 2.))
+    g = hp.almxfl(alm, fl)
+    re, im = oracle.alm2map_spin([g, np.zeros_like(g)], nside, 1, lmax)
+    th, ph = hp.pix2ang(nside)
+    assert np.abs(re - np.sin(th)).max() < 1e-13 and np.abs(im).max() < 1e-13
+    # T = x = sin(theta) cos(phi): -(d_theta T, d_phi T / sin) = (-cos(theta) cos(phi), +sin(phi))
+    alm[:] = 0
+    alm[hp.Alm.getidx(lmax, 1, 1)] = -np.sqrt(2 * np.pi / 3)
+    g = hp.almxfl(alm, fl)
+    re, im = oracle.alm2map_spin([g, np.zeros_like(g)], nside, 1, lmax)
+    assert np.abs(re + np.cos(th) * np.cos(ph)).max() < 1e-13 and np.abs(im - np.sin(ph)).max() < 1e-13
