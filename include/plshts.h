@@ -1,0 +1,88 @@
+/* plshts.h -- C ABI of the MI355X (gfx950) HEALPix spherical-harmonic-transform engine.
+ *
+ * Drop-in boundary for the SHT seam of carronj/plancklens.  The reference reaches its SHTs through
+ * Python functions with healpy's signatures (plancklens/shts.py:12-35, and direct hp.* calls at
+ * qest.py:259,280,464,504,514,530, filt/filt_simple.py:399,404, qcinv/opfilt_tt.py:34,187,189,
+ * qcinv/opfilt_pp.py:260,265,314, qcinv/opfilt_tp.py:23,276,281).  A ctypes module
+ * (plancklens_amd/_lib.py) binds the entry points below and re-creates those signatures
+ * (plancklens_amd/shts.py); INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Data conventions (healpy):
+ *   alm : complex128 as interleaved (re, im) doubles, m-major triangular, idx(l,m) = m(2 lmax+1-m)/2 + l,
+ *         mmax = lmax, size nalm = (lmax+1)(lmax+2)/2; spin > 0 takes [G | C] = 2 * nalm complex.
+ *   map : float64 RING-ordered, npix = 12 nside^2; spin > 0 takes [Q | U] = 2 * npix doubles.
+ *   map2alm uses uniform pixel weights 4 pi / npix and no iterations (every reference call passes iter=0).
+ *
+ * All pointers are plain device or host pointers (flag PL_HOST / PL_DEVICE); no framework types.
+ * Every call is stream-ordered on `stream` (a hipStream_t passed as void*, NULL = default stream) and
+ * asynchronous with device pointers; with host pointers it synchronises before returning.
+ * Return value: 0 on success, non-zero on error (message from pl_last_error()).
+ * A plan is bound to the device that was current when it was created and is not thread-safe.
+ */
+#ifndef PLSHTS_H
+#define PLSHTS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pl_plan pl_plan;
+
+#define PL_HOST 0   /* alm / map / fl pointers are host memory   */
+#define PL_DEVICE 1 /* alm / map / fl pointers are device memory */
+
+/* ABI version of this header (bumped on incompatible change). */
+int pl_version(void);
+const char *pl_last_error(void);
+/* Number of visible HIP devices, or -1 (with pl_last_error set) if the runtime cannot be initialised. */
+int pl_device_count(void);
+
+/* Plan: HEALPix ring geometry, recursion tables and FFT tables for one (nside, lmax, mmax = lmax).
+ * Replaces what healpy / libsharp build internally per call (shts.py:13,18,23,28 build a geometry per call). */
+int pl_plan_create(int nside, int lmax, pl_plan **plan);
+int pl_plan_destroy(pl_plan *plan);
+int64_t pl_plan_npix(const pl_plan *plan);
+int64_t pl_plan_nalm(const pl_plan *plan);
+int64_t pl_plan_bytes(const pl_plan *plan); /* device bytes held by the plan */
+
+/* shts.alm2map (shts.py:12-15) / shts.alm2map_spin (shts.py:22-24).  spin = 0: alm -> map;
+ * spin = 1,2,3: [G|C] -> [Q|U].  If fl != NULL (length lmax + 1) the alm are multiplied by fl_l on the
+ * fly (hp.almxfl fused; qest.py:463,502-503,592).  Inputs are not modified. */
+int pl_alm2map(pl_plan *plan, int spin, const double *alm, double *map, const double *fl, int where, void *stream);
+
+/* shts.map2alm(iter=0) (shts.py:16-20) / shts.map2alm_spin (shts.py:26-30).  If fl != NULL the
+ * result is multiplied by fl_l (hp.almxfl fused; filt_simple.py:400,405-406, qest.py:261-262). */
+int pl_map2alm(pl_plan *plan, int spin, const double *map, double *alm, const double *fl, int where, void *stream);
+
+/* Stage-level entry points (used by tests and by bench.py to time the dominant kernel in isolation).
+ * phase buffer: [npairs][mstride][ncomp][4] doubles = (F_north re, im, F_south re, im). */
+int64_t pl_plan_phase_doubles(const pl_plan *plan, int spin);
+int pl_legendre_synth(pl_plan *plan, int spin, const double *alm_dev, const double *fl_dev, double *phase_dev, void *stream);
+int pl_legendre_anal(pl_plan *plan, int spin, const double *phase_dev, double *alm_dev, const double *fl_dev, void *stream);
+int pl_phase2map(pl_plan *plan, int spin, const double *phase_dev, double *map_dev, void *stream);
+int pl_map2phase(pl_plan *plan, int spin, const double *map_dev, double *phase_dev, void *stream);
+
+/* Harmonic-space helpers on device arrays (hp.almxfl: 147 call sites; hp.alm2cl / dot_op:
+ * opfilt_tt.py:43-51, opfilt_pp.py:27-34, qecl.py:147-148; utils.alm_copy: utils.py:19-35). */
+int pl_almxfl(int lmax, const double *alm_in, const double *fl, int nfl, double *alm_out, void *stream);
+int pl_alm2cl(int lmax, const double *alm_a, const double *alm_b, double *cl_out /* lmax+1, device */, void *stream);
+int pl_alm_copy(int lmax_in, const double *alm_in, int lmax_out, double *alm_out, void *stream);
+/* out = a * x + y on n doubles (cd_solve.py:75,86,102 axpy on alm arrays), all device pointers. */
+int pl_axpy(int64_t n, double a, const double *x, const double *y, double *out, void *stream);
+
+/* Pixel-space helpers (qest.py:256-257,276-278; opfilt_tt.py:195, opfilt_pp.py:276-299). */
+/* out = a * b (element-wise, n doubles) */
+int pl_map_mul(int64_t n, const double *a, const double *b, double *out, void *stream);
+/* complex product of spin maps: (or + i oi) (+)= sign * (ar + s1 i ai)(br + s2 i bi); accumulate != 0 adds into out */
+int pl_map_cmul(int64_t n, const double *ar, const double *ai, double s1, const double *br, const double *bi, double s2,
+                double sign, double *outr, double *outi, int accumulate, void *stream);
+
+/* FP64 FMA-rate microbenchmark (independent chains, no memory traffic): returns achieved TFLOP/s. */
+double pl_fma64_peak_tflops(int iters, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

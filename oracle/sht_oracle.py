@@ -25,12 +25,30 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
+def _cpu_tag():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('flags'):
+                    import hashlib
+                    return hashlib.sha1(line.encode()).hexdigest()[:12]
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def build(force=False):
-    """Compile oracle/libshtoracle.so (and oracle/_ref when /root/reference is present)."""
+    """Compile oracle/libshtoracle.so (and oracle/_ref when /root/reference is present).  The library is
+    built with -march=native, so it is rebuilt when the host CPU differs from the one it was built on."""
     so = os.path.join(_HERE, 'libshtoracle.so')
     src = os.path.join(_HERE, 'sht_oracle.c')
-    if force or (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(['make', '-C', _HERE, 'libshtoracle.so'], stdout=subprocess.DEVNULL)
+    tagf = so + '.cpu'
+    tag = _cpu_tag()
+    old = open(tagf).read().strip() if os.path.exists(tagf) else ''
+    if force or (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src) or old != tag:
+        subprocess.check_call(['make', '-B', '-C', _HERE, 'libshtoracle.so'], stdout=subprocess.DEVNULL)
+        with open(tagf, 'w') as f:
+            f.write(tag)
     if os.path.exists('/root/reference/plancklens/wigners/wigners.f90') and \
             not os.path.exists(os.path.join(_HERE, '_ref', 'libwigners_ref.so')):
         subprocess.call(['make', '-C', _HERE, 'ref'], stdout=subprocess.DEVNULL)

@@ -1,0 +1,72 @@
+"""ctypes binding of the C ABI declared in include/plshts.h (the drop-in boundary).
+
+The product path has no CPU fallback: if the HIP library is missing or no GPU is visible, every transform
+raises.  Loading the library itself needs no GPU (used by the `not gpu` tests to check the exported symbols).
+"""
+import ctypes
+import os
+
+from . import _build
+
+_LIB = None
+
+SYMBOLS = ['pl_version', 'pl_last_error', 'pl_device_count', 'pl_plan_create', 'pl_plan_destroy', 'pl_plan_npix',
+           'pl_plan_nalm', 'pl_plan_bytes', 'pl_alm2map', 'pl_map2alm', 'pl_plan_phase_doubles', 'pl_legendre_synth',
+           'pl_legendre_anal', 'pl_phase2map', 'pl_map2phase', 'pl_almxfl', 'pl_alm2cl', 'pl_alm_copy', 'pl_axpy',
+           'pl_map_mul', 'pl_map_cmul', 'pl_fma64_peak_tflops']
+
+PL_HOST, PL_DEVICE = 0, 1
+
+
+class PlshtsError(AssertionError):
+    """Raised on a non-zero return of the C ABI (AssertionError-compatible: the reference only asserts)."""
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = _build.lib_path()
+    if not os.path.exists(so):
+        raise RuntimeError('%s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                           '(the HIP path has no CPU fallback)' % so)
+    L = ctypes.CDLL(so)
+    vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+    L.pl_version.restype = i32
+    L.pl_last_error.restype = ctypes.c_char_p
+    L.pl_device_count.restype = i32
+    L.pl_plan_create.argtypes = [i32, i32, ctypes.POINTER(vp)]
+    L.pl_plan_destroy.argtypes = [vp]
+    for f in ('pl_plan_npix', 'pl_plan_nalm', 'pl_plan_bytes'):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = i64
+    L.pl_plan_phase_doubles.argtypes = [vp, i32]
+    L.pl_plan_phase_doubles.restype = i64
+    L.pl_alm2map.argtypes = [vp, i32, vp, vp, vp, i32, vp]
+    L.pl_map2alm.argtypes = [vp, i32, vp, vp, vp, i32, vp]
+    L.pl_legendre_synth.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.pl_legendre_anal.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.pl_phase2map.argtypes = [vp, i32, vp, vp, vp]
+    L.pl_map2phase.argtypes = [vp, i32, vp, vp, vp]
+    L.pl_almxfl.argtypes = [i32, vp, vp, i32, vp, vp]
+    L.pl_alm2cl.argtypes = [i32, vp, vp, vp, vp]
+    L.pl_alm_copy.argtypes = [i32, vp, i32, vp, vp]
+    L.pl_axpy.argtypes = [i64, dbl, vp, vp, vp, vp]
+    L.pl_map_mul.argtypes = [i64, vp, vp, vp, vp]
+    L.pl_map_cmul.argtypes = [i64, vp, vp, dbl, vp, vp, dbl, dbl, vp, vp, i32, vp]
+    L.pl_fma64_peak_tflops.argtypes = [i32, vp]
+    L.pl_fma64_peak_tflops.restype = dbl
+    _LIB = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise PlshtsError(lib().pl_last_error().decode())
+
+
+def device_count():
+    n = lib().pl_device_count()
+    if n < 0:
+        raise RuntimeError(lib().pl_last_error().decode())
+    return n

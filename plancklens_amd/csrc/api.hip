@@ -1,0 +1,400 @@
+// C ABI (include/plshts.h): plan management and the stream-ordered transform entry points.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/plshts.h"
+#include "device_plan.h"
+#include "plshts_internal.h"
+#include "ringfft.h"
+
+namespace plshts {
+int rings_per_group(int spin);
+void launch_prep0(const DevPlan &P, const double *alm, const double *fl, double *prep, hipStream_t st);
+void launch_preps(const DevPlan &P, const DevSpinTab &S, int spin, const double *alm, const double *fl, double *prep, hipStream_t st);
+void launch_synth0(const DevPlan &P, const double *prep, double *phase, hipStream_t st);
+void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st);
+void launch_anal0(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st);
+void launch_anals(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
+                  const double *fl, double *alm, hipStream_t st);
+void launch_almxfl(int lmax, const double *in, const double *fl, int nfl, double *out, hipStream_t st);
+void launch_alm_copy(int lmax_in, const double *in, int lmax_out, double *out, hipStream_t st);
+void launch_alm2cl(int lmax, const double *a, const double *b, double *cl, hipStream_t st);
+void launch_axpy(int64_t n, double a, const double *x, const double *y, double *out, hipStream_t st);
+void launch_map_mul(int64_t n, const double *a, const double *b, double *out, hipStream_t st);
+void launch_map_cmul(int64_t n, const double *ar, const double *ai, double s1, const double *br, const double *bi, double s2,
+                     double sign, double *outr, double *outi, int accumulate, hipStream_t st);
+void launch_fma_peak(int iters, double *out, int nblk, hipStream_t st);
+}  // namespace plshts
+
+using namespace plshts;
+
+static thread_local std::string g_err;
+static int fail(const std::string &msg)
+{
+    g_err = msg;
+    return 1;
+}
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+struct pl_plan {
+    int device = 0;
+    DevPlan P{};
+    DevFFT F{};
+    DevSpinTab S[kMaxSpin + 1]{};
+    bool have_spin[kMaxSpin + 1] = {false, false, false, false};
+    int64_t nent[kMaxSpin + 1] = {0, 0, 0, 0};
+    std::vector<void *> allocs;
+    int64_t bytes = 0;
+    // workspaces (grown on demand)
+    double *phase = nullptr; int64_t phase_cap = 0;
+    double *prep = nullptr; int64_t prep_cap = 0;
+    double *partial = nullptr; int64_t partial_cap = 0;
+    double *h_alm = nullptr; int64_t h_alm_cap = 0;   // device staging for host-pointer calls
+    double *h_map = nullptr; int64_t h_map_cap = 0;
+    double *h_fl = nullptr;
+};
+
+template <typename T>
+static int upload(pl_plan *p, const std::vector<T> &v, const T **out)
+{
+    void *d = nullptr;
+    size_t nb = v.size() * sizeof(T);
+    if (nb == 0) nb = sizeof(T);
+    HIPCHK(hipMalloc(&d, nb));
+    p->allocs.push_back(d);
+    p->bytes += nb;
+    if (!v.empty()) HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T *>(d);
+    return 0;
+}
+
+static int grow(pl_plan *p, double **buf, int64_t *cap, int64_t ndoubles)
+{
+    if (*cap >= ndoubles) return 0;
+    if (*buf) { HIPCHK(hipFree(*buf)); p->bytes -= *cap * 8; }
+    *buf = nullptr; *cap = 0;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(buf), ndoubles * sizeof(double)));
+    *cap = ndoubles;
+    p->bytes += ndoubles * 8;
+    return 0;
+}
+
+static int ensure_spin(pl_plan *p, int spin)
+{
+    if (spin < 1 || spin > kMaxSpin) return fail("spin must be 1, 2 or 3");
+    if (p->have_spin[spin]) return 0;
+    SpinTables t;
+    build_spin_tables(spin, p->P.lmax, p->P.mmax, t);
+    DevSpinTab &S = p->S[spin];
+    if (upload(p, t.off, &S.off) || upload(p, t.ab, &S.ab) || upload(p, t.beta, &S.beta) || upload(p, t.seedfac_n, &S.seedfac_n) ||
+        upload(p, t.seedfac_p, &S.seedfac_p) || upload(p, t.psin, &S.psin) || upload(p, t.phalf, &S.phalf) ||
+        upload(p, t.usecos_n, &S.usecos_n) || upload(p, t.usecos_p, &S.usecos_p))
+        return 1;
+    RingGeom g;
+    build_geometry(p->P.nside, g);
+    std::vector<int> mlim(g.npairs);
+    for (int i = 0; i < g.npairs; ++i) mlim[i] = mlim_ring(p->P.lmax, spin, g.sth[i], g.cth[i]);
+    if (upload(p, mlim, &S.mlim)) return 1;
+    S.gstart = nullptr;
+    p->nent[spin] = t.off.back();
+    p->have_spin[spin] = true;
+    return 0;
+}
+
+static inline int ncomp_of(int spin) { return spin == 0 ? 1 : 2; }
+static inline const int *mlim_of(pl_plan *p, int spin) { return spin == 0 ? p->P.mlim0 : p->S[spin].mlim; }
+
+extern "C" {
+
+int pl_version(void) { return 1; }
+const char *pl_last_error(void) { return g_err.c_str(); }
+
+int pl_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { g_err = std::string("hipGetDeviceCount: ") + hipGetErrorString(e); return -1; }
+    return n;
+}
+
+int pl_plan_create(int nside, int lmax, pl_plan **out)
+{
+    if (!out) return fail("null plan pointer");
+    *out = nullptr;
+    if (nside < 1 || nside > 8192) return fail("nside out of range [1, 8192]");
+    if (lmax < 0 || lmax > 4 * nside) return fail("lmax out of range [0, 4 nside]");
+    pl_plan *p = new pl_plan();
+    if (hipGetDevice(&p->device) != hipSuccess) { delete p; return fail("no HIP device (hipGetDevice failed)"); }
+    DevPlan &P = p->P;
+    P.nside = nside; P.lmax = lmax; P.mmax = lmax;
+    P.npix = 12LL * nside * nside;
+    P.nalm = (int64_t)(lmax + 1) * (lmax + 2) / 2;
+    P.mstride = (lmax + 1 + 3) / 4 * 4;
+    RingGeom g;
+    build_geometry(nside, g);
+    P.npairs = g.npairs;
+    int rc = upload(p, g.cth, &P.cth) || upload(p, g.sth, &P.sth) || upload(p, g.chalf, &P.chalf) || upload(p, g.shalf, &P.shalf) ||
+             upload(p, g.phi0, &P.phi0) || upload(p, g.nphi, &P.nphi) || upload(p, g.ofs_n, &P.ofs_n) || upload(p, g.ofs_s, &P.ofs_s);
+    Spin0Tables t0;
+    build_spin0_tables(lmax, lmax, t0);
+    rc = rc || upload(p, t0.off, &P.off0) || upload(p, t0.ab, &P.ab0) || upload(p, t0.alpha, &P.alpha0) || upload(p, t0.eps, &P.eps0) ||
+         upload(p, t0.seed, &P.seed0);
+    P.nent0 = t0.off.back();
+    p->nent[0] = P.nent0;
+    std::vector<int> mlim(g.npairs);
+    for (int i = 0; i < g.npairs; ++i) mlim[i] = mlim_ring(lmax, 0, g.sth[i], g.cth[i]);
+    rc = rc || upload(p, mlim, &P.mlim0);
+    if (rc) { pl_plan_destroy(p); return 1; }
+
+    // FFT tables: ring lengths 4 q, q = 1 .. nside
+    DevFFT &F = p->F;
+    std::vector<int> Mof(nside + 1, 0), qlist;
+    std::vector<int64_t> woff(nside + 1, 0), coff(nside + 1, 0);
+    int64_t nw = 0, nc = 0;
+    int Lmax = 1;
+    for (int q = 1; q <= nside; ++q) {
+        bool present = (q < nside) || true;  // q = nside: equatorial rings
+        if (!present) continue;
+        if ((q & (q - 1)) == 0) { Mof[q] = 0; if (q > Lmax) Lmax = q; continue; }
+        int M = 2;
+        while (M < 2 * q - 1) M <<= 1;
+        Mof[q] = M; woff[q] = nw; coff[q] = nc; nw += q; nc += M;
+        if (M > Lmax) Lmax = M;
+        qlist.push_back(q);
+    }
+    F.Mtw = Lmax < 2 ? 2 : Lmax;
+    F.Lmax = Lmax;
+    if ((size_t)Lmax * 16 > 160 * 1024) { pl_plan_destroy(p); return fail("ring FFT workspace exceeds the 160 KiB LDS of a CU"); }
+    double *tw = nullptr, *chirp = nullptr, *filt = nullptr;
+    const int *qlist_dev = nullptr;
+    auto dalloc = [&](double **ptr, int64_t nd) -> int {
+        if (nd < 2) nd = 2;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(ptr), nd * sizeof(double)));
+        p->allocs.push_back(*ptr);
+        p->bytes += nd * 8;
+        return 0;
+    };
+    rc = dalloc(&tw, F.Mtw) || dalloc(&chirp, 2 * nw) || dalloc(&filt, 2 * nc) || upload(p, Mof, &F.Mof) || upload(p, woff, &F.woff) ||
+         upload(p, coff, &F.coff) || upload(p, qlist, &qlist_dev);
+    if (rc) { pl_plan_destroy(p); return 1; }
+    F.tw = reinterpret_cast<const double2 *>(tw);
+    F.chirp = reinterpret_cast<const double2 *>(chirp);
+    F.filt = reinterpret_cast<const double2 *>(filt);
+    hipError_t e = launch_twiddles(tw, F.Mtw, nullptr);
+    if (e == hipSuccess) e = launch_bluestein_setup(F, qlist_dev, (int)qlist.size(), chirp, filt, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { pl_plan_destroy(p); return fail(std::string("FFT table setup: ") + hipGetErrorString(e)); }
+    *out = p;
+    return 0;
+}
+
+int pl_plan_destroy(pl_plan *p)
+{
+    if (!p) return 0;
+    for (void *d : p->allocs) (void)hipFree(d);
+    if (p->phase) (void)hipFree(p->phase);
+    if (p->prep) (void)hipFree(p->prep);
+    if (p->partial) (void)hipFree(p->partial);
+    if (p->h_alm) (void)hipFree(p->h_alm);
+    if (p->h_map) (void)hipFree(p->h_map);
+    if (p->h_fl) (void)hipFree(p->h_fl);
+    delete p;
+    return 0;
+}
+
+int64_t pl_plan_npix(const pl_plan *p) { return p ? p->P.npix : 0; }
+int64_t pl_plan_nalm(const pl_plan *p) { return p ? p->P.nalm : 0; }
+int64_t pl_plan_bytes(const pl_plan *p) { return p ? p->bytes : 0; }
+
+int64_t pl_plan_phase_doubles(const pl_plan *p, int spin)
+{
+    if (!p) return 0;
+    return (int64_t)p->P.npairs * p->P.mstride * 4 * ncomp_of(spin);
+}
+
+int pl_legendre_synth(pl_plan *p, int spin, const double *alm, const double *fl, double *phase, void *stream)
+{
+    if (!p) return fail("null plan");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (spin == 0) {
+        if (grow(p, &p->prep, &p->prep_cap, p->P.nent0 * 4)) return 1;
+        launch_prep0(p->P, alm, fl, p->prep, st);
+        launch_synth0(p->P, p->prep, phase, st);
+    } else {
+        if (ensure_spin(p, spin)) return 1;
+        if (grow(p, &p->prep, &p->prep_cap, p->nent[spin] * 4)) return 1;
+        launch_preps(p->P, p->S[spin], spin, alm, fl, p->prep, st);
+        launch_synths(p->P, p->S[spin], spin, p->prep, phase, st);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_legendre_anal(pl_plan *p, int spin, const double *phase, double *alm, const double *fl, void *stream)
+{
+    if (!p) return fail("null plan");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int RG = rings_per_group(spin);
+    const int ngroups = (p->P.npairs + RG - 1) / RG;
+    if (spin == 0) {
+        if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * p->P.nent0 * 4)) return 1;
+        launch_anal0(p->P, phase, p->partial, fl, alm, st);
+    } else {
+        if (ensure_spin(p, spin)) return 1;
+        if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * p->nent[spin] * 4)) return 1;
+        launch_anals(p->P, p->S[spin], spin, p->nent[spin], phase, p->partial, fl, alm, st);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_phase2map(pl_plan *p, int spin, const double *phase, double *map, void *stream)
+{
+    if (!p) return fail("null plan");
+    if (spin && ensure_spin(p, spin)) return 1;
+    HIPCHK(launch_phase2map(p->P, p->F, mlim_of(p, spin), ncomp_of(spin), phase, map, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int pl_map2phase(pl_plan *p, int spin, const double *map, double *phase, void *stream)
+{
+    if (!p) return fail("null plan");
+    if (spin && ensure_spin(p, spin)) return 1;
+    HIPCHK(launch_map2phase(p->P, p->F, mlim_of(p, spin), ncomp_of(spin), map, phase, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+static int stage_fl(pl_plan *p, const double *fl, int where, hipStream_t st, const double **fl_dev)
+{
+    *fl_dev = nullptr;
+    if (!fl) return 0;
+    if (where == PL_DEVICE) { *fl_dev = fl; return 0; }
+    if (!p->h_fl) { HIPCHK(hipMalloc(reinterpret_cast<void **>(&p->h_fl), (p->P.lmax + 1) * sizeof(double))); p->bytes += (p->P.lmax + 1) * 8; }
+    HIPCHK(hipMemcpyAsync(p->h_fl, fl, (p->P.lmax + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+    *fl_dev = p->h_fl;
+    return 0;
+}
+
+int pl_alm2map(pl_plan *p, int spin, const double *alm, double *map, const double *fl, int where, void *stream)
+{
+    if (!p) return fail("null plan");
+    if (spin < 0 || spin > kMaxSpin) return fail("spin must be 0..3");
+    if (!alm || !map) return fail("null alm / map pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nc = ncomp_of(spin);
+    const double *alm_d = alm, *fl_d = nullptr;
+    double *map_d = map;
+    if (stage_fl(p, fl, where, st, &fl_d)) return 1;
+    if (where == PL_HOST) {
+        if (grow(p, &p->h_alm, &p->h_alm_cap, 2 * p->P.nalm * nc) || grow(p, &p->h_map, &p->h_map_cap, p->P.npix * nc)) return 1;
+        HIPCHK(hipMemcpyAsync(p->h_alm, alm, 2 * p->P.nalm * nc * sizeof(double), hipMemcpyHostToDevice, st));
+        alm_d = p->h_alm; map_d = p->h_map;
+    }
+    if (grow(p, &p->phase, &p->phase_cap, pl_plan_phase_doubles(p, spin))) return 1;
+    if (pl_legendre_synth(p, spin, alm_d, fl_d, p->phase, stream)) return 1;
+    if (pl_phase2map(p, spin, p->phase, map_d, stream)) return 1;
+    if (where == PL_HOST) {
+        HIPCHK(hipMemcpyAsync(map, map_d, p->P.npix * nc * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+int pl_map2alm(pl_plan *p, int spin, const double *map, double *alm, const double *fl, int where, void *stream)
+{
+    if (!p) return fail("null plan");
+    if (spin < 0 || spin > kMaxSpin) return fail("spin must be 0..3");
+    if (!alm || !map) return fail("null alm / map pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nc = ncomp_of(spin);
+    const double *map_d = map, *fl_d = nullptr;
+    double *alm_d = alm;
+    if (stage_fl(p, fl, where, st, &fl_d)) return 1;
+    if (where == PL_HOST) {
+        if (grow(p, &p->h_alm, &p->h_alm_cap, 2 * p->P.nalm * nc) || grow(p, &p->h_map, &p->h_map_cap, p->P.npix * nc)) return 1;
+        HIPCHK(hipMemcpyAsync(p->h_map, map, p->P.npix * nc * sizeof(double), hipMemcpyHostToDevice, st));
+        map_d = p->h_map; alm_d = p->h_alm;
+    }
+    if (grow(p, &p->phase, &p->phase_cap, pl_plan_phase_doubles(p, spin))) return 1;
+    if (pl_map2phase(p, spin, map_d, p->phase, stream)) return 1;
+    if (pl_legendre_anal(p, spin, p->phase, alm_d, fl_d, stream)) return 1;
+    if (where == PL_HOST) {
+        HIPCHK(hipMemcpyAsync(alm, alm_d, 2 * p->P.nalm * nc * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+int pl_almxfl(int lmax, const double *alm_in, const double *fl, int nfl, double *alm_out, void *stream)
+{
+    launch_almxfl(lmax, alm_in, fl, nfl, alm_out, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_alm2cl(int lmax, const double *a, const double *b, double *cl, void *stream)
+{
+    launch_alm2cl(lmax, a, b ? b : a, cl, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_alm_copy(int lmax_in, const double *in, int lmax_out, double *out, void *stream)
+{
+    launch_alm_copy(lmax_in, in, lmax_out, out, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_axpy(int64_t n, double a, const double *x, const double *y, double *out, void *stream)
+{
+    launch_axpy(n, a, x, y, out, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_map_mul(int64_t n, const double *a, const double *b, double *out, void *stream)
+{
+    launch_map_mul(n, a, b, out, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_map_cmul(int64_t n, const double *ar, const double *ai, double s1, const double *br, const double *bi, double s2, double sign,
+                double *outr, double *outi, int accumulate, void *stream)
+{
+    launch_map_cmul(n, ar, ai, s1, br, bi, s2, sign, outr, outi, accumulate, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+double pl_fma64_peak_tflops(int iters, void *stream)
+{
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double *out = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&out), 8) != hipSuccess) return -1.0;
+    const int nblk = 256 * 8;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    launch_fma_peak(iters / 8 + 1, out, nblk, st);
+    hipEventRecord(e0, st);
+    launch_fma_peak(iters, out, nblk, st);
+    hipEventRecord(e1, st);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(out);
+    const double flops = 2.0 * 16.0 * (double)iters * 256.0 * nblk;
+    return flops / (ms * 1e-3) / 1e12;
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+// HBM-bound helpers on alm / map arrays (hp.almxfl, hp.alm2cl, alm_copy, axpy, pixel products) and the
+// FP64 FMA-rate microbenchmark.  All are streaming kernels: coalesced 16-byte accesses, grid-stride.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace plshts {
+
+// alm index -> (l, m) without a table: thread per (m, l) on a 2-D grid
+__global__ void k_almxfl(int lmax, const double2 *__restrict__ in, const double *__restrict__ fl, int nfl, double2 *__restrict__ out)
+{
+    const int m = blockIdx.y;
+    const int64_t base = (int64_t)m * (2 * lmax + 1 - m) / 2;
+    for (int l = m + blockIdx.x * blockDim.x + threadIdx.x; l <= lmax; l += gridDim.x * blockDim.x) {
+        const double f = l < nfl ? fl[l] : 0.0;
+        const double2 a = in[base + l];
+        out[base + l] = make_double2(a.x * f, a.y * f);
+    }
+}
+
+__global__ void k_alm_copy(int lmax_in, const double2 *__restrict__ in, int lmax_out, double2 *__restrict__ out)
+{
+    const int m = blockIdx.y;
+    const int64_t bo = (int64_t)m * (2 * lmax_out + 1 - m) / 2;
+    const int64_t bi = (int64_t)m * (2 * lmax_in + 1 - m) / 2;
+    for (int l = m + blockIdx.x * blockDim.x + threadIdx.x; l <= lmax_out; l += gridDim.x * blockDim.x)
+        out[bo + l] = (l <= lmax_in && m <= lmax_in) ? in[bi + l] : make_double2(0., 0.);
+}
+
+// cl[l] = 1/(2l+1) sum_m w_m Re(a b*); one workgroup per l, deterministic tree reduction
+__global__ void k_alm2cl(int lmax, const double2 *__restrict__ a, const double2 *__restrict__ b, double *__restrict__ cl)
+{
+    __shared__ double red[256];
+    const int l = blockIdx.x;
+    double s = 0.0;
+    for (int m = threadIdx.x; m <= l; m += blockDim.x) {
+        const int64_t i = (int64_t)m * (2 * lmax + 1 - m) / 2 + l;
+        const double2 x = a[i], y = b[i];
+        const double p = x.x * y.x + x.y * y.y;
+        s += (m == 0) ? p : 2.0 * p;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = blockDim.x >> 1; h >= 1; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cl[l] = red[0] / (2.0 * l + 1.0);
+}
+
+__global__ void k_axpy(int64_t n, double a, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = fma(a, x[i], y[i]);
+}
+
+__global__ void k_map_mul(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = a[i] * b[i];
+}
+
+__global__ void k_map_cmul(int64_t n, const double *__restrict__ ar, const double *__restrict__ ai, double s1,
+                           const double *__restrict__ br, const double *__restrict__ bi, double s2, double sign,
+                           double *__restrict__ outr, double *__restrict__ outi, int accumulate)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double xr = ar[i], xi = s1 * ai[i], yr = br[i], yi = s2 * bi[i];
+        double pr = sign * (xr * yr - xi * yi), pi = sign * (xr * yi + xi * yr);
+        if (accumulate) { pr += outr[i]; pi += outi[i]; }
+        outr[i] = pr; outi[i] = pi;
+    }
+}
+
+// 16 independent FMA chains per lane: the FP64 vector-FMA issue ceiling of the chip
+__global__ __launch_bounds__(256) void k_fma_peak(int iters, double *out)
+{
+    double a[16];
+    const double x = 1.0 + 1e-9 * threadIdx.x, y = 1e-12 * blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = i * 0.125;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = fma(a[i], x, y);
+    }
+    double s = 0.;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += a[i];
+    if (s == 12345.678) out[0] = s;
+}
+
+static inline int nblocks(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+
+void launch_almxfl(int lmax, const double *in, const double *fl, int nfl, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_almxfl, dim3(4, lmax + 1), dim3(256), 0, st, lmax, reinterpret_cast<const double2 *>(in), fl, nfl,
+                       reinterpret_cast<double2 *>(out));
+}
+void launch_alm_copy(int lmax_in, const double *in, int lmax_out, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_alm_copy, dim3(4, lmax_out + 1), dim3(256), 0, st, lmax_in, reinterpret_cast<const double2 *>(in),
+                       lmax_out, reinterpret_cast<double2 *>(out));
+}
+void launch_alm2cl(int lmax, const double *a, const double *b, double *cl, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_alm2cl, dim3(lmax + 1), dim3(256), 0, st, lmax, reinterpret_cast<const double2 *>(a),
+                       reinterpret_cast<const double2 *>(b), cl);
+}
+void launch_axpy(int64_t n, double a, const double *x, const double *y, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_axpy, dim3(nblocks(n)), dim3(256), 0, st, n, a, x, y, out);
+}
+void launch_map_mul(int64_t n, const double *a, const double *b, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_map_mul, dim3(nblocks(n)), dim3(256), 0, st, n, a, b, out);
+}
+void launch_map_cmul(int64_t n, const double *ar, const double *ai, double s1, const double *br, const double *bi, double s2,
+                     double sign, double *outr, double *outi, int accumulate, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_map_cmul, dim3(nblocks(n)), dim3(256), 0, st, n, ar, ai, s1, br, bi, s2, sign, outr, outi, accumulate);
+}
+void launch_fma_peak(int iters, double *out, int nblk, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_fma_peak, dim3(nblk), dim3(256), 0, st, iters, out);
+}
+
+}  // namespace plshts

@@ -1,0 +1,140 @@
+// Per-lane arithmetic of the Legendre kernels: scaled seeds, recursion steps, alm <-> recursion-basis
+// transforms.  Everything here is __host__ __device__ so that tests/host/ can run the very same code on
+// the CPU (one "lane" at a time) against the oracle before anything touches a GPU.
+#pragma once
+#include <cmath>
+
+#if defined(__HIPCC__)
+#define PL_HD __host__ __device__ __forceinline__
+#else
+#define PL_HD inline
+#endif
+
+namespace plshts {
+
+// A value is represented as v * 2^(512 s), s <= 0, with |v| kept inside [2^-256, 2^256] while s < 0.
+// A lane is "active" (s == 0) once the true value has reached 2^-256; below that its contribution to
+// any sum is < 1e-77 of an O(1) term and is dropped, exactly as libsharp does below its own threshold.
+constexpr double kFBig = 0x1p+512, kFSmall = 0x1p-512, kTBig = 0x1p+256, kTSmall = 0x1p-256;
+constexpr int kNeverActive = -(1 << 28);
+
+PL_HD void renorm(double &v, int &s)
+{
+    double a = fabs(v);
+    if (a > kTBig) { v *= kFSmall; s += 1; }
+    else if (a < kTSmall && a != 0.0) { v *= kFBig; s -= 1; }
+}
+
+// b^e for 0 <= b <= 1, e >= 0 by binary powering with renormalisation
+PL_HD void scaled_pow(double b, int e, double &v, int &s)
+{
+    double r = 1.0, bb = b;
+    int rs = 0, bs = 0;
+    while (e) {
+        if (e & 1) { r *= bb; rs += bs; renorm(r, rs); }
+        bb *= bb; bs *= 2; renorm(bb, bs);
+        e >>= 1;
+    }
+    v = r; s = rs;
+}
+
+PL_HD double small_pow(double b, int e)
+{
+    double r = 1.0;
+    for (int i = 0; i < e; ++i) r *= b;
+    return r;
+}
+
+// ---- spin 0, two-step recursion ---------------------------------------------------------------------
+// state: p0 = P_{il-1}, p1 = P_il (scaled by 2^(512 sc)), x2 = cos^2(theta)
+struct Rec0 {
+    double p0, p1, x2;
+    int sc;
+};
+
+PL_HD void rec0_init(Rec0 &r, double seed_m, int m, double cth, double sth, bool ring_active)
+{
+    r.x2 = cth * cth;
+    r.p0 = 0.0;
+    double v; int s;
+    scaled_pow(sth, m, v, s);
+    v *= seed_m;
+    renorm(v, s);
+    if (!ring_active || v == 0.0) { v = 0.0; s = kNeverActive; }
+    if (s > 0) { v *= kFBig; s -= 1; }  // cannot happen for |seed| sin^m < 2^256, kept for safety
+    r.p1 = v; r.sc = s;
+}
+
+// advance il -> il + 1 (A, B of the current il)
+PL_HD void rec0_step_fast(Rec0 &r, double A, double B)
+{
+    double t = fma(A, r.x2, B);
+    double pn = fma(t, r.p1, -r.p0);
+    r.p0 = r.p1; r.p1 = pn;
+}
+
+PL_HD void rec0_step_careful(Rec0 &r, double A, double B)
+{
+    rec0_step_fast(r, A, B);
+    if (r.sc < 0 && fabs(r.p1) > kTBig) { r.p0 *= kFSmall; r.p1 *= kFSmall; r.sc += 1; }
+}
+
+// value usable in sums for the current il (0 while still scaled)
+PL_HD double rec0_value(const Rec0 &r) { return r.sc == 0 ? r.p1 : 0.0; }
+
+// ---- spin s >= 1, one-step recursion of the (n = -s, n = +s) pair --------------------------------------
+struct RecS {
+    double n0, n1, p0, p1, x;  // S^-_{l-1}, S^-_l, S^+_{l-1}, S^+_l, cos(theta)
+    int scn, scp;
+};
+
+PL_HD void recs_seed_one(double fac, int psin, int phalf, double sth, double half, bool ring_active, double &v, int &s)
+{
+    scaled_pow(sth, psin, v, s);
+    v *= small_pow(half, phalf);
+    renorm(v, s);
+    v *= fac;
+    renorm(v, s);
+    if (!ring_active || v == 0.0) { v = 0.0; s = kNeverActive; }
+    if (s > 0) { v *= kFBig; s -= 1; }
+}
+
+PL_HD void recs_init(RecS &r, double fac_n, double fac_p, int psin, int phalf, int usecos_n, int usecos_p,
+                     double cth, double sth, double chalf, double shalf, bool ring_active)
+{
+    r.x = cth; r.n0 = 0.0; r.p0 = 0.0;
+    recs_seed_one(fac_n, psin, phalf, sth, usecos_n ? chalf : shalf, ring_active, r.n1, r.scn);
+    recs_seed_one(fac_p, psin, phalf, sth, usecos_p ? chalf : shalf, ring_active, r.p1, r.scp);
+}
+
+PL_HD void recs_step_fast(RecS &r, double a, double b)
+{
+    double tn = fma(r.x, a, b);   // n = -s:  x a + b
+    double tp = fma(r.x, a, -b);  // n = +s:  x a - b
+    double nn = fma(tn, r.n1, -r.n0);
+    double pn = fma(tp, r.p1, -r.p0);
+    r.n0 = r.n1; r.n1 = nn; r.p0 = r.p1; r.p1 = pn;
+}
+
+PL_HD void recs_step_careful(RecS &r, double a, double b)
+{
+    recs_step_fast(r, a, b);
+    if (r.scn < 0 && fabs(r.n1) > kTBig) { r.n0 *= kFSmall; r.n1 *= kFSmall; r.scn += 1; }
+    if (r.scp < 0 && fabs(r.p1) > kTBig) { r.p0 *= kFSmall; r.p1 *= kFSmall; r.scp += 1; }
+}
+
+PL_HD double recs_value_n(const RecS &r) { return r.scn == 0 ? r.n1 : 0.0; }
+PL_HD double recs_value_p(const RecS &r) { return r.scp == 0 ? r.p1 : 0.0; }
+
+// ---- alm <-> recursion basis ---------------------------------------------------------------------------
+// spin 0 synthesis: sum_l a_l lambda_l = sum_il (c_il + x d_il) P_il with
+//   c_il = alpha_l (eps_{l+1} a_l + eps_{l+2} a_{l+2}),  d_il = alpha_l a_{l+1},  l = m + 2 il  (a_{>lmax} = 0)
+// spin 0 analysis (adjoint): a_l = eps_{l+1} alpha_l C_il + eps_l alpha_{l-2} C_{il-1} (l - m even),
+//                            a_{l+1} = alpha_l D_il
+// spin s synthesis: An_l = -1/2 sg beta_l (G + iC)_l, Ap_l = -1/2 beta_l (G - iC)_l, sg = (-1)^s
+//   X_N = sum Sn An, Y_N = sum Sp Ap, X_S = sum sigma_l Sp An, Y_S = sum sigma_l Sn Ap, sigma_l = (-1)^{l+m}
+//   Q = X + Y, U = i (Y - X)
+// spin s analysis: Tn_l = sum_rings Sn_l (Wp_N + sigma_l Wm_S), Tp_l = sum_rings Sp_l (Wm_N + sigma_l Wp_S),
+//   Wp = Q + iU, Wm = Q - iU;  G_l = -1/2 beta_l (sg Tn + Tp),  C_l = i/2 beta_l (sg Tn - Tp)
+
+}  // namespace plshts

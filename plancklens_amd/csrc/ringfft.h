@@ -1,0 +1,26 @@
+// FFT-stage tables (device pointers) and launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "device_plan.h"
+
+namespace plshts {
+
+struct DevFFT {
+    const double2 *tw;       // e^{-2 pi i t / Mtw}, t < Mtw / 2
+    int Mtw;                 // largest power-of-two transform size used by the plan
+    int Lmax;                // LDS workspace elements (double2) per workgroup
+    const int *Mof;          // [nside + 1] Bluestein size for ring length 4 q, 0 when q is a power of two
+    const int64_t *woff;     // [nside + 1] offset of q's chirp (q entries)
+    const int64_t *coff;     // [nside + 1] offset of q's filter spectrum (M entries)
+    const double2 *chirp;    // e^{i pi t^2 / q}
+    const double2 *filt;     // bit-reversed FFT_M of the wrapped conj chirp, times 1 / M
+};
+
+hipError_t launch_phase2map(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *phase, double *map, hipStream_t st);
+hipError_t launch_map2phase(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *map, double *phase, hipStream_t st);
+hipError_t launch_twiddles(double *tw, int Mtw, hipStream_t st);
+hipError_t launch_bluestein_setup(const DevFFT &F, const int *qlist_dev, int nq, double *chirp, double *filt, hipStream_t st);
+
+}  // namespace plshts

@@ -1,0 +1,203 @@
+"""MI355X spherical harmonic transforms behind the reference's SHT seam.
+
+Mirrors plancklens/shts.py:12-35 (alm2map, map2alm, alm2map_spin, map2alm_spin with healpy's signatures and
+semantics) and the direct hp.* SHT call shapes used by the reference (qest.py:259,514, opfilt_tp.py:276,281).
+The arithmetic runs in the hand-written HIP kernels of plancklens_amd/csrc through the C ABI of
+include/plshts.h; there is no CPU fallback (a missing library or GPU raises).
+
+numpy in -> numpy out (host pointers, synchronous: the reference's blocking call semantics, inputs are never
+modified).  torch CUDA tensors in -> torch CUDA tensors out (device pointers, asynchronous on torch's current
+stream): used by the device-resident QE / CG layers.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .hp import Alm, npix2nside
+
+try:  # torch is only plumbing for device memory / streams
+    import torch
+except ImportError:  # pragma: no cover
+    torch = None
+
+_PLANS = {}
+
+
+class Plan(object):
+    """One (nside, lmax) plan of the HIP engine (ring geometry, recursion and FFT tables, workspaces)."""
+
+    def __init__(self, nside, lmax):
+        L = _lib.lib()
+        if _lib.device_count() < 1:
+            raise RuntimeError('no HIP device visible: plancklens_amd.shts has no CPU path')
+        h = ctypes.c_void_p()
+        _lib.check(L.pl_plan_create(int(nside), int(lmax), ctypes.byref(h)))
+        self.h = h
+        self.nside, self.lmax = int(nside), int(lmax)
+        self.npix = int(L.pl_plan_npix(h))
+        self.nalm = int(L.pl_plan_nalm(h))
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                _lib.lib().pl_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def bytes(self):
+        return int(_lib.lib().pl_plan_bytes(self.h))
+
+    def phase_doubles(self, spin):
+        return int(_lib.lib().pl_plan_phase_doubles(self.h, int(spin)))
+
+
+def get_plan(nside, lmax):
+    key = (int(nside), int(lmax))
+    if key not in _PLANS:
+        _PLANS[key] = Plan(*key)
+    return _PLANS[key]
+
+
+def clear_plans():
+    _PLANS.clear()
+
+
+def _is_dev(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if _is_dev(a):
+        return ctypes.c_void_p(a.data_ptr())
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def _fl_arg(fl, lmax, dev):
+    """l-filter zero-extended / truncated to lmax + 1 entries (hp.almxfl semantics)."""
+    if fl is None:
+        return None
+    if dev:
+        f = torch.zeros(lmax + 1, dtype=torch.float64, device='cuda')
+        flt = fl if _is_dev(fl) else torch.as_tensor(np.asarray(fl, dtype=np.float64))
+        n = min(lmax + 1, flt.numel())
+        f[:n] = flt[:n].to('cuda')
+        return f
+    f = np.zeros(lmax + 1, dtype=np.float64)
+    fl = np.asarray(fl, dtype=np.float64)
+    n = min(lmax + 1, fl.size)
+    f[:n] = fl[:n]
+    return f
+
+
+def _synth(spin, alm, nside, lmax, fl=None):
+    """alm: (nalm,) or (2, nalm) complex128 -> map (npix,) or (2, npix) float64."""
+    dev = _is_dev(alm)
+    plan = get_plan(nside, lmax)
+    ncomp = 1 if spin == 0 else 2
+    f = _fl_arg(fl, lmax, dev)
+    L = _lib.lib()
+    if dev:
+        a = alm.to(torch.complex128).contiguous()
+        assert a.numel() == ncomp * plan.nalm, (a.shape, plan.nalm)
+        out = torch.empty((ncomp, plan.npix) if ncomp == 2 else (plan.npix,), dtype=torch.float64, device=a.device)
+        _lib.check(L.pl_alm2map(plan.h, spin, _ptr(a), _ptr(out), _ptr(f), _lib.PL_DEVICE, _stream()))
+        return out
+    a = np.ascontiguousarray(alm, dtype=np.complex128)
+    assert a.size == ncomp * plan.nalm, (a.shape, plan.nalm)
+    out = np.empty((ncomp, plan.npix) if ncomp == 2 else (plan.npix,), dtype=np.float64)
+    _lib.check(L.pl_alm2map(plan.h, spin, _ptr(a), _ptr(out), _ptr(f), _lib.PL_HOST, None))
+    return out
+
+
+def _anal(spin, maps, lmax, fl=None):
+    dev = _is_dev(maps)
+    ncomp = 1 if spin == 0 else 2
+    L = _lib.lib()
+    if dev:
+        m = maps.to(torch.float64).contiguous()
+        npix = m.numel() // ncomp
+        plan = get_plan(npix2nside(npix), lmax)
+        f = _fl_arg(fl, lmax, True)
+        out = torch.empty((ncomp, plan.nalm) if ncomp == 2 else (plan.nalm,), dtype=torch.complex128, device=m.device)
+        _lib.check(L.pl_map2alm(plan.h, spin, _ptr(m), _ptr(out), _ptr(f), _lib.PL_DEVICE, _stream()))
+        return out
+    m = np.ascontiguousarray(maps, dtype=np.float64)
+    npix = m.size // ncomp
+    plan = get_plan(npix2nside(npix), lmax)
+    f = _fl_arg(fl, lmax, False)
+    out = np.empty((ncomp, plan.nalm) if ncomp == 2 else (plan.nalm,), dtype=np.complex128)
+    _lib.check(L.pl_map2alm(plan.h, spin, _ptr(m), _ptr(out), _ptr(f), _lib.PL_HOST, None))
+    return out
+
+
+def _stack(pair):
+    if _is_dev(pair):
+        return pair
+    if _is_dev(pair[0]):
+        return torch.stack([pair[0], pair[1]])
+    return np.stack([np.asarray(pair[0]), np.asarray(pair[1])])
+
+
+# ---- the four functions of plancklens/shts.py --------------------------------------------------------
+def alm2map(alm, nside, lmax=None, mmax=None, pol=False, verbose=False, fl=None, **kwargs):
+    """hp.alm2map (shts.py:12-15): T(p) = sum a_lm Y_lm(p).  pol=True takes (t, e, b) (opfilt_tp.py:276)."""
+    if pol or (not _is_dev(alm) and np.ndim(alm) == 2 and len(alm) == 3) or (_is_dev(alm) and alm.dim() == 2 and alm.shape[0] == 3):
+        t, e, b = alm[0], alm[1], alm[2]
+        lm = Alm.getlmax(t.numel() if _is_dev(t) else np.size(t)) if lmax is None else lmax
+        tm = alm2map(t, nside, lmax=lm)
+        qu = alm2map_spin([e, b], nside, 2, lm)
+        return [tm, qu[0], qu[1]]
+    size = alm.numel() if _is_dev(alm) else np.size(alm)
+    if lmax is None:
+        lmax = Alm.getlmax(size)
+    assert lmax >= 0 and Alm.getsize(lmax) == size, 'alm size does not match lmax (mmax = lmax only)'
+    assert mmax is None or mmax == lmax
+    return _synth(0, alm, nside, lmax, fl=fl)
+
+
+def map2alm(m, lmax=None, mmax=None, iter=0, pol=False, use_weights=False, fl=None, **kwargs):
+    """hp.map2alm(iter=0) (shts.py:16-20): uniform-weight quadrature, no Jacobi iterations.
+    pol=True takes [T, Q, U] (opfilt_tp.py:281)."""
+    assert iter == 0, 'only iter=0 is implemented: every reference call passes iter=0 (SURVEY.md Appendix A.2)'
+    assert not use_weights
+    if pol or (not _is_dev(m) and np.ndim(m) == 2 and len(m) == 3) or (_is_dev(m) and m.dim() == 2 and m.shape[0] == 3):
+        t = map2alm(m[0], lmax=lmax, iter=0)
+        lm = Alm.getlmax(t.numel() if _is_dev(t) else t.size)
+        e, b = map2alm_spin([m[1], m[2]], 2, lm)
+        return [t, e, b]
+    npix = m.numel() if _is_dev(m) else np.size(m)
+    nside = npix2nside(npix)
+    if lmax is None:
+        lmax = 3 * nside - 1
+    assert mmax is None or mmax == lmax
+    return _anal(0, m, lmax, fl=fl)
+
+
+def alm2map_spin(gclm, nside, spin, lmax, mmax=None, fl=None):
+    """hp.alm2map_spin (shts.py:22-24): (Re, Im) of sum -(G + iC) _sY_lm, spin = 1, 2, 3."""
+    assert spin > 0, spin
+    assert len(gclm) == 2, len(gclm)
+    assert mmax is None or mmax == lmax
+    out = _synth(int(spin), _stack(gclm), nside, lmax, fl=fl)
+    return [out[0], out[1]]
+
+
+def map2alm_spin(maps, spin, lmax=None, mmax=None, fl=None):
+    """hp.map2alm_spin (shts.py:26-30): the 4 pi / npix weighted adjoint of alm2map_spin; returns [G, C]."""
+    assert spin > 0, spin
+    assert len(maps) == 2
+    m = _stack(maps)
+    npix = m.shape[1]
+    if lmax is None:
+        lmax = 3 * npix2nside(npix) - 1
+    assert mmax is None or mmax == lmax
+    out = _anal(int(spin), m, lmax, fl=fl)
+    return [out[0], out[1]]
