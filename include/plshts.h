@@ -64,6 +64,15 @@ int pl_legendre_anal(pl_plan *plan, int spin, const double *phase_dev, double *a
 int pl_phase2map(pl_plan *plan, int spin, const double *phase_dev, double *map_dev, void *stream);
 int pl_map2phase(pl_plan *plan, int spin, const double *map_dev, double *phase_dev, void *stream);
 
+/* Per-stage timing with HIP events recorded on the caller's stream around the dominant kernels (used by
+ * bench.py for the roofline numbers).  Kinds: 0 Legendre synthesis spin 0, 1 Legendre synthesis spin s,
+ * 2 Legendre analysis spin 0 (+ reduction), 3 Legendre analysis spin s (+ reduction), 4 ring FFT synthesis,
+ * 5 ring FFT analysis.  pl_profile_read synchronises the recorded events, returns summed milliseconds and
+ * launch counts per kind (arrays of PL_PROFILE_KINDS entries) and resets the record. */
+#define PL_PROFILE_KINDS 6
+int pl_profile_enable(pl_plan *plan, int on);
+int pl_profile_read(pl_plan *plan, double *ms_sum, int64_t *counts);
+
 /* Harmonic-space helpers on device arrays (hp.almxfl: 147 call sites; hp.alm2cl / dot_op:
  * opfilt_tt.py:43-51, opfilt_pp.py:27-34, qecl.py:147-148; utils.alm_copy: utils.py:19-35). */
 int pl_almxfl(int lmax, const double *alm_in, const double *fl, int nfl, double *alm_out, void *stream);

@@ -60,6 +60,28 @@ struct pl_plan {
     double *h_alm = nullptr; int64_t h_alm_cap = 0;   // device staging for host-pointer calls
     double *h_map = nullptr; int64_t h_map_cap = 0;
     double *h_fl = nullptr;
+    // optional per-stage timing with HIP events on the caller's stream (pl_profile_*)
+    bool profiling = false;
+    struct Ev { int kind; hipEvent_t e0, e1; };
+    std::vector<Ev> events;
+};
+
+enum { PK_LEG_SYNTH0 = 0, PK_LEG_SYNTHS, PK_LEG_ANAL0, PK_LEG_ANALS, PK_FFT_SYNTH, PK_FFT_ANAL, PK_NKINDS };
+
+struct ProfScope {
+    pl_plan *p; hipStream_t st; hipEvent_t e0 = nullptr, e1 = nullptr; int kind;
+    ProfScope(pl_plan *p_, int kind_, hipStream_t st_) : p(p_), st(st_), kind(kind_)
+    {
+        if (!p->profiling) return;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+        (void)hipEventRecord(e0, st);
+    }
+    ~ProfScope()
+    {
+        if (!e0) return;
+        (void)hipEventRecord(e1, st);
+        p->events.push_back({kind, e0, e1});
+    }
 };
 
 template <typename T>
@@ -210,6 +232,28 @@ int pl_plan_destroy(pl_plan *p)
     return 0;
 }
 
+int pl_profile_enable(pl_plan *p, int on)
+{
+    if (!p) return fail("null plan");
+    p->profiling = on != 0;
+    return 0;
+}
+
+int pl_profile_read(pl_plan *p, double *ms_sum, int64_t *counts)
+{
+    if (!p) return fail("null plan");
+    for (int k = 0; k < PK_NKINDS; ++k) { ms_sum[k] = 0.0; counts[k] = 0; }
+    for (auto &ev : p->events) {
+        float ms = 0.f;
+        HIPCHK(hipEventSynchronize(ev.e1));
+        HIPCHK(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+        ms_sum[ev.kind] += ms; counts[ev.kind] += 1;
+        (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1);
+    }
+    p->events.clear();
+    return 0;
+}
+
 int64_t pl_plan_npix(const pl_plan *p) { return p ? p->P.npix : 0; }
 int64_t pl_plan_nalm(const pl_plan *p) { return p ? p->P.nalm : 0; }
 int64_t pl_plan_bytes(const pl_plan *p) { return p ? p->bytes : 0; }
@@ -227,12 +271,12 @@ int pl_legendre_synth(pl_plan *p, int spin, const double *alm, const double *fl,
     if (spin == 0) {
         if (grow(p, &p->prep, &p->prep_cap, p->P.nent0 * 4)) return 1;
         launch_prep0(p->P, alm, fl, p->prep, st);
-        launch_synth0(p->P, p->prep, phase, st);
+        { ProfScope ps(p, PK_LEG_SYNTH0, st); launch_synth0(p->P, p->prep, phase, st); }
     } else {
         if (ensure_spin(p, spin)) return 1;
         if (grow(p, &p->prep, &p->prep_cap, p->nent[spin] * 4)) return 1;
         launch_preps(p->P, p->S[spin], spin, alm, fl, p->prep, st);
-        launch_synths(p->P, p->S[spin], spin, p->prep, phase, st);
+        { ProfScope ps(p, PK_LEG_SYNTHS, st); launch_synths(p->P, p->S[spin], spin, p->prep, phase, st); }
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -246,11 +290,11 @@ int pl_legendre_anal(pl_plan *p, int spin, const double *phase, double *alm, con
     const int ngroups = (p->P.npairs + RG - 1) / RG;
     if (spin == 0) {
         if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * p->P.nent0 * 4)) return 1;
-        launch_anal0(p->P, phase, p->partial, fl, alm, st);
+        { ProfScope ps(p, PK_LEG_ANAL0, st); launch_anal0(p->P, phase, p->partial, fl, alm, st); }
     } else {
         if (ensure_spin(p, spin)) return 1;
         if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * p->nent[spin] * 4)) return 1;
-        launch_anals(p->P, p->S[spin], spin, p->nent[spin], phase, p->partial, fl, alm, st);
+        { ProfScope ps(p, PK_LEG_ANALS, st); launch_anals(p->P, p->S[spin], spin, p->nent[spin], phase, p->partial, fl, alm, st); }
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -260,6 +304,7 @@ int pl_phase2map(pl_plan *p, int spin, const double *phase, double *map, void *s
 {
     if (!p) return fail("null plan");
     if (spin && ensure_spin(p, spin)) return 1;
+    ProfScope ps(p, PK_FFT_SYNTH, static_cast<hipStream_t>(stream));
     HIPCHK(launch_phase2map(p->P, p->F, mlim_of(p, spin), ncomp_of(spin), phase, map, static_cast<hipStream_t>(stream)));
     return 0;
 }
@@ -268,6 +313,7 @@ int pl_map2phase(pl_plan *p, int spin, const double *map, double *phase, void *s
 {
     if (!p) return fail("null plan");
     if (spin && ensure_spin(p, spin)) return 1;
+    ProfScope ps(p, PK_FFT_ANAL, static_cast<hipStream_t>(stream));
     HIPCHK(launch_map2phase(p->P, p->F, mlim_of(p, spin), ncomp_of(spin), map, phase, static_cast<hipStream_t>(stream)));
     return 0;
 }

@@ -1,6 +1,6 @@
 // Per-lane arithmetic of the Legendre kernels: scaled seeds, recursion steps, alm <-> recursion-basis
-// transforms.  Everything here is __host__ __device__ so that tests/host/ can run the very same code on
-// the CPU (one "lane" at a time) against the oracle before anything touches a GPU.
+// transforms.  Everything here is __host__ __device__ so that a host unit test can run the very same
+// per-lane code on the CPU.
 #pragma once
 #include <cmath>
 
@@ -134,7 +134,9 @@ PL_HD double recs_value_p(const RecS &r) { return r.scp == 0 ? r.p1 : 0.0; }
 // spin s synthesis: An_l = -1/2 sg beta_l (G + iC)_l, Ap_l = -1/2 beta_l (G - iC)_l, sg = (-1)^s
 //   X_N = sum Sn An, Y_N = sum Sp Ap, X_S = sum sigma_l Sp An, Y_S = sum sigma_l Sn Ap, sigma_l = (-1)^{l+m}
 //   Q = X + Y, U = i (Y - X)
-// spin s analysis: Tn_l = sum_rings Sn_l (Wp_N + sigma_l Wm_S), Tp_l = sum_rings Sp_l (Wm_N + sigma_l Wp_S),
-//   Wp = Q + iU, Wm = Q - iU;  G_l = -1/2 beta_l (sg Tn + Tp),  C_l = i/2 beta_l (sg Tn - Tp)
+// spin s analysis (adjoint), Wp = Q + iU, Wm = Q - iU, mirror ring: Sn <-> sigma_l Sp:
+//   G'_l = sum_pairs Sn_l (sg Wp_N + sigma_l Wm_S) + Sp_l (Wm_N + sg sigma_l Wp_S)
+//   C'_l = sum_pairs Sn_l (sg Wp_N - sigma_l Wm_S) - Sp_l (Wm_N - sg sigma_l Wp_S)
+//   G_l = -1/2 beta_l G'_l,  C_l = i/2 beta_l C'_l
 
 }  // namespace plshts

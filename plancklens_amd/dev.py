@@ -1,0 +1,92 @@
+"""Device-array plumbing for the QE / CG layers: torch CUDA tensors hold maps (float64) and alms
+(complex128) in HBM; the arithmetic is done by the HIP kernels of plancklens_amd/csrc (through shts /
+_lib), torch only allocates, copies and launches trivial element-wise glue on its current stream."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .hp import Alm
+
+_LIDX = {}
+
+
+def device():
+    if not torch.cuda.is_available():
+        raise RuntimeError('no GPU visible: the QE / CG layers of plancklens_amd run on the MI355X only')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def to_dev(x, dtype=None):
+    if isinstance(x, torch.Tensor):
+        t = x.to(device())
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(x)).to(device(), non_blocking=False)
+    return t if dtype is None else t.to(dtype)
+
+
+def to_host(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def lidx(lmax):
+    """Device int64 tensor: l of every entry of a healpy alm array."""
+    key = (lmax, torch.cuda.current_device())
+    if key not in _LIDX:
+        ls = np.concatenate([np.arange(m, lmax + 1, dtype=np.int64) for m in range(lmax + 1)])
+        if len(_LIDX) > 8:
+            _LIDX.clear()
+        _LIDX[key] = torch.from_numpy(ls).to(device())
+    return _LIDX[key]
+
+
+def fl_dev(fl, lmax):
+    """l-filter as a device float64 tensor of length lmax + 1 (zero-extended / truncated: hp.almxfl semantics)."""
+    f = torch.zeros(lmax + 1, dtype=torch.float64, device=device())
+    src = fl if isinstance(fl, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(fl, dtype=np.float64)))
+    n = min(lmax + 1, src.numel())
+    f[:n] = src[:n].to(device())
+    return f
+
+
+def almxfl(alm, fl):
+    """hp.almxfl on a device alm through the C ABI (pl_almxfl); returns a new tensor."""
+    lmax = Alm.getlmax(alm.numel())
+    assert lmax >= 0
+    f = fl_dev(fl, lmax)
+    out = torch.empty_like(alm)
+    _lib.check(_lib.lib().pl_almxfl(lmax, alm.data_ptr(), f.data_ptr(), lmax + 1, out.data_ptr(), stream_ptr()))
+    return out
+
+
+def alm_copy(alm, lmax_out):
+    lmax_in = Alm.getlmax(alm.numel())
+    if lmax_out == lmax_in:
+        return alm.clone()
+    out = torch.empty(Alm.getsize(lmax_out), dtype=torch.complex128, device=alm.device)
+    _lib.check(_lib.lib().pl_alm_copy(lmax_in, alm.data_ptr(), lmax_out, out.data_ptr(), stream_ptr()))
+    return out
+
+
+def alm2cl(a, b=None):
+    lmax = Alm.getlmax(a.numel())
+    out = torch.empty(lmax + 1, dtype=torch.float64, device=a.device)
+    _lib.check(_lib.lib().pl_alm2cl(lmax, a.data_ptr(), (a if b is None else b).data_ptr(), out.data_ptr(), stream_ptr()))
+    return out
+
+
+def map_mul(a, b, out=None):
+    out = torch.empty_like(a) if out is None else out
+    _lib.check(_lib.lib().pl_map_mul(a.numel(), a.data_ptr(), b.data_ptr(), out.data_ptr(), stream_ptr()))
+    return out
+
+
+def map_cmul(ar, ai, s1, br, bi, s2, sign, outr, outi, accumulate):
+    """(outr + i outi) (+)= sign (ar + i s1 ai)(br + i s2 bi)"""
+    _lib.check(_lib.lib().pl_map_cmul(ar.numel(), ar.data_ptr(), ai.data_ptr(), float(s1), br.data_ptr(), bi.data_ptr(),
+                                     float(s2), float(sign), outr.data_ptr(), outi.data_ptr(), int(accumulate), stream_ptr()))

@@ -252,3 +252,64 @@ def synalm(cls, lmax=None, rng=None):
     alm = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * np.sqrt(0.5)
     alm[:lmax + 1] = rng.standard_normal(lmax + 1)
     return almxfl(alm, np.sqrt(np.maximum(cls[:lmax + 1], 0.)), inplace=True)
+
+
+# ---------------------------------------------------------------------------------------------
+# on-disk formats (reference cache files: filt_simple.py:97-99, qest.py:17,201)
+# ---------------------------------------------------------------------------------------------
+def write_alm(filename, alms, lmax=-1, mmax=-1, overwrite=False, **kwargs):
+    """healpy.write_alm layout: one binary table, columns index = l^2 + l + m + 1, real, imag."""
+    from . import fitsio
+    alms = np.asarray(alms)
+    lmax_in = Alm.getlmax(alms.size)
+    assert lmax_in >= 0
+    if lmax < 0 or lmax > lmax_in:
+        lmax = lmax_in
+    if mmax < 0 or mmax > lmax:
+        mmax = lmax
+    l, m = Alm.getlm(lmax_in)
+    keep = (l <= lmax) & (m <= mmax)
+    idx = (l[keep].astype(np.int64) ** 2 + l[keep] + m[keep] + 1).astype(np.int32)
+    fitsio.write_bintable(filename, [('index', idx), ('real', alms.real[keep]), ('imag', alms.imag[keep])],
+                          extname='xtension', overwrite=overwrite)
+
+
+def read_alm(filename, hdu=1, return_mmax=False):
+    from . import fitsio
+    cols, _ = fitsio.read_bintable(filename, hdu=hdu)
+    names = list(cols.keys())
+    idx = cols[names[0]].astype(np.int64)
+    l = np.floor(np.sqrt(idx - 1)).astype(np.int64)
+    m = idx - l * l - l - 1
+    lmax, mmax = int(l.max()), int(m.max())
+    alm = np.zeros(Alm.getsize(lmax, mmax), dtype=complex)
+    i = m * (2 * lmax + 1 - m) // 2 + l
+    alm.real[i] = cols[names[1]]
+    alm.imag[i] = cols[names[2]]
+    return (alm, mmax) if return_mmax else alm
+
+
+def write_map(filename, m, nest=False, dtype=None, overwrite=False, **kwargs):
+    from . import fitsio
+    m = np.asarray(m, dtype=np.float64 if dtype is None else dtype)
+    maps = [m] if m.ndim == 1 else list(m)
+    npix = maps[0].size
+    nside = npix2nside(npix)
+    rep = 1024 if npix % 1024 == 0 else 1
+    names = ['TEMPERATURE', 'Q_POLARISATION', 'U_POLARISATION'] if len(maps) == 3 else ['I_STOKES%d' % i for i in range(len(maps))]
+    if len(maps) == 1:
+        names = ['TEMPERATURE']
+    cols = [(n, mm.reshape(-1, rep) if rep > 1 else mm) for n, mm in zip(names, maps)]
+    fitsio.write_bintable(filename, cols, extname='xtension', overwrite=overwrite,
+                          extra=[('PIXTYPE', 'HEALPIX'), ('ORDERING', 'NESTED' if nest else 'RING'), ('NSIDE', nside),
+                                 ('FIRSTPIX', 0), ('LASTPIX', npix - 1), ('INDXSCHM', 'IMPLICIT')])
+
+
+def read_map(filename, field=0, dtype=None, nest=False, hdu=1, verbose=False, **kwargs):
+    from . import fitsio
+    cols, hdr = fitsio.read_bintable(filename, hdu=hdu)
+    assert str(hdr.get('ORDERING', 'RING')).strip() == ('NESTED' if nest else 'RING'), 'ordering conversion not implemented'
+    names = list(cols.keys())
+    fields = [field] if np.isscalar(field) else (range(len(names)) if field is None else list(field))
+    out = [np.asarray(cols[names[f]], dtype=np.float64 if dtype is None else dtype).ravel() for f in fields]
+    return out[0] if np.isscalar(field) else out

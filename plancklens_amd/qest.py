@@ -1,0 +1,545 @@
+"""Quadratic estimators on the MI355X, behind the API of plancklens/qest.py.
+
+Same classes, methods, keys, cache-file names and normalisations as the reference (`library` qest.py:50-438,
+`lib_filt2map` :441-530, `lib_filt2map_sepTP` :533-638, `eval_qe` :19-39).  What differs is where the work
+happens: the filtered alms are uploaded once per leg, every spin-0/1/2/3 transform, l-filter and pixel
+product runs on the GPU (plancklens_amd.shts / dev, HIP kernels), the l-weights are fused into the
+transforms, and only the final gradient / curl alm comes back to the host.
+
+Formulas as coded in the reference, with Tb = inverse-variance filtered,
+T^WF = C^TT Tb (+ C^TE Eb for the MV estimator):
+  ptt / xtt : (G, C) = -sqrt(L(L+1)) map2alm_spin_1[ Tb(n) alm2map_spin_1(-sqrt(l(l+1)) T^WF_lm, 0) ]
+  p_p / x_p : d = (Qb - iUb)(3G + i 3C) - (Qb + iUb)(1G - i 1C), (Qb, Ub) = alm2map_spin_2(Eb/2, Bb/2),
+              sG = alm2map_spin_s(w^s_l (E^WF, B^WF)), w^3 = sqrt((l-2)(l+3)), w^1 = sqrt((l+2)(l-1));
+              (G, C) = -sqrt(L(L+1)) map2alm_spin_1(Re d, Im d)
+  p / x     : p_p form with E^WF += C^TE Tb, plus ptt form with T^WF += C^TE Eb
+"""
+from __future__ import print_function
+
+import collections
+import os
+import pickle as pk
+
+import numpy as np
+import torch
+
+from . import dev, hp, shts
+from . import utils as ut
+from .helpers import mpi
+
+_write_alm = lambda fn, alm: hp.write_alm(fn, alm, overwrite=True)
+
+
+def eval_qe(qe_key, lmax_ivf, cls_weight, get_alm, nside, lmax_qlm, verbose=True, get_alm2=None, transf=None):
+    """Generic spin-weight route (qest.py:19-39): gradient and curl of the estimator `qe_key` built from the
+    leg decomposition of qresp.get_qes and evaluated by utils_qe.qe_eval on the GPU."""
+    from . import qresp, utils_qe as uqe
+    qe_list = qresp.get_qes(qe_key, lmax_ivf, cls_weight, transf=transf)
+    return uqe.qe_eval(qe_list, nside, get_alm, lmax_qlm, verbose=verbose, get_alm2=get_alm2)
+
+
+def library_jtTP(lib_dir, ivfs1, ivfs2, nside, lmax_qlm=None, resplib=None, **kwargs):
+    return library(lib_dir, ivfs1, ivfs2, nside, lmax_qlm=lmax_qlm, resplib=resplib, **kwargs)
+
+
+def library_sepTP(lib_dir, ivfs1, ivfs2, clte, nside, lmax_qlm=None, resplib=None, **kwargs):
+    return library(lib_dir, ivfs1, ivfs2, nside, clte=clte, lmax_qlm=lmax_qlm, resplib=resplib, **kwargs)
+
+
+def _lens_weight(lmax):
+    """-sqrt(L (L + 1)), L = 0 .. lmax (qest.py:260,282,463,592)."""
+    ell = np.arange(lmax + 1, dtype=float)
+    return -np.sqrt(ell * (ell + 1.))
+
+
+def _spin_weight(spin, lmax):
+    """sqrt((l+2)(l-1)) for spin 1, sqrt((l-2)(l+3)) for spin 3, first `spin` entries zeroed (qest.py:494-501)."""
+    if spin == 1:
+        fl = np.arange(2, lmax + 3, dtype=float) * np.arange(-1, lmax)
+    elif spin == 3:
+        fl = np.arange(-2, lmax - 1, dtype=float) * np.arange(3, lmax + 4)
+    else:
+        assert 0, spin
+    fl[:spin] = 0.
+    return np.sqrt(fl)
+
+
+class library(object):
+    """QE library from two inverse-variance filtered CMB libraries (qest.py:50-438).
+
+        Args:
+            lib_dir: QE estimates are cached there (same file names as the reference).
+            ivfs1, ivfs2: filtering instances of the first and second leg.
+            nside: resolution of the real-space products.
+            clte (optional): TE spectrum, builds X^WF from Xb for separately filtered T and P.
+            lmax_qlm (optional): output band-limit (defaults to 3 nside - 1).
+            resplib (optional): response library, only for the bias-hardened keys.
+            cache (extension, default True): set False to skip all disk IO of the estimates.
+    """
+
+    def __init__(self, lib_dir, ivfs1, ivfs2, nside, clte=None, lmax_qlm=None, resplib=None, cache=True):
+        if lmax_qlm is None:
+            lmax_qlm = 3 * nside - 1
+        self.lib_dir = lib_dir
+        self.prefix = lib_dir
+        self.cache = cache
+        self.lmax_qlm = {'T': lmax_qlm, 'P': lmax_qlm, 'PS': lmax_qlm}
+        if clte is None:
+            self.f2map1, self.f2map2 = lib_filt2map(ivfs1, nside), lib_filt2map(ivfs2, nside)
+        else:
+            self.f2map1, self.f2map2 = lib_filt2map_sepTP(ivfs1, nside, clte), lib_filt2map_sepTP(ivfs2, nside, clte)
+        assert self.lmax_qlm['T'] == self.lmax_qlm['P'], 'implement this'
+        fnhash = os.path.join(self.lib_dir, "qe_sim_hash.pk")
+        if mpi.rank == 0 and not os.path.exists(fnhash):
+            if not os.path.exists(self.lib_dir):
+                os.makedirs(self.lib_dir)
+            pk.dump(self.hashdict(), open(fnhash, 'wb'), protocol=2)
+        mpi.barrier()
+        ut.hash_check(pk.load(open(fnhash, 'rb')), self.hashdict(), fn=fnhash)
+        fn_fsky = os.path.join(lib_dir, 'fskies.dat')
+        if mpi.rank == 0 and not os.path.exists(fn_fsky):
+            masks = {1: self.get_mask(1), 2: self.get_mask(2)}
+            with open(fn_fsky, 'w') as f:
+                for lab in [11, 12, 22]:
+                    f.write('%4s %.5f \n' % (lab, np.mean(masks[lab // 10] * masks[lab % 10])))
+        mpi.barrier()
+        self.fskies = {}
+        with open(fn_fsky) as f:
+            for line in f:
+                key, val = line.split()
+                self.fskies[int(key)] = float(val)
+        self.fsky11, self.fsky12, self.fsky22 = self.fskies[11], self.fskies[12], self.fskies[22]
+        self.resplib = resplib
+        self.keys_fund = ['ptt', 'xtt', 'p_p', 'x_p', 'p', 'x', 'stt', 's', 'ftt', 'f_p', 'f', 'dtt', 'ntt', 'a_p',
+                          'pte', 'pet', 'ptb', 'pbt', 'pee', 'peb', 'pbe', 'pbb',
+                          'xte', 'xet', 'xtb', 'xbt', 'xee', 'xeb', 'xbe', 'xbb']
+        self.keys = self.keys_fund + ['p_tp', 'x_tp', 'p_te', 'p_tb', 'p_eb', 'x_te', 'x_tb', 'x_eb', 'ptt_bh_n',
+                                      'ptt_bh_s', 'ptt_bh_f', 'ptt_bh_d', 'dtt_bh_p', 'stt_bh_p', 'ftt_bh_d', 'p_bh_s']
+        self.keys_remaps = {'s': 'stt'}
+        self._mem = {}
+
+    def hashdict(self):
+        return {'f2map1': self.f2map1.hashdict(), 'f2map2': self.f2map2.hashdict()}
+
+    def get_fundkeys(self, k_list):
+        """Fundamental estimators needed to build the (possibly derived) keys of k_list (qest.py:122-141)."""
+        ret = []
+        for k in (k_list if isinstance(k_list, list) else [k_list]):
+            if k in self.keys_fund:
+                ret.append(k)
+            elif '_tp' in k:
+                ret += [k[0] + 'tt', k[0] + '_p']
+            elif 'tt_bh_' in k:
+                l, f = k.split('_bh_')
+                ret += [l, f + 'tt']
+            elif k in ['p_te', 'p_tb', 'p_eb', 'x_te', 'x_tb', 'x_eb']:
+                ret += [k[0] + k[2] + k[3], k[0] + k[3] + k[2]]
+        return list(collections.OrderedDict.fromkeys(ret))
+
+    def get_fsky(self, id):
+        assert id in [11, 22, 12], id
+        return self.fskies[id]
+
+    def get_lmax_qlm(self, k):
+        assert self.lmax_qlm['T'] == self.lmax_qlm['P']
+        return self.lmax_qlm['T']
+
+    def get_mask(self, leg):
+        assert leg in [1, 2]
+        return self.f2map1.ivfs.get_fmask() if leg == 1 else self.f2map2.ivfs.get_fmask()
+
+    # ---- cache -----------------------------------------------------------------------------------
+    def _fname(self, k, idx):
+        return os.path.join(self.lib_dir, 'sim_%s_%04d.fits' % (k, idx) if idx != -1 else 'dat_%s.fits' % k)
+
+    def _has(self, k, idx):
+        return (k, idx) in self._mem or (self.cache and os.path.exists(self._fname(k, idx)))
+
+    def _store(self, k, idx, alm):
+        if self.cache:
+            _write_alm(self._fname(k, idx), alm)
+        else:
+            self._mem[(k, idx)] = alm
+
+    def _load(self, k, idx):
+        if (k, idx) in self._mem:
+            return self._mem[(k, idx)]
+        return hp.read_alm(self._fname(k, idx))
+
+    # ---- public getters ----------------------------------------------------------------------------
+    def get_sim_qlm(self, k, idx, lmax=None):
+        """QE estimate for key k and simulation idx, computed and cached on first request (qest.py:155-201)."""
+        k = self.keys_remaps.get(k, k)
+        if lmax is None:
+            lmax = self.get_lmax_qlm(k)
+        assert lmax <= self.get_lmax_qlm(k)
+        if k in ['p_tp', 'x_tp', 'f_tp', 's_tp']:
+            return self.get_sim_qlm('%stt' % k[0], idx, lmax=lmax) + self.get_sim_qlm('%s_p' % k[0], idx, lmax=lmax)
+        if k in ['p_te', 'p_tb', 'p_eb', 'x_te', 'x_tb', 'x_eb']:
+            return self.get_sim_qlm(k[0] + k[2] + k[3], idx, lmax=lmax) + self.get_sim_qlm(k[0] + k[3] + k[2], idx, lmax=lmax)
+        if '_bh_' in k:
+            kQE, wL = self._bh_weights(k)
+            lmax = self.get_lmax_qlm(kQE)
+            ksrc = k.split('_bh_')[1] + kQE[1:]
+            return self.get_sim_qlm(kQE, idx, lmax=lmax) - hp.almxfl(self.get_sim_qlm(ksrc, idx, lmax=lmax), wL)
+        assert k in self.keys_fund, (k, self.keys_fund)
+        if not self._has(k, idx):
+            if k in ['ptt', 'xtt']: self._build_sim_Tgclm(idx)
+            elif k in ['p_p', 'x_p']: self._build_sim_Pgclm(idx)
+            elif k in ['p', 'x']: self._build_sim_MVgclm(idx)
+            elif k in ['f']: self._build_sim_f(idx)
+            elif k in ['stt']: self._build_sim_stt(idx)
+            elif k in ['ftt']: self._build_sim_ftt(idx)
+            elif k in ['f_p']: self._build_sim_f_p(idx)
+            elif k in ['ntt']: self._build_sim_ntt(idx)
+            elif k in ['a_p']: self._build_sim_a_p(idx)
+            elif k[0] in 'px' and len(k) == 3 and k[1] in 'teb' and k[2] in 'teb':
+                self._build_sim_xfiltMVgclm(idx, k)
+            else:
+                assert 0, k
+        return ut.alm_copy(self._load(k, idx), lmax=lmax)
+
+    def get_dat_qlm(self, k, **kwargs):
+        return self.get_sim_qlm(k, -1, **kwargs)
+
+    def _bh_weights(self, k):
+        assert self.resplib is not None, 'resplib arg necessary for this'
+        kQE, ksource = k.split('_bh_')
+        assert len(ksource) == 1, (ksource, kQE)
+        assert self.get_lmax_qlm(kQE) == self.get_lmax_qlm(ksource + kQE[1:]), 'fix this (easy)'
+        wL = self.resplib.get_response(kQE, ksource) * ut.cli(self.resplib.get_response(ksource + kQE[1:], ksource))
+        return kQE, wL
+
+    def get_sim_qlm_mf(self, k, mc_sims, lmax=None):
+        """Mean field: average of the estimates over mc_sims, cached (qest.py:206-246)."""
+        k = self.keys_remaps.get(k, k)
+        if lmax is None:
+            lmax = self.get_lmax_qlm(k)
+        assert lmax <= self.get_lmax_qlm(k)
+        if k in ['p_tp', 'x_tp']:
+            return self.get_sim_qlm_mf('%stt' % k[0], mc_sims, lmax=lmax) + self.get_sim_qlm_mf('%s_p' % k[0], mc_sims, lmax=lmax)
+        if k in ['p_te', 'p_tb', 'p_eb', 'x_te', 'x_tb', 'x_eb']:
+            return self.get_sim_qlm_mf(k[0] + k[2] + k[3], mc_sims, lmax=lmax) \
+                   + self.get_sim_qlm_mf(k[0] + k[3] + k[2], mc_sims, lmax=lmax)
+        if '_bh_' in k:
+            kQE, wL = self._bh_weights(k)
+            lmax = self.get_lmax_qlm(kQE)
+            ksrc = k.split('_bh_')[1] + kQE[1:]
+            return self.get_sim_qlm_mf(kQE, mc_sims, lmax=lmax) - hp.almxfl(self.get_sim_qlm_mf(ksrc, mc_sims, lmax=lmax), wL)
+        assert k in self.keys_fund, (k, self.keys_fund)
+        fname = os.path.join(self.lib_dir, 'simMF_k1%s_%s.fits' % (k, ut.mchash(mc_sims)))
+        if (not self.cache and ('mf', fname) in self._mem):
+            return ut.alm_copy(self._mem[('mf', fname)], lmax=lmax)
+        if not (self.cache and os.path.exists(fname)):
+            this_mcs = np.unique(mc_sims)
+            MF = np.zeros(hp.Alm.getsize(lmax), dtype=complex)
+            if len(this_mcs) == 0:
+                return MF
+            for i, idx in ut.enumerate_progress(this_mcs, label='calculating %s MF' % k):
+                MF += self.get_sim_qlm(k, idx, lmax=lmax)
+            MF /= len(this_mcs)
+            if self.cache:
+                _write_alm(fname, MF)
+                print("Cached ", fname)
+            else:
+                self._mem[('mf', fname)] = MF
+                return ut.alm_copy(MF, lmax=lmax)
+        return ut.alm_copy(hp.read_alm(fname), lmax=lmax)
+
+    # ---- estimators (device) -----------------------------------------------------------------------
+    def _legs(self, swapped):
+        return (self.f2map2, self.f2map1) if swapped else (self.f2map1, self.f2map2)
+
+    def _gc_from_product(self, re, im, lmax_key):
+        """-sqrt(L(L+1)) map2alm_spin_1(re, im), weight fused into the analysis (qest.py:259-262,280-284)."""
+        lmax = self.lmax_qlm[lmax_key]
+        G, C = shts.map2alm_spin([re, im], 1, lmax=lmax, fl=_lens_weight(lmax))
+        return G, C
+
+    def _get_sim_Tgclm_dev(self, idx, k, swapped=False, xfilt1=None, xfilt2=None):
+        f2map1, f2map2 = self._legs(swapped)
+        xf1, xf2 = (xfilt2, xfilt1) if swapped else (xfilt1, xfilt2)
+        tmap = f2map1.get_irestmap(idx, xfilt=xf1)
+        G, C = f2map2.get_gtmap(idx, k=k, xfilt=xf2)
+        G = dev.map_mul(G, tmap, out=G)
+        C = dev.map_mul(C, tmap, out=C)
+        del tmap
+        return self._gc_from_product(G, C, 'T')
+
+    def _get_sim_Pgclm_dev(self, idx, k, swapped=False, xfilt1=None, xfilt2=None):
+        f2map1, f2map2 = self._legs(swapped)
+        xf1, xf2 = (xfilt2, xfilt1) if swapped else (xfilt1, xfilt2)
+        repmap, impmap = f2map1.get_irespmap(idx, xfilt=xf1)
+        Gs, Cs = f2map2.get_gpmap(idx, 3, k=k, xfilt=xf2)
+        dre, dim = torch.empty_like(repmap), torch.empty_like(repmap)
+        dev.map_cmul(repmap, impmap, -1., Gs, Cs, +1., +1., dre, dim, False)   # (Qb - iUb)(3G + i 3C)
+        Gs, Cs = f2map2.get_gpmap(idx, 1, k=k, xfilt=xf2)
+        dev.map_cmul(repmap, impmap, +1., Gs, Cs, -1., -1., dre, dim, True)    # -(Qb + iUb)(1G - i 1C)
+        del repmap, impmap, Gs, Cs
+        return self._gc_from_product(dre, dim, 'P')
+
+    def _get_sim_Tgclm(self, idx, k, swapped=False, xfilt1=None, xfilt2=None):
+        """T-only lensing gradient / curl (qest.py:248-263)."""
+        G, C = self._get_sim_Tgclm_dev(idx, k, swapped=swapped, xfilt1=xfilt1, xfilt2=xfilt2)
+        return dev.to_host(G), dev.to_host(C)
+
+    def _get_sim_Pgclm(self, idx, k, swapped=False, xfilt1=None, xfilt2=None):
+        """Polarization-only lensing gradient / curl (qest.py:265-285)."""
+        G, C = self._get_sim_Pgclm_dev(idx, k, swapped=swapped, xfilt1=xfilt1, xfilt2=xfilt2)
+        return dev.to_host(G), dev.to_host(C)
+
+    def _get_sim_MVgclm(self, idx, k, swapped=False):
+        """Minimum-variance estimator = P part + T part, two separate final analyses (qest.py:318-322)."""
+        assert k == 'p'
+        GP, CP = self._get_sim_Pgclm_dev(idx, 'p', swapped=swapped)
+        GT, CT = self._get_sim_Tgclm_dev(idx, 'p', swapped=swapped)
+        return dev.to_host(GP + GT), dev.to_host(CP + CT)
+
+    def _scalar_from_product(self, prod, fac, lmax_key):
+        lmax = self.get_lmax_qlm(lmax_key)
+        return dev.to_host(shts.map2alm(prod, lmax=lmax, iter=0)) * fac
+
+    def _get_sim_stt(self, idx, swapped=False):
+        """Point-source estimator -1/2 map2alm(Tb1 Tb2) (qest.py:287-291)."""
+        f1, f2 = self._legs(swapped)
+        return self._scalar_from_product(dev.map_mul(f1.get_irestmap(idx), f2.get_irestmap(idx)), -0.5, 'PS')
+
+    def _get_sim_ntt(self, idx, swapped=False):
+        """Noise-inhomogeneity estimator on beam-deconvolved maps (qest.py:293-298)."""
+        f1, f2 = self._legs(swapped)
+        t1 = f1.get_wirestmap(idx, f1.ivfs.get_tal('t')[:])
+        t2 = f2.get_wirestmap(idx, f2.ivfs.get_tal('t')[:])
+        return self._scalar_from_product(dev.map_mul(t1, t2), -0.5, 'T')
+
+    def _get_sim_ftt(self, idx, joint=False, swapped=False):
+        """Temperature modulation estimator -map2alm(Tb T^WF) (qest.py:300-304)."""
+        f1, f2 = self._legs(swapped)
+        return self._scalar_from_product(dev.map_mul(f1.get_irestmap(idx), f2.get_tmap(idx, joint=joint)), -1., 'T')
+
+    def _get_sim_f_p(self, idx, joint=False, swapped=False):
+        """Polarization modulation estimator -2 map2alm(Qb Q^WF + Ub U^WF) (qest.py:306-310)."""
+        f1, f2 = self._legs(swapped)
+        Q1, U1 = f1.get_irespmap(idx)
+        Q2, U2 = f2.get_pmap(idx, joint=joint)
+        return self._scalar_from_product(Q1 * Q2 + U1 * U2, -2., 'P')
+
+    def _get_sim_a_p(self, idx, joint=False, swapped=False):
+        """Polarization rotation estimator -4 map2alm(Qb U^WF - Ub Q^WF) (qest.py:312-316)."""
+        f1, f2 = self._legs(swapped)
+        Q1, U1 = f1.get_irespmap(idx)
+        Q2, U2 = f2.get_pmap(idx, joint=joint)
+        return self._scalar_from_product(Q1 * U2 - U1 * Q2, -4., 'P')
+
+    # ---- builders: symmetrise when the legs differ, then cache ---------------------------------------
+    def _same_legs(self):
+        return self.f2map1.ivfs == self.f2map2.ivfs
+
+    def _sym_gc(self, fun, idx, *args, **kwargs):
+        G, C = fun(idx, *args, **kwargs)
+        if not self._same_legs():
+            _G, _C = fun(idx, *args, swapped=True, **kwargs)
+            G, C = 0.5 * (G + _G), 0.5 * (C + _C)
+        return G, C
+
+    def _build_sim_Tgclm(self, idx):
+        G, C = self._sym_gc(self._get_sim_Tgclm, idx, 'ptt')
+        self._store('ptt', idx, G)
+        self._store('xtt', idx, C)
+
+    def _build_sim_Pgclm(self, idx):
+        G, C = self._sym_gc(self._get_sim_Pgclm, idx, 'p_p')
+        self._store('p_p', idx, G)
+        self._store('x_p', idx, C)
+
+    def _build_sim_MVgclm(self, idx):
+        G, C = self._sym_gc(self._get_sim_MVgclm, idx, 'p')
+        self._store('p', idx, G)
+        self._store('x', idx, C)
+
+    def _build_sim_f(self, idx):
+        G = self._get_sim_f_p(idx, joint=True)
+        if not self._same_legs():
+            G = 0.5 * (G + self._get_sim_f_p(idx, joint=True, swapped=True))
+        GT = self._get_sim_ftt(idx, joint=True)
+        if not self._same_legs():
+            GT = 0.5 * (GT + self._get_sim_ftt(idx, joint=True, swapped=True))
+        self._store('f', idx, G + GT)
+
+    def _build_sim_xfiltMVgclm(self, idx, k):
+        """Single field-pair estimators V X_1 W Y_2 from the MV machinery with 0/1 field selectors
+        (qest.py:372-402)."""
+        assert k[0] in 'px' and k[1] in 'teb' and k[2] in 'teb', k
+        xfilt1 = {f: (k[-2] == f) * np.ones(10000) for f in ['t', 'e', 'b']}
+        xfilt2 = {f: (k[-1] == f) * np.ones(10000) for f in ['t', 'e', 'b']}
+        G, C = self._sym_gc(self._get_sim_Pgclm, idx, 'p', xfilt1=xfilt1, xfilt2=xfilt2)
+        GT, CT = self._sym_gc(self._get_sim_Tgclm, idx, 'p', xfilt1=xfilt1, xfilt2=xfilt2)
+        self._store('p' + k[1:], idx, G + GT)
+        self._store('x' + k[1:], idx, C + CT)
+
+    def _build_sim_stt(self, idx):
+        self._store('stt', idx, self._get_sim_stt(idx))  # symmetric in its legs
+
+    def _build_sim_ntt(self, idx):
+        self._store('ntt', idx, self._get_sim_ntt(idx))
+
+    def _build_sim_ftt(self, idx):
+        fLM = self._get_sim_ftt(idx)
+        if not self._same_legs():
+            fLM = 0.5 * (fLM + self._get_sim_ftt(idx, swapped=True))
+        self._store('ftt', idx, fLM)
+
+    def _build_sim_f_p(self, idx):
+        fLM = self._get_sim_f_p(idx)
+        if not self._same_legs():
+            fLM = 0.5 * (fLM + self._get_sim_f_p(idx, swapped=True))
+        self._store('f_p', idx, fLM)
+
+    def _build_sim_a_p(self, idx):
+        fLM = self._get_sim_a_p(idx)
+        if not self._same_legs():
+            # the reference symmetrises with _get_sim_f_p here (qest.py:435); parity first
+            fLM = 0.5 * (fLM + self._get_sim_f_p(idx, swapped=True))
+        self._store('a_p', idx, fLM)
+
+
+class lib_filt2map(object):
+    """Filtered alms -> real-space legs of the estimators, on the GPU (qest.py:441-530; joint T-P filtering)."""
+
+    def __init__(self, ivfs, nside):
+        self.ivfs = ivfs
+        self.nside = nside
+
+    def hashdict(self):
+        return {'ivfs': self.ivfs.hashdict(), 'nside': self.nside}
+
+    # device copies of the filtered alms; an ivfs may hand over device tensors itself (get_sim_alm_dev)
+    def _alm(self, name, idx):
+        getter = getattr(self.ivfs, 'get_sim_alm_dev', None)
+        if getter is not None:
+            t = getter(name, idx)
+            if t is not None:
+                return t
+        return dev.to_dev(getattr(self.ivfs, 'get_sim_' + name)(idx), torch.complex128)
+
+    @staticmethod
+    def _lmax(alm):
+        return hp.Alm.getlmax(alm.numel())
+
+    def get_gtmap(self, idx, k=None, xfilt=None):
+        """alm2map_spin_1(-sqrt(l(l+1)) T^WF_lm, 0) (qest.py:453-464)."""
+        assert xfilt is None, 'not implemented'
+        mlik = self._alm('tmliklm', idx)
+        lmax = self._lmax(mlik)
+        return shts.alm2map_spin([mlik, torch.zeros_like(mlik)], self.nside, 1, lmax, fl=_lens_weight(lmax))
+
+    def get_tmap(self, idx, joint=False):
+        return shts.alm2map(self._alm('tmliklm', idx), self.nside)
+
+    def get_pmap(self, idx, joint=False):
+        G, C = self._alm('emliklm', idx), self._alm('bmliklm', idx)
+        return shts.alm2map_spin([G, C], self.nside, 2, self._lmax(G))
+
+    def get_gpmap(self, idx, spin, k=None, xfilt=None):
+        """alm2map_spin_s(w^s_l (E^WF, B^WF)), s = 1, 3 (qest.py:481-504)."""
+        assert spin in [1, 3]
+        assert xfilt is None, 'not implemented'
+        G, C = self._alm('emliklm', idx), self._alm('bmliklm', idx)
+        assert G.numel() == C.numel()
+        lmax = self._lmax(G)
+        return shts.alm2map_spin([G, C], self.nside, spin, lmax, fl=_spin_weight(spin, lmax))
+
+    def get_irestmap(self, idx, xfilt=None):
+        if xfilt is not None:
+            assert isinstance(xfilt, dict) and 't' in xfilt.keys()
+            if not np.any(xfilt['t']):
+                return torch.zeros(hp.nside2npix(self.nside), dtype=torch.float64, device=dev.device())
+        reslm = self._alm('tlm', idx)
+        return shts.alm2map(reslm, self.nside, lmax=self._lmax(reslm), fl=None if xfilt is None else xfilt['t'])
+
+    def get_wirestmap(self, idx, wl):
+        reslm = self._alm('tlm', idx)
+        return shts.alm2map(reslm, self.nside, lmax=self._lmax(reslm), fl=wl)
+
+    def get_irespmap(self, idx, xfilt=None):
+        """(Qb, Ub) = alm2map_spin_2(Eb / 2, Bb / 2) (qest.py:521-530)."""
+        e, b = self._alm('elm', idx), self._alm('blm', idx)
+        assert e.numel() == b.numel()
+        lmax = self._lmax(e)
+        if xfilt is not None:
+            assert isinstance(xfilt, dict) and 'e' in xfilt.keys() and 'b' in xfilt.keys()
+            e, b = dev.almxfl(e, xfilt['e']), dev.almxfl(b, xfilt['b'])
+        return shts.alm2map_spin([e, b], self.nside, 2, lmax, fl=0.5 * np.ones(lmax + 1))
+
+
+class lib_filt2map_sepTP(lib_filt2map):
+    """Same for separately filtered T and P: X^WF is built here from Xb with C^TE (qest.py:533-638)."""
+
+    def __init__(self, ivfs, nside, clte):
+        super(lib_filt2map_sepTP, self).__init__(ivfs, nside)
+        self.clte = clte
+
+    def hashdict(self):
+        return {'ivfs': self.ivfs.hashdict(), 'nside': self.nside, 'clte': ut.clhash(self.clte)}
+
+    def get_tmap(self, idx, joint=False):
+        tlm = self._alm('tmliklm', idx)
+        if joint:
+            tlm = tlm + dev.almxfl(self._alm('elm', idx), self.clte)
+        return shts.alm2map(tlm, self.nside)
+
+    def get_pmap(self, idx, joint=False):
+        G, C = self._alm('emliklm', idx), self._alm('bmliklm', idx)
+        if joint:
+            G = G + dev.almxfl(self._alm('tlm', idx), self.clte)
+        return shts.alm2map_spin([G, C], self.nside, 2, self._lmax(G))
+
+    def _zeros(self):
+        z = torch.zeros(hp.nside2npix(self.nside), dtype=torch.float64, device=dev.device())
+        return [z, z.clone()]
+
+    def get_gtmap(self, idx, k=None, xfilt=None):
+        """Spin-1 gradient leg of T^WF (+ C^TE Eb for k = 'p'), with optional 0/1 field selectors (qest.py:566-595)."""
+        assert k in ['ptt', 'p'], k
+        if xfilt is not None:
+            assert isinstance(xfilt, dict) and 't' in xfilt.keys()
+            if k == 'p':
+                assert 'e' in xfilt.keys()
+        need_t = xfilt is None or np.any(xfilt['t'])
+        mlik = None
+        if need_t:
+            mlik = self._alm('tmliklm', idx)
+            if xfilt is not None:
+                mlik = dev.almxfl(mlik, xfilt['t'])
+        if k == 'p' and (xfilt is None or np.any(xfilt['e'])):
+            telm = dev.almxfl(self._alm('elm', idx), self.clte)
+            if xfilt is not None:
+                telm = dev.almxfl(telm, xfilt['e'])
+            mlik = telm if mlik is None else mlik + telm
+        if mlik is None or not bool(torch.any(mlik != 0)):
+            return self._zeros()
+        lmax = self._lmax(mlik)
+        return shts.alm2map_spin([mlik, torch.zeros_like(mlik)], self.nside, 1, lmax, fl=_lens_weight(lmax))
+
+    def get_gpmap(self, idx, spin, k=None, xfilt=None):
+        """Spin-1 / spin-3 legs of (E^WF (+ C^TE Tb for k = 'p'), B^WF) (qest.py:597-638)."""
+        assert k in ['p_p', 'p'], k
+        assert spin in [1, 3]
+        if xfilt is not None:
+            assert isinstance(xfilt, dict) and all(f in xfilt.keys() for f in 'teb')
+        need_p = xfilt is None or np.any(xfilt['e']) or np.any(xfilt['b'])
+        G = C = None
+        if need_p:
+            G, C = self._alm('emliklm', idx), self._alm('bmliklm', idx)
+            if xfilt is not None:
+                G, C = dev.almxfl(G, xfilt['e']), dev.almxfl(C, xfilt['b'])
+        if k == 'p' and (xfilt is None or np.any(xfilt['t'])):
+            G_t = dev.almxfl(self._alm('tlm', idx), self.clte)
+            if xfilt is not None:
+                G_t = dev.almxfl(G_t, xfilt['t'])
+            G = G_t if G is None else G + G_t
+        if G is None or not (bool(torch.any(G != 0)) or (C is not None and bool(torch.any(C != 0)))):
+            return self._zeros()
+        if C is None:
+            C = torch.zeros_like(G)
+        lmax = self._lmax(G)
+        return shts.alm2map_spin([G, C], self.nside, spin, lmax, fl=_spin_weight(spin, lmax))

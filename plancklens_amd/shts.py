@@ -52,6 +52,18 @@ class Plan(object):
     def phase_doubles(self, spin):
         return int(_lib.lib().pl_plan_phase_doubles(self.h, int(spin)))
 
+    PROFILE_KINDS = ('leg_synth0', 'leg_synths', 'leg_anal0', 'leg_anals', 'fft_synth', 'fft_anal')
+
+    def profile(self, on=True):
+        _lib.check(_lib.lib().pl_profile_enable(self.h, int(on)))
+
+    def profile_read(self):
+        """{kind: (total ms, launches)} of the HIP-event timings recorded since the last read."""
+        ms = (ctypes.c_double * 6)()
+        cnt = (ctypes.c_int64 * 6)()
+        _lib.check(_lib.lib().pl_profile_read(self.h, ms, cnt))
+        return {k: (ms[i], int(cnt[i])) for i, k in enumerate(self.PROFILE_KINDS)}
+
 
 def get_plan(nside, lmax):
     key = (int(nside), int(lmax))

@@ -1,0 +1,93 @@
+"""CMB map simulation libraries, API of plancklens/sims/maps.py (`cmb_maps` :13-77, `cmb_maps_nlev` :100-173):
+sky alm x transfer function -> alm2map / alm2map_spin (GPU) + white pixel noise."""
+import os
+import pickle as pk
+
+import numpy as np
+
+from .. import dev, hp, shts
+from ..helpers import mpi
+from ..utils import clhash, hash_check
+
+
+class cmb_maps(object):
+    """Sky library + transfer function -> T, Q, U maps (maps.py:13-77).  With device_maps=True (extension) the
+    maps are returned as device tensors and never leave HBM."""
+
+    def __init__(self, sims_cmb_len, cl_transf, nside=2048, cl_transf_P=None, lib_dir=None, device_maps=False):
+        self.sims_cmb_len = sims_cmb_len
+        self.cl_transf_T = cl_transf
+        self.cl_transf_P = np.copy(cl_transf) if cl_transf_P is None else cl_transf_P
+        self.nside = nside
+        self.device_maps = device_maps
+        if lib_dir is not None:
+            fn_hash = os.path.join(lib_dir, 'sim_hash.pk')
+            if mpi.rank == 0 and not os.path.exists(fn_hash):
+                if not os.path.exists(lib_dir):
+                    os.makedirs(lib_dir)
+                pk.dump(self.hashdict(), open(fn_hash, 'wb'), protocol=2)
+            mpi.barrier()
+            hash_check(self.hashdict(), pk.load(open(fn_hash, 'rb')), fn=fn_hash)
+
+    def hashdict(self):
+        ret = {'sims_cmb_len': self.sims_cmb_len.hashdict(), 'nside': self.nside, 'cl_transf': clhash(self.cl_transf_T)}
+        if not np.all(self.cl_transf_P == self.cl_transf_T):
+            ret['cl_transf_P'] = clhash(self.cl_transf_P)
+        return ret
+
+    def _out(self, t):
+        return t if self.device_maps else dev.to_host(t)
+
+    def get_sim_tmap(self, idx):
+        tlm = dev.to_dev(self.sims_cmb_len.get_sim_tlm(idx))
+        tmap = shts.alm2map(tlm, self.nside, fl=self.cl_transf_T)
+        return self._out(tmap + dev.to_dev(self.get_sim_tnoise(idx)))
+
+    def get_sim_pmap(self, idx):
+        elm = dev.to_dev(self.sims_cmb_len.get_sim_elm(idx))
+        blm = dev.to_dev(self.sims_cmb_len.get_sim_blm(idx))
+        Q, U = shts.alm2map_spin([elm, blm], self.nside, 2, hp.Alm.getlmax(elm.numel()), fl=self.cl_transf_P)
+        return self._out(Q + dev.to_dev(self.get_sim_qnoise(idx))), self._out(U + dev.to_dev(self.get_sim_unoise(idx)))
+
+    def get_sim_tnoise(self, idx):
+        assert 0, 'subclass this'
+
+    def get_sim_qnoise(self, idx):
+        assert 0, 'subclass this'
+
+    def get_sim_unoise(self, idx):
+        assert 0, 'subclass this'
+
+
+class cmb_maps_nlev(cmb_maps):
+    """Homogeneous white noise of nlev_t / nlev_p muK-arcmin on top of the sky maps (maps.py:100-173)."""
+
+    def __init__(self, sims_cmb_len, cl_transf, nlev_t, nlev_p, nside, lib_dir=None, pix_lib_phas=None, device_maps=False):
+        if pix_lib_phas is None:
+            assert lib_dir is not None
+            from . import phas
+            pix_lib_phas = phas.pix_lib_phas(lib_dir, 3, (hp.nside2npix(nside),))
+        assert pix_lib_phas.shape == (hp.nside2npix(nside),), (pix_lib_phas.shape, (hp.nside2npix(nside),))
+        self.pix_lib_phas = pix_lib_phas
+        self.nlev_t = nlev_t
+        self.nlev_p = nlev_p
+        super(cmb_maps_nlev, self).__init__(sims_cmb_len, cl_transf, nside=nside, lib_dir=lib_dir, device_maps=device_maps)
+
+    def hashdict(self):
+        ret = {'sims_cmb_len': self.sims_cmb_len.hashdict(), 'nside': self.nside, 'cl_transf': clhash(self.cl_transf_T),
+               'nlev_t': self.nlev_t, 'nlev_p': self.nlev_p, 'pixphas': self.pix_lib_phas.hashdict()}
+        if not np.all(self.cl_transf_P == self.cl_transf_T):
+            ret['cl_transf_P'] = clhash(self.cl_transf_P)
+        return ret
+
+    def _vamin(self):
+        return np.sqrt(hp.nside2pixarea(self.nside, degrees=True)) * 60
+
+    def get_sim_tnoise(self, idx):
+        return self.nlev_t / self._vamin() * self.pix_lib_phas.get_sim(idx, idf=0)
+
+    def get_sim_qnoise(self, idx):
+        return self.nlev_p / self._vamin() * self.pix_lib_phas.get_sim(idx, idf=1)
+
+    def get_sim_unoise(self, idx):
+        return self.nlev_p / self._vamin() * self.pix_lib_phas.get_sim(idx, idf=2)

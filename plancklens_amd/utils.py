@@ -1,0 +1,104 @@
+"""Host utilities mirroring the hot-path subset of plancklens/utils.py (alm_copy :19-35, clhash :115-124,
+mchash :126-130, cli :132-138, hash_check :144-180, camb_clfile :308-333, enumerate_progress :94-113)."""
+import hashlib
+import sys
+import time
+
+import numpy as np
+
+from . import hp
+
+
+def alm_copy(alm, lmax=None):
+    """Copy of a healpy alm array, optionally truncated to a smaller lmax (utils.py:19-35)."""
+    alm = np.asarray(alm)
+    alm_lmax = hp.Alm.getlmax(alm.size)
+    assert alm_lmax >= 0, alm.size
+    if lmax is None or lmax == alm_lmax:
+        return np.copy(alm)
+    assert lmax <= alm_lmax, (lmax, alm_lmax)
+    ret = np.zeros(hp.Alm.getsize(lmax), dtype=complex)
+    for m in range(lmax + 1):
+        o, i = hp.Alm.getidx(lmax, m, m), hp.Alm.getidx(alm_lmax, m, m)
+        ret[o:o + lmax - m + 1] = alm[i:i + lmax - m + 1]
+    return ret
+
+
+def enumerate_progress(lst, label=''):
+    """Progress bar over an iterable, yielding (index, value) (utils.py:94-113)."""
+    t0 = time.time()
+    n = len(lst)
+    for i, v in enumerate(lst):
+        yield i, v
+        if n and int(100. * (i + 1) / n) > int(100. * i / n):
+            dt = time.time() - t0
+            sys.stdout.write("\r [%02d:%02d:%02d] %s %s> %02d%%" % (dt // 3600, (dt % 3600) // 60, dt % 60, label,
+                                                                   int(10. * (i + 1) / n) * '-', int(100. * (i + 1) / n)))
+            sys.stdout.flush()
+    sys.stdout.write("\n")
+    sys.stdout.flush()
+
+
+def clhash(cl, dtype=np.float16):
+    """SHA-1 of the array cast to low precision (machine-independent cache keys, utils.py:115-124)."""
+    return hashlib.sha1(np.copy(np.asarray(cl).astype(dtype), order='C')).hexdigest()
+
+
+def mchash(cl):
+    """Order-independent hash of an integer array (simulation indices, utils.py:126-130)."""
+    return hashlib.sha1(np.copy(np.sort(cl), order='C')).hexdigest()
+
+
+def cli(cl):
+    """Pseudo-inverse of a non-negative array (utils.py:132-138)."""
+    cl = np.asarray(cl)
+    ret = np.zeros_like(cl)
+    pos = cl > 0
+    ret[pos] = 1. / cl[pos]
+    return ret
+
+
+def joincls(cls_list):
+    n = min(len(cl) for cl in cls_list)
+    return np.prod(np.array([cl[:n] for cl in cls_list]), axis=0)
+
+
+def hash_check(hash1, hash2, ignore=('lib_dir', 'prefix'), keychain=(), fn=None):
+    """Asserts equality of two (nested) hash dictionaries (utils.py:144-180)."""
+    keys1 = [k for k in hash1.keys() if k not in ignore]
+    keys2 = [k for k in hash2.keys() if k not in ignore]
+    for key in set(keys1).union(keys2):
+        if key not in hash1 or key not in hash2:
+            raise KeyError("Cannot find key %s in hashdict %s" % (key, fn))
+        v1, v2 = hash1[key], hash2[key]
+        where = 'hash check failed (%s) at %s' % (fn, '/'.join(list(keychain) + [str(key)]))
+        assert type(v1) == type(v2), where + ': types %s vs %s' % (type(v1), type(v2))
+        if isinstance(v1, dict):
+            hash_check(v1, v2, ignore=ignore, keychain=tuple(keychain) + (str(key),), fn=fn)
+        elif isinstance(v1, np.ndarray):
+            assert np.allclose(v1, v2), where + ': unequal arrays'
+        else:
+            assert v1 == v2, where + ': %s vs %s' % (v1, v2)
+
+
+def camb_clfile(fname, lmax=None):
+    """CAMB lensedCls / lenspotentialCls text file -> dict of C_l arrays (D_l factors removed), utils.py:308-333."""
+    cols = np.loadtxt(fname).transpose()
+    ell = cols[0].astype(int)
+    if lmax is None:
+        lmax = ell[-1]
+    assert ell[-1] >= lmax, (ell[-1], lmax)
+    sel = ell <= lmax
+    w = ell * (ell + 1) / (2. * np.pi)
+    cls = {}
+    for i, k in enumerate(['tt', 'ee', 'bb', 'te']):
+        cls[k] = np.zeros(lmax + 1)
+        cls[k][ell[sel]] = cols[i + 1][sel] / w[sel]
+    if len(cols) > 5:
+        el = ell[sel].astype(float)
+        wpp = el ** 2 * (el + 1) ** 2 / (2. * np.pi)
+        wpx = np.sqrt(el ** 3 * (el + 1.) ** 3) / (2. * np.pi)
+        for i, (k, wk) in enumerate(zip(['pp', 'pt', 'pe'], [wpp, wpx, wpx])):
+            cls[k] = np.zeros(lmax + 1)
+            cls[k][ell[sel]] = cols[5 + i][sel] / wk
+    return cls

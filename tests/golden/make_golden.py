@@ -1,0 +1,148 @@
+"""Generates tests/golden/*.npz by running the REFERENCE's own Python (imported from /root/reference, in this
+container only) on seeded inputs, with its `healpy` dependency (absent here) stood in by the CPU oracle's SHTs
+(oracle/sht_oracle.py) and the healpy-compatible host helpers (plancklens_amd/hp.py).
+
+What the fixtures pin: everything the reference does ABOVE the SHT seam -- isotropic filtering
+(filt_simple.library_fullsky_sepTP), the specialised QE route (qest.library_sepTP.get_sim_qlm), the generic
+route (qest.eval_qe), index shuffling / leg symmetrisation (filt_util.library_shuffle), spectra (qecl) --
+evaluated with SHTs that are themselves pinned by tests/test_oracle.py.  Only data (inputs and the
+reference's outputs) is stored; no reference source is copied.
+
+Run:  python tests/golden/make_golden.py      (needs /root/reference; not needed on the GPU box)
+"""
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = '/root/reference'
+
+from oracle import sht_oracle as so  # noqa: E402
+from plancklens_amd import hp as myhp  # noqa: E402
+
+
+def install_healpy_standin():
+    """A module object named `healpy` built from the oracle SHTs + host helpers (never written to disk)."""
+    m = types.ModuleType('healpy')
+    for name in ['Alm', 'almxfl', 'alm2cl', 'gauss_beam', 'nside2npix', 'npix2nside', 'nside2pixarea', 'ud_grade',
+                 'read_alm', 'write_alm', 'read_map', 'write_map', 'pix2ang', 'pix2vec', 'UNSEEN']:
+        setattr(m, name, getattr(myhp, name))
+    m.alm2map = lambda alm, nside, lmax=None, mmax=None, **kw: so.alm2map(np.asarray(alm), nside, lmax=lmax)
+    m.map2alm = lambda mp, lmax=None, mmax=None, iter=0, **kw: so.map2alm(np.asarray(mp), lmax=lmax, iter=iter)
+    m.alm2map_spin = lambda gclm, nside, spin, lmax, mmax=None: so.alm2map_spin(gclm, nside, spin, lmax)
+    m.map2alm_spin = lambda maps, spin, lmax=None, mmax=None: so.map2alm_spin(maps, spin, lmax)
+    proj = types.ModuleType('healpy.projector')
+    proj.CartesianProj = object
+    m.projector = proj
+    sys.modules['healpy'] = m
+    sys.modules['healpy.projector'] = proj
+
+
+class tiny_sims(object):
+    """Seeded T, Q, U maps: correlated Gaussian sky x beam + white noise (same recipe as tests/helpers)."""
+
+    def __init__(self, nside, lmax, cls, transf, nlev_t, nlev_p):
+        self.nside, self.lmax, self.cls, self.transf, self.nlev_t, self.nlev_p = nside, lmax, cls, transf, nlev_t, nlev_p
+
+    def hashdict(self):
+        return {'nside': self.nside, 'lmax': self.lmax}
+
+    def _alms(self, idx):
+        rng = np.random.default_rng(1000 + idx)
+        n = so.alm_size(self.lmax)
+
+        def unit():
+            a = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) / np.sqrt(2.)
+            a[:self.lmax + 1] = np.sqrt(2.) * a[:self.lmax + 1].real
+            return a
+        u1, u2, u3 = unit(), unit(), unit()
+        tt, ee, bb, te = (self.cls[k][:self.lmax + 1] for k in ['tt', 'ee', 'bb', 'te'])
+        tlm = myhp.almxfl(u1, np.sqrt(tt))
+        r = te * np.where(tt > 0, 1. / np.sqrt(np.where(tt > 0, tt, 1.)), 0.)
+        elm = myhp.almxfl(u1, r) + myhp.almxfl(u2, np.sqrt(np.maximum(ee - r ** 2, 0.)))
+        blm = myhp.almxfl(u3, np.sqrt(bb))
+        return tlm, elm, blm
+
+    def _noise(self, idx, f):
+        rng = np.random.default_rng(2000 + 3 * idx + f)
+        vamin = np.sqrt(myhp.nside2pixarea(self.nside, degrees=True)) * 60
+        return (self.nlev_t if f == 0 else self.nlev_p) / vamin * rng.standard_normal(12 * self.nside ** 2)
+
+    def get_sim_tmap(self, idx):
+        tlm, _, _ = self._alms(idx)
+        return so.alm2map(myhp.almxfl(tlm, self.transf), self.nside, lmax=self.lmax) + self._noise(idx, 0)
+
+    def get_sim_pmap(self, idx):
+        _, elm, blm = self._alms(idx)
+        q, u = so.alm2map_spin([myhp.almxfl(elm, self.transf), myhp.almxfl(blm, self.transf)], self.nside, 2, self.lmax)
+        return q + self._noise(idx, 1), u + self._noise(idx, 2)
+
+
+def main():
+    assert os.path.isdir(REF), 'the reference is only present in the build container'
+    install_healpy_standin()
+    sys.path.insert(0, REF)
+    from plancklens import qest, qecl, utils  # the REFERENCE modules
+    from plancklens.filt import filt_simple, filt_util
+
+    nside, lmax_ivf, lmax_qlm, lmin_ivf = 16, 40, 47, 4
+    cls_path = os.path.join(ROOT, 'plancklens_amd', 'data', 'cls', 'FFP10_wdipole_lensedCls.dat')
+    cl_len = utils.camb_clfile(cls_path, lmax=lmax_ivf)
+    # bring the spectra to O(1) signal-to-noise at these tiny multipoles
+    nlev_t, nlev_p = 1200., 35.
+    transf = myhp.gauss_beam(4. / 180. * np.pi, lmax=lmax_ivf)
+    sims = tiny_sims(nside, lmax_ivf, cl_len, transf, nlev_t, nlev_p)
+    arcmin = np.pi / 180. / 60.
+    ftl = utils.cli(cl_len['tt'][:lmax_ivf + 1] + (nlev_t * arcmin) ** 2 * utils.cli(transf ** 2))
+    fel = utils.cli(cl_len['ee'][:lmax_ivf + 1] + (nlev_p * arcmin) ** 2 * utils.cli(transf ** 2))
+    fbl = utils.cli(cl_len['bb'][:lmax_ivf + 1] + (nlev_p * arcmin) ** 2 * utils.cli(transf ** 2))
+    ftl[:lmin_ivf] = 0; fel[:lmin_ivf] = 0; fbl[:lmin_ivf] = 0
+
+    tmp = tempfile.mkdtemp(prefix='plgolden_')
+    out = {'nside': nside, 'lmax_ivf': lmax_ivf, 'lmax_qlm': lmax_qlm, 'nlev_t': nlev_t, 'nlev_p': nlev_p,
+           'transf': transf, 'ftl': ftl, 'fel': fel, 'fbl': fbl}
+    for k in ['tt', 'ee', 'bb', 'te']:
+        out['cl_' + k] = cl_len[k]
+    try:
+        ivfs = filt_simple.library_fullsky_sepTP(os.path.join(tmp, 'ivfs'), sims, nside, transf, cl_len, ftl, fel, fbl, cache=False)
+        for idx in (0, 1):
+            out['tmap_%d' % idx] = sims.get_sim_tmap(idx)
+            q, u = sims.get_sim_pmap(idx)
+            out['qmap_%d' % idx], out['umap_%d' % idx] = q, u
+            out['tlm_%d' % idx], out['elm_%d' % idx], out['blm_%d' % idx] = ivfs.get_sim_tlm(idx), ivfs.get_sim_elm(idx), ivfs.get_sim_blm(idx)
+        qlms_dd = qest.library_sepTP(os.path.join(tmp, 'qlms_dd'), ivfs, ivfs, cl_len['te'], nside, lmax_qlm=lmax_qlm)
+        for k in ['ptt', 'xtt', 'p_p', 'x_p', 'p', 'x', 'stt', 'ftt', 'f_p', 'a_p', 'pte', 'peb', 'p_tp', 'p_eb']:
+            out['dd_%s_0' % k] = qlms_dd.get_sim_qlm(k, 0)
+        out['dd_p_1'] = qlms_dd.get_sim_qlm('p', 1)
+        out['dd_mf_p'] = qlms_dd.get_sim_qlm_mf('p', np.array([0, 1]))
+        # different legs -> symmetrised estimators (qest.py:327-332)
+        ivfs_s = filt_util.library_shuffle(ivfs, {0: 1, 1: 0})
+        qlms_ds = qest.library_sepTP(os.path.join(tmp, 'qlms_ds'), ivfs, ivfs_s, cl_len['te'], nside, lmax_qlm=lmax_qlm)
+        for k in ['ptt', 'p_p', 'p', 'x', 'ftt', 'f_p']:
+            out['ds_%s_0' % k] = qlms_ds.get_sim_qlm(k, 0)
+        # generic spin-weight route (qest.py:19-39)
+        get_alm = lambda a: {'t': ivfs.get_sim_tlm, 'e': ivfs.get_sim_elm, 'b': ivfs.get_sim_blm}[a](0)
+        for k in ['ptt', 'p_p', 'p']:
+            G, C = qest.eval_qe(k, lmax_ivf, cl_len, get_alm, nside, lmax_qlm, verbose=False)
+            out['gen_%s_G' % k], out['gen_%s_C' % k] = G, C
+        # spectra (qecl.py:85-124)
+        qcls = qecl.library(os.path.join(tmp, 'qcls'), qlms_dd, qlms_dd, np.array([]))
+        out['qcl_p_0'] = qcls.get_sim_qcl('p', 0)
+        out['qcl_ptt_p_p_0'] = qcls.get_sim_qcl('ptt', 0, k2='p_p')
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    np.savez_compressed(os.path.join(HERE, 'qe_golden.npz'), **out)
+    print('wrote qe_golden.npz with %d arrays' % len(out))
+    for k in ['ptt', 'p_p', 'p']:
+        d = np.abs(out['gen_%s_G' % k] - out['dd_%s_0' % k]).max() / np.abs(out['dd_%s_0' % k]).max()
+        print('reference route agreement (library vs eval_qe) %s: %.2e' % (k, d))
+
+
+if __name__ == '__main__':
+    main()

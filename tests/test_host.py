@@ -1,0 +1,91 @@
+"""Host-side logic: healpy-compatible helpers, FITS cache formats, utils (no GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from plancklens_amd import hp, utils
+from helpers import random_alm, alm_size
+
+
+def test_alm_indexing():
+    lmax = 13
+    assert hp.Alm.getsize(lmax) == alm_size(lmax) and hp.Alm.getlmax(alm_size(lmax)) == lmax
+    assert hp.Alm.getlmax(alm_size(lmax) + 1) == -1
+    l, m = hp.Alm.getlm(lmax)
+    assert np.all(hp.Alm.getidx(lmax, l, m) == np.arange(alm_size(lmax)))
+    assert l.min() == 0 and l.max() == lmax and np.all(m <= l)
+
+
+def test_almxfl_alm2cl():
+    rng = np.random.default_rng(0)
+    lmax = 20
+    a, b = random_alm(rng, lmax), random_alm(rng, lmax)
+    fl = rng.standard_normal(12)  # shorter than lmax + 1 -> zero extended
+    out = hp.almxfl(a, fl)
+    l, m = hp.Alm.getlm(lmax)
+    f = np.zeros(lmax + 1); f[:12] = fl
+    assert np.allclose(out, a * f[l]) and not np.shares_memory(out, a)
+    cl = hp.alm2cl(a, b)
+    ref = np.zeros(lmax + 1)
+    for i in range(a.size):
+        ref[l[i]] += (1. if m[i] == 0 else 2.) * (a[i] * np.conj(b[i])).real
+    assert np.allclose(cl, ref / (2 * np.arange(lmax + 1) + 1))
+    assert np.allclose(hp.alm2cl(a, lmax_out=5), hp.alm2cl(a)[:6])
+
+
+def test_alm_copy_and_cli():
+    rng = np.random.default_rng(1)
+    a = random_alm(rng, 15)
+    b = utils.alm_copy(a, lmax=9)
+    l, m = hp.Alm.getlm(9)
+    assert np.all(b == a[hp.Alm.getidx(15, l, m)])
+    assert np.all(utils.alm_copy(a) == a)
+    with pytest.raises(AssertionError):
+        utils.alm_copy(a, lmax=16)
+    assert np.all(utils.cli(np.array([0., 2., -1., 4.])) == np.array([0., 0.5, 0., 0.25]))
+
+
+def test_geometry_and_ud_grade():
+    for nside in (1, 2, 8):
+        cth, sth, nphi, phi0, ofs = hp.ring_info(nside)
+        assert nphi.sum() == 12 * nside ** 2 and np.allclose(cth ** 2 + sth ** 2, 1.)
+        assert np.allclose(cth, -cth[::-1]) and np.all(nphi == nphi[::-1])
+        x, y, z = hp.pix2vec(nside)
+        assert abs(z.sum()) < 1e-10 and abs(x.sum()) < 1e-10  # symmetric pixelisation
+    p = hp.nest2ring(8, np.arange(768))
+    assert sorted(p) == list(range(768))
+    m = np.arange(768, dtype=float)
+    d = hp.ud_grade(m, 4, power=-2)
+    assert d.size == 192 and np.isclose(d.sum(), m.sum())  # power=-2: children are summed
+    # children of a coarse pixel are spatially inside it: degrade of a smooth map is close to the coarse map
+    x8, y8, z8 = hp.pix2vec(8)
+    x4, y4, z4 = hp.pix2vec(4)
+    assert np.abs(hp.ud_grade(z8, 4) - z4).max() < 0.02
+
+
+def test_fits_roundtrip(tmp_path):
+    rng = np.random.default_rng(2)
+    a = random_alm(rng, 17)
+    fn = str(tmp_path / 'a.fits')
+    hp.write_alm(fn, a, overwrite=True)
+    assert np.all(hp.read_alm(fn) == a)
+    assert os.path.getsize(fn) % 2880 == 0
+    with pytest.raises(OSError):
+        hp.write_alm(fn, a, overwrite=False)
+    m = rng.standard_normal((3, 12 * 16 ** 2))
+    fm = str(tmp_path / 'm.fits')
+    hp.write_map(fm, m, overwrite=True)
+    assert np.all(np.array(hp.read_map(fm, field=None)) == m)
+    assert np.all(hp.read_map(fm, field=1) == m[1])
+
+
+def test_camb_clfile_and_hash():
+    fn = os.path.join(os.path.dirname(utils.__file__), 'data', 'cls', 'FFP10_wdipole_lensedCls.dat')
+    cl = utils.camb_clfile(fn, lmax=100)
+    assert set(cl.keys()) >= {'tt', 'ee', 'bb', 'te'} and len(cl['tt']) == 101 and cl['tt'][0] == 0
+    assert 1000 < cl['tt'][2] * 2 * 3 / (2 * np.pi) < 1100  # D_2^TT of FFP10 ~ 1035 muK^2
+    utils.hash_check({'a': 1, 'b': {'c': np.ones(3)}}, {'a': 1, 'b': {'c': np.ones(3)}})
+    with pytest.raises(AssertionError):
+        utils.hash_check({'a': 1}, {'a': 2})
+    assert utils.mchash([3, 1, 2]) == utils.mchash([1, 2, 3])
