@@ -116,6 +116,7 @@ static int ensure_spin(pl_plan *p, int spin)
     SpinTables t;
     build_spin_tables(spin, p->P.lmax, p->P.mmax, t);
     DevSpinTab &S = p->S[spin];
+    t.ab.resize(t.ab.size() + 64, 0.0);  // 8-entry scalar loads may read past the last m (values unused)
     if (upload(p, t.off, &S.off) || upload(p, t.ab, &S.ab) || upload(p, t.beta, &S.beta) || upload(p, t.seedfac_n, &S.seedfac_n) ||
         upload(p, t.seedfac_p, &S.seedfac_p) || upload(p, t.psin, &S.psin) || upload(p, t.phalf, &S.phalf) ||
         upload(p, t.usecos_n, &S.usecos_n) || upload(p, t.usecos_p, &S.usecos_p))
@@ -167,6 +168,7 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
              upload(p, g.phi0, &P.phi0) || upload(p, g.nphi, &P.nphi) || upload(p, g.ofs_n, &P.ofs_n) || upload(p, g.ofs_s, &P.ofs_s);
     Spin0Tables t0;
     build_spin0_tables(lmax, lmax, t0);
+    t0.ab.resize(t0.ab.size() + 64, 0.0);  // 8-entry scalar loads may read past the last m (values unused)
     rc = rc || upload(p, t0.off, &P.off0) || upload(p, t0.ab, &P.ab0) || upload(p, t0.alpha, &P.alpha0) || upload(p, t0.eps, &P.eps0) ||
          upload(p, t0.seed, &P.seed0);
     P.nent0 = t0.off.back();

@@ -11,14 +11,53 @@
 // Bound: FP64 FMA issue; no MFMA (a recurrence, not a contraction).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "device_plan.h"
 #include "legendre_math.h"
+
+#ifndef PL_REDUCE_SWAP
+#define PL_REDUCE_SWAP 1
+#endif
 
 namespace plshts {
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 __device__ __forceinline__ bool wave_all(bool p) { return __all(p) != 0; }
+__device__ __forceinline__ bool wave_any(bool p) { return __any(p) != 0; }
+
+// Hand-placed scalar loads.  hipcc sinks ordinary wave-uniform loads to their first use and then waits for them
+// with lgkmcnt(0) at the top of every trip (measured: 50 % of the wave cycles of the Legendre loops parked in
+// s_waitcnt).  Issued through asm they stay where they are written: one trip ahead of their use, with a single
+// wait at the end of the trip.  Contract: nothing reads the destination between *_issue and sload_wait.
+typedef double d2v_t __attribute__((ext_vector_type(2)));
+typedef double d4v_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sload2_issue(d2v_t &dst, const void *p)
+{
+    asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(dst) : "s"(p) : "memory");
+}
+__device__ __forceinline__ void sload4_issue(d4v_t &dst, const void *p)
+{
+    asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(dst) : "s"(p) : "memory");
+}
+__device__ __forceinline__ void sload_wait(d2v_t &a, d2v_t &b, d4v_t &c, d4v_t &d)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d)::"memory");
+}
+typedef double d8v_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void sload8_issue(d8v_t &dst, const void *p)
+{
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(dst) : "s"(p) : "memory");
+}
+__device__ __forceinline__ void sload_wait(d8v_t &a, d8v_t &b)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory");
+}
+__device__ __forceinline__ void sload_wait(d2v_t &a, d4v_t &c)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(c)::"memory");
+}
 
 // -----------------------------------------------------------------------------------------------------
 // alm -> recursion-basis coefficients (fused hp.almxfl)
@@ -89,7 +128,9 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
     const int wave = wave_id();
     const int lane = threadIdx.x & 63;
     const int ngroups = (P.npairs + RG - 1) / RG;
-    const int mg = blockIdx.x / ngroups, g = blockIdx.x % ngroups;
+    // workgroups are dealt round-robin over the 8 XCDs: rotate the ring group with the m group so that every XCD
+    // sees all latitudes (polar groups are light, equatorial ones heavy) -- otherwise the XCDs finish unevenly
+    const int mg = blockIdx.x / ngroups, g = (blockIdx.x % ngroups + mg) % ngroups;
     const int last = min(P.npairs - 1, g * RG + RG - 1);
     if (P.mlim0[last] < 4 * mg) return;  // every ring of the group is pruned for every m of the group
     const int m = 4 * mg + wave;
@@ -113,7 +154,17 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
         const double2 *__restrict__ ab = reinterpret_cast<const double2 *>(P.ab0) + base;
         const double4 *__restrict__ cd = prep + base;
         int il = 0;
-        // scaled phase: some lane has not yet reached the IEEE range
+        // phase A: no lane of the wave has reached the IEEE range yet -- recursion only, nothing to accumulate
+        for (; il < nil; ++il) {
+            bool act = false, live = false;
+#pragma unroll
+            for (int k = 0; k < R; ++k) { act = act || (r[k].sc == 0); live = live || (r[k].sc != kNeverActive); }
+            if (wave_any(act) || !wave_any(live)) break;
+            const double2 c_ab = ab[il];
+#pragma unroll
+            for (int k = 0; k < R; ++k) rec0_step_careful(r[k], c_ab.x, c_ab.y);
+        }
+        // phase B: some lanes active, some still scaled
         for (; il < nil; ++il) {
             bool done = true;
 #pragma unroll
@@ -129,17 +180,27 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
                 rec0_step_careful(r[k], c_ab.x, c_ab.y);
             }
         }
-        // IEEE phase: pure FMA stream
-#pragma unroll 2
-        for (; il < nil; ++il) {
-            const double2 c_ab = ab[il];
-            const double4 c = cd[il];
+        // phase C: every live lane is in the IEEE range -- pure FMA stream, coefficient loads one trip ahead
+        if (il < nil) {
+            d2v_t n_ab;
+            d4v_t n_c;
+            sload2_issue(n_ab, ab + il); sload4_issue(n_c, cd + il);
+            sload_wait(n_ab, n_c);
+            for (; il < nil; ++il) {
+                const d2v_t c_ab = n_ab;
+                const d4v_t c = n_c;
+                const int ip = min(il + 1, nil - 1);
+                sload2_issue(n_ab, ab + ip); sload4_issue(n_c, cd + ip);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const double v = r[k].p1;
-                cr[k] = fma(v, c.x, cr[k]); ci[k] = fma(v, c.y, ci[k]);
-                dr[k] = fma(v, c.z, dr[k]); di[k] = fma(v, c.w, di[k]);
-                rec0_step_fast(r[k], c_ab.x, c_ab.y);
+                for (int k = 0; k < R; ++k) {
+                    const double v = r[k].p1;
+                    cr[k] = fma(v, c.x, cr[k]); ci[k] = fma(v, c.y, ci[k]);
+                    dr[k] = fma(v, c.z, dr[k]); di[k] = fma(v, c.w, di[k]);
+                    rec0_step_fast(r[k], c_ab.x, c_ab.y);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                sload_wait(n_ab, n_c);
             }
         }
     }
@@ -176,19 +237,28 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
     const int wave = wave_id();
     const int lane = threadIdx.x & 63;
     const int ngroups = (P.npairs + RG - 1) / RG;
-    const int mg = blockIdx.x / ngroups, g = blockIdx.x % ngroups;
+    // workgroups are dealt round-robin over the 8 XCDs: rotate the ring group with the m group so that every XCD
+    // sees all latitudes (polar groups are light, equatorial ones heavy) -- otherwise the XCDs finish unevenly
+    const int mg = blockIdx.x / ngroups, g = (blockIdx.x % ngroups + mg) % ngroups;
     const int last = min(P.npairs - 1, g * RG + RG - 1);
     if (S.mlim[last] < 4 * mg) return;
     const int m = 4 * mg + wave;
     const int l0 = m > spin ? m : spin;
 
-    // X_N = sum Sn An, Y_N = sum Sp Ap, X_S = sum sigma Sp An, Y_S = sum sigma Sn Ap
-    double xn_r[R], xn_i[R], yn_r[R], yn_i[R], xs_r[R], xs_i[R], ys_r[R], ys_i[R];
+    // X_N = sum Sn An, Y_N = sum Sp Ap, X_S = sum sigma Sp An, Y_S = sum sigma Sn Ap, sigma_l = (-1)^(l+m).
+    // The mirror sums are kept per parity of i = l - l0 (xe / xo, ye / yo) so that no sign multiply is needed.
+    double xn_r[R], xn_i[R], yn_r[R], yn_i[R];
+    double xe_r[R], xe_i[R], ye_r[R], ye_i[R], xo_r[R], xo_i[R], yo_r[R], yo_i[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) xn_r[k] = xn_i[k] = yn_r[k] = yn_i[k] = xs_r[k] = xs_i[k] = ys_r[k] = ys_i[k] = 0.0;
+    for (int k = 0; k < R; ++k) {
+        xn_r[k] = xn_i[k] = yn_r[k] = yn_i[k] = 0.0;
+        xe_r[k] = xe_i[k] = ye_r[k] = ye_i[k] = xo_r[k] = xo_i[k] = yo_r[k] = yo_i[k] = 0.0;
+    }
+    double sig0 = 1.0;
 
     if (m <= P.mmax && l0 <= P.lmax) {
         RecS r[R];
+        sig0 = ((l0 + m) & 1) ? -1.0 : 1.0;
         const double fn = S.seedfac_n[m], fp = S.seedfac_p[m];
         const int psin = S.psin[m], phalf = S.phalf[m], ucn = S.usecos_n[m], ucp = S.usecos_p[m];
 #pragma unroll
@@ -202,8 +272,21 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
         const int64_t base = S.off[m];
         const double2 *__restrict__ ab = reinterpret_cast<const double2 *>(S.ab) + base;
         const double4 *__restrict__ aa = prep + base;
-        double sig = ((l0 + m) & 1) ? -1.0 : 1.0;  // sigma_l = (-1)^(l + m)
         int i = 0;
+        // phase A: no lane active yet -- recursion only
+        for (; i < nl; ++i) {
+            bool act = false, live = false;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                act = act || r[k].scn == 0 || r[k].scp == 0;
+                live = live || r[k].scn != kNeverActive || r[k].scp != kNeverActive;
+            }
+            if (wave_any(act) || !wave_any(live)) break;
+            const double2 c_ab = ab[i];
+#pragma unroll
+            for (int k = 0; k < R; ++k) recs_step_careful(r[k], c_ab.x, c_ab.y);
+        }
+        // phase B: mixed
         for (; i < nl; ++i) {
             bool done = true;
 #pragma unroll
@@ -212,39 +295,69 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
             if (wave_all(done)) break;
             const double2 c_ab = ab[i];
             const double4 a = aa[i];
-            const double sar = sig * a.x, sai = sig * a.y, spr = sig * a.z, spi = sig * a.w;
+            const bool odd = (i & 1) != 0;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const double vn = recs_value_n(r[k]), vp = recs_value_p(r[k]);
                 xn_r[k] = fma(vn, a.x, xn_r[k]); xn_i[k] = fma(vn, a.y, xn_i[k]);
                 yn_r[k] = fma(vp, a.z, yn_r[k]); yn_i[k] = fma(vp, a.w, yn_i[k]);
-                xs_r[k] = fma(vp, sar, xs_r[k]); xs_i[k] = fma(vp, sai, xs_i[k]);
-                ys_r[k] = fma(vn, spr, ys_r[k]); ys_i[k] = fma(vn, spi, ys_i[k]);
+                if (!odd) {
+                    xe_r[k] = fma(vp, a.x, xe_r[k]); xe_i[k] = fma(vp, a.y, xe_i[k]);
+                    ye_r[k] = fma(vn, a.z, ye_r[k]); ye_i[k] = fma(vn, a.w, ye_i[k]);
+                } else {
+                    xo_r[k] = fma(vp, a.x, xo_r[k]); xo_i[k] = fma(vp, a.y, xo_i[k]);
+                    yo_r[k] = fma(vn, a.z, yo_r[k]); yo_i[k] = fma(vn, a.w, yo_i[k]);
+                }
                 recs_step_careful(r[k], c_ab.x, c_ab.y);
             }
-            sig = -sig;
         }
-        // IEEE phase, two l per trip so that sigma is a compile-time sign
-        for (; i + 1 < nl; i += 2) {
-            const double2 c_ab0 = ab[i], c_ab1 = ab[i + 1];
-            const double4 a0 = aa[i], a1 = aa[i + 1];
-            const double s0 = sig;
+        // phase C: pure FMA stream, two l per trip (even i, odd i)
+        if (i < nl && (i & 1)) {
+            const double2 c_ab = ab[i];
+            const double4 a = aa[i];
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                double vn = r[k].n1, vp = r[k].p1;
-                const double wn = s0 * vn, wp = s0 * vp;
-                xn_r[k] = fma(vn, a0.x, xn_r[k]); xn_i[k] = fma(vn, a0.y, xn_i[k]);
-                yn_r[k] = fma(vp, a0.z, yn_r[k]); yn_i[k] = fma(vp, a0.w, yn_i[k]);
-                xs_r[k] = fma(wp, a0.x, xs_r[k]); xs_i[k] = fma(wp, a0.y, xs_i[k]);
-                ys_r[k] = fma(wn, a0.z, ys_r[k]); ys_i[k] = fma(wn, a0.w, ys_i[k]);
-                recs_step_fast(r[k], c_ab0.x, c_ab0.y);
-                vn = r[k].n1; vp = r[k].p1;
-                const double un = -s0 * vn, up = -s0 * vp;
-                xn_r[k] = fma(vn, a1.x, xn_r[k]); xn_i[k] = fma(vn, a1.y, xn_i[k]);
-                yn_r[k] = fma(vp, a1.z, yn_r[k]); yn_i[k] = fma(vp, a1.w, yn_i[k]);
-                xs_r[k] = fma(up, a1.x, xs_r[k]); xs_i[k] = fma(up, a1.y, xs_i[k]);
-                ys_r[k] = fma(un, a1.z, ys_r[k]); ys_i[k] = fma(un, a1.w, ys_i[k]);
-                recs_step_fast(r[k], c_ab1.x, c_ab1.y);
+                const double vn = r[k].n1, vp = r[k].p1;
+                xn_r[k] = fma(vn, a.x, xn_r[k]); xn_i[k] = fma(vn, a.y, xn_i[k]);
+                yn_r[k] = fma(vp, a.z, yn_r[k]); yn_i[k] = fma(vp, a.w, yn_i[k]);
+                xo_r[k] = fma(vp, a.x, xo_r[k]); xo_i[k] = fma(vp, a.y, xo_i[k]);
+                yo_r[k] = fma(vn, a.z, yo_r[k]); yo_i[k] = fma(vn, a.w, yo_i[k]);
+                recs_step_fast(r[k], c_ab.x, c_ab.y);
+            }
+            ++i;
+        }
+        if (i + 1 < nl) {
+            // software pipeline: the (wave-uniform, scalar) coefficient loads of trip t + 1 are issued before the
+            // FMA stream of trip t, so their latency hides under ~50 v_fma_f64 instead of stalling every trip
+            d2v_t n_ab0, n_ab1;
+            d4v_t n_a0, n_a1;
+            sload2_issue(n_ab0, ab + i); sload2_issue(n_ab1, ab + i + 1);
+            sload4_issue(n_a0, aa + i); sload4_issue(n_a1, aa + i + 1);
+            sload_wait(n_ab0, n_ab1, n_a0, n_a1);
+            for (; i + 1 < nl; i += 2) {
+                const d2v_t c_ab0 = n_ab0, c_ab1 = n_ab1;
+                const d4v_t a0 = n_a0, a1 = n_a1;
+                const int ip = min(i + 2, nl - 2);  // clamped: the last prefetch re-reads valid entries
+                sload2_issue(n_ab0, ab + ip); sload2_issue(n_ab1, ab + ip + 1);
+                sload4_issue(n_a0, aa + ip); sload4_issue(n_a1, aa + ip + 1);
+                __builtin_amdgcn_sched_barrier(0);  // keep the issues ahead of the FMA stream
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    double vn = r[k].n1, vp = r[k].p1;
+                    xn_r[k] = fma(vn, a0.x, xn_r[k]); xn_i[k] = fma(vn, a0.y, xn_i[k]);
+                    yn_r[k] = fma(vp, a0.z, yn_r[k]); yn_i[k] = fma(vp, a0.w, yn_i[k]);
+                    xe_r[k] = fma(vp, a0.x, xe_r[k]); xe_i[k] = fma(vp, a0.y, xe_i[k]);
+                    ye_r[k] = fma(vn, a0.z, ye_r[k]); ye_i[k] = fma(vn, a0.w, ye_i[k]);
+                    recs_step_fast(r[k], c_ab0.x, c_ab0.y);
+                    vn = r[k].n1; vp = r[k].p1;
+                    xn_r[k] = fma(vn, a1.x, xn_r[k]); xn_i[k] = fma(vn, a1.y, xn_i[k]);
+                    yn_r[k] = fma(vp, a1.z, yn_r[k]); yn_i[k] = fma(vp, a1.w, yn_i[k]);
+                    xo_r[k] = fma(vp, a1.x, xo_r[k]); xo_i[k] = fma(vp, a1.y, xo_i[k]);
+                    yo_r[k] = fma(vn, a1.z, yo_r[k]); yo_i[k] = fma(vn, a1.w, yo_i[k]);
+                    recs_step_fast(r[k], c_ab1.x, c_ab1.y);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                sload_wait(n_ab0, n_ab1, n_a0, n_a1);
             }
         }
         if (i < nl) {
@@ -252,11 +365,10 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const double vn = r[k].n1, vp = r[k].p1;
-                const double wn = sig * vn, wp = sig * vp;
                 xn_r[k] = fma(vn, a.x, xn_r[k]); xn_i[k] = fma(vn, a.y, xn_i[k]);
                 yn_r[k] = fma(vp, a.z, yn_r[k]); yn_i[k] = fma(vp, a.w, yn_i[k]);
-                xs_r[k] = fma(wp, a.x, xs_r[k]); xs_i[k] = fma(wp, a.y, xs_i[k]);
-                ys_r[k] = fma(wn, a.z, ys_r[k]); ys_i[k] = fma(wn, a.w, ys_i[k]);
+                xe_r[k] = fma(vp, a.x, xe_r[k]); xe_i[k] = fma(vp, a.y, xe_i[k]);
+                ye_r[k] = fma(vn, a.z, ye_r[k]); ye_i[k] = fma(vn, a.w, ye_i[k]);
             }
         }
     }
@@ -265,10 +377,12 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
     for (int k = 0; k < R; ++k) {
         const int rl = k * 64 + lane;
         double *t = tile + rl * 32 + wave * 8;
+        const double xs_r = sig0 * (xe_r[k] - xo_r[k]), xs_i = sig0 * (xe_i[k] - xo_i[k]);
+        const double ys_r = sig0 * (ye_r[k] - yo_r[k]), ys_i = sig0 * (ye_i[k] - yo_i[k]);
         t[0] = xn_r[k] + yn_r[k]; t[1] = xn_i[k] + yn_i[k];
-        t[2] = xs_r[k] + ys_r[k]; t[3] = xs_i[k] + ys_i[k];
+        t[2] = xs_r + ys_r; t[3] = xs_i + ys_i;
         t[4] = -(yn_i[k] - xn_i[k]); t[5] = yn_r[k] - xn_r[k];
-        t[6] = -(ys_i[k] - xs_i[k]); t[7] = ys_r[k] - xs_r[k];
+        t[6] = -(ys_i - xs_i); t[7] = ys_r - xs_r;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < RG * 16; c += 256) {
@@ -284,15 +398,51 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
 // -----------------------------------------------------------------------------------------------------
 // cross-lane transpose-reduce: every lane holds v[0..63]; on return lane L holds sum over lanes of v[L]
 // -----------------------------------------------------------------------------------------------------
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+
+// gfx950 v_permlane32_swap / v_permlane16_swap: exchange the upper half (odd 16-lane rows) of `a` with the lower
+// half (even rows) of `b`.  Afterwards a + b is, in the lower lanes, own a + partner's a and, in the upper lanes,
+// partner's b + own b: one transpose-reduce step without any select.
+__device__ __forceinline__ double swap_add32(double a, double b)
+{
+    const v2u_t lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const v2u_t hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
+}
+__device__ __forceinline__ double swap_add16(double a, double b)
+{
+    const v2u_t lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const v2u_t hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(hi.x, lo.x) + __hiloint2double(hi.y, lo.y);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 template <int HALF>
 __device__ __forceinline__ void reduce_step(double *v, int lane)
 {
     const bool up = (lane & HALF) != 0;  // the lane-id bit handled by this step equals the half size
 #pragma unroll
     for (int i = 0; i < HALF; ++i) {
+#if PL_REDUCE_SWAP
+        if (HALF == 32) { v[i] = swap_add32(v[i], v[i + HALF]); continue; }
+        if (HALF == 16) { v[i] = swap_add16(v[i], v[i + HALF]); continue; }
+#endif
         const double keep = up ? v[i + HALF] : v[i];
         const double send = up ? v[i] : v[i + HALF];
-        const double recv = __shfl_xor(send, HALF, 64);
+        double recv;
+#if PL_REDUCE_SWAP
+        if (HALF == 8) recv = dpp_move<0x128>(send);       // row_ror:8  = lane ^ 8 inside a row of 16
+        else if (HALF == 2) recv = dpp_move<0x4E>(send);   // quad_perm [2,3,0,1] = lane ^ 2
+        else if (HALF == 1) recv = dpp_move<0xB1>(send);   // quad_perm [1,0,3,2] = lane ^ 1
+        else
+#endif
+            recv = __shfl_xor(send, HALF, 64);
         v[i] = keep + recv;
     }
 }
@@ -320,7 +470,9 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
     const int wave = wave_id();
     const int lane = threadIdx.x & 63;
     const int ngroups = (P.npairs + RG - 1) / RG;
-    const int mg = blockIdx.x / ngroups, g = blockIdx.x % ngroups;
+    // workgroups are dealt round-robin over the 8 XCDs: rotate the ring group with the m group so that every XCD
+    // sees all latitudes (polar groups are light, equatorial ones heavy) -- otherwise the XCDs finish unevenly
+    const int mg = blockIdx.x / ngroups, g = (blockIdx.x % ngroups + mg) % ngroups;
     const int last = min(P.npairs - 1, g * RG + RG - 1);
     if (P.mlim0[last] < 4 * mg) return;
     const int m = 4 * mg + wave;
@@ -355,32 +507,67 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
     const int64_t base = P.off0[m];
     const double2 *__restrict__ ab = reinterpret_cast<const double2 *>(P.ab0) + base;
     double *__restrict__ out = partial + ((int64_t)g * P.nent0 + base) * 4;
-    bool all_active = false;
+    bool all_active = false, any_active = false;
+    int pf = -1;
+    d8v_t n0, n1;
     for (int il0 = 0; il0 < nil; il0 += T) {
+        if (!any_active) {
+            // no lane has reached the IEEE range: recursion only.  A lane that activates inside this tile is
+            // at 2^-256 then and cannot grow past ~2^-70 within the tile, so the tile's sums are exactly
+            // representable as zero at double precision.
+            bool act = false, live = false;
+#pragma unroll
+            for (int k = 0; k < R; ++k) { act = act || (r[k].sc == 0); live = live || (r[k].sc != kNeverActive); }
+            any_active = wave_any(act) || !wave_any(live);
+            if (!any_active) {
+                const int nt = min(T, nil - il0);
+                for (int t = 0; t < nt; ++t) {
+                    const double2 c_ab = ab[il0 + t];
+#pragma unroll
+                    for (int k = 0; k < R; ++k) rec0_step_careful(r[k], c_ab.x, c_ab.y);
+                }
+                if (il0 + (lane >> 2) < nil) out[(int64_t)il0 * 4 + lane] = 0.0;
+                continue;
+            }
+        }
         double acc[64];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int il = il0 + t;
-            double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
-            if (il < nil) {
-                const double2 c_ab = ab[il];
-                if (!all_active) {
+        for (int h = 0; h < 2; ++h) {
+            // (A, B) of 8 consecutive il: loaded one half tile ahead (tables are padded, reads past nil are unused)
+            const int ib = il0 + 8 * h;
+            if (pf != ib) { sload8_issue(n0, ab + ib); sload8_issue(n1, ab + ib + 4); sload_wait(n0, n1); }
+            const d8v_t c0 = n0, c1 = n1;
+            sload8_issue(n0, ab + ib + 8); sload8_issue(n1, ab + ib + 12);  // next half tile, one ahead
+            pf = ib + 8;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int k = 0; k < R; ++k) {
-                        const double v = rec0_value(r[k]);
-                        a0 = fma(v, er[k], a0); a1 = fma(v, ei[k], a1); a2 = fma(v, orr[k], a2); a3 = fma(v, oi[k], a3);
-                        rec0_step_careful(r[k], c_ab.x, c_ab.y);
-                    }
-                } else {
+            for (int tt = 0; tt < 8; ++tt) {
+                const int t = 8 * h + tt;
+                const int il = il0 + t;
+                double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+                if (il < nil) {
+                    const double cA = tt < 4 ? c0[2 * tt] : c1[2 * (tt - 4)];
+                    const double cB = tt < 4 ? c0[2 * tt + 1] : c1[2 * (tt - 4) + 1];
+                    if (!all_active) {
 #pragma unroll
-                    for (int k = 0; k < R; ++k) {
-                        const double v = r[k].p1;
-                        a0 = fma(v, er[k], a0); a1 = fma(v, ei[k], a1); a2 = fma(v, orr[k], a2); a3 = fma(v, oi[k], a3);
-                        rec0_step_fast(r[k], c_ab.x, c_ab.y);
+                        for (int k = 0; k < R; ++k) {
+                            const double v = rec0_value(r[k]);
+                            a0 = fma(v, er[k], a0); a1 = fma(v, ei[k], a1); a2 = fma(v, orr[k], a2); a3 = fma(v, oi[k], a3);
+                            rec0_step_careful(r[k], cA, cB);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < R; ++k) {
+                            const double v = r[k].p1;
+                            a0 = fma(v, er[k], a0); a1 = fma(v, ei[k], a1); a2 = fma(v, orr[k], a2); a3 = fma(v, oi[k], a3);
+                            rec0_step_fast(r[k], cA, cB);
+                        }
                     }
                 }
+                acc[4 * t] = a0; acc[4 * t + 1] = a1; acc[4 * t + 2] = a2; acc[4 * t + 3] = a3;
             }
-            acc[4 * t] = a0; acc[4 * t + 1] = a1; acc[4 * t + 2] = a2; acc[4 * t + 3] = a3;
+            __builtin_amdgcn_sched_barrier(0);
+            sload_wait(n0, n1);
         }
         if (!all_active) {
             bool done = true;
@@ -446,7 +633,9 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
     const int wave = wave_id();
     const int lane = threadIdx.x & 63;
     const int ngroups = (P.npairs + RG - 1) / RG;
-    const int mg = blockIdx.x / ngroups, g = blockIdx.x % ngroups;
+    // workgroups are dealt round-robin over the 8 XCDs: rotate the ring group with the m group so that every XCD
+    // sees all latitudes (polar groups are light, equatorial ones heavy) -- otherwise the XCDs finish unevenly
+    const int mg = blockIdx.x / ngroups, g = (blockIdx.x % ngroups + mg) % ngroups;
     const int last = min(P.npairs - 1, g * RG + RG - 1);
     if (S.mlim[last] < 4 * mg) return;
     const int m = 4 * mg + wave;
@@ -501,32 +690,66 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
     const int64_t base = S.off[m];
     const double2 *__restrict__ ab = reinterpret_cast<const double2 *>(S.ab) + base;
     double *__restrict__ out = partial + ((int64_t)g * nent + base) * 4;
-    bool all_active = false;
+    bool all_active = false, any_active = false;
+    int pf = -1;
+    d8v_t n0, n1;
     for (int i0 = 0; i0 < nl; i0 += T) {
+        if (!any_active) {
+            bool act = false, live = false;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                act = act || r[k].scn == 0 || r[k].scp == 0;
+                live = live || r[k].scn != kNeverActive || r[k].scp != kNeverActive;
+            }
+            any_active = wave_any(act) || !wave_any(live);
+            if (!any_active) {
+                const int nt = min(T, nl - i0);
+                for (int t = 0; t < nt; ++t) {
+                    const double2 c_ab = ab[i0 + t];
+#pragma unroll
+                    for (int k = 0; k < R; ++k) recs_step_careful(r[k], c_ab.x, c_ab.y);
+                }
+                if (i0 + (lane >> 2) < nl) out[(int64_t)i0 * 4 + lane] = 0.0;
+                continue;
+            }
+        }
         double acc[64];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int i = i0 + t;
-            double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
-            if (i < nl) {
-                const double2 c_ab = ab[i];
+        for (int h = 0; h < 2; ++h) {
+            const int ib = i0 + 8 * h;
+            if (pf != ib) { sload8_issue(n0, ab + ib); sload8_issue(n1, ab + ib + 4); sload_wait(n0, n1); }
+            const d8v_t c0 = n0, c1 = n1;
+            sload8_issue(n0, ab + ib + 8); sload8_issue(n1, ab + ib + 12);  // next half tile, one ahead
+            pf = ib + 8;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    double vn, vp;
-                    if (!all_active) { vn = recs_value_n(r[k]); vp = recs_value_p(r[k]); }
-                    else { vn = r[k].n1; vp = r[k].p1; }
-                    if ((t & 1) == 0) {
-                        a0 = fma(vn, aer[k], a0); a1 = fma(vn, aei[k], a1); a2 = fma(vn, aor[k], a2); a3 = fma(vn, aoi[k], a3);
-                        a0 = fma(vp, ber[k], a0); a1 = fma(vp, bei[k], a1); a2 = fma(-vp, bor[k], a2); a3 = fma(-vp, boi[k], a3);
-                    } else {
-                        a0 = fma(vn, aor[k], a0); a1 = fma(vn, aoi[k], a1); a2 = fma(vn, aer[k], a2); a3 = fma(vn, aei[k], a3);
-                        a0 = fma(vp, bor[k], a0); a1 = fma(vp, boi[k], a1); a2 = fma(-vp, ber[k], a2); a3 = fma(-vp, bei[k], a3);
+            for (int tt = 0; tt < 8; ++tt) {
+                const int t = 8 * h + tt;
+                const int i = i0 + t;
+                double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+                if (i < nl) {
+                    const double cA = tt < 4 ? c0[2 * tt] : c1[2 * (tt - 4)];
+                    const double cB = tt < 4 ? c0[2 * tt + 1] : c1[2 * (tt - 4) + 1];
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        double vn, vp;
+                        if (!all_active) { vn = recs_value_n(r[k]); vp = recs_value_p(r[k]); }
+                        else { vn = r[k].n1; vp = r[k].p1; }
+                        if ((t & 1) == 0) {
+                            a0 = fma(vn, aer[k], a0); a1 = fma(vn, aei[k], a1); a2 = fma(vn, aor[k], a2); a3 = fma(vn, aoi[k], a3);
+                            a0 = fma(vp, ber[k], a0); a1 = fma(vp, bei[k], a1); a2 = fma(-vp, bor[k], a2); a3 = fma(-vp, boi[k], a3);
+                        } else {
+                            a0 = fma(vn, aor[k], a0); a1 = fma(vn, aoi[k], a1); a2 = fma(vn, aer[k], a2); a3 = fma(vn, aei[k], a3);
+                            a0 = fma(vp, bor[k], a0); a1 = fma(vp, boi[k], a1); a2 = fma(-vp, ber[k], a2); a3 = fma(-vp, bei[k], a3);
+                        }
+                        if (!all_active) recs_step_careful(r[k], cA, cB);
+                        else recs_step_fast(r[k], cA, cB);
                     }
-                    if (!all_active) recs_step_careful(r[k], c_ab.x, c_ab.y);
-                    else recs_step_fast(r[k], c_ab.x, c_ab.y);
                 }
+                acc[4 * t] = a0; acc[4 * t + 1] = a1; acc[4 * t + 2] = a2; acc[4 * t + 3] = a3;
             }
-            acc[4 * t] = a0; acc[4 * t + 1] = a1; acc[4 * t + 2] = a2; acc[4 * t + 3] = a3;
+            __builtin_amdgcn_sched_barrier(0);
+            sload_wait(n0, n1);
         }
         if (!all_active) {
             bool done = true;
@@ -577,10 +800,18 @@ __global__ void k_posts(DevPlan P, DevSpinTab S, int spin, int RG, int64_t nent,
 // -----------------------------------------------------------------------------------------------------
 // host launchers
 // -----------------------------------------------------------------------------------------------------
-constexpr int kR0 = 4;   // ring pairs per lane, spin 0
-constexpr int kRS = 2;   // ring pairs per lane, spin s
+// ring pairs per lane (tunable at run time for experiments: PLSHTS_R0 / PLSHTS_RS in the environment)
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+static int r0_synth() { static int r = env_int("PLSHTS_R0", 3); return r; }
+static int rs_synth() { static int r = env_int("PLSHTS_RS", 2); return r; }
+static int r0_anal() { static int r = env_int("PLSHTS_R0A", 4); return r; }
+static int rs_anal() { static int r = env_int("PLSHTS_RSA", 3); return r; }
 
-int rings_per_group(int spin) { return 64 * (spin == 0 ? kR0 : kRS); }
+int rings_per_group(int spin) { return 64 * (spin == 0 ? r0_anal() : rs_anal()); }
 
 void launch_prep0(const DevPlan &P, const double *alm, const double *fl, double *prep, hipStream_t st)
 {
@@ -596,40 +827,85 @@ void launch_preps(const DevPlan &P, const DevSpinTab &S, int spin, const double 
                        reinterpret_cast<const double2 *>(alm) + P.nalm, fl, reinterpret_cast<double4 *>(prep));
 }
 
+template <int R>
+static void launch_synth0_r(const DevPlan &P, const double *prep, double *phase, hipStream_t st)
+{
+    constexpr int RG = 64 * R;
+    const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
+    hipLaunchKernelGGL(k_leg_synth0<R>, dim3(ngroups * nmg), dim3(256), 0, st, P, reinterpret_cast<const double4 *>(prep), phase);
+}
+
 void launch_synth0(const DevPlan &P, const double *prep, double *phase, hipStream_t st)
 {
-    constexpr int RG = 64 * kR0;
+    switch (r0_synth()) {
+    case 1: launch_synth0_r<1>(P, prep, phase, st); break;
+    case 2: launch_synth0_r<2>(P, prep, phase, st); break;
+    case 5: launch_synth0_r<5>(P, prep, phase, st); break;
+    case 6: launch_synth0_r<6>(P, prep, phase, st); break;
+    case 4: launch_synth0_r<4>(P, prep, phase, st); break;
+    default: launch_synth0_r<3>(P, prep, phase, st); break;
+    }
+}
+
+template <int R>
+static void launch_synths_r(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st)
+{
+    constexpr int RG = 64 * R;
     const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
-    hipLaunchKernelGGL(k_leg_synth0<kR0>, dim3(ngroups * nmg), dim3(256), 0, st, P, reinterpret_cast<const double4 *>(prep), phase);
+    hipLaunchKernelGGL(k_leg_synths<R>, dim3(ngroups * nmg), dim3(256), 0, st, P, S, spin,
+                       reinterpret_cast<const double4 *>(prep), phase);
 }
 
 void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st)
 {
-    constexpr int RG = 64 * kRS;
-    const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
-    hipLaunchKernelGGL(k_leg_synths<kRS>, dim3(ngroups * nmg), dim3(256), 0, st, P, S, spin,
-                       reinterpret_cast<const double4 *>(prep), phase);
+    switch (rs_synth()) {
+    case 1: launch_synths_r<1>(P, S, spin, prep, phase, st); break;
+    case 3: launch_synths_r<3>(P, S, spin, prep, phase, st); break;
+    case 4: launch_synths_r<4>(P, S, spin, prep, phase, st); break;
+    default: launch_synths_r<2>(P, S, spin, prep, phase, st); break;
+    }
 }
 
-void launch_anal0(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st)
+template <int R>
+static void launch_anal0_r(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st)
 {
-    constexpr int RG = 64 * kR0;
+    constexpr int RG = 64 * R;
     const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
-    hipLaunchKernelGGL(k_leg_anal0<kR0>, dim3(ngroups * nmg), dim3(256), 0, st, P, phase, partial);
+    hipLaunchKernelGGL(k_leg_anal0<R>, dim3(ngroups * nmg), dim3(256), 0, st, P, phase, partial);
     dim3 grid(4, P.mmax + 1);
     hipLaunchKernelGGL(k_post0, grid, dim3(256), 0, st, P, RG, reinterpret_cast<const double4 *>(partial), fl,
                        reinterpret_cast<double2 *>(alm));
 }
 
-void launch_anals(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
-                  const double *fl, double *alm, hipStream_t st)
+void launch_anal0(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st)
 {
-    constexpr int RG = 64 * kRS;
+    switch (r0_anal()) {
+    case 2: launch_anal0_r<2>(P, phase, partial, fl, alm, st); break;
+    case 3: launch_anal0_r<3>(P, phase, partial, fl, alm, st); break;
+    default: launch_anal0_r<4>(P, phase, partial, fl, alm, st); break;
+    }
+}
+
+template <int R>
+static void launch_anals_r(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
+                           const double *fl, double *alm, hipStream_t st)
+{
+    constexpr int RG = 64 * R;
     const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
-    hipLaunchKernelGGL(k_leg_anals<kRS>, dim3(ngroups * nmg), dim3(256), 0, st, P, S, spin, phase, partial, nent);
+    hipLaunchKernelGGL(k_leg_anals<R>, dim3(ngroups * nmg), dim3(256), 0, st, P, S, spin, phase, partial, nent);
     dim3 grid(4, P.mmax + 1);
     hipLaunchKernelGGL(k_posts, grid, dim3(256), 0, st, P, S, spin, RG, nent, reinterpret_cast<const double4 *>(partial), fl,
                        reinterpret_cast<double2 *>(alm), reinterpret_cast<double2 *>(alm) + P.nalm);
+}
+
+void launch_anals(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
+                  const double *fl, double *alm, hipStream_t st)
+{
+    switch (rs_anal()) {
+    case 1: launch_anals_r<1>(P, S, spin, nent, phase, partial, fl, alm, st); break;
+    case 2: launch_anals_r<2>(P, S, spin, nent, phase, partial, fl, alm, st); break;
+    default: launch_anals_r<3>(P, S, spin, nent, phase, partial, fl, alm, st); break;
+    }
 }
 
 }  // namespace plshts

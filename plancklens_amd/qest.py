@@ -256,26 +256,32 @@ class library(object):
         G, C = shts.map2alm_spin([re, im], 1, lmax=lmax, fl=_lens_weight(lmax))
         return G, C
 
-    def _get_sim_Tgclm_dev(self, idx, k, swapped=False, xfilt1=None, xfilt2=None):
+    def _t_product(self, idx, k, swapped=False, xfilt1=None, xfilt2=None):
+        """Tb(n) x spin-1 gradient leg: the real-space product of the T estimator (qest.py:254-257)."""
         f2map1, f2map2 = self._legs(swapped)
         xf1, xf2 = (xfilt2, xfilt1) if swapped else (xfilt1, xfilt2)
         tmap = f2map1.get_irestmap(idx, xfilt=xf1)
         G, C = f2map2.get_gtmap(idx, k=k, xfilt=xf2)
-        G = dev.map_mul(G, tmap, out=G)
-        C = dev.map_mul(C, tmap, out=C)
-        del tmap
-        return self._gc_from_product(G, C, 'T')
+        return dev.map_mul(G, tmap, out=G), dev.map_mul(C, tmap, out=C)
 
-    def _get_sim_Pgclm_dev(self, idx, k, swapped=False, xfilt1=None, xfilt2=None):
+    def _p_product(self, idx, k, swapped=False, xfilt1=None, xfilt2=None):
+        """(Qb - iUb)(3G + i 3C) - (Qb + iUb)(1G - i 1C): the real-space product of the P estimator (qest.py:273-278)."""
         f2map1, f2map2 = self._legs(swapped)
         xf1, xf2 = (xfilt2, xfilt1) if swapped else (xfilt1, xfilt2)
         repmap, impmap = f2map1.get_irespmap(idx, xfilt=xf1)
         Gs, Cs = f2map2.get_gpmap(idx, 3, k=k, xfilt=xf2)
         dre, dim = torch.empty_like(repmap), torch.empty_like(repmap)
-        dev.map_cmul(repmap, impmap, -1., Gs, Cs, +1., +1., dre, dim, False)   # (Qb - iUb)(3G + i 3C)
+        dev.map_cmul(repmap, impmap, -1., Gs, Cs, +1., +1., dre, dim, False)
         Gs, Cs = f2map2.get_gpmap(idx, 1, k=k, xfilt=xf2)
-        dev.map_cmul(repmap, impmap, +1., Gs, Cs, -1., -1., dre, dim, True)    # -(Qb + iUb)(1G - i 1C)
-        del repmap, impmap, Gs, Cs
+        dev.map_cmul(repmap, impmap, +1., Gs, Cs, -1., -1., dre, dim, True)
+        return dre, dim
+
+    def _get_sim_Tgclm_dev(self, idx, k, swapped=False, xfilt1=None, xfilt2=None):
+        G, C = self._t_product(idx, k, swapped=swapped, xfilt1=xfilt1, xfilt2=xfilt2)
+        return self._gc_from_product(G, C, 'T')
+
+    def _get_sim_Pgclm_dev(self, idx, k, swapped=False, xfilt1=None, xfilt2=None):
+        dre, dim = self._p_product(idx, k, swapped=swapped, xfilt1=xfilt1, xfilt2=xfilt2)
         return self._gc_from_product(dre, dim, 'P')
 
     def _get_sim_Tgclm(self, idx, k, swapped=False, xfilt1=None, xfilt2=None):
@@ -289,11 +295,17 @@ class library(object):
         return dev.to_host(G), dev.to_host(C)
 
     def _get_sim_MVgclm(self, idx, k, swapped=False):
-        """Minimum-variance estimator = P part + T part, two separate final analyses (qest.py:318-322)."""
+        """Minimum-variance estimator = P part + T part (qest.py:318-322).  The reference analyses the two
+        product maps separately and adds the alms; map2alm_spin is linear, so the product maps are summed on the
+        device and analysed once (one spin-1 transform less, results equal to rounding)."""
         assert k == 'p'
-        GP, CP = self._get_sim_Pgclm_dev(idx, 'p', swapped=swapped)
-        GT, CT = self._get_sim_Tgclm_dev(idx, 'p', swapped=swapped)
-        return dev.to_host(GP + GT), dev.to_host(CP + CT)
+        dre, dim = self._p_product(idx, 'p', swapped=swapped)
+        gt, ct = self._t_product(idx, 'p', swapped=swapped)
+        dre += gt
+        dim += ct
+        del gt, ct
+        G, C = self._gc_from_product(dre, dim, 'P')
+        return dev.to_host(G), dev.to_host(C)
 
     def _scalar_from_product(self, prod, fac, lmax_key):
         lmax = self.get_lmax_qlm(lmax_key)
