@@ -196,7 +196,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        mf_sum += dev.to_dev(state['last'][0])
+        if qlms._last_dev is not None:
+            mf_sum += qlms._last_dev[0]            # running mean-field sum stays on the device
+        else:
+            mf_sum += dev.to_dev(state['last'][0])
     if world > 1:
         buf = torch.view_as_real(mf_sum)
         dist.all_reduce(buf)                                     # mean-field sum over ranks (RCCL)

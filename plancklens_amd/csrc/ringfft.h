@@ -11,6 +11,7 @@ struct DevFFT {
     const double2 *tw;       // e^{-2 pi i t / Mtw}, t < Mtw / 2
     int Mtw;                 // largest power-of-two transform size used by the plan
     int Lmax;                // LDS workspace elements (double2) per workgroup
+    int twl_cap;             // LDS twiddle-table elements after the workspace (0: read twiddles from global memory)
     const int *Mof;          // [nside + 1] Bluestein size for ring length 4 q, 0 when q is a power of two
     const int64_t *woff;     // [nside + 1] offset of q's chirp (q entries)
     const int64_t *coff;     // [nside + 1] offset of q's filter spectrum (M entries)

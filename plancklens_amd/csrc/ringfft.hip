@@ -14,6 +14,8 @@
 // Bound: LDS bandwidth / HBM (the stage does O(npix log n) flops on 8 npix + 32 (mmax+1) nrings bytes).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "device_plan.h"
 #include "ringfft.h"
 
@@ -40,58 +42,171 @@ __device__ __forceinline__ double2 cispi(double t)  // e^{i pi t}
     return make_double2(c, s);
 }
 
-// forward (e^{-}) decimation-in-frequency FFT, natural order in, bit-reversed order out
-template <int NT>
-__device__ void fft_dif_fwd(double2 *a, int M, const double2 *__restrict__ tw, int Mtw)
+// ---- in-LDS power-of-two FFT, radix 8 / 4 / 2 passes done in registers ------------------------------------
+// Forward = decimation in frequency (natural order in, digit-reversed order out); inverse = the exact reverse
+// (decimation in time, digit-reversed in, natural out, unnormalised).  One __syncthreads per pass; a size-4096
+// transform is 4 passes of radix 8 instead of 12 radix-2 sweeps.
+constexpr double kSqrtHalf = 0.70710678118654752440;
+
+template <bool FWD>
+__device__ __forceinline__ double2 mul_i(double2 a)  // forward: a * (-i); inverse: a * (+i)
 {
-    for (int h = M >> 1; h >= 1; h >>= 1) {
-        __syncthreads();
-        const int tstep = Mtw / (2 * h);
-        for (int b = threadIdx.x; b < (M >> 1); b += NT) {
-            const int pos = b & (h - 1);
-            const int i0 = ((b - pos) << 1) + pos, i1 = i0 + h;
-            const double2 u = a[i0], v = a[i1];
-            const double2 w = tw[pos * tstep];
-            a[i0] = cadd(u, v);
-            a[i1] = cmul(csub(u, v), w);
+    return FWD ? make_double2(a.y, -a.x) : make_double2(-a.y, a.x);
+}
+
+template <int R, bool FWD>
+__device__ __forceinline__ void dft_small(double2 (&x)[R])
+{
+    if constexpr (R == 2) {
+        const double2 a = x[0], b = x[1];
+        x[0] = cadd(a, b); x[1] = csub(a, b);
+    } else if constexpr (R == 4) {
+        const double2 s02 = cadd(x[0], x[2]), d02 = csub(x[0], x[2]);
+        const double2 s13 = cadd(x[1], x[3]), d13 = mul_i<FWD>(csub(x[1], x[3]));
+        x[0] = cadd(s02, s13); x[2] = csub(s02, s13);
+        x[1] = cadd(d02, d13); x[3] = csub(d02, d13);
+    } else {  // R == 8
+        double2 e[4] = {x[0], x[2], x[4], x[6]}, o[4] = {x[1], x[3], x[5], x[7]};
+        dft_small<4, FWD>(e);
+        dft_small<4, FWD>(o);
+        // o_k * w8^k, w8 = e^{-+ 2 pi i / 8}
+        const double2 o1 = FWD ? make_double2((o[1].x + o[1].y) * kSqrtHalf, (o[1].y - o[1].x) * kSqrtHalf)
+                               : make_double2((o[1].x - o[1].y) * kSqrtHalf, (o[1].y + o[1].x) * kSqrtHalf);
+        const double2 o2 = mul_i<FWD>(o[2]);
+        const double2 o3 = FWD ? make_double2((o[3].y - o[3].x) * kSqrtHalf, -(o[3].x + o[3].y) * kSqrtHalf)
+                               : make_double2(-(o[3].x + o[3].y) * kSqrtHalf, (o[3].x - o[3].y) * kSqrtHalf);
+        x[0] = cadd(e[0], o[0]); x[4] = csub(e[0], o[0]);
+        x[1] = cadd(e[1], o1);   x[5] = csub(e[1], o1);
+        x[2] = cadd(e[2], o2);   x[6] = csub(e[2], o2);
+        x[3] = cadd(e[3], o3);   x[7] = csub(e[3], o3);
+    }
+}
+
+// Pass structure for size M = 2^k: radix 8 while the remaining block size allows, then one radix-4 or radix-2
+// pass (block sizes L: M, M/8, M/64, ..., tail).  Twiddles W_L^{pos}, W_L^{2 pos}, W_L^{4 pos} of every pass are
+// staged once per workgroup in LDS (`twl`, pass with the smallest L first): a global-memory twiddle fetch
+// (~500 cycles) inside every butterfly was the long pole of the passes.  twl == nullptr uses the global table.
+__device__ __forceinline__ int fft_tail_radix(int M)  // radix of the smallest-L pass
+{
+    const int k = 31 - __clz(M);
+    return (k % 3 == 0) ? 8 : (k % 3 == 2 ? 4 : 2);
+}
+__device__ __forceinline__ int fft_nk(int r) { return r == 8 ? 3 : r == 4 ? 2 : 1; }
+
+template <int NT>
+__device__ void fft_build_twl(double2 *twl, int M, const double2 *__restrict__ tw, int Mtw)
+{
+    int off = 0;
+    int r = fft_tail_radix(M);
+    for (int L = r; L <= M; L *= 8) {  // after the tail pass every pass is radix 8
+        const int s = L / r, nk = fft_nk(r), tstep = Mtw / L;
+        for (int i = threadIdx.x; i < nk * s; i += NT) {
+            const int kk = i / s, pos = i - kk * s;
+            twl[off + i] = tw[(pos << kk) * tstep];
         }
+        off += nk * s;
+        r = 8;
     }
     __syncthreads();
 }
 
-// inverse (e^{+}, unnormalised) decimation-in-time FFT, bit-reversed order in, natural order out
-template <int NT>
-__device__ void fft_dit_inv(double2 *a, int M, const double2 *__restrict__ tw, int Mtw)
+// one pass over blocks of size L (stride s = L / R); twp: this pass's LDS twiddles or nullptr
+template <int NT, int R, bool FWD>
+__device__ __forceinline__ void fft_pass(double2 *a, int M, int L, const double2 *twp, const double2 *__restrict__ tw, int Mtw)
 {
-    for (int h = 1; h < M; h <<= 1) {
-        __syncthreads();
-        const int tstep = Mtw / (2 * h);
-        for (int b = threadIdx.x; b < (M >> 1); b += NT) {
-            const int pos = b & (h - 1);
-            const int i0 = ((b - pos) << 1) + pos, i1 = i0 + h;
-            const double2 u = a[i0];
-            const double2 v = cmulc(a[i1], tw[pos * tstep]);
-            a[i0] = cadd(u, v);
-            a[i1] = csub(u, v);
+    const int s = L / R;
+    const int ls = 31 - __clz(s);
+    const int tstep = Mtw / L;
+    for (int t = threadIdx.x; t < M / R; t += NT) {
+        const int blk = t >> ls, pos = t & (s - 1);
+        double2 *p = a + blk * L + pos;
+        double2 x[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) x[j] = p[j * s];
+        double2 w[R];
+        w[0] = make_double2(1., 0.);
+        if (twp) {
+            w[1] = twp[pos];
+            if constexpr (R >= 4) { w[2] = twp[s + pos]; w[3] = cmul(w[1], w[2]); }
+            if constexpr (R == 8) { w[4] = twp[2 * s + pos]; w[5] = cmul(w[1], w[4]); w[6] = cmul(w[2], w[4]); w[7] = cmul(w[3], w[4]); }
+        } else {
+            w[1] = tw[pos * tstep];
+            if constexpr (R >= 4) { w[2] = tw[2 * pos * tstep]; w[3] = cmul(w[1], w[2]); }
+            if constexpr (R == 8) { w[4] = tw[4 * pos * tstep]; w[5] = cmul(w[1], w[4]); w[6] = cmul(w[2], w[4]); w[7] = cmul(w[3], w[4]); }
         }
+        if constexpr (FWD) {
+            dft_small<R, true>(x);
+#pragma unroll
+            for (int k = 1; k < R; ++k) x[k] = cmul(x[k], w[k]);
+        } else {
+#pragma unroll
+            for (int k = 1; k < R; ++k) x[k] = cmulc(x[k], w[k]);
+            dft_small<R, false>(x);
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) p[j * s] = x[j];
     }
+}
+
+// position of natural index f in the digit-reversed layout produced by the forward transform
+__device__ __forceinline__ int digit_reverse(int f, int M)
+{
+    const int rt = fft_tail_radix(M);
+    int p = 0, s = M;
+    while (s > rt) { s >>= 3; p += (f & 7) * s; f >>= 3; }  // radix-8 passes, largest L first
+    return p + f;                                             // tail digit has stride 1
+}
+
+template <int NT>
+__device__ void fft_dif_fwd(double2 *a, int M, const double2 *twl, const double2 *__restrict__ tw, int Mtw)
+{
+    if (M < 2) { __syncthreads(); return; }
+    const int rt = fft_tail_radix(M);
+    // LDS twiddle offset of the largest pass = total - its own size; walk downwards
+    int off = 0;
+    { int r = rt; for (int L = rt; L <= M; L *= 8) { off += fft_nk(r) * (L / r); r = 8; } }
+    for (int L = M; L > rt; L >>= 3) {
+        off -= 3 * (L / 8);
+        __syncthreads();
+        fft_pass<NT, 8, true>(a, M, L, twl ? twl + off : nullptr, tw, Mtw);
+    }
+    __syncthreads();
+    if (rt == 8) fft_pass<NT, 8, true>(a, M, 8, twl, tw, Mtw);
+    else if (rt == 4) fft_pass<NT, 4, true>(a, M, 4, twl, tw, Mtw);
+    else fft_pass<NT, 2, true>(a, M, 2, twl, tw, Mtw);
     __syncthreads();
 }
 
-__device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
-__device__ __forceinline__ int bitrev(int k, int lq) { return lq ? (int)(__brev((unsigned)k) >> (32 - lq)) : 0; }
+template <int NT>
+__device__ void fft_dit_inv(double2 *a, int M, const double2 *twl, const double2 *__restrict__ tw, int Mtw)
+{
+    if (M < 2) { __syncthreads(); return; }
+    const int rt = fft_tail_radix(M);
+    __syncthreads();
+    if (rt == 8) fft_pass<NT, 8, false>(a, M, 8, twl, tw, Mtw);
+    else if (rt == 4) fft_pass<NT, 4, false>(a, M, 4, twl, tw, Mtw);
+    else fft_pass<NT, 2, false>(a, M, 2, twl, tw, Mtw);
+    int off = fft_nk(rt) * 1;  // tail pass table: nk * (rt / rt) entries
+    for (int L = rt * 8; L <= M; L *= 8) {
+        __syncthreads();
+        fft_pass<NT, 8, false>(a, M, L, twl ? twl + off : nullptr, tw, Mtw);
+        off += 3 * (L / 8);
+    }
+    __syncthreads();
+}
 
 // In: ws[0..q) filled (Bluestein: x_k w_k, zero padded to M by the caller; direct: x at bit-reversed positions).
 // Out: ws[j] (times chirp[j] for Bluestein, applied by the caller through sub_value) = sum_k x_k e^{+2 pi i jk/q}.
 template <int NT>
-__device__ __forceinline__ void sub_dft_inverse(double2 *ws, int q, int M, const double2 *__restrict__ filt, const DevFFT &F)
+__device__ __forceinline__ void sub_dft_inverse(double2 *ws, int q, int M, const double2 *__restrict__ filt, const DevFFT &F,
+                                                const double2 *twl)
 {
     if (M) {
-        fft_dif_fwd<NT>(ws, M, F.tw, F.Mtw);
+        fft_dif_fwd<NT>(ws, M, twl, F.tw, F.Mtw);
         for (int t = threadIdx.x; t < M; t += NT) ws[t] = cmul(ws[t], filt[t]);
-        fft_dit_inv<NT>(ws, M, F.tw, F.Mtw);
+        fft_dit_inv<NT>(ws, M, twl, F.tw, F.Mtw);
     } else {
-        fft_dit_inv<NT>(ws, q, F.tw, F.Mtw);
+        fft_dit_inv<NT>(ws, q, twl, F.tw, F.Mtw);
     }
 }
 
@@ -117,7 +232,7 @@ __global__ __launch_bounds__(NT) void k_bluestein_setup(DevFFT F, const int *__r
         ws[t] = c;
         if (t > 0) ws[M - t] = c;
     }
-    fft_dif_fwd<NT>(ws, M, F.tw, F.Mtw);
+    fft_dif_fwd<NT>(ws, M, nullptr, F.tw, F.Mtw);
     const double inv = 1.0 / M;
     for (int t = threadIdx.x; t < M; t += NT) filt[t] = make_double2(ws[t].x * inv, ws[t].y * inv);
 }
@@ -134,7 +249,7 @@ __global__ void k_twiddles(double2 *tw, int Mtw)
 // -----------------------------------------------------------------------------------------------------
 template <int NT, int QMAX>
 __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int *__restrict__ mlim, int ncomp,
-                                                  const double *__restrict__ phase, double *__restrict__ map)
+                                                  const double *__restrict__ phase, double *__restrict__ map, int dbg)
 {
     extern __shared__ double2 ws[];
     const int ip = P.npairs - 1 - blockIdx.x;  // largest rings first
@@ -148,7 +263,8 @@ __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int
     const double inv_n = 1.0 / n;
     const int estride = 4 * ncomp;
     const double *__restrict__ ph = phase + (int64_t)ip * P.mstride * estride + comp * 4;
-    const int lq = ilog2(q);
+    double2 *twl = F.twl_cap ? ws + F.Lmax : nullptr;
+    if (twl) fft_build_twl<NT>(twl, M ? M : q, F.tw, F.Mtw);
 
     double2 acc[4][QMAX], e1[QMAX];
 #pragma unroll
@@ -163,9 +279,10 @@ __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int
         for (int k1 = threadIdx.x; k1 < q; k1 += NT) {
             const int k = 4 * k1 + k2;
             double zr = 0., zi = 0.;
+            if (dbg & 4) { ws[k1] = make_double2(1., 0.); continue; }
             for (int m = k; m <= ml; m += n) {  // positive frequencies aliased onto bin k
                 const double4 f = *reinterpret_cast<const double4 *>(ph + (int64_t)m * estride);
-                double2 p = shifted ? cispi(m * inv_n) : make_double2(1., 0.);
+                double2 p = (shifted && !(dbg & 1)) ? cispi(m * inv_n) : make_double2(1., 0.);
                 const double2 fn = cmul(make_double2(f.x, f.y), p), fs = cmul(make_double2(f.z, f.w), p);
                 zr += fn.x - fs.y; zi += fn.y + fs.x;  // f_N + i f_S
             }
@@ -177,9 +294,10 @@ __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int
             }
             const double2 z = make_double2(zr, zi);
             if (M) ws[k1] = cmul(z, chirp[k1]);
-            else ws[bitrev(k1, lq)] = z;
+            else ws[digit_reverse(k1, q)] = z;
         }
-        sub_dft_inverse<NT>(ws, q, M, filt, F);
+        if (!(dbg & 2)) sub_dft_inverse<NT>(ws, q, M, filt, F, twl);
+        else __syncthreads();
 #pragma unroll
         for (int qq = 0; qq < QMAX; ++qq) {
             const int j1 = threadIdx.x + NT * qq;
@@ -233,7 +351,8 @@ __global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int
     const double inv_n = 1.0 / n;
     const int estride = 4 * ncomp;
     double *__restrict__ ph = phase + (int64_t)ip * P.mstride * estride + comp * 4;
-    const int lq = ilog2(q);
+    double2 *twl = F.twl_cap ? ws + F.Lmax : nullptr;
+    if (twl) fft_build_twl<NT>(twl, M ? M : q, F.tw, F.Mtw);
     const double wgt = 0.5 * 4.0 * 3.14159265358979323846 / (double)P.npix;  // includes the 1/2 of the N/S split
     const double *__restrict__ mp = map + (int64_t)comp * P.npix;
     const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
@@ -289,10 +408,10 @@ __global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int
                 if (k2 >= 3) tw = cmul(tw, e1[qq]);
                 x = cmul(x, tw);
                 if (M) ws[j1] = cmul(x, chirp[j1]);
-                else ws[bitrev(j1, lq)] = x;
+                else ws[digit_reverse(j1, q)] = x;
             }
         }
-        sub_dft_inverse<NT>(ws, q, M, filt, F);
+        sub_dft_inverse<NT>(ws, q, M, filt, F, twl);
         // now V_{4 k1 + k2} = ws[k1] (* chirp[k1])
         if (k2 == 0 || k2 == 2) {
             for (int m = k2 + 4 * threadIdx.x; m <= ml; m += 4 * NT) {
@@ -333,7 +452,7 @@ __global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int
 // -----------------------------------------------------------------------------------------------------
 // host launchers
 // -----------------------------------------------------------------------------------------------------
-static size_t fft_lds_bytes(const DevFFT &F) { return (size_t)F.Lmax * sizeof(double2); }
+static size_t fft_lds_bytes(const DevFFT &F) { return (size_t)(F.Lmax + F.twl_cap) * sizeof(double2); }
 
 template <int NT, int QMAX>
 static hipError_t launch_p2m(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *phase, double *map,
@@ -347,7 +466,8 @@ static hipError_t launch_p2m(const DevPlan &P, const DevFFT &F, const int *mlim,
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_phase2map<NT, QMAX>), dim3(P.npairs, ncomp), dim3(NT), lds, st, P, F, mlim, ncomp, phase, map);
+    static int dbg = getenv("PLSHTS_FFTDBG") ? atoi(getenv("PLSHTS_FFTDBG")) : 0;
+    hipLaunchKernelGGL((k_phase2map<NT, QMAX>), dim3(P.npairs, ncomp), dim3(NT), lds, st, P, F, mlim, ncomp, phase, map, dbg);
     return hipGetLastError();
 }
 

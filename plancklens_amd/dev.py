@@ -31,7 +31,16 @@ def to_dev(x, dtype=None):
 
 
 def to_host(t):
-    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+    """Device tensor -> numpy array through a pinned staging tensor (PCIe at full rate; torch's host allocator
+    recycles the pinned blocks).  The returned array owns its memory (a view of a private pinned tensor)."""
+    if not isinstance(t, torch.Tensor):
+        return np.asarray(t)
+    if not t.is_cuda:
+        return t.detach().numpy()
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t.detach(), non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return h.numpy()
 
 
 def lidx(lmax):

@@ -117,6 +117,7 @@ class library(object):
                                       'ptt_bh_s', 'ptt_bh_f', 'ptt_bh_d', 'dtt_bh_p', 'stt_bh_p', 'ftt_bh_d', 'p_bh_s']
         self.keys_remaps = {'s': 'stt'}
         self._mem = {}
+        self._last_dev = None  # device tensors (G, C) of the most recent MV evaluation
 
     def hashdict(self):
         return {'f2map1': self.f2map1.hashdict(), 'f2map2': self.f2map2.hashdict()}
@@ -197,6 +198,8 @@ class library(object):
                 self._build_sim_xfiltMVgclm(idx, k)
             else:
                 assert 0, k
+        if not self.cache and lmax == self.get_lmax_qlm(k):
+            return self._load(k, idx)  # in-memory mode: the stored array is handed over as is
         return ut.alm_copy(self._load(k, idx), lmax=lmax)
 
     def get_dat_qlm(self, k, **kwargs):
@@ -270,7 +273,8 @@ class library(object):
         xf1, xf2 = (xfilt2, xfilt1) if swapped else (xfilt1, xfilt2)
         repmap, impmap = f2map1.get_irespmap(idx, xfilt=xf1)
         Gs, Cs = f2map2.get_gpmap(idx, 3, k=k, xfilt=xf2)
-        dre, dim = torch.empty_like(repmap), torch.empty_like(repmap)
+        d = torch.empty((2, repmap.numel()), dtype=torch.float64, device=repmap.device)
+        dre, dim = d[0], d[1]
         dev.map_cmul(repmap, impmap, -1., Gs, Cs, +1., +1., dre, dim, False)
         Gs, Cs = f2map2.get_gpmap(idx, 1, k=k, xfilt=xf2)
         dev.map_cmul(repmap, impmap, +1., Gs, Cs, -1., -1., dre, dim, True)
@@ -305,6 +309,7 @@ class library(object):
         dim += ct
         del gt, ct
         G, C = self._gc_from_product(dre, dim, 'P')
+        self._last_dev = (G, C)
         return dev.to_host(G), dev.to_host(C)
 
     def _scalar_from_product(self, prod, fac, lmax_key):
@@ -527,7 +532,7 @@ class lib_filt2map_sepTP(lib_filt2map):
             if xfilt is not None:
                 telm = dev.almxfl(telm, xfilt['e'])
             mlik = telm if mlik is None else mlik + telm
-        if mlik is None or not bool(torch.any(mlik != 0)):
+        if mlik is None or (xfilt is not None and not bool(torch.any(mlik != 0))):
             return self._zeros()
         lmax = self._lmax(mlik)
         return shts.alm2map_spin([mlik, torch.zeros_like(mlik)], self.nside, 1, lmax, fl=_lens_weight(lmax))
@@ -549,7 +554,7 @@ class lib_filt2map_sepTP(lib_filt2map):
             if xfilt is not None:
                 G_t = dev.almxfl(G_t, xfilt['t'])
             G = G_t if G is None else G + G_t
-        if G is None or not (bool(torch.any(G != 0)) or (C is not None and bool(torch.any(C != 0)))):
+        if G is None or (xfilt is not None and not (bool(torch.any(G != 0)) or (C is not None and bool(torch.any(C != 0))))):
             return self._zeros()
         if C is None:
             C = torch.zeros_like(G)

@@ -154,7 +154,12 @@ def _stack(pair):
     if _is_dev(pair):
         return pair
     if _is_dev(pair[0]):
-        return torch.stack([pair[0], pair[1]])
+        a, b = pair[0], pair[1]
+        base = a._base
+        if (base is not None and base is b._base and base.dim() == 2 and base.shape[0] == 2 and base.is_contiguous()
+                and a.data_ptr() == base.data_ptr() and b.data_ptr() == base[1].data_ptr() and a.numel() == base.shape[1]):
+            return base  # the two halves of one (2, n) tensor (what alm2map_spin / map2alm_spin return): no copy
+        return torch.stack([a, b])
     return np.stack([np.asarray(pair[0]), np.asarray(pair[1])])
 
 
