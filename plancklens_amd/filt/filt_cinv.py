@@ -1,0 +1,298 @@
+"""Conjugate-gradient (anisotropic noise / masked sky) CMB filtering on the MI355X, API of
+plancklens/filt/filt_cinv.py (`cinv` :22-53, `cinv_t` :56-203, `cinv_p` :206-338, `library_cinv_sepTP` :515-580).
+
+Same multigrid chains, rescalings, side files (ftl.dat, fel.dat, fbl.dat, tal.dat, fmask.fits.gz, filt_hash.pk) and
+stopping rule as the reference; the solve itself (plancklens_amd.qcinv) runs with every vector, map and SHT in HBM.
+The joint T+P filter (cinv_tp, opfilt_tp) is not part of this round."""
+from __future__ import print_function
+
+import os
+import pickle as pk
+
+import numpy as np
+import torch
+
+from .. import dev, hp, utils
+from ..helpers import mpi
+from ..qcinv import cd_solve, multigrid, opfilt_pp, opfilt_tt, util, util_alm
+from . import filt_simple
+
+
+class cinv(object):
+    def __init__(self, lib_dir, lmax):
+        self.lib_dir = lib_dir
+        self.lmax = lmax
+
+    def _load(self, name, lmax):
+        if lmax is None:
+            lmax = self.lmax
+        ret = np.loadtxt(os.path.join(self.lib_dir, name))
+        assert len(ret) > lmax, (len(ret), lmax)
+        return ret[:lmax + 1]
+
+    def get_tal(self, a, lmax=None):
+        assert a.lower() in ['t', 'e', 'b'], a
+        return self._load("tal.dat", lmax)
+
+    def get_fmask(self):
+        return hp.read_map(os.path.join(self.lib_dir, "fmask.fits.gz"))
+
+    def get_ftl(self, lmax=None):
+        return self._load("ftl.dat", lmax)
+
+    def get_fel(self, lmax=None):
+        return self._load("fel.dat", lmax)
+
+    def get_fbl(self, lmax=None):
+        return self._load("fbl.dat", lmax)
+
+    def _setup_dir(self, files):
+        """rank 0 writes the side files, everybody waits, then the hash is checked (filt_cinv.py:121-139)."""
+        if mpi.rank == 0:
+            if not os.path.exists(self.lib_dir):
+                os.makedirs(self.lib_dir)
+            fn_hash = os.path.join(self.lib_dir, "filt_hash.pk")
+            if not os.path.exists(fn_hash):
+                pk.dump(self.hashdict(), open(fn_hash, 'wb'), protocol=2)
+            for name, make in files:
+                if not os.path.exists(os.path.join(self.lib_dir, name)):
+                    make(os.path.join(self.lib_dir, name))
+        mpi.barrier()
+        fn_hash = os.path.join(self.lib_dir, "filt_hash.pk")
+        utils.hash_check(pk.load(open(fn_hash, 'rb')), self.hashdict(), fn=fn_hash)
+
+
+def _nlev_uKamin(ninv):
+    """Effective white-noise level of an inverse-variance map over its unmasked pixels."""
+    npix = ninv.numel()
+    nz = int((ninv != 0.0).sum())
+    return np.sqrt(4. * np.pi / npix / float(ninv.sum()) * nz) * 180. * 60. / np.pi
+
+
+class cinv_t(cinv):
+    r"""Temperature-only inverse-variance filter  :math:`\bar T = S^{-1}(S^{-1} + B^tY^tN^{-1}YB)^{-1}B^tY^tN^{-1} d`.
+
+        Args as the reference: lib_dir, lmax, nside, cl (dict with 'tt'), transf, ninv (list of maps / paths whose
+        product is the inverse pixel variance), rescal_cl ('default': D_l modes are solved for), marge_monopole,
+        marge_dipole, marge_maps, pcf (dense preconditioner cache), chain_descr.
+    """
+
+    def __init__(self, lib_dir, lmax, nside, cl, transf, ninv, rescal_cl='default', marge_monopole=True, marge_dipole=True,
+                 marge_maps=(), pcf='default', chain_descr=None):
+        assert lib_dir is not None and lmax >= 1024 and nside >= 512, (lib_dir, lmax, nside)
+        assert isinstance(ninv, list)
+        super(cinv_t, self).__init__(lib_dir, lmax)
+        if rescal_cl in ['default', None]:
+            default_rescal = True
+            rescal_cl = np.sqrt(np.arange(lmax + 1, dtype=float) * np.arange(1, lmax + 2, dtype=float) / 2. / np.pi)
+        else:
+            default_rescal = False
+            assert len(rescal_cl) >= lmax + 1, [rescal_cl.shape, lmax]
+        dl = {k: rescal_cl[:lmax + 1] ** 2 * cl[k][:lmax + 1] for k in cl.keys()}
+        transf_dl = transf[:lmax + 1] * utils.cli(rescal_cl)
+        self.nside = nside
+        self.cl = cl
+        self.dl = dl
+        self.transf = transf[:lmax + 1]
+        self.rescaled_transf = transf_dl
+        self.rescal_cl = rescal_cl
+        self.default_rescal = default_rescal
+        self.ninv = ninv
+        self.marge_monopole = marge_monopole
+        self.marge_dipole = marge_dipole
+        self.marge_maps = marge_maps
+        pcf = os.path.join(lib_dir, "dense.pk") if pcf == 'default' else ''
+        if chain_descr is None:
+            chain_descr = \
+                [[3, ["split(dense(" + pcf + "), 64, diag_cl)"], 256, 128, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
+                 [2, ["split(stage(3),  256, diag_cl)"], 512, 256, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
+                 [1, ["split(stage(2),  512, diag_cl)"], 1024, 512, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
+                 [0, ["split(stage(1), 1024, diag_cl)"], lmax, nside, np.inf, 1.0e-5, cd_solve.tr_cg, cd_solve.cache_mem()]]
+        n_inv_filt = util.jit(opfilt_tt.alm_filter_ninv, ninv, transf_dl, marge_monopole=marge_monopole,
+                              marge_dipole=marge_dipole, marge_maps=marge_maps)
+        self.chain_descr = chain_descr
+        self.chain = util.jit(multigrid.multigrid_chain, opfilt_tt, self.chain_descr, dl, n_inv_filt)
+        self._setup_dir([("ftl.dat", lambda fn: np.savetxt(fn, self._calc_ftl())),
+                         ("tal.dat", lambda fn: np.savetxt(fn, self._calc_tal())),
+                         ("fmask.fits.gz", lambda fn: hp.write_map(fn, self._calc_mask()))])
+
+    def _ninv_hash(self):
+        return [utils.clhash(c) if (isinstance(c, np.ndarray) and c.size > 1) else c for c in self.ninv]
+
+    def _calc_ftl(self):
+        ninv = self.chain.n_inv_filt.n_inv
+        nlev = _nlev_uKamin(ninv)
+        print("cinv_t::noiseT_uk_arcmin = %.3f" % nlev)
+        s_cls, b_transf = self.cl, self.transf
+        if s_cls['tt'][0] == 0.:
+            assert self.chain.n_inv_filt.marge_monopole
+        if s_cls['tt'][1] == 0.:
+            assert self.chain.n_inv_filt.marge_dipole
+        ftl = utils.cli(s_cls['tt'][0:self.lmax + 1] + (nlev * np.pi / 180. / 60.) ** 2 * utils.cli(b_transf[0:self.lmax + 1] ** 2))
+        if self.chain.n_inv_filt.marge_monopole:
+            ftl[0] = 0.0
+        if self.chain.n_inv_filt.marge_dipole:
+            ftl[1] = 0.0
+        return ftl
+
+    def _calc_tal(self):
+        return utils.cli(self.transf)
+
+    def _calc_mask(self):
+        ninv = self.chain.n_inv_filt.n_inv
+        assert hp.npix2nside(ninv.numel()) == self.nside
+        return dev.to_host((ninv > 0).to(torch.float64))
+
+    def hashdict(self):
+        hd = {'lmax': self.lmax, 'nside': self.nside, 'cltt': utils.clhash(self.cl['tt'][:self.lmax + 1]),
+              'transf': utils.clhash(self.transf[:self.lmax + 1]), 'ninv': self._ninv_hash(),
+              'marge_monopole': self.marge_monopole, 'marge_dipole': self.marge_dipole, 'marge_maps': self.marge_maps}
+        if self.default_rescal is False:
+            hd['rescal_cl'] = utils.clhash(self.rescal_cl)
+        return hd
+
+    def apply_ivf(self, tmap, soltn=None):
+        """Inverse-variance filtered temperature alm of the map (numpy in -> numpy out, device tensor -> device tensor)."""
+        on_dev = isinstance(tmap, torch.Tensor)
+        if soltn is None:
+            talm = torch.zeros(hp.Alm.getsize(self.lmax), dtype=torch.complex128, device=dev.device())
+        else:
+            talm = dev.to_dev(soltn, torch.complex128).clone()
+        self.chain.solve(talm, tmap)
+        talm = dev.almxfl(talm, self.rescal_cl)
+        return talm if on_dev else dev.to_host(talm)
+
+
+class cinv_p(cinv):
+    r"""Polarization-only inverse-variance filter (E, B); ninv is a list of 1 (QQ = UU) or 3 (QQ, QU, UU) entries,
+    each itself a list of maps / paths to multiply."""
+
+    def __init__(self, lib_dir, lmax, nside, cl, transf, ninv, pcf='default', chain_descr=None, transf_blm=None,
+                 marge_qmaps=(), marge_umaps=()):
+        assert lib_dir is not None and lmax >= 1024 and nside >= 512, (lib_dir, lmax, nside)
+        super(cinv_p, self).__init__(lib_dir, lmax)
+        self.nside = nside
+        self.cl = cl
+        self.transf_e = transf
+        self.transf_b = transf if transf_blm is None else transf_blm
+        self.transf = transf if transf_blm is None else 0.5 * self.transf_e + 0.5 * self.transf_b
+        self.ninv = ninv
+        pcf = os.path.join(lib_dir, "dense.pk") if pcf == 'default' else None
+        if chain_descr is None:
+            chain_descr = \
+                [[2, ["split(dense(%s), 32, diag_cl)" % pcf], 512, 256, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
+                 [1, ["split(stage(2),  512, diag_cl)"], 1024, 512, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
+                 [0, ["split(stage(1), 1024, diag_cl)"], lmax, nside, np.inf, 1.0e-5, cd_solve.tr_cg, cd_solve.cache_mem()]]
+        n_inv_filt = util.jit(opfilt_pp.alm_filter_ninv, ninv, transf[0:lmax + 1], b_transf_b=transf_blm,
+                              marge_umaps=marge_umaps, marge_qmaps=marge_qmaps)
+        self.chain_descr = chain_descr
+        self.chain = util.jit(multigrid.multigrid_chain, opfilt_pp, chain_descr, cl, n_inv_filt)
+
+        def _write_febl(fn):
+            fel, fbl = self._calc_febl()
+            np.savetxt(os.path.join(self.lib_dir, "fel.dat"), fel)
+            np.savetxt(fn, fbl)
+        self._setup_dir([("fbl.dat", _write_febl), ("tal.dat", lambda fn: np.savetxt(fn, self._calc_tal())),
+                         ("fmask.fits.gz", lambda fn: hp.write_map(fn, self._calc_mask()))])
+
+    def hashdict(self):
+        return {'lmax': self.lmax, 'nside': self.nside, 'clee': utils.clhash(self.cl.get('ee', np.array([0.]))),
+                'cleb': utils.clhash(self.cl.get('eb', np.array([0.]))), 'clbb': utils.clhash(self.cl.get('bb', np.array([0.]))),
+                'transf': utils.clhash(self.transf), 'ninv': self._ninv_hash()}
+
+    def _ninv_hash(self):
+        return [[utils.clhash(c) if (isinstance(c, np.ndarray) and c.size > 1) else c for c in self.ninv[0]]]
+
+    def apply_ivf(self, tmap, soltn=None):
+        assert len(tmap) == 2
+        on_dev = isinstance(tmap[0], torch.Tensor)
+        n = hp.Alm.getsize(self.lmax)
+        if soltn is not None:
+            assert len(soltn) == 2 and hp.Alm.getlmax(np.size(soltn[0])) == self.lmax
+            talm = util_alm.eblm([dev.to_dev(soltn[0], torch.complex128).clone(), dev.to_dev(soltn[1], torch.complex128).clone()])
+        else:
+            talm = util_alm.eblm([torch.zeros(n, dtype=torch.complex128, device=dev.device()),
+                                  torch.zeros(n, dtype=torch.complex128, device=dev.device())])
+        self.chain.solve(talm, [tmap[0], tmap[1]])
+        if on_dev:
+            return talm.elm, talm.blm
+        return dev.to_host(talm.elm), dev.to_host(talm.blm)
+
+    def _calc_febl(self):
+        assert 'eb' not in self.chain.s_cls.keys()
+        ninv = self.chain.n_inv_filt.get_ninv()
+        if len(ninv) == 1:
+            nlev = _nlev_uKamin(ninv[0])
+        else:
+            assert len(ninv) == 3
+            nlev = 0.5 * _nlev_uKamin(ninv[0]) + 0.5 * _nlev_uKamin(ninv[2])
+        print("cinv_p::noiseP_uk_arcmin = %.3f" % nlev)
+        s_cls = self.chain.s_cls
+        b_e, b_b = self.chain.n_inv_filt.b_transf_e, self.chain.n_inv_filt.b_transf_b
+        fel = utils.cli(s_cls['ee'][:self.lmax + 1] + (nlev * np.pi / 180. / 60.) ** 2 * utils.cli(b_e[0:self.lmax + 1] ** 2))
+        fbl = utils.cli(s_cls['bb'][:self.lmax + 1] + (nlev * np.pi / 180. / 60.) ** 2 * utils.cli(b_b[0:self.lmax + 1] ** 2))
+        fel[0:2] *= 0.0
+        fbl[0:2] *= 0.0
+        return fel, fbl
+
+    def _calc_tal(self):
+        return utils.cli(self.transf)
+
+    def _calc_mask(self):
+        mask = np.ones(hp.nside2npix(self.nside), dtype=float)
+        for ninv in self.chain.n_inv_filt.get_ninv():
+            assert hp.npix2nside(ninv.numel()) == self.nside
+            mask *= dev.to_host((ninv > 0.).to(torch.float64))
+        return mask
+
+
+class library_cinv_sepTP(filt_simple.library_sepTP):
+    """Filters a simulation library with separate temperature and polarization CG filters (filt_cinv.py:515-580)."""
+
+    def __init__(self, lib_dir, sim_lib, cinvt, cinvp, cl_weights, soltn_lib=None):
+        self.cinv_t = cinvt
+        self.cinv_p = cinvp
+        super(library_cinv_sepTP, self).__init__(lib_dir, sim_lib, cl_weights, soltn_lib=soltn_lib)
+        if mpi.rank == 0:
+            fname_mask = os.path.join(self.lib_dir, "fmask.fits.gz")
+            if not os.path.exists(fname_mask):
+                fmask = self.cinv_t.get_fmask()
+                assert np.all(fmask == self.cinv_p.get_fmask())
+                hp.write_map(fname_mask, fmask)
+        mpi.barrier()
+        fn = os.path.join(lib_dir, "filt_hash.pk")
+        utils.hash_check(pk.load(open(fn, 'rb')), self.hashdict(), fn=fn)
+
+    def hashdict(self):
+        return {'cinv_t': self.cinv_t.hashdict(), 'cinv_p': self.cinv_p.hashdict(), 'sim_lib': self.sim_lib.hashdict()}
+
+    def get_fmask(self):
+        return hp.read_map(os.path.join(self.lib_dir, "fmask.fits.gz"))
+
+    def get_tal(self, a, lmax=None):
+        assert a.lower() in ['t', 'e', 'b'], a
+        return self.cinv_t.get_tal(a, lmax=lmax) if a.lower() == 't' else self.cinv_p.get_tal(a, lmax=lmax)
+
+    def get_ftl(self, lmax=None):
+        return self.cinv_t.get_ftl(lmax=lmax)
+
+    def get_fel(self, lmax=None):
+        return self.cinv_p.get_fel(lmax=lmax)
+
+    def get_fbl(self, lmax=None):
+        return self.cinv_p.get_fbl(lmax=lmax)
+
+    def _apply_ivf_t(self, tmap, soltn=None):
+        return self.cinv_t.apply_ivf(tmap, soltn=soltn)
+
+    def _apply_ivf_p(self, pmap, soltn=None):
+        return self.cinv_p.apply_ivf(pmap, soltn=soltn)
+
+    def get_tmliklm(self, idx):
+        return hp.almxfl(self.get_sim_tlm(idx), self.cinv_t.cl['tt'])
+
+    def get_emliklm(self, idx):
+        return hp.almxfl(self.get_sim_elm(idx), self.cinv_p.cl['ee'])
+
+    def get_bmliklm(self, idx):
+        return hp.almxfl(self.get_sim_blm(idx), self.cinv_p.cl['bb'])

@@ -2,6 +2,7 @@
 healpy write_alm / read_alm (columns index = l^2 + l + m + 1, real, imag) and write_map / read_map.
 No astropy / healpy is available, so the FITS standard (80-char cards, 2880-byte blocks, big-endian data)
 is written directly.  Files written here are readable by healpy and vice versa for these two layouts."""
+import gzip
 import os
 
 import numpy as np
@@ -62,7 +63,7 @@ def write_bintable(fname, columns, extname='xtension', extra=(), overwrite=True)
         cards.append(_card(k, v))
     data = rec.tobytes()
     tmp = fname + '.tmp%d' % os.getpid()
-    with open(tmp, 'wb') as f:
+    with (gzip.open(tmp, 'wb') if fname.endswith('.gz') else open(tmp, 'wb')) as f:
         f.write(prim)
         f.write(_header(cards))
         f.write(data)
@@ -100,19 +101,19 @@ def _read_header(f):
 
 def read_bintable(fname, hdu=1):
     """Returns (dict name -> array, header dict) of binary-table extension number `hdu`."""
-    with open(fname, 'rb') as f:
+    with (gzip.open(fname, 'rb') if fname.endswith('.gz') else open(fname, 'rb')) as f:
         hdr = _read_header(f)  # primary
         nbytes = abs(hdr.get('BITPIX', 8)) // 8
         if hdr.get('NAXIS', 0) > 0:
             n = 1
             for i in range(hdr['NAXIS']):
                 n *= hdr['NAXIS%d' % (i + 1)]
-            f.seek((n * nbytes + _BLOCK - 1) // _BLOCK * _BLOCK, 1)
+            f.read((n * nbytes + _BLOCK - 1) // _BLOCK * _BLOCK)
         for ih in range(1, hdu + 1):
             hdr = _read_header(f)
             size = hdr['NAXIS1'] * hdr['NAXIS2'] + hdr.get('PCOUNT', 0)
             if ih < hdu:
-                f.seek((size + _BLOCK - 1) // _BLOCK * _BLOCK, 1)
+                f.read((size + _BLOCK - 1) // _BLOCK * _BLOCK)
         fields = []
         for i in range(1, hdr['TFIELDS'] + 1):
             tf = str(hdr['TFORM%d' % i]).strip()

@@ -1,0 +1,77 @@
+"""Flexible conjugate-directions solver, API and algorithm of plancklens/qcinv/cd_solve.py (`cd_solve` :35-107,
+`cache_mem` :15-32, `tr_cg` / `tr_cd` / `PTR` :7-12).  The vectors are opaque objects supporting + - * += -=
+(numpy arrays, device tensors, eblm / teblm); all arithmetic on them happens wherever they live."""
+import numpy as np
+
+
+def PTR(p, t, r):
+    return lambda i: max(0, i - max(p, int(min(t, np.mod(i, r)))))
+
+
+tr_cg = (lambda i: i - 1)
+tr_cd = (lambda i: 0)
+
+
+class cache_mem(dict):
+    """In-memory store of the search directions of past iterations."""
+
+    def __init__(self):
+        dict.__init__(self)
+
+    def store(self, key, data):
+        dTAd_inv, searchdirs, searchfwds = data
+        self[key] = [dTAd_inv, searchdirs, searchfwds]
+
+    def restore(self, key):
+        return self[key]
+
+    def remove(self, key):
+        del self[key]
+
+    def trim(self, keys):
+        assert set(keys).issubset(self.keys())
+        for key in set(self.keys()) - set(keys):
+            del self[key]
+
+
+def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=25):
+    """Solves fwd_op(x) = b in place on x by preconditioned conjugate directions; returns the iteration count.
+
+        fwd_op, the pre_ops and dot_op must not modify their arguments.  `tr` selects how many past search
+        directions each new one is orthogonalised against (tr_cg: the last one).  The residual is recomputed
+        from scratch every `roundoff` iterations.
+    """
+    if cache is None:
+        cache = cache_mem()
+    n_pre = len(pre_ops)
+    residual = b - fwd_op(x)
+    searchdirs = [op(residual) for op in pre_ops]
+    it = 0
+    while not criterion(it, x, residual):
+        searchfwds = [fwd_op(d) for d in searchdirs]
+        deltas = [dot_op(d, residual) for d in searchdirs]
+        dTAd = np.zeros((n_pre, n_pre))
+        for i1 in range(n_pre):
+            for i2 in range(i1 + 1):
+                dTAd[i1, i2] = dTAd[i2, i1] = dot_op(searchdirs[i1], searchfwds[i2])
+        dTAd_inv = np.linalg.inv(dTAd)
+        alphas = np.dot(dTAd_inv, deltas)
+        for d, alpha in zip(searchdirs, alphas):
+            x += d * alpha
+        cache.store(it, [dTAd_inv, searchdirs, searchfwds])
+        it += 1
+        if np.mod(it, roundoff) == 0:
+            residual = b - fwd_op(x)
+        else:
+            for q, alpha in zip(searchfwds, alphas):
+                residual -= q * alpha
+        searchdirs = [op(residual) for op in pre_ops]
+        for titer in range(tr(it), it):
+            prev_dTAd_inv, prev_dirs, prev_fwds = cache.restore(titer)
+            for d in searchdirs:
+                proj = [dot_op(d, pq) for pq in prev_fwds]
+                betas = np.dot(prev_dTAd_inv, proj)
+                for beta, pd in zip(betas, prev_dirs):
+                    d -= pd * beta
+        cache.trim(range(tr(it + 1), it))
+    return it

@@ -1,0 +1,177 @@
+"""Dense low-l preconditioners, API of plancklens/qcinv/dense.py (`alm2rlm` / `rlm2alm` :16-54, `pre_op_dense_tt`
+:57-119, `pre_op_dense_pp` :123-202).  The (lmax+1)^2 k square matrix is filled by applying the coarse fwd_op to unit
+vectors (device SHTs), pseudo-inverted on the host with eigh exactly as the reference does, and applied as a device
+mat-vec."""
+from __future__ import print_function
+
+import os
+import pickle as pk
+
+import numpy as np
+import torch
+
+from .. import dev
+from ..hp import Alm
+from .util_alm import eblm
+
+_RLM_IDX = {}
+
+
+def _rlm_maps(lmax):
+    """Index maps between the complex alm layout and the 'real harmonic' layout rlm[l^2 + 2m - 1 | 2m]."""
+    if lmax not in _RLM_IDX:
+        ls = np.arange(lmax + 1)
+        re_alm, re_rlm, im_alm, im_rlm = [ls.copy()], [ls ** 2], [], []
+        for m in range(1, lmax + 1):
+            a = m * (2 * lmax + 1 - m) // 2 + ls[m:]
+            re_alm.append(a); re_rlm.append(ls[m:] ** 2 + 2 * m - 1)
+            im_alm.append(a); im_rlm.append(ls[m:] ** 2 + 2 * m)
+        cat = lambda x: np.concatenate(x) if len(x) else np.zeros(0, dtype=int)
+        _RLM_IDX[lmax] = (cat(re_alm), cat(re_rlm), cat(im_alm), cat(im_rlm))
+    return _RLM_IDX[lmax]
+
+
+def alm2rlm(alm):
+    """Complex alm -> real harmonic coefficients (m = 0 real part; sqrt(2) Re, sqrt(2) Im for m > 0)."""
+    is_dev = isinstance(alm, torch.Tensor)
+    n = alm.numel() if is_dev else alm.size
+    lmax = Alm.getlmax(n)
+    ra, rr, ia, ir = _rlm_maps(lmax)
+    rt2 = np.sqrt(2.)
+    if is_dev:
+        d = alm.device
+        rlm = torch.zeros((lmax + 1) ** 2, dtype=torch.float64, device=d)
+        w = torch.full((ra.size,), rt2, dtype=torch.float64, device=d)
+        w[:lmax + 1] = 1.
+        rlm[torch.from_numpy(rr).to(d)] = alm.real[torch.from_numpy(ra).to(d)] * w
+        rlm[torch.from_numpy(ir).to(d)] = alm.imag[torch.from_numpy(ia).to(d)] * rt2
+        return rlm
+    rlm = np.zeros((lmax + 1) ** 2)
+    w = np.full(ra.size, rt2)
+    w[:lmax + 1] = 1.
+    rlm[rr] = alm.real[ra] * w
+    rlm[ir] = alm.imag[ia] * rt2
+    return rlm
+
+
+def rlm2alm(rlm):
+    """Inverse of alm2rlm."""
+    is_dev = isinstance(rlm, torch.Tensor)
+    n = rlm.numel() if is_dev else len(rlm)
+    lmax = int(np.sqrt(n) - 1)
+    assert (lmax + 1) ** 2 == n
+    ra, rr, ia, ir = _rlm_maps(lmax)
+    ir2 = 1.0 / np.sqrt(2.)
+    if is_dev:
+        d = rlm.device
+        re = torch.zeros(Alm.getsize(lmax), dtype=torch.float64, device=d)
+        im = torch.zeros_like(re)
+        w = torch.full((ra.size,), ir2, dtype=torch.float64, device=d)
+        w[:lmax + 1] = 1.
+        re[torch.from_numpy(ra).to(d)] = rlm[torch.from_numpy(rr).to(d)] * w
+        im[torch.from_numpy(ia).to(d)] = rlm[torch.from_numpy(ir).to(d)] * ir2
+        return torch.complex(re, im)
+    alm = np.zeros(Alm.getsize(lmax), dtype=complex)
+    w = np.full(ra.size, ir2)
+    w[:lmax + 1] = 1.
+    alm.real[ra] = rlm[rr] * w
+    alm.imag[ia] = rlm[ir] * ir2
+    return alm
+
+
+class _pre_op_dense(object):
+    """Shared machinery: brute-force matrix, eigen pseudo-inverse with `ntmpl` lowest modes left untouched, cache."""
+
+    def __init__(self, lmax, fwd_op, cache_fname=None):
+        self.lmax = lmax
+        minv = None
+        if cache_fname is not None and os.path.exists(cache_fname):
+            cache_lmax, cache_hashdict, cache_minv = pk.load(open(cache_fname, 'rb'))
+            if lmax == cache_lmax and self.hashdict(lmax, fwd_op) == cache_hashdict:
+                minv = cache_minv
+            else:
+                print("WARNING: PRE_OP_DENSE CACHE: hashcheck failed. recomputing.")
+                os.remove(cache_fname)
+        if minv is None:
+            minv = self.compute_minv(lmax, fwd_op, cache_fname=cache_fname)
+        self.minv = dev.to_dev(minv, torch.float64)
+
+    def _ntmpl(self, fwd_op):
+        assert 0, 'override this'
+
+    def _nrlm(self, lmax):
+        assert 0, 'override this'
+
+    def _to_rlm(self, alm):
+        assert 0, 'override this'
+
+    def _to_alm(self, rlm):
+        assert 0, 'override this'
+
+    def compute_minv(self, lmax, fwd_op, cache_fname=None):
+        if cache_fname is not None:
+            assert not os.path.exists(cache_fname)
+        nrlm = self._nrlm(lmax)
+        ntmpl = self._ntmpl(fwd_op)
+        print("computing dense preconditioner: lmax = %d, ntmpl = %d, size %d" % (lmax, ntmpl, nrlm))
+        tmat = torch.zeros((nrlm, nrlm), dtype=torch.float64, device=dev.device())
+        trlm = torch.zeros(nrlm, dtype=torch.float64, device=dev.device())
+        for i in range(nrlm):
+            trlm[i] = 1.0
+            tmat[:, i] = self._to_rlm(fwd_op(self._to_alm(trlm)))
+            trlm[i] = 0.0
+        eigv, eigw = np.linalg.eigh(dev.to_host(tmat))
+        assert np.all(eigv[ntmpl:] > 0.)
+        eigv_inv = np.zeros_like(eigv)
+        eigv_inv[ntmpl:] = 1.0 / eigv[ntmpl:]
+        if ntmpl > 0:  # the ntmpl lowest eigenmodes (marginalised templates) are left untouched
+            eigv_inv[0:ntmpl] = 1.0
+        minv = np.dot(np.dot(eigw, np.diag(eigv_inv)), np.transpose(eigw))
+        if cache_fname is not None:
+            pk.dump([lmax, self.hashdict(lmax, fwd_op), minv], open(cache_fname, 'wb'))
+        return minv
+
+    @staticmethod
+    def hashdict(lmax, fwd_op):
+        return {'lmax': lmax, 'fwd_op': fwd_op.hashdict()}
+
+    def __call__(self, talm):
+        return self.calc(talm)
+
+    def calc(self, talm):
+        return self._to_alm(torch.mv(self.minv, self._to_rlm(talm)))
+
+
+class pre_op_dense_tt(_pre_op_dense):
+    def _ntmpl(self, fwd_op):
+        return int(sum(t.nmodes for t in fwd_op.n_inv_filt.templates))
+
+    def _nrlm(self, lmax):
+        return (lmax + 1) ** 2
+
+    def _to_rlm(self, alm):
+        return alm2rlm(alm)
+
+    def _to_alm(self, rlm):
+        return rlm2alm(rlm)
+
+
+pre_op_dense_kk = pre_op_dense_tt
+
+
+class pre_op_dense_pp(_pre_op_dense):
+    def _ntmpl(self, fwd_op):
+        ntmpl = 0
+        for t in (getattr(fwd_op.n_inv_filt, 'templates_p', None) or []):
+            ntmpl += t.nmodes
+        return ntmpl + 8  # (1 mono + 3 dip) * (e + b): the l < 2 modes that do not exist in polarization
+
+    def _nrlm(self, lmax):
+        return 2 * (lmax + 1) ** 2
+
+    def _to_rlm(self, alm):
+        return torch.cat([alm2rlm(alm.elm), alm2rlm(alm.blm)])
+
+    def _to_alm(self, rlm):
+        n = rlm.numel() // 2
+        return eblm([rlm2alm(rlm[:n]), rlm2alm(rlm[n:])])

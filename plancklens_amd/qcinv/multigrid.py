@@ -1,0 +1,164 @@
+"""Multigrid-preconditioned CG chains, API of plancklens/qcinv/multigrid.py (`multigrid_chain` :25-111,
+`parse_pre_op_descr` :113-160, `pre_op_split` :163-182, `pre_op_multigrid` :185-215).
+
+A chain is a list of stages [id, pre_ops_descr, lmax, nside, iter_max, eps_min, tr, cache]; the descriptors are the
+reference's mini-language: "split(<low>, lsplit, <high>)", "diag_cl", "dense(<cache file>)", "stage(<id>)".
+All vectors handed between the stages stay on the device."""
+from __future__ import print_function
+
+import copy
+import re
+import sys
+
+import numpy as np
+
+from . import cd_monitors, cd_solve, util, util_alm
+
+
+class multigrid_stage(object):
+    def __init__(self, ids, pre_ops_descr, lmax, nside, iter_max, eps_min, tr, cache):
+        self.depth = ids
+        self.pre_ops_descr = pre_ops_descr
+        self.lmax = lmax
+        self.nside = nside
+        self.iter_max = iter_max
+        self.eps_min = eps_min
+        self.tr = tr
+        self.cache = cache
+        self.pre_ops = []
+
+
+class multigrid_chain(object):
+    def __init__(self, opfilt, chain_descr, s_cls, n_inv_filt, debug_log_prefix=None, plogdepth=0):
+        self.debug_log_prefix = debug_log_prefix
+        self.plogdepth = plogdepth
+        self.opfilt = opfilt
+        self.chain_descr = chain_descr
+        self.s_cls = s_cls
+        self.n_inv_filt = n_inv_filt
+        stages = {}
+        for [sid, pre_ops_descr, lmax, nside, iter_max, eps_min, tr, cache] in self.chain_descr:
+            stages[sid] = multigrid_stage(sid, pre_ops_descr, lmax, nside, iter_max, eps_min, tr, cache)
+            for descr in pre_ops_descr:  # coarser stages were parsed before and are reachable through `stages`
+                stages[sid].pre_ops.append(parse_pre_op_descr(descr, opfilt=self.opfilt, s_cls=self.s_cls,
+                                                              n_inv_filt=self.n_inv_filt, stages=stages, lmax=lmax,
+                                                              nside=nside, chain=self))
+        self.bstage = stages[0]
+        self.iter_tot = 0
+        self.watch = util.stopwatch()
+        self.prev_eps = None
+
+    def solve(self, soltn, tpn_map, apply_fini='', dot_op=None):
+        """Solves in place for `soltn` given the data map(s); finishes with opfilt.apply_fini (S^-1 x)."""
+        assert hasattr(self.opfilt, 'apply_fini%s' % apply_fini)
+        finifunc = getattr(self.opfilt, 'apply_fini%s' % apply_fini)
+        self.watch = util.stopwatch()
+        self.iter_tot = 0
+        self.prev_eps = None
+        if dot_op is None:
+            dot_op = self.opfilt.dot_op()
+        logger = (lambda iter, eps, stage=self.bstage, **kwargs: self.log(stage, iter, eps, **kwargs))
+        tpn_alm = self.opfilt.calc_prep(tpn_map, self.s_cls, self.n_inv_filt)
+        monitor = cd_monitors.monitor_basic(dot_op, logger=logger, iter_max=self.bstage.iter_max,
+                                            eps_min=self.bstage.eps_min, d0=dot_op(tpn_alm, tpn_alm))
+        fwd_op = self.opfilt.fwd_op(self.s_cls, self.n_inv_filt)
+        self.last_iters = cd_solve.cd_solve(soltn, tpn_alm, fwd_op, self.bstage.pre_ops, dot_op, monitor,
+                                            tr=self.bstage.tr, cache=self.bstage.cache)
+        finifunc(soltn, self.s_cls, self.n_inv_filt)
+
+    def log(self, stage, iter, eps, **kwargs):
+        self.iter_tot += 1
+        elapsed = self.watch.elapsed()
+        if stage.depth > self.plogdepth:
+            return
+        log_str = '   ' * stage.depth + '(%4d, %04d) [%s] (%d, %.8f)' % (stage.nside, stage.lmax, str(elapsed), iter, eps) + '\n'
+        sys.stdout.write(log_str)
+        if self.debug_log_prefix is not None:
+            with open(self.debug_log_prefix + 'stage_all.dat', 'a') as f:
+                f.write(log_str)
+            if stage.depth == 0:
+                from .. import dev
+                s = kwargs['soltn']
+                np.save(self.debug_log_prefix + 'stage_soltn_%d_%04d.npy' % (stage.depth, iter),
+                        dev.to_host(s) if not hasattr(s, 'elm') else np.array([dev.to_host(s.elm), dev.to_host(s.blm)]))
+            with open(self.debug_log_prefix + 'stage_%d.dat' % stage.depth, 'a') as f:
+                f.write('%05d %05d %10.6e %05d %s\n' % (self.iter_tot, int(elapsed), eps, iter, str(elapsed)))
+
+
+def parse_pre_op_descr(pre_op_descr, **kwargs):
+    m = re.match(r"split\((.*),\s*(.*),\s*(.*)\)\Z", pre_op_descr)
+    if m:
+        low_descr, lsplit, hgh_descr = m.groups()
+        lsplit = int(lsplit)
+        kwargs_low = copy.copy(kwargs)
+        kwargs_low['lmax'] = lsplit
+        kwargs_hgh = copy.copy(kwargs)
+        kwargs_hgh['lmin'] = lsplit + 1
+        return pre_op_split(lsplit, kwargs['lmax'], parse_pre_op_descr(low_descr, **kwargs_low),
+                            parse_pre_op_descr(hgh_descr, **kwargs_hgh))
+    if re.match(r"diag_cl\Z", pre_op_descr):
+        return kwargs['opfilt'].pre_op_diag(kwargs['s_cls'], kwargs['n_inv_filt'])
+    m = re.match(r"dense(\((.*)\))?\Z", pre_op_descr)
+    if m:
+        cache_fname = m.group(2)
+        if cache_fname in ('', 'None'):
+            cache_fname = None
+        print('creating dense preconditioner. (nside = %d, lmax = %d, cache = %s)' % (kwargs['nside'], kwargs['lmax'], cache_fname))
+        fwd_op = kwargs['opfilt'].fwd_op(kwargs['s_cls'], kwargs['n_inv_filt'].degrade(kwargs['nside']))
+        return kwargs['opfilt'].pre_op_dense(kwargs['lmax'], fwd_op, cache_fname=cache_fname)
+    m = re.match(r"stage\((.*)\)\Z", pre_op_descr)
+    if m:
+        stage = kwargs['stages'][int(m.group(1))]
+        logger = (lambda iter, eps, stage=stage, chain=kwargs['chain'], **kw: chain.log(stage, iter, eps, **kw))
+        assert stage.lmax == kwargs['lmax']
+        return pre_op_multigrid(kwargs['opfilt'], stage.lmax, stage.nside, kwargs['s_cls'],
+                                kwargs['n_inv_filt'].degrade(stage.nside), stage.pre_ops, logger, stage.tr, stage.cache,
+                                stage.iter_max, stage.eps_min)
+    assert 0, 'pre_op_descr ' + pre_op_descr + ' is unrecognized!'
+
+
+class pre_op_split(object):
+    """Low multipoles (l <= lsplit) through one preconditioner, the rest through another."""
+
+    def __init__(self, lsplit, lmax, pre_op_low, pre_op_hgh):
+        self.lsplit = lsplit
+        self.lmax = lmax
+        self.pre_op_low = pre_op_low
+        self.pre_op_hgh = pre_op_hgh
+        self.iter = 0
+
+    def __call__(self, talm):
+        return self.calc(talm)
+
+    def calc(self, talm):
+        self.iter += 1
+        talm_low = self.pre_op_low(util_alm.alm_copy(talm, lmax=self.lsplit))
+        talm_hgh = self.pre_op_hgh(util_alm.alm_copy(talm, lmax=self.lmax))
+        return util_alm.alm_splice(talm_low, talm_hgh, self.lsplit)
+
+
+class pre_op_multigrid(object):
+    """A few CG iterations at a coarser (nside, lmax) as preconditioner."""
+
+    def __init__(self, opfilt, lmax, nside, s_cls, n_inv_filt, pre_ops, logger, tr, cache, iter_max, eps_min):
+        self.opfilt = opfilt
+        self.fwd_op = opfilt.fwd_op(s_cls, n_inv_filt)
+        self.lmax = lmax
+        self.nside = nside
+        self.s_cls = s_cls
+        self.pre_ops = pre_ops
+        self.logger = logger
+        self.tr = tr
+        self.cache = cache
+        self.iter_max = iter_max
+        self.eps_min = eps_min
+
+    def __call__(self, talm):
+        return self.calc(talm)
+
+    def calc(self, talm):
+        monitor = cd_monitors.monitor_basic(self.opfilt.dot_op(), iter_max=self.iter_max, eps_min=self.eps_min, logger=self.logger)
+        soltn = talm * 0.0
+        cd_solve.cd_solve(soltn, util_alm.alm_copy(talm, lmax=self.lmax), self.fwd_op, self.pre_ops, self.opfilt.dot_op(),
+                          monitor, tr=self.tr, cache=self.cache)
+        return util_alm.alm_splice(soltn, talm, self.lmax)

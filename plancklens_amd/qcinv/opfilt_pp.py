@@ -1,0 +1,266 @@
+"""Polarization Wiener / inverse-variance filtering operators on the device, API of plancklens/qcinv/opfilt_pp.py
+(`dot_op` :27-34, `fwd_op` :37-55, `pre_op_diag` :57-80, `alm_filter_sinv` :87-110, `alm_filter_ninv` :113-303,
+`calc_prep` :306-317, `apply_fini` :320-324).  Vectors are util_alm.eblm pairs of device tensors."""
+from __future__ import print_function
+
+import numpy as np
+import torch
+
+from .. import dev, hp, shts
+from ..utils import clhash
+from . import dense, template_removal, util
+from .util_alm import eblm
+
+alm2map_spin, map2alm_spin = shts.alm2map_spin, shts.map2alm_spin
+
+
+class dot_op(object):
+    """sum_{l >= 2} (2l + 1) (C_l^{EE'} + C_l^{BB'})."""
+
+    def __call__(self, alm1, alm2):
+        assert alm1.lmax == alm2.lmax
+        tcl = dev.alm2cl(alm1.elm, alm2.elm) + dev.alm2cl(alm1.blm, alm2.blm)
+        w = 2. * np.arange(alm1.lmax + 1) + 1.
+        w[:2] = 0.
+        return float(torch.dot(tcl, dev.fl_dev(w, alm1.lmax)))
+
+
+class fwd_op(object):
+    def __init__(self, s_cls, n_inv_filt):
+        lmax = len(n_inv_filt.b_transf) - 1
+        self.s_inv_filt = alm_filter_sinv(s_cls, lmax)
+        self.n_inv_filt = n_inv_filt
+
+    def hashdict(self):
+        return {'s_inv_filt': self.s_inv_filt.hashdict(), 'n_inv_filt': self.n_inv_filt.hashdict()}
+
+    def __call__(self, alm):
+        return self.calc(alm)
+
+    def calc(self, alm):
+        nlm = alm * 1.0
+        self.n_inv_filt.apply_alm(nlm)
+        return nlm + self.s_inv_filt.calc(alm)
+
+
+def _apply_2x2(tmat, alm):
+    """(E, B) <- per-l 2x2 matrix applied to (E, B); off-diagonal terms skipped when they vanish identically."""
+    relm, rblm = dev.almxfl(alm.elm, tmat[:, 0, 0]), dev.almxfl(alm.blm, tmat[:, 1, 1])
+    if np.any(tmat[:, 0, 1]):
+        relm = relm + dev.almxfl(alm.blm, tmat[:, 0, 1])
+    if np.any(tmat[:, 1, 0]):
+        rblm = rblm + dev.almxfl(alm.elm, tmat[:, 1, 0])
+    return eblm([relm, rblm])
+
+
+class pre_op_diag(object):
+    def __init__(self, s_cls, n_inv_filt):
+        lmax = len(n_inv_filt.b_transf) - 1
+        s_inv_filt = alm_filter_sinv(s_cls, lmax)
+        assert (s_inv_filt.lmax + 1) >= len(n_inv_filt.b_transf)
+        ninv_fel, ninv_fbl = n_inv_filt.get_febl()
+        flmat = s_inv_filt.slinv.copy()
+        flmat[:, 0, 0] += ninv_fel[:lmax + 1]
+        flmat[:, 1, 1] += ninv_fbl[:lmax + 1]
+        self.flmat = np.linalg.pinv(flmat)
+
+    def __call__(self, talm):
+        return self.calc(talm)
+
+    def calc(self, alm):
+        return _apply_2x2(self.flmat, alm)
+
+
+def pre_op_dense(lmax, fwd_op, cache_fname=None):
+    return dense.pre_op_dense_pp(lmax, fwd_op, cache_fname=cache_fname)
+
+
+class alm_filter_sinv(object):
+    """S^-1: per-l pseudo-inverse of the (EE, EB; EB, BB) spectral matrix."""
+
+    def __init__(self, s_cls, lmax):
+        slmat = np.zeros((lmax + 1, 2, 2))
+        slmat[:, 0, 0] = s_cls.get('ee', np.zeros(lmax + 1))[:lmax + 1]
+        slmat[:, 0, 1] = s_cls.get('eb', np.zeros(lmax + 1))[:lmax + 1]
+        slmat[:, 1, 0] = s_cls.get('eb', np.zeros(lmax + 1))[:lmax + 1]
+        slmat[:, 1, 1] = s_cls.get('bb', np.zeros(lmax + 1))[:lmax + 1]
+        self.lmax = lmax
+        self.slinv = np.linalg.pinv(slmat)
+
+    def calc(self, alm):
+        return _apply_2x2(self.slinv, alm)
+
+    def hashdict(self):
+        return {'slinv': clhash(self.slinv.flatten())}
+
+
+class alm_filter_ninv(object):
+    """Pixel-space inverse noise for (Q, U): one map (QQ = UU, QU = 0) or three (QQ, QU, UU); optional Q / U templates."""
+
+    def __init__(self, n_inv, b_transf, nlev_febl=None, b_transf_b=None, marge_qmaps=(), marge_umaps=()):
+        self.b_transf_e = b_transf
+        self.b_transf_b = b_transf_b if b_transf_b is not None else b_transf
+        self.b_transf = 0.5 * (self.b_transf_e + self.b_transf_b)
+        self.nside = None
+        self.n_inv = None
+        self.nlev_febl = nlev_febl
+        self._n_inv = n_inv
+        self.marge_qmaps = marge_qmaps
+        self.marge_umaps = marge_umaps
+        self.wmarg = max(len(self.marge_qmaps), len(self.marge_umaps)) > 0
+        self.tniti = None
+        self.templates_p = []
+
+    def _load_ninv(self):
+        if self.n_inv is None:
+            self.n_inv = [dev.to_dev(util.read_map(tn), torch.float64) for tn in self._n_inv]
+            assert len(self.n_inv) in [1, 3], len(self.n_inv)
+            self.nside = hp.npix2nside(self.n_inv[0].numel())
+
+    def _build_tniti(self):
+        if not self.wmarg or self.tniti is not None:
+            return
+        blocks = []
+        for im, marge_m in enumerate((self.marge_qmaps, self.marge_umaps)):
+            if len(marge_m) == 0:
+                continue
+            this_n_inv = self.get_ninv()
+            assert len(this_n_inv) == 1, 'QQ QU UU not implemented'
+            templates = [_template_pmap(m, im) for m in marge_m]
+            nmodes = len(templates)
+            mat = np.zeros((nmodes, nmodes))
+            for ir in range(nmodes):
+                w = this_n_inv[0] * templates[ir].map
+                for ic in range(ir + 1):
+                    mat[ir, ic] = mat[ic, ir] = float(torch.dot(templates[ic].map, w))
+            eigv, eigw = np.linalg.eigh(mat)
+            blocks.append(np.dot(np.dot(eigw, np.diag(1.0 / eigv)), eigw.T))
+            self.templates_p = self.templates_p + templates
+        if blocks:
+            n = sum(b.shape[0] for b in blocks)
+            self.tniti = np.zeros((n, n))
+            i = 0
+            for b in blocks:
+                self.tniti[i:i + b.shape[0], i:i + b.shape[0]] = b
+                i += b.shape[0]
+
+    def _calc_febl(self):
+        self._load_ninv()
+        if len(self.n_inv) == 1:
+            s = float(self.n_inv[0].sum())
+        else:
+            s = float((0.5 * (self.n_inv[0] + self.n_inv[2])).sum())
+        nlev_febl = 10800. / np.sqrt(s / (4.0 * np.pi)) / np.pi
+        print("ninv_febl: using %.2f uK-amin noise Cl" % nlev_febl)
+        return nlev_febl
+
+    def get_ninv(self):
+        self._load_ninv()
+        return self.n_inv
+
+    def get_mask(self):
+        ninv = self.get_ninv()
+        mask = (ninv[0] > 0).to(torch.float64)
+        for ni in ninv[1:]:
+            mask *= (ni > 0)
+        return dev.to_host(mask)
+
+    def get_febl(self):
+        if self.nlev_febl is None:
+            self.nlev_febl = self._calc_febl()
+        f = 1. / (self.nlev_febl / 180. / 60. * np.pi) ** 2
+        return self.b_transf_e ** 2 * f, self.b_transf_b ** 2 * f
+
+    def hashdict(self):
+        t_hash = []
+        if self.wmarg:
+            t_hash = [util.mask_hash(m, dtype=np.float32) for m in self.marge_qmaps] + \
+                     [util.mask_hash(m, dtype=np.float32) for m in self.marge_umaps]
+        return {'n_inv': [util.mask_hash(n, dtype=np.float16) for n in self._n_inv], 'b_transf': clhash(self.b_transf),
+                'templates_p': t_hash}
+
+    def degrade(self, nside):
+        self._load_ninv()
+        if nside == self.nside:
+            return self
+        return alm_filter_ninv([hp.ud_grade(dev.to_host(n), nside, power=-2) for n in self.n_inv], self.b_transf_e,
+                               b_transf_b=self.b_transf_b)
+
+    def apply_alm(self, alm):
+        """(E, B) <- B^t Y^t N^-1 Y B (E, B), in place."""
+        self._load_ninv()
+        lmax = alm.lmax
+        same_b = self.b_transf_b is self.b_transf_e or np.array_equal(self.b_transf_e, self.b_transf_b)
+        if same_b:
+            qmap, umap = alm2map_spin([alm.elm, alm.blm], self.nside, 2, lmax, fl=self.b_transf_e)
+        else:
+            qmap, umap = alm2map_spin([dev.almxfl(alm.elm, self.b_transf_e), dev.almxfl(alm.blm, self.b_transf_b)], self.nside, 2, lmax)
+        self.apply_map([qmap, umap])
+        npix = qmap.numel()
+        if same_b:
+            telm, tblm = map2alm_spin([qmap, umap], 2, lmax=lmax, fl=self.b_transf_e * (npix / (4. * np.pi)))
+        else:
+            telm, tblm = map2alm_spin([qmap, umap], 2, lmax=lmax)
+            telm = dev.almxfl(telm, self.b_transf_e * (npix / (4. * np.pi)))
+            tblm = dev.almxfl(tblm, self.b_transf_b * (npix / (4. * np.pi)))
+        alm.elm.copy_(telm)
+        alm.blm.copy_(tblm)
+
+    def apply_map(self, amap):
+        """(Q, U) <- N^-1 (Q, U) in place."""
+        self._load_ninv()
+        qmap, umap = amap
+        if len(self.n_inv) == 1:
+            qmap *= self.n_inv[0]
+            umap *= self.n_inv[0]
+            if self.wmarg:
+                self._build_tniti()
+                coeffs = np.concatenate([t.dot([qmap, umap]) for t in self.templates_p])
+                coeffs = np.dot(self.tniti, coeffs)
+                pmodes = [torch.zeros_like(qmap), torch.zeros_like(umap)]
+                for t, c in zip(self.templates_p, coeffs):
+                    t.accum(pmodes, [c])
+                pmodes[0] *= self.n_inv[0]
+                pmodes[1] *= self.n_inv[0]
+                qmap -= pmodes[0]
+                umap -= pmodes[1]
+        elif len(self.n_inv) == 3:
+            qcopy = qmap.clone()
+            qmap *= self.n_inv[0]
+            qmap += self.n_inv[1] * umap
+            umap *= self.n_inv[2]
+            umap += self.n_inv[1] * qcopy
+        else:
+            assert 0
+
+
+class _template_pmap(object):
+    """A Q-only (comp 0) or U-only (comp 1) template map (template_removal.py template_qmap / template_umap)."""
+
+    def __init__(self, tmap, comp):
+        self.nmodes = 1
+        self.comp = comp
+        self.map = dev.to_dev(util.read_map(tmap), torch.float64)
+
+    def accum(self, pmap, coeffs):
+        pmap[self.comp] += self.map * float(coeffs[0])
+
+    def dot(self, pmap):
+        return [float(torch.dot(self.map, pmap[self.comp]))]
+
+
+def calc_prep(maps, s_cls, n_inv_filt):
+    qmap = dev.to_dev(util.read_map(maps[0]), torch.float64).clone()
+    umap = dev.to_dev(util.read_map(maps[1]), torch.float64).clone()
+    assert qmap.numel() == umap.numel()
+    lmax = len(n_inv_filt.b_transf) - 1
+    npix = qmap.numel()
+    n_inv_filt.apply_map([qmap, umap])
+    elm, blm = map2alm_spin([qmap, umap], 2, lmax=lmax)
+    return eblm([dev.almxfl(elm, n_inv_filt.b_transf_e * npix / (4. * np.pi)), dev.almxfl(blm, n_inv_filt.b_transf_b * npix / (4. * np.pi))])
+
+
+def apply_fini(alm, s_cls, n_inv_filt):
+    ret = alm_filter_sinv(s_cls, alm.lmax).calc(alm)
+    alm.elm.copy_(ret.elm)
+    alm.blm.copy_(ret.blm)

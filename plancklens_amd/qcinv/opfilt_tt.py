@@ -1,0 +1,178 @@
+"""Temperature Wiener / inverse-variance filtering operators on the device, API of plancklens/qcinv/opfilt_tt.py
+(`calc_prep` :30-36, `apply_fini` :39-41, `dot_op` :43-51, `fwd_op` :54-73, `pre_op_diag` :76-93, `alm_filter_ninv`
+:99-205).  The CG solves  [S^-1 + B^t Y^t N^-1 Y B] x = B^t Y^t N^-1 d  and returns S^-1 x.
+
+Y = alm2map and Y^t = (npix / 4 pi) map2alm run on the GPU (plancklens_amd.shts); the beam factors are fused into the
+transforms; the inverse-noise map, the template projector and every CG vector live in HBM."""
+from __future__ import print_function
+
+import hashlib
+
+import numpy as np
+import torch
+
+from .. import dev, hp, shts
+from ..utils import clhash, enumerate_progress
+from . import dense, template_removal, util
+
+alm2map, map2alm = shts.alm2map, shts.map2alm  # exported so that they can be customised, as in the reference
+
+
+def _cli(cl):
+    ret = np.zeros_like(cl)
+    ret[np.where(cl != 0.)] = 1. / cl[np.where(cl != 0.)]
+    return ret
+
+
+def calc_prep(m, s_cls, n_inv_filt):
+    """b = B^t Y^t N^-1 d."""
+    tmap = dev.to_dev(m, torch.float64).clone()
+    n_inv_filt.apply_map(tmap)
+    lmax = len(n_inv_filt.b_transf) - 1
+    return map2alm(tmap, lmax=lmax, iter=0, fl=n_inv_filt.b_transf * (tmap.numel() / (4. * np.pi)))
+
+
+def apply_fini(alm, s_cls, n_inv_filt):
+    """Wiener-filtered solution -> inverse-variance filtered: x <- S^-1 x (in place)."""
+    alm.copy_(dev.almxfl(alm, _cli(s_cls['tt'])))
+
+
+class dot_op(object):
+    """sum_l (2l + 1) C_l^{ab}: the scalar product of the CG (opfilt_tt.py:43-51)."""
+
+    def __call__(self, alm1, alm2):
+        lmax1 = hp.Alm.getlmax(alm1.numel())
+        assert lmax1 == hp.Alm.getlmax(alm2.numel())
+        w = dev.fl_dev(2. * np.arange(lmax1 + 1) + 1., lmax1)
+        return float(torch.dot(dev.alm2cl(alm1, alm2), w))
+
+
+class fwd_op(object):
+    """x -> S^-1 x + B^t Y^t N^-1 Y B x."""
+
+    def __init__(self, s_cls, n_inv_filt):
+        self.cltt_inv = _cli(s_cls['tt'])
+        self.n_inv_filt = n_inv_filt
+
+    def hashdict(self):
+        return {'cltt_inv': clhash(self.cltt_inv), 'n_inv_filt': self.n_inv_filt.hashdict()}
+
+    def __call__(self, talm):
+        return self.calc(talm)
+
+    def calc(self, talm):
+        if not bool(torch.any(talm != 0)):  # nothing to do on zeros (starting point of the nested solves)
+            return talm
+        alm = talm.clone()
+        self.n_inv_filt.apply_alm(alm)
+        alm += dev.almxfl(talm, self.cltt_inv)
+        return alm
+
+
+class pre_op_diag(object):
+    """Harmonic-space diagonal preconditioner 1 / (1 / C_l + b_l^2 sum(N^-1) / 4 pi)."""
+
+    def __init__(self, s_cls, n_inv_filt):
+        cltt = s_cls['tt']
+        assert len(cltt) >= len(n_inv_filt.b_transf)
+        n_inv_cl = float(n_inv_filt.n_inv.sum()) / (4.0 * np.pi)
+        lmax = len(n_inv_filt.b_transf) - 1
+        filt = _cli(cltt[:lmax + 1])
+        filt += n_inv_cl * n_inv_filt.b_transf[:lmax + 1] ** 2
+        self.filt = _cli(filt)
+
+    def __call__(self, talm):
+        return self.calc(talm)
+
+    def calc(self, talm):
+        return dev.almxfl(talm, self.filt)
+
+
+def pre_op_dense(lmax, fwd_op, cache_fname=None):
+    return dense.pre_op_dense_tt(lmax, fwd_op, cache_fname=cache_fname)
+
+
+class alm_filter_ninv(object):
+    """N^-1 in pixel space (product of the listed maps), with optional marginalisation of monopole, dipole and
+    arbitrary template maps: N^-1 <- N^-1 - N^-1 P (P^t N^-1 P)^-1 P^t N^-1."""
+
+    def __init__(self, n_inv, b_transf, marge_monopole=False, marge_dipole=False, marge_uptolmin=-1, marge_maps=(), nlev_ftl=None):
+        n_inv = util.load_map(n_inv)
+        self.n_inv = dev.to_dev(n_inv, torch.float64)
+        nz = self.n_inv[self.n_inv != 0.0]
+        print("opfilt_tt: inverse noise map std dev / av = %.3e" % (float(nz.std(unbiased=False)) / float(nz.mean())))
+        templates, templates_hash = [], []
+        for tmap in [util.load_map(m) for m in marge_maps]:
+            assert len(n_inv) == len(tmap)
+            templates.append(template_removal.template_map(tmap))
+            templates_hash.append(hashlib.sha1(np.ascontiguousarray(tmap).view(np.uint8)).hexdigest())
+        assert marge_uptolmin < 0, 'marge_uptolmin not implemented'
+        if marge_monopole:
+            templates.append(template_removal.template_monopole())
+        if marge_dipole:
+            templates.append(template_removal.template_dipole())
+        if len(templates) != 0:
+            nmodes = int(np.sum([t.nmodes for t in templates]))
+            modes_idx_t = np.concatenate([t.nmodes * [int(im)] for im, t in enumerate(templates)])
+            modes_idx_i = np.concatenate([range(0, t.nmodes) for t in templates])
+            Pt_Nn1_P = np.zeros((nmodes, nmodes))
+            for ir in range(nmodes):
+                tmap = self.n_inv.clone()
+                templates[modes_idx_t[ir]].apply_mode(tmap, int(modes_idx_i[ir]))
+                ic = 0
+                for tc in templates[0:modes_idx_t[ir] + 1]:
+                    Pt_Nn1_P[ir, ic:(ic + tc.nmodes)] = tc.dot(tmap)
+                    Pt_Nn1_P[ic:(ic + tc.nmodes), ir] = Pt_Nn1_P[ir, ic:(ic + tc.nmodes)]
+                    ic += tc.nmodes
+            eigv, eigw = np.linalg.eigh(Pt_Nn1_P)
+            self.Pt_Nn1_P_inv = np.dot(np.dot(eigw, np.diag(1.0 / eigv)), np.transpose(eigw))
+        self.b_transf = b_transf
+        self.npix = self.n_inv.numel()
+        self.nside = hp.npix2nside(self.npix)
+        self.marge_monopole = marge_monopole
+        self.marge_dipole = marge_dipole
+        self.marge_uptolmin = marge_uptolmin
+        self.templates = templates
+        self.templates_hash = templates_hash
+        if nlev_ftl is None:
+            nlev_ftl = 10800. / np.sqrt(float(self.n_inv.sum()) / (4.0 * np.pi)) / np.pi
+        self.nlev_ftl = nlev_ftl
+        print("ninv_ftl: using %.2f uK-amin noise Cl" % self.nlev_ftl)
+
+    def hashdict(self):
+        return {'n_inv': clhash(dev.to_host(self.n_inv)), 'b_transf': clhash(self.b_transf),
+                'marge_monopole': self.marge_monopole, 'marge_dipole': self.marge_dipole,
+                'templates_hash': self.templates_hash, 'marge_uptolmin': self.marge_uptolmin}
+
+    def get_ftl(self):
+        return self.b_transf ** 2 / (self.nlev_ftl / 60. / 180. * np.pi) ** 2
+
+    def degrade(self, nside):
+        """Coarser copy: hp.ud_grade(power=-2) sums the inverse variances of the children; template maps are dropped."""
+        if nside == self.nside:
+            return self
+        print("DEGRADING WITH NO MARGE MAPS")
+        return alm_filter_ninv(hp.ud_grade(dev.to_host(self.n_inv), nside, power=-2), self.b_transf,
+                               marge_monopole=self.marge_monopole, marge_dipole=self.marge_dipole,
+                               marge_uptolmin=self.marge_uptolmin, marge_maps=[])
+
+    def apply_alm(self, alm):
+        """alm <- B^t Y^t N^-1 Y B alm (in place)."""
+        lmax = hp.Alm.getlmax(alm.numel())
+        tmap = alm2map(alm, self.nside, lmax=lmax, fl=self.b_transf)
+        self.apply_map(tmap)
+        alm.copy_(map2alm(tmap, lmax=lmax, iter=0, fl=self.b_transf * (self.npix / (4. * np.pi))))
+
+    def apply_map(self, tmap):
+        """tmap <- N^-1 tmap with the templates projected out (in place)."""
+        tmap *= self.n_inv
+        if len(self.templates) != 0:
+            coeffs = np.concatenate([t.dot(tmap) for t in self.templates])
+            coeffs = np.dot(self.Pt_Nn1_P_inv, coeffs)
+            pmodes = torch.zeros_like(tmap)
+            im = 0
+            for t in self.templates:
+                t.accum(pmodes, coeffs[im:(im + t.nmodes)])
+                im += t.nmodes
+            pmodes *= self.n_inv
+            tmap -= pmodes

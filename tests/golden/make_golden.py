@@ -138,10 +138,70 @@ def main():
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     np.savez_compressed(os.path.join(HERE, 'qe_golden.npz'), **out)
+    make_cg_golden()
     print('wrote qe_golden.npz with %d arrays' % len(out))
     for k in ['ptt', 'p_p', 'p']:
         d = np.abs(out['gen_%s_G' % k] - out['dd_%s_0' % k]).max() / np.abs(out['dd_%s_0' % k]).max()
         print('reference route agreement (library vs eval_qe) %s: %.2e' % (k, d))
+
+
+def make_cg_golden():
+    """Reference multigrid CG (qcinv.multigrid_chain + opfilt_tt / opfilt_pp + dense + template_removal) on a masked,
+    inhomogeneous-noise sky at nside 16: solutions after a fixed number of iterations and the residual trace."""
+    from plancklens.qcinv import multigrid, opfilt_tt, opfilt_pp, cd_solve, util_alm
+    nside, lmax = 16, 32
+    npix = 12 * nside ** 2
+    rng = np.random.default_rng(77)
+    ell = np.arange(lmax + 1.)
+    cl = {'tt': np.where(ell >= 2, 3e3 / np.maximum(ell, 1.) ** 2.2, 0.), 'ee': np.where(ell >= 2, 60. / np.maximum(ell, 1.) ** 1.8, 0.),
+          'bb': np.where(ell >= 2, 2. / np.maximum(ell, 1.) ** 1.5, 0.)}
+    transf = myhp.gauss_beam(6. / 180. * np.pi, lmax=lmax)
+    th, ph = myhp.pix2ang(nside)
+    mask = (np.abs(np.cos(th)) > 0.25).astype(float)                         # galactic-like band removed
+    ninv_t = mask * (0.5 + 0.4 * np.sin(3 * ph) * np.sin(th)) / 40. ** 2 * (npix / (4 * np.pi)) * 1e-4
+    ninv_p = mask * (0.6 + 0.3 * np.cos(2 * ph)) / 10. ** 2 * (npix / (4 * np.pi)) * 1e-4
+    tmap = so.alm2map(myhp.almxfl(myhp.synalm(cl['tt'], lmax, rng), transf), nside) + rng.standard_normal(npix) * 40.
+    e, b = myhp.synalm(cl['ee'], lmax, rng), myhp.synalm(cl['bb'], lmax, rng)
+    q, u = so.alm2map_spin([myhp.almxfl(e, transf), myhp.almxfl(b, transf)], nside, 2, lmax)
+    qmap, umap = q + rng.standard_normal(npix) * 10., u + rng.standard_normal(npix) * 10.
+    out = {'nside': nside, 'lmax': lmax, 'transf': transf, 'ninv_t': ninv_t, 'ninv_p': ninv_p, 'tmap': tmap, 'qmap': qmap,
+           'umap': umap, 'cl_tt': cl['tt'], 'cl_ee': cl['ee'], 'cl_bb': cl['bb']}
+    trace = []
+
+    def chain_descr(niter, dense_lmax):
+        return [[1, ["split(dense(), %d, diag_cl)" % dense_lmax], 16, 8, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
+                [0, ["split(stage(1), 16, diag_cl)"], lmax, nside, niter, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()]]
+
+    # temperature, monopole + dipole marginalised
+    n_inv_filt = opfilt_tt.alm_filter_ninv(ninv_t, transf, marge_monopole=True, marge_dipole=True)
+    chain = multigrid.multigrid_chain(opfilt_tt, chain_descr(6, 6), cl, n_inv_filt)
+    orig_log = chain.log
+    chain.log = lambda stage, it, eps, **kw: (trace.append((stage.depth, it, eps)), orig_log(stage, it, eps, **kw))
+    talm = np.zeros(so.alm_size(lmax), dtype=complex)
+    chain.solve(talm, tmap)
+    out['cg_tlm'] = talm
+    out['cg_t_trace'] = np.array([t[2] for t in trace if t[0] == 0])
+    out['cg_t_prep'] = opfilt_tt.calc_prep(tmap, cl, n_inv_filt)
+    x = myhp.synalm(cl['tt'], lmax, rng)
+    out['cg_t_x'] = x
+    out['cg_t_fwd'] = opfilt_tt.fwd_op(cl, n_inv_filt)(x)
+    out['cg_t_diag'] = opfilt_tt.pre_op_diag(cl, n_inv_filt)(x)
+    # polarization
+    del trace[:]
+    n_inv_filt_p = opfilt_pp.alm_filter_ninv([ninv_p], transf)
+    chain_p = multigrid.multigrid_chain(opfilt_pp, chain_descr(5, 5), cl, n_inv_filt_p)
+    orig_log_p = chain_p.log
+    chain_p.log = lambda stage, it, eps, **kw: (trace.append((stage.depth, it, eps)), orig_log_p(stage, it, eps, **kw))
+    palm = util_alm.eblm([np.zeros(so.alm_size(lmax), dtype=complex), np.zeros(so.alm_size(lmax), dtype=complex)])
+    chain_p.solve(palm, [qmap, umap])
+    out['cg_elm'], out['cg_blm'] = palm.elm, palm.blm
+    out['cg_p_trace'] = np.array([t[2] for t in trace if t[0] == 0])
+    xe = util_alm.eblm([myhp.synalm(cl['ee'], lmax, rng), myhp.synalm(cl['bb'], lmax, rng)])
+    out['cg_p_xe'], out['cg_p_xb'] = xe.elm, xe.blm
+    f = opfilt_pp.fwd_op(cl, n_inv_filt_p)(xe)
+    out['cg_p_fwd_e'], out['cg_p_fwd_b'] = f.elm, f.blm
+    np.savez_compressed(os.path.join(HERE, 'cg_golden.npz'), **out)
+    print('wrote cg_golden.npz; T residual trace', out['cg_t_trace'], 'P', out['cg_p_trace'])
 
 
 if __name__ == '__main__':
