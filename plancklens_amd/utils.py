@@ -102,3 +102,43 @@ def camb_clfile(fname, lmax=None):
             cls[k] = np.zeros(lmax + 1)
             cls[k][ell[sel]] = cols[5 + i][sel] / wk
     return cls
+
+
+class stats(object):
+    """Running mean / covariance over simulations (utils.py:181-260, the part qecl uses)."""
+
+    def __init__(self, size, xcoord=None, docov=True):
+        self.N = 0
+        self.size = size
+        self.sum = np.zeros(self.size)
+        if docov:
+            self.mom = np.zeros((self.size, self.size))
+        self.xcoord = xcoord
+        self.docov = docov
+
+    def add(self, v):
+        assert v.shape == (self.size,), "input not understood"
+        self.sum += v
+        if self.docov:
+            self.mom += np.outer(v, v)
+        self.N += 1
+
+    def mean(self):
+        assert self.N > 0
+        return self.sum / float(self.N)
+
+    avg = mean
+
+    def cov(self):
+        assert self.docov and self.N > 0
+        if self.N == 1:
+            return np.zeros((self.size, self.size))
+        mean = self.mean()
+        return self.mom / (self.N - 1.) - self.N / (self.N - 1.) * np.outer(mean, mean)
+
+    def sigmas(self):
+        return np.sqrt(np.diagonal(self.cov()))
+
+    def sigmas_on_mean(self):
+        assert self.N > 0
+        return self.sigmas() / np.sqrt(self.N)

@@ -105,3 +105,23 @@ def test_mv_vs_oracle_chain_medium_size(oracle):
         ivfs = filt_simple.library_fullsky_sepTP(os.path.join(tmp, 'i'), sims(), nside, transf, cl, fl, fl, fl, cache=False)
         ql = qest.library_sepTP(os.path.join(tmp, 'q'), ivfs, ivfs, cl['te'], nside, lmax_qlm=lmax, cache=False)
         assert relrms(ql.get_sim_qlm('p', 0), Go) < TOL and relrms(ql.get_sim_qlm('x', 0), Co) < TOL
+
+
+@pytest.mark.parametrize('key', ['ptt', 'p_p', 'p'])
+def test_generic_route_eval_qe_vs_reference(setup, key):
+    """qest.eval_qe (qresp.get_qes + utils_qe.qe_eval on the GPU) against the reference's eval_qe outputs."""
+    from plancklens_amd import qest
+    g, ivfs, cl = setup[0], setup[1], setup[4]
+    get_alm = lambda a: {'t': ivfs.get_sim_tlm, 'e': ivfs.get_sim_elm, 'b': ivfs.get_sim_blm}[a](0)
+    G, C = qest.eval_qe(key, int(g['lmax_ivf']), cl, get_alm, int(g['nside']), int(g['lmax_qlm']), verbose=False)
+    assert relrms(G, g['gen_%s_G' % key]) < TOL and relrms(C, g['gen_%s_C' % key]) < TOL
+
+
+def test_qecl_vs_reference(setup, tmp_path):
+    from plancklens_amd import qecl
+    g, qdd = setup[0], setup[2]
+    qcls = qecl.library(str(tmp_path / 'qcls'), qdd, qdd, np.array([]))
+    assert relrms(qcls.get_sim_qcl('p', 0), g['qcl_p_0']) < 1e-7
+    assert relrms(qcls.get_sim_qcl('ptt', 0, k2='p_p'), g['qcl_ptt_p_p_0']) < 1e-7
+    assert os.path.exists(str(tmp_path / 'qcls' / 'cldb.db'))
+    assert relrms(qcls.get_sim_qcl('p', 0, lmax=10), g['qcl_p_0'][:11]) < 1e-7  # served from the sqlite cache
