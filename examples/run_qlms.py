@@ -1,0 +1,84 @@
+"""Filtering -> quadratic estimators -> mean fields -> spectra driver, CLI and job structure of the reference's
+examples/run_qlms.py (:25-121), one process per GPU:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        examples/run_qlms.py params/idealized_example.py -imin 0 -imax 255 -k p -ivt -ivp -dd
+
+Every phase shards its jobs as jobs[rank::size] and ends on a barrier, exactly like the reference under srun; the
+products land in the same cache files, so a killed run is simply re-run.
+"""
+import argparse
+import os
+import sys
+from importlib.machinery import SourceFileLoader
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from plancklens_amd.helpers import mpi  # noqa: E402
+
+parser = argparse.ArgumentParser(description='QE calculation driver (MI355X)')
+parser.add_argument('parfile', type=str, nargs=1)
+parser.add_argument('-imin', dest='imin', default=-1, type=int, help='starting index (-1 stands for data map)')
+parser.add_argument('-imax', dest='imax', default=-2, type=int, help='last index')
+parser.add_argument('-k', dest='k', action='store', default=[], nargs='+', help='QE keys (gradient and curl come together)')
+parser.add_argument('-kA', dest='kA', action='store', default=[], nargs='+', help='QE spectra keys (left leg)')
+parser.add_argument('-kB', dest='kB', action='store', default=[], nargs='+', help='QE spectra keys (right leg)')
+parser.add_argument('-ivt', dest='ivt', action='store_true', help='do T. filtering')
+parser.add_argument('-ivp', dest='ivp', action='store_true', help='do P. filtering')
+parser.add_argument('-dd', dest='dd', action='store_true', help='perform dd qlms / qcls library QEs')
+parser.add_argument('-ds', dest='ds', action='store_true', help='perform ds qlms / qcls library QEs')
+parser.add_argument('-ss', dest='ss', action='store_true', help='perform ss qlms / qcls library QEs')
+parser.add_argument('-mfdd', dest='mfdd', action='store_true', help='perform dd qlms mean-fields for qcls keys')
+
+
+def main():
+    args = parser.parse_args()
+    mpi.init()
+    par = SourceFileLoader('run_qlms_parfile', args.parfile[0]).load_module()
+
+    # --- filtering
+    jobs = []
+    for flag, lab in ((args.ivt, 't'), (args.ivp, 'p')):
+        if flag:
+            jobs += [(idx, lab) for idx in range(args.imin, args.imax + 1)]
+            if args.ds and args.imin >= 0:
+                jobs += [(-1, lab)]
+    for i, (idx, lab) in enumerate(jobs[mpi.rank::mpi.size]):
+        print('rank %s filtering sim %s %s, job %s in %s' % (mpi.rank, idx, lab, i, len(jobs[mpi.rank::mpi.size])))
+        if lab == 't':
+            par.ivfs.get_sim_tlm(idx)
+        else:
+            par.ivfs.get_sim_elm(idx)  # caches blm as well
+    mpi.barrier()
+
+    # --- unnormalized QE calculation
+    qlibs = [par.qlms_dd] * args.dd + [par.qlms_ss] * args.ss + [par.qlms_ds] * args.ds
+    jobs = [(qlib, idx, k) for qlib in qlibs for k in args.k for idx in range(args.imin, args.imax + 1)]
+    for i, (qlib, idx, k) in enumerate(jobs[mpi.rank::mpi.size]):
+        print('rank %s doing QE sim %s %s, qlm_lib %s, job %s in %s' % (mpi.rank, idx, k, qlib.lib_dir, i, len(jobs)))
+        qlib.get_sim_qlm(k, idx)
+    mpi.barrier()
+
+    # --- mean-fields
+    if args.mfdd:
+        keys = list(np.unique(np.concatenate([args.kA, args.kB])))
+        jobs = [(k, 0) for k in keys] + [(k, 1) for k in keys]
+        for i, (k, id0) in enumerate(jobs[mpi.rank::mpi.size]):
+            print("rank %s doing %s QE MF %s" % (mpi.rank, k, id0))
+            par.qlms_dd.get_sim_qlm_mf(k, par.qcls_dd.mc_sims_mf[id0::2])
+    mpi.barrier()
+
+    # --- unnormalized QE power spectra
+    qlibs = [par.qcls_dd] * args.dd + [par.qcls_ss] * args.ss + [par.qcls_ds] * args.ds
+    jobs = [(qlib, idx, kA, kB) for qlib in qlibs for kA in args.kA for kB in args.kB for idx in range(args.imin, args.imax)
+            if idx not in qlib.mc_sims_mf]
+    for i, (qlib, idx, kA, kB) in enumerate(jobs[mpi.rank::mpi.size]):
+        print('rank %s doing QE spectra sim %s %s %s, qcl_lib %s, job %s in %s' % (mpi.rank, idx, kA, kB, qlib.lib_dir, i, len(jobs)))
+        qlib.get_sim_qcl(kA, idx, k2=kB)
+    mpi.barrier()
+    mpi.finalize()
+
+
+if __name__ == '__main__':
+    main()

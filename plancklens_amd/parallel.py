@@ -1,0 +1,67 @@
+"""One-process-per-GPU job sharding and the two collectives the hot path needs.
+
+The reference fans (simulation, key) jobs over MPI ranks with jobs[rank::size] and exchanges results through files
+(examples/run_qlms.py:57,72,92,106; mean field = file-based average, qest.py:238-244).  Here the same static
+round-robin is kept and the only cross-rank data movement -- the mean-field sum and the gather of the output qlm --
+is done with RCCL collectives over xGMI (torch.distributed backend "nccl"; "gloo" on CPU for the tests).
+No data-path collective exists inside a reconstruction: simulations are independent.
+"""
+import numpy as np
+import torch
+
+from .helpers import mpi
+
+
+def shard(jobs):
+    """This rank's jobs: the reference's static round-robin jobs[rank::size]."""
+    return list(jobs)[mpi.rank::mpi.size]
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+
+
+def _as_real(t):
+    return torch.view_as_real(t) if t.is_complex() else t
+
+
+def allreduce_sum(x):
+    """In-place sum over ranks of a (complex or real) tensor or numpy array; returns it."""
+    dist = _dist()
+    if dist is None:
+        return x
+    if isinstance(x, np.ndarray):
+        t = torch.from_numpy(np.ascontiguousarray(x))
+        if dist.get_backend() == 'nccl':
+            t = t.cuda()
+        dist.all_reduce(_as_real(t))
+        x[...] = t.cpu().numpy()
+        return x
+    dist.all_reduce(_as_real(x))
+    return x
+
+
+def allgather(x):
+    """List (one entry per rank) of tensors equal to every rank's x (same shape on all ranks)."""
+    dist = _dist()
+    if dist is None:
+        return [x]
+    r = _as_real(x.contiguous())
+    out = [torch.empty_like(r) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, r)
+    return [torch.view_as_complex(o) if x.is_complex() else o for o in out]
+
+
+def mean_field(get_qlm, idxs, like):
+    """Mean of get_qlm(idx) over ALL idxs, each rank evaluating only its shard: sum locally, all-reduce, divide.
+    `like` is a zero tensor giving shape / dtype / device of the accumulator."""
+    idxs = list(np.unique(np.asarray(idxs)))
+    acc = torch.zeros_like(like)
+    for idx in shard(idxs):
+        q = get_qlm(idx)
+        acc += q if isinstance(q, torch.Tensor) else torch.as_tensor(q).to(acc.device)
+    allreduce_sum(acc)
+    if len(idxs) > 0:
+        acc /= len(idxs)
+    return acc
