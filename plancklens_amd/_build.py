@@ -28,17 +28,19 @@ def needs_build():
     return any(os.path.exists(os.path.join(CSRC, f)) and os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, libname=None):
+    """libname: build under another file name (development variants selected at run time with PLSHTS_LIB)"""
+    if libname is None and not force and not needs_build():
         return lib_path()
     srcs = [f for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-result',
-           '-o', LIBNAME] + srcs
+    cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-result'] + \
+          os.environ.get('PLSHTS_CXXFLAGS', '').split() + ['-o', libname or LIBNAME] + srcs
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    return lib_path()
+    return os.path.join(CSRC, libname) if libname else lib_path()
 
 
 if __name__ == '__main__':
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force=True, verbose=True, libname=sys.argv[1] if len(sys.argv) > 1 else None))

@@ -26,7 +26,7 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    so = _build.lib_path()
+    so = os.environ.get('PLSHTS_LIB', '') or _build.lib_path()  # PLSHTS_LIB: an alternative build of the same library
     if not os.path.exists(so):
         raise RuntimeError('%s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                            '(the HIP path has no CPU fallback)' % so)

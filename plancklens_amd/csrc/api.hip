@@ -103,7 +103,8 @@ static int grow(pl_plan *p, double **buf, int64_t *cap, int64_t ndoubles)
     if (*cap >= ndoubles) return 0;
     if (*buf) { HIPCHK(hipFree(*buf)); p->bytes -= *cap * 8; }
     *buf = nullptr; *cap = 0;
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(buf), ndoubles * sizeof(double)));
+    // + 64: the Legendre kernels fetch coefficients 8 entries at a time and may read (never use) past the last m
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(buf), (ndoubles + 64) * sizeof(double)));
     *cap = ndoubles;
     p->bytes += ndoubles * 8;
     return 0;
@@ -438,16 +439,16 @@ double pl_fma64_peak_tflops(int iters, void *stream)
     if (hipMalloc(reinterpret_cast<void **>(&out), 8) != hipSuccess) return -1.0;
     const int nblk = 256 * 8;
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
     launch_fma_peak(iters / 8 + 1, out, nblk, st);
-    hipEventRecord(e0, st);
+    ok = ok && hipEventRecord(e0, st) == hipSuccess;
     launch_fma_peak(iters, out, nblk, st);
-    hipEventRecord(e1, st);
-    hipEventSynchronize(e1);
+    ok = ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(out);
+    ok = ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(out);
+    if (!ok || ms <= 0.f) return -1.0;
     const double flops = 2.0 * 16.0 * (double)iters * 256.0 * nblk;
     return flops / (ms * 1e-3) / 1e12;
 }

@@ -12,13 +12,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "device_plan.h"
 #include "legendre_math.h"
-
-#ifndef PL_REDUCE_SWAP
-#define PL_REDUCE_SWAP 1
-#endif
 
 namespace plshts {
 
@@ -27,37 +24,42 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 __device__ __forceinline__ bool wave_all(bool p) { return __all(p) != 0; }
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p) != 0; }
 
-// Hand-placed scalar loads.  hipcc sinks ordinary wave-uniform loads to their first use and then waits for them
-// with lgkmcnt(0) at the top of every trip (measured: 50 % of the wave cycles of the Legendre loops parked in
-// s_waitcnt).  Issued through asm they stay where they are written: one trip ahead of their use, with a single
-// wait at the end of the trip.  Contract: nothing reads the destination between *_issue and sload_wait.
+// Wave-uniform coefficient loads, written one trip ahead of their use.  hipcc is free to sink them to the first use;
+// an asm-pinned variant (PL_ASM_PREFETCH=1) keeps them in place but is unsafe under SGPR pressure (see below).
 typedef double d2v_t __attribute__((ext_vector_type(2)));
 typedef double d4v_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void sload2_issue(d2v_t &dst, const void *p)
-{
-    asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(dst) : "s"(p) : "memory");
-}
-__device__ __forceinline__ void sload4_issue(d4v_t &dst, const void *p)
-{
-    asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(dst) : "s"(p) : "memory");
-}
-__device__ __forceinline__ void sload_wait(d2v_t &a, d2v_t &b, d4v_t &c, d4v_t &d)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d)::"memory");
-}
 typedef double d8v_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void sload8_issue(d8v_t &dst, const void *p)
+// Wave-uniform table loads through the constant address space: the tables are read-only for the lifetime of the
+// kernel, and an address_space(4) load with a uniform address is always selected as s_load (a plain global load
+// degrades to a per-lane VMEM load as soon as the kernel also stores to global memory: 64 VGPRs of coefficients).
+template <class T>
+__device__ __forceinline__ T ldc(const void *p)
 {
-    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(dst) : "s"(p) : "memory");
+    typedef const T __attribute__((address_space(4))) *cptr_t;
+    return *(cptr_t)(unsigned long long)p;
 }
-__device__ __forceinline__ void sload_wait(d8v_t &a, d8v_t &b)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory");
-}
-__device__ __forceinline__ void sload_wait(d2v_t &a, d4v_t &c)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(c)::"memory");
-}
+__device__ __forceinline__ d8v_t ld8(const double2 *p) { return ldc<d8v_t>(p); }
+#ifndef PL_ASM_PREFETCH
+#define PL_ASM_PREFETCH 0
+#endif
+#if PL_ASM_PREFETCH
+// EXPERIMENTAL: the register allocator does not know that the destination is written asynchronously; under SGPR
+// pressure it may copy / spill the destination between issue and wait (observed in the analysis kernels: NaN).
+__device__ __forceinline__ void sload2_issue(d2v_t &dst, const void *p) { asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(dst) : "s"(p) : "memory"); }
+__device__ __forceinline__ void sload4_issue(d4v_t &dst, const void *p) { asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(dst) : "s"(p) : "memory"); }
+__device__ __forceinline__ void sload8_issue(d8v_t &dst, const void *p) { asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(dst) : "s"(p) : "memory"); }
+__device__ __forceinline__ void sload_wait(d2v_t &a, d2v_t &b, d4v_t &c, d4v_t &d) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d)::"memory"); }
+__device__ __forceinline__ void sload_wait(d8v_t &a, d8v_t &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory"); }
+__device__ __forceinline__ void sload_wait(d2v_t &a, d4v_t &c) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(c)::"memory"); }
+#else
+// compiler-managed wave-uniform loads (s_load + s_waitcnt placed by hipcc)
+__device__ __forceinline__ void sload2_issue(d2v_t &dst, const void *p) { dst = *reinterpret_cast<const d2v_t *>(p); }
+__device__ __forceinline__ void sload4_issue(d4v_t &dst, const void *p) { dst = *reinterpret_cast<const d4v_t *>(p); }
+__device__ __forceinline__ void sload8_issue(d8v_t &dst, const void *p) { dst = *reinterpret_cast<const d8v_t *>(p); }
+__device__ __forceinline__ void sload_wait(d2v_t &, d2v_t &, d4v_t &, d4v_t &) {}
+__device__ __forceinline__ void sload_wait(d8v_t &, d8v_t &) {}
+__device__ __forceinline__ void sload_wait(d2v_t &, d4v_t &) {}
+#endif
 
 // -----------------------------------------------------------------------------------------------------
 // alm -> recursion-basis coefficients (fused hp.almxfl)
@@ -153,23 +155,99 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
         const int64_t base = P.off0[m];
         const double2 *__restrict__ ab = reinterpret_cast<const double2 *>(P.ab0) + base;
         const double4 *__restrict__ cd = prep + base;
+        const d2v_t *__restrict__ abv = reinterpret_cast<const d2v_t *>(ab);
+        const d4v_t *__restrict__ cdv = reinterpret_cast<const d4v_t *>(cd);
         int il = 0;
-        // phase A: no lane of the wave has reached the IEEE range yet -- recursion only, nothing to accumulate
-        for (; il < nil; ++il) {
-            bool act = false, live = false;
+        bool all_done = false;
+        {
+            bool live = false;
 #pragma unroll
-            for (int k = 0; k < R; ++k) { act = act || (r[k].sc == 0); live = live || (r[k].sc != kNeverActive); }
-            if (wave_any(act) || !wave_any(live)) break;
-            const double2 c_ab = ab[il];
-#pragma unroll
-            for (int k = 0; k < R; ++k) rec0_step_careful(r[k], c_ab.x, c_ab.y);
+            for (int k = 0; k < R; ++k) live = live || (r[k].sc != kNeverActive);
+            if (!wave_any(live)) il = nil;  // every ring of this wave is pruned for this m
         }
-        // phase B: some lanes active, some still scaled
-        for (; il < nil; ++il) {
+        // phase A: no lane of the wave has reached the IEEE range yet -- recursion only; the rescale check is deferred
+        // to the end of each block of 8 il (see rec0_renorm_up)
+        while (il + 8 <= nil) {
+            bool act = false;
+#pragma unroll
+            for (int k = 0; k < R; ++k) act = act || (r[k].sc == 0);
+            if (wave_any(act)) break;
+            const d8v_t c0 = ld8(ab + il), c1 = ld8(ab + il + 4);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const double cA = t < 4 ? c0[2 * t] : c1[2 * (t - 4)], cB = t < 4 ? c0[2 * t + 1] : c1[2 * (t - 4) + 1];
+#pragma unroll
+                for (int k = 0; k < R; ++k) rec0_step_fast(r[k], cA, cB);
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) rec0_renorm_up(r[k]);
+            il += 8;
+        }
+        // phase B: some lanes active, some still scaled -- fast steps, each ring's terms multiplied by its 0/1 mask,
+        // masks and scales refreshed every 8 il
+        while (il + 8 <= nil) {
             bool done = true;
 #pragma unroll
             for (int k = 0; k < R; ++k) done = done && (r[k].sc == 0 || r[k].sc == kNeverActive);
-            if (wave_all(done)) break;
+            if (wave_all(done)) { all_done = true; break; }
+            double mk[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) mk[k] = r[k].sc == 0 ? 1.0 : 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const d8v_t c = ld8(ab + il + 4 * h);
+                const d8v_t q0 = ldc<d8v_t>(cdv + il + 4 * h), q1 = ldc<d8v_t>(cdv + il + 4 * h + 2);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int o = 4 * (t & 1);
+                    const double qx = t < 2 ? q0[o] : q1[o], qy = t < 2 ? q0[o + 1] : q1[o + 1];
+                    const double qz = t < 2 ? q0[o + 2] : q1[o + 2], qw = t < 2 ? q0[o + 3] : q1[o + 3];
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const double v = r[k].p1 * mk[k];
+                        cr[k] = fma(v, qx, cr[k]); ci[k] = fma(v, qy, ci[k]);
+                        dr[k] = fma(v, qz, dr[k]); di[k] = fma(v, qw, di[k]);
+                        rec0_step_fast(r[k], c[2 * t], c[2 * t + 1]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) rec0_renorm_up(r[k]);
+            il += 8;
+        }
+        // phase C: every live lane is in the IEEE range -- pure FMA stream, coefficient loads one trip ahead
+        if (all_done) {
+            auto one_step = [&](const d2v_t &c_ab, const d4v_t &c) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const double v = r[k].p1;
+                    cr[k] = fma(v, c.x, cr[k]); ci[k] = fma(v, c.y, ci[k]);
+                    dr[k] = fma(v, c.z, dr[k]); di[k] = fma(v, c.w, di[k]);
+                    rec0_step_fast(r[k], c_ab.x, c_ab.y);
+                }
+            };
+            // two coefficient sets of two steps each, loaded one set ahead (see k_leg_synths)
+            d2v_t A0 = ldc<d2v_t>(abv + il), A1 = ldc<d2v_t>(abv + min(il + 1, nil - 1));
+            d4v_t Ac0 = ldc<d4v_t>(cdv + il), Ac1 = ldc<d4v_t>(cdv + min(il + 1, nil - 1));
+            while (il + 3 < nil) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                const d2v_t B0 = ldc<d2v_t>(abv + il + 2), B1 = ldc<d2v_t>(abv + il + 3);
+                const d4v_t Bc0 = ldc<d4v_t>(cdv + il + 2), Bc1 = ldc<d4v_t>(cdv + il + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                one_step(A0, Ac0); one_step(A1, Ac1);
+                __builtin_amdgcn_sched_barrier(0);
+                const int ip = min(il + 4, nil - 2);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                A0 = ldc<d2v_t>(abv + ip); A1 = ldc<d2v_t>(abv + ip + 1); Ac0 = ldc<d4v_t>(cdv + ip); Ac1 = ldc<d4v_t>(cdv + ip + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                one_step(B0, Bc0); one_step(B1, Bc1);
+                __builtin_amdgcn_sched_barrier(0);
+                il += 4;
+            }
+            if (il + 1 < nil) { one_step(A0, Ac0); one_step(A1, Ac1); il += 2; }
+        }
+        // tail (at most 7 il, any mix of active and scaled lanes): one careful step at a time
+        for (; il < nil; ++il) {
             const double2 c_ab = ab[il];
             const double4 c = cd[il];
 #pragma unroll
@@ -178,29 +256,6 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
                 cr[k] = fma(v, c.x, cr[k]); ci[k] = fma(v, c.y, ci[k]);
                 dr[k] = fma(v, c.z, dr[k]); di[k] = fma(v, c.w, di[k]);
                 rec0_step_careful(r[k], c_ab.x, c_ab.y);
-            }
-        }
-        // phase C: every live lane is in the IEEE range -- pure FMA stream, coefficient loads one trip ahead
-        if (il < nil) {
-            d2v_t n_ab;
-            d4v_t n_c;
-            sload2_issue(n_ab, ab + il); sload4_issue(n_c, cd + il);
-            sload_wait(n_ab, n_c);
-            for (; il < nil; ++il) {
-                const d2v_t c_ab = n_ab;
-                const d4v_t c = n_c;
-                const int ip = min(il + 1, nil - 1);
-                sload2_issue(n_ab, ab + ip); sload4_issue(n_c, cd + ip);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    const double v = r[k].p1;
-                    cr[k] = fma(v, c.x, cr[k]); ci[k] = fma(v, c.y, ci[k]);
-                    dr[k] = fma(v, c.z, dr[k]); di[k] = fma(v, c.w, di[k]);
-                    rec0_step_fast(r[k], c_ab.x, c_ab.y);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                sload_wait(n_ab, n_c);
             }
         }
     }
@@ -272,27 +327,106 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
         const int64_t base = S.off[m];
         const double2 *__restrict__ ab = reinterpret_cast<const double2 *>(S.ab) + base;
         const double4 *__restrict__ aa = prep + base;
+        const d2v_t *__restrict__ abv = reinterpret_cast<const d2v_t *>(ab);
+        const d4v_t *__restrict__ aav = reinterpret_cast<const d4v_t *>(aa);
         int i = 0;
-        // phase A: no lane active yet -- recursion only
-        for (; i < nl; ++i) {
-            bool act = false, live = false;
+        bool all_done = false;
+        {
+            bool live = false;
+#pragma unroll
+            for (int k = 0; k < R; ++k) live = live || r[k].scn != kNeverActive || r[k].scp != kNeverActive;
+            if (!wave_any(live)) i = nl;  // every ring of this wave is pruned for this m
+        }
+        double mn[R], mp[R];  // phase B: 0/1 masks of the (n, p) recursions of each ring
+        // two consecutive l (even i, odd i); i stays even through phases A, B and C
+        auto pair_step = [&](auto masked, double ca0, double cb0, double ca1, double cb1, const d4v_t &a0, const d4v_t &a1) {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                act = act || r[k].scn == 0 || r[k].scp == 0;
-                live = live || r[k].scn != kNeverActive || r[k].scp != kNeverActive;
+                double vn = r[k].n1, vp = r[k].p1;
+                if constexpr (decltype(masked)::value) { vn *= mn[k]; vp *= mp[k]; }
+                xn_r[k] = fma(vn, a0.x, xn_r[k]); xn_i[k] = fma(vn, a0.y, xn_i[k]);
+                yn_r[k] = fma(vp, a0.z, yn_r[k]); yn_i[k] = fma(vp, a0.w, yn_i[k]);
+                xe_r[k] = fma(vp, a0.x, xe_r[k]); xe_i[k] = fma(vp, a0.y, xe_i[k]);
+                ye_r[k] = fma(vn, a0.z, ye_r[k]); ye_i[k] = fma(vn, a0.w, ye_i[k]);
+                recs_step_fast(r[k], ca0, cb0);
+                vn = r[k].n1; vp = r[k].p1;
+                if constexpr (decltype(masked)::value) { vn *= mn[k]; vp *= mp[k]; }
+                xn_r[k] = fma(vn, a1.x, xn_r[k]); xn_i[k] = fma(vn, a1.y, xn_i[k]);
+                yn_r[k] = fma(vp, a1.z, yn_r[k]); yn_i[k] = fma(vp, a1.w, yn_i[k]);
+                xo_r[k] = fma(vp, a1.x, xo_r[k]); xo_i[k] = fma(vp, a1.y, xo_i[k]);
+                yo_r[k] = fma(vn, a1.z, yo_r[k]); yo_i[k] = fma(vn, a1.w, yo_i[k]);
+                recs_step_fast(r[k], ca1, cb1);
             }
-            if (wave_any(act) || !wave_any(live)) break;
-            const double2 c_ab = ab[i];
+        };
+        // phase A: no lane active yet -- recursion only, rescale check deferred to the end of each block of 8 l
+        while (i + 8 <= nl) {
+            bool act = false;
 #pragma unroll
-            for (int k = 0; k < R; ++k) recs_step_careful(r[k], c_ab.x, c_ab.y);
+            for (int k = 0; k < R; ++k) act = act || r[k].scn == 0 || r[k].scp == 0;
+            if (wave_any(act)) break;
+            const d8v_t c0 = ld8(ab + i), c1 = ld8(ab + i + 4);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const double ca = t < 4 ? c0[2 * t] : c1[2 * (t - 4)], cb = t < 4 ? c0[2 * t + 1] : c1[2 * (t - 4) + 1];
+#pragma unroll
+                for (int k = 0; k < R; ++k) recs_step_fast(r[k], ca, cb);
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) recs_renorm_up(r[k]);
+            i += 8;
         }
-        // phase B: mixed
-        for (; i < nl; ++i) {
+        // phase B: mixed -- fast steps with per-ring 0/1 masks, masks and scales refreshed every 8 l
+        while (i + 8 <= nl) {
             bool done = true;
 #pragma unroll
             for (int k = 0; k < R; ++k)
                 done = done && (r[k].scn == 0 || r[k].scn == kNeverActive) && (r[k].scp == 0 || r[k].scp == kNeverActive);
-            if (wave_all(done)) break;
+            if (wave_all(done)) { all_done = true; break; }
+#pragma unroll
+            for (int k = 0; k < R; ++k) { mn[k] = r[k].scn == 0 ? 1.0 : 0.0; mp[k] = r[k].scp == 0 ? 1.0 : 0.0; }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const d8v_t c = ld8(ab + i + 4 * h);
+                const d8v_t q0 = ldc<d8v_t>(aav + i + 4 * h), q1 = ldc<d8v_t>(aav + i + 4 * h + 2);
+                pair_step(std::true_type(), c[0], c[1], c[2], c[3], __builtin_shufflevector(q0, q0, 0, 1, 2, 3),
+                          __builtin_shufflevector(q0, q0, 4, 5, 6, 7));
+                pair_step(std::true_type(), c[4], c[5], c[6], c[7], __builtin_shufflevector(q1, q1, 0, 1, 2, 3),
+                          __builtin_shufflevector(q1, q1, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) recs_renorm_up(r[k]);
+            i += 8;
+        }
+        // phase C: pure FMA stream, two l per pair_step
+        if (all_done && i + 1 < nl) {
+            // Software pipeline with two coefficient sets (A, B), two l per set: the wave-uniform loads of the next
+            // pair are issued before the FMA stream of the current pair.  SMEM returns out of order, so every set is
+            // waited for with lgkmcnt(0) before the other one is issued -- after ~50 v_fma_f64, i.e. hidden.
+            // The sched_barriers keep hipcc from sinking the loads to their first use.
+            d2v_t A0 = ldc<d2v_t>(abv + i), A1 = ldc<d2v_t>(abv + i + 1);
+            d4v_t Aa0 = ldc<d4v_t>(aav + i), Aa1 = ldc<d4v_t>(aav + i + 1);
+            while (i + 3 < nl) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): set A has landed (it was issued one half trip ago) ...
+                const d2v_t B0 = ldc<d2v_t>(abv + i + 2), B1 = ldc<d2v_t>(abv + i + 3);  // ... so that B can be issued without A's uses waiting on it
+                const d4v_t Ba0 = ldc<d4v_t>(aav + i + 2), Ba1 = ldc<d4v_t>(aav + i + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                pair_step(std::false_type(), A0.x, A0.y, A1.x, A1.y, Aa0, Aa1);
+                __builtin_amdgcn_sched_barrier(0);
+                const int ip = min(i + 4, nl - 2);  // clamped: the last prefetch re-reads valid entries
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                A0 = ldc<d2v_t>(abv + ip); A1 = ldc<d2v_t>(abv + ip + 1); Aa0 = ldc<d4v_t>(aav + ip); Aa1 = ldc<d4v_t>(aav + ip + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                pair_step(std::false_type(), B0.x, B0.y, B1.x, B1.y, Ba0, Ba1);
+                __builtin_amdgcn_sched_barrier(0);
+                i += 4;
+            }
+            if (i + 1 < nl) {
+                pair_step(std::false_type(), A0.x, A0.y, A1.x, A1.y, Aa0, Aa1);
+                i += 2;
+            }
+        }
+        // tail (at most 7 l, any mix of active and scaled lanes): one careful step at a time
+        for (; i < nl; ++i) {
             const double2 c_ab = ab[i];
             const double4 a = aa[i];
             const bool odd = (i & 1) != 0;
@@ -309,66 +443,6 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
                     yo_r[k] = fma(vn, a.z, yo_r[k]); yo_i[k] = fma(vn, a.w, yo_i[k]);
                 }
                 recs_step_careful(r[k], c_ab.x, c_ab.y);
-            }
-        }
-        // phase C: pure FMA stream, two l per trip (even i, odd i)
-        if (i < nl && (i & 1)) {
-            const double2 c_ab = ab[i];
-            const double4 a = aa[i];
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const double vn = r[k].n1, vp = r[k].p1;
-                xn_r[k] = fma(vn, a.x, xn_r[k]); xn_i[k] = fma(vn, a.y, xn_i[k]);
-                yn_r[k] = fma(vp, a.z, yn_r[k]); yn_i[k] = fma(vp, a.w, yn_i[k]);
-                xo_r[k] = fma(vp, a.x, xo_r[k]); xo_i[k] = fma(vp, a.y, xo_i[k]);
-                yo_r[k] = fma(vn, a.z, yo_r[k]); yo_i[k] = fma(vn, a.w, yo_i[k]);
-                recs_step_fast(r[k], c_ab.x, c_ab.y);
-            }
-            ++i;
-        }
-        if (i + 1 < nl) {
-            // software pipeline: the (wave-uniform, scalar) coefficient loads of trip t + 1 are issued before the
-            // FMA stream of trip t, so their latency hides under ~50 v_fma_f64 instead of stalling every trip
-            d2v_t n_ab0, n_ab1;
-            d4v_t n_a0, n_a1;
-            sload2_issue(n_ab0, ab + i); sload2_issue(n_ab1, ab + i + 1);
-            sload4_issue(n_a0, aa + i); sload4_issue(n_a1, aa + i + 1);
-            sload_wait(n_ab0, n_ab1, n_a0, n_a1);
-            for (; i + 1 < nl; i += 2) {
-                const d2v_t c_ab0 = n_ab0, c_ab1 = n_ab1;
-                const d4v_t a0 = n_a0, a1 = n_a1;
-                const int ip = min(i + 2, nl - 2);  // clamped: the last prefetch re-reads valid entries
-                sload2_issue(n_ab0, ab + ip); sload2_issue(n_ab1, ab + ip + 1);
-                sload4_issue(n_a0, aa + ip); sload4_issue(n_a1, aa + ip + 1);
-                __builtin_amdgcn_sched_barrier(0);  // keep the issues ahead of the FMA stream
-#pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    double vn = r[k].n1, vp = r[k].p1;
-                    xn_r[k] = fma(vn, a0.x, xn_r[k]); xn_i[k] = fma(vn, a0.y, xn_i[k]);
-                    yn_r[k] = fma(vp, a0.z, yn_r[k]); yn_i[k] = fma(vp, a0.w, yn_i[k]);
-                    xe_r[k] = fma(vp, a0.x, xe_r[k]); xe_i[k] = fma(vp, a0.y, xe_i[k]);
-                    ye_r[k] = fma(vn, a0.z, ye_r[k]); ye_i[k] = fma(vn, a0.w, ye_i[k]);
-                    recs_step_fast(r[k], c_ab0.x, c_ab0.y);
-                    vn = r[k].n1; vp = r[k].p1;
-                    xn_r[k] = fma(vn, a1.x, xn_r[k]); xn_i[k] = fma(vn, a1.y, xn_i[k]);
-                    yn_r[k] = fma(vp, a1.z, yn_r[k]); yn_i[k] = fma(vp, a1.w, yn_i[k]);
-                    xo_r[k] = fma(vp, a1.x, xo_r[k]); xo_i[k] = fma(vp, a1.y, xo_i[k]);
-                    yo_r[k] = fma(vn, a1.z, yo_r[k]); yo_i[k] = fma(vn, a1.w, yo_i[k]);
-                    recs_step_fast(r[k], c_ab1.x, c_ab1.y);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                sload_wait(n_ab0, n_ab1, n_a0, n_a1);
-            }
-        }
-        if (i < nl) {
-            const double4 a = aa[i];
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const double vn = r[k].n1, vp = r[k].p1;
-                xn_r[k] = fma(vn, a.x, xn_r[k]); xn_i[k] = fma(vn, a.y, xn_i[k]);
-                yn_r[k] = fma(vp, a.z, yn_r[k]); yn_i[k] = fma(vp, a.w, yn_i[k]);
-                xe_r[k] = fma(vp, a.x, xe_r[k]); xe_i[k] = fma(vp, a.y, xe_i[k]);
-                ye_r[k] = fma(vn, a.z, ye_r[k]); ye_i[k] = fma(vn, a.w, ye_i[k]);
             }
         }
     }
@@ -429,34 +503,35 @@ __device__ __forceinline__ void reduce_step(double *v, int lane)
     const bool up = (lane & HALF) != 0;  // the lane-id bit handled by this step equals the half size
 #pragma unroll
     for (int i = 0; i < HALF; ++i) {
-#if PL_REDUCE_SWAP
-        if (HALF == 32) { v[i] = swap_add32(v[i], v[i + HALF]); continue; }
-        if (HALF == 16) { v[i] = swap_add16(v[i], v[i + HALF]); continue; }
-#endif
         const double keep = up ? v[i + HALF] : v[i];
         const double send = up ? v[i] : v[i + HALF];
         double recv;
-#if PL_REDUCE_SWAP
         if (HALF == 8) recv = dpp_move<0x128>(send);       // row_ror:8  = lane ^ 8 inside a row of 16
         else if (HALF == 2) recv = dpp_move<0x4E>(send);   // quad_perm [2,3,0,1] = lane ^ 2
         else if (HALF == 1) recv = dpp_move<0xB1>(send);   // quad_perm [1,0,3,2] = lane ^ 1
-        else
-#endif
-            recv = __shfl_xor(send, HALF, 64);
+        else recv = __shfl_xor(send, HALF, 64);
         v[i] = keep + recv;
     }
 }
 
-__device__ __forceinline__ double reduce64_transpose(double *v, int lane)
+// The transpose-reduce of the analysis kernels, in two parts so that only one double per l stays live:
+// fold4: the 4 per-lane sums (a0..a3) of one l are folded over the 4 rows of 16 lanes as soon as they exist;
+//        afterwards row q (lanes 16 q .. 16 q + 15) holds component {a0, a2, a1, a3}[q], still spread over its 16 lanes.
+// reduce16: 16 such values (one per l of the tile) are transposed-reduced inside the rows; on return lane 16 q + j
+//        holds the wave total of component {0, 2, 1, 3}[q] of the j-th l of the tile.
+__device__ __forceinline__ double fold4(double a0, double a1, double a2, double a3)
 {
-    reduce_step<32>(v, lane);
-    reduce_step<16>(v, lane);
+    return swap_add16(swap_add32(a0, a1), swap_add32(a2, a3));
+}
+__device__ __forceinline__ double reduce16(double *v, int lane)
+{
     reduce_step<8>(v, lane);
     reduce_step<4>(v, lane);
     reduce_step<2>(v, lane);
     reduce_step<1>(v, lane);
     return v[0];
 }
+__device__ __forceinline__ int fold4_component(int lane) { const int q = lane >> 4; return ((q & 1) << 1) | (q >> 1); }
 
 // -----------------------------------------------------------------------------------------------------
 // analysis, spin 0: partial[g][entry] = {C_re, C_im, D_re, D_im} summed over the ring pairs of group g
@@ -508,75 +583,134 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
     const double2 *__restrict__ ab = reinterpret_cast<const double2 *>(P.ab0) + base;
     double *__restrict__ out = partial + ((int64_t)g * P.nent0 + base) * 4;
     bool all_active = false, any_active = false;
-    int pf = -1;
-    d8v_t n0, n1;
+    int pfa = -1;  // tile start whose first-half coefficients are already in SA
+    d8v_t SA0, SA1, SB0, SB1;
+    double acc[16];  // one folded value per l of the tile (see fold4)
+    // one half tile (8 consecutive il) with the coefficient set (c0, c1) = 8 (A, B) pairs
+    auto half = [&](auto hc, const d8v_t &c0, const d8v_t &c1, int ib) {
+        constexpr int h = decltype(hc)::value;
+        if (all_active && ib + 8 <= nil) {  // every lane in the IEEE range, all 8 il in range: one branch-free FMA block
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+                const int t = 8 * h + tt;
+                const double cA = tt < 4 ? c0[2 * tt] : c1[2 * (tt - 4)];
+                const double cB = tt < 4 ? c0[2 * tt + 1] : c1[2 * (tt - 4) + 1];
+                double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const double v = r[k].p1;
+                    a0 = fma(v, er[k], a0); a1 = fma(v, ei[k], a1); a2 = fma(v, orr[k], a2); a3 = fma(v, oi[k], a3);
+                    rec0_step_fast(r[k], cA, cB);
+                }
+                acc[t] = fold4(a0, a1, a2, a3);
+            }
+        } else if (ib + 8 <= nil) {  // mixed: fast steps, each ring's terms times its 0/1 mask; rescale check after the 8 il
+            double mk[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) mk[k] = r[k].sc == 0 ? 1.0 : 0.0;
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+                const int t = 8 * h + tt;
+                const double cA = tt < 4 ? c0[2 * tt] : c1[2 * (tt - 4)];
+                const double cB = tt < 4 ? c0[2 * tt + 1] : c1[2 * (tt - 4) + 1];
+                double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const double v = r[k].p1 * mk[k];
+                    a0 = fma(v, er[k], a0); a1 = fma(v, ei[k], a1); a2 = fma(v, orr[k], a2); a3 = fma(v, oi[k], a3);
+                    rec0_step_fast(r[k], cA, cB);
+                }
+                acc[t] = fold4(a0, a1, a2, a3);
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) rec0_renorm_up(r[k]);
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+                const int t = 8 * h + tt;
+                const int il = ib + tt;
+                double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+                if (il < nil) {
+                    const double cA = tt < 4 ? c0[2 * tt] : c1[2 * (tt - 4)];
+                    const double cB = tt < 4 ? c0[2 * tt + 1] : c1[2 * (tt - 4) + 1];
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const double v = rec0_value(r[k]);
+                        a0 = fma(v, er[k], a0); a1 = fma(v, ei[k], a1); a2 = fma(v, orr[k], a2); a3 = fma(v, oi[k], a3);
+                        rec0_step_careful(r[k], cA, cB);
+                    }
+                }
+                acc[t] = fold4(a0, a1, a2, a3);
+            }
+        }
+    };
+    {
+        bool live = false;
+#pragma unroll
+        for (int k = 0; k < R; ++k) live = live || (r[k].sc != kNeverActive);
+        if (!wave_any(live)) {  // every ring of this wave is pruned for this m: the partial sums are zero
+            for (int il0 = 0; il0 < nil; il0 += T)
+                if (il0 + (lane >> 2) < nil) out[(int64_t)il0 * 4 + lane] = 0.0;
+            return;
+        }
+    }
     for (int il0 = 0; il0 < nil; il0 += T) {
         if (!any_active) {
             // no lane has reached the IEEE range: recursion only.  A lane that activates inside this tile is
             // at 2^-256 then and cannot grow past ~2^-70 within the tile, so the tile's sums are exactly
             // representable as zero at double precision.
-            bool act = false, live = false;
+            bool act = false;
 #pragma unroll
-            for (int k = 0; k < R; ++k) { act = act || (r[k].sc == 0); live = live || (r[k].sc != kNeverActive); }
-            any_active = wave_any(act) || !wave_any(live);
+            for (int k = 0; k < R; ++k) act = act || (r[k].sc == 0);
+            any_active = wave_any(act);
             if (!any_active) {
                 const int nt = min(T, nil - il0);
-                for (int t = 0; t < nt; ++t) {
-                    const double2 c_ab = ab[il0 + t];
+                if (nt == T) {  // two blocks of 8 fast steps, rescale check after each (see rec0_renorm_up)
 #pragma unroll
-                    for (int k = 0; k < R; ++k) rec0_step_careful(r[k], c_ab.x, c_ab.y);
+                    for (int h = 0; h < 2; ++h) {
+                        const d8v_t c0 = ld8(ab + il0 + 8 * h), c1 = ld8(ab + il0 + 8 * h + 4);
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const double cA = t < 4 ? c0[2 * t] : c1[2 * (t - 4)], cB = t < 4 ? c0[2 * t + 1] : c1[2 * (t - 4) + 1];
+#pragma unroll
+                            for (int k = 0; k < R; ++k) rec0_step_fast(r[k], cA, cB);
+                        }
+#pragma unroll
+                        for (int k = 0; k < R; ++k) rec0_renorm_up(r[k]);
+                    }
+                } else {
+                    for (int t = 0; t < nt; ++t) {
+                        const double2 c_ab = ab[il0 + t];
+#pragma unroll
+                        for (int k = 0; k < R; ++k) rec0_step_careful(r[k], c_ab.x, c_ab.y);
+                    }
                 }
                 if (il0 + (lane >> 2) < nil) out[(int64_t)il0 * 4 + lane] = 0.0;
                 continue;
             }
         }
-        double acc[64];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            // (A, B) of 8 consecutive il: loaded one half tile ahead (tables are padded, reads past nil are unused)
-            const int ib = il0 + 8 * h;
-            if (pf != ib) { sload8_issue(n0, ab + ib); sload8_issue(n1, ab + ib + 4); sload_wait(n0, n1); }
-            const d8v_t c0 = n0, c1 = n1;
-            sload8_issue(n0, ab + ib + 8); sload8_issue(n1, ab + ib + 12);  // next half tile, one ahead
-            pf = ib + 8;
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
-                const int t = 8 * h + tt;
-                const int il = il0 + t;
-                double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
-                if (il < nil) {
-                    const double cA = tt < 4 ? c0[2 * tt] : c1[2 * (tt - 4)];
-                    const double cB = tt < 4 ? c0[2 * tt + 1] : c1[2 * (tt - 4) + 1];
-                    if (!all_active) {
-#pragma unroll
-                        for (int k = 0; k < R; ++k) {
-                            const double v = rec0_value(r[k]);
-                            a0 = fma(v, er[k], a0); a1 = fma(v, ei[k], a1); a2 = fma(v, orr[k], a2); a3 = fma(v, oi[k], a3);
-                            rec0_step_careful(r[k], cA, cB);
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < R; ++k) {
-                            const double v = r[k].p1;
-                            a0 = fma(v, er[k], a0); a1 = fma(v, ei[k], a1); a2 = fma(v, orr[k], a2); a3 = fma(v, oi[k], a3);
-                            rec0_step_fast(r[k], cA, cB);
-                        }
-                    }
-                }
-                acc[4 * t] = a0; acc[4 * t + 1] = a1; acc[4 * t + 2] = a2; acc[4 * t + 3] = a3;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            sload_wait(n0, n1);
-        }
+        // Two coefficient sets: SA (first 8 il of the tile) and SB (last 8); each is loaded while the other is being
+        // consumed, so the wave-uniform load latency hides under ~100 v_fma_f64 (tables are padded: reads past nil are unused)
+        if (pfa != il0) { SA0 = ld8(ab + il0); SA1 = ld8(ab + il0 + 4); }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): SA has landed before SB is issued
+        SB0 = ld8(ab + il0 + 8); SB1 = ld8(ab + il0 + 12);
+        __builtin_amdgcn_sched_barrier(0);
+        half(std::integral_constant<int, 0>(), SA0, SA1, il0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        SA0 = ld8(ab + il0 + 16); SA1 = ld8(ab + il0 + 20);
+        pfa = il0 + 16;
+        __builtin_amdgcn_sched_barrier(0);
+        half(std::integral_constant<int, 1>(), SB0, SB1, il0 + 8);
+        __builtin_amdgcn_sched_barrier(0);
         if (!all_active) {
             bool done = true;
 #pragma unroll
             for (int k = 0; k < R; ++k) done = done && (r[k].sc == 0 || r[k].sc == kNeverActive);
             all_active = wave_all(done);
         }
-        const double tot = reduce64_transpose(acc, lane);
-        if (il0 + (lane >> 2) < nil) out[(int64_t)il0 * 4 + lane] = tot;
+        const double tot = reduce16(acc, lane);
+        if (il0 + (lane & 15) < nil) out[(int64_t)(il0 + (lane & 15)) * 4 + fold4_component(lane)] = tot;
     }
 }
 
@@ -669,9 +803,9 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
         const bool ok = ip < P.npairs && m <= S.mlim[ipc];
         recs_init(r[k], fn, fp, psin, phalf, ucn, ucp, P.cth[ipc], P.sth[ipc], P.chalf[ipc], P.shalf[ipc], ok);
         const double *t = tile + rl * 32 + wave * 8;
-        const double z = ok ? 1.0 : 0.0;
-        const double qnr = z * t[0], qni = z * t[1], qsr = z * t[2], qsi = z * t[3];
-        const double unr = z * t[4], uni = z * t[5], usr = z * t[6], usi = z * t[7];
+        // select, not multiply: entries of pruned (m, ring) are never written by the FFT stage and may hold anything
+        const double qnr = ok ? t[0] : 0., qni = ok ? t[1] : 0., qsr = ok ? t[2] : 0., qsi = ok ? t[3] : 0.;
+        const double unr = ok ? t[4] : 0., uni = ok ? t[5] : 0., usr = ok ? t[6] : 0., usi = ok ? t[7] : 0.;
         // Wp = Q + iU = (q.re - u.im) + i (q.im + u.re);  Wm = Q - iU = (q.re + u.im) + i (q.im - u.re)
         const double wpn_r = sg * (qnr - uni), wpn_i = sg * (qni + unr), wmn_r = qnr + uni, wmn_i = qni - unr;
         const double wps_r = sg * (qsr - usi), wps_i = sg * (qsi + usr), wms_r = qsr + usi, wms_i = qsi - usr;
@@ -691,66 +825,127 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
     const double2 *__restrict__ ab = reinterpret_cast<const double2 *>(S.ab) + base;
     double *__restrict__ out = partial + ((int64_t)g * nent + base) * 4;
     bool all_active = false, any_active = false;
-    int pf = -1;
-    d8v_t n0, n1;
-    for (int i0 = 0; i0 < nl; i0 += T) {
-        if (!any_active) {
-            bool act = false, live = false;
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                act = act || r[k].scn == 0 || r[k].scp == 0;
-                live = live || r[k].scn != kNeverActive || r[k].scp != kNeverActive;
-            }
-            any_active = wave_any(act) || !wave_any(live);
-            if (!any_active) {
-                const int nt = min(T, nl - i0);
-                for (int t = 0; t < nt; ++t) {
-                    const double2 c_ab = ab[i0 + t];
-#pragma unroll
-                    for (int k = 0; k < R; ++k) recs_step_careful(r[k], c_ab.x, c_ab.y);
-                }
-                if (i0 + (lane >> 2) < nl) out[(int64_t)i0 * 4 + lane] = 0.0;
-                continue;
-            }
+    int pfa = -1;
+    d8v_t SA0, SA1, SB0, SB1;
+    double acc[16];  // one folded value per l of the tile (see fold4)
+    // the 8 FMAs of one (l, ring): sigma_l = +1 for even t (after the swap above), -1 for odd t
+    auto accum = [&](int t, int k, double vn, double vp, double &a0, double &a1, double &a2, double &a3) {
+        if ((t & 1) == 0) {
+            a0 = fma(vn, aer[k], a0); a1 = fma(vn, aei[k], a1); a2 = fma(vn, aor[k], a2); a3 = fma(vn, aoi[k], a3);
+            a0 = fma(vp, ber[k], a0); a1 = fma(vp, bei[k], a1); a2 = fma(-vp, bor[k], a2); a3 = fma(-vp, boi[k], a3);
+        } else {
+            a0 = fma(vn, aor[k], a0); a1 = fma(vn, aoi[k], a1); a2 = fma(vn, aer[k], a2); a3 = fma(vn, aei[k], a3);
+            a0 = fma(vp, bor[k], a0); a1 = fma(vp, boi[k], a1); a2 = fma(-vp, ber[k], a2); a3 = fma(-vp, bei[k], a3);
         }
-        double acc[64];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int ib = i0 + 8 * h;
-            if (pf != ib) { sload8_issue(n0, ab + ib); sload8_issue(n1, ab + ib + 4); sload_wait(n0, n1); }
-            const d8v_t c0 = n0, c1 = n1;
-            sload8_issue(n0, ab + ib + 8); sload8_issue(n1, ab + ib + 12);  // next half tile, one ahead
-            pf = ib + 8;
-            __builtin_amdgcn_sched_barrier(0);
+    };
+    auto half = [&](auto hc, const d8v_t &c0, const d8v_t &c1, int ib) {
+        constexpr int h = decltype(hc)::value;
+        if (all_active && ib + 8 <= nl) {  // every lane in the IEEE range, all 8 l in range: one branch-free FMA block
 #pragma unroll
             for (int tt = 0; tt < 8; ++tt) {
                 const int t = 8 * h + tt;
-                const int i = i0 + t;
+                const double cA = tt < 4 ? c0[2 * tt] : c1[2 * (tt - 4)];
+                const double cB = tt < 4 ? c0[2 * tt + 1] : c1[2 * (tt - 4) + 1];
+                double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    accum(t, k, r[k].n1, r[k].p1, a0, a1, a2, a3);
+                    recs_step_fast(r[k], cA, cB);
+                }
+                acc[t] = fold4(a0, a1, a2, a3);
+            }
+        } else if (ib + 8 <= nl) {  // mixed: fast steps, each ring's terms times its 0/1 masks; rescale check after the 8 l
+            double mn[R], mp[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) { mn[k] = r[k].scn == 0 ? 1.0 : 0.0; mp[k] = r[k].scp == 0 ? 1.0 : 0.0; }
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+                const int t = 8 * h + tt;
+                const double cA = tt < 4 ? c0[2 * tt] : c1[2 * (tt - 4)];
+                const double cB = tt < 4 ? c0[2 * tt + 1] : c1[2 * (tt - 4) + 1];
+                double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    accum(t, k, r[k].n1 * mn[k], r[k].p1 * mp[k], a0, a1, a2, a3);
+                    recs_step_fast(r[k], cA, cB);
+                }
+                acc[t] = fold4(a0, a1, a2, a3);
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) recs_renorm_up(r[k]);
+        } else {  // last, partial tile: one careful step at a time
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+                const int t = 8 * h + tt;
+                const int i = ib + tt;
                 double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
                 if (i < nl) {
                     const double cA = tt < 4 ? c0[2 * tt] : c1[2 * (tt - 4)];
                     const double cB = tt < 4 ? c0[2 * tt + 1] : c1[2 * (tt - 4) + 1];
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
-                        double vn, vp;
-                        if (!all_active) { vn = recs_value_n(r[k]); vp = recs_value_p(r[k]); }
-                        else { vn = r[k].n1; vp = r[k].p1; }
-                        if ((t & 1) == 0) {
-                            a0 = fma(vn, aer[k], a0); a1 = fma(vn, aei[k], a1); a2 = fma(vn, aor[k], a2); a3 = fma(vn, aoi[k], a3);
-                            a0 = fma(vp, ber[k], a0); a1 = fma(vp, bei[k], a1); a2 = fma(-vp, bor[k], a2); a3 = fma(-vp, boi[k], a3);
-                        } else {
-                            a0 = fma(vn, aor[k], a0); a1 = fma(vn, aoi[k], a1); a2 = fma(vn, aer[k], a2); a3 = fma(vn, aei[k], a3);
-                            a0 = fma(vp, bor[k], a0); a1 = fma(vp, boi[k], a1); a2 = fma(-vp, ber[k], a2); a3 = fma(-vp, bei[k], a3);
-                        }
-                        if (!all_active) recs_step_careful(r[k], cA, cB);
-                        else recs_step_fast(r[k], cA, cB);
+                        accum(t, k, recs_value_n(r[k]), recs_value_p(r[k]), a0, a1, a2, a3);
+                        recs_step_careful(r[k], cA, cB);
                     }
                 }
-                acc[4 * t] = a0; acc[4 * t + 1] = a1; acc[4 * t + 2] = a2; acc[4 * t + 3] = a3;
+                acc[t] = fold4(a0, a1, a2, a3);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            sload_wait(n0, n1);
         }
+    };
+    {
+        bool live = false;
+#pragma unroll
+        for (int k = 0; k < R; ++k) live = live || r[k].scn != kNeverActive || r[k].scp != kNeverActive;
+        if (!wave_any(live)) {  // every ring of this wave is pruned for this m: the partial sums are zero
+            for (int i0 = 0; i0 < nl; i0 += T)
+                if (i0 + (lane >> 2) < nl) out[(int64_t)i0 * 4 + lane] = 0.0;
+            return;
+        }
+    }
+    for (int i0 = 0; i0 < nl; i0 += T) {
+        if (!any_active) {
+            bool act = false;
+#pragma unroll
+            for (int k = 0; k < R; ++k) act = act || r[k].scn == 0 || r[k].scp == 0;
+            any_active = wave_any(act);
+            if (!any_active) {
+                const int nt = min(T, nl - i0);
+                if (nt == T) {  // two blocks of 8 fast steps, rescale check after each (see rec0_renorm_up)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const d8v_t c0 = ld8(ab + i0 + 8 * h), c1 = ld8(ab + i0 + 8 * h + 4);
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const double ca = t < 4 ? c0[2 * t] : c1[2 * (t - 4)], cb = t < 4 ? c0[2 * t + 1] : c1[2 * (t - 4) + 1];
+#pragma unroll
+                            for (int k = 0; k < R; ++k) recs_step_fast(r[k], ca, cb);
+                        }
+#pragma unroll
+                        for (int k = 0; k < R; ++k) recs_renorm_up(r[k]);
+                    }
+                } else {
+                    for (int t = 0; t < nt; ++t) {
+                        const double2 c_ab = ab[i0 + t];
+#pragma unroll
+                        for (int k = 0; k < R; ++k) recs_step_careful(r[k], c_ab.x, c_ab.y);
+                    }
+                }
+                if (i0 + (lane >> 2) < nl) out[(int64_t)i0 * 4 + lane] = 0.0;
+                continue;
+            }
+        }
+        if (pfa != i0) { SA0 = ld8(ab + i0); SA1 = ld8(ab + i0 + 4); }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): SA has landed before SB is issued
+        SB0 = ld8(ab + i0 + 8); SB1 = ld8(ab + i0 + 12);
+        __builtin_amdgcn_sched_barrier(0);
+        half(std::integral_constant<int, 0>(), SA0, SA1, i0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        SA0 = ld8(ab + i0 + 16); SA1 = ld8(ab + i0 + 20);
+        pfa = i0 + 16;
+        __builtin_amdgcn_sched_barrier(0);
+        half(std::integral_constant<int, 1>(), SB0, SB1, i0 + 8);
+        __builtin_amdgcn_sched_barrier(0);
         if (!all_active) {
             bool done = true;
 #pragma unroll
@@ -758,8 +953,8 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
                 done = done && (r[k].scn == 0 || r[k].scn == kNeverActive) && (r[k].scp == 0 || r[k].scp == kNeverActive);
             all_active = wave_all(done);
         }
-        const double tot = reduce64_transpose(acc, lane);
-        if (i0 + (lane >> 2) < nl) out[(int64_t)i0 * 4 + lane] = tot;
+        const double tot = reduce16(acc, lane);
+        if (i0 + (lane & 15) < nl) out[(int64_t)(i0 + (lane & 15)) * 4 + fold4_component(lane)] = tot;
     }
 }
 
@@ -806,10 +1001,10 @@ static int env_int(const char *name, int dflt)
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-static int r0_synth() { static int r = env_int("PLSHTS_R0", 3); return r; }
-static int rs_synth() { static int r = env_int("PLSHTS_RS", 2); return r; }
-static int r0_anal() { static int r = env_int("PLSHTS_R0A", 4); return r; }
-static int rs_anal() { static int r = env_int("PLSHTS_RSA", 3); return r; }
+static int r0_synth() { static int r = env_int("PLSHTS_R0", 3); return r >= 1 && r <= 6 ? r : 3; }
+static int rs_synth() { static int r = env_int("PLSHTS_RS", 2); return r >= 1 && r <= 4 ? r : 2; }
+static int r0_anal() { static int r = env_int("PLSHTS_R0A", 4); return r >= 2 && r <= 6 ? r : 4; }
+static int rs_anal() { static int r = env_int("PLSHTS_RSA", 3); return r >= 1 && r <= 4 ? r : 3; }
 
 int rings_per_group(int spin) { return 64 * (spin == 0 ? r0_anal() : rs_anal()); }
 
@@ -882,6 +1077,8 @@ void launch_anal0(const DevPlan &P, const double *phase, double *partial, const 
     switch (r0_anal()) {
     case 2: launch_anal0_r<2>(P, phase, partial, fl, alm, st); break;
     case 3: launch_anal0_r<3>(P, phase, partial, fl, alm, st); break;
+    case 5: launch_anal0_r<5>(P, phase, partial, fl, alm, st); break;
+    case 6: launch_anal0_r<6>(P, phase, partial, fl, alm, st); break;
     default: launch_anal0_r<4>(P, phase, partial, fl, alm, st); break;
     }
 }
@@ -904,6 +1101,7 @@ void launch_anals(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent,
     switch (rs_anal()) {
     case 1: launch_anals_r<1>(P, S, spin, nent, phase, partial, fl, alm, st); break;
     case 2: launch_anals_r<2>(P, S, spin, nent, phase, partial, fl, alm, st); break;
+    case 4: launch_anals_r<4>(P, S, spin, nent, phase, partial, fl, alm, st); break;
     default: launch_anals_r<3>(P, S, spin, nent, phase, partial, fl, alm, st); break;
     }
 }

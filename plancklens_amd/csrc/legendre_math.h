@@ -79,6 +79,16 @@ PL_HD void rec0_step_careful(Rec0 &r, double A, double B)
     if (r.sc < 0 && fabs(r.p1) > kTBig) { r.p0 *= kFSmall; r.p1 *= kFSmall; r.sc += 1; }
 }
 
+// Deferred form of the careful step: a still-scaled lane may run up to 8 fast steps before this check.  One step
+// multiplies the value by at most |A| + |B| + 1 (resp. |a| + |b| + 1), which stays below 2^16 for every table entry at
+// lmax < 2^15, so at most 2^128 is gained between checks: far from overflow (2^256 * 2^128 << 2^1024) and a single
+// rescale is always enough.  A lane that crosses 2^-256 between checks is below 2^-128 when it is noticed; until
+// then it is left out of the sums, which is exact at double precision for any sum with an O(1) term.
+PL_HD void rec0_renorm_up(Rec0 &r)
+{
+    if (r.sc < 0 && fabs(r.p1) > kTBig) { r.p0 *= kFSmall; r.p1 *= kFSmall; r.sc += 1; }
+}
+
 // value usable in sums for the current il (0 while still scaled)
 PL_HD double rec0_value(const Rec0 &r) { return r.sc == 0 ? r.p1 : 0.0; }
 
@@ -119,6 +129,12 @@ PL_HD void recs_step_fast(RecS &r, double a, double b)
 PL_HD void recs_step_careful(RecS &r, double a, double b)
 {
     recs_step_fast(r, a, b);
+    if (r.scn < 0 && fabs(r.n1) > kTBig) { r.n0 *= kFSmall; r.n1 *= kFSmall; r.scn += 1; }
+    if (r.scp < 0 && fabs(r.p1) > kTBig) { r.p0 *= kFSmall; r.p1 *= kFSmall; r.scp += 1; }
+}
+
+PL_HD void recs_renorm_up(RecS &r)  // see rec0_renorm_up
+{
     if (r.scn < 0 && fabs(r.n1) > kTBig) { r.n0 *= kFSmall; r.n1 *= kFSmall; r.scn += 1; }
     if (r.scp < 0 && fabs(r.p1) > kTBig) { r.p0 *= kFSmall; r.p1 *= kFSmall; r.scp += 1; }
 }
