@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -12,7 +13,7 @@
 #include "ringfft.h"
 
 namespace plshts {
-int rings_per_group(int spin);
+int rings_per_group(int spin, const DevPlan &P);
 void launch_prep0(const DevPlan &P, const double *alm, const double *fl, double *prep, hipStream_t st);
 void launch_preps(const DevPlan &P, const DevSpinTab &S, int spin, const double *alm, const double *fl, double *prep, hipStream_t st);
 void launch_synth0(const DevPlan &P, const double *prep, double *phase, hipStream_t st);
@@ -179,34 +180,72 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
     rc = rc || upload(p, mlim, &P.mlim0);
     if (rc) { pl_plan_destroy(p); return 1; }
 
-    // FFT tables: ring lengths 4 q, q = 1 .. nside
+    // FFT tables: ring lengths 4 q, q = 1 .. nside.  Every ring pair is served either by a register-resident kernel of
+    // transform size N = 256 << c (ringfft.hip) or, for the short polar rings and anything unusual, by the
+    // LDS-resident generic kernel ("legacy" list).  PLSHTS_FFT_LEGACY=1 sends every pair to the generic kernel.
     DevFFT &F = p->F;
-    std::vector<int> Mof(nside + 1, 0), qlist;
-    std::vector<int64_t> woff(nside + 1, 0), coff(nside + 1, 0);
-    int64_t nw = 0, nc = 0;
-    int Lmax = 1;
+    const bool all_legacy = getenv("PLSHTS_FFT_LEGACY") && atoi(getenv("PLSHTS_FFT_LEGACY")) != 0;
+    std::vector<int> K2of(nside + 1, 0), M2of(nside + 1, 0), clsof(nside + 1, -1);
+    {
+        std::vector<int> mlmax(nside + 1, 0);
+        for (int i = 0; i < g.npairs; ++i) {
+            const int q = g.nphi[i] / 4;
+            for (int s = 0; s <= kMaxSpin; ++s) {
+                int ml = mlim_ring(lmax, s, g.sth[i], g.cth[i]);
+                if (ml > lmax) ml = lmax;
+                if (ml > mlmax[q]) mlmax[q] = ml;
+            }
+        }
+        for (int q = 1; q <= nside; ++q) {
+            const int K = (mlmax[q] + 3) / 4 + 1;  // sub-DFT inputs c = k1 or k1 - q with 4 |c| <= mlim + 3
+            K2of[q] = K;
+            if (all_legacy) continue;
+            int N = 0;
+            if (2 * K + 1 >= q) continue;                               // aliased ring (mlim >= n / 2 - 5): generic kernel
+            if ((q & (q - 1)) == 0) { if (q >= 256) N = q; }           // the ring's own sub-DFT length
+            else { N = 256; while (N < q + 2 * K + 1) N <<= 1; M2of[q] = N; }
+            if (N >= 256 && N <= 4096) { int c = 0; while ((256 << c) < N) ++c; clsof[q] = c; }
+            else M2of[q] = 0;
+        }
+    }
+    std::vector<int> cls_list[5], legacy_list;
+    for (int i = g.npairs - 1; i >= 0; --i) {  // longest rings first
+        const int c = clsof[g.nphi[i] / 4];
+        if (c >= 0) cls_list[c].push_back(i); else legacy_list.push_back(i);
+    }
+    std::vector<int> Mof(nside + 1, 0), qlist, qlist2;
+    std::vector<int64_t> woff(nside + 1, 0), coff(nside + 1, 0), coff2(nside + 1, 0);
+    int64_t nw = 0, nc = 0, nc2 = 0;
+    int Lmax = 1, M2max = 2;
     for (int q = 1; q <= nside; ++q) {
-        bool present = (q < nside) || true;  // q = nside: equatorial rings
-        if (!present) continue;
-        if ((q & (q - 1)) == 0) { Mof[q] = 0; if (q > Lmax) Lmax = q; continue; }
+        if ((q & (q - 1)) == 0) { if (clsof[q] < 0 && q > Lmax) Lmax = q; continue; }
+        woff[q] = nw; nw += q;
+        qlist.push_back(q);
+        if (clsof[q] >= 0) {
+            coff2[q] = nc2; nc2 += M2of[q];
+            if (M2of[q] > M2max) M2max = M2of[q];
+            qlist2.push_back(q);
+            continue;
+        }
         int M = 2;
         while (M < 2 * q - 1) M <<= 1;
-        Mof[q] = M; woff[q] = nw; coff[q] = nc; nw += q; nc += M;
+        Mof[q] = M; coff[q] = nc; nc += M;
         if (M > Lmax) Lmax = M;
-        qlist.push_back(q);
     }
-    F.Mtw = Lmax < 2 ? 2 : Lmax;
     F.Lmax = Lmax;
+    F.Mtw = Lmax < 2 ? 2 : Lmax;
+    if (F.Mtw < M2max) F.Mtw = M2max;
+    for (int c = 0; c < 5; ++c) if (!cls_list[c].empty() && F.Mtw < (256 << c)) F.Mtw = 256 << c;
     if ((size_t)Lmax * 16 > 160 * 1024) { pl_plan_destroy(p); return fail("ring FFT workspace exceeds the 160 KiB LDS of a CU"); }
-    {   // LDS twiddle tables of the largest transform (radix-8 passes + one radix-4/2 tail), if they fit beside it
+    {   // LDS twiddle tables of the largest generic transform (radix-8 passes + one radix-4/2 tail), if they fit beside it
         int k = 0; while ((1 << k) < Lmax) ++k;
         const int rt = (k % 3 == 0) ? 8 : (k % 3 == 2 ? 4 : 2);
         int tot = (rt == 8 ? 3 : rt == 4 ? 2 : 1);
         for (int64_t L = (int64_t)rt * 8; L <= Lmax; L *= 8) tot += 3 * (int)(L / 8);
         F.twl_cap = ((size_t)(Lmax + tot) * 16 <= 160 * 1024) ? tot : 0;
     }
-    double *tw = nullptr, *chirp = nullptr, *filt = nullptr;
-    const int *qlist_dev = nullptr;
+    double *tw = nullptr, *chirp = nullptr, *filt = nullptr, *filt2 = nullptr;
+    const int *qlist_dev = nullptr, *qlist2_dev = nullptr;
     auto dalloc = [&](double **ptr, int64_t nd) -> int {
         if (nd < 2) nd = 2;
         HIPCHK(hipMalloc(reinterpret_cast<void **>(ptr), nd * sizeof(double)));
@@ -214,14 +253,19 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
         p->bytes += nd * 8;
         return 0;
     };
-    rc = dalloc(&tw, F.Mtw) || dalloc(&chirp, 2 * nw) || dalloc(&filt, 2 * nc) || upload(p, Mof, &F.Mof) || upload(p, woff, &F.woff) ||
-         upload(p, coff, &F.coff) || upload(p, qlist, &qlist_dev);
+    rc = dalloc(&tw, F.Mtw) || dalloc(&chirp, 2 * nw) || dalloc(&filt, 2 * nc) || dalloc(&filt2, 2 * nc2) || upload(p, Mof, &F.Mof) ||
+         upload(p, woff, &F.woff) || upload(p, coff, &F.coff) || upload(p, qlist, &qlist_dev) || upload(p, qlist2, &qlist2_dev) ||
+         upload(p, K2of, &F.K2of) || upload(p, M2of, &F.M2of) || upload(p, coff2, &F.coff2) || upload(p, legacy_list, &F.legacy_pairs);
+    F.legacy_n = (int)legacy_list.size();
+    for (int c = 0; c < 5 && !rc; ++c) { rc = upload(p, cls_list[c], &F.cls_pairs[c]); F.cls_n[c] = (int)cls_list[c].size(); }
     if (rc) { pl_plan_destroy(p); return 1; }
     F.tw = reinterpret_cast<const double2 *>(tw);
     F.chirp = reinterpret_cast<const double2 *>(chirp);
     F.filt = reinterpret_cast<const double2 *>(filt);
+    F.filt2 = reinterpret_cast<const double2 *>(filt2);
     hipError_t e = launch_twiddles(tw, F.Mtw, nullptr);
     if (e == hipSuccess) e = launch_bluestein_setup(F, qlist_dev, (int)qlist.size(), chirp, filt, nullptr);
+    if (e == hipSuccess) e = launch_bluestein_setup2(F, qlist2_dev, (int)qlist2.size(), M2max, filt2, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { pl_plan_destroy(p); return fail(std::string("FFT table setup: ") + hipGetErrorString(e)); }
     *out = p;
@@ -296,7 +340,7 @@ int pl_legendre_anal(pl_plan *p, int spin, const double *phase, double *alm, con
 {
     if (!p) return fail("null plan");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int RG = rings_per_group(spin);
+    const int RG = rings_per_group(spin, p->P);
     const int ngroups = (p->P.npairs + RG - 1) / RG;
     if (spin == 0) {
         if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * p->P.nent0 * 4)) return 1;

@@ -1001,12 +1001,24 @@ static int env_int(const char *name, int dflt)
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-static int r0_synth() { static int r = env_int("PLSHTS_R0", 3); return r >= 1 && r <= 6 ? r : 3; }
-static int rs_synth() { static int r = env_int("PLSHTS_RS", 2); return r >= 1 && r <= 4 ? r : 2; }
-static int r0_anal() { static int r = env_int("PLSHTS_R0A", 4); return r >= 2 && r <= 6 ? r : 4; }
-static int rs_anal() { static int r = env_int("PLSHTS_RSA", 3); return r >= 1 && r <= 4 ? r : 3; }
+// Ring pairs per lane (R): more rings per lane amortise the per-l overhead (coefficient fetch, cross-lane reduce) but
+// coarsen the polar pruning and shrink the grid.  The defaults are the measured optima at nside = lmax = 2048; smaller
+// transforms step R down until the grid has at least ~4 workgroups per CU.  PLSHTS_R0 / RS / R0A / RSA override.
+static int pick_r(const char *env, int dflt, int rmax, const DevPlan &P)
+{
+    const int e = env_int(env, 0);
+    if (e >= 1 && e <= rmax) return e;
+    int r = dflt;
+    const int nmg = (P.mmax + 4) / 4;
+    while (r > 1 && (int64_t)((P.npairs + 64 * r - 1) / (64 * r)) * nmg < 1024) --r;
+    return r;
+}
+static int r0_synth(const DevPlan &P) { return pick_r("PLSHTS_R0", 3, 6, P); }
+static int rs_synth(const DevPlan &P) { return pick_r("PLSHTS_RS", 2, 4, P); }
+static int r0_anal(const DevPlan &P) { return pick_r("PLSHTS_R0A", 6, 6, P); }
+static int rs_anal(const DevPlan &P) { return pick_r("PLSHTS_RSA", 4, 4, P); }
 
-int rings_per_group(int spin) { return 64 * (spin == 0 ? r0_anal() : rs_anal()); }
+int rings_per_group(int spin, const DevPlan &P) { return 64 * (spin == 0 ? r0_anal(P) : rs_anal(P)); }
 
 void launch_prep0(const DevPlan &P, const double *alm, const double *fl, double *prep, hipStream_t st)
 {
@@ -1032,7 +1044,7 @@ static void launch_synth0_r(const DevPlan &P, const double *prep, double *phase,
 
 void launch_synth0(const DevPlan &P, const double *prep, double *phase, hipStream_t st)
 {
-    switch (r0_synth()) {
+    switch (r0_synth(P)) {
     case 1: launch_synth0_r<1>(P, prep, phase, st); break;
     case 2: launch_synth0_r<2>(P, prep, phase, st); break;
     case 5: launch_synth0_r<5>(P, prep, phase, st); break;
@@ -1053,7 +1065,7 @@ static void launch_synths_r(const DevPlan &P, const DevSpinTab &S, int spin, con
 
 void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st)
 {
-    switch (rs_synth()) {
+    switch (rs_synth(P)) {
     case 1: launch_synths_r<1>(P, S, spin, prep, phase, st); break;
     case 3: launch_synths_r<3>(P, S, spin, prep, phase, st); break;
     case 4: launch_synths_r<4>(P, S, spin, prep, phase, st); break;
@@ -1074,7 +1086,8 @@ static void launch_anal0_r(const DevPlan &P, const double *phase, double *partia
 
 void launch_anal0(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st)
 {
-    switch (r0_anal()) {
+    switch (r0_anal(P)) {
+    case 1: launch_anal0_r<1>(P, phase, partial, fl, alm, st); break;
     case 2: launch_anal0_r<2>(P, phase, partial, fl, alm, st); break;
     case 3: launch_anal0_r<3>(P, phase, partial, fl, alm, st); break;
     case 5: launch_anal0_r<5>(P, phase, partial, fl, alm, st); break;
@@ -1098,7 +1111,7 @@ static void launch_anals_r(const DevPlan &P, const DevSpinTab &S, int spin, int6
 void launch_anals(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
                   const double *fl, double *alm, hipStream_t st)
 {
-    switch (rs_anal()) {
+    switch (rs_anal(P)) {
     case 1: launch_anals_r<1>(P, S, spin, nent, phase, partial, fl, alm, st); break;
     case 2: launch_anals_r<2>(P, S, spin, nent, phase, partial, fl, alm, st); break;
     case 4: launch_anals_r<4>(P, S, spin, nent, phase, partial, fl, alm, st); break;

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(NT) void k_bluestein_setup(DevFFT F, const int *__r
 {
     extern __shared__ double2 ws[];
     const int q = qlist[blockIdx.x];
-    const int M = F.Mof[q];
+    const int M = F.Mof[q];  // 0: this q is served by a register-resident class, only its chirp is needed
     double2 *chirp = chirp_out + F.woff[q];
     double2 *filt = filt_out + F.coff[q];
     for (int t = threadIdx.x; t < M; t += NT) ws[t] = make_double2(0., 0.);
@@ -228,10 +228,12 @@ __global__ __launch_bounds__(NT) void k_bluestein_setup(DevFFT F, const int *__r
         const long long t2 = ((long long)t * t) % (2LL * q);
         const double2 w = cispi((double)t2 / (double)q);  // e^{i pi t^2 / q}
         chirp[t] = w;
+        if (M == 0) continue;
         const double2 c = cconj(w);
         ws[t] = c;
         if (t > 0) ws[M - t] = c;
     }
+    if (M == 0) return;
     fft_dif_fwd<NT>(ws, M, nullptr, F.tw, F.Mtw);
     const double inv = 1.0 / M;
     for (int t = threadIdx.x; t < M; t += NT) filt[t] = make_double2(ws[t].x * inv, ws[t].y * inv);
@@ -248,11 +250,11 @@ __global__ void k_twiddles(double2 *tw, int Mtw)
 // synthesis: phase -> pixels
 // -----------------------------------------------------------------------------------------------------
 template <int NT, int QMAX>
-__global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int *__restrict__ mlim, int ncomp,
+__global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim, int ncomp,
                                                   const double *__restrict__ phase, double *__restrict__ map, int dbg)
 {
     extern __shared__ double2 ws[];
-    const int ip = P.npairs - 1 - blockIdx.x;  // largest rings first
+    const int ip = pairs[blockIdx.x];  // largest rings first
     const int comp = blockIdx.y;
     const int n = P.nphi[ip], q = n >> 2;
     const int M = F.Mof[q];
@@ -336,11 +338,11 @@ __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int
 // analysis: pixels -> phase (uniform quadrature weights 4 pi / npix)
 // -----------------------------------------------------------------------------------------------------
 template <int NT, int QMAX>
-__global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int *__restrict__ mlim, int ncomp,
+__global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim, int ncomp,
                                                   const double *__restrict__ map, double *__restrict__ phase)
 {
     extern __shared__ double2 ws[];
-    const int ip = P.npairs - 1 - blockIdx.x;
+    const int ip = pairs[blockIdx.x];
     const int comp = blockIdx.y;
     const int n = P.nphi[ip], q = n >> 2;
     const int M = F.Mof[q];
@@ -449,6 +451,340 @@ __global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int
     }
 }
 
+// =====================================================================================================
+// Register-resident path for the long rings (sub-DFT or Bluestein convolution size N = 512 ... 4096)
+// =====================================================================================================
+// One workgroup of G = N / 8 threads per ring pair and component; every thread keeps 8 points of each of the four
+// sub-DFTs in registers (4 x 8 complex).  A size-N transform is a Stockham autosort FFT: radix-8 butterflies in
+// registers, data exchanged between passes through one N-point LDS buffer (natural order in, natural order out, so
+// neither the direct nor the Bluestein route needs a reordering pass).  Thread tl always owns points tl + G j.
+// LDS slots are XOR-swizzled so that both the stride-8^p stores (ds_write_b128: 8-lane groups, 32 banks) and the
+// unit-stride loads (ds_read_b128: 16-lane groups, 64 banks) are conflict-free.
+// Bluestein here uses the band limit of the ring: only the bins |m| <= mlim are non-zero, i.e. sub-DFT inputs
+// c in [-K, K] (K = F.K2of[q]), so a convolution of size N >= q + 2 K + 1 is enough (instead of 2 q - 1).
+__device__ __forceinline__ int swz(int i) { return i ^ ((i >> 3) & 7); }
+// Launders a table index: the kernels below are fully unrolled and hipcc would otherwise load every table entry once
+// at the top and keep it in registers across all four sub-DFTs (CSE of identical loads: > 400 VGPRs, occupancy 1).
+__device__ __forceinline__ int fresh(int i) { asm volatile("" : "+v"(i)); return i; }
+
+template <int N>
+struct Tw8 {
+    static constexpr int P8 = (N >= 4096) ? 4 : (N >= 512) ? 3 : 2;   // radix-8 passes
+    static constexpr int T = N >> (3 * P8);           // tail radix: 1, 2 or 4
+    double2 w[P8 - 1];                                // pass p = 1 .. P8-1: W_L^k, L = 8^(p+1), k = tl mod 8^p
+    double2 wt[T == 2 ? 4 : 2];                       // tail: W_N^(tl + G u) of its 8 / T butterflies
+};
+
+template <int N>
+__device__ __forceinline__ void tw8_load(Tw8<N> &t, int tl, const double2 *__restrict__ tw, int Mtw)
+{
+    constexpr int G = N / 8;
+#pragma unroll
+    for (int p = 1; p < Tw8<N>::P8; ++p) {
+        const int L = 1 << (3 * (p + 1));
+        t.w[p - 1] = tw[(tl & ((1 << (3 * p)) - 1)) * (Mtw / L)];
+    }
+    if constexpr (Tw8<N>::T > 1) {
+#pragma unroll
+        for (int u = 0; u < 8 / Tw8<N>::T; ++u) t.wt[u] = tw[(tl + G * u) * (Mtw / N)];
+    }
+}
+
+template <bool FWD>
+__device__ __forceinline__ double2 twmul(double2 a, double2 w) { return FWD ? cmul(a, w) : cmulc(a, w); }
+
+// x[j] = point tl + G j on entry and on return; FWD: e^{-2 pi i jk/N}, else e^{+2 pi i jk/N} (unnormalised).
+// Powers of a twiddle are formed by multiplication (at most 3 products deep: ~4 ulp), which keeps one complex
+// number per pass in registers instead of seven.
+template <int N, bool FWD>
+__device__ __forceinline__ void fft8(double2 (&x)[8], double2 *lds, int tl, const Tw8<N> &tw)
+{
+    constexpr int G = N / 8, P8 = Tw8<N>::P8, T = Tw8<N>::T;
+    // sched_barrier: hipcc otherwise hoists the table loads of every later phase of the fully unrolled kernel to the
+    // top (hundreds of VGPRs in flight, occupancy 1)
+    __builtin_amdgcn_sched_barrier(0);
+    dft_small<8, FWD>(x);  // pass 0: sub-transform length 1, no twiddles
+#pragma unroll
+    for (int p = 1; p <= P8; ++p) {
+        if (p == P8 && T == 1) break;
+        // results of pass p - 1 (sub-transform length Ns = 8^(p-1)) go to (tl / Ns) * 8 Ns + (tl mod Ns) + r Ns
+        const int Ns = 1 << (3 * (p - 1));
+        const int base = ((tl >> (3 * (p - 1))) << (3 * p)) | (tl & (Ns - 1));
+        __syncthreads();  // every thread is done reading the previous contents
+#pragma unroll
+        for (int r = 0; r < 8; ++r) lds[swz(base + r * Ns)] = x[r];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = lds[swz(tl + G * j)];
+        if (p < P8) {
+            const double2 w1 = tw.w[p - 1], w2 = cmul(w1, w1), w3 = cmul(w1, w2), w4 = cmul(w2, w2);
+            const double2 w5 = cmul(w1, w4), w6 = cmul(w2, w4), w7 = cmul(w3, w4);
+            x[1] = twmul<FWD>(x[1], w1); x[2] = twmul<FWD>(x[2], w2); x[3] = twmul<FWD>(x[3], w3); x[4] = twmul<FWD>(x[4], w4);
+            x[5] = twmul<FWD>(x[5], w5); x[6] = twmul<FWD>(x[6], w6); x[7] = twmul<FWD>(x[7], w7);
+            dft_small<8, FWD>(x);
+        } else if constexpr (T == 2) {  // 4 radix-2 butterflies: points u and u + 4, twiddle W_N^(tl + G u)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double2 a = x[u], b = twmul<FWD>(x[u + 4], tw.wt[u]);
+                x[u] = cadd(a, b); x[u + 4] = csub(a, b);
+            }
+        } else if constexpr (T == 4) {  // 2 radix-4 butterflies: points u, u + 2, u + 4, u + 6
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const double2 w1 = tw.wt[u], w2 = cmul(w1, w1), w3 = cmul(w1, w2);
+                double2 y[4] = {x[u], twmul<FWD>(x[u + 2], w1), twmul<FWD>(x[u + 4], w2), twmul<FWD>(x[u + 6], w3)};
+                dft_small<4, FWD>(y);
+                x[u] = y[0]; x[u + 2] = y[1]; x[u + 4] = y[2]; x[u + 6] = y[3];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// The register classes are only used for rings without aliasing (mlim < n / 2 - 5, see pl_plan_create), so every
+// spectrum bin k = 4 k1 + k2 holds at most one term: frequency +k when k <= mlim, else -(n - k) when n - k <= mlim.
+// Slot idx = tl + G j of a thread is sub-DFT bin k1 = idx (direct, or Bluestein input c = idx >= 0) or, in the
+// Bluestein classes, c = idx - N < 0, i.e. k1 = q + c.  sgn: +1 positive-frequency side, -1 negative side, 0 out of band.
+struct FastBin { int k1, cabs, sgn; };
+__device__ __forceinline__ FastBin fast_bin(bool blue, int idx, int N, int q, int K)
+{
+    FastBin b;
+    if (!blue) { b.k1 = idx; b.cabs = 0; b.sgn = 2 * idx < q ? 1 : -1; return b; }  // direct: first half +, second half -
+    if (idx <= K) { b.k1 = idx; b.cabs = idx; b.sgn = 1; return b; }
+    if (idx >= N - K) { b.k1 = q - (N - idx); b.cabs = N - idx; b.sgn = -1; return b; }
+    b.k1 = 0; b.cabs = 0; b.sgn = 0;
+    return b;
+}
+
+template <int N>
+__global__ __launch_bounds__(N / 8) void k_phase2map_fast(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim,
+                                                          int ncomp, const double *__restrict__ phase, double *__restrict__ map)
+{
+    extern __shared__ double2 lds[];
+    constexpr int G = N / 8;
+    const int tl = threadIdx.x;
+    const int ip = pairs[blockIdx.x], comp = blockIdx.y;
+    const int n = P.nphi[ip], q = n >> 2;
+    const bool blue = q != N;
+    const int K = F.K2of[q];
+    const double2 *__restrict__ chirp = F.chirp + F.woff[q];
+    const double2 *__restrict__ filt = F.filt2 + F.coff2[q];
+    const int ml = min(mlim[ip], P.mmax);
+    const bool shifted = P.phi0[ip] != 0.0;
+    const double inv_n = 1.0 / n;
+    const int estride = 4 * ncomp;
+    const double *__restrict__ ph = phase + (int64_t)ip * P.mstride * estride + comp * 4;
+    Tw8<N> tw;
+    tw8_load<N>(tw, tl, F.tw, F.Mtw);
+
+    // Ring offset phase e^{i pi m / n} of the shifted rings by recurrence: with Pk = e^{i pi k / n}, k = 4 idx + k2,
+    // the positive side (m = k) needs Pk and the negative side (m = 4 (N - idx) - k2) needs e^{i pi 4 N / n} conj(Pk)
+    double2 pj = make_double2(1., 0.), pstep = pj, s1 = pj, s2 = pj, s3 = pj, uneg = pj;
+    if (shifted) {
+        pj = cispi(4.0 * tl * inv_n); pstep = cispi(4.0 * G * inv_n);
+        s1 = cispi(inv_n); s2 = cmul(s1, s1); s3 = cmul(s2, s1);
+        uneg = cispi(4.0 * N * inv_n);
+    }
+    // gather: d[k2][j] = z_(4 k1 + k2) (times the chirp), z = f_N + i f_S (+ side) or conj(f_N) + i conj(f_S) (- side)
+    double2 d[4][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
+        double2 cw = make_double2(1., 0.);
+        if (blue && b.sgn != 0) cw = chirp[fresh(b.cabs)];
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            const int k = 4 * b.k1 + k2;
+            const int m = b.sgn > 0 ? k : n - k;
+            double2 z = make_double2(0., 0.);
+            if (b.sgn != 0 && m <= ml) {
+                const double4 f = *reinterpret_cast<const double4 *>(ph + (int64_t)m * estride);
+                double2 fn = make_double2(f.x, f.y), fs = make_double2(f.z, f.w);
+                if (shifted) {
+                    const double2 pk = cmul(pj, k2 == 0 ? make_double2(1., 0.) : k2 == 1 ? s1 : k2 == 2 ? s2 : s3);
+                    const double2 pm = b.sgn > 0 ? pk : cmulc(uneg, pk);
+                    fn = cmul(fn, pm); fs = cmul(fs, pm);
+                }
+                z = b.sgn > 0 ? make_double2(fn.x - fs.y, fn.y + fs.x) : make_double2(fn.x + fs.y, -fn.y + fs.x);
+            }
+            d[k2][j] = cmul(z, cw);
+        }
+        pj = cmul(pj, pstep);
+        if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // keep at most 8 x 32-byte loads in flight per thread
+    }
+    // the four sub-DFTs, in place
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+        if (blue) {
+            fft8<N, true>(d[k2], lds, tl, tw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[k2][j] = cmul(d[k2][j], filt[fresh(tl + G * j)]);
+            fft8<N, false>(d[k2], lds, tl, tw);
+        } else {
+            fft8<N, false>(d[k2], lds, tl, tw);
+        }
+    }
+    // twiddle e^{2 pi i j1 k2 / n} (recurrence over j), radix-4 butterfly over k2, pixels j = j1 + q j2
+    double *__restrict__ mp = map + (int64_t)comp * P.npix;
+    const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
+    double2 e1 = cispi(2.0 * tl * inv_n);
+    const double2 estep = cispi(2.0 * G * inv_n);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int j1 = tl + G * j;
+        if (j1 < q) {
+            const double2 cw = blue ? chirp[fresh(j1)] : make_double2(1., 0.);
+            const double2 e2 = cmul(e1, e1), e3 = cmul(e2, e1);
+            double2 y[4] = {cmul(d[0][j], cw), cmul(d[1][j], cmul(cw, e1)), cmul(d[2][j], cmul(cw, e2)), cmul(d[3][j], cmul(cw, e3))};
+            dft_small<4, false>(y);  // y[j2] = sum_k2 i^(j2 k2) y_k2
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                mp[on + j1 + q * j2] = y[j2].x;
+                if (os >= 0) mp[os + j1 + q * j2] = y[j2].y;
+            }
+        }
+        e1 = cmul(e1, estep);
+        if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(N / 8) void k_map2phase_fast(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim,
+                                                          int ncomp, const double *__restrict__ map, double *__restrict__ phase)
+{
+    extern __shared__ double2 lds[];
+    constexpr int G = N / 8;
+    const int tl = threadIdx.x;
+    const int ip = pairs[blockIdx.x], comp = blockIdx.y;
+    const int n = P.nphi[ip], q = n >> 2;
+    const bool blue = q != N;
+    const int K = F.K2of[q];
+    const double2 *__restrict__ chirp = F.chirp + F.woff[q];
+    const double2 *__restrict__ filt = F.filt2 + F.coff2[q];
+    const int ml = min(mlim[ip], P.mmax);
+    const bool shifted = P.phi0[ip] != 0.0;
+    const double inv_n = 1.0 / n;
+    const int estride = 4 * ncomp;
+    double *__restrict__ ph = phase + (int64_t)ip * P.mstride * estride + comp * 4;
+    const double wgt = 0.5 * 4.0 * 3.14159265358979323846 / (double)P.npix;  // includes the 1/2 of the N/S split
+    const double *__restrict__ mp = map + (int64_t)comp * P.npix;
+    const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
+    const bool has_s = os >= 0;
+    Tw8<N> tw;
+    tw8_load<N>(tw, tl, F.tw, F.Mtw);
+
+    // conj(z_j) = north - i south at j = j1 + q j2; radix-4 over j2, twiddle, (chirp): d[k2][j] = input j1 of sub-DFT k2
+    double2 d[4][8];
+    {
+        double2 e1 = cispi(2.0 * tl * inv_n);
+        const double2 estep = cispi(2.0 * G * inv_n);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int j1 = tl + G * j;
+            double2 y[4];
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                y[j2] = make_double2(0., 0.);
+                if (j1 < q) {
+                    y[j2].x = mp[on + j1 + q * j2];
+                    y[j2].y = has_s ? -mp[os + j1 + q * j2] : 0.0;
+                }
+            }
+            dft_small<4, false>(y);  // y[k2] = sum_j2 i^(j2 k2) zc_j2
+            double2 cw = make_double2(1., 0.);
+            if (blue && j1 < q) cw = chirp[fresh(j1)];
+            const double2 e2 = cmul(e1, e1), e3 = cmul(e2, e1);
+            d[0][j] = cmul(y[0], cw); d[1][j] = cmul(y[1], cmul(cw, e1)); d[2][j] = cmul(y[2], cmul(cw, e2)); d[3][j] = cmul(y[3], cmul(cw, e3));
+            e1 = cmul(e1, estep);
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // sub-DFTs: d[k2][j] becomes V_(4 k1 + k2), V = conj(Z), at the in-band slots of this thread
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+        if (blue) {
+            fft8<N, true>(d[k2], lds, tl, tw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[k2][j] = cmul(d[k2][j], filt[fresh((N - (tl + G * j)) & (N - 1))]);  // spectrum of the mirrored filter
+            fft8<N, false>(d[k2], lds, tl, tw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
+                if (b.sgn != 0) d[k2][j] = cmul(d[k2][j], chirp[fresh(b.cabs)]);
+            }
+        } else {
+            fft8<N, false>(d[k2], lds, tl, tw);
+        }
+    }
+    // F_N, F_S of order m from V_m and its mirror V_(n - m): the thread owning the + side bin k1 emits m = 4 k1 + k2 after
+    // fetching the mirror value from the - side owner through LDS.  Mirror of (k1, k2): k2 = 0: (q - k1) mod q, same k2;
+    // k2 = 1, 2, 3: k1' = q - 1 - k1 with k2' = 4 - k2.
+    double2 pj = make_double2(1., 0.), pstep = pj, s1 = pj, s2 = pj, s3 = pj;
+    if (shifted) {
+        pj = cispi(4.0 * tl * inv_n); pstep = cispi(4.0 * G * inv_n);
+        s1 = cispi(inv_n); s2 = cmul(s1, s1); s3 = cmul(s2, s1);
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+        const int k2m = (4 - k2) & 3;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
+            if (b.sgn < 0 || (b.sgn > 0 && b.k1 == 0)) lds[swz(b.k1)] = d[k2m][j];  // - side values of sub-DFT k2m (bin 0 is its own mirror)
+        }
+        __syncthreads();
+        double2 pjj = pj;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
+            const int m = 4 * b.k1 + k2;
+            if (b.sgn > 0 && m <= ml) {
+                const int k1m = k2 == 0 ? (b.k1 == 0 ? 0 : q - b.k1) : q - 1 - b.k1;
+                const double2 a = cconj(d[k2][j]);        // conj(V_m) = Z_m
+                const double2 vm = lds[swz(k1m)];         // V_(n - m)
+                double2 fn = cadd(a, vm);
+                const double2 dd = csub(a, vm);
+                double2 fs = make_double2(dd.y, -dd.x);   // (conj(V_m) - V_(n-m)) / i
+                if (shifted) {
+                    const double2 pk = cmul(pjj, k2 == 0 ? make_double2(1., 0.) : k2 == 1 ? s1 : k2 == 2 ? s2 : s3);
+                    fn = cmulc(fn, pk); fs = cmulc(fs, pk);   // e^{-i pi m / n}
+                }
+                double4 o;
+                o.x = fn.x * wgt; o.y = fn.y * wgt;
+                o.z = has_s ? fs.x * wgt : 0.0; o.w = has_s ? fs.y * wgt : 0.0;
+                *reinterpret_cast<double4 *>(ph + (int64_t)m * estride) = o;
+            }
+            pjj = cmul(pjj, pstep);
+            if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// plan-time: natural-order spectrum (times 1/M) of the wrapped conjugate chirp h_d = e^{-i pi d^2 / q}, d in [-K, q-1+K]
+template <int NT>
+__global__ __launch_bounds__(NT) void k_bluestein_setup2(DevFFT F, const int *__restrict__ qlist, double2 *__restrict__ filt_out)
+{
+    extern __shared__ double2 ws[];
+    const int q = qlist[blockIdx.x];
+    const int M = F.M2of[q], K = F.K2of[q];
+    double2 *filt = filt_out + F.coff2[q];
+    for (int t = threadIdx.x; t < M; t += NT) ws[t] = make_double2(0., 0.);
+    __syncthreads();
+    for (int t = threadIdx.x; t < q + 2 * K; t += NT) {
+        const int dd = t - K;  // -K .. q - 1 + K
+        const long long t2 = ((long long)dd * dd) % (2LL * q);
+        const double2 w = cispi((double)t2 / (double)q);
+        ws[(dd + M) & (M - 1)] = cconj(w);
+    }
+    fft_dif_fwd<NT>(ws, M, nullptr, F.tw, F.Mtw);
+    const double inv = 1.0 / M;
+    for (int t = threadIdx.x; t < M; t += NT) {
+        const double2 v = ws[digit_reverse(t, M)];
+        filt[t] = make_double2(v.x * inv, v.y * inv);
+    }
+}
+
 // -----------------------------------------------------------------------------------------------------
 // host launchers
 // -----------------------------------------------------------------------------------------------------
@@ -458,6 +794,7 @@ template <int NT, int QMAX>
 static hipError_t launch_p2m(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *phase, double *map,
                              hipStream_t st)
 {
+    if (F.legacy_n == 0) return hipSuccess;
     const size_t lds = fft_lds_bytes(F);
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
@@ -467,7 +804,7 @@ static hipError_t launch_p2m(const DevPlan &P, const DevFFT &F, const int *mlim,
         attr_done = true;
     }
     static int dbg = getenv("PLSHTS_FFTDBG") ? atoi(getenv("PLSHTS_FFTDBG")) : 0;
-    hipLaunchKernelGGL((k_phase2map<NT, QMAX>), dim3(P.npairs, ncomp), dim3(NT), lds, st, P, F, mlim, ncomp, phase, map, dbg);
+    hipLaunchKernelGGL((k_phase2map<NT, QMAX>), dim3(F.legacy_n, ncomp), dim3(NT), lds, st, P, F, F.legacy_pairs, mlim, ncomp, phase, map, dbg);
     return hipGetLastError();
 }
 
@@ -475,6 +812,7 @@ template <int NT, int QMAX>
 static hipError_t launch_m2p(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *map, double *phase,
                              hipStream_t st)
 {
+    if (F.legacy_n == 0) return hipSuccess;
     const size_t lds = fft_lds_bytes(F);
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
@@ -483,7 +821,7 @@ static hipError_t launch_m2p(const DevPlan &P, const DevFFT &F, const int *mlim,
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_map2phase<NT, QMAX>), dim3(P.npairs, ncomp), dim3(NT), lds, st, P, F, mlim, ncomp, map, phase);
+    hipLaunchKernelGGL((k_map2phase<NT, QMAX>), dim3(F.legacy_n, ncomp), dim3(NT), lds, st, P, F, F.legacy_pairs, mlim, ncomp, map, phase);
     return hipGetLastError();
 }
 
@@ -499,16 +837,63 @@ static hipError_t launch_m2p(const DevPlan &P, const DevFFT &F, const int *mlim,
         return hipErrorInvalidValue;                                        \
     } while (0)
 
+static hipError_t launch_phase2map_legacy(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *phase, double *map,
+                                          hipStream_t st)
+{
+    PL_FFT_DISPATCH(launch_p2m, P, F, mlim, ncomp, phase, map, st);
+}
+
+static hipError_t launch_map2phase_legacy(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *map, double *phase,
+                                          hipStream_t st)
+{
+    PL_FFT_DISPATCH(launch_m2p, P, F, mlim, ncomp, map, phase, st);
+}
+
+template <int N>
+static hipError_t launch_fast_class(const DevPlan &P, const DevFFT &F, int cls, bool synth, const int *mlim, int ncomp, const double *in,
+                                    double *out, hipStream_t st)
+{
+    if (F.cls_n[cls] == 0) return hipSuccess;
+    const size_t lds = (size_t)N * sizeof(double2);
+    if (lds > 48 * 1024) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map_fast<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_map2phase_fast<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+    }
+    if (synth) hipLaunchKernelGGL((k_phase2map_fast<N>), dim3(F.cls_n[cls], ncomp), dim3(N / 8), lds, st, P, F, F.cls_pairs[cls], mlim, ncomp, in, out);
+    else hipLaunchKernelGGL((k_map2phase_fast<N>), dim3(F.cls_n[cls], ncomp), dim3(N / 8), lds, st, P, F, F.cls_pairs[cls], mlim, ncomp, in, out);
+    return hipGetLastError();
+}
+
+static hipError_t launch_fast(const DevPlan &P, const DevFFT &F, bool synth, const int *mlim, int ncomp, const double *in, double *out,
+                              hipStream_t st)
+{
+    hipError_t e = launch_fast_class<4096>(P, F, 4, synth, mlim, ncomp, in, out, st);  // longest transforms first
+    if (e == hipSuccess) e = launch_fast_class<2048>(P, F, 3, synth, mlim, ncomp, in, out, st);
+    if (e == hipSuccess) e = launch_fast_class<1024>(P, F, 2, synth, mlim, ncomp, in, out, st);
+    if (e == hipSuccess) e = launch_fast_class<512>(P, F, 1, synth, mlim, ncomp, in, out, st);
+    if (e == hipSuccess) e = launch_fast_class<256>(P, F, 0, synth, mlim, ncomp, in, out, st);
+    return e;
+}
+
 hipError_t launch_phase2map(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *phase, double *map,
                             hipStream_t st)
 {
-    PL_FFT_DISPATCH(launch_p2m, P, F, mlim, ncomp, phase, map, st);
+    hipError_t e = launch_fast(P, F, true, mlim, ncomp, phase, map, st);
+    if (e == hipSuccess) e = launch_phase2map_legacy(P, F, mlim, ncomp, phase, map, st);
+    return e;
 }
 
 hipError_t launch_map2phase(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *map, double *phase,
                             hipStream_t st)
 {
-    PL_FFT_DISPATCH(launch_m2p, P, F, mlim, ncomp, map, phase, st);
+    hipError_t e = launch_fast(P, F, false, mlim, ncomp, map, phase, st);
+    if (e == hipSuccess) e = launch_map2phase_legacy(P, F, mlim, ncomp, map, phase, st);
+    return e;
 }
 
 hipError_t launch_twiddles(double *tw, int Mtw, hipStream_t st)
@@ -528,6 +913,19 @@ hipError_t launch_bluestein_setup(const DevFFT &F, const int *qlist_dev, int nq,
     }
     hipLaunchKernelGGL(k_bluestein_setup<256>, dim3(nq), dim3(256), lds, st, F, qlist_dev, reinterpret_cast<double2 *>(chirp),
                        reinterpret_cast<double2 *>(filt));
+    return hipGetLastError();
+}
+
+hipError_t launch_bluestein_setup2(const DevFFT &F, const int *qlist_dev, int nq, int Mmax, double *filt2, hipStream_t st)
+{
+    if (nq == 0) return hipSuccess;
+    const size_t lds = (size_t)Mmax * sizeof(double2);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bluestein_setup2<256>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_bluestein_setup2<256>, dim3(nq), dim3(256), lds, st, F, qlist_dev, reinterpret_cast<double2 *>(filt2));
     return hipGetLastError();
 }
 

@@ -147,3 +147,56 @@ def test_lmax_qlm_differs_from_lmax_ivf(shts, oracle):
     q, u = rng.standard_normal(12 * nside ** 2), rng.standard_normal(12 * nside ** 2)
     for lmax in (20, 95):
         assert relrms(np.stack(shts.map2alm_spin([q, u], 1, lmax)), np.stack(oracle.map2alm_spin([q, u], 1, lmax))) < TOL
+
+
+def _run_with_plan(shts, plan, fn):
+    key = (plan.nside, plan.lmax)
+    old = shts._PLANS.get(key)
+    shts._PLANS[key] = plan
+    try:
+        return fn()
+    finally:
+        if old is None:
+            shts._PLANS.pop(key, None)
+        else:
+            shts._PLANS[key] = old
+
+
+@pytest.mark.parametrize('nside,lmax', [(256, 300), (512, 512), (1024, 1400), (2048, 2048)])
+def test_register_fft_kernels_match_generic_kernel(shts, nside, lmax):
+    """The long rings go through the register-resident ring-FFT kernels (sizes 256 .. 4096, direct and band-limited
+    Bluestein); PLSHTS_FFT_LEGACY=1 at plan creation sends every ring through the generic LDS kernel, which the
+    small-nside tests above pin against the oracle.  Same inputs, both plans: maps and alm must agree to rounding."""
+    import os
+    os.environ['PLSHTS_FFT_LEGACY'] = '1'
+    try:
+        generic = shts.Plan(nside, lmax)
+    finally:
+        del os.environ['PLSHTS_FFT_LEGACY']
+    fast = shts.Plan(nside, lmax)
+    rng = np.random.default_rng(nside + lmax)
+    a = random_alm(rng, lmax)
+    g, c = random_alm(rng, lmax, 2), random_alm(rng, lmax, 2)
+    m = rng.standard_normal(12 * nside ** 2)
+    qu = rng.standard_normal((2, 12 * nside ** 2))
+    res = {}
+    for name, plan in (('generic', generic), ('fast', fast)):
+        res[name] = _run_with_plan(shts, plan, lambda: (
+            shts.alm2map(a, nside, lmax=lmax), np.stack(shts.alm2map_spin([g, c], nside, 2, lmax)),
+            shts.map2alm(m, lmax=lmax, iter=0), np.stack(shts.map2alm_spin(qu, 2, lmax))))
+    for x, y in zip(res['generic'], res['fast']):
+        assert relrms(y, x) < 1e-13
+
+
+@pytest.mark.parametrize('nside,lmax', [(256, 383), (512, 512)])
+def test_mid_size_vs_oracle(shts, oracle, nside, lmax):
+    """sizes whose rings use the register-resident FFT classes, against the oracle (spin 0 and 2, both directions)"""
+    rng = np.random.default_rng(7 * nside + lmax)
+    a = random_alm(rng, lmax)
+    assert relrms(shts.alm2map(a, nside, lmax=lmax), oracle.alm2map(a, nside, lmax=lmax)) < TOL
+    m = rng.standard_normal(12 * nside ** 2)
+    assert relrms(shts.map2alm(m, lmax=lmax, iter=0), oracle.map2alm(m, lmax=lmax)) < TOL
+    g, c = random_alm(rng, lmax, 2), random_alm(rng, lmax, 2)
+    assert relrms(np.stack(shts.alm2map_spin([g, c], nside, 2, lmax)), np.stack(oracle.alm2map_spin([g, c], nside, 2, lmax))) < TOL
+    qu = rng.standard_normal((2, 12 * nside ** 2))
+    assert relrms(np.stack(shts.map2alm_spin(qu, 2, lmax)), np.stack(oracle.map2alm_spin(qu, 2, lmax))) < TOL
