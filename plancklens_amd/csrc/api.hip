@@ -49,6 +49,7 @@ struct pl_plan {
     int device = 0;
     DevPlan P{};
     DevFFT F{};
+    FftStreams fs{};
     DevSpinTab S[kMaxSpin + 1]{};
     bool have_spin[kMaxSpin + 1] = {false, false, false, false};
     int64_t nent[kMaxSpin + 1] = {0, 0, 0, 0};
@@ -180,12 +181,12 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
     rc = rc || upload(p, mlim, &P.mlim0);
     if (rc) { pl_plan_destroy(p); return 1; }
 
-    // FFT tables: ring lengths 4 q, q = 1 .. nside.  Every ring pair is served either by a register-resident kernel of
-    // transform size N = 256 << c (ringfft.hip) or, for the short polar rings and anything unusual, by the
-    // LDS-resident generic kernel ("legacy" list).  PLSHTS_FFT_LEGACY=1 sends every pair to the generic kernel.
+    // FFT tables: ring lengths 4 q, q = 1 .. nside.  In each direction every ring pair is served either by a
+    // register-resident kernel of transform size N = 256 << c (ringfft.hip) or, for the short polar rings, aliased rings
+    // and anything unusual, by the LDS-resident generic kernel.  PLSHTS_FFT_LEGACY=1 sends every pair to the generic kernel.
     DevFFT &F = p->F;
     const bool all_legacy = getenv("PLSHTS_FFT_LEGACY") && atoi(getenv("PLSHTS_FFT_LEGACY")) != 0;
-    std::vector<int> K2of(nside + 1, 0), M2of(nside + 1, 0), clsof(nside + 1, -1);
+    std::vector<int> K2of(nside + 1, 0), MofS(nside + 1, 0), MofA(nside + 1, 0), clsS(nside + 1, -1), clsA(nside + 1, -1);
     {
         std::vector<int> mlmax(nside + 1, 0);
         for (int i = 0; i < g.npairs; ++i) {
@@ -196,37 +197,38 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
                 if (ml > mlmax[q]) mlmax[q] = ml;
             }
         }
+        auto cls_of = [](int N) { int c = -1; if (N >= 256 && N <= 4096) { c = 0; while ((256 << c) < N) ++c; } return c; };
         for (int q = 1; q <= nside; ++q) {
-            const int K = (mlmax[q] + 3) / 4 + 1;  // sub-DFT inputs c = k1 or k1 - q with 4 |c| <= mlim + 3
+            const int K = (mlmax[q] + 3) / 4 + 1;  // analysis: sub-DFT bins c = k1 or k1 - q with 4 |c| <= mlim + 3
             K2of[q] = K;
-            if (all_legacy) continue;
-            int N = 0;
-            if (2 * K + 1 >= q) continue;                               // aliased ring (mlim >= n / 2 - 5): generic kernel
-            if ((q & (q - 1)) == 0) { if (q >= 256) N = q; }           // the ring's own sub-DFT length
-            else { N = 256; while (N < q + 2 * K + 1) N <<= 1; M2of[q] = N; }
-            if (N >= 256 && N <= 4096) { int c = 0; while ((256 << c) < N) ++c; clsof[q] = c; }
-            else M2of[q] = 0;
+            if (all_legacy || 2 * K + 1 >= q) continue;                 // aliased ring (mlim >= n / 2 - 5): generic kernel
+            if ((q & (q - 1)) == 0) { clsS[q] = clsA[q] = cls_of(q); continue; }  // the ring's own sub-DFT length
+            int Ns = 256, Na = 256;
+            while (Ns < 2 * q - 1) Ns <<= 1;           // synthesis: every sub-DFT input is non-zero
+            while (Na < q + 2 * K + 1) Na <<= 1;       // analysis: only the 2 K + 1 in-band outputs are needed
+            clsS[q] = cls_of(Ns); clsA[q] = cls_of(Na);
+            if (clsS[q] >= 0) MofS[q] = Ns;
+            if (clsA[q] >= 0) MofA[q] = Na;
         }
     }
-    std::vector<int> cls_list[5], legacy_list;
+    std::vector<int> listS[5], listA[5], legacyS, legacyA;
     for (int i = g.npairs - 1; i >= 0; --i) {  // longest rings first
-        const int c = clsof[g.nphi[i] / 4];
-        if (c >= 0) cls_list[c].push_back(i); else legacy_list.push_back(i);
+        const int q = g.nphi[i] / 4;
+        if (clsS[q] >= 0) listS[clsS[q]].push_back(i); else legacyS.push_back(i);
+        if (clsA[q] >= 0) listA[clsA[q]].push_back(i); else legacyA.push_back(i);
     }
-    std::vector<int> Mof(nside + 1, 0), qlist, qlist2;
-    std::vector<int64_t> woff(nside + 1, 0), coff(nside + 1, 0), coff2(nside + 1, 0);
-    int64_t nw = 0, nc = 0, nc2 = 0;
+    std::vector<int> Mof(nside + 1, 0), qlist, qlistS, qlistA;
+    std::vector<int64_t> woff(nside + 1, 0), coff(nside + 1, 0), coffS(nside + 1, 0), coffA(nside + 1, 0);
+    int64_t nw = 0, nc = 0, ncS = 0, ncA = 0;
     int Lmax = 1, M2max = 2;
     for (int q = 1; q <= nside; ++q) {
-        if ((q & (q - 1)) == 0) { if (clsof[q] < 0 && q > Lmax) Lmax = q; continue; }
+        const bool generic = clsS[q] < 0 || clsA[q] < 0;  // some direction of this ring length runs in the generic kernel
+        if ((q & (q - 1)) == 0) { if (generic && q > Lmax) Lmax = q; continue; }
         woff[q] = nw; nw += q;
         qlist.push_back(q);
-        if (clsof[q] >= 0) {
-            coff2[q] = nc2; nc2 += M2of[q];
-            if (M2of[q] > M2max) M2max = M2of[q];
-            qlist2.push_back(q);
-            continue;
-        }
+        if (MofS[q]) { coffS[q] = ncS; ncS += MofS[q]; if (MofS[q] > M2max) M2max = MofS[q]; qlistS.push_back(q); }
+        if (MofA[q]) { coffA[q] = ncA; ncA += MofA[q]; if (MofA[q] > M2max) M2max = MofA[q]; qlistA.push_back(q); }
+        if (!generic) continue;
         int M = 2;
         while (M < 2 * q - 1) M <<= 1;
         Mof[q] = M; coff[q] = nc; nc += M;
@@ -235,7 +237,7 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
     F.Lmax = Lmax;
     F.Mtw = Lmax < 2 ? 2 : Lmax;
     if (F.Mtw < M2max) F.Mtw = M2max;
-    for (int c = 0; c < 5; ++c) if (!cls_list[c].empty() && F.Mtw < (256 << c)) F.Mtw = 256 << c;
+    for (int c = 0; c < 5; ++c) if ((!listS[c].empty() || !listA[c].empty()) && F.Mtw < (256 << c)) F.Mtw = 256 << c;
     if ((size_t)Lmax * 16 > 160 * 1024) { pl_plan_destroy(p); return fail("ring FFT workspace exceeds the 160 KiB LDS of a CU"); }
     {   // LDS twiddle tables of the largest generic transform (radix-8 passes + one radix-4/2 tail), if they fit beside it
         int k = 0; while ((1 << k) < Lmax) ++k;
@@ -244,8 +246,8 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
         for (int64_t L = (int64_t)rt * 8; L <= Lmax; L *= 8) tot += 3 * (int)(L / 8);
         F.twl_cap = ((size_t)(Lmax + tot) * 16 <= 160 * 1024) ? tot : 0;
     }
-    double *tw = nullptr, *chirp = nullptr, *filt = nullptr, *filt2 = nullptr;
-    const int *qlist_dev = nullptr, *qlist2_dev = nullptr;
+    double *tw = nullptr, *chirp = nullptr, *filt = nullptr, *filtS = nullptr, *filtA = nullptr;
+    const int *qlist_dev = nullptr, *qlistS_dev = nullptr, *qlistA_dev = nullptr;
     auto dalloc = [&](double **ptr, int64_t nd) -> int {
         if (nd < 2) nd = 2;
         HIPCHK(hipMalloc(reinterpret_cast<void **>(ptr), nd * sizeof(double)));
@@ -253,20 +255,28 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
         p->bytes += nd * 8;
         return 0;
     };
-    rc = dalloc(&tw, F.Mtw) || dalloc(&chirp, 2 * nw) || dalloc(&filt, 2 * nc) || dalloc(&filt2, 2 * nc2) || upload(p, Mof, &F.Mof) ||
-         upload(p, woff, &F.woff) || upload(p, coff, &F.coff) || upload(p, qlist, &qlist_dev) || upload(p, qlist2, &qlist2_dev) ||
-         upload(p, K2of, &F.K2of) || upload(p, M2of, &F.M2of) || upload(p, coff2, &F.coff2) || upload(p, legacy_list, &F.legacy_pairs);
-    F.legacy_n = (int)legacy_list.size();
-    for (int c = 0; c < 5 && !rc; ++c) { rc = upload(p, cls_list[c], &F.cls_pairs[c]); F.cls_n[c] = (int)cls_list[c].size(); }
+    rc = dalloc(&tw, F.Mtw) || dalloc(&chirp, 2 * nw) || dalloc(&filt, 2 * nc) || dalloc(&filtS, 2 * ncS) || dalloc(&filtA, 2 * ncA) ||
+         upload(p, Mof, &F.Mof) || upload(p, woff, &F.woff) || upload(p, coff, &F.coff) || upload(p, K2of, &F.K2of) ||
+         upload(p, qlist, &qlist_dev) || upload(p, qlistS, &qlistS_dev) || upload(p, qlistA, &qlistA_dev) ||
+         upload(p, MofS, &F.S.Mof) || upload(p, coffS, &F.S.coff) || upload(p, legacyS, &F.S.legacy_pairs) ||
+         upload(p, MofA, &F.A.Mof) || upload(p, coffA, &F.A.coff) || upload(p, legacyA, &F.A.legacy_pairs);
+    F.S.legacy_n = (int)legacyS.size(); F.A.legacy_n = (int)legacyA.size();
+    for (int c = 0; c < 5 && !rc; ++c) {
+        rc = upload(p, listS[c], &F.S.cls_pairs[c]) || upload(p, listA[c], &F.A.cls_pairs[c]);
+        F.S.cls_n[c] = (int)listS[c].size(); F.A.cls_n[c] = (int)listA[c].size();
+    }
     if (rc) { pl_plan_destroy(p); return 1; }
     F.tw = reinterpret_cast<const double2 *>(tw);
     F.chirp = reinterpret_cast<const double2 *>(chirp);
     F.filt = reinterpret_cast<const double2 *>(filt);
-    F.filt2 = reinterpret_cast<const double2 *>(filt2);
+    F.S.filt = reinterpret_cast<const double2 *>(filtS);
+    F.A.filt = reinterpret_cast<const double2 *>(filtA);
     hipError_t e = launch_twiddles(tw, F.Mtw, nullptr);
     if (e == hipSuccess) e = launch_bluestein_setup(F, qlist_dev, (int)qlist.size(), chirp, filt, nullptr);
-    if (e == hipSuccess) e = launch_bluestein_setup2(F, qlist2_dev, (int)qlist2.size(), M2max, filt2, nullptr);
+    if (e == hipSuccess) e = launch_bluestein_setup2(F, 1, qlistS_dev, (int)qlistS.size(), M2max, filtS, nullptr);
+    if (e == hipSuccess) e = launch_bluestein_setup2(F, 0, qlistA_dev, (int)qlistA.size(), M2max, filtA, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = fft_streams_create(p->fs);
     if (e != hipSuccess) { pl_plan_destroy(p); return fail(std::string("FFT table setup: ") + hipGetErrorString(e)); }
     *out = p;
     return 0;
@@ -275,6 +285,7 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
 int pl_plan_destroy(pl_plan *p)
 {
     if (!p) return 0;
+    fft_streams_destroy(p->fs);
     for (void *d : p->allocs) (void)hipFree(d);
     if (p->phase) (void)hipFree(p->phase);
     if (p->prep) (void)hipFree(p->prep);
@@ -359,7 +370,7 @@ int pl_phase2map(pl_plan *p, int spin, const double *phase, double *map, void *s
     if (!p) return fail("null plan");
     if (spin && ensure_spin(p, spin)) return 1;
     ProfScope ps(p, PK_FFT_SYNTH, static_cast<hipStream_t>(stream));
-    HIPCHK(launch_phase2map(p->P, p->F, mlim_of(p, spin), ncomp_of(spin), phase, map, static_cast<hipStream_t>(stream)));
+    HIPCHK(launch_phase2map(p->P, p->F, p->fs, mlim_of(p, spin), ncomp_of(spin), phase, map, static_cast<hipStream_t>(stream)));
     return 0;
 }
 
@@ -368,7 +379,7 @@ int pl_map2phase(pl_plan *p, int spin, const double *map, double *phase, void *s
     if (!p) return fail("null plan");
     if (spin && ensure_spin(p, spin)) return 1;
     ProfScope ps(p, PK_FFT_ANAL, static_cast<hipStream_t>(stream));
-    HIPCHK(launch_map2phase(p->P, p->F, mlim_of(p, spin), ncomp_of(spin), map, phase, static_cast<hipStream_t>(stream)));
+    HIPCHK(launch_map2phase(p->P, p->F, p->fs, mlim_of(p, spin), ncomp_of(spin), map, phase, static_cast<hipStream_t>(stream)));
     return 0;
 }
 

@@ -7,6 +7,17 @@
 
 namespace plshts {
 
+// Work lists of one direction: every ring pair is in exactly one list.
+struct FftSide {
+    const int *legacy_pairs; // generic LDS-resident kernel (short polar rings, aliased rings), longest rings first
+    int legacy_n;
+    const int *cls_pairs[5]; // register-resident kernels, transform size N = 256 << c
+    int cls_n[5];
+    const int *Mof;          // [nside + 1] Bluestein convolution size of q in its class (0: direct, or generic list)
+    const int64_t *coff;     // [nside + 1] offset of q's natural-order filter spectrum (Mof[q] entries)
+    const double2 *filt;
+};
+
 struct DevFFT {
     const double2 *tw;       // e^{-2 pi i t / Mtw}, t < Mtw / 2
     int Mtw;                 // largest power-of-two transform size used by the plan
@@ -17,22 +28,26 @@ struct DevFFT {
     const int64_t *coff;     // [nside + 1] offset of q's filter spectrum (M entries)
     const double2 *chirp;    // e^{i pi t^2 / q}
     const double2 *filt;     // bit-reversed FFT_M of the wrapped conj chirp, times 1 / M
-    // workgroup-per-pair kernels with an LDS-resident transform (any ring): the pairs not covered by a register class
-    const int *legacy_pairs; // ring pair indices, longest rings first
-    int legacy_n;
-    // register-resident kernels (ringfft.hip, second half): transform size classes N = 256 << c, c = 0 .. 4
-    const int *cls_pairs[5]; // ring pair indices of each class
-    int cls_n[5];
-    const int *K2of;         // [nside + 1] band half-width of the sub-DFT inputs of ring length 4 q: |c| <= K2of[q]
-    const int *M2of;         // [nside + 1] band-limited Bluestein size (0: q itself is the transform size, or legacy class)
-    const int64_t *coff2;    // [nside + 1] offset of q's natural-order filter spectrum (M2of[q] entries)
-    const double2 *filt2;
+    // register-resident kernels (ringfft.hip, second half): per-direction class lists and Bluestein tables
+    int const *K2of;         // [nside + 1] band half-width of the sub-DFT bins of ring length 4 q: |c| <= K2of[q] (analysis)
+    FftSide S, A;            // synthesis (phase -> map), analysis (map -> phase)
 };
 
-hipError_t launch_phase2map(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *phase, double *map, hipStream_t st);
-hipError_t launch_map2phase(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *map, double *phase, hipStream_t st);
+// Side streams of a plan: the ring-length classes of one FFT stage are independent kernels of very different sizes
+// (the short-ring ones are latency-bound), so they are forked from the caller's stream and joined back with events.
+struct FftStreams {
+    static constexpr int kN = 5;
+    hipStream_t s[kN] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[kN] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ok = false;
+};
+hipError_t fft_streams_create(FftStreams &fs);
+void fft_streams_destroy(FftStreams &fs);
+
+hipError_t launch_phase2map(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *phase, double *map, hipStream_t st);
+hipError_t launch_map2phase(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *map, double *phase, hipStream_t st);
 hipError_t launch_twiddles(double *tw, int Mtw, hipStream_t st);
 hipError_t launch_bluestein_setup(const DevFFT &F, const int *qlist_dev, int nq, double *chirp, double *filt, hipStream_t st);
-hipError_t launch_bluestein_setup2(const DevFFT &F, const int *qlist_dev, int nq, int Mmax, double *filt2, hipStream_t st);
+hipError_t launch_bluestein_setup2(const DevFFT &F, int synth, const int *qlist_dev, int nq, int Mmax, double *filt2, hipStream_t st);
 
 }  // namespace plshts

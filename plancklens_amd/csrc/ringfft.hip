@@ -462,10 +462,15 @@ __global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int
 // unit-stride loads (ds_read_b128: 16-lane groups, 64 banks) are conflict-free.
 // Bluestein here uses the band limit of the ring: only the bins |m| <= mlim are non-zero, i.e. sub-DFT inputs
 // c in [-K, K] (K = F.K2of[q]), so a convolution of size N >= q + 2 K + 1 is enough (instead of 2 q - 1).
+#ifndef PL_FFT_ABL
+#define PL_FFT_ABL 0   // timing ablations of the register-resident kernels (development only, results wrong): 1 no FFT, 2 no gather, 4 no stores
+#endif
 __device__ __forceinline__ int swz(int i) { return i ^ ((i >> 3) & 7); }
 // Launders a table index: the kernels below are fully unrolled and hipcc would otherwise load every table entry once
-// at the top and keep it in registers across all four sub-DFTs (CSE of identical loads: > 400 VGPRs, occupancy 1).
-__device__ __forceinline__ int fresh(int i) { asm volatile("" : "+v"(i)); return i; }
+// at the top -- or hoist the loads of a later phase above the barriers of the current one -- and park the values in
+// registers for the whole kernel (> 400 VGPRs, occupancy 1).  The memory clobber pins the load behind the preceding barrier.
+__device__ __forceinline__ int fresh(int i) { asm volatile("" : "+v"(i)::"memory"); return i; }
+__device__ __forceinline__ void phase_fence() { asm volatile("" ::: "memory"); }
 
 template <int N>
 struct Tw8 {
@@ -496,10 +501,23 @@ __device__ __forceinline__ double2 twmul(double2 a, double2 w) { return FWD ? cm
 // x[j] = point tl + G j on entry and on return; FWD: e^{-2 pi i jk/N}, else e^{+2 pi i jk/N} (unnormalised).
 // Powers of a twiddle are formed by multiplication (at most 3 products deep: ~4 ulp), which keeps one complex
 // number per pass in registers instead of seven.
+__device__ __forceinline__ void launder(double2 &w) { asm volatile("" : "+v"(w.x), "+v"(w.y)); }
+
 template <int N, bool FWD>
-__device__ __forceinline__ void fft8(double2 (&x)[8], double2 *lds, int tl, const Tw8<N> &tw)
+__device__ __forceinline__ void fft8(double2 (&x)[8], double2 *lds, int tl_in, const Tw8<N> &tw_in)
 {
     constexpr int G = N / 8, P8 = Tw8<N>::P8, T = Tw8<N>::T;
+    if (PL_FFT_ABL & 1) return;
+    // A kernel calls this 4 to 8 times with the same twiddles and thread index.  Left alone, hipcc computes the twiddle
+    // powers and LDS addresses of all passes once and keeps them live across every call (CSE): +130 VGPRs.  Laundering the
+    // inputs makes each call recompute them (a few dozen multiplies) and keeps the kernel at 2-3 waves per SIMD.
+    Tw8<N> tw = tw_in;
+    int tl = tl_in;
+    asm volatile("" : "+v"(tl));
+#pragma unroll
+    for (int p = 0; p < P8 - 1; ++p) launder(tw.w[p]);
+#pragma unroll
+    for (int u = 0; u < (T == 2 ? 4 : 2); ++u) launder(tw.wt[u]);
     // sched_barrier: hipcc otherwise hoists the table loads of every later phase of the fully unrolled kernel to the
     // top (hundreds of VGPRs in flight, occupancy 1)
     __builtin_amdgcn_sched_barrier(0);
@@ -556,223 +574,244 @@ __device__ __forceinline__ FastBin fast_bin(bool blue, int idx, int N, int q, in
     return b;
 }
 
+// ---- synthesis: radix-4 on the pixel side ---------------------------------------------------------------------------
+// pixel j = j1 + q j2, bin k = 4 k1 + k2: x_(j1 + q j2) = sum_k2 i^(j2 k2) e^{2 pi i j1 k2 / n} [sum_k1 e^{2 pi i j1 k1 / q} X_(4 k1 + k2)].
+// All four sub-DFTs stay resident (d[4][8]) because every pixel needs all of them; the workgroup keeps to 256 registers
+// per thread (two workgroups per CU).  The sub-DFT inputs are band-limited (|c| <= K), so the Bluestein classes use the
+// same convolution sizes and filter tables as the analysis (side A lists and tables).
 template <int N>
-__global__ __launch_bounds__(N / 8) void k_phase2map_fast(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim,
-                                                          int ncomp, const double *__restrict__ phase, double *__restrict__ map)
+__global__ __launch_bounds__(N / 8, 2) void k_phase2map_fast(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim,
+                                                             int ncomp, const double *__restrict__ phase, double *__restrict__ map)
 {
     extern __shared__ double2 lds[];
     constexpr int G = N / 8;
-    const int tl = threadIdx.x;
+    const int tl0 = threadIdx.x;
     const int ip = pairs[blockIdx.x], comp = blockIdx.y;
     const int n = P.nphi[ip], q = n >> 2;
     const bool blue = q != N;
     const int K = F.K2of[q];
     const double2 *__restrict__ chirp = F.chirp + F.woff[q];
-    const double2 *__restrict__ filt = F.filt2 + F.coff2[q];
+    const double2 *__restrict__ filt = F.A.filt + F.A.coff[q];
     const int ml = min(mlim[ip], P.mmax);
     const bool shifted = P.phi0[ip] != 0.0;
     const double inv_n = 1.0 / n;
     const int estride = 4 * ncomp;
     const double *__restrict__ ph = phase + (int64_t)ip * P.mstride * estride + comp * 4;
     Tw8<N> tw;
-    tw8_load<N>(tw, tl, F.tw, F.Mtw);
+    tw8_load<N>(tw, tl0, F.tw, F.Mtw);
 
+    // gather: d[k2][j] = z_(4 k1 + k2) (times the chirp), z = f_N + i f_S (+ side) or conj(f_N) + i conj(f_S) (- side).
     // Ring offset phase e^{i pi m / n} of the shifted rings by recurrence: with Pk = e^{i pi k / n}, k = 4 idx + k2,
-    // the positive side (m = k) needs Pk and the negative side (m = 4 (N - idx) - k2) needs e^{i pi 4 N / n} conj(Pk)
-    double2 pj = make_double2(1., 0.), pstep = pj, s1 = pj, s2 = pj, s3 = pj, uneg = pj;
-    if (shifted) {
-        pj = cispi(4.0 * tl * inv_n); pstep = cispi(4.0 * G * inv_n);
-        s1 = cispi(inv_n); s2 = cmul(s1, s1); s3 = cmul(s2, s1);
-        uneg = cispi(4.0 * N * inv_n);
-    }
-    // gather: d[k2][j] = z_(4 k1 + k2) (times the chirp), z = f_N + i f_S (+ side) or conj(f_N) + i conj(f_S) (- side)
+    // the + side (m = k) needs Pk and the - side (m = 4 (N - idx) - k2) needs e^{i pi 4 N / n} conj(Pk).
     double2 d[4][8];
+    {
+        const int tl = fresh(tl0);
+        double2 pj = make_double2(1., 0.), pstep = pj, s1 = pj, s2 = pj, s3 = pj, uneg = pj;
+        if (shifted) {
+            pj = cispi(4.0 * tl * inv_n); pstep = cispi(4.0 * G * inv_n);
+            s1 = cispi(inv_n); s2 = cmul(s1, s1); s3 = cmul(s2, s1);
+            uneg = cispi(4.0 * N * inv_n);
+        }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
-        double2 cw = make_double2(1., 0.);
-        if (blue && b.sgn != 0) cw = chirp[fresh(b.cabs)];
+        for (int j = 0; j < 8; ++j) {
+            const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
+            double2 cw = make_double2(1., 0.);
+            if (blue) cw = chirp[b.cabs];
 #pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2) {
-            const int k = 4 * b.k1 + k2;
-            const int m = b.sgn > 0 ? k : n - k;
-            double2 z = make_double2(0., 0.);
-            if (b.sgn != 0 && m <= ml) {
-                const double4 f = *reinterpret_cast<const double4 *>(ph + (int64_t)m * estride);
+            for (int k2 = 0; k2 < 4; ++k2) {
+                // branch-free: out-of-band bins load entry m = 0 (always valid) and are zeroed by the select below
+                const int k = 4 * b.k1 + k2;
+                const int mm = b.sgn > 0 ? k : n - k;
+                const bool have = b.sgn != 0 && mm <= ml;
+                const int m = have ? mm : 0;
+                const double4 f = (PL_FFT_ABL & 2) ? make_double4(1., 2., 3., m) : *reinterpret_cast<const double4 *>(ph + (int64_t)m * estride);
                 double2 fn = make_double2(f.x, f.y), fs = make_double2(f.z, f.w);
                 if (shifted) {
                     const double2 pk = cmul(pj, k2 == 0 ? make_double2(1., 0.) : k2 == 1 ? s1 : k2 == 2 ? s2 : s3);
                     const double2 pm = b.sgn > 0 ? pk : cmulc(uneg, pk);
                     fn = cmul(fn, pm); fs = cmul(fs, pm);
                 }
-                z = b.sgn > 0 ? make_double2(fn.x - fs.y, fn.y + fs.x) : make_double2(fn.x + fs.y, -fn.y + fs.x);
+                double2 z;
+                z.x = have ? (b.sgn > 0 ? fn.x - fs.y : fn.x + fs.y) : 0.0;
+                z.y = have ? (b.sgn > 0 ? fn.y + fs.x : -fn.y + fs.x) : 0.0;
+                d[k2][j] = cmul(z, cw);
             }
-            d[k2][j] = cmul(z, cw);
+            pj = cmul(pj, pstep);
         }
-        pj = cmul(pj, pstep);
-        if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // keep at most 8 x 32-byte loads in flight per thread
     }
     // the four sub-DFTs, in place
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) {
         if (blue) {
-            fft8<N, true>(d[k2], lds, tl, tw);
+            fft8<N, true>(d[k2], lds, tl0, tw);
+            const int tl = fresh(tl0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d[k2][j] = cmul(d[k2][j], filt[fresh(tl + G * j)]);
-            fft8<N, false>(d[k2], lds, tl, tw);
+            for (int j = 0; j < 8; ++j) d[k2][j] = cmul(d[k2][j], filt[tl + G * j]);
+            fft8<N, false>(d[k2], lds, tl0, tw);
         } else {
-            fft8<N, false>(d[k2], lds, tl, tw);
+            fft8<N, false>(d[k2], lds, tl0, tw);
         }
     }
     // twiddle e^{2 pi i j1 k2 / n} (recurrence over j), radix-4 butterfly over k2, pixels j = j1 + q j2
     double *__restrict__ mp = map + (int64_t)comp * P.npix;
     const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
+    const int tl = fresh(tl0);
     double2 e1 = cispi(2.0 * tl * inv_n);
     const double2 estep = cispi(2.0 * G * inv_n);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int j1 = tl + G * j;
+        double2 cw = make_double2(1., 0.);
+        if (blue) cw = chirp[min(j1, q - 1)];
         if (j1 < q) {
-            const double2 cw = blue ? chirp[fresh(j1)] : make_double2(1., 0.);
             const double2 e2 = cmul(e1, e1), e3 = cmul(e2, e1);
             double2 y[4] = {cmul(d[0][j], cw), cmul(d[1][j], cmul(cw, e1)), cmul(d[2][j], cmul(cw, e2)), cmul(d[3][j], cmul(cw, e3))};
             dft_small<4, false>(y);  // y[j2] = sum_k2 i^(j2 k2) y_k2
 #pragma unroll
             for (int j2 = 0; j2 < 4; ++j2) {
+                if ((PL_FFT_ABL & 4) && y[j2].x != 1.2345) continue;
                 mp[on + j1 + q * j2] = y[j2].x;
                 if (os >= 0) mp[os + j1 + q * j2] = y[j2].y;
             }
         }
         e1 = cmul(e1, estep);
-        if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
+// ---- analysis: radix-4 on the pixel side ----------------------------------------------------------------------------
+// pixel j = j1 + q j2, bin k = 4 k1 + k2: V_(4 k1 + k2) = sum_j1 e^{2 pi i j1 k1 / q} [e^{2 pi i j1 k2 / n} sum_j2 i^(j2 k2) conj(z)_(j1 + q j2)].
+// Sub-DFTs are processed as the pairs (k2 = 0, 2) and (1, 3) -- the mirror bin n - k of k2 lives in sub-DFT (4 - k2) mod 4,
+// so each pair is self-contained -- with the ring pixels loaded again for the second pair (coalesced, from L2).
 template <int N>
-__global__ __launch_bounds__(N / 8) void k_map2phase_fast(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim,
-                                                          int ncomp, const double *__restrict__ map, double *__restrict__ phase)
+__global__ __launch_bounds__(N / 8, 2) void k_map2phase_fast(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim,
+                                                          int ncomp, const double *map, double *phase)
 {
     extern __shared__ double2 lds[];
     constexpr int G = N / 8;
-    const int tl = threadIdx.x;
+    const int tl0 = threadIdx.x;
     const int ip = pairs[blockIdx.x], comp = blockIdx.y;
     const int n = P.nphi[ip], q = n >> 2;
     const bool blue = q != N;
     const int K = F.K2of[q];
     const double2 *__restrict__ chirp = F.chirp + F.woff[q];
-    const double2 *__restrict__ filt = F.filt2 + F.coff2[q];
+    const double2 *__restrict__ filt = F.A.filt + F.A.coff[q];
     const int ml = min(mlim[ip], P.mmax);
     const bool shifted = P.phi0[ip] != 0.0;
     const double inv_n = 1.0 / n;
     const int estride = 4 * ncomp;
-    double *__restrict__ ph = phase + (int64_t)ip * P.mstride * estride + comp * 4;
+    double *ph = phase + (int64_t)ip * P.mstride * estride + comp * 4;
     const double wgt = 0.5 * 4.0 * 3.14159265358979323846 / (double)P.npix;  // includes the 1/2 of the N/S split
-    const double *__restrict__ mp = map + (int64_t)comp * P.npix;
+    const double *mp = map + (int64_t)comp * P.npix;  // no __restrict__: see k_phase2map_fast
     const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
     const bool has_s = os >= 0;
     Tw8<N> tw;
-    tw8_load<N>(tw, tl, F.tw, F.Mtw);
+    tw8_load<N>(tw, tl0, F.tw, F.Mtw);
+    const double2 e10 = cispi(2.0 * tl0 * inv_n), e1step = cispi(2.0 * G * inv_n);
+    double2 pj0 = make_double2(1., 0.), pstep = pj0, s1 = pj0;
+    if (shifted) { pj0 = cispi(4.0 * tl0 * inv_n); pstep = cispi(4.0 * G * inv_n); s1 = cispi(inv_n); }
 
-    // conj(z_j) = north - i south at j = j1 + q j2; radix-4 over j2, twiddle, (chirp): d[k2][j] = input j1 of sub-DFT k2
-    double2 d[4][8];
-    {
-        double2 e1 = cispi(2.0 * tl * inv_n);
-        const double2 estep = cispi(2.0 * G * inv_n);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int j1 = tl + G * j;
-            double2 y[4];
-#pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) {
-                y[j2] = make_double2(0., 0.);
-                if (j1 < q) {
-                    y[j2].x = mp[on + j1 + q * j2];
-                    y[j2].y = has_s ? -mp[os + j1 + q * j2] : 0.0;
-                }
-            }
-            dft_small<4, false>(y);  // y[k2] = sum_j2 i^(j2 k2) zc_j2
-            double2 cw = make_double2(1., 0.);
-            if (blue && j1 < q) cw = chirp[fresh(j1)];
-            const double2 e2 = cmul(e1, e1), e3 = cmul(e2, e1);
-            d[0][j] = cmul(y[0], cw); d[1][j] = cmul(y[1], cmul(cw, e1)); d[2][j] = cmul(y[2], cmul(cw, e2)); d[3][j] = cmul(y[3], cmul(cw, e3));
-            e1 = cmul(e1, estep);
-            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    // sub-DFTs: d[k2][j] becomes V_(4 k1 + k2), V = conj(Z), at the in-band slots of this thread
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) {
-        if (blue) {
-            fft8<N, true>(d[k2], lds, tl, tw);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) d[k2][j] = cmul(d[k2][j], filt[fresh((N - (tl + G * j)) & (N - 1))]);  // spectrum of the mirrored filter
-            fft8<N, false>(d[k2], lds, tl, tw);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
-                if (b.sgn != 0) d[k2][j] = cmul(d[k2][j], chirp[fresh(b.cabs)]);
-            }
-        } else {
-            fft8<N, false>(d[k2], lds, tl, tw);
-        }
-    }
-    // F_N, F_S of order m from V_m and its mirror V_(n - m): the thread owning the + side bin k1 emits m = 4 k1 + k2 after
-    // fetching the mirror value from the - side owner through LDS.  Mirror of (k1, k2): k2 = 0: (q - k1) mod q, same k2;
-    // k2 = 1, 2, 3: k1' = q - 1 - k1 with k2' = 4 - k2.
-    double2 pj = make_double2(1., 0.), pstep = pj, s1 = pj, s2 = pj, s3 = pj;
-    if (shifted) {
-        pj = cispi(4.0 * tl * inv_n); pstep = cispi(4.0 * G * inv_n);
-        s1 = cispi(inv_n); s2 = cmul(s1, s1); s3 = cmul(s2, s1);
-    }
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) {
-        const int k2m = (4 - k2) & 3;
+    // F_N, F_S of order m = 4 k1 + k2 (+ side owner): a = V_m (own register), vm = V_(n - m) (from the - side owner via LDS)
+    auto emit_side = [&](int k2, const double2 (&own)[8], const double2 (&other)[8]) {
+        const int tl = fresh(tl0);  // per-call copy: keeps the bin bookkeeping of one call from living across the others
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
-            if (b.sgn < 0 || (b.sgn > 0 && b.k1 == 0)) lds[swz(b.k1)] = d[k2m][j];  // - side values of sub-DFT k2m (bin 0 is its own mirror)
+            if (b.sgn < 0 || (b.sgn > 0 && b.k1 == 0)) lds[swz(b.k1)] = other[j];  // - side values of the mirror sub-DFT
         }
         __syncthreads();
-        double2 pjj = pj;
+        double2 pjj = pj0;
+        launder(pjj);
+        const double2 sk = k2 == 0 ? make_double2(1., 0.) : k2 == 1 ? s1 : k2 == 2 ? cmul(s1, s1) : cmul(s1, cmul(s1, s1));
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
             const int m = 4 * b.k1 + k2;
             if (b.sgn > 0 && m <= ml) {
                 const int k1m = k2 == 0 ? (b.k1 == 0 ? 0 : q - b.k1) : q - 1 - b.k1;
-                const double2 a = cconj(d[k2][j]);        // conj(V_m) = Z_m
-                const double2 vm = lds[swz(k1m)];         // V_(n - m)
+                const double2 a = cconj(own[j]);
+                const double2 vm = lds[swz(k1m)];
                 double2 fn = cadd(a, vm);
                 const double2 dd = csub(a, vm);
                 double2 fs = make_double2(dd.y, -dd.x);   // (conj(V_m) - V_(n-m)) / i
-                if (shifted) {
-                    const double2 pk = cmul(pjj, k2 == 0 ? make_double2(1., 0.) : k2 == 1 ? s1 : k2 == 2 ? s2 : s3);
-                    fn = cmulc(fn, pk); fs = cmulc(fs, pk);   // e^{-i pi m / n}
-                }
+                if (shifted) { const double2 pk = cmul(pjj, sk); fn = cmulc(fn, pk); fs = cmulc(fs, pk); }  // e^{-i pi m / n}
                 double4 o;
                 o.x = fn.x * wgt; o.y = fn.y * wgt;
                 o.z = has_s ? fs.x * wgt : 0.0; o.w = has_s ? fs.y * wgt : 0.0;
-                *reinterpret_cast<double4 *>(ph + (int64_t)m * estride) = o;
+                if (!(PL_FFT_ABL & 4) || o.x == 1.2345) *reinterpret_cast<double4 *>(ph + (int64_t)m * estride) = o;
             }
             pjj = cmul(pjj, pstep);
-            if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            if ((j & 1) == 1) phase_fence();  // at most two j (8 loads) in flight
         }
+    };
+
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        const int k2a = pp, k2b = pp + 2;   // (0, 2) then (1, 3)
+        phase_fence();  // the loads of this pass stay behind the barriers of the previous one
+        const int tl = fresh(tl0);  // see k_phase2map_fast
+        double2 d[2][8];
+        double2 e1 = e10;
+        launder(e1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int j1 = tl + G * j;
+            double2 y[4];
+            const int j1c = min(j1, q - 1);  // branch-free loads; slots beyond the ring are zeroed by the select
+            const double *mps = has_s ? mp + os : mp + on;
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                const double vn = (PL_FFT_ABL & 2) ? 1.0 + j1c : mp[on + j1c + q * j2], vs = (PL_FFT_ABL & 2) ? 2.0 : mps[j1c + q * j2];
+                y[j2].x = j1 < q ? vn : 0.0;
+                y[j2].y = (j1 < q && has_s) ? -vs : 0.0;
+            }
+            dft_small<4, false>(y);  // y[k2] = sum_j2 i^(j2 k2) conj(z)_(j1 + q j2)
+            double2 cw = make_double2(1., 0.);
+            if (blue) cw = chirp[j1c];
+            const double2 e2 = cmul(e1, e1);
+            if (pp == 0) { d[0][j] = cmul(y[0], cw); d[1][j] = cmul(y[2], cmul(cw, e2)); }
+            else { d[0][j] = cmul(y[1], cmul(cw, e1)); d[1][j] = cmul(y[3], cmul(cw, cmul(e2, e1))); }
+            e1 = cmul(e1, e1step);
+            if ((j & 1) == 1) phase_fence();  // at most two j (8 loads) in flight
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (blue) {
+                fft8<N, true>(d[h], lds, tl, tw);
+                phase_fence();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[h][j] = cmul(d[h][j], filt[(N - (tl + G * j)) & (N - 1)]);  // spectrum of the mirrored filter
+                fft8<N, false>(d[h], lds, tl, tw);
+                phase_fence();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
+                    d[h][j] = cmul(d[h][j], chirp[b.cabs]);  // out-of-band slots: chirp[0], value never used
+                }
+            } else {
+                fft8<N, false>(d[h], lds, tl, tw);
+            }
+        }
+        if (pp == 0) { emit_side(k2a, d[0], d[0]); emit_side(k2b, d[1], d[1]); }   // k2 = 0 and 2 mirror into themselves
+        else { emit_side(k2a, d[0], d[1]); emit_side(k2b, d[1], d[0]); }           // k2 = 1 <-> 3
     }
 }
 
-// plan-time: natural-order spectrum (times 1/M) of the wrapped conjugate chirp h_d = e^{-i pi d^2 / q}, d in [-K, q-1+K]
+// plan-time: natural-order spectrum (times 1/M) of the wrapped conjugate chirp h_d = e^{-i pi d^2 / q}, d in [-Kn, q-1+Kp]:
+// analysis tables (side A) Kn = Kp = K2of[q] (band-limited outputs), synthesis tables (side S) Kn = q - 1, Kp = 0
 template <int NT>
-__global__ __launch_bounds__(NT) void k_bluestein_setup2(DevFFT F, const int *__restrict__ qlist, double2 *__restrict__ filt_out)
+__global__ __launch_bounds__(NT) void k_bluestein_setup2(DevFFT F, int synth, const int *__restrict__ qlist, double2 *__restrict__ filt_out)
 {
     extern __shared__ double2 ws[];
     const int q = qlist[blockIdx.x];
-    const int M = F.M2of[q], K = F.K2of[q];
-    double2 *filt = filt_out + F.coff2[q];
+    const FftSide &sd = synth ? F.S : F.A;
+    const int M = sd.Mof[q];
+    const int Kn = synth ? q - 1 : F.K2of[q], Kp = synth ? 0 : F.K2of[q];
+    double2 *filt = filt_out + sd.coff[q];
     for (int t = threadIdx.x; t < M; t += NT) ws[t] = make_double2(0., 0.);
     __syncthreads();
-    for (int t = threadIdx.x; t < q + 2 * K; t += NT) {
-        const int dd = t - K;  // -K .. q - 1 + K
+    for (int t = threadIdx.x; t < q + Kn + Kp; t += NT) {
+        const int dd = t - Kn;  // -Kn .. q - 1 + Kp
         const long long t2 = ((long long)dd * dd) % (2LL * q);
         const double2 w = cispi((double)t2 / (double)q);
         ws[(dd + M) & (M - 1)] = cconj(w);
@@ -794,7 +833,7 @@ template <int NT, int QMAX>
 static hipError_t launch_p2m(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *phase, double *map,
                              hipStream_t st)
 {
-    if (F.legacy_n == 0) return hipSuccess;
+    if (F.A.legacy_n == 0) return hipSuccess;
     const size_t lds = fft_lds_bytes(F);
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
@@ -804,7 +843,7 @@ static hipError_t launch_p2m(const DevPlan &P, const DevFFT &F, const int *mlim,
         attr_done = true;
     }
     static int dbg = getenv("PLSHTS_FFTDBG") ? atoi(getenv("PLSHTS_FFTDBG")) : 0;
-    hipLaunchKernelGGL((k_phase2map<NT, QMAX>), dim3(F.legacy_n, ncomp), dim3(NT), lds, st, P, F, F.legacy_pairs, mlim, ncomp, phase, map, dbg);
+    hipLaunchKernelGGL((k_phase2map<NT, QMAX>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds, st, P, F, F.A.legacy_pairs, mlim, ncomp, phase, map, dbg);
     return hipGetLastError();
 }
 
@@ -812,7 +851,7 @@ template <int NT, int QMAX>
 static hipError_t launch_m2p(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *map, double *phase,
                              hipStream_t st)
 {
-    if (F.legacy_n == 0) return hipSuccess;
+    if (F.A.legacy_n == 0) return hipSuccess;
     const size_t lds = fft_lds_bytes(F);
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
@@ -821,7 +860,7 @@ static hipError_t launch_m2p(const DevPlan &P, const DevFFT &F, const int *mlim,
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_map2phase<NT, QMAX>), dim3(F.legacy_n, ncomp), dim3(NT), lds, st, P, F, F.legacy_pairs, mlim, ncomp, map, phase);
+    hipLaunchKernelGGL((k_map2phase<NT, QMAX>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds, st, P, F, F.A.legacy_pairs, mlim, ncomp, map, phase);
     return hipGetLastError();
 }
 
@@ -853,7 +892,8 @@ template <int N>
 static hipError_t launch_fast_class(const DevPlan &P, const DevFFT &F, int cls, bool synth, const int *mlim, int ncomp, const double *in,
                                     double *out, hipStream_t st)
 {
-    if (F.cls_n[cls] == 0) return hipSuccess;
+    const FftSide &sd = F.A;  // both directions use the band-limited classes
+    if (sd.cls_n[cls] == 0) return hipSuccess;
     const size_t lds = (size_t)N * sizeof(double2);
     if (lds > 48 * 1024) {
         static bool attr_done = false;
@@ -864,36 +904,87 @@ static hipError_t launch_fast_class(const DevPlan &P, const DevFFT &F, int cls, 
             attr_done = true;
         }
     }
-    if (synth) hipLaunchKernelGGL((k_phase2map_fast<N>), dim3(F.cls_n[cls], ncomp), dim3(N / 8), lds, st, P, F, F.cls_pairs[cls], mlim, ncomp, in, out);
-    else hipLaunchKernelGGL((k_map2phase_fast<N>), dim3(F.cls_n[cls], ncomp), dim3(N / 8), lds, st, P, F, F.cls_pairs[cls], mlim, ncomp, in, out);
+    if (synth) hipLaunchKernelGGL((k_phase2map_fast<N>), dim3(sd.cls_n[cls], ncomp), dim3(N / 8), lds, st, P, F, sd.cls_pairs[cls], mlim, ncomp, in, out);
+    else hipLaunchKernelGGL((k_map2phase_fast<N>), dim3(sd.cls_n[cls], ncomp), dim3(N / 8), lds, st, P, F, sd.cls_pairs[cls], mlim, ncomp, in, out);
     return hipGetLastError();
 }
 
-static hipError_t launch_fast(const DevPlan &P, const DevFFT &F, bool synth, const int *mlim, int ncomp, const double *in, double *out,
-                              hipStream_t st)
+hipError_t fft_streams_create(FftStreams &fs)
 {
-    hipError_t e = launch_fast_class<4096>(P, F, 4, synth, mlim, ncomp, in, out, st);  // longest transforms first
-    if (e == hipSuccess) e = launch_fast_class<2048>(P, F, 3, synth, mlim, ncomp, in, out, st);
-    if (e == hipSuccess) e = launch_fast_class<1024>(P, F, 2, synth, mlim, ncomp, in, out, st);
-    if (e == hipSuccess) e = launch_fast_class<512>(P, F, 1, synth, mlim, ncomp, in, out, st);
-    if (e == hipSuccess) e = launch_fast_class<256>(P, F, 0, synth, mlim, ncomp, in, out, st);
+    hipError_t e = hipEventCreateWithFlags(&fs.fork, hipEventDisableTiming);
+    for (int i = 0; i < FftStreams::kN && e == hipSuccess; ++i) {
+        e = hipStreamCreateWithFlags(&fs.s[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&fs.join[i], hipEventDisableTiming);
+    }
+    fs.ok = e == hipSuccess;
     return e;
 }
 
-hipError_t launch_phase2map(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *phase, double *map,
-                            hipStream_t st)
+void fft_streams_destroy(FftStreams &fs)
 {
-    hipError_t e = launch_fast(P, F, true, mlim, ncomp, phase, map, st);
-    if (e == hipSuccess) e = launch_phase2map_legacy(P, F, mlim, ncomp, phase, map, st);
+    for (int i = 0; i < FftStreams::kN; ++i) {
+        if (fs.s[i]) (void)hipStreamDestroy(fs.s[i]);
+        if (fs.join[i]) (void)hipEventDestroy(fs.join[i]);
+        fs.s[i] = nullptr; fs.join[i] = nullptr;
+    }
+    if (fs.fork) (void)hipEventDestroy(fs.fork);
+    fs.fork = nullptr; fs.ok = false;
+}
+
+// One FFT stage = up to six independent kernels (five register classes + the generic kernel).  The biggest one runs on
+// the caller's stream, the others on the plan's side streams between a fork and a join event.
+static hipError_t launch_stage(const DevPlan &P, const DevFFT &F, const FftStreams &fs, bool synth, const int *mlim, int ncomp,
+                               const double *in, double *out, hipStream_t st)
+{
+    const bool par = fs.ok && !(getenv("PLSHTS_FFT_SERIAL") && atoi(getenv("PLSHTS_FFT_SERIAL")) != 0);
+    int big = -1;  // class with the most work stays on the caller's stream
+    { int64_t best = -1; for (int c = 0; c < 5; ++c) { const int64_t w = (int64_t)F.A.cls_n[c] * (256 << c); if (F.A.cls_n[c] > 0 && w > best) { best = w; big = c; } } }
+    hipError_t e = hipSuccess;
+    if (par) e = hipEventRecord(fs.fork, st);
+    int used = 0;
+    bool joined[FftStreams::kN] = {false, false, false, false, false};
+    auto side = [&](int c) -> hipStream_t {
+        if (!par || c == big || used >= FftStreams::kN) return st;
+        const int i = used++;
+        if (hipStreamWaitEvent(fs.s[i], fs.fork, 0) != hipSuccess) return st;
+        joined[i] = true;
+        return fs.s[i];
+    };
+    auto run = [&](int c) -> hipError_t {
+        if (F.A.cls_n[c] == 0) return hipSuccess;
+        hipStream_t s = side(c);
+        switch (c) {
+        case 4: return launch_fast_class<4096>(P, F, 4, synth, mlim, ncomp, in, out, s);
+        case 3: return launch_fast_class<2048>(P, F, 3, synth, mlim, ncomp, in, out, s);
+        case 2: return launch_fast_class<1024>(P, F, 2, synth, mlim, ncomp, in, out, s);
+        case 1: return launch_fast_class<512>(P, F, 1, synth, mlim, ncomp, in, out, s);
+        default: return launch_fast_class<256>(P, F, 0, synth, mlim, ncomp, in, out, s);
+        }
+    };
+    for (int c = 4; c >= 0 && e == hipSuccess; --c) e = run(c);  // longest transforms first
+    if (e == hipSuccess && F.A.legacy_n > 0) {
+        hipStream_t s = big < 0 ? st : side(-1);
+        e = synth ? launch_phase2map_legacy(P, F, mlim, ncomp, in, out, s) : launch_map2phase_legacy(P, F, mlim, ncomp, in, out, s);
+    }
+    for (int i = 0; i < used; ++i) {
+        if (!joined[i]) continue;
+        hipError_t e2 = hipEventRecord(fs.join[i], fs.s[i]);
+        if (e2 == hipSuccess) e2 = hipStreamWaitEvent(st, fs.join[i], 0);
+        if (e == hipSuccess) e = e2;
+    }
     return e;
 }
 
-hipError_t launch_map2phase(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *map, double *phase,
-                            hipStream_t st)
+hipError_t launch_phase2map(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *phase,
+                            double *map, hipStream_t st)
 {
-    hipError_t e = launch_fast(P, F, false, mlim, ncomp, map, phase, st);
-    if (e == hipSuccess) e = launch_map2phase_legacy(P, F, mlim, ncomp, map, phase, st);
-    return e;
+    return launch_stage(P, F, fs, true, mlim, ncomp, phase, map, st);
+}
+
+hipError_t launch_map2phase(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *map,
+                            double *phase, hipStream_t st)
+{
+    return launch_stage(P, F, fs, false, mlim, ncomp, map, phase, st);
 }
 
 hipError_t launch_twiddles(double *tw, int Mtw, hipStream_t st)
@@ -916,7 +1007,7 @@ hipError_t launch_bluestein_setup(const DevFFT &F, const int *qlist_dev, int nq,
     return hipGetLastError();
 }
 
-hipError_t launch_bluestein_setup2(const DevFFT &F, const int *qlist_dev, int nq, int Mmax, double *filt2, hipStream_t st)
+hipError_t launch_bluestein_setup2(const DevFFT &F, int synth, const int *qlist_dev, int nq, int Mmax, double *filt2, hipStream_t st)
 {
     if (nq == 0) return hipSuccess;
     const size_t lds = (size_t)Mmax * sizeof(double2);
@@ -925,7 +1016,7 @@ hipError_t launch_bluestein_setup2(const DevFFT &F, const int *qlist_dev, int nq
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_bluestein_setup2<256>, dim3(nq), dim3(256), lds, st, F, qlist_dev, reinterpret_cast<double2 *>(filt2));
+    hipLaunchKernelGGL(k_bluestein_setup2<256>, dim3(nq), dim3(256), lds, st, F, synth, qlist_dev, reinterpret_cast<double2 *>(filt2));
     return hipGetLastError();
 }
 
