@@ -32,6 +32,28 @@ if ROOT not in sys.path:
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 vector (= matrix) peak; SURVEY.md 8(d)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+# k_leg_synths, spin 2, nside = lmax = 2048: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), bytes per launch
+# (profiles/round1_pmc_traffic.csv; refreshed whenever the kernel changes materially)
+SYNTHS_TRAFFIC_BYTES = (1334384 + 373984) * 1024
+
+
+def executed_flops(nside, lmax, spin):
+    """Flops of the (l, m, ring pair) recursion steps a Legendre kernel actually runs: rings with m > mlim(theta) are
+    pruned (same rule as the kernels, csrc/tables.cpp mlim_ring).  spin >= 1: 12 FMA per step; spin 0: the two-step
+    recursion does 6 FMA per pair of l."""
+    from plancklens_amd import hp
+    cth, sth, _, _, _ = hp.ring_info(nside)
+    cth, sth = cth[:2 * nside], sth[:2 * nside]           # north member of every ring pair (equator included)
+    ofs = max(100., 0.01 * lmax)
+    b = -2. * spin * np.abs(cth)
+    t1 = lmax * sth + ofs
+    disc = b * b - 4. * (spin * spin - t1 * t1)
+    ml = np.where(disc <= 0, lmax, np.minimum((-b + np.sqrt(np.maximum(disc, 0.))) / 2., lmax))
+    ml = np.minimum(np.floor(ml + 0.5).astype(np.int64), lmax)
+    m = np.arange(lmax + 1)
+    nl = np.cumsum(lmax - np.maximum(m, spin) + 1)        # l-steps for all m <= M
+    steps = float(np.sum(nl[ml]))
+    return steps * (24. if spin else 6.)
 
 
 def parse():
@@ -219,6 +241,7 @@ def main():
         nalm = hp.Alm.getsize(lmax)
         steps_leg = nalm * 2 * nside                      # (l, m, ring pair) recursion steps per transform
         flops_spin, flops_scal = 24.0 * steps_leg, 8.0 * steps_leg
+        exec_spin, exec_scal = executed_flops(nside, lmax, 2), executed_flops(nside, lmax, 0)
         npix = hp.nside2npix(nside)
         ms, cnt = prof['leg_synths']
         res = {
@@ -236,17 +259,25 @@ def main():
             avg_ms = ms / cnt
             ach = flops_spin / (avg_ms * 1e-3) / 1e12
             res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / FP64_PEAK_TFLOPS, 'traffic': None, 'kernel': 'k_leg_synths (spin-weighted Legendre synthesis)',
+                               'frac': ach / FP64_PEAK_TFLOPS, 'traffic': SYNTHS_TRAFFIC_BYTES, 'kernel': 'k_leg_synths (spin-weighted Legendre synthesis)',
                                'avg_launch_ms': avg_ms, 'launches': cnt,
-                               'note': 'FP64 vector-FMA issue bound (v_fma_f64); gfx950 FP64 MFMA peak = FP64 vector peak; no MFMA used'}
+                               'executed_tflops': exec_spin / (avg_ms * 1e-3) / 1e12,
+                               'frac_executed': exec_spin / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                               'note': 'FP64 vector-FMA issue bound (v_fma_f64); gfx950 FP64 MFMA peak = FP64 vector peak; no MFMA used. '
+                                       'achieved = SURVEY 8(d) fixed-denominator count (24 flop x nalm x 2 nside, polar pruning not counted); '
+                                       'executed_tflops counts only the (l, m, ring pair) steps the kernel runs after libsharp-style polar pruning. '
+                                       'traffic = FETCH_SIZE + WRITE_SIZE bytes per launch from profiles/ (PMC passes of an earlier run of the same kernel; '
+                                       'coefficient-table re-reads by the ring groups are served by L2 / Infinity Cache)'}
         per_kernel = {}
         alg = {'leg_synth0': flops_scal, 'leg_synths': flops_spin, 'leg_anal0': flops_scal, 'leg_anals': flops_spin}
+        exe = {'leg_synth0': exec_scal, 'leg_synths': exec_spin, 'leg_anal0': exec_scal, 'leg_anals': exec_spin}
         for k, (m_, c_) in prof.items():
             if c_ == 0:
                 continue
             ent = {'avg_ms': m_ / c_, 'launches': c_, 'share_of_step': m_ / (1e3 * dt)}
             if k in alg:
                 ent['alg_tflops'] = alg[k] / (m_ / c_ * 1e-3) / 1e12
+                ent['executed_tflops'] = exe[k] / (m_ / c_ * 1e-3) / 1e12
             else:  # ring FFT stage: algorithmic bytes = 8 npix + 32 nrings_pairs (mmax+1) per component
                 ent['alg_gbs'] = (8.0 * npix + 32.0 * 2 * nside * (lmax + 1)) / (m_ / c_ * 1e-3) / 1e9
             per_kernel[k] = ent

@@ -1,9 +1,9 @@
 """Conjugate-gradient (anisotropic noise / masked sky) CMB filtering on the MI355X, API of
-plancklens/filt/filt_cinv.py (`cinv` :22-53, `cinv_t` :56-203, `cinv_p` :206-338, `library_cinv_sepTP` :515-580).
+plancklens/filt/filt_cinv.py (`cinv` :22-53, `cinv_t` :56-203, `cinv_p` :206-338, `cinv_tp` :341-512,
+`library_cinv_sepTP` :515-580, `library_cinv_jTP` :582-620).
 
 Same multigrid chains, rescalings, side files (ftl.dat, fel.dat, fbl.dat, tal.dat, fmask.fits.gz, filt_hash.pk) and
-stopping rule as the reference; the solve itself (plancklens_amd.qcinv) runs with every vector, map and SHT in HBM.
-The joint T+P filter (cinv_tp, opfilt_tp) is not part of this round."""
+stopping rule as the reference; the solve itself (plancklens_amd.qcinv) runs with every vector, map and SHT in HBM."""
 from __future__ import print_function
 
 import os
@@ -14,7 +14,7 @@ import torch
 
 from .. import dev, hp, utils
 from ..helpers import mpi
-from ..qcinv import cd_solve, multigrid, opfilt_pp, opfilt_tt, util, util_alm
+from ..qcinv import cd_solve, multigrid, opfilt_pp, opfilt_tp, opfilt_tt, util, util_alm
 from . import filt_simple
 
 
@@ -246,6 +246,134 @@ class cinv_p(cinv):
         return mask
 
 
+class cinv_tp(object):
+    r"""Joint temperature-polarization inverse-variance filter (filt_cinv.py:341-512).  ninv: [TT, (QQ + UU) / 2] or
+    [TT, QQ, QU, UU], each entry a list of maps / paths / scalars to multiply.  The CG runs on D_l-rescaled spectra
+    (rescal_cl) exactly as the reference does; the solution is scaled back on return."""
+
+    def __init__(self, lib_dir, lmax, nside, cl, transf, ninv, marge_maps_t=(), marge_monopole=False, marge_dipole=False,
+                 pcf='default', rescal_cl='default', chain_descr=None, transf_p=None):
+        assert lmax >= 1024 and nside >= 512, (lmax, nside)
+        assert len(ninv) == 2 or len(ninv) == 4  # TT, (QQ + UU) / 2 or TT, QQ, QU, UU
+        ls = np.arange(lmax + 1, dtype=float)
+        dl_w = np.sqrt(ls * (ls + 1.) / 2. / np.pi)
+        if rescal_cl == 'default':
+            rescal_cl = {a: dl_w.copy() for a in ['t', 'e', 'b']}
+        elif rescal_cl is None:
+            rescal_cl = {a: np.ones(lmax + 1, dtype=float) for a in ['t', 'e', 'b']}
+        elif rescal_cl == 'tonly':
+            rescal_cl = {a: np.ones(lmax + 1, dtype=float) for a in ['e', 'b']}
+            rescal_cl['t'] = dl_w.copy()
+        else:
+            assert 0
+        for k in rescal_cl.keys():
+            rescal_cl[k] /= np.mean(rescal_cl[k])  # keeps the relative TEB weights of the spectra
+        dl = {k: rescal_cl[k[0]] * rescal_cl[k[1]] * cl[k][:lmax + 1] for k in cl.keys()}
+        if transf_p is None:
+            transf_p = transf
+        transf_dls = {a: transf_p[:lmax + 1] * utils.cli(rescal_cl[a]) for a in ['e', 'b']}
+        transf_dls['t'] = transf[:lmax + 1] * utils.cli(rescal_cl['t'])
+        self.lmax = lmax
+        self.nside = nside
+        self.cl = cl
+        self.transf_t = transf
+        self.transf_p = transf_p
+        self.ninv = ninv
+        self.marge_maps_t = marge_maps_t
+        self.marge_maps_p = []
+        self.lib_dir = lib_dir
+        self.rescal_cl = rescal_cl
+        if chain_descr is None:
+            pcf = os.path.join(lib_dir, "dense_tp.pk") if pcf == 'default' else None
+            chain_descr = \
+                [[3, ["split(dense(%s), 64, diag_cl)" % pcf], 256, 128, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
+                 [2, ["split(stage(3),  256, diag_cl)"], 512, 256, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
+                 [1, ["split(stage(2),  512, diag_cl)"], 1024, 512, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
+                 [0, ["split(stage(1), 1024, diag_cl)"], lmax, nside, np.inf, 1.0e-5, cd_solve.tr_cg, cd_solve.cache_mem()]]
+        n_inv_filt = util.jit(opfilt_tp.alm_filter_ninv, ninv, transf_dls['t'], b_transf_e=transf_dls['e'], b_transf_b=transf_dls['b'],
+                              marge_maps_t=marge_maps_t, marge_monopole=marge_monopole, marge_dipole=marge_dipole)
+        self.chain_descr = chain_descr
+        self.chain = util.jit(multigrid.multigrid_chain, opfilt_tp, chain_descr, dl, n_inv_filt)
+        if mpi.rank == 0:
+            if not os.path.exists(lib_dir):
+                os.makedirs(lib_dir)
+            if not os.path.exists(os.path.join(lib_dir, "filt_hash.pk")):
+                pk.dump(self.hashdict(), open(os.path.join(lib_dir, "filt_hash.pk"), 'wb'), protocol=2)
+            if not os.path.exists(os.path.join(lib_dir, "fal.pk")):
+                pk.dump(self._calc_fal(), open(os.path.join(lib_dir, "fal.pk"), 'wb'), protocol=2)
+            if not os.path.exists(os.path.join(lib_dir, "fmask.fits.gz")):
+                hp.write_map(os.path.join(lib_dir, "fmask.fits.gz"), self.calc_mask())
+        mpi.barrier()
+        fn = os.path.join(lib_dir, "filt_hash.pk")
+        utils.hash_check(pk.load(open(fn, 'rb')), self.hashdict(), fn=fn)
+
+    def hashdict(self):
+        ret = {'lmax': self.lmax, 'nside': self.nside,
+               'rescal_cl': {k: utils.clhash(self.rescal_cl[k]) for k in self.rescal_cl.keys()},
+               'cls': {k: utils.clhash(self.cl[k]) for k in self.cl.keys()},
+               'transf': utils.clhash(self.transf_t), 'ninv': self._ninv_hash(),
+               'marge_maps_t': self.marge_maps_t, 'marge_maps_p': self.marge_maps_p}
+        if self.transf_p is not self.transf_t:
+            ret['transf_p'] = utils.clhash(self.transf_p)
+        return ret
+
+    def get_fal(self, lmax=None):
+        fal = pk.load(open(os.path.join(self.lib_dir, "fal.pk"), 'rb'))
+        return fal if lmax is None else {k: v[:lmax + 1] for k, v in fal.items()}
+
+    def _calc_fal(self):
+        """Isotropic approximation to the filtering matrix (used by the response calculations)."""
+        ninv = self.chain.n_inv_filt.n_inv
+        assert len(ninv) == 2, 'implement this, easy'
+        nlevt, nlevp = _nlev_uKamin(ninv[0]), _nlev_uKamin(ninv[1])
+        print("cinv_tp::noiseT_uk_arcmin = %.3f" % nlevt)
+        print("cinv_tp::noiseP_uk_arcmin = %.3f" % nlevp)
+        fals = np.zeros((self.lmax + 1, 3, 3), dtype=float)
+        for i, a in enumerate(['t', 'e', 'b']):
+            for j, b in enumerate(['t', 'e', 'b']):
+                fals[:, i, j] = self.cl.get(a + b, self.cl.get(b + a, np.zeros(self.lmax + 1)))[:self.lmax + 1]
+        fals[1:, 0, 0] += ((nlevt / 180 / 60 * np.pi) / self.transf_t[1:self.lmax + 1]) ** 2
+        fals[2:, 1, 1] += ((nlevp / 180 / 60 * np.pi) / self.transf_p[2:self.lmax + 1]) ** 2
+        fals[2:, 2, 2] += ((nlevp / 180 / 60 * np.pi) / self.transf_p[2:self.lmax + 1]) ** 2
+        fals = np.linalg.pinv(fals)
+        fals_dict = {}
+        for i, a in enumerate(['t', 'e', 'b']):
+            for j, b in enumerate(['t', 'e', 'b'][i:]):
+                if np.any(fals[:, i, i + j]):
+                    fals_dict[a + b] = fals[:, i, i + j]
+        return fals_dict
+
+    def calc_mask(self):
+        mask = np.ones(hp.nside2npix(self.nside), dtype=float)
+        for ninv in self.chain.n_inv_filt.n_inv:
+            assert hp.npix2nside(ninv.numel()) == self.nside
+            mask *= dev.to_host((ninv > 0.).to(torch.float64))
+        return mask
+
+    def get_fmask(self):
+        return hp.read_map(os.path.join(self.lib_dir, "fmask.fits.gz"))
+
+    def apply_ivf(self, tqumap, soltn=None, apply_fini=''):
+        assert len(tqumap) == 3
+        on_dev = isinstance(tqumap[0], torch.Tensor)
+        n = hp.Alm.getsize(self.lmax)
+        if soltn is None:
+            alms = [torch.zeros(n, dtype=torch.complex128, device=dev.device()) for _ in range(3)]
+        else:
+            alms = [dev.almxfl(dev.to_dev(a, torch.complex128), self.rescal_cl[f]) for a, f in zip(soltn, 'teb')]
+        talm = util_alm.teblm(alms)
+        self.chain.solve(talm, [tqumap[0], tqumap[1], tqumap[2]], apply_fini=apply_fini)
+        ret = [dev.almxfl(a, self.rescal_cl[f]) for a, f in zip((talm.tlm, talm.elm, talm.blm), 'teb')]
+        return tuple(ret) if on_dev else tuple(dev.to_host(a) for a in ret)
+
+    def _ninv_hash(self):
+        def h(c):  # arrays by content, nested lists element-wise, paths and scalars as they are
+            if isinstance(c, (list, tuple)):
+                return [h(x) for x in c]
+            return utils.clhash(c) if (isinstance(c, np.ndarray) and c.size > 1) else c
+        return [[h(c) for c in self.ninv]]
+
+
 class library_cinv_sepTP(filt_simple.library_sepTP):
     """Filters a simulation library with separate temperature and polarization CG filters (filt_cinv.py:515-580)."""
 
@@ -296,3 +424,31 @@ class library_cinv_sepTP(filt_simple.library_sepTP):
 
     def get_bmliklm(self, idx):
         return hp.almxfl(self.get_sim_blm(idx), self.cinv_p.cl['bb'])
+
+
+class library_cinv_jTP(filt_simple.library_jTP):
+    """Filters a simulation library with the joint temperature-polarization CG filter (filt_cinv.py:582-620)."""
+
+    def __init__(self, lib_dir, sim_lib, cinv_jtp, cl_weights, soltn_lib=None):
+        self.cinv_tp = cinv_jtp
+        super(library_cinv_jTP, self).__init__(lib_dir, sim_lib, cl_weights, soltn_lib=soltn_lib)
+        if mpi.rank == 0:
+            fname_mask = os.path.join(self.lib_dir, "fmask.fits.gz")
+            if not os.path.exists(fname_mask):
+                hp.write_map(fname_mask, self.cinv_tp.get_fmask())
+        mpi.barrier()
+        fn = os.path.join(lib_dir, "filt_hash.pk")
+        utils.hash_check(pk.load(open(fn, 'rb')), self.hashdict(), fn=fn)
+
+    def hashdict(self):
+        return {'cinv_tp': self.cinv_tp.hashdict(), 'clw': {k: utils.clhash(self.cl[k]) for k in self.cl.keys()},
+                'sim_lib': self.sim_lib.hashdict()}
+
+    def get_fmask(self):
+        return hp.read_map(os.path.join(self.lib_dir, "fmask.fits.gz"))
+
+    def get_fal(self, lmax=None):
+        return self.cinv_tp.get_fal(lmax=lmax)
+
+    def _apply_ivf(self, tqumap, soltn=None):
+        return self.cinv_tp.apply_ivf(tqumap, soltn=soltn)

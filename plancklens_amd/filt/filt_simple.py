@@ -133,6 +133,99 @@ class library_sepTP(object):
         return hp.almxfl(self.get_sim_blm(idx), self.cl['bb'])
 
 
+class library_jTP(object):
+    """Template for jointly filtered T and P (filt_simple.py:187-343).  Subclasses provide `_apply_ivf` (three maps ->
+    three alms), `get_fal`, `get_fmask`, `hashdict`.  The Wiener-filtered legs mix the fields through the
+    cross-spectra of `cl_weights` (te, tb, eb when present)."""
+
+    _dev_slots = 4
+
+    def __init__(self, lib_dir, sim_lib, cl_weights, soltn_lib=None, cache=True):
+        assert np.all([k in cl_weights.keys() for k in ['tt', 'ee', 'bb']])
+        self.lib_dir = lib_dir
+        self.sim_lib = sim_lib
+        self.cl = cl_weights
+        self.soltn_lib = soltn_lib
+        self.cache = cache
+        self._dev_cache = {}
+        fn_hash = os.path.join(lib_dir, 'filt_hash.pk')
+        if mpi.rank == 0:
+            if not os.path.exists(lib_dir):
+                os.makedirs(lib_dir)
+            if not os.path.exists(fn_hash):
+                pk.dump(self.hashdict(), open(fn_hash, 'wb'), protocol=2)
+        mpi.barrier()
+        utils.hash_check(pk.load(open(fn_hash, 'rb')), self.hashdict(), fn=fn_hash)
+
+    def hashdict(self):
+        assert 0, 'override this'
+
+    def get_fmask(self):
+        assert 0, 'override this'
+
+    def _apply_ivf(self, tqumap, soltn=None):
+        assert 0, 'override this'
+
+    def get_fal(self):
+        assert 0, 'override this'
+
+    def _fn(self, a, idx):
+        return os.path.join(self.lib_dir, ('sim_%04d_%slm.fits' % (idx, a)) if idx >= 0 else 'dat_%slm.fits' % a)
+
+    def _dev_entry(self, idx):
+        if idx not in self._dev_cache:
+            while len(self._dev_cache) >= self._dev_slots:
+                self._dev_cache.pop(next(iter(self._dev_cache)))
+            self._dev_cache[idx] = {}
+        return self._dev_cache[idx]
+
+    def get_sim_alm_dev(self, name, idx):
+        """Device tensor of 'tlm' | 'elm' | 'blm' | 'tmliklm' | 'emliklm' | 'bmliklm' for simulation idx."""
+        a = name[0]
+        if name.endswith('mliklm'):
+            ret = dev.almxfl(self.get_sim_alm_dev(a + 'lm', idx), self.cl[a + a])
+            for b in 'teb':
+                if b != a:
+                    cl = self.cl.get(a + b, self.cl.get(b + a, None))
+                    if cl is not None:
+                        ret = ret + dev.almxfl(self.get_sim_alm_dev(b + 'lm', idx), cl)
+            return ret
+        ent = self._dev_entry(idx)
+        if a not in ent:
+            if self.cache and os.path.exists(self._fn(a, idx)):
+                ent[a] = dev.to_dev(hp.read_alm(self._fn(a, idx)), torch.complex128)
+            else:
+                T = self.sim_lib.get_sim_tmap(idx)
+                Q, U = self.sim_lib.get_sim_pmap(idx)
+                soltn = None
+                if self.soltn_lib is not None:
+                    soltn = (self.soltn_lib.get_sim_tmliklm(idx), self.soltn_lib.get_sim_emliklm(idx), self.soltn_lib.get_sim_bmliklm(idx))
+                alms = self._apply_ivf([dev.to_dev(m, torch.float64) for m in (T, Q, U)], soltn=soltn)
+                for f, alm in zip('teb', alms):
+                    ent[f] = dev.to_dev(alm)
+                    if self.cache:
+                        hp.write_alm(self._fn(f, idx), dev.to_host(ent[f]), overwrite=True)
+        return ent[a]
+
+    def get_sim_tlm(self, idx):
+        return dev.to_host(self.get_sim_alm_dev('tlm', idx))
+
+    def get_sim_elm(self, idx):
+        return dev.to_host(self.get_sim_alm_dev('elm', idx))
+
+    def get_sim_blm(self, idx):
+        return dev.to_host(self.get_sim_alm_dev('blm', idx))
+
+    def get_sim_tmliklm(self, idx):
+        return dev.to_host(self.get_sim_alm_dev('tmliklm', idx))
+
+    def get_sim_emliklm(self, idx):
+        return dev.to_host(self.get_sim_alm_dev('emliklm', idx))
+
+    def get_sim_bmliklm(self, idx):
+        return dev.to_host(self.get_sim_alm_dev('bmliklm', idx))
+
+
 def _as_transf_dict(transf):
     d = transf if isinstance(transf, dict) else {'t': transf, 'e': transf, 'b': transf}
     assert all(k in d.keys() for k in 'teb')

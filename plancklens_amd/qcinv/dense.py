@@ -1,5 +1,5 @@
 """Dense low-l preconditioners, API of plancklens/qcinv/dense.py (`alm2rlm` / `rlm2alm` :16-54, `pre_op_dense_tt`
-:57-119, `pre_op_dense_pp` :123-202).  The (lmax+1)^2 k square matrix is filled by applying the coarse fwd_op to unit
+:57-119, `pre_op_dense_pp` :123-202, `pre_op_dense_tp` :204-285).  The (lmax+1)^2 k square matrix is filled by applying the coarse fwd_op to unit
 vectors (device SHTs), pseudo-inverted on the host with eigh exactly as the reference does, and applied as a device
 mat-vec."""
 from __future__ import print_function
@@ -12,7 +12,7 @@ import torch
 
 from .. import dev
 from ..hp import Alm
-from .util_alm import eblm
+from .util_alm import eblm, teblm
 
 _RLM_IDX = {}
 
@@ -175,3 +175,25 @@ class pre_op_dense_pp(_pre_op_dense):
     def _to_alm(self, rlm):
         n = rlm.numel() // 2
         return eblm([rlm2alm(rlm[:n]), rlm2alm(rlm[n:])])
+
+
+class pre_op_dense_tp(_pre_op_dense):
+    """Joint (T, E, B) dense block (dense.py:204-285): rlm = [T | E | B], 3 (lmax + 1)^2 real coefficients."""
+
+    def _ntmpl(self, fwd_op):
+        ntmpl = 0
+        for t in fwd_op.n_inv_filt.templates_t:
+            ntmpl += t.nmodes  # includes monopole and dipole when marginalised
+        for t in fwd_op.n_inv_filt.templates_p:
+            ntmpl += t.nmodes
+        return ntmpl + 8  # (1 mono + 3 dip) * (e + b)
+
+    def _nrlm(self, lmax):
+        return 3 * (lmax + 1) ** 2
+
+    def _to_rlm(self, alm):
+        return torch.cat([alm2rlm(alm.tlm), alm2rlm(alm.elm), alm2rlm(alm.blm)])
+
+    def _to_alm(self, rlm):
+        n = rlm.numel() // 3
+        return teblm([rlm2alm(rlm[:n]), rlm2alm(rlm[n:2 * n]), rlm2alm(rlm[2 * n:])])

@@ -1,0 +1,260 @@
+"""Joint temperature + polarization Wiener / inverse-variance filtering operators on the device, API of
+plancklens/qcinv/opfilt_tp.py (`calc_prep` :14-31, `apply_fini` :34-40, `dot_op` :46-59, `fwd_op` :62-83, `pre_op_diag`
+:88-118, `alm_filter_sinv` :126-160, `alm_filter_ninv` :163-327).  Vectors are util_alm.teblm triplets of device tensors.
+
+Y = (alm2map, alm2map_spin 2) and Y^t = npix / 4 pi (map2alm, map2alm_spin 2) run on the GPU with the beams fused into
+the transforms; the inverse-noise maps, the T template projector and every CG vector live in HBM."""
+from __future__ import print_function
+
+import numpy as np
+import torch
+
+from .. import dev, hp, shts
+from ..utils import clhash
+from . import dense, template_removal, util
+from .util_alm import teblm
+
+alm2map, map2alm, alm2map_spin, map2alm_spin = shts.alm2map, shts.map2alm, shts.alm2map_spin, shts.map2alm_spin
+
+
+def calc_prep(maps, s_cls, n_inv_filt):
+    """b = B^t Y^t N^-1 d for d = (T, Q, U)."""
+    tmap, qmap, umap = (dev.to_dev(m, torch.float64).clone() for m in maps)
+    assert tmap.numel() == qmap.numel() == umap.numel()
+    npix = tmap.numel()
+    n_inv_filt.apply_map([tmap, qmap, umap])
+    lmax = len(n_inv_filt.b_transf) - 1
+    tlm = map2alm(tmap, lmax=lmax, iter=0, fl=n_inv_filt.b_transf_t * (npix / (4. * np.pi)))
+    elm, blm = map2alm_spin([qmap, umap], 2, lmax=lmax)
+    elm = dev.almxfl(elm, n_inv_filt.b_transf_e * (npix / (4. * np.pi)))
+    blm = dev.almxfl(blm, n_inv_filt.b_transf_b * (npix / (4. * np.pi)))
+    return teblm([tlm, elm, blm])
+
+
+def apply_fini(alm, s_cls, n_inv_filt):
+    """Wiener-filtered solution -> inverse-variance filtered: x <- S^-1 x (in place)."""
+    lmax = len(n_inv_filt.b_transf) - 1
+    ret = alm_filter_sinv(s_cls, lmax).calc(alm)
+    alm.tlm.copy_(ret.tlm)
+    alm.elm.copy_(ret.elm)
+    alm.blm.copy_(ret.blm)
+
+
+def apply_finiMLIK(alm, s_cls, n_inv_filt):
+    pass
+
+
+class dot_op(object):
+    """sum_l (2l + 1) (C_l^{TT'} + C_l^{EE'} + C_l^{BB'})."""
+
+    def __call__(self, alm1, alm2):
+        assert alm1.lmaxt == alm2.lmaxt, (alm1.lmaxt, alm2.lmaxt)
+        assert alm1.lmaxe == alm2.lmaxe, (alm1.lmaxe, alm2.lmaxe)
+        assert alm1.lmaxb == alm2.lmaxb, (alm1.lmaxb, alm2.lmaxb)
+        ret = 0.
+        for a, b, lmax in ((alm1.tlm, alm2.tlm, alm1.lmaxt), (alm1.elm, alm2.elm, alm1.lmaxe), (alm1.blm, alm2.blm, alm1.lmaxb)):
+            ret += float(torch.dot(dev.alm2cl(a, b), dev.fl_dev(2. * np.arange(lmax + 1) + 1., lmax)))
+        return ret
+
+
+class fwd_op(object):
+    """x -> S^-1 x + B^t Y^t N^-1 Y B x."""
+
+    def __init__(self, s_cls, n_inv_filt):
+        lmax = len(n_inv_filt.b_transf) - 1
+        self.s_inv_filt = alm_filter_sinv(s_cls, lmax)
+        self.n_inv_filt = n_inv_filt
+
+    def hashdict(self):
+        return {'s_inv_filt': self.s_inv_filt.hashdict(), 'n_inv_filt': self.n_inv_filt.hashdict()}
+
+    def __call__(self, alm):
+        return self.calc(alm)
+
+    def calc(self, alm):
+        nlm = alm * 1.0
+        self.n_inv_filt.apply_alm(nlm)
+        return nlm + self.s_inv_filt.calc(alm)
+
+
+def _apply_3x3(tmat, alm, te_only):
+    """(T, E, B) <- per-l 3x3 matrix applied to (T, E, B); B decouples when there is no TB / EB power (te_only)."""
+    rtlm = dev.almxfl(alm.tlm, tmat[:, 0, 0]) + dev.almxfl(alm.elm, tmat[:, 0, 1])
+    relm = dev.almxfl(alm.tlm, tmat[:, 1, 0]) + dev.almxfl(alm.elm, tmat[:, 1, 1])
+    rblm = dev.almxfl(alm.blm, tmat[:, 2, 2])
+    if not te_only:
+        rtlm = rtlm + dev.almxfl(alm.blm, tmat[:, 0, 2])
+        relm = relm + dev.almxfl(alm.blm, tmat[:, 1, 2])
+        rblm = rblm + dev.almxfl(alm.tlm, tmat[:, 2, 0]) + dev.almxfl(alm.elm, tmat[:, 2, 1])
+    return teblm([rtlm, relm, rblm])
+
+
+class pre_op_diag(object):
+    """Harmonic-space block-diagonal preconditioner: per-l pseudo-inverse of S^-1 + diag(N^-1 b^2) (3 x 3 in T, E, B)."""
+
+    def __init__(self, s_cls, n_inv_filt):
+        lmax = len(n_inv_filt.b_transf) - 1
+        s_inv_filt = alm_filter_sinv(s_cls, lmax)
+        assert (s_inv_filt.lmax + 1) >= len(n_inv_filt.b_transf)
+        ninv_ftl, ninv_fel, ninv_fbl = n_inv_filt.get_ftebl()
+        flmat = s_inv_filt.slinv[0:lmax + 1, :, :].copy()
+        flmat[:, 0, 0] += ninv_ftl
+        flmat[:, 1, 1] += ninv_fel
+        flmat[:, 2, 2] += ninv_fbl
+        self.flmat = np.linalg.pinv(flmat)
+        self.te_only = s_inv_filt.te_only
+
+    def __call__(self, talm):
+        return self.calc(talm)
+
+    def calc(self, alm):
+        return _apply_3x3(self.flmat, alm, self.te_only)
+
+
+def pre_op_dense(lmax, fwd_op, cache_fname=None):
+    return dense.pre_op_dense_tp(lmax, fwd_op, cache_fname=cache_fname)
+
+
+class alm_filter_sinv(object):
+    """S^-1: per-l pseudo-inverse of the 3 x 3 matrix of TEB spectra."""
+
+    def __init__(self, s_cls, lmax):
+        slmat = np.zeros((lmax + 1, 3, 3))
+        z = np.zeros(lmax + 1)
+        slmat[:, 0, 0] = s_cls.get('tt', z)[:lmax + 1]
+        slmat[:, 0, 1] = s_cls.get('te', z)[:lmax + 1]
+        slmat[:, 1, 0] = slmat[:, 0, 1]
+        slmat[:, 0, 2] = s_cls.get('tb', z)[:lmax + 1]
+        slmat[:, 2, 0] = slmat[:, 0, 2]
+        slmat[:, 1, 1] = s_cls.get('ee', z)[:lmax + 1]
+        slmat[:, 1, 2] = s_cls.get('eb', z)[:lmax + 1]
+        slmat[:, 2, 1] = slmat[:, 1, 2]
+        slmat[:, 2, 2] = s_cls.get('bb', z)[:lmax + 1]
+        self.lmax = lmax
+        self.slinv = np.linalg.pinv(slmat)
+        self.te_only = not (np.any(slmat[:, 0, 2]) or np.any(slmat[:, 1, 2]))
+
+    def calc(self, alm):
+        return _apply_3x3(self.slinv, alm, self.te_only)
+
+    def hashdict(self):
+        return {'slinv': clhash(self.slinv.flatten())}
+
+
+class alm_filter_ninv(object):
+    """Pixel-space inverse noise for (T, Q, U): maps (TT, (QQ + UU) / 2) or (TT, QQ, QU, UU); each entry may be a list of
+    maps / paths / scalars to be multiplied together.  Optional T templates (monopole, dipole, maps) are projected out."""
+
+    def __init__(self, n_inv, b_transf, b_transf_e=None, b_transf_b=None, marge_monopole=False, marge_dipole=False,
+                 marge_maps_t=(), marge_maps_p=()):
+        self.n_inv = []
+        for tn in n_inv:
+            if isinstance(tn, list):
+                prod = np.array(util.read_map(tn[0]), dtype=float)
+                for n in tn[1:]:
+                    prod = prod * util.read_map(n)
+                self.n_inv.append(dev.to_dev(prod, torch.float64))
+            else:
+                self.n_inv.append(dev.to_dev(util.read_map(tn), torch.float64))
+        assert len(self.n_inv) in (2, 4), len(self.n_inv)
+        npix = self.n_inv[0].numel()
+        for n in self.n_inv[1:]:
+            assert n.numel() == npix
+        templates_t, templates_t_hash = [], []
+        for tmap in [util.read_map(m) for m in marge_maps_t]:
+            assert npix == len(tmap)
+            templates_t.append(template_removal.template_map(tmap))
+            templates_t_hash.append(clhash(tmap))
+        if marge_monopole:
+            templates_t.append(template_removal.template_monopole())
+        if marge_dipole:
+            templates_t.append(template_removal.template_dipole())
+        if len(templates_t) != 0:
+            nmodes = int(np.sum([t.nmodes for t in templates_t]))
+            modes_idx_t = np.concatenate([t.nmodes * [int(im)] for im, t in enumerate(templates_t)])
+            modes_idx_i = np.concatenate([range(0, t.nmodes) for t in templates_t])
+            Pt_Nn1_P = np.zeros((nmodes, nmodes))
+            for ir in range(nmodes):
+                tmap = self.n_inv[0].clone()
+                templates_t[modes_idx_t[ir]].apply_mode(tmap, int(modes_idx_i[ir]))
+                ic = 0
+                for tc in templates_t[0:modes_idx_t[ir] + 1]:
+                    Pt_Nn1_P[ir, ic:(ic + tc.nmodes)] = tc.dot(tmap)
+                    Pt_Nn1_P[ic:(ic + tc.nmodes), ir] = Pt_Nn1_P[ir, ic:(ic + tc.nmodes)]
+                    ic += tc.nmodes
+            self.Pt_Nn1_P_inv = np.linalg.inv(Pt_Nn1_P)
+        self.b_transf_t = b_transf
+        self.b_transf_e = b_transf_e if b_transf_e is not None else b_transf
+        self.b_transf_b = b_transf_b if b_transf_b is not None else b_transf
+        assert len(self.b_transf_t) == len(self.b_transf_e) and len(self.b_transf_t) == len(self.b_transf_b)
+        self.b_transf = (self.b_transf_t + self.b_transf_e + self.b_transf_t) / 3.  # as in the reference (opfilt_tp.py:221)
+        self.marge_monopole = marge_monopole
+        self.marge_dipole = marge_dipole
+        self.templates_t = templates_t
+        self.templates_t_hash = templates_t_hash
+        assert len(marge_maps_p) == 0
+        self.templates_p = []
+        self.npix = npix
+        self.nside = hp.npix2nside(npix)
+
+    def get_ftebl(self):
+        if len(self.n_inv) == 2:  # TT, 1/2 (QQ + UU)
+            nt, npol = float(self.n_inv[0].sum()), float(self.n_inv[1].sum())
+        else:  # TT, QQ, QU, UU
+            nt, npol = float(self.n_inv[0].sum()), float((0.5 * (self.n_inv[1] + self.n_inv[3])).sum())
+        return (nt / (4.0 * np.pi) * self.b_transf_t ** 2, npol / (4.0 * np.pi) * self.b_transf_e ** 2,
+                npol / (4.0 * np.pi) * self.b_transf_b ** 2)
+
+    def hashdict(self):
+        return {'n_inv': [clhash(dev.to_host(n)) for n in self.n_inv], 'b_transf': clhash(self.b_transf),
+                'marge_monopole': self.marge_monopole, 'marge_dipole': self.marge_dipole,
+                'templates_t_hash': self.templates_t_hash}
+
+    def degrade(self, nside):
+        """Coarser copy: hp.ud_grade(power=-2) sums the inverse variances of the children; template maps are dropped."""
+        if nside == self.nside:
+            return self
+        print("DEGRADING WITH NO MARGE MAPS")
+        return alm_filter_ninv([hp.ud_grade(dev.to_host(n), nside, power=-2) for n in self.n_inv], self.b_transf_t,
+                               b_transf_e=self.b_transf_e, b_transf_b=self.b_transf_b, marge_monopole=self.marge_monopole,
+                               marge_dipole=self.marge_dipole, marge_maps_t=(), marge_maps_p=())
+
+    def apply_alm(self, alm):
+        """alm <- B^t Y^t N^-1 Y B alm (in place)."""
+        lmax = alm.lmax
+        assert alm.lmaxt == alm.lmaxe == alm.lmaxb == lmax
+        tmap = alm2map(alm.tlm, self.nside, lmax=lmax, fl=self.b_transf_t)
+        elm, blm = dev.almxfl(alm.elm, self.b_transf_e), dev.almxfl(alm.blm, self.b_transf_b)
+        qmap, umap = alm2map_spin([elm, blm], self.nside, 2, lmax)
+        maps = [tmap, qmap, umap]
+        self.apply_map(maps)
+        fac = self.npix / (4. * np.pi)
+        alm.tlm.copy_(map2alm(maps[0], lmax=lmax, iter=0, fl=self.b_transf_t * fac))
+        telm, tblm = map2alm_spin([maps[1], maps[2]], 2, lmax=lmax)
+        alm.elm.copy_(dev.almxfl(telm, self.b_transf_e * fac))
+        alm.blm.copy_(dev.almxfl(tblm, self.b_transf_b * fac))
+
+    def apply_map(self, amap):
+        """(T, Q, U) <- N^-1 (T, Q, U) with the T templates projected out (in place)."""
+        tmap, qmap, umap = amap
+        if len(self.n_inv) == 2:  # TT, QQ = UU
+            tmap *= self.n_inv[0]
+            qmap *= self.n_inv[1]
+            umap *= self.n_inv[1]
+        else:  # TT, QQ, QU, UU
+            qmap_copy = qmap.clone()
+            tmap *= self.n_inv[0]
+            qmap *= self.n_inv[1]
+            qmap += self.n_inv[2] * umap
+            umap *= self.n_inv[3]
+            umap += self.n_inv[2] * qmap_copy
+        if len(self.templates_t) != 0:
+            coeffs = np.concatenate([t.dot(tmap) for t in self.templates_t])
+            coeffs = np.dot(self.Pt_Nn1_P_inv, coeffs)
+            pmodes = torch.zeros_like(tmap)
+            im = 0
+            for t in self.templates_t:
+                t.accum(pmodes, coeffs[im:(im + t.nmodes)])
+                im += t.nmodes
+            pmodes *= self.n_inv[0]
+            tmap -= pmodes

@@ -33,8 +33,18 @@ def install_healpy_standin():
     for name in ['Alm', 'almxfl', 'alm2cl', 'gauss_beam', 'nside2npix', 'npix2nside', 'nside2pixarea', 'ud_grade',
                  'read_alm', 'write_alm', 'read_map', 'write_map', 'pix2ang', 'pix2vec', 'UNSEEN']:
         setattr(m, name, getattr(myhp, name))
-    m.alm2map = lambda alm, nside, lmax=None, mmax=None, **kw: so.alm2map(np.asarray(alm), nside, lmax=lmax)
-    m.map2alm = lambda mp, lmax=None, mmax=None, iter=0, **kw: so.map2alm(np.asarray(mp), lmax=lmax, iter=iter)
+    def alm2map(alm, nside, lmax=None, mmax=None, pol=False, **kw):
+        if pol and not isinstance(alm, np.ndarray) and len(alm) == 3:  # (T, E, B) -> (T, Q, U), as healpy's pol=True
+            q, u = so.alm2map_spin([np.asarray(alm[1]), np.asarray(alm[2])], nside, 2, so.alm_lmax(len(alm[1])))
+            return np.array([so.alm2map(np.asarray(alm[0]), nside, lmax=lmax), q, u])
+        return so.alm2map(np.asarray(alm), nside, lmax=lmax)
+
+    def map2alm(mp, lmax=None, mmax=None, iter=0, pol=False, **kw):
+        if pol and np.ndim(mp[0]) == 1 and len(mp) == 3:
+            e, b = so.map2alm_spin([np.asarray(mp[1]), np.asarray(mp[2])], 2, lmax)
+            return np.array([so.map2alm(np.asarray(mp[0]), lmax=lmax, iter=iter), e, b])
+        return so.map2alm(np.asarray(mp), lmax=lmax, iter=iter)
+    m.alm2map, m.map2alm = alm2map, map2alm
     m.alm2map_spin = lambda gclm, nside, spin, lmax, mmax=None: so.alm2map_spin(gclm, nside, spin, lmax)
     m.map2alm_spin = lambda maps, spin, lmax=None, mmax=None: so.map2alm_spin(maps, spin, lmax)
     proj = types.ModuleType('healpy.projector')
@@ -200,9 +210,42 @@ def make_cg_golden():
     out['cg_p_xe'], out['cg_p_xb'] = xe.elm, xe.blm
     f = opfilt_pp.fwd_op(cl, n_inv_filt_p)(xe)
     out['cg_p_fwd_e'], out['cg_p_fwd_b'] = f.elm, f.blm
+    # joint temperature + polarization (opfilt_tp): TE-correlated spectra, T monopole + dipole marginalised
+    from plancklens.qcinv import opfilt_tp
+    del trace[:]
+    cl_tp = dict(cl)
+    cl_tp['te'] = 0.6 * np.sqrt(cl['tt'] * cl['ee'])
+    out['cl_te'] = cl_tp['te']
+    transf_e = myhp.gauss_beam(7. / 180. * np.pi, lmax=lmax)   # different beam for polarization
+    out['transf_e'] = transf_e
+    n_inv_filt_tp = opfilt_tp.alm_filter_ninv([ninv_t, ninv_p], transf, b_transf_e=transf_e, b_transf_b=transf_e,
+                                              marge_monopole=True, marge_dipole=True)
+    chain_tp = multigrid.multigrid_chain(opfilt_tp, chain_descr(5, 4), cl_tp, n_inv_filt_tp)
+    orig_log_tp = chain_tp.log
+    chain_tp.log = lambda stage, it, eps, **kw: (trace.append((stage.depth, it, eps)), orig_log_tp(stage, it, eps, **kw))
+    z = lambda: np.zeros(so.alm_size(lmax), dtype=complex)
+    tpalm = util_alm.teblm([z(), z(), z()])
+    chain_tp.solve(tpalm, [tmap, qmap, umap])
+    out['cg_tp_tlm'], out['cg_tp_elm'], out['cg_tp_blm'] = tpalm.tlm, tpalm.elm, tpalm.blm
+    out['cg_tp_trace'] = np.array([t[2] for t in trace if t[0] == 0])
+    xt = util_alm.teblm([myhp.synalm(cl['tt'], lmax, rng), myhp.synalm(cl['ee'], lmax, rng), myhp.synalm(cl['bb'], lmax, rng)])
+    out['cg_tp_xt'], out['cg_tp_xe'], out['cg_tp_xb'] = xt.tlm, xt.elm, xt.blm
+    f = opfilt_tp.fwd_op(cl_tp, n_inv_filt_tp)(xt)
+    out['cg_tp_fwd_t'], out['cg_tp_fwd_e'], out['cg_tp_fwd_b'] = f.tlm, f.elm, f.blm
+    dg = opfilt_tp.pre_op_diag(cl_tp, n_inv_filt_tp)(xt)
+    out['cg_tp_diag_t'], out['cg_tp_diag_e'], out['cg_tp_diag_b'] = dg.tlm, dg.elm, dg.blm
+    pr = opfilt_tp.calc_prep([tmap, qmap, umap], cl_tp, n_inv_filt_tp)
+    out['cg_tp_prep_t'], out['cg_tp_prep_e'], out['cg_tp_prep_b'] = pr.tlm, pr.elm, pr.blm
+    out['cg_tp_dot'] = opfilt_tp.dot_op()(xt, f)
     np.savez_compressed(os.path.join(HERE, 'cg_golden.npz'), **out)
-    print('wrote cg_golden.npz; T residual trace', out['cg_t_trace'], 'P', out['cg_p_trace'])
+    print('wrote cg_golden.npz; T residual trace', out['cg_t_trace'], 'P', out['cg_p_trace'], 'TP', out['cg_tp_trace'])
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'cg':   # only the CG fixtures
+        assert os.path.isdir(REF), 'the reference is only present in the build container'
+        install_healpy_standin()
+        sys.path.insert(0, REF)
+        make_cg_golden()
+    else:
+        main()

@@ -114,3 +114,85 @@ def test_cinv_t_p_fullsky_white_noise_known_answer(tmp_path):
     er, br = shts.map2alm_spin([q, u], 2, lmax)
     er, br = hp.almxfl(er, cinv_p.get_fel() * utils.cli(transf)), hp.almxfl(br, cinv_p.get_fbl() * utils.cli(transf))
     assert relrms(elm[sel], er[sel]) < 2e-3 and relrms(blm[sel], br[sel]) < 2e-2
+
+
+def test_tp_operators_and_chain_vs_reference(g):
+    """Joint T + P filter (opfilt_tp, dense.pre_op_dense_tp, teblm): operators and the multigrid solve against the
+    reference's own run on the same TE-correlated inputs (T monopole + dipole marginalised, separate P beam)."""
+    import torch
+    from plancklens_amd import dev
+    from plancklens_amd.qcinv import multigrid, opfilt_tp
+    from plancklens_amd.qcinv.util_alm import teblm
+    lmax, nside = int(g['lmax']), int(g['nside'])
+    cl = {'tt': g['cl_tt'], 'ee': g['cl_ee'], 'bb': g['cl_bb'], 'te': g['cl_te']}
+    nf = opfilt_tp.alm_filter_ninv([g['ninv_t'], g['ninv_p']], g['transf'], b_transf_e=g['transf_e'], b_transf_b=g['transf_e'],
+                                   marge_monopole=True, marge_dipole=True)
+    x = teblm([dev.to_dev(g['cg_tp_xt']), dev.to_dev(g['cg_tp_xe']), dev.to_dev(g['cg_tp_xb'])])
+    x0 = [a.clone() for a in (x.tlm, x.elm, x.blm)]
+    f = opfilt_tp.fwd_op(cl, nf)(x)
+    for a, k in ((f.tlm, 'cg_tp_fwd_t'), (f.elm, 'cg_tp_fwd_e'), (f.blm, 'cg_tp_fwd_b')):
+        assert relrms(dev.to_host(a), g[k]) < 1e-11
+    dg = opfilt_tp.pre_op_diag(cl, nf)(x)
+    for a, k in ((dg.tlm, 'cg_tp_diag_t'), (dg.elm, 'cg_tp_diag_e'), (dg.blm, 'cg_tp_diag_b')):
+        assert relrms(dev.to_host(a), g[k]) < 1e-11
+    assert all(bool((a == b).all()) for a, b in zip((x.tlm, x.elm, x.blm), x0))  # operators leave their argument alone
+    assert abs(opfilt_tp.dot_op()(x, f) - float(g['cg_tp_dot'])) < 1e-10 * abs(float(g['cg_tp_dot']))
+    pr = opfilt_tp.calc_prep([g['tmap'], g['qmap'], g['umap']], cl, nf)
+    for a, k in ((pr.tlm, 'cg_tp_prep_t'), (pr.elm, 'cg_tp_prep_e'), (pr.blm, 'cg_tp_prep_b')):
+        assert relrms(dev.to_host(a), g[k]) < 1e-11
+    chain = multigrid.multigrid_chain(opfilt_tp, _chain_descr(lmax, nside, 5, 4), cl, nf)
+    n = g['cg_tp_tlm'].size
+    z = lambda: torch.zeros(n, dtype=torch.complex128, device='cuda')
+    sol = teblm([z(), z(), z()])
+    chain.solve(sol, [g['tmap'], g['qmap'], g['umap']])
+    assert relrms(dev.to_host(sol.tlm), g['cg_tp_tlm']) < 1e-8
+    assert relrms(dev.to_host(sol.elm), g['cg_tp_elm']) < 1e-8 and relrms(dev.to_host(sol.blm), g['cg_tp_blm']) < 1e-7
+
+
+def test_cinv_tp_fullsky_white_noise_known_answer(tmp_path):
+    """Joint filter on a full sky with white noise: for l >= 2 the solution is the per-l 3x3 isotropic filter
+    (C + N / b^2)^-1 applied to the beam-deconvolved alms (cinv_tp.get_fal), TE coupling included."""
+    from plancklens_amd import hp, shts, utils
+    from plancklens_amd.filt import filt_cinv
+    rng = np.random.default_rng(5)
+    nside, lmax = 512, 1024
+    npix = 12 * nside ** 2
+    ell = np.arange(lmax + 1.)
+    cl = {'tt': np.where(ell >= 2, 1e4 / np.maximum(ell, 1) ** 2.5, 0.), 'ee': np.where(ell >= 2, 50. / np.maximum(ell, 1) ** 2, 0.),
+          'bb': np.where(ell >= 2, 1. / np.maximum(ell, 1) ** 2, 0.)}
+    cl['te'] = 0.5 * np.sqrt(cl['tt'] * cl['ee'])
+    transf = hp.gauss_beam(10. / 60 / 180 * np.pi, lmax=lmax)
+    nlev_t, nlev_p = 30., 40.
+    vamin = np.sqrt(hp.nside2pixarea(nside, degrees=True)) * 60
+    u1, u2 = hp.synalm(np.ones(lmax + 1), lmax, rng), hp.synalm(np.ones(lmax + 1), lmax, rng)
+    r = cl['te'] * utils.cli(np.sqrt(cl['tt']))
+    tlm = hp.almxfl(u1, np.sqrt(cl['tt']))
+    elm = hp.almxfl(u1, r) + hp.almxfl(u2, np.sqrt(np.maximum(cl['ee'] - r ** 2, 0.)))
+    blm = hp.synalm(cl['bb'], lmax, rng)
+    tmap = shts.alm2map(hp.almxfl(tlm, transf), nside) + nlev_t / vamin * rng.standard_normal(npix)
+    q, u = shts.alm2map_spin([hp.almxfl(elm, transf), hp.almxfl(blm, transf)], nside, 2, lmax)
+    q = q + nlev_p / vamin * rng.standard_normal(npix)
+    u = u + nlev_p / vamin * rng.standard_normal(npix)
+    ninv = [[np.ones(npix) * (vamin / nlev_t) ** 2], [np.ones(npix) * (vamin / nlev_p) ** 2]]
+    # the reference's default 4-stage chain, with the dense block at lmax 32 instead of 64: its 12 675 column build
+    # (one coarse fwd_op each) would take two minutes of the GPU test budget, 3 267 columns take half a minute
+    from plancklens_amd.qcinv import cd_solve
+    pcf = str(tmp_path / 'cinv_tp' / 'dense_tp.pk')
+    chain_descr = [[3, ["split(dense(%s), 32, diag_cl)" % pcf], 256, 128, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
+                   [2, ["split(stage(3),  256, diag_cl)"], 512, 256, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
+                   [1, ["split(stage(2),  512, diag_cl)"], 1024, 512, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
+                   [0, ["split(stage(1), 1024, diag_cl)"], lmax, nside, np.inf, 1.0e-5, cd_solve.tr_cg, cd_solve.cache_mem()]]
+    cinv = filt_cinv.cinv_tp(str(tmp_path / 'cinv_tp'), lmax, nside, cl, transf, ninv, marge_monopole=True, marge_dipole=True,
+                             chain_descr=chain_descr)
+    st, se, sb = cinv.apply_ivf([tmap, q, u])
+    fal = cinv.get_fal()
+    dt = hp.almxfl(shts.map2alm(tmap, lmax=lmax, iter=0), utils.cli(transf))
+    de, db = shts.map2alm_spin([q, u], 2, lmax)
+    de, db = hp.almxfl(de, utils.cli(transf)), hp.almxfl(db, utils.cli(transf))
+    rt = hp.almxfl(dt, fal['tt']) + hp.almxfl(de, fal['te'])
+    re = hp.almxfl(dt, fal['te']) + hp.almxfl(de, fal['ee'])
+    rb = hp.almxfl(db, fal['bb'])
+    ls = np.concatenate([np.arange(m, lmax + 1) for m in range(lmax + 1)])
+    sel = (ls >= 2) & (ls <= 800)
+    assert relrms(st[sel], rt[sel]) < 2e-3 and relrms(se[sel], re[sel]) < 2e-3 and relrms(sb[sel], rb[sel]) < 2e-2
+    assert os.path.exists(str(tmp_path / 'cinv_tp' / 'fal.pk')) and os.path.exists(str(tmp_path / 'cinv_tp' / 'dense_tp.pk'))
