@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 import plancklens_amd
-from plancklens_amd import hp, qecl, qest, utils
+from plancklens_amd import hp, nhl, qecl, qest, qresp, utils
 from plancklens_amd.filt import filt_simple, filt_util
 from plancklens_amd.sims import cmbs, maps, phas, utils as maps_utils
 
@@ -64,3 +64,10 @@ mc_sims_var = np.arange(min(60, nsims // 5), nsims)
 qcls_dd = qecl.library(os.path.join(TEMP, 'qcls_dd'), qlms_dd, qlms_dd, mc_sims_bias)
 qcls_ds = qecl.library(os.path.join(TEMP, 'qcls_ds'), qlms_ds, qlms_ds, np.array([]))
 qcls_ss = qecl.library(os.path.join(TEMP, 'qcls_ss'), qlms_ss, qlms_ss, np.array([]))
+
+#---- semi-analytical Gaussian lensing bias library (idealized_example.py:123):
+nhl_dd = nhl.nhl_lib_simple(os.path.join(TEMP, 'nhl_dd'), ivfs, cl_weight, lmax_qlm)
+
+#---- QE response calculation library (idealized_example.py:130-131); the N1 library (n1f Fortran) is not provided:
+qresp_dd = qresp.resp_lib_simple(os.path.join(TEMP, 'qresp'), lmax_ivf, cl_weight, cl_len,
+                                 {'t': ivfs.get_ftl(), 'e': ivfs.get_fel(), 'b': ivfs.get_fbl()}, lmax_qlm)

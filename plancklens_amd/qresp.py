@@ -1,10 +1,15 @@
 """Quadratic-estimator weights, hot-path part of plancklens/qresp.py (`get_qes` :50-101, `get_resp_legs` :104-133,
-`get_covresp` :135-163, `qe_spin_data` :165-181).  The analytic responses (`get_response`, `resp_lib_simple`) need the
-Wigner-series module and are out of scope."""
+`get_covresp` :135-163, `qe_spin_data` :165-181) and the analytic responses (`resp_lib_simple` :183-267, `get_response`
+:269-310, `_get_response_custom` :313-356, `_get_response` :373-418) on the numpy Wigner series of plancklens_amd.wigners."""
+import os
+import pickle as pk
+
 import numpy as np
 
+from . import utils as ut
 from . import utils_qe as uqe
 from . import utils_spin as uspin
+from .helpers import mpi, sql
 
 
 def _clinv(cl):
@@ -93,3 +98,174 @@ def qe_spin_data(qe_key):
     assert len(np.unique(spins_out)) == 1, spins_out
     assert spins_out[0] >= 0, spins_out[0]
     return spins_out[0], 'C' if qe_key[0] == 'x' else 'G', spins_in, 'p' if qe_key[0] == 'x' else qe_key[0]
+
+
+# ---- analytic responses -----------------------------------------------------------------------------------------------
+def _gc_sums(acc, prefac, Rp, Rm, sgn):
+    """Accumulates the gradient / curl combinations of the +r and -r source-spin terms (sgn = (-1)^r)."""
+    acc[0] += prefac * (Rp.real + sgn * Rm.real)   # GG
+    acc[1] += prefac * (Rp.real - sgn * Rm.real)   # CC
+    acc[2] += prefac * (-Rp.imag + sgn * Rm.imag)  # GC
+    acc[3] += prefac * (Rp.imag + sgn * Rm.imag)   # CG
+
+
+def _get_response(qes, source, cls_cmb, fal_leg1, lmax_qlm, fal_leg2=None):
+    """Response of the estimator legs `qes` to the anisotropy `source`, both legs filtered by the isotropic matrices
+    fal_leg1 / fal_leg2: for every pair of intermediate spins (s2, t2) reached by the filters, the covariance response
+    acts on leg b (term 'st') or on leg a (term 'ts'), for the source spin +r and, when r > 0, -r."""
+    fal_leg2 = fal_leg1 if fal_leg2 is None else fal_leg2
+    acc = [np.zeros(lmax_qlm + 1, dtype=float) for _ in range(4)]
+    Ls = np.arange(lmax_qlm + 1, dtype=int)
+    for q in qes:
+        si, ti = q.leg_a.spin_in, q.leg_b.spin_in
+        so, to = q.leg_a.spin_ou, q.leg_b.spin_ou
+        for s2 in (0, -2, 2):
+            FA = uspin.get_spin_matrix(si, s2, fal_leg1)
+            if not np.any(FA):
+                continue
+            for t2 in (0, -2, 2):
+                FB = uspin.get_spin_matrix(ti, t2, fal_leg2)
+                if not np.any(FB):
+                    continue
+                r_st, pr_st, mr_st, cL_st = get_covresp(source, -s2, t2, cls_cmb, len(FB) - 1)
+                r_ts, pr_ts, mr_ts, cL_ts = get_covresp(source, -t2, s2, cls_cmb, len(FA) - 1)
+                assert r_st == r_ts and r_st >= 0, (r_st, r_ts)
+                a0, b0 = ut.joincls([q.leg_a.cl, FA]), ut.joincls([q.leg_b.cl, FB])
+
+                def term(w_st, w_ts, r):
+                    R = uspin.wignerc(a0, ut.joincls([b0, w_st.conj()]), so, s2, to, -s2 + r, lmax_out=lmax_qlm) * cL_st(Ls)
+                    return R + uspin.wignerc(ut.joincls([a0, w_ts.conj()]), b0, so, -t2 + r, to, t2, lmax_out=lmax_qlm) * cL_ts(Ls)
+                Rp = term(mr_st, mr_ts, r_st)
+                Rm = term(pr_st, pr_ts, -r_st) if r_st > 0 else Rp
+                _gc_sums(acc, q.cL(Ls), Rp, Rm, (-1) ** r_st)
+    return tuple(acc)
+
+
+def _get_response_custom(qe_key, qes, source, fal_leg1, lmax_qlm, fal_leg2=None, transf=None):
+    """Responses that do not fit the covariance-response parametrisation: temperature estimators to a noise-variance
+    (mask-like) spin-0 source 'n' / 'ntt'.  Returns None for everything else."""
+    if not ('tt' in qe_key and source in ['n', 'ntt']):
+        return None
+    assert transf is not None
+    fal_leg2 = fal_leg1 if fal_leg2 is None else fal_leg2
+    acc = [np.zeros(lmax_qlm + 1, dtype=float) for _ in range(4)]
+    Ls = np.arange(lmax_qlm + 1, dtype=int)
+    transfi = _clinv(transf)
+    for q in qes:
+        si, ti = q.leg_a.spin_in, q.leg_b.spin_in
+        so, to = q.leg_a.spin_ou, q.leg_b.spin_ou
+        assert (si, ti) == (0, 0)
+        s_qe = abs(so + to)
+        FA, FB = uspin.get_spin_matrix(si, 0, fal_leg1), uspin.get_spin_matrix(ti, 0, fal_leg2)
+        if not (np.any(FA) and np.any(FB)):
+            continue
+        Rp = uspin.wignerc(ut.joincls([q.leg_a.cl, FA, transfi]), ut.joincls([q.leg_b.cl, FB, transfi]), so, 0, to, 0, lmax_out=lmax_qlm)
+        if s_qe > 0:
+            fac = (-1) ** (so + si + to + ti)
+            FAm, FBm = uspin.get_spin_matrix(-si, 0, fal_leg1), uspin.get_spin_matrix(-ti, 0, fal_leg2)
+            Rm = fac * uspin.wignerc(ut.joincls([q.leg_a.cl.conj(), FAm, transfi]), ut.joincls([q.leg_b.cl.conj(), FBm, transfi]),
+                                     -so, 0, -to, 0, lmax_out=lmax_qlm)
+        else:
+            Rm = Rp
+        _gc_sums(acc, 0.5 * q.cL(Ls), Rp, Rm, (-1) ** s_qe)
+    return tuple(acc)
+
+
+def get_response(qe_key, lmax_ivf, source, cls_weight, cls_cmb, fal, fal_leg2=None, lmax_ivf2=None, lmax_qlm=None, transf=None):
+    """(GG, CC, GC, CG) responses of estimator `qe_key` to the anisotropy `source` (qresp.py:269-310); '_bh_' keys are
+    bias-hardened combinations.  Not symmetrised in the two legs' filters when these differ."""
+    if lmax_ivf2 is None:
+        lmax_ivf2 = lmax_ivf
+    if lmax_qlm is None:
+        lmax_qlm = lmax_ivf + lmax_ivf2
+    kw = dict(fal_leg2=fal_leg2, lmax_ivf2=lmax_ivf2, lmax_qlm=lmax_qlm, transf=transf)
+    if '_bh_' in qe_key:
+        k, hsource = qe_key.split('_bh_')
+        assert len(hsource) == 1, hsource
+        h = hsource[0]
+        ks = get_response(k, lmax_ivf, source, cls_weight, cls_cmb, fal, **kw)
+        hs = get_response(h + k[1:], lmax_ivf, source, cls_weight, cls_cmb, fal, **kw)
+        kh = get_response(k, lmax_ivf, h, cls_weight, cls_cmb, fal, **kw)
+        hh = get_response(h + k[1:], lmax_ivf, h, cls_weight, cls_cmb, fal, **kw)
+        iG, iC = ut.cli(hh[0]), ut.cli(hh[1])   # indices: 0 GG, 1 CC, 2 GC, 3 CG
+        RGG = ks[0] - (kh[0] * hs[0] * iG + kh[2] * hs[3] * iC)
+        RCC = ks[1] - (kh[3] * hs[2] * iG + kh[1] * hs[1] * iC)
+        RGC = ks[2] - (kh[0] * hs[2] * iG + kh[2] * hs[1] * iC)
+        RCG = ks[3] - (kh[3] * hs[0] * iG + kh[1] * hs[3] * iC)
+        return RGG, RCC, RGC, RCG
+    qes = get_qes(qe_key, lmax_ivf, cls_weight, lmax2=lmax_ivf2, transf=transf)
+    custom = _get_response_custom(qe_key, qes, source, fal, lmax_qlm, fal_leg2=fal_leg2, transf=transf)
+    return custom if custom is not None else _get_response(qes, source, cls_cmb, fal, lmax_qlm, fal_leg2=fal_leg2)
+
+
+def get_dresponse_dlncl(qe_key, l, cl_key, lmax_ivf, source, cls_weight, cls_cmb, fal_leg1, fal_leg2=None, lmax_ivf2=None, lmax_out=None):
+    """dR_L / dln C_l for the spectrum `cl_key` (qresp.py:359-371)."""
+    if lmax_ivf2 is None:
+        lmax_ivf2 = lmax_ivf
+    if lmax_out is None:
+        lmax_out = lmax_ivf2 + lmax_ivf
+    dcls = {k: np.zeros_like(cls_cmb[k]) for k in cls_cmb.keys()}
+    dcls[cl_key][l] = cls_cmb[cl_key][l]
+    return _get_response(get_qes(qe_key, lmax_ivf, cls_weight, lmax2=lmax_ivf2), source, dcls, fal_leg1, lmax_out, fal_leg2=fal_leg2)
+
+
+class resp_lib_simple(object):
+    """Caches get_response outputs in an sqlite npdb under lib_dir (qresp.py:183-267)."""
+
+    def __init__(self, lib_dir, lmax_ivf, cls_weight, cls_cmb, fal, lmax_qlm, transf=None):
+        self.lmax_qe = lmax_ivf
+        self.lmax_qlm = lmax_qlm
+        self.cls_weight = cls_weight
+        self.cls_cmb = cls_cmb
+        self.fal = fal
+        self.transf = transf
+        self.lib_dir = lib_dir
+        fn_hash = os.path.join(lib_dir, 'resp_hash.pk')
+        if mpi.rank == 0:
+            if not os.path.exists(lib_dir):
+                os.makedirs(lib_dir)
+            if not os.path.exists(fn_hash):
+                pk.dump(self.hashdict(), open(fn_hash, 'wb'), protocol=2)
+        mpi.barrier()
+        ut.hash_check(pk.load(open(fn_hash, 'rb')), self.hashdict(), fn=fn_hash)
+        self.npdb = sql.npdb(os.path.join(lib_dir, 'npdb.db'))
+
+    def hashdict(self):
+        ret = {'lmaxqe': self.lmax_qe, 'lmax_qlm': self.lmax_qlm}
+        for k in self.cls_weight.keys():
+            ret['clsweight ' + k] = ut.clhash(self.cls_weight[k])
+        for k in self.cls_cmb.keys():
+            ret['clscmb ' + k] = ut.clhash(self.cls_cmb[k])
+        for k in self.fal.keys():
+            ret['fal' + k] = ut.clhash(self.fal[k])
+        return ret
+
+    def get_response(self, k, ksource, recache=False):
+        """Response of estimator key k to source ksource: GG for gradient keys, CC for curl ('x...') keys."""
+        if '_bh_' in k:
+            kQE, bh = k.split('_bh_')
+            assert len(ksource) == 1, (kQE, ksource)
+            wL = self.get_response(kQE, bh, recache=recache)
+            wL = wL * ut.cli(self.get_response(bh + kQE[1:], bh, recache=recache))
+            return self.get_response(kQE, ksource, recache=recache) - wL * self.get_response(bh + kQE[1:], ksource, recache=recache)
+        if k in ['xmtt', 'pmtt']:
+            return self.get_response(k[0], ksource, recache=recache) - self.get_response(k[0] + 'tt', ksource, recache=recache)
+        s, GorC, _, ksp = qe_spin_data(k)
+        assert s >= 0, s
+        if s == 0:
+            assert GorC == 'G', (s, GorC)
+        base = 'qe_' + ksp + k[1:] + '_source_%s' % ksource
+        fn = base + '_' + GorC + GorC
+        if self.npdb.get(fn) is None or recache:
+            GG, CC, GC, CG = get_response(k, self.lmax_qe, ksource, self.cls_weight, self.cls_cmb, self.fal,
+                                          lmax_qlm=self.lmax_qlm, transf=self.transf)
+            if np.any(CG) or np.any(GC):
+                print("Warning: C-G or G-C responses non-zero but not returned")
+            if recache and self.npdb.get(fn) is not None:
+                self.npdb.remove(base + '_GG')
+                if s > 0:
+                    self.npdb.remove(base + '_CC')
+            self.npdb.add(base + '_GG', GG)
+            if s > 0:
+                self.npdb.add(base + '_CC', CC)
+        return self.npdb.get(fn)

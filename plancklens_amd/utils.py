@@ -142,3 +142,24 @@ class stats(object):
     def sigmas_on_mean(self):
         assert self.N > 0
         return self.sigmas() / np.sqrt(self.N)
+
+
+def cl_inverse(cls):
+    """Per-multipole pseudo-inverse of the symmetric T, E, B spectral matrix given as a dictionary ('tt', 'ee', 'bb',
+    'te', 'tb', 'eb'; missing entries are zero, shorter arrays are zero-padded); returns the non-zero entries of the
+    inverse under the same keys (utils.py:336-365)."""
+    lmax = max(len(cl) for cl in cls.values()) - 1
+    order = ['t', 'e', 'b']
+    mat = np.zeros((lmax + 1, 3, 3))
+    for i, a in enumerate(order):
+        for j, b in enumerate(order[i:], start=i):
+            cl = np.asarray(cls.get(a + b, [0.]), dtype=float)
+            n = min(len(cl), lmax + 1)
+            mat[:n, i, j] = cl[:n]
+            mat[:n, j, i] = cl[:n]
+    inv = np.linalg.pinv(mat)
+    ret = {}
+    for k, (i, j) in zip(['tt', 'ee', 'bb', 'te', 'tb', 'eb'], [(0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)]):
+        if np.any(inv[:, i, j]):
+            ret[k] = inv[:, i, j].copy()
+    return ret

@@ -149,6 +149,7 @@ def main():
         shutil.rmtree(tmp, ignore_errors=True)
     np.savez_compressed(os.path.join(HERE, 'qe_golden.npz'), **out)
     make_cg_golden()
+    make_resp_golden()
     print('wrote qe_golden.npz with %d arrays' % len(out))
     for k in ['ptt', 'p_p', 'p']:
         d = np.abs(out['gen_%s_G' % k] - out['dd_%s_0' % k]).max() / np.abs(out['dd_%s_0' % k]).max()
@@ -241,8 +242,97 @@ def make_cg_golden():
     print('wrote cg_golden.npz; T residual trace', out['cg_t_trace'], 'P', out['cg_p_trace'], 'TP', out['cg_tp_trace'])
 
 
+def install_fortran_wigners():
+    """`plancklens.wigners.wigners` (an f2py extension in the reference) stood in by ctypes calls into
+    oracle/_ref/libwigners_ref.so, which oracle/Makefile builds from the reference's own wigners.f90."""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, 'oracle', '_ref', 'libwigners_ref.so'))
+    dp = ctypes.POINTER(ctypes.c_double)
+    ci, cd, ref = ctypes.c_int, ctypes.c_double, ctypes.byref
+    m = types.ModuleType('plancklens.wigners.wigners')
+
+    def get_xgwg(x1, x2, n):
+        x, w = np.zeros(n), np.zeros(n)
+        lib.get_xgwg_(ref(cd(x1)), ref(cd(x2)), x.ctypes.data_as(dp), w.ctypes.data_as(dp), ref(ci(n)))
+        return x, w
+
+    def wignerpos(cl, x, s1, s2):
+        cl, x = np.ascontiguousarray(cl, dtype=float), np.ascontiguousarray(x, dtype=float)
+        xi = np.zeros_like(x)
+        if cl.size - 1 <= max(abs(s1), abs(s2)):  # the Fortran writes out of bounds when lmax == lmin (SURVEY.md 8(c)): pad
+            cl = np.concatenate([cl, np.zeros(max(abs(s1), abs(s2)) + 2 - cl.size)])
+        lib.wignerpos_(xi.ctypes.data_as(dp), ref(ci(x.size)), ref(ci(cl.size - 1)), cl.ctypes.data_as(dp), x.ctypes.data_as(dp),
+                       ref(ci(s1)), ref(ci(s2)))
+        return xi
+
+    def wignercoeff(xi, x, s1, s2, lmax):
+        xi, x = np.ascontiguousarray(xi, dtype=float), np.ascontiguousarray(x, dtype=float)
+        cl = np.zeros(lmax + 1)
+        lib.wignercoeff_(cl.ctypes.data_as(dp), xi.ctypes.data_as(dp), x.ctypes.data_as(dp), ref(ci(s1)), ref(ci(s2)),
+                         ref(ci(lmax)), ref(ci(x.size)))
+        return cl
+    m.get_xgwg, m.wignerpos, m.wignercoeff = get_xgwg, wignerpos, wignercoeff
+    import plancklens.wigners as pw
+    pw.wigners = m
+    sys.modules['plancklens.wigners.wigners'] = m
+    return m
+
+
+def make_resp_golden():
+    """Reference qresp.get_response / nhl.get_nhl (its Python + its Fortran Wigner module) on the tiny configuration of
+    the QE fixtures, plus raw Gauss-Legendre / Wigner-series vectors of the Fortran module."""
+    wig = install_fortran_wigners()
+    from plancklens import qresp, nhl, utils, utils_spin
+    assert utils_spin.HASWIGNER
+    lmax_ivf, lmax_qlm, lmin_ivf = 40, 47, 4
+    cls_path = os.path.join(ROOT, 'plancklens_amd', 'data', 'cls', 'FFP10_wdipole_lensedCls.dat')
+    cl_len = utils.camb_clfile(cls_path, lmax=lmax_ivf)
+    transf = myhp.gauss_beam(4. / 180. * np.pi, lmax=lmax_ivf)
+    arcmin = np.pi / 180. / 60.
+    fal = {'tt': utils.cli(cl_len['tt'][:lmax_ivf + 1] + (1200. * arcmin) ** 2 * utils.cli(transf ** 2)),
+           'ee': utils.cli(cl_len['ee'][:lmax_ivf + 1] + (35. * arcmin) ** 2 * utils.cli(transf ** 2)),
+           'bb': utils.cli(cl_len['bb'][:lmax_ivf + 1] + (35. * arcmin) ** 2 * utils.cli(transf ** 2))}
+    for f in fal.values():
+        f[:lmin_ivf] = 0
+    out = {'lmax_ivf': lmax_ivf, 'lmax_qlm': lmax_qlm}
+    for k in ['tt', 'te', 'ee', 'bb']:
+        out['cl_' + k] = cl_len[k]
+    for k in fal:
+        out['fal_' + k] = fal[k]
+    for key, source in [('ptt', 'p'), ('p_p', 'p'), ('p', 'p'), ('x', 'x'), ('p', 'f'), ('ftt', 'f'), ('ptt_bh_s', 'p'), ('a_p', 'a')]:
+        R = qresp.get_response(key, lmax_ivf, source, cl_len, cl_len, fal, lmax_qlm=lmax_qlm)
+        for r, tag in zip(R, ['GG', 'CC', 'GC', 'CG']):
+            out['R_%s_%s_%s' % (key, source, tag)] = r
+    ivf = {k: fal[k].copy() for k in fal}
+    ivf['te'] = cl_len['te'][:lmax_ivf + 1] * fal['tt'] * fal['ee']
+    for k in ivf:
+        out['ivf_' + k] = ivf[k]
+    for k1, k2 in [('ptt', 'ptt'), ('p_p', 'p_p'), ('p', 'p'), ('p_p', 'ptt'), ('x', 'x'), ('p', 'x')]:
+        N = nhl.get_nhl(k1, k2, cl_len, ivf, lmax_ivf, lmax_ivf, lmax_out=lmax_qlm)
+        for n, tag in zip(N, ['GG', 'CC', 'GC', 'CG']):
+            out['N_%s_%s_%s' % (k1, k2, tag)] = n
+    for n in (7, 64, 301):
+        out['xg_%d' % n], out['wg_%d' % n] = wig.get_xgwg(-1., 1., n)
+    rng = np.random.default_rng(11)
+    x = np.sort(rng.uniform(-1, 1, 40))
+    cl, xi = rng.standard_normal(31), rng.standard_normal(40)
+    pos, coeff = [], []
+    for s1 in range(-3, 4):
+        for s2 in range(-3, 4):
+            pos.append(wig.wignerpos(cl, x, s1, s2))
+            coeff.append(wig.wignercoeff(xi, x, s1, s2, 30))
+    out.update({'w_x': x, 'w_cl': cl, 'w_xi': xi, 'w_pos': np.array(pos), 'w_coeff': np.array(coeff)})
+    np.savez_compressed(os.path.join(HERE, 'resp_golden.npz'), **out)
+    print('wrote resp_golden.npz with %d arrays' % len(out))
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'cg':   # only the CG fixtures
+    if len(sys.argv) > 1 and sys.argv[1] == 'resp':   # only the response / N0 fixtures
+        assert os.path.isdir(REF), 'the reference is only present in the build container'
+        install_healpy_standin()
+        sys.path.insert(0, REF)
+        make_resp_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'cg':   # only the CG fixtures
         assert os.path.isdir(REF), 'the reference is only present in the build container'
         install_healpy_standin()
         sys.path.insert(0, REF)
