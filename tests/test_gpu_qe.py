@@ -125,3 +125,73 @@ def test_qecl_vs_reference(setup, tmp_path):
     assert relrms(qcls.get_sim_qcl('ptt', 0, k2='p_p'), g['qcl_ptt_p_p_0']) < 1e-7
     assert os.path.exists(str(tmp_path / 'qcls' / 'cldb.db'))
     assert relrms(qcls.get_sim_qcl('p', 0, lmax=10), g['qcl_p_0'][:11]) < 1e-7  # served from the sqlite cache
+
+
+class _gauss_sims(object):
+    """Seeded Gaussian T, Q, U skies (TE-correlated) x beam + white noise, synthesised on the GPU."""
+
+    def __init__(self, nside, lmax, cls, transf, nlev_t, nlev_p):
+        self.nside, self.lmax, self.cls, self.transf, self.nlev_t, self.nlev_p = nside, lmax, cls, transf, nlev_t, nlev_p
+
+    def hashdict(self):
+        return {'gauss': self.nside, 'lmax': self.lmax}
+
+    def _alms(self, idx):
+        from plancklens_amd import hp
+        rng = np.random.default_rng(4000 + idx)
+        one = np.ones(self.lmax + 1)
+        u1, u2, u3 = (hp.synalm(one, self.lmax, rng) for _ in range(3))
+        tt, ee, bb, te = (self.cls[k][:self.lmax + 1] for k in ['tt', 'ee', 'bb', 'te'])
+        r = te * np.where(tt > 0, 1. / np.sqrt(np.where(tt > 0, tt, 1.)), 0.)
+        return (hp.almxfl(u1, np.sqrt(tt)), hp.almxfl(u1, r) + hp.almxfl(u2, np.sqrt(np.maximum(ee - r ** 2, 0.))),
+                hp.almxfl(u3, np.sqrt(bb)))
+
+    def _noise(self, idx, f):
+        from plancklens_amd import hp
+        rng = np.random.default_rng(9000 + 3 * idx + f)
+        vamin = np.sqrt(hp.nside2pixarea(self.nside, degrees=True)) * 60
+        return (self.nlev_t if f == 0 else self.nlev_p) / vamin * rng.standard_normal(12 * self.nside ** 2)
+
+    def get_sim_tmap(self, idx):
+        from plancklens_amd import hp, shts
+        return shts.alm2map(hp.almxfl(self._alms(idx)[0], self.transf), self.nside, lmax=self.lmax) + self._noise(idx, 0)
+
+    def get_sim_pmap(self, idx):
+        from plancklens_amd import hp, shts
+        _, e, b = self._alms(idx)
+        q, u = shts.alm2map_spin([hp.almxfl(e, self.transf), hp.almxfl(b, self.transf)], self.nside, 2, self.lmax)
+        return q + self._noise(idx, 1), u + self._noise(idx, 2)
+
+
+def test_qe_power_of_gaussian_skies_matches_analytic_n0(tmp_path):
+    """for Gaussian skies whose spectra are the filter's, the power of the GPU-made (unnormalised)
+    estimator averaged over simulations is the semi-analytical N0 of nhl.get_nhl (which tests/test_resp.py pins to the
+    response and to the reference).  Catches any sign / normalisation slip between the QE kernels and the analytic
+    side (factors of 2, signs, missing weights): 10 simulations, bands of 20 multipoles, 12 % tolerance on the band ratios
+    (the estimator power is a 4-point function, its scatter is larger than the Gaussian mode-counting estimate)."""
+    from plancklens_amd import hp, nhl, qest, utils
+    from plancklens_amd.filt import filt_simple
+    nside, lmax, nsims = 64, 128, 10
+    cls_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'plancklens_amd', 'data', 'cls',
+                            'FFP10_wdipole_lensedCls.dat')
+    cl = utils.camb_clfile(cls_path, lmax=lmax)
+    transf = hp.gauss_beam(60. / 60. / 180. * np.pi, lmax=lmax)
+    nlev_t, nlev_p = 300., 40.
+    arcmin = np.pi / 180. / 60.
+    ftl = utils.cli(cl['tt'][:lmax + 1] + (nlev_t * arcmin) ** 2 * utils.cli(transf ** 2))
+    fel = utils.cli(cl['ee'][:lmax + 1] + (nlev_p * arcmin) ** 2 * utils.cli(transf ** 2))
+    fbl = utils.cli(cl['bb'][:lmax + 1] + (nlev_p * arcmin) ** 2 * utils.cli(transf ** 2))
+    for f in (ftl, fel, fbl):
+        f[:2] = 0
+    sims = _gauss_sims(nside, lmax, cl, transf, nlev_t, nlev_p)
+    ivfs = filt_simple.library_fullsky_sepTP(str(tmp_path / 'ivfs'), sims, nside, transf, cl, ftl, fel, fbl, cache=False)
+    qlms = qest.library_sepTP(str(tmp_path / 'qlms'), ivfs, ivfs, cl['te'], nside, lmax_qlm=lmax)
+    cls_ivfs = {'tt': ftl, 'ee': fel, 'bb': fbl, 'te': cl['te'][:lmax + 1] * ftl * fel}
+    for key in ('ptt', 'p_p', 'p'):
+        pg = np.mean([hp.alm2cl(qlms.get_sim_qlm(key, i)) for i in range(nsims)], axis=0)
+        pc = np.mean([hp.alm2cl(qlms.get_sim_qlm('x' + key[1:], i)) for i in range(nsims)], axis=0)
+        GG, CC, _, _ = nhl.get_nhl(key, key, cl, cls_ivfs, lmax, lmax, lmax_out=lmax)
+        for lo in range(10, 110, 20):
+            sl = slice(lo, lo + 20)
+            assert abs(np.sum(pg[sl]) / np.sum(GG[sl]) - 1.) < 0.12, (key, 'G', lo, np.sum(pg[sl]) / np.sum(GG[sl]))
+            assert abs(np.sum(pc[sl]) / np.sum(CC[sl]) - 1.) < 0.12, (key, 'C', lo, np.sum(pc[sl]) / np.sum(CC[sl]))
