@@ -531,6 +531,24 @@ __device__ __forceinline__ double reduce16(double *v, int lane)
     reduce_step<1>(v, lane);
     return v[0];
 }
+// Same result as reduce16 through a wave-private LDS transpose: every lane stores its 16 values (row t, column lane; rows
+// padded to 66 doubles so that the 16 lanes of a row-group hit different banks), then lane 16 q + j adds the 16 entries of
+// row j that belong to lane row q.  15 v_add_f64 instead of ~105 VALU instructions of selects and DPP moves.
+constexpr int kRedStride = 66;
+constexpr int kRedDoubles = 16 * kRedStride;  // per wave
+__device__ __forceinline__ double reduce16_lds(const double *v, int lane, double *scratch)
+{
+#pragma unroll
+    for (int t = 0; t < 16; ++t) scratch[t * kRedStride + lane] = v[t];
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): own stores landed (wave-private region, no barrier needed)
+    __builtin_amdgcn_wave_barrier();
+    const double2 *row = reinterpret_cast<const double2 *>(scratch + (lane & 15) * kRedStride + (lane >> 4) * 16);
+    double2 s = row[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { const double2 u = row[k]; s.x += u.x; s.y += u.y; }
+    __builtin_amdgcn_wave_barrier();  // all reads issued before the next tile overwrites the region
+    return s.x + s.y;
+}
 __device__ __forceinline__ int fold4_component(int lane) { const int q = lane >> 4; return ((q & 1) << 1) | (q >> 1); }
 
 // -----------------------------------------------------------------------------------------------------
@@ -541,7 +559,8 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
 {
     constexpr int RG = 64 * R;
     constexpr int T = 16;
-    __shared__ double tile[RG * 16];
+    constexpr int kTile = RG * 16 > 4 * kRedDoubles ? RG * 16 : 4 * kRedDoubles;
+    __shared__ __attribute__((aligned(16))) double tile[kTile];  // phase values of the ring group; reused as the reduce scratch of the 4 waves
     const int wave = wave_id();
     const int lane = threadIdx.x & 63;
     const int ngroups = (P.npairs + RG - 1) / RG;
@@ -578,6 +597,8 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
         er[k] = nr + sr; ei[k] = ni + si;
         orr[k] = (nr - sr) * x; oi[k] = (ni - si) * x;
     }
+    __syncthreads();  // every wave has taken its phase values: the tile becomes reduce scratch
+    double *scratch = tile + wave * kRedDoubles;
     const int nil = (P.lmax - m) / 2 + 1;
     const int64_t base = P.off0[m];
     const double2 *__restrict__ ab = reinterpret_cast<const double2 *>(P.ab0) + base;
@@ -709,7 +730,7 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
             for (int k = 0; k < R; ++k) done = done && (r[k].sc == 0 || r[k].sc == kNeverActive);
             all_active = wave_all(done);
         }
-        const double tot = reduce16(acc, lane);
+        const double tot = reduce16_lds(acc, lane, scratch);
         if (il0 + (lane & 15) < nil) out[(int64_t)(il0 + (lane & 15)) * 4 + fold4_component(lane)] = tot;
     }
 }
@@ -763,7 +784,8 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
 {
     constexpr int RG = 64 * R;
     constexpr int T = 16;
-    __shared__ double tile[RG * 32];
+    constexpr int kTile = RG * 32 > 4 * kRedDoubles ? RG * 32 : 4 * kRedDoubles;
+    __shared__ __attribute__((aligned(16))) double tile[kTile];  // phase values of the ring group; reused as the reduce scratch of the 4 waves
     const int wave = wave_id();
     const int lane = threadIdx.x & 63;
     const int ngroups = (P.npairs + RG - 1) / RG;
@@ -820,6 +842,8 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
             t_ = ber[k]; ber[k] = bor[k]; bor[k] = t_; t_ = bei[k]; bei[k] = boi[k]; boi[k] = t_;
         }
     }
+    __syncthreads();  // every wave has taken its phase values: the tile becomes reduce scratch
+    double *scratch = tile + wave * kRedDoubles;
     const int nl = P.lmax - l0 + 1;
     const int64_t base = S.off[m];
     const double2 *__restrict__ ab = reinterpret_cast<const double2 *>(S.ab) + base;
@@ -953,7 +977,7 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
                 done = done && (r[k].scn == 0 || r[k].scn == kNeverActive) && (r[k].scp == 0 || r[k].scp == kNeverActive);
             all_active = wave_all(done);
         }
-        const double tot = reduce16(acc, lane);
+        const double tot = reduce16_lds(acc, lane, scratch);
         if (i0 + (lane & 15) < nl) out[(int64_t)(i0 + (lane & 15)) * 4 + fold4_component(lane)] = tot;
     }
 }
