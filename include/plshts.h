@@ -88,6 +88,15 @@ int pl_map_mul(int64_t n, const double *a, const double *b, double *out, void *s
 int pl_map_cmul(int64_t n, const double *ar, const double *ai, double s1, const double *br, const double *bi, double s2,
                 double sign, double *outr, double *outi, int accumulate, void *stream);
 
+/* Real-space product of the lensing quadratic estimators in one pass over the pixels (qest.py:254-257 temperature part,
+ * :273-278 polarization part, :318-322 their sum for the minimum-variance estimator):
+ *   out_re + i out_im = (rep - i imp)(g3 + i c3) - (rep + i imp)(g1 - i c1) + tmap (gt + i ct)
+ * rep, imp: spin-2 inverse-variance filtered map; (g3, c3), (g1, c1): spin-3 and spin-1 gradient legs; tmap: filtered
+ * temperature; (gt, ct): spin-1 temperature gradient leg.  Pass tmap = NULL or rep = NULL to leave a part out. */
+int pl_qe_lens_product(int64_t n, const double *tmap, const double *gt, const double *ct, const double *rep, const double *imp,
+                       const double *g3, const double *c3, const double *g1, const double *c1, double *out_re, double *out_im,
+                       void *stream);
+
 /* FP64 FMA-rate microbenchmark (independent chains, no memory traffic): returns achieved TFLOP/s. */
 double pl_fma64_peak_tflops(int iters, void *stream);
 

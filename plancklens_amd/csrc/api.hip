@@ -26,6 +26,8 @@ void launch_alm_copy(int lmax_in, const double *in, int lmax_out, double *out, h
 void launch_alm2cl(int lmax, const double *a, const double *b, double *cl, hipStream_t st);
 void launch_axpy(int64_t n, double a, const double *x, const double *y, double *out, hipStream_t st);
 void launch_map_mul(int64_t n, const double *a, const double *b, double *out, hipStream_t st);
+void launch_qe_lens_product(int64_t n, const double *tmap, const double *gt, const double *ct, const double *rep, const double *imp,
+                            const double *g3, const double *c3, const double *g1, const double *c1, double *outr, double *outi, hipStream_t st);
 void launch_map_cmul(int64_t n, const double *ar, const double *ai, double s1, const double *br, const double *bi, double s2,
                      double sign, double *outr, double *outi, int accumulate, hipStream_t st);
 void launch_fma_peak(int iters, double *out, int nblk, hipStream_t st);
@@ -483,6 +485,17 @@ int pl_map_cmul(int64_t n, const double *ar, const double *ai, double s1, const 
                 double *outr, double *outi, int accumulate, void *stream)
 {
     launch_map_cmul(n, ar, ai, s1, br, bi, s2, sign, outr, outi, accumulate, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_qe_lens_product(int64_t n, const double *tmap, const double *gt, const double *ct, const double *rep, const double *imp,
+                       const double *g3, const double *c3, const double *g1, const double *c1, double *out_re, double *out_im, void *stream)
+{
+    if (!out_re || !out_im) return fail("null output");
+    if (!tmap && !rep) return fail("neither the temperature nor the polarization part given");
+    if ((tmap && (!gt || !ct)) || (rep && (!imp || !g3 || !c3 || !g1 || !c1))) return fail("incomplete set of leg maps");
+    launch_qe_lens_product(n, tmap, gt, ct, rep, imp, g3, c3, g1, c1, out_re, out_im, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return 0;
 }

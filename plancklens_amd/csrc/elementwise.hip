@@ -73,6 +73,29 @@ __global__ void k_map_cmul(int64_t n, const double *__restrict__ ar, const doubl
     }
 }
 
+// Real-space product of the lensing estimators in one pass (qest.py:254-257 T part, :273-278 P part, :318-322 MV sum):
+//   d = (rep - i imp)(g3 + i c3) - (rep + i imp)(g1 - i c1) + tmap (gt + i ct);  either part may be absent (null).
+__global__ void k_qe_lens_product(int64_t n, const double *__restrict__ tmap, const double *__restrict__ gt, const double *__restrict__ ct,
+                                  const double *__restrict__ rep, const double *__restrict__ imp, const double *__restrict__ g3,
+                                  const double *__restrict__ c3, const double *__restrict__ g1, const double *__restrict__ c1,
+                                  double *__restrict__ outr, double *__restrict__ outi)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double dr = 0., di = 0.;
+        if (rep) {
+            const double pr = rep[i], pi = imp[i], a3 = g3[i], b3 = c3[i], a1 = g1[i], b1 = c1[i];
+            dr = (pr * a3 + pi * b3) - (pr * a1 + pi * b1);
+            di = (pr * b3 - pi * a3) - (pi * a1 - pr * b1);
+        }
+        if (tmap) {
+            const double t = tmap[i];
+            dr = fma(t, gt[i], dr); di = fma(t, ct[i], di);
+        }
+        outr[i] = dr; outi[i] = di;
+    }
+}
+
 // 16 independent FMA chains per lane: the FP64 vector-FMA issue ceiling of the chip
 __global__ __launch_bounds__(256) void k_fma_peak(int iters, double *out)
 {
@@ -119,6 +142,11 @@ void launch_map_cmul(int64_t n, const double *ar, const double *ai, double s1, c
                      double sign, double *outr, double *outi, int accumulate, hipStream_t st)
 {
     hipLaunchKernelGGL(k_map_cmul, dim3(nblocks(n)), dim3(256), 0, st, n, ar, ai, s1, br, bi, s2, sign, outr, outi, accumulate);
+}
+void launch_qe_lens_product(int64_t n, const double *tmap, const double *gt, const double *ct, const double *rep, const double *imp,
+                            const double *g3, const double *c3, const double *g1, const double *c1, double *outr, double *outi, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_qe_lens_product, dim3(nblocks(n)), dim3(256), 0, st, n, tmap, gt, ct, rep, imp, g3, c3, g1, c1, outr, outi);
 }
 void launch_fma_peak(int iters, double *out, int nblk, hipStream_t st)
 {

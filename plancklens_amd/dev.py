@@ -99,3 +99,15 @@ def map_cmul(ar, ai, s1, br, bi, s2, sign, outr, outi, accumulate):
     """(outr + i outi) (+)= sign (ar + i s1 ai)(br + i s2 bi)"""
     _lib.check(_lib.lib().pl_map_cmul(ar.numel(), ar.data_ptr(), ai.data_ptr(), float(s1), br.data_ptr(), bi.data_ptr(),
                                      float(s2), float(sign), outr.data_ptr(), outi.data_ptr(), int(accumulate), stream_ptr()))
+
+
+def qe_lens_product(tpart, ppart):
+    """(re, im) of (rep - i imp)(g3 + i c3) - (rep + i imp)(g1 - i c1) + tmap (gt + i ct) in one pass (pl_qe_lens_product).
+    tpart = (tmap, gt, ct) or None; ppart = (rep, imp, g3, c3, g1, c1) or None."""
+    ref = tpart[0] if tpart is not None else ppart[0]
+    out = torch.empty((2, ref.numel()), dtype=torch.float64, device=ref.device)
+    ptr = lambda t: t.data_ptr()
+    targs = [ptr(t) for t in tpart] if tpart is not None else [None] * 3
+    pargs = [ptr(t) for t in ppart] if ppart is not None else [None] * 6
+    _lib.check(_lib.lib().pl_qe_lens_product(ref.numel(), *targs, *pargs, out[0].data_ptr(), out[1].data_ptr(), stream_ptr()))
+    return out[0], out[1]

@@ -303,11 +303,14 @@ class library(object):
         product maps separately and adds the alms; map2alm_spin is linear, so the product maps are summed on the
         device and analysed once (one spin-1 transform less, results equal to rounding)."""
         assert k == 'p'
-        dre, dim = self._p_product(idx, 'p', swapped=swapped)
-        gt, ct = self._t_product(idx, 'p', swapped=swapped)
-        dre += gt
-        dim += ct
-        del gt, ct
+        f2map1, f2map2 = self._legs(swapped)
+        tmap = f2map1.get_irestmap(idx)
+        gt, ct = f2map2.get_gtmap(idx, k='p')
+        rep, imp = f2map1.get_irespmap(idx)
+        g3, c3 = f2map2.get_gpmap(idx, 3, k='p')
+        g1, c1 = f2map2.get_gpmap(idx, 1, k='p')
+        dre, dim = dev.qe_lens_product((tmap, gt, ct), (rep, imp, g3, c3, g1, c1))  # all nine leg maps in one pass
+        del tmap, gt, ct, rep, imp, g3, c3, g1, c1
         G, C = self._gc_from_product(dre, dim, 'P')
         self._last_dev = (G, C)
         return dev.to_host(G), dev.to_host(C)
