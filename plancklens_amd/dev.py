@@ -54,13 +54,32 @@ def lidx(lmax):
     return _LIDX[key]
 
 
+_FL_CACHE = {}
+
+
 def fl_dev(fl, lmax):
-    """l-filter as a device float64 tensor of length lmax + 1 (zero-extended / truncated: hp.almxfl semantics)."""
-    f = torch.zeros(lmax + 1, dtype=torch.float64, device=device())
-    src = fl if isinstance(fl, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(fl, dtype=np.float64)))
-    n = min(lmax + 1, src.numel())
-    f[:n] = src[:n].to(device())
-    return f
+    """l-filter as a device float64 tensor of length lmax + 1 (zero-extended / truncated: hp.almxfl semantics).
+    Host arrays are uploaded once per content: the same few filters (beams, C_l, 1 / C_l, l-weights) are applied
+    thousands of times, and every pageable upload is a blocking copy that idles the GPU.  The cached tensors are
+    read-only by convention (callers never modify a filter in place)."""
+    if isinstance(fl, torch.Tensor):
+        f = torch.zeros(lmax + 1, dtype=torch.float64, device=device())
+        n = min(lmax + 1, fl.numel())
+        f[:n] = fl[:n].to(device())
+        return f
+    a = np.zeros(lmax + 1, dtype=np.float64)
+    src = np.asarray(fl, dtype=np.float64)
+    n = min(lmax + 1, src.size)
+    a[:n] = src[:n]
+    key = (lmax, torch.cuda.current_device(), hash(a.tobytes()))
+    hit = _FL_CACHE.get(key)
+    if hit is not None and hit[0].shape == a.shape and np.array_equal(hit[0], a):
+        return hit[1]
+    if len(_FL_CACHE) > 256:
+        _FL_CACHE.clear()
+    t = torch.from_numpy(a).to(device())
+    _FL_CACHE[key] = (a, t)
+    return t
 
 
 def almxfl(alm, fl):

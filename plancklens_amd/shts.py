@@ -97,11 +97,8 @@ def _fl_arg(fl, lmax, dev):
     if fl is None:
         return None
     if dev:
-        f = torch.zeros(lmax + 1, dtype=torch.float64, device='cuda')
-        flt = fl if _is_dev(fl) else torch.as_tensor(np.asarray(fl, dtype=np.float64))
-        n = min(lmax + 1, flt.numel())
-        f[:n] = flt[:n].to('cuda')
-        return f
+        from . import dev as _dev
+        return _dev.fl_dev(fl, lmax)  # cached upload of host filters
     f = np.zeros(lmax + 1, dtype=np.float64)
     fl = np.asarray(fl, dtype=np.float64)
     n = min(lmax + 1, fl.size)
