@@ -34,28 +34,37 @@ class cache_mem(dict):
             del self[key]
 
 
-def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=25):
+def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=25, x_is_zero=False):
     """Solves fwd_op(x) = b in place on x by preconditioned conjugate directions; returns the iteration count.
 
         fwd_op, the pre_ops and dot_op must not modify their arguments.  `tr` selects how many past search
         directions each new one is orthogonalised against (tr_cg: the last one).  The residual is recomputed
-        from scratch every `roundoff` iterations.
+        from scratch every `roundoff` iterations.  x_is_zero: the caller guarantees x = 0 on entry (the nested
+        multigrid solves), which saves the first fwd_op.
+
+        With a single preconditioner and a dot_op that offers `dev(a, b)` (a 0-dim device tensor) the step lengths
+        stay on the device: no host synchronisation inside an iteration, same arithmetic.
     """
     if cache is None:
         cache = cache_mem()
     n_pre = len(pre_ops)
-    residual = b - fwd_op(x)
+    on_dev = n_pre == 1 and hasattr(dot_op, 'dev')
+    residual = b * 1.0 if x_is_zero else b - fwd_op(x)
     searchdirs = [op(residual) for op in pre_ops]
     it = 0
     while not criterion(it, x, residual):
         searchfwds = [fwd_op(d) for d in searchdirs]
-        deltas = [dot_op(d, residual) for d in searchdirs]
-        dTAd = np.zeros((n_pre, n_pre))
-        for i1 in range(n_pre):
-            for i2 in range(i1 + 1):
-                dTAd[i1, i2] = dTAd[i2, i1] = dot_op(searchdirs[i1], searchfwds[i2])
-        dTAd_inv = np.linalg.inv(dTAd)
-        alphas = np.dot(dTAd_inv, deltas)
+        if on_dev:
+            dTAd_inv = 1.0 / dot_op.dev(searchdirs[0], searchfwds[0])
+            alphas = [dot_op.dev(searchdirs[0], residual) * dTAd_inv]
+        else:
+            deltas = [dot_op(d, residual) for d in searchdirs]
+            dTAd = np.zeros((n_pre, n_pre))
+            for i1 in range(n_pre):
+                for i2 in range(i1 + 1):
+                    dTAd[i1, i2] = dTAd[i2, i1] = dot_op(searchdirs[i1], searchfwds[i2])
+            dTAd_inv = np.linalg.inv(dTAd)
+            alphas = np.dot(dTAd_inv, deltas)
         for d, alpha in zip(searchdirs, alphas):
             x += d * alpha
         cache.store(it, [dTAd_inv, searchdirs, searchfwds])
@@ -69,9 +78,12 @@ def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=
         for titer in range(tr(it), it):
             prev_dTAd_inv, prev_dirs, prev_fwds = cache.restore(titer)
             for d in searchdirs:
-                proj = [dot_op(d, pq) for pq in prev_fwds]
-                betas = np.dot(prev_dTAd_inv, proj)
-                for beta, pd in zip(betas, prev_dirs):
-                    d -= pd * beta
+                if on_dev:
+                    d -= prev_dirs[0] * (dot_op.dev(d, prev_fwds[0]) * prev_dTAd_inv)
+                else:
+                    proj = [dot_op(d, pq) for pq in prev_fwds]
+                    betas = np.dot(prev_dTAd_inv, proj)
+                    for beta, pd in zip(betas, prev_dirs):
+                        d -= pd * beta
         cache.trim(range(tr(it + 1), it))
     return it

@@ -31,6 +31,23 @@ def _rlm_maps(lmax):
     return _RLM_IDX[lmax]
 
 
+_RLM_DEV = {}
+
+
+def _rlm_maps_dev(lmax, d):
+    """device copies of the index maps and m-weights (uploaded once: the dense preconditioner is applied dozens of times
+    per CG iteration and every pageable upload is a blocking copy -- and illegal inside a graph capture)"""
+    key = (lmax, str(d))
+    if key not in _RLM_DEV:
+        ra, rr, ia, ir = _rlm_maps(lmax)
+        w2 = torch.full((ra.size,), np.sqrt(2.), dtype=torch.float64, device=d)
+        w2[:lmax + 1] = 1.
+        wi = torch.full((ra.size,), 1.0 / np.sqrt(2.), dtype=torch.float64, device=d)
+        wi[:lmax + 1] = 1.
+        _RLM_DEV[key] = tuple(torch.from_numpy(x).to(d) for x in (ra, rr, ia, ir)) + (w2, wi)
+    return _RLM_DEV[key]
+
+
 def alm2rlm(alm):
     """Complex alm -> real harmonic coefficients (m = 0 real part; sqrt(2) Re, sqrt(2) Im for m > 0)."""
     is_dev = isinstance(alm, torch.Tensor)
@@ -40,11 +57,10 @@ def alm2rlm(alm):
     rt2 = np.sqrt(2.)
     if is_dev:
         d = alm.device
+        dra, drr, dia, dir_, w2, _ = _rlm_maps_dev(lmax, d)
         rlm = torch.zeros((lmax + 1) ** 2, dtype=torch.float64, device=d)
-        w = torch.full((ra.size,), rt2, dtype=torch.float64, device=d)
-        w[:lmax + 1] = 1.
-        rlm[torch.from_numpy(rr).to(d)] = alm.real[torch.from_numpy(ra).to(d)] * w
-        rlm[torch.from_numpy(ir).to(d)] = alm.imag[torch.from_numpy(ia).to(d)] * rt2
+        rlm[drr] = alm.real[dra] * w2
+        rlm[dir_] = alm.imag[dia] * rt2
         return rlm
     rlm = np.zeros((lmax + 1) ** 2)
     w = np.full(ra.size, rt2)
@@ -64,12 +80,11 @@ def rlm2alm(rlm):
     ir2 = 1.0 / np.sqrt(2.)
     if is_dev:
         d = rlm.device
+        dra, drr, dia, dir_, _, wi = _rlm_maps_dev(lmax, d)
         re = torch.zeros(Alm.getsize(lmax), dtype=torch.float64, device=d)
         im = torch.zeros_like(re)
-        w = torch.full((ra.size,), ir2, dtype=torch.float64, device=d)
-        w[:lmax + 1] = 1.
-        re[torch.from_numpy(ra).to(d)] = rlm[torch.from_numpy(rr).to(d)] * w
-        im[torch.from_numpy(ia).to(d)] = rlm[torch.from_numpy(ir).to(d)] * ir2
+        re[dra] = rlm[drr] * wi
+        im[dia] = rlm[dir_] * ir2
         return torch.complex(re, im)
     alm = np.zeros(Alm.getsize(lmax), dtype=complex)
     w = np.full(ra.size, ir2)

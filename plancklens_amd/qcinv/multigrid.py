@@ -7,10 +7,12 @@ All vectors handed between the stages stay on the device."""
 from __future__ import print_function
 
 import copy
+import os
 import re
 import sys
 
 import numpy as np
+import torch
 
 from . import cd_monitors, cd_solve, util, util_alm
 
@@ -111,9 +113,11 @@ def parse_pre_op_descr(pre_op_descr, **kwargs):
         stage = kwargs['stages'][int(m.group(1))]
         logger = (lambda iter, eps, stage=stage, chain=kwargs['chain'], **kw: chain.log(stage, iter, eps, **kw))
         assert stage.lmax == kwargs['lmax']
+        chain = kwargs['chain']
+        quiet = (lambda stage=stage, chain=chain: stage.depth > chain.plogdepth and chain.debug_log_prefix is None)
         return pre_op_multigrid(kwargs['opfilt'], stage.lmax, stage.nside, kwargs['s_cls'],
                                 kwargs['n_inv_filt'].degrade(stage.nside), stage.pre_ops, logger, stage.tr, stage.cache,
-                                stage.iter_max, stage.eps_min)
+                                stage.iter_max, stage.eps_min, quiet=quiet)
     assert 0, 'pre_op_descr ' + pre_op_descr + ' is unrecognized!'
 
 
@@ -140,7 +144,9 @@ class pre_op_split(object):
 class pre_op_multigrid(object):
     """A few CG iterations at a coarser (nside, lmax) as preconditioner."""
 
-    def __init__(self, opfilt, lmax, nside, s_cls, n_inv_filt, pre_ops, logger, tr, cache, iter_max, eps_min):
+    def __init__(self, opfilt, lmax, nside, s_cls, n_inv_filt, pre_ops, logger, tr, cache, iter_max, eps_min, quiet=None):
+        self.quiet = quiet  # callable: True when this stage's iterations are not logged anywhere
+        self._graphs = {}
         self.opfilt = opfilt
         self.fwd_op = opfilt.fwd_op(s_cls, n_inv_filt)
         self.lmax = lmax
@@ -156,9 +162,75 @@ class pre_op_multigrid(object):
     def __call__(self, talm):
         return self.calc(talm)
 
+    # A nested solve with a fixed iteration count and nobody reading its log has no host-side data dependence: the same
+    # few thousand small kernels (coarse SHTs, dense mat-vec, alm arithmetic) in the same order every time, and at the
+    # coarse resolutions they cost less to run than to launch from Python.  After `graph_after` eager calls the outermost
+    # such preconditioner is captured into a HIP graph (torch.cuda.CUDAGraph; the kernels of libplshts are launched on
+    # torch's current stream, so they are captured with everything else) and replayed from then on.
+    graph_after = 2
+
+    def _capturable(self, talm):
+        if os.environ.get('PLENS_CG_GRAPH', '1') == '0' or self.iter_max == np.inf or self.eps_min != 0.:
+            return False
+        if self.quiet is None or not self.quiet():
+            return False
+        parts = _parts(talm)
+        return all(isinstance(p, torch.Tensor) and p.is_cuda for p in parts) and not torch.cuda.is_current_stream_capturing()
+
     def calc(self, talm):
-        monitor = cd_monitors.monitor_basic(self.opfilt.dot_op(), iter_max=self.iter_max, eps_min=self.eps_min, logger=self.logger)
+        if not self._capturable(talm):
+            return self._calc_eager(talm)
+        key = tuple((p.numel(), p.dtype) for p in _parts(talm))
+        st = self._graphs.setdefault(key, {'calls': 0, 'graph': None})
+        if st['graph'] is None:
+            st['calls'] += 1
+            if st['calls'] <= self.graph_after:
+                return self._calc_eager(talm)
+            try:
+                st['in'] = [torch.empty_like(p) for p in _parts(talm)]
+                for d, p in zip(st['in'], _parts(talm)):
+                    d.copy_(p)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = self._calc_eager(_like(talm, st['in']))
+                st['out'], st['graph'] = _parts(out), g
+            except Exception as e:  # capture is an optimisation: fall back to the eager path for good
+                print('pre_op_multigrid: graph capture failed (%s); staying eager' % str(e).split('\n')[0])
+                if os.environ.get('PLENS_CG_GRAPH_DEBUG'):
+                    import traceback
+                    traceback.print_exc()
+                torch.cuda.synchronize()
+                st['graph'] = False
+                return self._calc_eager(talm)
+        if st['graph'] is False:
+            return self._calc_eager(talm)
+        for d, p in zip(st['in'], _parts(talm)):
+            d.copy_(p)
+        st['graph'].replay()
+        return _like(talm, [o.clone() for o in st['out']])
+
+    def _calc_eager(self, talm):
+        monitor = cd_monitors.monitor_basic(self.opfilt.dot_op(), iter_max=self.iter_max, eps_min=self.eps_min, logger=self.logger,
+                                            quiet=bool(self.quiet is not None and self.quiet()))
         soltn = talm * 0.0
         cd_solve.cd_solve(soltn, util_alm.alm_copy(talm, lmax=self.lmax), self.fwd_op, self.pre_ops, self.opfilt.dot_op(),
-                          monitor, tr=self.tr, cache=self.cache)
+                          monitor, tr=self.tr, cache=self.cache, x_is_zero=True)
         return util_alm.alm_splice(soltn, talm, self.lmax)
+
+
+def _parts(v):
+    """component tensors of a CG vector (plain alm, eblm, teblm)"""
+    if hasattr(v, 'tlm'):
+        return [v.tlm, v.elm, v.blm]
+    if hasattr(v, 'elm'):
+        return [v.elm, v.blm]
+    return [v]
+
+
+def _like(v, parts):
+    if hasattr(v, 'tlm'):
+        return util_alm.teblm(parts)
+    if hasattr(v, 'elm'):
+        return util_alm.eblm(parts)
+    return parts[0]

@@ -17,12 +17,16 @@ alm2map_spin, map2alm_spin = shts.alm2map_spin, shts.map2alm_spin
 class dot_op(object):
     """sum_{l >= 2} (2l + 1) (C_l^{EE'} + C_l^{BB'})."""
 
-    def __call__(self, alm1, alm2):
+    def dev(self, alm1, alm2):
+        """the scalar product as a 0-dim device tensor (no host synchronisation)"""
         assert alm1.lmax == alm2.lmax
         tcl = dev.alm2cl(alm1.elm, alm2.elm) + dev.alm2cl(alm1.blm, alm2.blm)
         w = 2. * np.arange(alm1.lmax + 1) + 1.
         w[:2] = 0.
-        return float(torch.dot(tcl, dev.fl_dev(w, alm1.lmax)))
+        return torch.dot(tcl, dev.fl_dev(w, alm1.lmax))
+
+    def __call__(self, alm1, alm2):
+        return float(self.dev(alm1, alm2))
 
 
 class fwd_op(object):

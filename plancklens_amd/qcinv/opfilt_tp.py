@@ -47,14 +47,19 @@ def apply_finiMLIK(alm, s_cls, n_inv_filt):
 class dot_op(object):
     """sum_l (2l + 1) (C_l^{TT'} + C_l^{EE'} + C_l^{BB'})."""
 
-    def __call__(self, alm1, alm2):
+    def dev(self, alm1, alm2):
+        """the scalar product as a 0-dim device tensor (no host synchronisation)"""
         assert alm1.lmaxt == alm2.lmaxt, (alm1.lmaxt, alm2.lmaxt)
         assert alm1.lmaxe == alm2.lmaxe, (alm1.lmaxe, alm2.lmaxe)
         assert alm1.lmaxb == alm2.lmaxb, (alm1.lmaxb, alm2.lmaxb)
-        ret = 0.
+        ret = None
         for a, b, lmax in ((alm1.tlm, alm2.tlm, alm1.lmaxt), (alm1.elm, alm2.elm, alm1.lmaxe), (alm1.blm, alm2.blm, alm1.lmaxb)):
-            ret += float(torch.dot(dev.alm2cl(a, b), dev.fl_dev(2. * np.arange(lmax + 1) + 1., lmax)))
+            t = torch.dot(dev.alm2cl(a, b), dev.fl_dev(2. * np.arange(lmax + 1) + 1., lmax))
+            ret = t if ret is None else ret + t
         return ret
+
+    def __call__(self, alm1, alm2):
+        return float(self.dev(alm1, alm2))
 
 
 class fwd_op(object):
@@ -249,12 +254,16 @@ class alm_filter_ninv(object):
             umap *= self.n_inv[3]
             umap += self.n_inv[2] * qmap_copy
         if len(self.templates_t) != 0:
-            coeffs = np.concatenate([t.dot(tmap) for t in self.templates_t])
-            coeffs = np.dot(self.Pt_Nn1_P_inv, coeffs)
-            pmodes = torch.zeros_like(tmap)
-            im = 0
-            for t in self.templates_t:
-                t.accum(pmodes, coeffs[im:(im + t.nmodes)])
-                im += t.nmodes
-            pmodes *= self.n_inv[0]
-            tmap -= pmodes
+            # all template modes as one device matrix P (nmodes x npix): coefficients, the small solve and the projected
+            # map are device operations, nothing comes back to the host inside a CG iteration
+            if getattr(self, '_pmat', None) is None:
+                rows = []
+                for t in self.templates_t:
+                    for i in range(t.nmodes):
+                        row = torch.ones_like(tmap)
+                        t.apply_mode(row, i)
+                        rows.append(row)
+                self._pmat = torch.stack(rows)
+                self._pinv_dev = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64)
+            coeffs = torch.mv(self._pinv_dev, torch.mv(self._pmat, tmap))
+            tmap -= self.n_inv[0] * torch.mv(self._pmat.t(), coeffs)

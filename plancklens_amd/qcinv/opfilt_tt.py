@@ -40,11 +40,15 @@ def apply_fini(alm, s_cls, n_inv_filt):
 class dot_op(object):
     """sum_l (2l + 1) C_l^{ab}: the scalar product of the CG (opfilt_tt.py:43-51)."""
 
-    def __call__(self, alm1, alm2):
+    def dev(self, alm1, alm2):
+        """the scalar product as a 0-dim device tensor (no host synchronisation)"""
         lmax1 = hp.Alm.getlmax(alm1.numel())
         assert lmax1 == hp.Alm.getlmax(alm2.numel())
         w = dev.fl_dev(2. * np.arange(lmax1 + 1) + 1., lmax1)
-        return float(torch.dot(dev.alm2cl(alm1, alm2), w))
+        return torch.dot(dev.alm2cl(alm1, alm2), w)
+
+    def __call__(self, alm1, alm2):
+        return float(self.dev(alm1, alm2))
 
 
 class fwd_op(object):
@@ -61,8 +65,6 @@ class fwd_op(object):
         return self.calc(talm)
 
     def calc(self, talm):
-        if not bool(torch.any(talm != 0)):  # nothing to do on zeros (starting point of the nested solves)
-            return talm
         alm = talm.clone()
         self.n_inv_filt.apply_alm(alm)
         alm += dev.almxfl(talm, self.cltt_inv)
@@ -167,12 +169,16 @@ class alm_filter_ninv(object):
         """tmap <- N^-1 tmap with the templates projected out (in place)."""
         tmap *= self.n_inv
         if len(self.templates) != 0:
-            coeffs = np.concatenate([t.dot(tmap) for t in self.templates])
-            coeffs = np.dot(self.Pt_Nn1_P_inv, coeffs)
-            pmodes = torch.zeros_like(tmap)
-            im = 0
-            for t in self.templates:
-                t.accum(pmodes, coeffs[im:(im + t.nmodes)])
-                im += t.nmodes
-            pmodes *= self.n_inv
-            tmap -= pmodes
+            # all template modes as one device matrix P (nmodes x npix): coefficients, the small solve and the projected
+            # map are device operations, nothing comes back to the host inside a CG iteration
+            if getattr(self, '_pmat', None) is None:
+                rows = []
+                for t in self.templates:
+                    for i in range(t.nmodes):
+                        row = torch.ones_like(tmap)
+                        t.apply_mode(row, i)
+                        rows.append(row)
+                self._pmat = torch.stack(rows)
+                self._pinv_dev = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64)
+            coeffs = torch.mv(self._pinv_dev, torch.mv(self._pmat, tmap))
+            tmap -= self.n_inv * torch.mv(self._pmat.t(), coeffs)
