@@ -213,11 +213,12 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
             if (clsA[q] >= 0) MofA[q] = Na;
         }
     }
-    std::vector<int> listS[5], listA[5], legacyS, legacyA;
+    std::vector<int> listS[5], listA[5], dirS[5], dirA[5], legacyS, legacyA;
     for (int i = g.npairs - 1; i >= 0; --i) {  // longest rings first
         const int q = g.nphi[i] / 4;
-        if (clsS[q] >= 0) listS[clsS[q]].push_back(i); else legacyS.push_back(i);
-        if (clsA[q] >= 0) listA[clsA[q]].push_back(i); else legacyA.push_back(i);
+        const bool direct = (q & (q - 1)) == 0;
+        if (clsS[q] >= 0) (direct ? dirS : listS)[clsS[q]].push_back(i); else legacyS.push_back(i);
+        if (clsA[q] >= 0) (direct ? dirA : listA)[clsA[q]].push_back(i); else legacyA.push_back(i);
     }
     std::vector<int> Mof(nside + 1, 0), qlist, qlistS, qlistA;
     std::vector<int64_t> woff(nside + 1, 0), coff(nside + 1, 0), coffS(nside + 1, 0), coffA(nside + 1, 0);
@@ -239,7 +240,7 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
     F.Lmax = Lmax;
     F.Mtw = Lmax < 2 ? 2 : Lmax;
     if (F.Mtw < M2max) F.Mtw = M2max;
-    for (int c = 0; c < 5; ++c) if ((!listS[c].empty() || !listA[c].empty()) && F.Mtw < (256 << c)) F.Mtw = 256 << c;
+    for (int c = 0; c < 5; ++c) if ((!listS[c].empty() || !listA[c].empty() || !dirS[c].empty() || !dirA[c].empty()) && F.Mtw < (256 << c)) F.Mtw = 256 << c;
     if ((size_t)Lmax * 16 > 160 * 1024) { pl_plan_destroy(p); return fail("ring FFT workspace exceeds the 160 KiB LDS of a CU"); }
     {   // LDS twiddle tables of the largest generic transform (radix-8 passes + one radix-4/2 tail), if they fit beside it
         int k = 0; while ((1 << k) < Lmax) ++k;
@@ -264,8 +265,10 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
          upload(p, MofA, &F.A.Mof) || upload(p, coffA, &F.A.coff) || upload(p, legacyA, &F.A.legacy_pairs);
     F.S.legacy_n = (int)legacyS.size(); F.A.legacy_n = (int)legacyA.size();
     for (int c = 0; c < 5 && !rc; ++c) {
-        rc = upload(p, listS[c], &F.S.cls_pairs[c]) || upload(p, listA[c], &F.A.cls_pairs[c]);
+        rc = upload(p, listS[c], &F.S.cls_pairs[c]) || upload(p, listA[c], &F.A.cls_pairs[c]) ||
+             upload(p, dirS[c], &F.S.dir_pairs[c]) || upload(p, dirA[c], &F.A.dir_pairs[c]);
         F.S.cls_n[c] = (int)listS[c].size(); F.A.cls_n[c] = (int)listA[c].size();
+        F.S.dir_n[c] = (int)dirS[c].size(); F.A.dir_n[c] = (int)dirA[c].size();
     }
     if (rc) { pl_plan_destroy(p); return 1; }
     F.tw = reinterpret_cast<const double2 *>(tw);

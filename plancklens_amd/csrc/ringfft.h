@@ -11,8 +11,10 @@ namespace plshts {
 struct FftSide {
     const int *legacy_pairs; // generic LDS-resident kernel (short polar rings, aliased rings), longest rings first
     int legacy_n;
-    const int *cls_pairs[5]; // register-resident kernels, transform size N = 256 << c
+    const int *cls_pairs[5]; // register-resident kernels, transform size N = 256 << c: Bluestein rings (q != N)
     int cls_n[5];
+    const int *dir_pairs[5]; // ... and the rings whose own sub-DFT length is N (q == N, a power of two)
+    int dir_n[5];
     const int *Mof;          // [nside + 1] Bluestein convolution size of q in its class (0: direct, or generic list)
     const int64_t *coff;     // [nside + 1] offset of q's natural-order filter spectrum (Mof[q] entries)
     const double2 *filt;

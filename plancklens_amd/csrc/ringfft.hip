@@ -579,7 +579,7 @@ __device__ __forceinline__ FastBin fast_bin(bool blue, int idx, int N, int q, in
 // All four sub-DFTs stay resident (d[4][8]) because every pixel needs all of them; the workgroup keeps to 256 registers
 // per thread (two workgroups per CU).  The sub-DFT inputs are band-limited (|c| <= K), so the Bluestein classes use the
 // same convolution sizes and filter tables as the analysis (side A lists and tables).
-template <int N>
+template <int N, bool BLUE>
 __global__ __launch_bounds__(N / 8, 2) void k_phase2map_fast(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim,
                                                              int ncomp, const double *__restrict__ phase, double *__restrict__ map)
 {
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(N / 8, 2) void k_phase2map_fast(DevPlan P, DevFFT F
     const int tl0 = threadIdx.x;
     const int ip = pairs[blockIdx.x], comp = blockIdx.y;
     const int n = P.nphi[ip], q = n >> 2;
-    const bool blue = q != N;
+    constexpr bool blue = BLUE;  // Bluestein rings and direct (q == N) rings run as separate launches: half the code each
     const int K = F.K2of[q];
     const double2 *__restrict__ chirp = F.chirp + F.woff[q];
     const double2 *__restrict__ filt = F.A.filt + F.A.coff[q];
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(N / 8, 2) void k_phase2map_fast(DevPlan P, DevFFT F
 // pixel j = j1 + q j2, bin k = 4 k1 + k2: V_(4 k1 + k2) = sum_j1 e^{2 pi i j1 k1 / q} [e^{2 pi i j1 k2 / n} sum_j2 i^(j2 k2) conj(z)_(j1 + q j2)].
 // Sub-DFTs are processed as the pairs (k2 = 0, 2) and (1, 3) -- the mirror bin n - k of k2 lives in sub-DFT (4 - k2) mod 4,
 // so each pair is self-contained -- with the ring pixels loaded again for the second pair (coalesced, from L2).
-template <int N>
+template <int N, bool BLUE>
 __global__ __launch_bounds__(N / 8, 2) void k_map2phase_fast(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim,
                                                           int ncomp, const double *map, double *phase)
 {
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(N / 8, 2) void k_map2phase_fast(DevPlan P, DevFFT F
     const int tl0 = threadIdx.x;
     const int ip = pairs[blockIdx.x], comp = blockIdx.y;
     const int n = P.nphi[ip], q = n >> 2;
-    const bool blue = q != N;
+    constexpr bool blue = BLUE;  // Bluestein rings and direct (q == N) rings run as separate launches: half the code each
     const int K = F.K2of[q];
     const double2 *__restrict__ chirp = F.chirp + F.woff[q];
     const double2 *__restrict__ filt = F.A.filt + F.A.coff[q];
@@ -888,24 +888,26 @@ static hipError_t launch_map2phase_legacy(const DevPlan &P, const DevFFT &F, con
     PL_FFT_DISPATCH(launch_m2p, P, F, mlim, ncomp, map, phase, st);
 }
 
-template <int N>
+template <int N, bool BLUE>
 static hipError_t launch_fast_class(const DevPlan &P, const DevFFT &F, int cls, bool synth, const int *mlim, int ncomp, const double *in,
                                     double *out, hipStream_t st)
 {
     const FftSide &sd = F.A;  // both directions use the band-limited classes
-    if (sd.cls_n[cls] == 0) return hipSuccess;
+    const int n = BLUE ? sd.cls_n[cls] : sd.dir_n[cls];
+    const int *pairs = BLUE ? sd.cls_pairs[cls] : sd.dir_pairs[cls];
+    if (n == 0) return hipSuccess;
     const size_t lds = (size_t)N * sizeof(double2);
     if (lds > 48 * 1024) {
         static bool attr_done = false;
         if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map_fast<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_map2phase_fast<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map_fast<N, BLUE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_map2phase_fast<N, BLUE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             attr_done = true;
         }
     }
-    if (synth) hipLaunchKernelGGL((k_phase2map_fast<N>), dim3(sd.cls_n[cls], ncomp), dim3(N / 8), lds, st, P, F, sd.cls_pairs[cls], mlim, ncomp, in, out);
-    else hipLaunchKernelGGL((k_map2phase_fast<N>), dim3(sd.cls_n[cls], ncomp), dim3(N / 8), lds, st, P, F, sd.cls_pairs[cls], mlim, ncomp, in, out);
+    if (synth) hipLaunchKernelGGL((k_phase2map_fast<N, BLUE>), dim3(n, ncomp), dim3(N / 8), lds, st, P, F, pairs, mlim, ncomp, in, out);
+    else hipLaunchKernelGGL((k_map2phase_fast<N, BLUE>), dim3(n, ncomp), dim3(N / 8), lds, st, P, F, pairs, mlim, ncomp, in, out);
     return hipGetLastError();
 }
 
@@ -937,36 +939,49 @@ static hipError_t launch_stage(const DevPlan &P, const DevFFT &F, const FftStrea
                                const double *in, double *out, hipStream_t st)
 {
     const bool par = fs.ok && !(getenv("PLSHTS_FFT_SERIAL") && atoi(getenv("PLSHTS_FFT_SERIAL")) != 0);
-    int big = -1;  // class with the most work stays on the caller's stream
-    { int64_t best = -1; for (int c = 0; c < 5; ++c) { const int64_t w = (int64_t)F.A.cls_n[c] * (256 << c); if (F.A.cls_n[c] > 0 && w > best) { best = w; big = c; } } }
+    // work items: (class c, Bluestein or direct); the one with the most work stays on the caller's stream
+    int big = -1;
+    { int64_t best = -1;
+      for (int w = 0; w < 10; ++w) {
+          const int c = w >> 1, n = (w & 1) ? F.A.cls_n[c] : F.A.dir_n[c];
+          const int64_t work = (int64_t)n * (256 << c) * ((w & 1) ? 2 : 1);
+          if (n > 0 && work > best) { best = work; big = w; }
+      } }
     hipError_t e = hipSuccess;
     if (par) e = hipEventRecord(fs.fork, st);
     int used = 0;
     bool joined[FftStreams::kN] = {false, false, false, false, false};
-    auto side = [&](int c) -> hipStream_t {
-        if (!par || c == big || used >= FftStreams::kN) return st;
-        const int i = used++;
-        if (hipStreamWaitEvent(fs.s[i], fs.fork, 0) != hipSuccess) return st;
+    auto side = [&](int w) -> hipStream_t {
+        if (!par || w == big) return st;
+        const int i = used < FftStreams::kN ? used++ : (used++ % FftStreams::kN);  // more items than streams: share round-robin
+        if (!joined[i] && hipStreamWaitEvent(fs.s[i], fs.fork, 0) != hipSuccess) return st;
         joined[i] = true;
         return fs.s[i];
     };
-    auto run = [&](int c) -> hipError_t {
-        if (F.A.cls_n[c] == 0) return hipSuccess;
-        hipStream_t s = side(c);
-        switch (c) {
-        case 4: return launch_fast_class<4096>(P, F, 4, synth, mlim, ncomp, in, out, s);
-        case 3: return launch_fast_class<2048>(P, F, 3, synth, mlim, ncomp, in, out, s);
-        case 2: return launch_fast_class<1024>(P, F, 2, synth, mlim, ncomp, in, out, s);
-        case 1: return launch_fast_class<512>(P, F, 1, synth, mlim, ncomp, in, out, s);
-        default: return launch_fast_class<256>(P, F, 0, synth, mlim, ncomp, in, out, s);
+    auto run = [&](int w) -> hipError_t {
+        const int c = w >> 1;
+        const bool blue = w & 1;
+        if ((blue ? F.A.cls_n[c] : F.A.dir_n[c]) == 0) return hipSuccess;
+        hipStream_t s = side(w);
+        switch (w) {
+        case 9: return launch_fast_class<4096, true>(P, F, 4, synth, mlim, ncomp, in, out, s);
+        case 8: return launch_fast_class<4096, false>(P, F, 4, synth, mlim, ncomp, in, out, s);
+        case 7: return launch_fast_class<2048, true>(P, F, 3, synth, mlim, ncomp, in, out, s);
+        case 6: return launch_fast_class<2048, false>(P, F, 3, synth, mlim, ncomp, in, out, s);
+        case 5: return launch_fast_class<1024, true>(P, F, 2, synth, mlim, ncomp, in, out, s);
+        case 4: return launch_fast_class<1024, false>(P, F, 2, synth, mlim, ncomp, in, out, s);
+        case 3: return launch_fast_class<512, true>(P, F, 1, synth, mlim, ncomp, in, out, s);
+        case 2: return launch_fast_class<512, false>(P, F, 1, synth, mlim, ncomp, in, out, s);
+        case 1: return launch_fast_class<256, true>(P, F, 0, synth, mlim, ncomp, in, out, s);
+        default: return launch_fast_class<256, false>(P, F, 0, synth, mlim, ncomp, in, out, s);
         }
     };
-    for (int c = 4; c >= 0 && e == hipSuccess; --c) e = run(c);  // longest transforms first
+    for (int w = 9; w >= 0 && e == hipSuccess; --w) e = run(w);  // longest transforms first
     if (e == hipSuccess && F.A.legacy_n > 0) {
         hipStream_t s = big < 0 ? st : side(-1);
         e = synth ? launch_phase2map_legacy(P, F, mlim, ncomp, in, out, s) : launch_map2phase_legacy(P, F, mlim, ncomp, in, out, s);
     }
-    for (int i = 0; i < used; ++i) {
+    for (int i = 0; i < FftStreams::kN; ++i) {
         if (!joined[i]) continue;
         hipError_t e2 = hipEventRecord(fs.join[i], fs.s[i]);
         if (e2 == hipSuccess) e2 = hipStreamWaitEvent(st, fs.join[i], 0);
