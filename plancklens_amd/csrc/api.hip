@@ -213,6 +213,13 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
             if (clsA[q] >= 0) MofA[q] = Na;
         }
     }
+    {   // a power-of-two ring length met by only a few ring pairs (the single cap rings q = 256, 512, ... below nside) is not
+        // worth a kernel launch of its own: those pairs join the generic list
+        std::vector<int> npairs_q(nside + 1, 0);
+        for (int i = 0; i < g.npairs; ++i) npairs_q[g.nphi[i] / 4] += 1;
+        for (int q = 1; q <= nside; ++q)
+            if ((q & (q - 1)) == 0 && npairs_q[q] < 8) clsS[q] = clsA[q] = -1;
+    }
     std::vector<int> listS[5], listA[5], dirS[5], dirA[5], legacyS, legacyA;
     for (int i = g.npairs - 1; i >= 0; --i) {  // longest rings first
         const int q = g.nphi[i] / 4;
