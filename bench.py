@@ -37,6 +37,15 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 SYNTHS_TRAFFIC_BYTES = (837191 + 373984) * 1024
 
 
+def fma_ceilings():
+    """Sustained v_fma_f64 rates of this GPU measured live (pl_fma64_rate_tflops: 16 independent chains per lane, no memory):
+    the datasheet peak is not reachable in steady state, and the rate depends on how many vector sources an FMA reads."""
+    from plancklens_amd import _lib
+    L = _lib.lib()
+    names = {1: 'two_scalar_sources (synthesis mix)', 0: 'one_vector_one_scalar', 2: 'three_vector_sources (analysis mix)'}
+    return {names[m]: float(L.pl_fma64_rate_tflops(m, 20000, None)) for m in (1, 0, 2)}
+
+
 def executed_flops(nside, lmax, spin):
     """Flops of the (l, m, ring pair) recursion steps a Legendre kernel actually runs: rings with m > mlim(theta) are
     pruned (same rule as the kernels, csrc/tables.cpp mlim_ring).  spin >= 1: 12 FMA per step; spin 0: the two-step
@@ -262,10 +271,12 @@ def main():
                                'frac': ach / FP64_PEAK_TFLOPS, 'traffic': SYNTHS_TRAFFIC_BYTES, 'kernel': 'k_leg_synths (spin-weighted Legendre synthesis)',
                                'avg_launch_ms': avg_ms, 'launches': cnt,
                                'executed_tflops': exec_spin / (avg_ms * 1e-3) / 1e12,
+                               'fma_issue_ceiling_measured_tflops': fma_ceilings(),
                                'frac_executed': exec_spin / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                                'note': 'FP64 vector-FMA issue bound (v_fma_f64); gfx950 FP64 MFMA peak = FP64 vector peak; no MFMA used. '
                                        'achieved = SURVEY 8(d) fixed-denominator count (24 flop x nalm x 2 nside, polar pruning not counted); '
-                                       'executed_tflops counts only the (l, m, ring pair) steps the kernel runs after libsharp-style polar pruning. '
+                                       'executed_tflops counts only the (l, m, ring pair) steps the kernel runs after libsharp-style polar pruning; '
+                                       'fma_issue_ceiling_measured_tflops is what a pure FMA loop sustains on this GPU. '
                                        'traffic = FETCH_SIZE + WRITE_SIZE bytes per launch from profiles/ (PMC passes of an earlier run of the same kernel; '
                                        'coefficient-table re-reads by the ring groups are served by L2 / Infinity Cache)'}
         per_kernel = {}

@@ -97,7 +97,11 @@ int pl_qe_lens_product(int64_t n, const double *tmap, const double *gt, const do
                        const double *g3, const double *c3, const double *g1, const double *c1, double *out_re, double *out_im,
                        void *stream);
 
-/* FP64 FMA-rate microbenchmark (independent chains, no memory traffic): returns achieved TFLOP/s. */
+/* FP64 FMA-rate microbenchmarks (16 independent chains per lane, no memory traffic): achieved TFLOP/s.
+ * pl_fma64_rate_tflops: mode 0 = one vector + one scalar source besides the accumulator, 1 = two scalar (wave-uniform)
+ * sources -- the operand mix of the synthesis kernels --, 2 = three vector sources -- the analysis kernels.
+ * pl_fma64_peak_tflops = mode 1, the highest of the three. */
+double pl_fma64_rate_tflops(int mode, int iters, void *stream);
 double pl_fma64_peak_tflops(int iters, void *stream);
 
 #ifdef __cplusplus

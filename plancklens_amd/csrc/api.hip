@@ -30,7 +30,7 @@ void launch_qe_lens_product(int64_t n, const double *tmap, const double *gt, con
                             const double *g3, const double *c3, const double *g1, const double *c1, double *outr, double *outi, hipStream_t st);
 void launch_map_cmul(int64_t n, const double *ar, const double *ai, double s1, const double *br, const double *bi, double s2,
                      double sign, double *outr, double *outi, int accumulate, hipStream_t st);
-void launch_fma_peak(int iters, double *out, int nblk, hipStream_t st);
+void launch_fma_peak(int mode, int iters, double *out, int nblk, hipStream_t st);
 }  // namespace plshts
 
 using namespace plshts;
@@ -510,17 +510,18 @@ int pl_qe_lens_product(int64_t n, const double *tmap, const double *gt, const do
     return 0;
 }
 
-double pl_fma64_peak_tflops(int iters, void *stream)
+double pl_fma64_rate_tflops(int mode, int iters, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
     double *out = nullptr;
+    if (mode < 0 || mode > 2) return -1.0;
     if (hipMalloc(reinterpret_cast<void **>(&out), 8) != hipSuccess) return -1.0;
     const int nblk = 256 * 8;
     hipEvent_t e0, e1;
     bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-    launch_fma_peak(iters / 8 + 1, out, nblk, st);
+    launch_fma_peak(mode, iters / 8 + 1, out, nblk, st);
     ok = ok && hipEventRecord(e0, st) == hipSuccess;
-    launch_fma_peak(iters, out, nblk, st);
+    launch_fma_peak(mode, iters, out, nblk, st);
     ok = ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
     float ms = 0.f;
     ok = ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
@@ -530,5 +531,7 @@ double pl_fma64_peak_tflops(int iters, void *stream)
     const double flops = 2.0 * 16.0 * (double)iters * 256.0 * nblk;
     return flops / (ms * 1e-3) / 1e12;
 }
+
+double pl_fma64_peak_tflops(int iters, void *stream) { return pl_fma64_rate_tflops(1, iters, stream); }
 
 }  // extern "C"

@@ -2,6 +2,8 @@
 // FP64 FMA-rate microbenchmark.  All are streaming kernels: coalesced 16-byte accesses, grid-stride.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <cstdint>
 
 namespace plshts {
@@ -96,11 +98,14 @@ __global__ void k_qe_lens_product(int64_t n, const double *__restrict__ tmap, co
     }
 }
 
-// 16 independent FMA chains per lane: the FP64 vector-FMA issue ceiling of the chip
-__global__ __launch_bounds__(256) void k_fma_peak(int iters, double *out)
+// 16 independent FMA chains per lane: the FP64 vector-FMA issue ceiling of the chip.  MODE selects where the two
+// non-accumulator operands live: 0 one VGPR + one SGPR, 1 both SGPR (wave-uniform), 2 both VGPR (three vector sources)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_fma_peak(int iters, double xs, double ys, double *out)
 {
     double a[16];
-    const double x = 1.0 + 1e-9 * threadIdx.x, y = 1e-12 * blockIdx.x;
+    const double xv = 1.0 + 1e-9 * threadIdx.x, yv = 1e-12 * threadIdx.x;
+    const double x = MODE == 1 ? xs : xv, y = MODE == 2 ? yv : ys;
 #pragma unroll
     for (int i = 0; i < 16; ++i) a[i] = i * 0.125;
     for (int it = 0; it < iters; ++it) {
@@ -148,9 +153,12 @@ void launch_qe_lens_product(int64_t n, const double *tmap, const double *gt, con
 {
     hipLaunchKernelGGL(k_qe_lens_product, dim3(nblocks(n)), dim3(256), 0, st, n, tmap, gt, ct, rep, imp, g3, c3, g1, c1, outr, outi);
 }
-void launch_fma_peak(int iters, double *out, int nblk, hipStream_t st)
+void launch_fma_peak(int mode, int iters, double *out, int nblk, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_fma_peak, dim3(nblk), dim3(256), 0, st, iters, out);
+    const double xs = 1.0 + 1e-9, ys = 1e-12;
+    if (mode == 1) hipLaunchKernelGGL(k_fma_peak<1>, dim3(nblk), dim3(256), 0, st, iters, xs, ys, out);
+    else if (mode == 2) hipLaunchKernelGGL(k_fma_peak<2>, dim3(nblk), dim3(256), 0, st, iters, xs, ys, out);
+    else hipLaunchKernelGGL(k_fma_peak<0>, dim3(nblk), dim3(256), 0, st, iters, xs, ys, out);
 }
 
 }  // namespace plshts
