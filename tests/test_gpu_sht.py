@@ -162,7 +162,7 @@ def _run_with_plan(shts, plan, fn):
             shts._PLANS[key] = old
 
 
-@pytest.mark.parametrize('nside,lmax', [(256, 300), (512, 512), (1024, 1400), (2048, 2048)])
+@pytest.mark.parametrize('nside,lmax', [(256, 300), (512, 512), (768, 1000), (1024, 1400), (2048, 1024), (2048, 2048)])
 def test_register_fft_kernels_match_generic_kernel(shts, nside, lmax):
     """The long rings go through the register-resident ring-FFT kernels (sizes 256 .. 4096, direct and band-limited
     Bluestein); PLSHTS_FFT_LEGACY=1 at plan creation sends every ring through the generic LDS kernel, which the
