@@ -33,10 +33,14 @@ cl_len = utils.camb_clfile(os.path.join(cls_path, 'FFP10_wdipole_lensedCls.dat')
 cl_weight = utils.camb_clfile(os.path.join(cls_path, 'FFP10_wdipole_lensedCls.dat'))
 cl_weight['bb'] *= 0.
 
-pix_phas = phas.pix_lib_phas(os.path.join(TEMP, 'pix_phas_nside%s' % nside), 3, (hp.nside2npix(nside),), seed=11)
-sky_phas = phas.lib_phas(os.path.join(TEMP, 'sky_phas_lmax%s' % lmax_ivf), 3, lmax_ivf, seed=12)
+# PLENS_DEVICE_SIMS=1: phases, sky alms, maps and noise are generated on the GPU (torch Philox streams instead of numpy's:
+# other realisations, same statistics, still a pure function of (seed, field, index)) and never pass through host memory
+DEVICE_SIMS = os.environ.get('PLENS_DEVICE_SIMS', '0') == '1'
+_pix, _sky = (phas.pix_lib_phas_dev, phas.lib_phas_dev) if DEVICE_SIMS else (phas.pix_lib_phas, phas.lib_phas)
+pix_phas = _pix(os.path.join(TEMP, 'pix_phas_nside%s%s' % (nside, '_dev' * DEVICE_SIMS)), 3, (hp.nside2npix(nside),), seed=11)
+sky_phas = _sky(os.path.join(TEMP, 'sky_phas_lmax%s%s' % (lmax_ivf, '_dev' * DEVICE_SIMS)), 3, lmax_ivf, seed=12)
 skies = cmbs.sims_cmb_unl({k: cl_len[k] for k in ['tt', 'ee', 'bb', 'te']}, sky_phas)
-sims = maps_utils.sim_lib_shuffle(maps.cmb_maps_nlev(skies, transf, nlev_t, nlev_p, nside, pix_lib_phas=pix_phas),
+sims = maps_utils.sim_lib_shuffle(maps.cmb_maps_nlev(skies, transf, nlev_t, nlev_p, nside, pix_lib_phas=pix_phas, device_maps=DEVICE_SIMS),
                                   {idx: nsims if idx == -1 else idx for idx in range(-1, nsims)})
 
 ftl = utils.cli(cl_len['tt'][:lmax_ivf + 1] + (nlev_t / 60. / 180. * np.pi / transf) ** 2)

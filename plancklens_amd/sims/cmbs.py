@@ -40,7 +40,15 @@ class sims_cmb_unl(object):
         return ret
 
     def _get_sim_alm(self, idx, idf):
-        ret = hp.almxfl(self.lib_pha.get_sim(idx, idf=0), self.rmat[:, idf, 0])
+        pha = self.lib_pha.get_sim(idx, idf=0)
+        if not isinstance(pha, np.ndarray):  # device phases (phas.lib_phas_dev): the alms are built and stay on the GPU
+            from .. import dev
+            ret = dev.almxfl(pha, self.rmat[:, idf, 0])
+            for i in range(1, len(self.fields)):
+                if np.any(self.rmat[:, idf, i]):
+                    ret = ret + dev.almxfl(self.lib_pha.get_sim(idx, idf=i), self.rmat[:, idf, i])
+            return ret
+        ret = hp.almxfl(pha, self.rmat[:, idf, 0])
         for i in range(1, len(self.fields)):
             ret += hp.almxfl(self.lib_pha.get_sim(idx, idf=i), self.rmat[:, idf, i])
         return ret

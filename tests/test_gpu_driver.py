@@ -31,3 +31,55 @@ def test_run_qlms_idealized_small(tmp_path):
     from plancklens_amd import hp
     qlm = hp.read_alm(os.path.join(temp, 'qlms_dd', 'sim_p_0004.fits'))
     assert hp.Alm.getlmax(qlm.size) == 256 and np.all(np.isfinite(qlm.real)) and np.abs(qlm).max() > 0
+
+
+def test_device_side_simulation_libraries(tmp_path):
+    """phases, correlated sky alms, sky maps and noise generated on the GPU (no host arrays on the way):
+    reproducible per (seed, field, index), unit variance, right spectra including the TE correlation."""
+    import numpy as np
+    import torch
+    from plancklens_amd import dev, hp, utils
+    from plancklens_amd.sims import cmbs, maps, phas
+    lmax, nside = 256, 128
+    cls = utils.camb_clfile(os.path.join(ROOT, 'plancklens_amd', 'data', 'cls', 'FFP10_wdipole_lensedCls.dat'), lmax=lmax)
+    pha = phas.lib_phas_dev(str(tmp_path / 'pha'), 3, lmax, seed=11)
+    a, b = pha.get_sim(3, idf=1), pha.get_sim(3, idf=1)
+    assert a.is_cuda and a.dtype == torch.complex128 and bool((a == b).all())            # pure function of (seed, idf, idx)
+    assert not bool((a == pha.get_sim(4, idf=1)).all()) and not bool((a == pha.get_sim(3, idf=2)).all())
+    assert float(a[:lmax + 1].imag.abs().max()) == 0.                                      # real m = 0 column
+    cl_unit = dev.to_host(dev.alm2cl(a))
+    assert abs(np.mean(cl_unit[20:]) - 1.) < 0.03                                          # unit variance per mode
+    sky = cmbs.sims_cmb_unl({k: cls[k] for k in ['tt', 'ee', 'bb', 'te']}, pha)
+    acc = {k: 0. for k in ['tt', 'ee', 'te']}
+    nsim = 6
+    for i in range(nsim):
+        t, e = sky.get_sim_tlm(i), sky.get_sim_elm(i)
+        assert t.is_cuda
+        acc['tt'] += dev.to_host(dev.alm2cl(t)); acc['ee'] += dev.to_host(dev.alm2cl(e)); acc['te'] += dev.to_host(dev.alm2cl(t, e))
+    for k in acc:
+        band = slice(50, 250)
+        assert abs(np.sum(acc[k][band] / nsim) / np.sum(cls[k][band]) - 1.) < 0.05, k
+    noise = phas.pix_lib_phas_dev(str(tmp_path / 'pix'), 3, (hp.nside2npix(nside),), seed=5)
+    sims = maps.cmb_maps_nlev(sky, hp.gauss_beam(30. / 60 / 180 * np.pi, lmax=lmax), 20., 30., nside, pix_lib_phas=noise, device_maps=True)
+    tmap = sims.get_sim_tmap(0)
+    q, u = sims.get_sim_pmap(0)
+    assert tmap.is_cuda and q.is_cuda and u.is_cuda and tmap.numel() == hp.nside2npix(nside)
+    assert bool((tmap == sims.get_sim_tmap(0)).all())
+    vamin = np.sqrt(hp.nside2pixarea(nside, degrees=True)) * 60
+    n = noise.get_sim(0, idf=1)
+    assert abs(float(n.std()) - 1.) < 0.01 and abs(float(n.mean())) < 0.01
+    assert float((q - 30. / vamin * n).std()) < float(q.std())                            # the Q map contains that noise realisation
+
+
+def test_run_qlms_with_device_side_sims(tmp_path):
+    """the same driver with PLENS_DEVICE_SIMS=1: inputs generated on the GPU end to end"""
+    env = dict(os.environ, PLENS=str(tmp_path), PLENS_NSIDE='64', PLENS_LMAX='128', PLENS_NSIMS='10', PLENS_DEVICE_SIMS='1')
+    cmd = [sys.executable, os.path.join(ROOT, 'examples', 'run_qlms.py'), os.path.join(ROOT, 'params', 'idealized_example.py'),
+           '-imin', '0', '-imax', '2', '-k', 'p', '-ivt', '-ivp', '-dd']
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert out.returncode == 0, out.stdout.decode()[-3000:]
+    temp = os.path.join(str(tmp_path), 'temp', 'idealized_example')
+    sys.path.insert(0, ROOT)
+    from plancklens_amd import hp
+    qlm = hp.read_alm(os.path.join(temp, 'qlms_dd', 'sim_p_0001.fits'))
+    assert np.all(np.isfinite(qlm.real)) and np.abs(qlm).max() > 0
