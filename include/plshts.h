@@ -52,6 +52,11 @@ int64_t pl_plan_bytes(const pl_plan *plan); /* device bytes held by the plan */
  * fly (hp.almxfl fused; qest.py:463,502-503,592).  Inputs are not modified. */
 int pl_alm2map(pl_plan *plan, int spin, const double *alm, double *map, const double *fl, int where, void *stream);
 
+/* pl_alm2map with spin >= 1 for an input whose curl component is identically zero (the gradient legs of the temperature
+ * lensing estimator, qest.py:453-464,566-595, hand hp.alm2map_spin a zero C array): almG holds the nalm gradient
+ * coefficients only; map receives both components.  Same result as pl_alm2map with C = 0 at 2/3 of the Legendre work. */
+int pl_alm2map_grad(pl_plan *plan, int spin, const double *almG, double *map, const double *fl, int where, void *stream);
+
 /* shts.map2alm(iter=0) (shts.py:16-20) / shts.map2alm_spin (shts.py:26-30).  If fl != NULL the
  * result is multiplied by fl_l (hp.almxfl fused; filt_simple.py:400,405-406, qest.py:261-262). */
 int pl_map2alm(pl_plan *plan, int spin, const double *map, double *alm, const double *fl, int where, void *stream);

@@ -15,9 +15,9 @@
 namespace plshts {
 int rings_per_group(int spin, const DevPlan &P);
 void launch_prep0(const DevPlan &P, const double *alm, const double *fl, double *prep, hipStream_t st);
-void launch_preps(const DevPlan &P, const DevSpinTab &S, int spin, const double *alm, const double *fl, double *prep, hipStream_t st);
+void launch_preps(const DevPlan &P, const DevSpinTab &S, int spin, const double *alm, const double *fl, double *prep, hipStream_t st, bool gonly);
 void launch_synth0(const DevPlan &P, const double *prep, double *phase, hipStream_t st);
-void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st);
+void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st, bool gonly);
 void launch_anal0(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st);
 void launch_anals(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
                   const double *fl, double *alm, hipStream_t st);
@@ -341,7 +341,7 @@ int64_t pl_plan_phase_doubles(const pl_plan *p, int spin)
     return (int64_t)p->P.npairs * p->P.mstride * 4 * ncomp_of(spin);
 }
 
-int pl_legendre_synth(pl_plan *p, int spin, const double *alm, const double *fl, double *phase, void *stream)
+static int legendre_synth_impl(pl_plan *p, int spin, const double *alm, const double *fl, double *phase, void *stream, bool gonly)
 {
     if (!p) return fail("null plan");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -352,11 +352,16 @@ int pl_legendre_synth(pl_plan *p, int spin, const double *alm, const double *fl,
     } else {
         if (ensure_spin(p, spin)) return 1;
         if (grow(p, &p->prep, &p->prep_cap, p->nent[spin] * 4)) return 1;
-        launch_preps(p->P, p->S[spin], spin, alm, fl, p->prep, st);
-        { ProfScope ps(p, PK_LEG_SYNTHS, st); launch_synths(p->P, p->S[spin], spin, p->prep, phase, st); }
+        launch_preps(p->P, p->S[spin], spin, alm, fl, p->prep, st, gonly);
+        { ProfScope ps(p, PK_LEG_SYNTHS, st); launch_synths(p->P, p->S[spin], spin, p->prep, phase, st, gonly); }
     }
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+int pl_legendre_synth(pl_plan *p, int spin, const double *alm, const double *fl, double *phase, void *stream)
+{
+    return legendre_synth_impl(p, spin, alm, fl, phase, stream, false);
 }
 
 int pl_legendre_anal(pl_plan *p, int spin, const double *phase, double *alm, const double *fl, void *stream)
@@ -406,29 +411,40 @@ static int stage_fl(pl_plan *p, const double *fl, int where, hipStream_t st, con
     return 0;
 }
 
-int pl_alm2map(pl_plan *p, int spin, const double *alm, double *map, const double *fl, int where, void *stream)
+static int alm2map_impl(pl_plan *p, int spin, const double *alm, double *map, const double *fl, int where, void *stream, bool gonly)
 {
     if (!p) return fail("null plan");
     if (spin < 0 || spin > kMaxSpin) return fail("spin must be 0..3");
+    if (gonly && spin == 0) return fail("gradient-only synthesis is a spin >= 1 transform");
     if (!alm || !map) return fail("null alm / map pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int nc = ncomp_of(spin);
+    const int nc = ncomp_of(spin), nca = gonly ? 1 : nc;
     const double *alm_d = alm, *fl_d = nullptr;
     double *map_d = map;
     if (stage_fl(p, fl, where, st, &fl_d)) return 1;
     if (where == PL_HOST) {
         if (grow(p, &p->h_alm, &p->h_alm_cap, 2 * p->P.nalm * nc) || grow(p, &p->h_map, &p->h_map_cap, p->P.npix * nc)) return 1;
-        HIPCHK(hipMemcpyAsync(p->h_alm, alm, 2 * p->P.nalm * nc * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(p->h_alm, alm, 2 * p->P.nalm * nca * sizeof(double), hipMemcpyHostToDevice, st));
         alm_d = p->h_alm; map_d = p->h_map;
     }
     if (grow(p, &p->phase, &p->phase_cap, pl_plan_phase_doubles(p, spin))) return 1;
-    if (pl_legendre_synth(p, spin, alm_d, fl_d, p->phase, stream)) return 1;
+    if (legendre_synth_impl(p, spin, alm_d, fl_d, p->phase, stream, gonly)) return 1;
     if (pl_phase2map(p, spin, p->phase, map_d, stream)) return 1;
     if (where == PL_HOST) {
         HIPCHK(hipMemcpyAsync(map, map_d, p->P.npix * nc * sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
     return 0;
+}
+
+int pl_alm2map(pl_plan *p, int spin, const double *alm, double *map, const double *fl, int where, void *stream)
+{
+    return alm2map_impl(p, spin, alm, map, fl, where, stream, false);
+}
+
+int pl_alm2map_grad(pl_plan *p, int spin, const double *almG, double *map, const double *fl, int where, void *stream)
+{
+    return alm2map_impl(p, spin, almG, map, fl, where, stream, true);
 }
 
 int pl_map2alm(pl_plan *p, int spin, const double *map, double *alm, const double *fl, int where, void *stream)

@@ -106,7 +106,7 @@ __global__ void k_preps(DevPlan P, DevSpinTab S, int spin, const double2 *__rest
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nl; i += gridDim.x * blockDim.x) {
         const int l = l0 + i;
         const int64_t e = base + i;
-        double2 g = almG[abase + l], c = almC[abase + l];
+        const double2 g = almG[abase + l], c = almC ? almC[abase + l] : make_double2(0., 0.);
         double f = -0.5 * S.beta[e];
         if (fl) f *= fl[l];
         double4 o;
@@ -283,7 +283,9 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
 // -----------------------------------------------------------------------------------------------------
 // synthesis, spin s: phase entry = {Q_N re, im, Q_S re, im, U_N re, im, U_S re, im}
 // -----------------------------------------------------------------------------------------------------
-template <int R>
+// GONLY: the curl input is identically zero (gradient legs of the temperature estimators): An = sg Ap, so the four sums
+// are combinations of Sn Ap and Sp Ap split by the parity of l -- 4 accumulation FMAs per step instead of 8.
+template <int R, bool GONLY>
 __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int spin, const double4 *__restrict__ prep,
                                                     double *__restrict__ phase)
 {
@@ -344,16 +346,24 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
             for (int k = 0; k < R; ++k) {
                 double vn = r[k].n1, vp = r[k].p1;
                 if constexpr (decltype(masked)::value) { vn *= mn[k]; vp *= mp[k]; }
-                xn_r[k] = fma(vn, a0.x, xn_r[k]); xn_i[k] = fma(vn, a0.y, xn_i[k]);
-                yn_r[k] = fma(vp, a0.z, yn_r[k]); yn_i[k] = fma(vp, a0.w, yn_i[k]);
-                xe_r[k] = fma(vp, a0.x, xe_r[k]); xe_i[k] = fma(vp, a0.y, xe_i[k]);
+                if constexpr (GONLY) {  // xe / xo hold sum Sp Ap, ye / yo sum Sn Ap (even / odd l)
+                    xe_r[k] = fma(vp, a0.z, xe_r[k]); xe_i[k] = fma(vp, a0.w, xe_i[k]);
+                } else {
+                    xn_r[k] = fma(vn, a0.x, xn_r[k]); xn_i[k] = fma(vn, a0.y, xn_i[k]);
+                    yn_r[k] = fma(vp, a0.z, yn_r[k]); yn_i[k] = fma(vp, a0.w, yn_i[k]);
+                    xe_r[k] = fma(vp, a0.x, xe_r[k]); xe_i[k] = fma(vp, a0.y, xe_i[k]);
+                }
                 ye_r[k] = fma(vn, a0.z, ye_r[k]); ye_i[k] = fma(vn, a0.w, ye_i[k]);
                 recs_step_fast(r[k], ca0, cb0);
                 vn = r[k].n1; vp = r[k].p1;
                 if constexpr (decltype(masked)::value) { vn *= mn[k]; vp *= mp[k]; }
-                xn_r[k] = fma(vn, a1.x, xn_r[k]); xn_i[k] = fma(vn, a1.y, xn_i[k]);
-                yn_r[k] = fma(vp, a1.z, yn_r[k]); yn_i[k] = fma(vp, a1.w, yn_i[k]);
-                xo_r[k] = fma(vp, a1.x, xo_r[k]); xo_i[k] = fma(vp, a1.y, xo_i[k]);
+                if constexpr (GONLY) {
+                    xo_r[k] = fma(vp, a1.z, xo_r[k]); xo_i[k] = fma(vp, a1.w, xo_i[k]);
+                } else {
+                    xn_r[k] = fma(vn, a1.x, xn_r[k]); xn_i[k] = fma(vn, a1.y, xn_i[k]);
+                    yn_r[k] = fma(vp, a1.z, yn_r[k]); yn_i[k] = fma(vp, a1.w, yn_i[k]);
+                    xo_r[k] = fma(vp, a1.x, xo_r[k]); xo_i[k] = fma(vp, a1.y, xo_i[k]);
+                }
                 yo_r[k] = fma(vn, a1.z, yo_r[k]); yo_i[k] = fma(vn, a1.w, yo_i[k]);
                 recs_step_fast(r[k], ca1, cb1);
             }
@@ -433,13 +443,16 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const double vn = recs_value_n(r[k]), vp = recs_value_p(r[k]);
-                xn_r[k] = fma(vn, a.x, xn_r[k]); xn_i[k] = fma(vn, a.y, xn_i[k]);
-                yn_r[k] = fma(vp, a.z, yn_r[k]); yn_i[k] = fma(vp, a.w, yn_i[k]);
+                const double px = GONLY ? a.z : a.x, py = GONLY ? a.w : a.y;  // what Sp multiplies in the parity sums
+                if constexpr (!GONLY) {
+                    xn_r[k] = fma(vn, a.x, xn_r[k]); xn_i[k] = fma(vn, a.y, xn_i[k]);
+                    yn_r[k] = fma(vp, a.z, yn_r[k]); yn_i[k] = fma(vp, a.w, yn_i[k]);
+                }
                 if (!odd) {
-                    xe_r[k] = fma(vp, a.x, xe_r[k]); xe_i[k] = fma(vp, a.y, xe_i[k]);
+                    xe_r[k] = fma(vp, px, xe_r[k]); xe_i[k] = fma(vp, py, xe_i[k]);
                     ye_r[k] = fma(vn, a.z, ye_r[k]); ye_i[k] = fma(vn, a.w, ye_i[k]);
                 } else {
-                    xo_r[k] = fma(vp, a.x, xo_r[k]); xo_i[k] = fma(vp, a.y, xo_i[k]);
+                    xo_r[k] = fma(vp, px, xo_r[k]); xo_i[k] = fma(vp, py, xo_i[k]);
                     yo_r[k] = fma(vn, a.z, yo_r[k]); yo_i[k] = fma(vn, a.w, yo_i[k]);
                 }
                 recs_step_careful(r[k], c_ab.x, c_ab.y);
@@ -451,6 +464,12 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
     for (int k = 0; k < R; ++k) {
         const int rl = k * 64 + lane;
         double *t = tile + rl * 32 + wave * 8;
+        if constexpr (GONLY) {  // An = sg Ap: X_N = sg sum Sn Ap, Y_N = sum Sp Ap, X_S = sg sum sigma Sp Ap, Y_S = sum sigma Sn Ap
+            const double sg = (spin & 1) ? -1.0 : 1.0;
+            xn_r[k] = sg * (ye_r[k] + yo_r[k]); xn_i[k] = sg * (ye_i[k] + yo_i[k]);
+            yn_r[k] = xe_r[k] + xo_r[k]; yn_i[k] = xe_i[k] + xo_i[k];
+            xe_r[k] *= sg; xe_i[k] *= sg; xo_r[k] *= sg; xo_i[k] *= sg;
+        }
         const double xs_r = sig0 * (xe_r[k] - xo_r[k]), xs_i = sig0 * (xe_i[k] - xo_i[k]);
         const double ys_r = sig0 * (ye_r[k] - yo_r[k]), ys_i = sig0 * (ye_i[k] - yo_i[k]);
         t[0] = xn_r[k] + yn_r[k]; t[1] = xn_i[k] + yn_i[k];
@@ -1051,11 +1070,11 @@ void launch_prep0(const DevPlan &P, const double *alm, const double *fl, double 
                        reinterpret_cast<double4 *>(prep));
 }
 
-void launch_preps(const DevPlan &P, const DevSpinTab &S, int spin, const double *alm, const double *fl, double *prep, hipStream_t st)
+void launch_preps(const DevPlan &P, const DevSpinTab &S, int spin, const double *alm, const double *fl, double *prep, hipStream_t st, bool gonly)
 {
     dim3 grid(4, P.mmax + 1);
     hipLaunchKernelGGL(k_preps, grid, dim3(256), 0, st, P, S, spin, reinterpret_cast<const double2 *>(alm),
-                       reinterpret_cast<const double2 *>(alm) + P.nalm, fl, reinterpret_cast<double4 *>(prep));
+                       gonly ? nullptr : reinterpret_cast<const double2 *>(alm) + P.nalm, fl, reinterpret_cast<double4 *>(prep));
 }
 
 template <int R>
@@ -1078,22 +1097,32 @@ void launch_synth0(const DevPlan &P, const double *prep, double *phase, hipStrea
     }
 }
 
-template <int R>
+template <int R, bool GONLY>
 static void launch_synths_r(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st)
 {
     constexpr int RG = 64 * R;
     const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
-    hipLaunchKernelGGL(k_leg_synths<R>, dim3(ngroups * nmg), dim3(256), 0, st, P, S, spin,
+    hipLaunchKernelGGL((k_leg_synths<R, GONLY>), dim3(ngroups * nmg), dim3(256), 0, st, P, S, spin,
                        reinterpret_cast<const double4 *>(prep), phase);
 }
 
-void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st)
+void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st, bool gonly)
 {
-    switch (rs_synth(P)) {
-    case 1: launch_synths_r<1>(P, S, spin, prep, phase, st); break;
-    case 3: launch_synths_r<3>(P, S, spin, prep, phase, st); break;
-    case 4: launch_synths_r<4>(P, S, spin, prep, phase, st); break;
-    default: launch_synths_r<2>(P, S, spin, prep, phase, st); break;
+    const int r = rs_synth(P);
+    if (gonly) {
+        switch (r) {
+        case 1: launch_synths_r<1, true>(P, S, spin, prep, phase, st); break;
+        case 3: launch_synths_r<3, true>(P, S, spin, prep, phase, st); break;
+        case 4: launch_synths_r<4, true>(P, S, spin, prep, phase, st); break;
+        default: launch_synths_r<2, true>(P, S, spin, prep, phase, st); break;
+        }
+        return;
+    }
+    switch (r) {
+    case 1: launch_synths_r<1, false>(P, S, spin, prep, phase, st); break;
+    case 3: launch_synths_r<3, false>(P, S, spin, prep, phase, st); break;
+    case 4: launch_synths_r<4, false>(P, S, spin, prep, phase, st); break;
+    default: launch_synths_r<2, false>(P, S, spin, prep, phase, st); break;
     }
 }
 

@@ -450,7 +450,7 @@ class lib_filt2map(object):
         assert xfilt is None, 'not implemented'
         mlik = self._alm('tmliklm', idx)
         lmax = self._lmax(mlik)
-        return shts.alm2map_spin([mlik, torch.zeros_like(mlik)], self.nside, 1, lmax, fl=_lens_weight(lmax))
+        return shts.alm2map_spin([mlik, None], self.nside, 1, lmax, fl=_lens_weight(lmax))  # no curl: gradient-only synthesis
 
     def get_tmap(self, idx, joint=False):
         return shts.alm2map(self._alm('tmliklm', idx), self.nside)
@@ -538,7 +538,7 @@ class lib_filt2map_sepTP(lib_filt2map):
         if mlik is None or (xfilt is not None and not bool(torch.any(mlik != 0))):
             return self._zeros()
         lmax = self._lmax(mlik)
-        return shts.alm2map_spin([mlik, torch.zeros_like(mlik)], self.nside, 1, lmax, fl=_lens_weight(lmax))
+        return shts.alm2map_spin([mlik, None], self.nside, 1, lmax, fl=_lens_weight(lmax))  # no curl: gradient-only synthesis
 
     def get_gpmap(self, idx, spin, k=None, xfilt=None):
         """Spin-1 / spin-3 legs of (E^WF (+ C^TE Tb for k = 'p'), B^WF) (qest.py:597-638)."""

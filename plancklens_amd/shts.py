@@ -106,23 +106,25 @@ def _fl_arg(fl, lmax, dev):
     return f
 
 
-def _synth(spin, alm, nside, lmax, fl=None):
+def _synth(spin, alm, nside, lmax, fl=None, grad_only=False):
     """alm: (nalm,) or (2, nalm) complex128 -> map (npix,) or (2, npix) float64."""
     dev = _is_dev(alm)
     plan = get_plan(nside, lmax)
     ncomp = 1 if spin == 0 else 2
     f = _fl_arg(fl, lmax, dev)
     L = _lib.lib()
+    fn = L.pl_alm2map_grad if grad_only else L.pl_alm2map
+    nin = 1 if grad_only else ncomp
     if dev:
         a = alm.to(torch.complex128).contiguous()
-        assert a.numel() == ncomp * plan.nalm, (a.shape, plan.nalm)
+        assert a.numel() == nin * plan.nalm, (a.shape, plan.nalm)
         out = torch.empty((ncomp, plan.npix) if ncomp == 2 else (plan.npix,), dtype=torch.float64, device=a.device)
-        _lib.check(L.pl_alm2map(plan.h, spin, _ptr(a), _ptr(out), _ptr(f), _lib.PL_DEVICE, _stream()))
+        _lib.check(fn(plan.h, spin, _ptr(a), _ptr(out), _ptr(f), _lib.PL_DEVICE, _stream()))
         return out
     a = np.ascontiguousarray(alm, dtype=np.complex128)
-    assert a.size == ncomp * plan.nalm, (a.shape, plan.nalm)
+    assert a.size == nin * plan.nalm, (a.shape, plan.nalm)
     out = np.empty((ncomp, plan.npix) if ncomp == 2 else (plan.npix,), dtype=np.float64)
-    _lib.check(L.pl_alm2map(plan.h, spin, _ptr(a), _ptr(out), _ptr(f), _lib.PL_HOST, None))
+    _lib.check(fn(plan.h, spin, _ptr(a), _ptr(out), _ptr(f), _lib.PL_HOST, None))
     return out
 
 
@@ -200,7 +202,10 @@ def alm2map_spin(gclm, nside, spin, lmax, mmax=None, fl=None):
     assert spin > 0, spin
     assert len(gclm) == 2, len(gclm)
     assert mmax is None or mmax == lmax
-    out = _synth(int(spin), _stack(gclm), nside, lmax, fl=fl)
+    if gclm[1] is None:  # extension: no curl component (C = 0), e.g. the gradient legs of the temperature estimators
+        out = _synth(int(spin), gclm[0], nside, lmax, fl=fl, grad_only=True)
+    else:
+        out = _synth(int(spin), _stack(gclm), nside, lmax, fl=fl)
     return [out[0], out[1]]
 
 
