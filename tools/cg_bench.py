@@ -76,6 +76,29 @@ for kind in ('t', 'p'):
     res[kind] = {'iters': iters, 'seconds': dt, 'iters_per_s': iters / dt, 'first_call_incl_dense_setup_s': setup,
                  'eps_trace': [float(t[2]) for t in trace][:iters + 1]}
     print(kind, json.dumps(res[kind]), flush=True)
+if os.environ.get('CG_BENCH_JOINT', '0') == '1':
+    # joint T+P filter (cinv_tp, default 4-stage chain; the dense block is 12 675 coarse fwd_ops to build, cached afterwards)
+    pcf = os.path.join(tmp, 'dense_tp.pk')
+    chain_tp = [[3, ["split(dense(" + pcf + "), 64, diag_cl)"], 256, 128, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
+                [2, ["split(stage(3),  256, diag_cl)"], 512, 256, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
+                [1, ["split(stage(2),  512, diag_cl)"], 1024, 512, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
+                [0, ["split(stage(1), 1024, diag_cl)"], lmax, nside, iters, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()]]
+    t0 = time.time()
+    cl_tp = {k: cl[k] for k in ['tt', 'ee', 'bb', 'te']}
+    f = filt_cinv.cinv_tp(os.path.join(tmp, 'cinv_tp'), lmax, nside, cl_tp, transf, [ninv_t[0], ninv_p[0][0]], marge_monopole=True,
+                          marge_dipole=True, chain_descr=chain_tp)
+    f.chain.plogdepth = -1
+    dmaps = [dev.to_dev(tmap), dev.to_dev(q), dev.to_dev(u)]
+    f.apply_ivf(dmaps)
+    setup = time.time() - t0
+    torch.cuda.synchronize()
+    t0 = time.time()
+    f.apply_ivf(dmaps)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    res['tp_joint'] = {'iters': iters, 'seconds': dt, 'iters_per_s': iters / dt, 'first_call_incl_dense_setup_s': setup}
+    print('tp_joint', json.dumps(res['tp_joint']), flush=True)
 tp = iters / (res['t']['seconds'] + res['p']['seconds'])
 print(json.dumps({'metric': 'CG-iter/sec (cinv_t + cinv_p, nside=%d lmax=%d, masked fsky=%.2f)' % (nside, lmax, mask.mean()),
-                  'T_iters_per_s': res['t']['iters_per_s'], 'P_iters_per_s': res['p']['iters_per_s'], 'TP_iters_per_s': tp}))
+                  'T_iters_per_s': res['t']['iters_per_s'], 'P_iters_per_s': res['p']['iters_per_s'], 'TP_iters_per_s': tp,
+                  'TP_joint_iters_per_s': res.get('tp_joint', {}).get('iters_per_s')}))
