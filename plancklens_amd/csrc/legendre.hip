@@ -550,18 +550,21 @@ __device__ __forceinline__ double reduce16(double *v, int lane)
     reduce_step<1>(v, lane);
     return v[0];
 }
-// Same result as reduce16 through a wave-private LDS transpose: every lane stores its 16 values (row t, column lane; rows
-// padded to 66 doubles so that the 16 lanes of a row-group hit different banks), then lane 16 q + j adds the 16 entries of
-// row j that belong to lane row q.  15 v_add_f64 instead of ~105 VALU instructions of selects and DPP moves.
-constexpr int kRedStride = 66;
-constexpr int kRedDoubles = 16 * kRedStride;  // per wave
+// Same result as reduce16 through a wave-private LDS transpose: every lane stores its 16 values, then lane 16 q + j adds
+// the 16 entries of value j that belong to lane row q.  15 v_add_f64 instead of ~105 VALU instructions of selects and DPP
+// moves.  Layout (conflict-free for both the ds_write_b64 stores and the ds_read_b128 loads, checked with
+// SQ_LDS_BANK_CONFLICT): value t of lane L at row (t & 7) of 130 doubles, column 32 (L >> 4) + 16 (t >> 3) + (L & 15).
+constexpr int kRedStride = 130;
+constexpr int kRedDoubles = 8 * kRedStride;  // per wave
 __device__ __forceinline__ double reduce16_lds(const double *v, int lane, double *scratch)
 {
+    double *w = scratch + 32 * (lane >> 4) + (lane & 15);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) scratch[t * kRedStride + lane] = v[t];
+    for (int t = 0; t < 16; ++t) w[(t & 7) * kRedStride + 16 * (t >> 3)] = v[t];
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): own stores landed (wave-private region, no barrier needed)
     __builtin_amdgcn_wave_barrier();
-    const double2 *row = reinterpret_cast<const double2 *>(scratch + (lane & 15) * kRedStride + (lane >> 4) * 16);
+    const int j = lane & 15;
+    const double2 *row = reinterpret_cast<const double2 *>(scratch + (j & 7) * kRedStride + 32 * (lane >> 4) + 16 * (j >> 3));
     double2 s = row[0];
 #pragma unroll
     for (int k = 1; k < 8; ++k) { const double2 u = row[k]; s.x += u.x; s.y += u.y; }
