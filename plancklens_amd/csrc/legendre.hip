@@ -642,7 +642,8 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     const double v = r[k].p1;
-                    a0 = fma(v, er[k], a0); a1 = fma(v, ei[k], a1); a2 = fma(v, orr[k], a2); a3 = fma(v, oi[k], a3);
+                    if (k == 0) { a0 = v * er[0]; a1 = v * ei[0]; a2 = v * orr[0]; a3 = v * oi[0]; }
+                    else { a0 = fma(v, er[k], a0); a1 = fma(v, ei[k], a1); a2 = fma(v, orr[k], a2); a3 = fma(v, oi[k], a3); }
                     rec0_step_fast(r[k], cA, cB);
                 }
                 acc[t] = fold4(a0, a1, a2, a3);
@@ -660,7 +661,8 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     const double v = r[k].p1 * mk[k];
-                    a0 = fma(v, er[k], a0); a1 = fma(v, ei[k], a1); a2 = fma(v, orr[k], a2); a3 = fma(v, oi[k], a3);
+                    if (k == 0) { a0 = v * er[0]; a1 = v * ei[0]; a2 = v * orr[0]; a3 = v * oi[0]; }
+                    else { a0 = fma(v, er[k], a0); a1 = fma(v, ei[k], a1); a2 = fma(v, orr[k], a2); a3 = fma(v, oi[k], a3); }
                     rec0_step_fast(r[k], cA, cB);
                 }
                 acc[t] = fold4(a0, a1, a2, a3);
@@ -679,7 +681,8 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
                         const double v = rec0_value(r[k]);
-                        a0 = fma(v, er[k], a0); a1 = fma(v, ei[k], a1); a2 = fma(v, orr[k], a2); a3 = fma(v, oi[k], a3);
+                        if (k == 0) { a0 = v * er[0]; a1 = v * ei[0]; a2 = v * orr[0]; a3 = v * oi[0]; }
+                    else { a0 = fma(v, er[k], a0); a1 = fma(v, ei[k], a1); a2 = fma(v, orr[k], a2); a3 = fma(v, oi[k], a3); }
                         rec0_step_careful(r[k], cA, cB);
                     }
                 }
@@ -875,14 +878,13 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
     d8v_t SA0, SA1, SB0, SB1;
     double acc[16];  // one folded value per l of the tile (see fold4)
     // the 8 FMAs of one (l, ring): sigma_l = +1 for even t (after the swap above), -1 for odd t
+    // ring k = 0 starts the four sums with a multiply instead of an FMA onto zero (no zero-initialising moves)
     auto accum = [&](int t, int k, double vn, double vp, double &a0, double &a1, double &a2, double &a3) {
-        if ((t & 1) == 0) {
-            a0 = fma(vn, aer[k], a0); a1 = fma(vn, aei[k], a1); a2 = fma(vn, aor[k], a2); a3 = fma(vn, aoi[k], a3);
-            a0 = fma(vp, ber[k], a0); a1 = fma(vp, bei[k], a1); a2 = fma(-vp, bor[k], a2); a3 = fma(-vp, boi[k], a3);
-        } else {
-            a0 = fma(vn, aor[k], a0); a1 = fma(vn, aoi[k], a1); a2 = fma(vn, aer[k], a2); a3 = fma(vn, aei[k], a3);
-            a0 = fma(vp, bor[k], a0); a1 = fma(vp, boi[k], a1); a2 = fma(-vp, ber[k], a2); a3 = fma(-vp, bei[k], a3);
-        }
+        const double *pa0 = (t & 1) == 0 ? aer : aor, *pa1 = (t & 1) == 0 ? aei : aoi, *pa2 = (t & 1) == 0 ? aor : aer, *pa3 = (t & 1) == 0 ? aoi : aei;
+        const double *pb0 = (t & 1) == 0 ? ber : bor, *pb1 = (t & 1) == 0 ? bei : boi, *pb2 = (t & 1) == 0 ? bor : ber, *pb3 = (t & 1) == 0 ? boi : bei;
+        if (k == 0) { a0 = vn * pa0[0]; a1 = vn * pa1[0]; a2 = vn * pa2[0]; a3 = vn * pa3[0]; }
+        else { a0 = fma(vn, pa0[k], a0); a1 = fma(vn, pa1[k], a1); a2 = fma(vn, pa2[k], a2); a3 = fma(vn, pa3[k], a3); }
+        a0 = fma(vp, pb0[k], a0); a1 = fma(vp, pb1[k], a1); a2 = fma(-vp, pb2[k], a2); a3 = fma(-vp, pb3[k], a3);
     };
     auto half = [&](auto hc, const d8v_t &c0, const d8v_t &c1, int ib) {
         constexpr int h = decltype(hc)::value;
