@@ -24,8 +24,10 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 __device__ __forceinline__ bool wave_all(bool p) { return __all(p) != 0; }
 __device__ __forceinline__ bool wave_any(bool p) { return __any(p) != 0; }
 
-// Wave-uniform coefficient loads, written one trip ahead of their use.  hipcc is free to sink them to the first use;
-// an asm-pinned variant (PL_ASM_PREFETCH=1) keeps them in place but is unsafe under SGPR pressure (see below).
+// Wave-uniform coefficient loads.  The l loops keep two coefficient sets in flight (issued one set ahead of their use,
+// fenced with sched_barrier + an explicit lgkmcnt(0) wait).  An asm-pinned s_load variant of the same idea was removed:
+// the register allocator does not know that an asm output is written asynchronously and may copy it before the wait
+// (NaNs in the analysis kernels under SGPR pressure).
 typedef double d2v_t __attribute__((ext_vector_type(2)));
 typedef double d4v_t __attribute__((ext_vector_type(4)));
 typedef double d8v_t __attribute__((ext_vector_type(8)));
@@ -39,27 +41,6 @@ __device__ __forceinline__ T ldc(const void *p)
     return *(cptr_t)(unsigned long long)p;
 }
 __device__ __forceinline__ d8v_t ld8(const double2 *p) { return ldc<d8v_t>(p); }
-#ifndef PL_ASM_PREFETCH
-#define PL_ASM_PREFETCH 0
-#endif
-#if PL_ASM_PREFETCH
-// EXPERIMENTAL: the register allocator does not know that the destination is written asynchronously; under SGPR
-// pressure it may copy / spill the destination between issue and wait (observed in the analysis kernels: NaN).
-__device__ __forceinline__ void sload2_issue(d2v_t &dst, const void *p) { asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(dst) : "s"(p) : "memory"); }
-__device__ __forceinline__ void sload4_issue(d4v_t &dst, const void *p) { asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(dst) : "s"(p) : "memory"); }
-__device__ __forceinline__ void sload8_issue(d8v_t &dst, const void *p) { asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(dst) : "s"(p) : "memory"); }
-__device__ __forceinline__ void sload_wait(d2v_t &a, d2v_t &b, d4v_t &c, d4v_t &d) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d)::"memory"); }
-__device__ __forceinline__ void sload_wait(d8v_t &a, d8v_t &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory"); }
-__device__ __forceinline__ void sload_wait(d2v_t &a, d4v_t &c) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(c)::"memory"); }
-#else
-// compiler-managed wave-uniform loads (s_load + s_waitcnt placed by hipcc)
-__device__ __forceinline__ void sload2_issue(d2v_t &dst, const void *p) { dst = *reinterpret_cast<const d2v_t *>(p); }
-__device__ __forceinline__ void sload4_issue(d4v_t &dst, const void *p) { dst = *reinterpret_cast<const d4v_t *>(p); }
-__device__ __forceinline__ void sload8_issue(d8v_t &dst, const void *p) { dst = *reinterpret_cast<const d8v_t *>(p); }
-__device__ __forceinline__ void sload_wait(d2v_t &, d2v_t &, d4v_t &, d4v_t &) {}
-__device__ __forceinline__ void sload_wait(d8v_t &, d8v_t &) {}
-__device__ __forceinline__ void sload_wait(d2v_t &, d4v_t &) {}
-#endif
 
 // -----------------------------------------------------------------------------------------------------
 // alm -> recursion-basis coefficients (fused hp.almxfl)
