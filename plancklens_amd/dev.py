@@ -48,8 +48,6 @@ def lidx(lmax):
     key = (lmax, torch.cuda.current_device())
     if key not in _LIDX:
         ls = np.concatenate([np.arange(m, lmax + 1, dtype=np.int64) for m in range(lmax + 1)])
-        if len(_LIDX) > 8:
-            _LIDX.clear()
         _LIDX[key] = torch.from_numpy(ls).to(device())
     return _LIDX[key]
 
@@ -75,8 +73,10 @@ def fl_dev(fl, lmax):
     hit = _FL_CACHE.get(key)
     if hit is not None and hit[0].shape == a.shape and np.array_equal(hit[0], a):
         return hit[1]
-    if len(_FL_CACHE) > 256:
-        _FL_CACHE.clear()
+    # no eviction: a captured HIP graph (qcinv.multigrid) holds the raw pointers of the filters it was recorded with, and a
+    # filter is 8 (lmax + 1) bytes -- thousands of distinct ones are still only tens of MB
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError('l-filter upload requested while a HIP graph is being captured (filter not seen during warm-up)')
     t = torch.from_numpy(a).to(device())
     _FL_CACHE[key] = (a, t)
     return t

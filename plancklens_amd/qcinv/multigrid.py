@@ -7,6 +7,7 @@ All vectors handed between the stages stay on the device."""
 from __future__ import print_function
 
 import copy
+import gc
 import os
 import re
 import sys
@@ -192,8 +193,17 @@ class pre_op_multigrid(object):
                     d.copy_(p)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    out = self._calc_eager(_like(talm, st['in']))
+                # The cyclic garbage collector must not run while the stream is capturing: finalisers of unrelated garbage
+                # (pinned host buffers, plans, older graphs) make HIP calls that are illegal during capture and abort the
+                # process.  torch.cuda.graph collects once on entry; keep the collector off until the capture has ended.
+                gc_was_on = gc.isenabled()
+                gc.disable()
+                try:
+                    with torch.cuda.graph(g):
+                        out = self._calc_eager(_like(talm, st['in']))
+                finally:
+                    if gc_was_on:
+                        gc.enable()
                 st['out'], st['graph'] = _parts(out), g
             except Exception as e:  # capture is an optimisation: fall back to the eager path for good
                 print('pre_op_multigrid: graph capture failed (%s); staying eager' % str(e).split('\n')[0])

@@ -27,8 +27,6 @@ def _low_index_maps(lmax_a, lmax_b, lcut):
     if key not in _IDX:
         ia = np.concatenate([m * (2 * lmax_a + 1 - m) // 2 + np.arange(m, lcut + 1) for m in range(lcut + 1)])
         ib = np.concatenate([m * (2 * lmax_b + 1 - m) // 2 + np.arange(m, lcut + 1) for m in range(lcut + 1)])
-        if len(_IDX) > 64:
-            _IDX.clear()
         _IDX[key] = [ia, ib, {}]
     return _IDX[key]
 
