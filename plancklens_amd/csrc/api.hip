@@ -105,7 +105,9 @@ static int upload(pl_plan *p, const std::vector<T> &v, const T **out)
 static int grow(pl_plan *p, double **buf, int64_t *cap, int64_t ndoubles)
 {
     if (*cap >= ndoubles) return 0;
-    if (*buf) { HIPCHK(hipFree(*buf)); p->bytes -= *cap * 8; }
+    // An outgrown workspace is retired, not freed: a captured HIP graph (qcinv.multigrid) may still replay kernels that
+    // were recorded with its address.  Workspaces grow at most a few times (spin 0 -> spin s), so this stays small.
+    if (*buf) p->allocs.push_back(*buf);
     *buf = nullptr; *cap = 0;
     // + 64: the Legendre kernels fetch coefficients 8 entries at a time and may read (never use) past the last m
     HIPCHK(hipMalloc(reinterpret_cast<void **>(buf), (ndoubles + 64) * sizeof(double)));
