@@ -39,6 +39,11 @@ const char *pl_last_error(void);
 /* Number of visible HIP devices, or -1 (with pl_last_error set) if the runtime cannot be initialised. */
 int pl_device_count(void);
 
+/* A second execution context on the same tables: own workspaces and side streams, geometry / recursion / FFT tables
+ * shared with (and owned by) `plan`.  Transforms issued on different forks and different streams may run concurrently --
+ * the ring-FFT kernels of one hide under the FMA-bound Legendre kernels of another.  Destroy forks before their parent. */
+int pl_plan_fork(pl_plan *plan, pl_plan **fork);
+
 /* Plan: HEALPix ring geometry, recursion tables and FFT tables for one (nside, lmax, mmax = lmax).
  * Replaces what healpy / libsharp build internally per call (shts.py:13,18,23,28 build a geometry per call). */
 int pl_plan_create(int nside, int lmax, pl_plan **plan);
@@ -61,10 +66,12 @@ int pl_alm2map_grad(pl_plan *plan, int spin, const double *almG, double *map, co
  * result is multiplied by fl_l (hp.almxfl fused; filt_simple.py:400,405-406, qest.py:261-262). */
 int pl_map2alm(pl_plan *plan, int spin, const double *map, double *alm, const double *fl, int where, void *stream);
 
-/* Stage-level entry points (used by tests and by bench.py to time the dominant kernel in isolation).
+/* Stage-level entry points: tests, stage timings, and callers that pipeline independent transforms (the Legendre stage of
+ * one on the caller's stream while the ring FFTs of another run on a second stream and a fork of the plan).
  * phase buffer: [npairs][mstride][ncomp][4] doubles = (F_north re, im, F_south re, im). */
 int64_t pl_plan_phase_doubles(const pl_plan *plan, int spin);
 int pl_legendre_synth(pl_plan *plan, int spin, const double *alm_dev, const double *fl_dev, double *phase_dev, void *stream);
+int pl_legendre_synth_grad(pl_plan *plan, int spin, const double *almG_dev, const double *fl_dev, double *phase_dev, void *stream); /* see pl_alm2map_grad */
 int pl_legendre_anal(pl_plan *plan, int spin, const double *phase_dev, double *alm_dev, const double *fl_dev, void *stream);
 int pl_phase2map(pl_plan *plan, int spin, const double *phase_dev, double *map_dev, void *stream);
 int pl_map2phase(pl_plan *plan, int spin, const double *map_dev, double *phase_dev, void *stream);

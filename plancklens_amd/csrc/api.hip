@@ -56,6 +56,7 @@ struct pl_plan {
     bool have_spin[kMaxSpin + 1] = {false, false, false, false};
     int64_t nent[kMaxSpin + 1] = {0, 0, 0, 0};
     std::vector<void *> allocs;
+    pl_plan *parent = nullptr;  // forked plan: geometry / recursion / FFT tables belong to (and are freed by) the parent
     int64_t bytes = 0;
     // workspaces (grown on demand)
     double *phase = nullptr; int64_t phase_cap = 0;
@@ -120,6 +121,13 @@ static int ensure_spin(pl_plan *p, int spin)
 {
     if (spin < 1 || spin > kMaxSpin) return fail("spin must be 1, 2 or 3");
     if (p->have_spin[spin]) return 0;
+    if (p->parent) {  // tables live in the parent
+        if (ensure_spin(p->parent, spin)) return 1;
+        p->S[spin] = p->parent->S[spin];
+        p->nent[spin] = p->parent->nent[spin];
+        p->have_spin[spin] = true;
+        return 0;
+    }
     SpinTables t;
     build_spin_tables(spin, p->P.lmax, p->P.mmax, t);
     DevSpinTab &S = p->S[spin];
@@ -296,6 +304,23 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
     return 0;
 }
 
+int pl_plan_fork(pl_plan *parent, pl_plan **out)
+{
+    if (!parent || !out) return fail("null plan pointer");
+    *out = nullptr;
+    if (parent->parent) return fail("fork the original plan, not a fork");
+    pl_plan *p = new pl_plan();
+    p->device = parent->device;
+    p->P = parent->P;
+    p->F = parent->F;
+    p->parent = parent;
+    p->nent[0] = parent->nent[0];
+    hipError_t e = fft_streams_create(p->fs);
+    if (e != hipSuccess) { delete p; return fail(std::string("fork: ") + hipGetErrorString(e)); }
+    *out = p;
+    return 0;
+}
+
 int pl_plan_destroy(pl_plan *p)
 {
     if (!p) return 0;
@@ -364,6 +389,12 @@ static int legendre_synth_impl(pl_plan *p, int spin, const double *alm, const do
 int pl_legendre_synth(pl_plan *p, int spin, const double *alm, const double *fl, double *phase, void *stream)
 {
     return legendre_synth_impl(p, spin, alm, fl, phase, stream, false);
+}
+
+int pl_legendre_synth_grad(pl_plan *p, int spin, const double *almG, const double *fl, double *phase, void *stream)
+{
+    if (spin == 0) return fail("gradient-only synthesis is a spin >= 1 transform");
+    return legendre_synth_impl(p, spin, almG, fl, phase, stream, true);
 }
 
 int pl_legendre_anal(pl_plan *p, int spin, const double *phase, double *alm, const double *fl, void *stream)

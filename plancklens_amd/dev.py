@@ -37,6 +37,8 @@ def to_host(t):
         return np.asarray(t)
     if not t.is_cuda:
         return t.detach().numpy()
+    from . import shts
+    shts.join_lanes()  # results of transforms still running on side lanes
     h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     h.copy_(t.detach(), non_blocking=True)
     torch.cuda.current_stream().synchronize()

@@ -304,11 +304,22 @@ class library(object):
         device and analysed once (one spin-1 transform less, results equal to rounding)."""
         assert k == 'p'
         f2map1, f2map2 = self._legs(swapped)
-        tmap = f2map1.get_irestmap(idx)
-        gt, ct = f2map2.get_gtmap(idx, k='p')
-        rep, imp = f2map1.get_irespmap(idx)
-        g3, c3 = f2map2.get_gpmap(idx, 3, k='p')
-        g1, c1 = f2map2.get_gpmap(idx, 1, k='p')
+        # The five leg syntheses are independent: inside a lane the FFT stage of a synthesis runs on a side stream (own plan
+        # fork and phase buffer) while the current stream goes on with the Legendre stage of the next one; joined before
+        # the pixel product.
+        lanes = os.environ.get('PLENS_LANES', '0') == '1'  # measured +-2 % at nside 2048 (see DESIGN.md 4.2): off by default
+        ln = (lambda i: shts.lane(i if lanes else 0))
+        with ln(1):
+            tmap = f2map1.get_irestmap(idx)
+        with ln(2):
+            gt, ct = f2map2.get_gtmap(idx, k='p')
+        with ln(3):
+            rep, imp = f2map1.get_irespmap(idx)
+        with ln(4):
+            g3, c3 = f2map2.get_gpmap(idx, 3, k='p')
+        with ln(5):
+            g1, c1 = f2map2.get_gpmap(idx, 1, k='p')
+        shts.join_lanes()
         dre, dim = dev.qe_lens_product((tmap, gt, ct), (rep, imp, g3, c3, g1, c1))  # all nine leg maps in one pass
         del tmap, gt, ct, rep, imp, g3, c3, g1, c1
         G, C = self._gc_from_product(dre, dim, 'P')
@@ -444,6 +455,20 @@ class lib_filt2map(object):
     @staticmethod
     def _lmax(alm):
         return hp.Alm.getlmax(alm.numel())
+
+    def prefetch_filtered(self, idx):
+        """Makes the filtered T, E, B alms of simulation idx resident on the device, the T and P filters running on two
+        lanes; True when that was possible without host round trips (filter library with the device route and without a
+        file cache), i.e. when every later device operation may assume the alms complete on the current stream."""
+        get = getattr(self.ivfs, 'get_sim_alm_dev', None)
+        if get is None or getattr(self.ivfs, 'cache', True) or not hasattr(self.ivfs, '_apply_ivf_t'):
+            return False
+        with shts.lane(1):
+            get('tlm', idx)
+        with shts.lane(2):
+            get('elm', idx)
+        shts.join_lanes()
+        return True
 
     def get_gtmap(self, idx, k=None, xfilt=None):
         """alm2map_spin_1(-sqrt(l(l+1)) T^WF_lm, 0) (qest.py:453-464)."""

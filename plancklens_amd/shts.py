@@ -38,8 +38,27 @@ class Plan(object):
         self.npix = int(L.pl_plan_npix(h))
         self.nalm = int(L.pl_plan_nalm(h))
 
+    def fork(self, i):
+        """Execution context i on the same tables (own workspaces and side streams, pl_plan_fork): transforms issued on
+        different forks and streams may overlap.  Fork 0 is the plan itself."""
+        if i == 0:
+            return self
+        forks = self.__dict__.setdefault('_forks', {})
+        if i not in forks:
+            h = ctypes.c_void_p()
+            _lib.check(_lib.lib().pl_plan_fork(self.h, ctypes.byref(h)))
+            f = Plan.__new__(Plan)
+            f.h, f.nside, f.lmax, f.npix, f.nalm, f._parent = h, self.nside, self.lmax, self.npix, self.nalm, self
+            if getattr(self, '_profiling', False):
+                f.profile(True)
+            forks[i] = f
+        return forks[i]
+
     def __del__(self):
         try:
+            for f in list(self.__dict__.get('_forks', {}).values()):  # forks go before the tables they use
+                f.__del__()
+            self.__dict__.get('_forks', {}).clear()
             if getattr(self, 'h', None):
                 _lib.lib().pl_plan_destroy(self.h)
                 self.h = None
@@ -55,14 +74,21 @@ class Plan(object):
     PROFILE_KINDS = ('leg_synth0', 'leg_synths', 'leg_anal0', 'leg_anals', 'fft_synth', 'fft_anal')
 
     def profile(self, on=True):
+        self._profiling = bool(on)
         _lib.check(_lib.lib().pl_profile_enable(self.h, int(on)))
+        for f in self.__dict__.get('_forks', {}).values():
+            f.profile(on)
 
     def profile_read(self):
-        """{kind: (total ms, launches)} of the HIP-event timings recorded since the last read."""
+        """{kind: (total ms, launches)} of the HIP-event timings recorded since the last read (forks included)."""
         ms = (ctypes.c_double * 6)()
         cnt = (ctypes.c_int64 * 6)()
         _lib.check(_lib.lib().pl_profile_read(self.h, ms, cnt))
-        return {k: (ms[i], int(cnt[i])) for i, k in enumerate(self.PROFILE_KINDS)}
+        ret = {k: (ms[i], int(cnt[i])) for i, k in enumerate(self.PROFILE_KINDS)}
+        for f in self.__dict__.get('_forks', {}).values():
+            for k, (m_, c_) in f.profile_read().items():
+                ret[k] = (ret[k][0] + m_, ret[k][1] + c_)
+        return ret
 
 
 def get_plan(nside, lmax):
@@ -74,6 +100,69 @@ def get_plan(nside, lmax):
 
 def clear_plans():
     _PLANS.clear()
+
+
+# ---- lanes: the ring-FFT stage of independent transforms on side streams ------------------------------------------------
+_LANE = None
+_LANE_STREAMS = {}
+_LANE_PHASE = {}
+_LANE_USED = set()
+
+
+class lane(object):
+    """`with shts.lane(i):` -- device-tensor transforms issued inside are split into their two stages: the FMA-bound
+    Legendre stage stays on the current stream (so the Legendre kernels of successive transforms run back to back), the
+    latency-bound ring-FFT stage goes to side stream i with fork i of the plan and a phase buffer of its own.  The FFT
+    stage of one transform then overlaps with the Legendre stage of the next.  The maps returned by syntheses issued in
+    a lane are complete only after `shts.join_lanes()`.  Analyses are not split here (their FFT stage comes first: to
+    overlap it with another transform both FFT stages must be issued before either Legendre stage, see map2alm_many).
+    Lane 0 = no splitting."""
+
+    def __init__(self, i):
+        self.i = int(i)
+
+    def __enter__(self):
+        global _LANE
+        self.prev = _LANE
+        _LANE = self.i
+        return self
+
+    def __exit__(self, *exc):
+        global _LANE
+        _LANE = self.prev
+        return False
+
+
+def _lane_stream(i):
+    key = (i, torch.cuda.current_device())
+    if key not in _LANE_STREAMS:
+        _LANE_STREAMS[key] = torch.cuda.Stream()
+    return _LANE_STREAMS[key]
+
+
+def _lane_phase(plan, i, spin):
+    """phase buffer of lane i (kept for the life of the process: a lane is used for the same few transform shapes)"""
+    n = plan.phase_doubles(spin)
+    key = (i, plan.nside, plan.lmax, torch.cuda.current_device())
+    buf = _LANE_PHASE.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(n, dtype=torch.float64, device='cuda')
+        _LANE_PHASE[key] = buf
+    return buf
+
+
+def _lane_active():
+    return _LANE is not None and _LANE != 0 and not torch.cuda.is_current_stream_capturing()
+
+
+def join_lanes():
+    """the current stream waits for the FFT stages still running on the side lanes"""
+    if not _LANE_USED:
+        return
+    main = torch.cuda.current_stream()
+    for i in sorted(_LANE_USED):
+        main.wait_stream(_lane_stream(i))
+    _LANE_USED.clear()
 
 
 def _is_dev(x):
@@ -119,6 +208,18 @@ def _synth(spin, alm, nside, lmax, fl=None, grad_only=False):
         a = alm.to(torch.complex128).contiguous()
         assert a.numel() == nin * plan.nalm, (a.shape, plan.nalm)
         out = torch.empty((ncomp, plan.npix) if ncomp == 2 else (plan.npix,), dtype=torch.float64, device=a.device)
+        if _lane_active():  # Legendre stage here, ring FFTs on the side lane
+            i, ls = _LANE, _lane_stream(_LANE)
+            ph = _lane_phase(plan, i, spin)
+            # the lane's previous FFT stage must have consumed the phase buffer before it is overwritten
+            torch.cuda.current_stream().wait_stream(ls)
+            leg = L.pl_legendre_synth_grad if grad_only else L.pl_legendre_synth
+            _lib.check(leg(plan.h, spin, _ptr(a), _ptr(f), _ptr(ph), _stream()))
+            ls.wait_stream(torch.cuda.current_stream())
+            out.record_stream(ls)
+            _lib.check(L.pl_phase2map(plan.fork(i).h, spin, _ptr(ph), _ptr(out), ctypes.c_void_p(ls.cuda_stream)))
+            _LANE_USED.add(i)
+            return out
         _lib.check(fn(plan.h, spin, _ptr(a), _ptr(out), _ptr(f), _lib.PL_DEVICE, _stream()))
         return out
     a = np.ascontiguousarray(alm, dtype=np.complex128)
