@@ -280,8 +280,11 @@ def main():
                                        'traffic = FETCH_SIZE + WRITE_SIZE bytes per launch from profiles/ (PMC passes of an earlier run of the same kernel; '
                                        'coefficient-table re-reads by the ring groups are served by L2 / Infinity Cache)'}
         per_kernel = {}
-        alg = {'leg_synth0': flops_scal, 'leg_synths': flops_spin, 'leg_anal0': flops_scal, 'leg_anals': flops_spin}
-        exe = {'leg_synth0': exec_scal, 'leg_synths': exec_spin, 'leg_anal0': exec_scal, 'leg_anals': exec_spin}
+        # gradient-only synthesis (curl alm = 0, shts.alm2map_spin([G, None])): 8 recurrence + 8 accumulation flop per step
+        alg = {'leg_synth0': flops_scal, 'leg_synths': flops_spin, 'leg_anal0': flops_scal, 'leg_anals': flops_spin,
+               'leg_synths_grad': flops_spin * 16. / 24.}
+        exe = {'leg_synth0': exec_scal, 'leg_synths': exec_spin, 'leg_anal0': exec_scal, 'leg_anals': exec_spin,
+               'leg_synths_grad': exec_spin * 16. / 24.}
         for k, (m_, c_) in prof.items():
             if c_ == 0:
                 continue

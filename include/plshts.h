@@ -79,9 +79,10 @@ int pl_map2phase(pl_plan *plan, int spin, const double *map_dev, double *phase_d
 /* Per-stage timing with HIP events recorded on the caller's stream around the dominant kernels (used by
  * bench.py for the roofline numbers).  Kinds: 0 Legendre synthesis spin 0, 1 Legendre synthesis spin s,
  * 2 Legendre analysis spin 0 (+ reduction), 3 Legendre analysis spin s (+ reduction), 4 ring FFT synthesis,
- * 5 ring FFT analysis.  pl_profile_read synchronises the recorded events, returns summed milliseconds and
+ * 5 ring FFT analysis, 6 gradient-only Legendre synthesis spin s (pl_legendre_synth_grad: 16 instead of 24 flop
+ * per recursion step, kept apart so that kind 1 prices full launches only).  pl_profile_read synchronises the recorded events, returns summed milliseconds and
  * launch counts per kind (arrays of PL_PROFILE_KINDS entries) and resets the record. */
-#define PL_PROFILE_KINDS 6
+#define PL_PROFILE_KINDS 7
 int pl_profile_enable(pl_plan *plan, int on);
 int pl_profile_read(pl_plan *plan, double *ms_sum, int64_t *counts);
 

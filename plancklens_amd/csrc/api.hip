@@ -71,7 +71,8 @@ struct pl_plan {
     std::vector<Ev> events;
 };
 
-enum { PK_LEG_SYNTH0 = 0, PK_LEG_SYNTHS, PK_LEG_ANAL0, PK_LEG_ANALS, PK_FFT_SYNTH, PK_FFT_ANAL, PK_NKINDS };
+enum { PK_LEG_SYNTH0 = 0, PK_LEG_SYNTHS, PK_LEG_ANAL0, PK_LEG_ANALS, PK_FFT_SYNTH, PK_FFT_ANAL, PK_LEG_SYNTHS_GRAD, PK_NKINDS };
+static_assert(PK_NKINDS == PL_PROFILE_KINDS, "include/plshts.h PL_PROFILE_KINDS out of date");
 
 struct ProfScope {
     pl_plan *p; hipStream_t st; hipEvent_t e0 = nullptr, e1 = nullptr; int kind;
@@ -380,7 +381,7 @@ static int legendre_synth_impl(pl_plan *p, int spin, const double *alm, const do
         if (ensure_spin(p, spin)) return 1;
         if (grow(p, &p->prep, &p->prep_cap, p->nent[spin] * 4)) return 1;
         launch_preps(p->P, p->S[spin], spin, alm, fl, p->prep, st, gonly);
-        { ProfScope ps(p, PK_LEG_SYNTHS, st); launch_synths(p->P, p->S[spin], spin, p->prep, phase, st, gonly); }
+        { ProfScope ps(p, gonly ? PK_LEG_SYNTHS_GRAD : PK_LEG_SYNTHS, st); launch_synths(p->P, p->S[spin], spin, p->prep, phase, st, gonly); }
     }
     HIPCHK(hipGetLastError());
     return 0;

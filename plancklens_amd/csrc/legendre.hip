@@ -42,6 +42,50 @@ __device__ __forceinline__ T ldc(const void *p)
 }
 __device__ __forceinline__ d8v_t ld8(const double2 *p) { return ldc<d8v_t>(p); }
 
+// L2 prefetch of the wave-uniform coefficient streams.  The scalar loads of the recursion loops are waited for with
+// lgkmcnt(0) one compute section (~50 FMA) after their issue; that hides an L2 hit but not an L2 miss (the tables do not
+// fit the 4 MB L2 of an XCD: every line is fetched from Infinity Cache / HBM once per XCD).  A vector load of one dword
+// per 64 B line, one line per lane, issued ~64 l ahead pulls the lines into L2.  Its result is only consumed (summed
+// into a dummy) when the next window is issued, 32 l later, so the vmcnt wait in front of that use never stalls.
+struct StreamPrefetch {
+    float pending = 0.f, acc = 0.f;
+    int next = 0;  // next stream position at which to issue
+    static constexpr int kSpan = 32, kAhead = 64;
+    // streams a (SA bytes per step) and b (SB bytes per step) of n steps each; SPAN steps starting at lwin
+    template <int SA, int SB, int SPAN>
+    __device__ __forceinline__ void issue(const void *pa, const void *pb, int lwin, int n, int lane)
+    {
+        constexpr int LA = SPAN * SA / 64, LB = SPAN * SB / 64;  // lines per window
+        static_assert(LA + LB <= 64 && (64 % SA == 0) && (64 % SB == 0), "window does not fit one wave");
+        const bool isb = lane >= LA;
+        const int li = lwin + (isb ? min(lane - LA, LB - 1) * (64 / SB) : lane * (64 / SA));
+        const char *p = isb ? static_cast<const char *>(pb) + (int64_t)min(li, n - 1) * SB
+                            : static_cast<const char *>(pa) + (int64_t)min(li, n - 1) * SA;
+        acc += pending;
+        pending = *reinterpret_cast<const volatile float *>(p);
+    }
+    template <int SA, int SB>
+    __device__ __forceinline__ void start(const void *pa, const void *pb, int i, int n, int lane)
+    {
+        next = i;
+        if (i < n) issue<SA, SB, kAhead>(pa, pb, i, n, lane);
+    }
+    // call once per loop trip with the current position i
+    template <int SA, int SB>
+    __device__ __forceinline__ void step(const void *pa, const void *pb, int i, int n, int lane)
+    {
+        if (i >= next) {
+            if (next + kAhead < n) issue<SA, SB, kSpan>(pa, pb, next + kAhead, n, lane);
+            next += kSpan;
+        }
+    }
+    __device__ __forceinline__ void drain()
+    {
+        acc += pending;
+        asm volatile("" : : "v"(acc));  // keeps the loads alive; nothing is stored
+    }
+};
+
 // -----------------------------------------------------------------------------------------------------
 // alm -> recursion-basis coefficients (fused hp.almxfl)
 // -----------------------------------------------------------------------------------------------------
@@ -146,6 +190,8 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
             for (int k = 0; k < R; ++k) live = live || (r[k].sc != kNeverActive);
             if (!wave_any(live)) il = nil;  // every ring of this wave is pruned for this m
         }
+        StreamPrefetch pf;
+        pf.start<32, 16>(cd, ab, il, nil, lane);
         // phase A: no lane of the wave has reached the IEEE range yet -- recursion only; the rescale check is deferred
         // to the end of each block of 8 il (see rec0_renorm_up)
         while (il + 8 <= nil) {
@@ -153,6 +199,7 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
 #pragma unroll
             for (int k = 0; k < R; ++k) act = act || (r[k].sc == 0);
             if (wave_any(act)) break;
+            pf.step<32, 16>(cd, ab, il, nil, lane);
             const d8v_t c0 = ld8(ab + il), c1 = ld8(ab + il + 4);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -174,6 +221,7 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
             double mk[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) mk[k] = r[k].sc == 0 ? 1.0 : 0.0;
+            pf.step<32, 16>(cd, ab, il, nil, lane);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const d8v_t c = ld8(ab + il + 4 * h);
@@ -211,6 +259,7 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
             d2v_t A0 = ldc<d2v_t>(abv + il), A1 = ldc<d2v_t>(abv + min(il + 1, nil - 1));
             d4v_t Ac0 = ldc<d4v_t>(cdv + il), Ac1 = ldc<d4v_t>(cdv + min(il + 1, nil - 1));
             while (il + 3 < nil) {
+                pf.step<32, 16>(cd, ab, il, nil, lane);
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 const d2v_t B0 = ldc<d2v_t>(abv + il + 2), B1 = ldc<d2v_t>(abv + il + 3);
                 const d4v_t Bc0 = ldc<d4v_t>(cdv + il + 2), Bc1 = ldc<d4v_t>(cdv + il + 3);
@@ -239,6 +288,7 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
                 rec0_step_careful(r[k], c_ab.x, c_ab.y);
             }
         }
+        pf.drain();
     }
     // F_north = C + x D, F_south = C - x D  -> LDS tile -> ring-major global phase array
 #pragma unroll
@@ -309,7 +359,11 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
         const int nl = P.lmax - l0 + 1;
         const int64_t base = S.off[m];
         const double2 *__restrict__ ab = reinterpret_cast<const double2 *>(S.ab) + base;
+#if defined(PL_EXP_SAMEALM)  // timing experiment only (wrong results): every wave reads the alm stream of m = 0
+        const double4 *__restrict__ aa = prep;
+#else
         const double4 *__restrict__ aa = prep + base;
+#endif
         const d2v_t *__restrict__ abv = reinterpret_cast<const d2v_t *>(ab);
         const d4v_t *__restrict__ aav = reinterpret_cast<const d4v_t *>(aa);
         int i = 0;
@@ -320,6 +374,8 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
             for (int k = 0; k < R; ++k) live = live || r[k].scn != kNeverActive || r[k].scp != kNeverActive;
             if (!wave_any(live)) i = nl;  // every ring of this wave is pruned for this m
         }
+        StreamPrefetch pf;
+        pf.start<32, 16>(aa, ab, i, nl, lane);
         double mn[R], mp[R];  // phase B: 0/1 masks of the (n, p) recursions of each ring
         // two consecutive l (even i, odd i); i stays even through phases A, B and C
         auto pair_step = [&](auto masked, double ca0, double cb0, double ca1, double cb1, const d4v_t &a0, const d4v_t &a1) {
@@ -355,6 +411,7 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
 #pragma unroll
             for (int k = 0; k < R; ++k) act = act || r[k].scn == 0 || r[k].scp == 0;
             if (wave_any(act)) break;
+            pf.step<32, 16>(aa, ab, i, nl, lane);
             const d8v_t c0 = ld8(ab + i), c1 = ld8(ab + i + 4);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -375,6 +432,7 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
             if (wave_all(done)) { all_done = true; break; }
 #pragma unroll
             for (int k = 0; k < R; ++k) { mn[k] = r[k].scn == 0 ? 1.0 : 0.0; mp[k] = r[k].scp == 0 ? 1.0 : 0.0; }
+            pf.step<32, 16>(aa, ab, i, nl, lane);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const d8v_t c = ld8(ab + i + 4 * h);
@@ -397,6 +455,7 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
             d2v_t A0 = ldc<d2v_t>(abv + i), A1 = ldc<d2v_t>(abv + i + 1);
             d4v_t Aa0 = ldc<d4v_t>(aav + i), Aa1 = ldc<d4v_t>(aav + i + 1);
             while (i + 3 < nl) {
+                pf.step<32, 16>(aa, ab, i, nl, lane);
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): set A has landed (it was issued one half trip ago) ...
                 const d2v_t B0 = ldc<d2v_t>(abv + i + 2), B1 = ldc<d2v_t>(abv + i + 3);  // ... so that B can be issued without A's uses waiting on it
                 const d4v_t Ba0 = ldc<d4v_t>(aav + i + 2), Ba1 = ldc<d4v_t>(aav + i + 3);
@@ -439,6 +498,7 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
                 recs_step_careful(r[k], c_ab.x, c_ab.y);
             }
         }
+        pf.drain();
     }
     // Q = X + Y, U = i (Y - X)
 #pragma unroll

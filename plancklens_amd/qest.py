@@ -584,7 +584,5 @@ class lib_filt2map_sepTP(lib_filt2map):
             G = G_t if G is None else G + G_t
         if G is None or (xfilt is not None and not (bool(torch.any(G != 0)) or (C is not None and bool(torch.any(C != 0))))):
             return self._zeros()
-        if C is None:
-            C = torch.zeros_like(G)
         lmax = self._lmax(G)
-        return shts.alm2map_spin([G, C], self.nside, spin, lmax, fl=_spin_weight(spin, lmax))
+        return shts.alm2map_spin([G, C], self.nside, spin, lmax, fl=_spin_weight(spin, lmax))  # C None: gradient-only synthesis

@@ -71,7 +71,7 @@ class Plan(object):
     def phase_doubles(self, spin):
         return int(_lib.lib().pl_plan_phase_doubles(self.h, int(spin)))
 
-    PROFILE_KINDS = ('leg_synth0', 'leg_synths', 'leg_anal0', 'leg_anals', 'fft_synth', 'fft_anal')
+    PROFILE_KINDS = ('leg_synth0', 'leg_synths', 'leg_anal0', 'leg_anals', 'fft_synth', 'fft_anal', 'leg_synths_grad')
 
     def profile(self, on=True):
         self._profiling = bool(on)
@@ -81,8 +81,8 @@ class Plan(object):
 
     def profile_read(self):
         """{kind: (total ms, launches)} of the HIP-event timings recorded since the last read (forks included)."""
-        ms = (ctypes.c_double * 6)()
-        cnt = (ctypes.c_int64 * 6)()
+        ms = (ctypes.c_double * len(self.PROFILE_KINDS))()
+        cnt = (ctypes.c_int64 * len(self.PROFILE_KINDS))()
         _lib.check(_lib.lib().pl_profile_read(self.h, ms, cnt))
         ret = {k: (ms[i], int(cnt[i])) for i, k in enumerate(self.PROFILE_KINDS)}
         for f in self.__dict__.get('_forks', {}).values():
