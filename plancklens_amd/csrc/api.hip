@@ -25,6 +25,10 @@ void launch_almxfl(int lmax, const double *in, const double *fl, int nfl, double
 void launch_alm_copy(int lmax_in, const double *in, int lmax_out, double *out, hipStream_t st);
 void launch_alm2cl(int lmax, const double *a, const double *b, double *cl, hipStream_t st);
 void launch_axpy(int64_t n, double a, const double *x, const double *y, double *out, hipStream_t st);
+void launch_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *out, double *scratch, hipStream_t st);
+void launch_axpy_dev(int64_t n, const double *num, const double *den, double sign, const double *x, double *y, hipStream_t st);
+void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st);
+void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st);
 void launch_map_mul(int64_t n, const double *a, const double *b, double *out, hipStream_t st);
 void launch_qe_lens_product(int64_t n, const double *tmap, const double *gt, const double *ct, const double *rep, const double *imp,
                             const double *g3, const double *c3, const double *g1, const double *c1, double *outr, double *outi, hipStream_t st);
@@ -530,6 +534,39 @@ int pl_alm_copy(int lmax_in, const double *in, int lmax_out, double *out, void *
 int pl_axpy(int64_t n, double a, const double *x, const double *y, double *out, void *stream)
 {
     launch_axpy(n, a, x, y, out, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *out_dev, double *scratch_dev, void *stream)
+{
+    if (lmax < 0 || !a || !b || !out_dev) return fail("pl_alm_dot: bad arguments");
+    launch_alm_dot(lmax, lmin < 0 ? 0 : lmin, a, b, accumulate, out_dev, scratch_dev, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_axpy_dev(int64_t n, const double *num_dev, const double *den_dev, double sign, const double *x, double *y, void *stream)
+{
+    if (n < 0 || !num_dev || !x || !y) return fail("pl_axpy_dev: bad arguments");
+    if (n == 0) return 0;
+    launch_axpy_dev(n, num_dev, den_dev, sign, x, y, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_alm_splice(int lmax_lo, const double *alm_lo, int lmax_hi, const double *alm_hi, int lsplit, double *out, void *stream)
+{
+    if (lsplit > lmax_lo || lsplit > lmax_hi || lmax_hi < 0) return fail("pl_alm_splice: lsplit exceeds a band-limit");
+    launch_alm_splice(lmax_lo, alm_lo, lmax_hi, alm_hi, lsplit, out, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, void *stream)
+{
+    if (lmax < 0 || !a || !b || !fl || !out) return fail("pl_almxfl_add: bad arguments");
+    launch_almxfl_add(lmax, a, b, fl, nfl, out, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -118,6 +118,107 @@ __global__ __launch_bounds__(256) void k_fma_peak(int iters, double xs, double y
     if (s == 12345.678) out[0] = s;
 }
 
+// ---- CG vector primitives (cd_solve.py:53-107): one launch each, scalars stay on the device -----------------------
+// dot = sum_{l >= lmin} sum_m w_m Re(a_lm conj(b_lm)), w_0 = 1, w_{m>0} = 2  (= sum_l (2l + 1) C_l^{ab}; opfilt_tt.py:43-51).
+// One workgroup walks the m-major array with a fixed thread stride and reduces in a fixed tree: deterministic.
+constexpr int kDotThreads = 1024;
+__device__ __forceinline__ double block_sum_1024(double s, double *red)
+{
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = kDotThreads / 2; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+        __syncthreads();
+    }
+    return red[0];
+}
+__device__ __forceinline__ double alm_dot_partial(int lmax, int lmin, const double2 *__restrict__ a, const double2 *__restrict__ b,
+                                                  int64_t first, int64_t stride, int64_t nalm)
+{
+    // (m, l) of entry `first` by bisection on the row starts m (2 lmax + 1 - m) / 2 + m, then advanced incrementally
+    int lo = 0, hi = lmax;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int64_t)mid * (2 * lmax + 1 - mid) / 2 + mid <= first) lo = mid; else hi = mid - 1;
+    }
+    int m = lo;
+    int64_t l = first - (int64_t)m * (2 * lmax + 1 - m) / 2;
+    double s = 0.0;
+    for (int64_t i = first; i < nalm; i += stride) {
+        if (l >= lmin) {
+            const double2 x = a[i], y = b[i];
+            const double p = x.x * y.x + x.y * y.y;
+            s += (m == 0) ? p : 2.0 * p;
+        }
+        l += stride;
+        while (l > lmax && m < lmax) { l -= lmax - m; m += 1; }  // row m has lmax - m + 1 entries and row m + 1 starts at l = m + 1
+    }
+    return s;
+}
+__global__ __launch_bounds__(kDotThreads) void k_alm_dot_small(int lmax, int lmin, const double2 *__restrict__ a, const double2 *__restrict__ b,
+                                                               int accumulate, double *__restrict__ out)
+{
+    __shared__ double red[kDotThreads];
+    const int64_t nalm = (int64_t)(lmax + 1) * (lmax + 2) / 2;
+    const double tot = block_sum_1024(alm_dot_partial(lmax, lmin, a, b, threadIdx.x, kDotThreads, nalm), red);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + tot : tot;
+}
+__global__ __launch_bounds__(kDotThreads) void k_alm_dot_part(int lmax, int lmin, const double2 *__restrict__ a, const double2 *__restrict__ b,
+                                                              double *__restrict__ part)
+{
+    __shared__ double red[kDotThreads];
+    const int64_t nalm = (int64_t)(lmax + 1) * (lmax + 2) / 2;
+    const double tot = block_sum_1024(alm_dot_partial(lmax, lmin, a, b, (int64_t)blockIdx.x * kDotThreads + threadIdx.x,
+                                                      (int64_t)gridDim.x * kDotThreads, nalm), red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(kDotThreads) void k_alm_dot_final(int nparts, const double *__restrict__ part, int accumulate, double *__restrict__ out)
+{
+    __shared__ double red[kDotThreads];
+    const double tot = block_sum_1024((int)threadIdx.x < nparts ? part[threadIdx.x] : 0.0, red);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + tot : tot;
+}
+
+// y += sign * num / den * x with the scalars read from device memory (den may be null: 1)
+__global__ void k_axpy_dev(int64_t n, const double *__restrict__ num, const double *__restrict__ den, double sign,
+                           const double *__restrict__ x, double *__restrict__ y)
+{
+    const double c = den ? sign * num[0] * (1.0 / den[0]) : sign * num[0];
+    const int64_t n2 = n >> 1;
+    const double2 *__restrict__ x2 = reinterpret_cast<const double2 *>(x);
+    double2 *__restrict__ y2 = reinterpret_cast<double2 *>(y);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+        const double2 u = x2[i];
+        double2 v = y2[i];
+        v.x = fma(c, u.x, v.x); v.y = fma(c, u.y, v.y);
+        y2[i] = v;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = fma(c, x[n - 1], y[n - 1]);
+}
+
+// out (band-limit lmax_hi) = alm_lo for l <= lsplit, alm_hi above (util_alm.py:8-24)
+__global__ void k_alm_splice(int lmax_lo, const double2 *__restrict__ lo, int lmax_hi, const double2 *__restrict__ hi, int lsplit,
+                             double2 *__restrict__ out)
+{
+    const int m = blockIdx.y;
+    const int64_t bh = (int64_t)m * (2 * lmax_hi + 1 - m) / 2;
+    const int64_t bl = (int64_t)m * (2 * lmax_lo + 1 - m) / 2;
+    for (int l = m + blockIdx.x * blockDim.x + threadIdx.x; l <= lmax_hi; l += gridDim.x * blockDim.x)
+        out[bh + l] = (l <= lsplit) ? lo[bl + l] : hi[bh + l];
+}
+
+// out = a + f_l b (fwd_op: N-part + S^-1 x, opfilt_tt.py:67-73); out may alias a
+__global__ void k_almxfl_add(int lmax, const double2 *a, const double2 *__restrict__ b, const double *__restrict__ fl, int nfl, double2 *out)
+{
+    const int m = blockIdx.y;
+    const int64_t base = (int64_t)m * (2 * lmax + 1 - m) / 2;
+    for (int l = m + blockIdx.x * blockDim.x + threadIdx.x; l <= lmax; l += gridDim.x * blockDim.x) {
+        const double f = l < nfl ? fl[l] : 0.0;
+        const double2 x = a[base + l], y = b[base + l];
+        out[base + l] = make_double2(fma(f, y.x, x.x), fma(f, y.y, x.y));
+    }
+}
+
 static inline int nblocks(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
 void launch_almxfl(int lmax, const double *in, const double *fl, int nfl, double *out, hipStream_t st)
@@ -129,6 +230,34 @@ void launch_alm_copy(int lmax_in, const double *in, int lmax_out, double *out, h
 {
     hipLaunchKernelGGL(k_alm_copy, dim3(4, lmax_out + 1), dim3(256), 0, st, lmax_in, reinterpret_cast<const double2 *>(in),
                        lmax_out, reinterpret_cast<double2 *>(out));
+}
+// dots of short arrays (the coarse CG levels) take one workgroup; long ones a partial pass into `scratch` (kDotParts doubles)
+void launch_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *out, double *scratch, hipStream_t st)
+{
+    const int64_t nalm = (int64_t)(lmax + 1) * (lmax + 2) / 2;
+    const double2 *a2 = reinterpret_cast<const double2 *>(a), *b2 = reinterpret_cast<const double2 *>(b);
+    if (nalm <= 64 * kDotThreads || !scratch) {
+        hipLaunchKernelGGL(k_alm_dot_small, dim3(1), dim3(kDotThreads), 0, st, lmax, lmin, a2, b2, accumulate, out);
+        return;
+    }
+    int64_t nb = (nalm + 8 * kDotThreads - 1) / (8 * kDotThreads);
+    if (nb > kDotThreads) nb = kDotThreads;
+    hipLaunchKernelGGL(k_alm_dot_part, dim3((int)nb), dim3(kDotThreads), 0, st, lmax, lmin, a2, b2, scratch);
+    hipLaunchKernelGGL(k_alm_dot_final, dim3(1), dim3(kDotThreads), 0, st, (int)nb, scratch, accumulate, out);
+}
+void launch_axpy_dev(int64_t n, const double *num, const double *den, double sign, const double *x, double *y, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_axpy_dev, dim3(nblocks((n + 1) / 2)), dim3(256), 0, st, n, num, den, sign, x, y);
+}
+void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_alm_splice, dim3(4, lmax_hi + 1), dim3(256), 0, st, lmax_lo, reinterpret_cast<const double2 *>(lo), lmax_hi,
+                       reinterpret_cast<const double2 *>(hi), lsplit, reinterpret_cast<double2 *>(out));
+}
+void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_almxfl_add, dim3(4, lmax + 1), dim3(256), 0, st, lmax, reinterpret_cast<const double2 *>(a),
+                       reinterpret_cast<const double2 *>(b), fl, nfl, reinterpret_cast<double2 *>(out));
 }
 void launch_alm2cl(int lmax, const double *a, const double *b, double *cl, hipStream_t st)
 {

@@ -103,6 +103,53 @@ def alm_copy(alm, lmax_out):
     return out
 
 
+def alm_splice(alm_lo, alm_hi, lsplit):
+    """alm_lo for l <= lsplit, alm_hi above; band-limit of alm_hi (pl_alm_splice)."""
+    lmax_lo, lmax_hi = Alm.getlmax(alm_lo.numel()), Alm.getlmax(alm_hi.numel())
+    assert lmax_lo >= lsplit and lmax_hi >= lsplit, (lmax_lo, lmax_hi, lsplit)
+    out = torch.empty_like(alm_hi)
+    _lib.check(_lib.lib().pl_alm_splice(lmax_lo, alm_lo.data_ptr(), lmax_hi, alm_hi.data_ptr(), int(lsplit), out.data_ptr(), stream_ptr()))
+    return out
+
+
+def almxfl_add(a, b, fl, out=None):
+    """a + f_l b in one pass (pl_almxfl_add); out may be a."""
+    lmax = Alm.getlmax(a.numel())
+    assert b.numel() == a.numel()
+    f = fl_dev(fl, lmax)
+    out = torch.empty_like(a) if out is None else out
+    _lib.check(_lib.lib().pl_almxfl_add(lmax, a.data_ptr(), b.data_ptr(), f.data_ptr(), lmax + 1, out.data_ptr(), stream_ptr()))
+    return out
+
+
+_DOT_SCRATCH = {}
+
+
+def alm_dot(pairs, lmin=0):
+    """sum over the (a, b) pairs of sum_{l >= lmin} (2l + 1) C_l^{ab} as a 0-dim device tensor: one deterministic launch
+    per pair (pl_alm_dot), nothing comes back to the host."""
+    d = torch.cuda.current_device()
+    if d not in _DOT_SCRATCH:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('dot scratch requested while a HIP graph is being captured')
+        _DOT_SCRATCH[d] = torch.empty(1024, dtype=torch.float64, device=device())
+    out = torch.empty((), dtype=torch.float64, device=device())
+    for i, (a, b) in enumerate(pairs):
+        assert a.numel() == b.numel() and a.dtype == torch.complex128 and b.dtype == torch.complex128
+        _lib.check(_lib.lib().pl_alm_dot(Alm.getlmax(a.numel()), int(lmin), a.data_ptr(), b.data_ptr(), int(i > 0), out.data_ptr(),
+                                        _DOT_SCRATCH[d].data_ptr(), stream_ptr()))
+    return out
+
+
+def axpy_dev(y, x, num, den=None, sign=1.0):
+    """y += sign * num / den * x in place; num, den: 0-dim float64 device tensors (pl_axpy_dev)."""
+    assert y.numel() == x.numel() and y.dtype == x.dtype and y.is_contiguous() and x.is_contiguous()
+    n = y.numel() * (2 if y.is_complex() else 1)
+    _lib.check(_lib.lib().pl_axpy_dev(n, num.data_ptr(), None if den is None else den.data_ptr(), float(sign), x.data_ptr(), y.data_ptr(),
+                                     stream_ptr()))
+    return y
+
+
 def alm2cl(a, b=None):
     lmax = Alm.getlmax(a.numel())
     out = torch.empty(lmax + 1, dtype=torch.float64, device=a.device)

@@ -94,6 +94,34 @@ def rlm2alm(rlm):
     return alm
 
 
+def _parts(v):
+    if hasattr(v, 'tlm'):
+        return [v.tlm, v.elm, v.blm]
+    if hasattr(v, 'elm'):
+        return [v.elm, v.blm]
+    return [v]
+
+
+def _flat_matrix(minv, lmax, nfields):
+    """P_out minv P_in: minv (acting on `nfields` stacked rlm vectors of band-limit lmax) re-indexed and re-scaled so
+    that it acts on the stacked interleaved (re, im) views of the alm arrays; rows and columns of Im a_l0 are zero."""
+    ra, rr, ia, ir = _rlm_maps(lmax)
+    nr, nf = (lmax + 1) ** 2, (lmax + 1) * (lmax + 2)
+    assert minv.shape[0] == nfields * nr, (minv.shape, nfields, nr)
+    f = np.zeros(nr, dtype=np.int64)
+    sin, sout = np.zeros(nr), np.zeros(nr)
+    w2 = np.full(ra.size, np.sqrt(2.)); w2[:lmax + 1] = 1.
+    f[rr], sin[rr], sout[rr] = 2 * ra, w2, 1. / w2
+    f[ir], sin[ir], sout[ir] = 2 * ia + 1, np.sqrt(2.), 1. / np.sqrt(2.)
+    d = minv.device
+    fa = torch.from_numpy(np.concatenate([f + k * nf for k in range(nfields)])).to(d)
+    si = torch.from_numpy(np.tile(sin, nfields)).to(d)
+    so = torch.from_numpy(np.tile(sout, nfields)).to(d)
+    amat = torch.zeros((nfields * nf, nfields * nf), dtype=torch.float64, device=d)
+    amat[fa.unsqueeze(1), fa.unsqueeze(0)] = so.unsqueeze(1) * minv * si.unsqueeze(0)
+    return amat
+
+
 class _pre_op_dense(object):
     """Shared machinery: brute-force matrix, eigen pseudo-inverse with `ntmpl` lowest modes left untouched, cache."""
 
@@ -154,7 +182,19 @@ class _pre_op_dense(object):
         return self.calc(talm)
 
     def calc(self, talm):
-        return self._to_alm(torch.mv(self.minv, self._to_rlm(talm)))
+        if isinstance(talm, np.ndarray):
+            return self._to_alm(torch.mv(self.minv, self._to_rlm(talm)))
+        # device vectors: alm -> rlm, the pseudo-inverse and rlm -> alm as ONE matrix acting on the interleaved (re, im)
+        # view of the alm arrays -- the preconditioner is applied dozens of times per top-level iteration at a
+        # resolution where a kernel costs less to run than to launch
+        parts = _parts(talm)
+        if getattr(self, '_amat', None) is None:
+            self._amat = _flat_matrix(self.minv, self.lmax, len(parts))
+        flat = [torch.view_as_real(p).reshape(-1) for p in parts]
+        out = torch.mv(self._amat, flat[0] if len(flat) == 1 else torch.cat(flat))
+        n = flat[0].numel()
+        res = [torch.view_as_complex(out[k * n:(k + 1) * n].view(-1, 2)) for k in range(len(parts))]
+        return res[0] if len(res) == 1 else (eblm(res) if len(res) == 2 else teblm(res))
 
 
 class pre_op_dense_tt(_pre_op_dense):

@@ -138,7 +138,8 @@ class pre_op_split(object):
     def calc(self, talm):
         self.iter += 1
         talm_low = self.pre_op_low(util_alm.alm_copy(talm, lmax=self.lsplit))
-        talm_hgh = self.pre_op_hgh(util_alm.alm_copy(talm, lmax=self.lmax))
+        # preconditioners do not modify their argument (cd_solve's contract): no copy when the band-limit already matches
+        talm_hgh = self.pre_op_hgh(talm if _lmax_of(talm) == self.lmax else util_alm.alm_copy(talm, lmax=self.lmax))
         return util_alm.alm_splice(talm_low, talm_hgh, self.lsplit)
 
 
@@ -223,10 +224,14 @@ class pre_op_multigrid(object):
     def _calc_eager(self, talm):
         monitor = cd_monitors.monitor_basic(self.opfilt.dot_op(), iter_max=self.iter_max, eps_min=self.eps_min, logger=self.logger,
                                             quiet=bool(self.quiet is not None and self.quiet()))
-        soltn = talm * 0.0
+        soltn = _like(talm, [torch.zeros_like(p) for p in _parts(talm)]) if all(isinstance(p, torch.Tensor) for p in _parts(talm)) else talm * 0.0
         cd_solve.cd_solve(soltn, util_alm.alm_copy(talm, lmax=self.lmax), self.fwd_op, self.pre_ops, self.opfilt.dot_op(),
                           monitor, tr=self.tr, cache=self.cache, x_is_zero=True)
         return util_alm.alm_splice(soltn, talm, self.lmax)
+
+
+def _lmax_of(v):
+    return v.lmax if hasattr(v, 'lmax') else util_alm.Alm.getlmax(util_alm._size(v))
 
 
 def _parts(v):

@@ -20,10 +20,13 @@ class dot_op(object):
     def dev(self, alm1, alm2):
         """the scalar product as a 0-dim device tensor (no host synchronisation)"""
         assert alm1.lmax == alm2.lmax
-        tcl = dev.alm2cl(alm1.elm, alm2.elm) + dev.alm2cl(alm1.blm, alm2.blm)
-        w = 2. * np.arange(alm1.lmax + 1) + 1.
-        w[:2] = 0.
-        return torch.dot(tcl, dev.fl_dev(w, alm1.lmax))
+        return dev.alm_dot([(alm1.elm, alm2.elm), (alm1.blm, alm2.blm)], lmin=2)
+
+    @staticmethod
+    def axpy(y, x, num, den, sign):
+        """y += sign num / den x in place (num, den: device scalars)"""
+        dev.axpy_dev(y.elm, x.elm, num, den, sign)
+        dev.axpy_dev(y.blm, x.blm, num, den, sign)
 
     def __call__(self, alm1, alm2):
         return float(self.dev(alm1, alm2))
@@ -42,19 +45,23 @@ class fwd_op(object):
         return self.calc(alm)
 
     def calc(self, alm):
-        nlm = alm * 1.0
-        self.n_inv_filt.apply_alm(nlm)
-        return nlm + self.s_inv_filt.calc(alm)
+        nlm = self.n_inv_filt.apply_alm_new(alm)
+        return _apply_2x2(self.s_inv_filt.slinv, alm, add_to=nlm)
 
 
-def _apply_2x2(tmat, alm):
-    """(E, B) <- per-l 2x2 matrix applied to (E, B); off-diagonal terms skipped when they vanish identically."""
-    relm, rblm = dev.almxfl(alm.elm, tmat[:, 0, 0]), dev.almxfl(alm.blm, tmat[:, 1, 1])
+def _apply_2x2(tmat, alm, add_to=None):
+    """(E, B) <- per-l 2x2 matrix applied to (E, B); off-diagonal terms skipped when they vanish identically.
+    add_to: an eblm the result is accumulated into in place (and which is returned)."""
+    if add_to is None:
+        relm, rblm = dev.almxfl(alm.elm, tmat[:, 0, 0]), dev.almxfl(alm.blm, tmat[:, 1, 1])
+    else:
+        relm = dev.almxfl_add(add_to.elm, alm.elm, tmat[:, 0, 0], out=add_to.elm)
+        rblm = dev.almxfl_add(add_to.blm, alm.blm, tmat[:, 1, 1], out=add_to.blm)
     if np.any(tmat[:, 0, 1]):
-        relm = relm + dev.almxfl(alm.blm, tmat[:, 0, 1])
+        dev.almxfl_add(relm, alm.blm, tmat[:, 0, 1], out=relm)
     if np.any(tmat[:, 1, 0]):
-        rblm = rblm + dev.almxfl(alm.elm, tmat[:, 1, 0])
-    return eblm([relm, rblm])
+        dev.almxfl_add(rblm, alm.elm, tmat[:, 1, 0], out=rblm)
+    return add_to if add_to is not None else eblm([relm, rblm])
 
 
 class pre_op_diag(object):
@@ -192,6 +199,12 @@ class alm_filter_ninv(object):
 
     def apply_alm(self, alm):
         """(E, B) <- B^t Y^t N^-1 Y B (E, B), in place."""
+        ret = self.apply_alm_new(alm)
+        alm.elm.copy_(ret.elm)
+        alm.blm.copy_(ret.blm)
+
+    def apply_alm_new(self, alm):
+        """B^t Y^t N^-1 Y B (E, B) as a new eblm (the input is left alone)."""
         self._load_ninv()
         lmax = alm.lmax
         same_b = self.b_transf_b is self.b_transf_e or np.array_equal(self.b_transf_e, self.b_transf_b)
@@ -207,8 +220,7 @@ class alm_filter_ninv(object):
             telm, tblm = map2alm_spin([qmap, umap], 2, lmax=lmax)
             telm = dev.almxfl(telm, self.b_transf_e * (npix / (4. * np.pi)))
             tblm = dev.almxfl(tblm, self.b_transf_b * (npix / (4. * np.pi)))
-        alm.elm.copy_(telm)
-        alm.blm.copy_(tblm)
+        return eblm([telm, tblm])
 
     def apply_map(self, amap):
         """(Q, U) <- N^-1 (Q, U) in place."""

@@ -52,11 +52,14 @@ class dot_op(object):
         assert alm1.lmaxt == alm2.lmaxt, (alm1.lmaxt, alm2.lmaxt)
         assert alm1.lmaxe == alm2.lmaxe, (alm1.lmaxe, alm2.lmaxe)
         assert alm1.lmaxb == alm2.lmaxb, (alm1.lmaxb, alm2.lmaxb)
-        ret = None
-        for a, b, lmax in ((alm1.tlm, alm2.tlm, alm1.lmaxt), (alm1.elm, alm2.elm, alm1.lmaxe), (alm1.blm, alm2.blm, alm1.lmaxb)):
-            t = torch.dot(dev.alm2cl(a, b), dev.fl_dev(2. * np.arange(lmax + 1) + 1., lmax))
-            ret = t if ret is None else ret + t
-        return ret
+        return dev.alm_dot([(alm1.tlm, alm2.tlm), (alm1.elm, alm2.elm), (alm1.blm, alm2.blm)])
+
+    @staticmethod
+    def axpy(y, x, num, den, sign):
+        """y += sign num / den x in place (num, den: device scalars)"""
+        dev.axpy_dev(y.tlm, x.tlm, num, den, sign)
+        dev.axpy_dev(y.elm, x.elm, num, den, sign)
+        dev.axpy_dev(y.blm, x.blm, num, den, sign)
 
     def __call__(self, alm1, alm2):
         return float(self.dev(alm1, alm2))
@@ -77,21 +80,27 @@ class fwd_op(object):
         return self.calc(alm)
 
     def calc(self, alm):
-        nlm = alm * 1.0
-        self.n_inv_filt.apply_alm(nlm)
-        return nlm + self.s_inv_filt.calc(alm)
+        nlm = self.n_inv_filt.apply_alm_new(alm)
+        return _apply_3x3(self.s_inv_filt.slinv, alm, self.s_inv_filt.te_only, add_to=nlm)
 
 
-def _apply_3x3(tmat, alm, te_only):
-    """(T, E, B) <- per-l 3x3 matrix applied to (T, E, B); B decouples when there is no TB / EB power (te_only)."""
-    rtlm = dev.almxfl(alm.tlm, tmat[:, 0, 0]) + dev.almxfl(alm.elm, tmat[:, 0, 1])
-    relm = dev.almxfl(alm.tlm, tmat[:, 1, 0]) + dev.almxfl(alm.elm, tmat[:, 1, 1])
-    rblm = dev.almxfl(alm.blm, tmat[:, 2, 2])
+def _apply_3x3(tmat, alm, te_only, add_to=None):
+    """(T, E, B) <- per-l 3x3 matrix applied to (T, E, B); B decouples when there is no TB / EB power (te_only).
+    add_to: a teblm the result is accumulated into in place (and which is returned)."""
+    if add_to is None:
+        rtlm, relm, rblm = dev.almxfl(alm.tlm, tmat[:, 0, 0]), dev.almxfl(alm.tlm, tmat[:, 1, 0]), dev.almxfl(alm.blm, tmat[:, 2, 2])
+    else:
+        rtlm = dev.almxfl_add(add_to.tlm, alm.tlm, tmat[:, 0, 0], out=add_to.tlm)
+        relm = dev.almxfl_add(add_to.elm, alm.tlm, tmat[:, 1, 0], out=add_to.elm)
+        rblm = dev.almxfl_add(add_to.blm, alm.blm, tmat[:, 2, 2], out=add_to.blm)
+    dev.almxfl_add(rtlm, alm.elm, tmat[:, 0, 1], out=rtlm)
+    dev.almxfl_add(relm, alm.elm, tmat[:, 1, 1], out=relm)
     if not te_only:
-        rtlm = rtlm + dev.almxfl(alm.blm, tmat[:, 0, 2])
-        relm = relm + dev.almxfl(alm.blm, tmat[:, 1, 2])
-        rblm = rblm + dev.almxfl(alm.tlm, tmat[:, 2, 0]) + dev.almxfl(alm.elm, tmat[:, 2, 1])
-    return teblm([rtlm, relm, rblm])
+        dev.almxfl_add(rtlm, alm.blm, tmat[:, 0, 2], out=rtlm)
+        dev.almxfl_add(relm, alm.blm, tmat[:, 1, 2], out=relm)
+        dev.almxfl_add(rblm, alm.tlm, tmat[:, 2, 0], out=rblm)
+        dev.almxfl_add(rblm, alm.elm, tmat[:, 2, 1], out=rblm)
+    return add_to if add_to is not None else teblm([rtlm, relm, rblm])
 
 
 class pre_op_diag(object):
@@ -226,18 +235,31 @@ class alm_filter_ninv(object):
 
     def apply_alm(self, alm):
         """alm <- B^t Y^t N^-1 Y B alm (in place)."""
+        ret = self.apply_alm_new(alm)
+        alm.tlm.copy_(ret.tlm)
+        alm.elm.copy_(ret.elm)
+        alm.blm.copy_(ret.blm)
+
+    def apply_alm_new(self, alm):
+        """B^t Y^t N^-1 Y B alm as a new teblm (the input is left alone); the beams are fused into the transforms."""
         lmax = alm.lmax
         assert alm.lmaxt == alm.lmaxe == alm.lmaxb == lmax
+        same_b = self.b_transf_b is self.b_transf_e or np.array_equal(self.b_transf_e, self.b_transf_b)
         tmap = alm2map(alm.tlm, self.nside, lmax=lmax, fl=self.b_transf_t)
-        elm, blm = dev.almxfl(alm.elm, self.b_transf_e), dev.almxfl(alm.blm, self.b_transf_b)
-        qmap, umap = alm2map_spin([elm, blm], self.nside, 2, lmax)
+        if same_b:
+            qmap, umap = alm2map_spin([alm.elm, alm.blm], self.nside, 2, lmax, fl=self.b_transf_e)
+        else:
+            qmap, umap = alm2map_spin([dev.almxfl(alm.elm, self.b_transf_e), dev.almxfl(alm.blm, self.b_transf_b)], self.nside, 2, lmax)
         maps = [tmap, qmap, umap]
         self.apply_map(maps)
         fac = self.npix / (4. * np.pi)
-        alm.tlm.copy_(map2alm(maps[0], lmax=lmax, iter=0, fl=self.b_transf_t * fac))
-        telm, tblm = map2alm_spin([maps[1], maps[2]], 2, lmax=lmax)
-        alm.elm.copy_(dev.almxfl(telm, self.b_transf_e * fac))
-        alm.blm.copy_(dev.almxfl(tblm, self.b_transf_b * fac))
+        ttlm = map2alm(maps[0], lmax=lmax, iter=0, fl=self.b_transf_t * fac)
+        if same_b:
+            telm, tblm = map2alm_spin([maps[1], maps[2]], 2, lmax=lmax, fl=self.b_transf_e * fac)
+        else:
+            telm, tblm = map2alm_spin([maps[1], maps[2]], 2, lmax=lmax)
+            telm, tblm = dev.almxfl(telm, self.b_transf_e * fac), dev.almxfl(tblm, self.b_transf_b * fac)
+        return teblm([ttlm, telm, tblm])
 
     def apply_map(self, amap):
         """(T, Q, U) <- N^-1 (T, Q, U) with the T templates projected out (in place)."""
@@ -264,6 +286,7 @@ class alm_filter_ninv(object):
                         t.apply_mode(row, i)
                         rows.append(row)
                 self._pmat = torch.stack(rows)
-                self._pinv_dev = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64)
-            coeffs = torch.mv(self._pinv_dev, torch.mv(self._pmat, tmap))
-            tmap -= self.n_inv[0] * torch.mv(self._pmat.t(), coeffs)
+                pinv = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64)
+                # N^-1 P (P^t N^-1 P)^-1 as one matrix: the projection is two mat-vecs, c = P^t t and t -= R^t c
+                self._rmat = torch.mm(pinv, self._pmat * self.n_inv[0].unsqueeze(0))
+            tmap.addmv_(self._rmat.t(), torch.mv(self._pmat, tmap), alpha=-1.0)

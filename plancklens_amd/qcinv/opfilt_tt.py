@@ -42,10 +42,13 @@ class dot_op(object):
 
     def dev(self, alm1, alm2):
         """the scalar product as a 0-dim device tensor (no host synchronisation)"""
-        lmax1 = hp.Alm.getlmax(alm1.numel())
-        assert lmax1 == hp.Alm.getlmax(alm2.numel())
-        w = dev.fl_dev(2. * np.arange(lmax1 + 1) + 1., lmax1)
-        return torch.dot(dev.alm2cl(alm1, alm2), w)
+        assert alm1.numel() == alm2.numel()
+        return dev.alm_dot([(alm1, alm2)])
+
+    @staticmethod
+    def axpy(y, x, num, den, sign):
+        """y += sign num / den x in place (num, den: device scalars): the vector updates of cd_solve in one launch"""
+        dev.axpy_dev(y, x, num, den, sign)
 
     def __call__(self, alm1, alm2):
         return float(self.dev(alm1, alm2))
@@ -65,10 +68,8 @@ class fwd_op(object):
         return self.calc(talm)
 
     def calc(self, talm):
-        alm = talm.clone()
-        self.n_inv_filt.apply_alm(alm)
-        alm += dev.almxfl(talm, self.cltt_inv)
-        return alm
+        alm = self.n_inv_filt.apply_alm_new(talm)
+        return dev.almxfl_add(alm, talm, self.cltt_inv, out=alm)
 
 
 class pre_op_diag(object):
@@ -160,10 +161,14 @@ class alm_filter_ninv(object):
 
     def apply_alm(self, alm):
         """alm <- B^t Y^t N^-1 Y B alm (in place)."""
+        alm.copy_(self.apply_alm_new(alm))
+
+    def apply_alm_new(self, alm):
+        """B^t Y^t N^-1 Y B alm as a new array (the input is left alone)."""
         lmax = hp.Alm.getlmax(alm.numel())
         tmap = alm2map(alm, self.nside, lmax=lmax, fl=self.b_transf)
         self.apply_map(tmap)
-        alm.copy_(map2alm(tmap, lmax=lmax, iter=0, fl=self.b_transf * (self.npix / (4. * np.pi))))
+        return map2alm(tmap, lmax=lmax, iter=0, fl=self.b_transf * (self.npix / (4. * np.pi)))
 
     def apply_map(self, tmap):
         """tmap <- N^-1 tmap with the templates projected out (in place)."""
@@ -179,6 +184,7 @@ class alm_filter_ninv(object):
                         t.apply_mode(row, i)
                         rows.append(row)
                 self._pmat = torch.stack(rows)
-                self._pinv_dev = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64)
-            coeffs = torch.mv(self._pinv_dev, torch.mv(self._pmat, tmap))
-            tmap -= self.n_inv * torch.mv(self._pmat.t(), coeffs)
+                pinv = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64)
+                # N^-1 P (P^t N^-1 P)^-1 as one matrix: the projection is two mat-vecs, c = P^t t and t -= R^t c
+                self._rmat = torch.mm(pinv, self._pmat * self.n_inv.unsqueeze(0))
+            tmap.addmv_(self._rmat.t(), torch.mv(self._pmat, tmap), alpha=-1.0)

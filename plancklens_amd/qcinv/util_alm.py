@@ -47,6 +47,9 @@ def alm_splice(alm_lo, alm_hi, lsplit):
         return alm_lo.alm_splice(alm_hi, lsplit)
     lmax_lo, lmax_hi = Alm.getlmax(_size(alm_lo)), Alm.getlmax(_size(alm_hi))
     assert lmax_lo >= lsplit and lmax_hi >= lsplit
+    if _is_dev(alm_hi) and _is_dev(alm_lo) and alm_hi.is_cuda and alm_hi.dtype == torch.complex128 and alm_lo.dtype == torch.complex128:
+        from .. import dev
+        return dev.alm_splice(alm_lo, alm_hi, lsplit)  # one kernel (pl_alm_splice)
     ilo, ihi = _maps_for(alm_hi, lmax_lo, lmax_hi, lsplit)
     ret = alm_hi.clone() if _is_dev(alm_hi) else np.copy(alm_hi)
     ret[ihi] = alm_lo[ilo]
@@ -61,6 +64,9 @@ def alm_copy(alm, lmax=None):
     assert lmax is None or lmax <= lmox
     if lmax is None or lmax == lmox:
         return alm.clone() if _is_dev(alm) else np.copy(alm)
+    if _is_dev(alm) and alm.is_cuda and alm.dtype == torch.complex128:
+        from .. import dev
+        return dev.alm_copy(alm, lmax)  # one kernel (pl_alm_copy)
     iin, iout = _maps_for(alm, lmox, lmax, lmax)
     if _is_dev(alm):
         ret = torch.zeros(Alm.getsize(lmax), dtype=alm.dtype, device=alm.device)
