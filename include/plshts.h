@@ -97,8 +97,9 @@ int pl_axpy(int64_t n, double a, const double *x, const double *y, double *out, 
 /* CG vector primitives with device-resident scalars: one launch each, no host synchronisation (they are what the
  * coarse multigrid levels consist of once their SHTs are small).
  * pl_alm_dot: out_dev[0] (+)= sum_{l >= lmin} sum_m w_m Re(a_lm conj(b_lm)), w_0 = 1, w_m = 2 -- the scalar product
- *   sum_l (2l + 1) C_l^{ab} of opfilt_tt.py:43-51 (lmin = 2: opfilt_pp.py:27-34); deterministic; scratch_dev holds
- *   >= 1024 doubles for long arrays (may be NULL: single-workgroup path).
+ *   sum_l (2l + 1) C_l^{ab} of opfilt_tt.py:43-51 (lmin = 2: opfilt_pp.py:27-34); bit-reproducible (partial sums are
+ *   added in index order by the workgroup that finishes last); scratch_dev: 1025 doubles, zero before the first call,
+ *   private to one stream at a time.
  * pl_axpy_dev: y += sign * num_dev[0] / den_dev[0] * x on n doubles (den_dev NULL: 1) -- the updates of
  *   cd_solve.py:75,86,102 with alpha = delta / dTAd formed on the device.
  * pl_alm_splice: out = alm_lo for l <= lsplit, alm_hi above, band-limit lmax_hi (util_alm.py:8-24).

@@ -540,7 +540,7 @@ int pl_axpy(int64_t n, double a, const double *x, const double *y, double *out, 
 
 int pl_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *out_dev, double *scratch_dev, void *stream)
 {
-    if (lmax < 0 || !a || !b || !out_dev) return fail("pl_alm_dot: bad arguments");
+    if (lmax < 0 || !a || !b || !out_dev || !scratch_dev) return fail("pl_alm_dot: bad arguments");
     launch_alm_dot(lmax, lmin < 0 ? 0 : lmin, a, b, accumulate, out_dev, scratch_dev, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return 0;

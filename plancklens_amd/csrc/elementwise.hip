@@ -155,28 +155,31 @@ __device__ __forceinline__ double alm_dot_partial(int lmax, int lmin, const doub
     }
     return s;
 }
-__global__ __launch_bounds__(kDotThreads) void k_alm_dot_small(int lmax, int lmin, const double2 *__restrict__ a, const double2 *__restrict__ b,
-                                                               int accumulate, double *__restrict__ out)
+// grid of workgroups -> per-group partial sums -> the group that finishes last adds them up in index order: one launch,
+// no host round trip, and bit-reproducible (the order of the final sum does not depend on which group is last).
+// scratch: kDotThreads partials followed by one counter word that is zero between launches.
+__global__ __launch_bounds__(kDotThreads) void k_alm_dot(int lmax, int lmin, const double2 *__restrict__ a, const double2 *__restrict__ b,
+                                                         int accumulate, double *__restrict__ out, double *__restrict__ scratch)
 {
     __shared__ double red[kDotThreads];
-    const int64_t nalm = (int64_t)(lmax + 1) * (lmax + 2) / 2;
-    const double tot = block_sum_1024(alm_dot_partial(lmax, lmin, a, b, threadIdx.x, kDotThreads, nalm), red);
-    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + tot : tot;
-}
-__global__ __launch_bounds__(kDotThreads) void k_alm_dot_part(int lmax, int lmin, const double2 *__restrict__ a, const double2 *__restrict__ b,
-                                                              double *__restrict__ part)
-{
-    __shared__ double red[kDotThreads];
+    __shared__ bool last;
     const int64_t nalm = (int64_t)(lmax + 1) * (lmax + 2) / 2;
     const double tot = block_sum_1024(alm_dot_partial(lmax, lmin, a, b, (int64_t)blockIdx.x * kDotThreads + threadIdx.x,
                                                       (int64_t)gridDim.x * kDotThreads, nalm), red);
-    if (threadIdx.x == 0) part[blockIdx.x] = tot;
-}
-__global__ __launch_bounds__(kDotThreads) void k_alm_dot_final(int nparts, const double *__restrict__ part, int accumulate, double *__restrict__ out)
-{
-    __shared__ double red[kDotThreads];
-    const double tot = block_sum_1024((int)threadIdx.x < nparts ? part[threadIdx.x] : 0.0, red);
-    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + tot : tot;
+    unsigned *counter = reinterpret_cast<unsigned *>(scratch + kDotThreads);
+    if (threadIdx.x == 0) {
+        scratch[blockIdx.x] = tot;
+        __threadfence();
+        last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const double all = block_sum_1024((unsigned)threadIdx.x < gridDim.x ? scratch[threadIdx.x] : 0.0, red);
+    if (threadIdx.x == 0) {
+        out[0] = accumulate ? out[0] + all : all;
+        *counter = 0u;
+    }
 }
 
 // y += sign * num / den * x with the scalars read from device memory (den may be null: 1)
@@ -231,19 +234,13 @@ void launch_alm_copy(int lmax_in, const double *in, int lmax_out, double *out, h
     hipLaunchKernelGGL(k_alm_copy, dim3(4, lmax_out + 1), dim3(256), 0, st, lmax_in, reinterpret_cast<const double2 *>(in),
                        lmax_out, reinterpret_cast<double2 *>(out));
 }
-// dots of short arrays (the coarse CG levels) take one workgroup; long ones a partial pass into `scratch` (kDotParts doubles)
 void launch_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *out, double *scratch, hipStream_t st)
 {
     const int64_t nalm = (int64_t)(lmax + 1) * (lmax + 2) / 2;
-    const double2 *a2 = reinterpret_cast<const double2 *>(a), *b2 = reinterpret_cast<const double2 *>(b);
-    if (nalm <= 64 * kDotThreads || !scratch) {
-        hipLaunchKernelGGL(k_alm_dot_small, dim3(1), dim3(kDotThreads), 0, st, lmax, lmin, a2, b2, accumulate, out);
-        return;
-    }
-    int64_t nb = (nalm + 8 * kDotThreads - 1) / (8 * kDotThreads);
-    if (nb > kDotThreads) nb = kDotThreads;
-    hipLaunchKernelGGL(k_alm_dot_part, dim3((int)nb), dim3(kDotThreads), 0, st, lmax, lmin, a2, b2, scratch);
-    hipLaunchKernelGGL(k_alm_dot_final, dim3(1), dim3(kDotThreads), 0, st, (int)nb, scratch, accumulate, out);
+    int64_t nb = (nalm + 4 * kDotThreads - 1) / (4 * kDotThreads);  // <= 4 entries per thread until the grid is 256 groups
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(k_alm_dot, dim3((int)nb), dim3(kDotThreads), 0, st, lmax, lmin, reinterpret_cast<const double2 *>(a),
+                       reinterpret_cast<const double2 *>(b), accumulate, out, scratch);
 }
 void launch_axpy_dev(int64_t n, const double *num, const double *den, double sign, const double *x, double *y, hipStream_t st)
 {

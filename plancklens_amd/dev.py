@@ -132,7 +132,7 @@ def alm_dot(pairs, lmin=0):
     if d not in _DOT_SCRATCH:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError('dot scratch requested while a HIP graph is being captured')
-        _DOT_SCRATCH[d] = torch.empty(1024, dtype=torch.float64, device=device())
+        _DOT_SCRATCH[d] = torch.zeros(1025, dtype=torch.float64, device=device())  # partials + the arrival counter
     out = torch.empty((), dtype=torch.float64, device=device())
     for i, (a, b) in enumerate(pairs):
         assert a.numel() == b.numel() and a.dtype == torch.complex128 and b.dtype == torch.complex128
