@@ -95,17 +95,17 @@ int pl_alm_copy(int lmax_in, const double *alm_in, int lmax_out, double *alm_out
 int pl_axpy(int64_t n, double a, const double *x, const double *y, double *out, void *stream);
 
 /* CG vector primitives with device-resident scalars: one launch each, no host synchronisation (they are what the
- * coarse multigrid levels consist of once their SHTs are small).
- * pl_alm_dot: out_dev[0] (+)= sum_{l >= lmin} sum_m w_m Re(a_lm conj(b_lm)), w_0 = 1, w_m = 2 -- the scalar product
- *   sum_l (2l + 1) C_l^{ab} of opfilt_tt.py:43-51 (lmin = 2: opfilt_pp.py:27-34); bit-reproducible (partial sums are
- *   added in index order by the workgroup that finishes last); scratch_dev: 1025 doubles, zero before the first call,
- *   private to one stream at a time.
- * pl_axpy_dev: y += sign * num_dev[0] / den_dev[0] * x on n doubles (den_dev NULL: 1) -- the updates of
- *   cd_solve.py:75,86,102 with alpha = delta / dTAd formed on the device.
+ * coarse multigrid levels consist of once their SHTs are small).  A scalar product lives in device memory as
+ * PL_DOT_PARTS partial sums (its value is their sum in index order): no second launch, no atomics, bit-reproducible.
+ * pl_alm_dot: parts_dev[0 .. PL_DOT_PARTS) (+)= partial sums of sum_{l >= lmin} sum_m w_m Re(a_lm conj(b_lm)), w_0 = 1,
+ *   w_m = 2 -- the scalar product sum_l (2l + 1) C_l^{ab} of opfilt_tt.py:43-51 (lmin = 2: opfilt_pp.py:27-34).
+ * pl_axpy_dev: y += sign * num / den * x on n doubles, num and den given as such partial sums (den NULL: 1) -- the
+ *   updates of cd_solve.py:75,86,102 with alpha = delta / dTAd formed on the device.
  * pl_alm_splice: out = alm_lo for l <= lsplit, alm_hi above, band-limit lmax_hi (util_alm.py:8-24).
  * pl_almxfl_add: out = a + f_l b (out may be a) -- N-part + S^-1 x of fwd_op (opfilt_tt.py:67-73). */
-int pl_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *out_dev, double *scratch_dev, void *stream);
-int pl_axpy_dev(int64_t n, const double *num_dev, const double *den_dev, double sign, const double *x, double *y, void *stream);
+#define PL_DOT_PARTS 64
+int pl_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *parts_dev, void *stream);
+int pl_axpy_dev(int64_t n, const double *num_parts_dev, const double *den_parts_dev, double sign, const double *x, double *y, void *stream);
 int pl_alm_splice(int lmax_lo, const double *alm_lo, int lmax_hi, const double *alm_hi, int lsplit, double *out, void *stream);
 int pl_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, void *stream);
 

@@ -56,7 +56,7 @@ def lib():
     L.pl_alm2cl.argtypes = [i32, vp, vp, vp, vp]
     L.pl_alm_copy.argtypes = [i32, vp, i32, vp, vp]
     L.pl_axpy.argtypes = [i64, dbl, vp, vp, vp, vp]
-    L.pl_alm_dot.argtypes = [i32, i32, vp, vp, i32, vp, vp, vp]
+    L.pl_alm_dot.argtypes = [i32, i32, vp, vp, i32, vp, vp]
     L.pl_axpy_dev.argtypes = [i64, vp, vp, dbl, vp, vp, vp]
     L.pl_alm_splice.argtypes = [i32, vp, i32, vp, i32, vp, vp]
     L.pl_almxfl_add.argtypes = [i32, vp, vp, vp, i32, vp, vp]

@@ -25,7 +25,7 @@ void launch_almxfl(int lmax, const double *in, const double *fl, int nfl, double
 void launch_alm_copy(int lmax_in, const double *in, int lmax_out, double *out, hipStream_t st);
 void launch_alm2cl(int lmax, const double *a, const double *b, double *cl, hipStream_t st);
 void launch_axpy(int64_t n, double a, const double *x, const double *y, double *out, hipStream_t st);
-void launch_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *out, double *scratch, hipStream_t st);
+void launch_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *parts, hipStream_t st);
 void launch_axpy_dev(int64_t n, const double *num, const double *den, double sign, const double *x, double *y, hipStream_t st);
 void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st);
 void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st);
@@ -538,19 +538,19 @@ int pl_axpy(int64_t n, double a, const double *x, const double *y, double *out, 
     return 0;
 }
 
-int pl_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *out_dev, double *scratch_dev, void *stream)
+int pl_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *parts_dev, void *stream)
 {
-    if (lmax < 0 || !a || !b || !out_dev || !scratch_dev) return fail("pl_alm_dot: bad arguments");
-    launch_alm_dot(lmax, lmin < 0 ? 0 : lmin, a, b, accumulate, out_dev, scratch_dev, static_cast<hipStream_t>(stream));
+    if (lmax < 0 || !a || !b || !parts_dev) return fail("pl_alm_dot: bad arguments");
+    launch_alm_dot(lmax, lmin < 0 ? 0 : lmin, a, b, accumulate, parts_dev, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-int pl_axpy_dev(int64_t n, const double *num_dev, const double *den_dev, double sign, const double *x, double *y, void *stream)
+int pl_axpy_dev(int64_t n, const double *num_parts_dev, const double *den_parts_dev, double sign, const double *x, double *y, void *stream)
 {
-    if (n < 0 || !num_dev || !x || !y) return fail("pl_axpy_dev: bad arguments");
+    if (n < 0 || !num_parts_dev || !x || !y) return fail("pl_axpy_dev: bad arguments");
     if (n == 0) return 0;
-    launch_axpy_dev(n, num_dev, den_dev, sign, x, y, static_cast<hipStream_t>(stream));
+    launch_axpy_dev(n, num_parts_dev, den_parts_dev, sign, x, y, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -132,61 +132,63 @@ __device__ __forceinline__ double block_sum_1024(double s, double *red)
     }
     return red[0];
 }
+// weight of entry i of an m-major alm array: 1 on the m = 0 row (i <= lmax), 2 elsewhere, 0 for l < lmin.  Entries with
+// l < lmin have m < lmin, i.e. they sit in the first lmin rows: only there is the row searched (lmin is 0 or 2 in practice).
+__device__ __forceinline__ double alm_dot_weight(int lmax, int lmin, int64_t i)
+{
+    double w = i <= lmax ? 1.0 : 2.0;
+    if (lmin > 0 && i < (int64_t)lmin * (2 * lmax + 1 - lmin) / 2 + lmin) {
+        int m = 0;
+        while (m + 1 < lmin && (int64_t)(m + 1) * (2 * lmax + 1 - (m + 1)) / 2 + (m + 1) <= i) ++m;
+        if (i - (int64_t)m * (2 * lmax + 1 - m) / 2 < lmin) w = 0.0;
+    }
+    return w;
+}
 __device__ __forceinline__ double alm_dot_partial(int lmax, int lmin, const double2 *__restrict__ a, const double2 *__restrict__ b,
                                                   int64_t first, int64_t stride, int64_t nalm)
 {
-    // (m, l) of entry `first` by bisection on the row starts m (2 lmax + 1 - m) / 2 + m, then advanced incrementally
-    int lo = 0, hi = lmax;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if ((int64_t)mid * (2 * lmax + 1 - mid) / 2 + mid <= first) lo = mid; else hi = mid - 1;
-    }
-    int m = lo;
-    int64_t l = first - (int64_t)m * (2 * lmax + 1 - m) / 2;
     double s = 0.0;
-    for (int64_t i = first; i < nalm; i += stride) {
-        if (l >= lmin) {
-            const double2 x = a[i], y = b[i];
-            const double p = x.x * y.x + x.y * y.y;
-            s += (m == 0) ? p : 2.0 * p;
+    for (int64_t i = first; i < nalm; i += 4 * stride) {
+        double2 x[4], y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // four independent loads in flight per thread
+            const int64_t j = i + u * stride;
+            const bool ok = j < nalm;
+            x[u] = ok ? a[j] : make_double2(0., 0.);
+            y[u] = ok ? b[j] : make_double2(0., 0.);
         }
-        l += stride;
-        while (l > lmax && m < lmax) { l -= lmax - m; m += 1; }  // row m has lmax - m + 1 entries and row m + 1 starts at l = m + 1
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s = fma(alm_dot_weight(lmax, lmin, i + u * stride), x[u].x * y[u].x + x[u].y * y[u].y, s);
     }
     return s;
 }
-// grid of workgroups -> per-group partial sums -> the group that finishes last adds them up in index order: one launch,
-// no host round trip, and bit-reproducible (the order of the final sum does not depend on which group is last).
-// scratch: kDotThreads partials followed by one counter word that is zero between launches.
-__global__ __launch_bounds__(kDotThreads) void k_alm_dot(int lmax, int lmin, const double2 *__restrict__ a, const double2 *__restrict__ b,
-                                                         int accumulate, double *__restrict__ out, double *__restrict__ scratch)
+// The scalar product is left as kDotParts per-workgroup partial sums; whoever consumes it (k_axpy_dev, the host) adds
+// them in index order.  One launch, no atomics, no cross-XCD fence, bit-reproducible.
+constexpr int kDotParts = 64;
+__global__ __launch_bounds__(kDotThreads) void k_alm_dot_parts(int lmax, int lmin, const double2 *__restrict__ a, const double2 *__restrict__ b,
+                                                               int accumulate, double *__restrict__ parts)
 {
     __shared__ double red[kDotThreads];
-    __shared__ bool last;
     const int64_t nalm = (int64_t)(lmax + 1) * (lmax + 2) / 2;
     const double tot = block_sum_1024(alm_dot_partial(lmax, lmin, a, b, (int64_t)blockIdx.x * kDotThreads + threadIdx.x,
                                                       (int64_t)gridDim.x * kDotThreads, nalm), red);
-    unsigned *counter = reinterpret_cast<unsigned *>(scratch + kDotThreads);
-    if (threadIdx.x == 0) {
-        scratch[blockIdx.x] = tot;
-        __threadfence();
-        last = atomicAdd(counter, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    const double all = block_sum_1024((unsigned)threadIdx.x < gridDim.x ? scratch[threadIdx.x] : 0.0, red);
-    if (threadIdx.x == 0) {
-        out[0] = accumulate ? out[0] + all : all;
-        *counter = 0u;
-    }
+    if (threadIdx.x == 0) parts[blockIdx.x] = accumulate ? parts[blockIdx.x] + tot : tot;
 }
 
-// y += sign * num / den * x with the scalars read from device memory (den may be null: 1)
+__device__ __forceinline__ double dot_parts_sum(const double *__restrict__ parts)
+{
+    double s = 0.0;
+    for (int i = 0; i < kDotParts; ++i) s += parts[i];
+    return s;
+}
+// y += sign * num / den * x, num and den given as partial sums in device memory (den may be null: 1)
 __global__ void k_axpy_dev(int64_t n, const double *__restrict__ num, const double *__restrict__ den, double sign,
                            const double *__restrict__ x, double *__restrict__ y)
 {
-    const double c = den ? sign * num[0] * (1.0 / den[0]) : sign * num[0];
+    __shared__ double cs;
+    if (threadIdx.x == 0) cs = den ? sign * dot_parts_sum(num) * (1.0 / dot_parts_sum(den)) : sign * dot_parts_sum(num);
+    __syncthreads();
+    const double c = cs;
     const int64_t n2 = n >> 1;
     const double2 *__restrict__ x2 = reinterpret_cast<const double2 *>(x);
     double2 *__restrict__ y2 = reinterpret_cast<double2 *>(y);
@@ -234,13 +236,10 @@ void launch_alm_copy(int lmax_in, const double *in, int lmax_out, double *out, h
     hipLaunchKernelGGL(k_alm_copy, dim3(4, lmax_out + 1), dim3(256), 0, st, lmax_in, reinterpret_cast<const double2 *>(in),
                        lmax_out, reinterpret_cast<double2 *>(out));
 }
-void launch_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *out, double *scratch, hipStream_t st)
+void launch_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *parts, hipStream_t st)
 {
-    const int64_t nalm = (int64_t)(lmax + 1) * (lmax + 2) / 2;
-    int64_t nb = (nalm + 4 * kDotThreads - 1) / (4 * kDotThreads);  // <= 4 entries per thread until the grid is 256 groups
-    if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(k_alm_dot, dim3((int)nb), dim3(kDotThreads), 0, st, lmax, lmin, reinterpret_cast<const double2 *>(a),
-                       reinterpret_cast<const double2 *>(b), accumulate, out, scratch);
+    hipLaunchKernelGGL(k_alm_dot_parts, dim3(kDotParts), dim3(kDotThreads), 0, st, lmax, lmin, reinterpret_cast<const double2 *>(a),
+                       reinterpret_cast<const double2 *>(b), accumulate, parts);
 }
 void launch_axpy_dev(int64_t n, const double *num, const double *den, double sign, const double *x, double *y, hipStream_t st)
 {

@@ -122,28 +122,25 @@ def almxfl_add(a, b, fl, out=None):
     return out
 
 
-_DOT_SCRATCH = {}
+DOT_PARTS = 64  # PL_DOT_PARTS of include/plshts.h
 
 
 def alm_dot(pairs, lmin=0):
-    """sum over the (a, b) pairs of sum_{l >= lmin} (2l + 1) C_l^{ab} as a 0-dim device tensor: one deterministic launch
-    per pair (pl_alm_dot), nothing comes back to the host."""
-    d = torch.cuda.current_device()
-    if d not in _DOT_SCRATCH:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError('dot scratch requested while a HIP graph is being captured')
-        _DOT_SCRATCH[d] = torch.zeros(1025, dtype=torch.float64, device=device())  # partials + the arrival counter
-    out = torch.empty((), dtype=torch.float64, device=device())
+    """sum over the (a, b) pairs of sum_{l >= lmin} (2l + 1) C_l^{ab}, left on the device as DOT_PARTS partial sums (the
+    value is their sum in index order: `float(dot.sum())` on the host, or axpy_dev on the device).  One deterministic
+    launch per pair (pl_alm_dot), nothing comes back to the host."""
+    out = torch.empty(DOT_PARTS, dtype=torch.float64, device=device())
     for i, (a, b) in enumerate(pairs):
         assert a.numel() == b.numel() and a.dtype == torch.complex128 and b.dtype == torch.complex128
         _lib.check(_lib.lib().pl_alm_dot(Alm.getlmax(a.numel()), int(lmin), a.data_ptr(), b.data_ptr(), int(i > 0), out.data_ptr(),
-                                        _DOT_SCRATCH[d].data_ptr(), stream_ptr()))
+                                        stream_ptr()))
     return out
 
 
 def axpy_dev(y, x, num, den=None, sign=1.0):
-    """y += sign * num / den * x in place; num, den: 0-dim float64 device tensors (pl_axpy_dev)."""
+    """y += sign * num / den * x in place; num, den: scalar products as returned by alm_dot (pl_axpy_dev)."""
     assert y.numel() == x.numel() and y.dtype == x.dtype and y.is_contiguous() and x.is_contiguous()
+    assert num.numel() == DOT_PARTS and (den is None or den.numel() == DOT_PARTS)
     n = y.numel() * (2 if y.is_complex() else 1)
     _lib.check(_lib.lib().pl_axpy_dev(n, num.data_ptr(), None if den is None else den.data_ptr(), float(sign), x.data_ptr(), y.data_ptr(),
                                      stream_ptr()))

@@ -44,22 +44,23 @@ def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=
 
         With a single preconditioner and a dot_op that offers `dev(a, b)` (a 0-dim device tensor) the step lengths
         stay on the device: no host synchronisation inside an iteration, same arithmetic.  If the dot_op also offers
-        `axpy(y, x, num, den, sign)` (y += sign num / den x in place, num and den device scalars) every vector update
-        is one launch and the cache holds d^t A d instead of its inverse.
+        `parts(a, b)` (the scalar product in whatever device-resident form `axpy` accepts) and `axpy(y, x, num, den, sign)`
+        (y += sign num / den x in place) every scalar product and vector update is one launch and the cache holds
+        d^t A d instead of its inverse.
     """
     if cache is None:
         cache = cache_mem()
     n_pre = len(pre_ops)
     on_dev = n_pre == 1 and hasattr(dot_op, 'dev')
-    fused = on_dev and hasattr(dot_op, 'axpy')
+    fused = on_dev and hasattr(dot_op, 'axpy') and hasattr(dot_op, 'parts')
     residual = b * 1.0 if x_is_zero else b - fwd_op(x)
     searchdirs = [op(residual) for op in pre_ops]
     it = 0
     while not criterion(it, x, residual):
         searchfwds = [fwd_op(d) for d in searchdirs]
         if fused:
-            dTAd = dot_op.dev(searchdirs[0], searchfwds[0])
-            delta = dot_op.dev(searchdirs[0], residual)
+            dTAd = dot_op.parts(searchdirs[0], searchfwds[0])
+            delta = dot_op.parts(searchdirs[0], residual)
             dot_op.axpy(x, searchdirs[0], delta, dTAd, 1.0)
             cache.store(it, [dTAd, searchdirs, searchfwds])
             it += 1
@@ -70,7 +71,7 @@ def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=
             searchdirs = [op(residual) for op in pre_ops]
             for titer in range(tr(it), it):
                 prev_dTAd, prev_dirs, prev_fwds = cache.restore(titer)
-                dot_op.axpy(searchdirs[0], prev_dirs[0], dot_op.dev(searchdirs[0], prev_fwds[0]), prev_dTAd, -1.0)
+                dot_op.axpy(searchdirs[0], prev_dirs[0], dot_op.parts(searchdirs[0], prev_fwds[0]), prev_dTAd, -1.0)
             cache.trim(range(tr(it + 1), it))
             continue
         if on_dev:

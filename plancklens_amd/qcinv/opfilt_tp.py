@@ -47,22 +47,27 @@ def apply_finiMLIK(alm, s_cls, n_inv_filt):
 class dot_op(object):
     """sum_l (2l + 1) (C_l^{TT'} + C_l^{EE'} + C_l^{BB'})."""
 
-    def dev(self, alm1, alm2):
-        """the scalar product as a 0-dim device tensor (no host synchronisation)"""
+    def parts(self, alm1, alm2):
+        """the scalar product as dev.DOT_PARTS partial sums in device memory (one launch per field, no host synchronisation);
+        its value is their sum, formed by whoever consumes it (axpy below, dev(), __call__)"""
         assert alm1.lmaxt == alm2.lmaxt, (alm1.lmaxt, alm2.lmaxt)
         assert alm1.lmaxe == alm2.lmaxe, (alm1.lmaxe, alm2.lmaxe)
         assert alm1.lmaxb == alm2.lmaxb, (alm1.lmaxb, alm2.lmaxb)
         return dev.alm_dot([(alm1.tlm, alm2.tlm), (alm1.elm, alm2.elm), (alm1.blm, alm2.blm)])
 
+    def dev(self, alm1, alm2):
+        """the scalar product as a 0-dim device tensor"""
+        return self.parts(alm1, alm2).sum()
+
     @staticmethod
     def axpy(y, x, num, den, sign):
-        """y += sign num / den x in place (num, den: device scalars)"""
+        """y += sign num / den x in place (num, den: scalar products as returned by parts)"""
         dev.axpy_dev(y.tlm, x.tlm, num, den, sign)
         dev.axpy_dev(y.elm, x.elm, num, den, sign)
         dev.axpy_dev(y.blm, x.blm, num, den, sign)
 
     def __call__(self, alm1, alm2):
-        return float(self.dev(alm1, alm2))
+        return float(self.parts(alm1, alm2).sum())
 
 
 class fwd_op(object):

@@ -40,18 +40,23 @@ def apply_fini(alm, s_cls, n_inv_filt):
 class dot_op(object):
     """sum_l (2l + 1) C_l^{ab}: the scalar product of the CG (opfilt_tt.py:43-51)."""
 
-    def dev(self, alm1, alm2):
-        """the scalar product as a 0-dim device tensor (no host synchronisation)"""
+    def parts(self, alm1, alm2):
+        """the scalar product as dev.DOT_PARTS partial sums in device memory (one launch per field, no host synchronisation);
+        its value is their sum, formed by whoever consumes it (axpy below, dev(), __call__)"""
         assert alm1.numel() == alm2.numel()
         return dev.alm_dot([(alm1, alm2)])
 
+    def dev(self, alm1, alm2):
+        """the scalar product as a 0-dim device tensor"""
+        return self.parts(alm1, alm2).sum()
+
     @staticmethod
     def axpy(y, x, num, den, sign):
-        """y += sign num / den x in place (num, den: device scalars): the vector updates of cd_solve in one launch"""
+        """y += sign num / den x in place (num, den: scalar products as returned by parts): the vector updates of cd_solve in one launch"""
         dev.axpy_dev(y, x, num, den, sign)
 
     def __call__(self, alm1, alm2):
-        return float(self.dev(alm1, alm2))
+        return float(self.parts(alm1, alm2).sum())
 
 
 class fwd_op(object):

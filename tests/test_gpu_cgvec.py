@@ -27,12 +27,12 @@ def test_alm_dot_axpy_almxfl_add(lmax):
         w[:lmin] = 0.
         ref = np.sum(hp.alm2cl(a, b) * w)
         scale = np.sum(np.abs(hp.alm2cl(a, a)) * w) + 1e-300
-        assert abs(float(dev.alm_dot([(da, db)], lmin=lmin)) - ref) < 1e-13 * max(scale, 1.)       # rounding only
-        assert abs(float(dev.alm_dot([(da, db), (db, da)], lmin=lmin)) - 2 * ref) < 2e-13 * max(scale, 1.)  # accumulation over pairs
+        assert abs(float(dev.alm_dot([(da, db)], lmin=lmin).sum()) - ref) < 1e-13 * max(scale, 1.)       # rounding only
+        assert abs(float(dev.alm_dot([(da, db), (db, da)], lmin=lmin).sum()) - 2 * ref) < 2e-13 * max(scale, 1.)  # accumulation over pairs
     # same inputs, same launch: bit-identical (fixed reduction tree, no atomics)
-    assert float(dev.alm_dot([(da, db)])) == float(dev.alm_dot([(da, db)]))
-    num = torch.tensor(3.0, dtype=torch.float64, device='cuda')
-    den = torch.tensor(-4.0, dtype=torch.float64, device='cuda')
+    assert torch.equal(dev.alm_dot([(da, db)]), dev.alm_dot([(da, db)]))
+    num = torch.zeros(dev.DOT_PARTS, dtype=torch.float64, device="cuda"); num[:3] = 1.0   # partial sums: 3
+    den = torch.zeros(dev.DOT_PARTS, dtype=torch.float64, device="cuda"); den[-4:] = -1.0  # partial sums: -4
     y = da.clone()
     dev.axpy_dev(y, db, num, den, -1.0)
     assert np.allclose(dev.to_host(y), a + 0.75 * b, rtol=1e-14, atol=1e-14)
