@@ -107,6 +107,14 @@ int pl_axpy(int64_t n, double a, const double *x, const double *y, double *out, 
 int pl_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *parts_dev, void *stream);
 int pl_axpy_dev(int64_t n, const double *num_parts_dev, const double *den_parts_dev, double sign, const double *x, double *y, void *stream);
 int pl_alm_splice(int lmax_lo, const double *alm_lo, int lmax_hi, const double *alm_hi, int lsplit, double *out, void *stream);
+
+/* Inverse-noise weighting with template marginalisation (alm_filter_ninv.apply_map, opfilt_tt.py:196-205) in two
+ * launches: tmap <- n_inv tmap - sum_k rmat[k] c_k, c_k = sum_i pmat[k][i] n_inv[i] tmap[i], with pmat (nmodes x npix,
+ * the template modes) and rmat = (P^t N^-1 P)^-1 (pmat . n_inv) (nmodes x npix), all device arrays; scratch_dev:
+ * PL_TEMPLATE_MAX_MODES * 256 doubles.  Bit-reproducible. */
+#define PL_TEMPLATE_MAX_MODES 16
+int pl_template_project(int64_t npix, int nmodes, double *tmap, const double *n_inv, const double *pmat, const double *rmat,
+                        double *scratch_dev, void *stream);
 int pl_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, void *stream);
 
 /* Pixel-space helpers (qest.py:256-257,276-278; opfilt_tt.py:195, opfilt_pp.py:276-299). */

@@ -28,6 +28,7 @@ void launch_axpy(int64_t n, double a, const double *x, const double *y, double *
 void launch_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *parts, hipStream_t st);
 void launch_axpy_dev(int64_t n, const double *num, const double *den, double sign, const double *x, double *y, hipStream_t st);
 void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st);
+void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st);
 void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st);
 void launch_map_mul(int64_t n, const double *a, const double *b, double *out, hipStream_t st);
 void launch_qe_lens_product(int64_t n, const double *tmap, const double *gt, const double *ct, const double *rep, const double *imp,
@@ -551,6 +552,15 @@ int pl_axpy_dev(int64_t n, const double *num_parts_dev, const double *den_parts_
     if (n < 0 || !num_parts_dev || !x || !y) return fail("pl_axpy_dev: bad arguments");
     if (n == 0) return 0;
     launch_axpy_dev(n, num_parts_dev, den_parts_dev, sign, x, y, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_template_project(int64_t npix, int nmodes, double *tmap, const double *n_inv, const double *pmat, const double *rmat, double *scratch, void *stream)
+{
+    if (npix <= 0 || nmodes < 1 || nmodes > PL_TEMPLATE_MAX_MODES || !tmap || !n_inv || !pmat || !rmat || !scratch)
+        return fail("pl_template_project: bad arguments (1 <= nmodes <= PL_TEMPLATE_MAX_MODES)");
+    launch_template_project(npix, nmodes, tmap, n_inv, pmat, rmat, scratch, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -201,6 +201,62 @@ __global__ void k_axpy_dev(int64_t n, const double *__restrict__ num, const doub
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = fma(c, x[n - 1], y[n - 1]);
 }
 
+// ---- N^-1 with template marginalisation in two launches (opfilt_tt.py:196-205) ----------------------------------------
+// t <- N^-1 t - N^-1 P (P^t N^-1 P)^-1 P^t N^-1 t with P (nmodes x n) and R = (P^t N^-1 P)^-1 (P . N^-1) (nmodes x n) given:
+//   pass 1: t <- n_inv t and the per-workgroup partial sums of c_k = sum_i P_ki t_i;  pass 2: t_i -= sum_k R_ki c_k.
+// The partial sums are added in index order by every workgroup of pass 2: bit-reproducible, no atomics.
+constexpr int kProjParts = 256, kProjMaxModes = 16, kProjThreads = 1024;
+__global__ __launch_bounds__(kProjThreads) void k_tproj_coeffs(int64_t n, int nmodes, double *__restrict__ t, const double *__restrict__ n_inv,
+                                                               const double *__restrict__ pm, double *__restrict__ parts)
+{
+    __shared__ double red[kProjMaxModes][kProjThreads / 64];
+    double acc[kProjMaxModes];
+#pragma unroll
+    for (int k = 0; k < kProjMaxModes; ++k) acc[k] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kProjThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kProjThreads) {
+        const double u = t[i] * n_inv[i];
+        t[i] = u;
+#pragma unroll
+        for (int k = 0; k < kProjMaxModes; ++k)
+            if (k < nmodes) acc[k] = fma(pm[(int64_t)k * n + i], u, acc[k]);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kProjMaxModes; ++k) {
+        if (k >= nmodes) break;
+        double v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[k][wave] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nmodes) {
+        double v = 0.0;
+        for (int w = 0; w < kProjThreads / 64; ++w) v += red[threadIdx.x][w];
+        parts[threadIdx.x * kProjParts + blockIdx.x] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_tproj_apply(int64_t n, int nmodes, double *__restrict__ t, const double *__restrict__ rm,
+                                                     const double *__restrict__ parts)
+{
+    __shared__ double c[kProjMaxModes];
+    __shared__ double red[kProjParts];
+    for (int k = 0; k < nmodes; ++k) {
+        red[threadIdx.x] = parts[k * kProjParts + threadIdx.x];
+        __syncthreads();
+        for (int h = kProjParts / 2; h > 0; h >>= 1) {
+            if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) c[k] = red[0];
+        __syncthreads();
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double v = t[i];
+        for (int k = 0; k < nmodes; ++k) v = fma(-rm[(int64_t)k * n + i], c[k], v);
+        t[i] = v;
+    }
+}
+
 // out (band-limit lmax_hi) = alm_lo for l <= lsplit, alm_hi above (util_alm.py:8-24)
 __global__ void k_alm_splice(int lmax_lo, const double2 *__restrict__ lo, int lmax_hi, const double2 *__restrict__ hi, int lsplit,
                              double2 *__restrict__ out)
@@ -244,6 +300,11 @@ void launch_alm_dot(int lmax, int lmin, const double *a, const double *b, int ac
 void launch_axpy_dev(int64_t n, const double *num, const double *den, double sign, const double *x, double *y, hipStream_t st)
 {
     hipLaunchKernelGGL(k_axpy_dev, dim3(nblocks((n + 1) / 2)), dim3(256), 0, st, n, num, den, sign, x, y);
+}
+void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_tproj_coeffs, dim3(kProjParts), dim3(kProjThreads), 0, st, n, nmodes, t, n_inv, pm, parts);
+    hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n)), dim3(256), 0, st, n, nmodes, t, rm, parts);
 }
 void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st)
 {

@@ -177,8 +177,9 @@ class alm_filter_ninv(object):
 
     def apply_map(self, tmap):
         """tmap <- N^-1 tmap with the templates projected out (in place)."""
-        tmap *= self.n_inv
-        if len(self.templates) != 0:
+        if len(self.templates) == 0:
+            tmap *= self.n_inv
+        else:
             # all template modes as one device matrix P (nmodes x npix): coefficients, the small solve and the projected
             # map are device operations, nothing comes back to the host inside a CG iteration
             if getattr(self, '_pmat', None) is None:
@@ -192,4 +193,8 @@ class alm_filter_ninv(object):
                 pinv = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64)
                 # N^-1 P (P^t N^-1 P)^-1 as one matrix: the projection is two mat-vecs, c = P^t t and t -= R^t c
                 self._rmat = torch.mm(pinv, self._pmat * self.n_inv.unsqueeze(0))
-            tmap.addmv_(self._rmat.t(), torch.mv(self._pmat, tmap), alpha=-1.0)
+            if self._pmat.shape[0] <= dev.TEMPLATE_MAX_MODES and tmap.is_contiguous():
+                dev.template_project(tmap, self.n_inv, self._pmat, self._rmat)  # N^-1 weighting + projection, two launches
+            else:
+                tmap *= self.n_inv
+                tmap.addmv_(self._rmat.t(), torch.mv(self._pmat, tmap), alpha=-1.0)

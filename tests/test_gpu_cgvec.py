@@ -83,3 +83,24 @@ def test_dense_single_matrix_equals_rlm_route(nfields):
     got = [res] if nfields == 1 else ([res.elm, res.blm] if nfields == 2 else [res.tlm, res.elm, res.blm])
     for r, g_ in zip(ref, got):
         assert np.allclose(r, dev.to_host(g_), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize('npix,nmodes', [(48, 1), (3072, 4), (196608, 4), (786432, 16)])
+def test_template_project(npix, nmodes):
+    import torch
+    from plancklens_amd import dev
+    rng = np.random.default_rng(npix + nmodes)
+    t, ninv = rng.standard_normal(npix), rng.uniform(0.5, 2., npix) * (rng.uniform(size=npix) > 0.3)
+    pm = rng.standard_normal((nmodes, npix))
+    pinv = np.linalg.inv(pm @ (pm * ninv).T)
+    rm = pinv @ (pm * ninv)
+    u = ninv * t
+    ref = u - rm.T @ (pm @ u)     # N^-1 t - N^-1 P (P^t N^-1 P)^-1 P^t N^-1 t
+    dt = dev.to_dev(t)
+    dev.template_project(dt, dev.to_dev(ninv), dev.to_dev(pm), dev.to_dev(rm))
+    got = dev.to_host(dt)
+    assert np.max(np.abs(got - ref)) < 1e-11 * np.max(np.abs(u))
+    assert np.max(np.abs(pm @ got)) < 1e-8 * np.max(np.abs(pm @ u))  # the template modes are gone from the weighted map
+    dt2 = dev.to_dev(t)
+    dev.template_project(dt2, dev.to_dev(ninv), dev.to_dev(pm), dev.to_dev(rm))
+    assert torch.equal(dt, dt2)  # bit-reproducible
