@@ -52,7 +52,7 @@ def chain(kind, n):
 ninv_t = [np.array([3. / nlev_t ** 2]) * mask]
 ninv_p = [[np.array([3. / nlev_p ** 2]) * mask]]
 res = {}
-for kind in ('t', 'p'):
+for kind in [k for k in ('t', 'p') if k in os.environ.get('CG_BENCH_ONLY', 'tp')]:
     t0 = time.time()
     if kind == 't':
         f = filt_cinv.cinv_t(os.path.join(tmp, 'cinv_t'), lmax, nside, cl, transf, ninv_t, chain_descr=chain('t', iters))
@@ -98,6 +98,8 @@ if os.environ.get('CG_BENCH_JOINT', '0') == '1':
     dt = time.time() - t0
     res['tp_joint'] = {'iters': iters, 'seconds': dt, 'iters_per_s': iters / dt, 'first_call_incl_dense_setup_s': setup}
     print('tp_joint', json.dumps(res['tp_joint']), flush=True)
+if 't' not in res or 'p' not in res:  # CG_BENCH_ONLY: a single filter (profiling runs)
+    sys.exit(0)
 tp = iters / (res['t']['seconds'] + res['p']['seconds'])
 print(json.dumps({'metric': 'CG-iter/sec (cinv_t + cinv_p, nside=%d lmax=%d, masked fsky=%.2f)' % (nside, lmax, mask.mean()),
                   'T_iters_per_s': res['t']['iters_per_s'], 'P_iters_per_s': res['p']['iters_per_s'], 'TP_iters_per_s': tp,
