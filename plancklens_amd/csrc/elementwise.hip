@@ -223,10 +223,12 @@ __global__ __launch_bounds__(kProjThreads) void k_tproj_coeffs(int64_t n, int nm
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < kProjMaxModes; ++k) {
-        if (k >= nmodes) break;
-        double v = acc[k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) red[k][wave] = v;
+        if (k < nmodes) {  // wave-uniform
+            double v = acc[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) red[k][wave] = v;
+        }
     }
     __syncthreads();
     if ((int)threadIdx.x < nmodes) {

@@ -111,15 +111,20 @@ __device__ void fft_build_twl(double2 *twl, int M, const double2 *__restrict__ t
 }
 
 // one pass over blocks of size L (stride s = L / R); twp: this pass's LDS twiddles or nullptr
+// `batch` transforms of size M at a, a + bstride, ... are swept together (the four sub-DFTs of a short ring: a single
+// size-256 transform has only 32 radix-8 butterflies per pass for 256 threads)
 template <int NT, int R, bool FWD>
-__device__ __forceinline__ void fft_pass(double2 *a, int M, int L, const double2 *twp, const double2 *__restrict__ tw, int Mtw)
+__device__ __forceinline__ void fft_pass(double2 *a, int M, int L, const double2 *twp, const double2 *__restrict__ tw, int Mtw,
+                                         int batch = 1, int bstride = 0)
 {
     const int s = L / R;
     const int ls = 31 - __clz(s);
+    const int lmr = 31 - __clz(M / R);
     const int tstep = Mtw / L;
-    for (int t = threadIdx.x; t < M / R; t += NT) {
+    for (int tb = threadIdx.x; tb < batch * (M / R); tb += NT) {
+        const int t = tb & (M / R - 1);
         const int blk = t >> ls, pos = t & (s - 1);
-        double2 *p = a + blk * L + pos;
+        double2 *p = a + (tb >> lmr) * bstride + blk * L + pos;
         double2 x[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) x[j] = p[j * s];
@@ -158,7 +163,7 @@ __device__ __forceinline__ int digit_reverse(int f, int M)
 }
 
 template <int NT>
-__device__ void fft_dif_fwd(double2 *a, int M, const double2 *twl, const double2 *__restrict__ tw, int Mtw)
+__device__ void fft_dif_fwd(double2 *a, int M, const double2 *twl, const double2 *__restrict__ tw, int Mtw, int batch = 1, int bstride = 0)
 {
     if (M < 2) { __syncthreads(); return; }
     const int rt = fft_tail_radix(M);
@@ -168,28 +173,28 @@ __device__ void fft_dif_fwd(double2 *a, int M, const double2 *twl, const double2
     for (int L = M; L > rt; L >>= 3) {
         off -= 3 * (L / 8);
         __syncthreads();
-        fft_pass<NT, 8, true>(a, M, L, twl ? twl + off : nullptr, tw, Mtw);
+        fft_pass<NT, 8, true>(a, M, L, twl ? twl + off : nullptr, tw, Mtw, batch, bstride);
     }
     __syncthreads();
-    if (rt == 8) fft_pass<NT, 8, true>(a, M, 8, twl, tw, Mtw);
-    else if (rt == 4) fft_pass<NT, 4, true>(a, M, 4, twl, tw, Mtw);
-    else fft_pass<NT, 2, true>(a, M, 2, twl, tw, Mtw);
+    if (rt == 8) fft_pass<NT, 8, true>(a, M, 8, twl, tw, Mtw, batch, bstride);
+    else if (rt == 4) fft_pass<NT, 4, true>(a, M, 4, twl, tw, Mtw, batch, bstride);
+    else fft_pass<NT, 2, true>(a, M, 2, twl, tw, Mtw, batch, bstride);
     __syncthreads();
 }
 
 template <int NT>
-__device__ void fft_dit_inv(double2 *a, int M, const double2 *twl, const double2 *__restrict__ tw, int Mtw)
+__device__ void fft_dit_inv(double2 *a, int M, const double2 *twl, const double2 *__restrict__ tw, int Mtw, int batch = 1, int bstride = 0)
 {
     if (M < 2) { __syncthreads(); return; }
     const int rt = fft_tail_radix(M);
     __syncthreads();
-    if (rt == 8) fft_pass<NT, 8, false>(a, M, 8, twl, tw, Mtw);
-    else if (rt == 4) fft_pass<NT, 4, false>(a, M, 4, twl, tw, Mtw);
-    else fft_pass<NT, 2, false>(a, M, 2, twl, tw, Mtw);
+    if (rt == 8) fft_pass<NT, 8, false>(a, M, 8, twl, tw, Mtw, batch, bstride);
+    else if (rt == 4) fft_pass<NT, 4, false>(a, M, 4, twl, tw, Mtw, batch, bstride);
+    else fft_pass<NT, 2, false>(a, M, 2, twl, tw, Mtw, batch, bstride);
     int off = fft_nk(rt) * 1;  // tail pass table: nk * (rt / rt) entries
     for (int L = rt * 8; L <= M; L *= 8) {
         __syncthreads();
-        fft_pass<NT, 8, false>(a, M, L, twl ? twl + off : nullptr, tw, Mtw);
+        fft_pass<NT, 8, false>(a, M, L, twl ? twl + off : nullptr, tw, Mtw, batch, bstride);
         off += 3 * (L / 8);
     }
     __syncthreads();
@@ -199,14 +204,18 @@ __device__ void fft_dit_inv(double2 *a, int M, const double2 *twl, const double2
 // Out: ws[j] (times chirp[j] for Bluestein, applied by the caller through sub_value) = sum_k x_k e^{+2 pi i jk/q}.
 template <int NT>
 __device__ __forceinline__ void sub_dft_inverse(double2 *ws, int q, int M, const double2 *__restrict__ filt, const DevFFT &F,
-                                                const double2 *twl)
+                                                const double2 *twl, int batch = 1, int bstride = 0)
 {
     if (M) {
-        fft_dif_fwd<NT>(ws, M, twl, F.tw, F.Mtw);
-        for (int t = threadIdx.x; t < M; t += NT) ws[t] = cmul(ws[t], filt[t]);
-        fft_dit_inv<NT>(ws, M, twl, F.tw, F.Mtw);
+        fft_dif_fwd<NT>(ws, M, twl, F.tw, F.Mtw, batch, bstride);
+        const int lm = 31 - __clz(M);
+        for (int t = threadIdx.x; t < batch * M; t += NT) {
+            double2 *w = ws + (t >> lm) * bstride + (t & (M - 1));
+            *w = cmul(*w, filt[t & (M - 1)]);
+        }
+        fft_dit_inv<NT>(ws, M, twl, F.tw, F.Mtw, batch, bstride);
     } else {
-        fft_dit_inv<NT>(ws, q, twl, F.tw, F.Mtw);
+        fft_dit_inv<NT>(ws, q, twl, F.tw, F.Mtw, batch, bstride);
     }
 }
 
@@ -249,7 +258,9 @@ __global__ void k_twiddles(double2 *tw, int Mtw)
 // -----------------------------------------------------------------------------------------------------
 // synthesis: phase -> pixels
 // -----------------------------------------------------------------------------------------------------
-template <int NT, int QMAX>
+// B4: the four sub-DFTs of the ring are transformed side by side (LDS for 4 F.Lmax points) -- the coarse grids of the CG
+// multigrid, where one short transform leaves most of the workgroup idle and the chain of barriers is the cost.
+template <int NT, int QMAX, bool B4>
 __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim, int ncomp,
                                                   const double *__restrict__ phase, double *__restrict__ map, int dbg)
 {
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int
     const double inv_n = 1.0 / n;
     const int estride = 4 * ncomp;
     const double *__restrict__ ph = phase + (int64_t)ip * P.mstride * estride + comp * 4;
-    double2 *twl = F.twl_cap ? ws + F.Lmax : nullptr;
+    double2 *twl = F.twl_cap ? ws + (B4 ? 4 : 1) * F.Lmax : nullptr;
     if (twl) fft_build_twl<NT>(twl, M ? M : q, F.tw, F.Mtw);
 
     double2 acc[4][QMAX], e1[QMAX];
@@ -275,36 +286,32 @@ __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int
         const int j1 = threadIdx.x + NT * qq;
         e1[qq] = cispi(2.0 * j1 * inv_n);  // e^{2 pi i j1 / n}
     }
-
-    for (int k2 = 0; k2 < 4; ++k2) {
-        if (M) for (int t = q + threadIdx.x; t < M; t += NT) ws[t] = make_double2(0., 0.);
-        for (int k1 = threadIdx.x; k1 < q; k1 += NT) {
-            const int k = 4 * k1 + k2;
-            double zr = 0., zi = 0.;
-            if (dbg & 4) { ws[k1] = make_double2(1., 0.); continue; }
-            for (int m = k; m <= ml; m += n) {  // positive frequencies aliased onto bin k
-                const double4 f = *reinterpret_cast<const double4 *>(ph + (int64_t)m * estride);
-                double2 p = (shifted && !(dbg & 1)) ? cispi(m * inv_n) : make_double2(1., 0.);
-                const double2 fn = cmul(make_double2(f.x, f.y), p), fs = cmul(make_double2(f.z, f.w), p);
-                zr += fn.x - fs.y; zi += fn.y + fs.x;  // f_N + i f_S
-            }
-            for (int m = n - k; m <= ml; m += n) {  // negative frequencies -m = k (mod n)
-                const double4 f = *reinterpret_cast<const double4 *>(ph + (int64_t)m * estride);
-                double2 p = shifted ? cispi(m * inv_n) : make_double2(1., 0.);
-                const double2 fn = cmul(make_double2(f.x, f.y), p), fs = cmul(make_double2(f.z, f.w), p);
-                zr += fn.x + fs.y; zi += -fn.y + fs.x;  // conj(f_N) + i conj(f_S)
-            }
-            const double2 z = make_double2(zr, zi);
-            if (M) ws[k1] = cmul(z, chirp[k1]);
-            else ws[digit_reverse(k1, q)] = z;
+    // input bin k = 4 k1 + k2 of the ring transform: all orders aliased onto it
+    auto fold = [&](int k1, int k2) -> double2 {
+        const int k = 4 * k1 + k2;
+        double zr = 0., zi = 0.;
+        if (dbg & 4) return make_double2(1., 0.);
+        for (int m = k; m <= ml; m += n) {  // positive frequencies aliased onto bin k
+            const double4 f = *reinterpret_cast<const double4 *>(ph + (int64_t)m * estride);
+            double2 p = (shifted && !(dbg & 1)) ? cispi(m * inv_n) : make_double2(1., 0.);
+            const double2 fn = cmul(make_double2(f.x, f.y), p), fs = cmul(make_double2(f.z, f.w), p);
+            zr += fn.x - fs.y; zi += fn.y + fs.x;  // f_N + i f_S
         }
-        if (!(dbg & 2)) sub_dft_inverse<NT>(ws, q, M, filt, F, twl);
-        else __syncthreads();
+        for (int m = n - k; m <= ml; m += n) {  // negative frequencies -m = k (mod n)
+            const double4 f = *reinterpret_cast<const double4 *>(ph + (int64_t)m * estride);
+            double2 p = shifted ? cispi(m * inv_n) : make_double2(1., 0.);
+            const double2 fn = cmul(make_double2(f.x, f.y), p), fs = cmul(make_double2(f.z, f.w), p);
+            zr += fn.x + fs.y; zi += -fn.y + fs.x;  // conj(f_N) + i conj(f_S)
+        }
+        return make_double2(zr, zi);
+    };
+    // sub-DFT k2 is in w[0 .. q): twiddle and radix-4 butterfly into the four quarter rings
+    auto scatter = [&](int k2, const double2 *w) {
 #pragma unroll
         for (int qq = 0; qq < QMAX; ++qq) {
             const int j1 = threadIdx.x + NT * qq;
             if (j1 < q) {
-                double2 y = ws[j1];
+                double2 y = w[j1];
                 if (M) y = cmul(y, chirp[j1]);
                 // twiddle e^{2 pi i j1 k2 / n}
                 double2 tw = make_double2(1., 0.);
@@ -316,7 +323,35 @@ __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int
                 for (int j2 = 0; j2 < 4; ++j2) acc[j2][qq] = cadd(acc[j2][qq], crot(y, j2 * k2));
             }
         }
-        __syncthreads();
+    };
+
+    if constexpr (B4) {
+        const int S = M ? M : q;  // a power of two either way (Bluestein size, or q itself on the direct route)
+        const int lS = 31 - __clz(S);
+        for (int idx = threadIdx.x; idx < 4 * S; idx += NT) {
+            const int k2 = idx >> lS, k1 = idx & (S - 1);
+            if (k1 >= q) { ws[idx] = make_double2(0., 0.); continue; }
+            const double2 z = fold(k1, k2);
+            if (M) ws[idx] = cmul(z, chirp[k1]);
+            else ws[k2 * S + digit_reverse(k1, q)] = z;
+        }
+        if (!(dbg & 2)) sub_dft_inverse<NT>(ws, q, M, filt, F, twl, 4, S);
+        else __syncthreads();
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) scatter(k2, ws + k2 * S);
+    } else {
+        for (int k2 = 0; k2 < 4; ++k2) {
+            if (M) for (int t = q + threadIdx.x; t < M; t += NT) ws[t] = make_double2(0., 0.);
+            for (int k1 = threadIdx.x; k1 < q; k1 += NT) {
+                const double2 z = fold(k1, k2);
+                if (M) ws[k1] = cmul(z, chirp[k1]);
+                else ws[digit_reverse(k1, q)] = z;
+            }
+            if (!(dbg & 2)) sub_dft_inverse<NT>(ws, q, M, filt, F, twl);
+            else __syncthreads();
+            scatter(k2, ws);
+            __syncthreads();
+        }
     }
     double *__restrict__ mp = map + (int64_t)comp * P.npix;
     const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
@@ -834,16 +869,24 @@ static hipError_t launch_p2m(const DevPlan &P, const DevFFT &F, const int *mlim,
                              hipStream_t st)
 {
     if (F.A.legacy_n == 0) return hipSuccess;
+    static int dbg = getenv("PLSHTS_FFTDBG") ? atoi(getenv("PLSHTS_FFTDBG")) : 0;
+    static const bool no_b4 = getenv("PLSHTS_FFT_NOB4") && atoi(getenv("PLSHTS_FFT_NOB4")) != 0;
+    const size_t lds4 = (size_t)(4 * F.Lmax + F.twl_cap) * sizeof(double2);
+    if (!no_b4 && lds4 <= 48 * 1024) {  // short transforms (coarse grids): the four sub-DFTs side by side
+        hipLaunchKernelGGL((k_phase2map<NT, QMAX, true>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds4, st, P, F, F.A.legacy_pairs, mlim, ncomp,
+                           phase, map, dbg);
+        return hipGetLastError();
+    }
     const size_t lds = fft_lds_bytes(F);
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map<NT, QMAX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map<NT, QMAX, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    static int dbg = getenv("PLSHTS_FFTDBG") ? atoi(getenv("PLSHTS_FFTDBG")) : 0;
-    hipLaunchKernelGGL((k_phase2map<NT, QMAX>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds, st, P, F, F.A.legacy_pairs, mlim, ncomp, phase, map, dbg);
+    hipLaunchKernelGGL((k_phase2map<NT, QMAX, false>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds, st, P, F, F.A.legacy_pairs, mlim, ncomp, phase,
+                       map, dbg);
     return hipGetLastError();
 }
 
