@@ -372,7 +372,7 @@ __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int
 // -----------------------------------------------------------------------------------------------------
 // analysis: pixels -> phase (uniform quadrature weights 4 pi / npix)
 // -----------------------------------------------------------------------------------------------------
-template <int NT, int QMAX>
+template <int NT, int QMAX, bool B4>
 __global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim, int ncomp,
                                                   const double *__restrict__ map, double *__restrict__ phase)
 {
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int
     const double inv_n = 1.0 / n;
     const int estride = 4 * ncomp;
     double *__restrict__ ph = phase + (int64_t)ip * P.mstride * estride + comp * 4;
-    double2 *twl = F.twl_cap ? ws + F.Lmax : nullptr;
+    double2 *twl = F.twl_cap ? ws + (B4 ? 4 : 1) * F.Lmax : nullptr;
     if (twl) fft_build_twl<NT>(twl, M ? M : q, F.tw, F.Mtw);
     const double wgt = 0.5 * 4.0 * 3.14159265358979323846 / (double)P.npix;  // includes the 1/2 of the N/S split
     const double *__restrict__ mp = map + (int64_t)comp * P.npix;
@@ -429,9 +429,9 @@ __global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int
         *reinterpret_cast<double4 *>(ph + (int64_t)m * estride) = o;
     };
 
-    for (int kk = 0; kk < 4; ++kk) {
-        const int k2 = (kk == 0) ? 0 : (kk == 1) ? 2 : (kk == 2) ? 1 : 3;
-        if (M) for (int t = q + threadIdx.x; t < M; t += NT) ws[t] = make_double2(0., 0.);
+    // input of sub-DFT k2 into w[0 .. S): radix-4 butterfly over the quarter rings, twiddle, (chirp), zero padding
+    auto gather = [&](int k2, double2 *w) {
+        if (M) for (int t = q + threadIdx.x; t < M; t += NT) w[t] = make_double2(0., 0.);
 #pragma unroll
         for (int qq = 0; qq < QMAX; ++qq) {
             const int j1 = threadIdx.x + NT * qq;
@@ -444,10 +444,30 @@ __global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int
                 if (k2 >= 2) tw = cmul(tw, e1[qq]);
                 if (k2 >= 3) tw = cmul(tw, e1[qq]);
                 x = cmul(x, tw);
-                if (M) ws[j1] = cmul(x, chirp[j1]);
-                else ws[digit_reverse(j1, q)] = x;
+                if (M) w[j1] = cmul(x, chirp[j1]);
+                else w[digit_reverse(j1, q)] = x;
             }
         }
+    };
+    if constexpr (B4) {  // the four sub-DFTs side by side: V_{4 k1 + k2} = ws[k2 S + k1] (* chirp[k1])
+        const int S = M ? M : q;
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) gather(k2, ws + k2 * S);
+        sub_dft_inverse<NT>(ws, q, M, filt, F, twl, 4, S);
+        auto val = [&](int k) {  // V_k, 0 <= k < n
+            double2 v = ws[(k & 3) * S + (k >> 2)];
+            if (M) v = cmul(v, chirp[k >> 2]);
+            return v;
+        };
+        for (int m = threadIdx.x; m <= ml; m += NT) {
+            const int k = m % n;
+            emit(m, val(k), val((n - k) % n));
+        }
+        return;
+    }
+    for (int kk = 0; kk < 4; ++kk) {
+        const int k2 = (kk == 0) ? 0 : (kk == 1) ? 2 : (kk == 2) ? 1 : 3;
+        gather(k2, ws);
         sub_dft_inverse<NT>(ws, q, M, filt, F, twl);
         // now V_{4 k1 + k2} = ws[k1] (* chirp[k1])
         if (k2 == 0 || k2 == 2) {
@@ -895,15 +915,23 @@ static hipError_t launch_m2p(const DevPlan &P, const DevFFT &F, const int *mlim,
                              hipStream_t st)
 {
     if (F.A.legacy_n == 0) return hipSuccess;
+    static const bool no_b4 = getenv("PLSHTS_FFT_NOB4") && atoi(getenv("PLSHTS_FFT_NOB4")) != 0;
+    const size_t lds4 = (size_t)(4 * F.Lmax + F.twl_cap) * sizeof(double2);
+    if (!no_b4 && lds4 <= 48 * 1024) {  // short transforms (coarse grids): the four sub-DFTs side by side
+        hipLaunchKernelGGL((k_map2phase<NT, QMAX, true>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds4, st, P, F, F.A.legacy_pairs, mlim, ncomp,
+                           map, phase);
+        return hipGetLastError();
+    }
     const size_t lds = fft_lds_bytes(F);
     static bool attr_done = false;
     if (!attr_done && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_map2phase<NT, QMAX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_map2phase<NT, QMAX, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_map2phase<NT, QMAX>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds, st, P, F, F.A.legacy_pairs, mlim, ncomp, map, phase);
+    hipLaunchKernelGGL((k_map2phase<NT, QMAX, false>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds, st, P, F, F.A.legacy_pairs, mlim, ncomp, map,
+                       phase);
     return hipGetLastError();
 }
 
