@@ -453,18 +453,28 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
             // waited for with lgkmcnt(0) before the other one is issued -- after ~50 v_fma_f64, i.e. hidden.
             // The sched_barriers keep hipcc from sinking the loads to their first use.
             d2v_t A0 = ldc<d2v_t>(abv + i), A1 = ldc<d2v_t>(abv + i + 1);
-            d4v_t Aa0 = ldc<d4v_t>(aav + i), Aa1 = ldc<d4v_t>(aav + i + 1);
+            // gradient-only: only the second half (Ap) of an entry is used -- load just that, so that the register
+            // allocator does not overlap the dead halves of two loads (which costs a wait between their issues)
+            auto lda = [&](int idx) -> d4v_t {
+                if constexpr (GONLY) {
+                    const d2v_t h = ldc<d2v_t>(reinterpret_cast<const d2v_t *>(aav + idx) + 1);
+                    return d4v_t{0., 0., h.x, h.y};
+                } else {
+                    return ldc<d4v_t>(aav + idx);
+                }
+            };
+            d4v_t Aa0 = lda(i), Aa1 = lda(i + 1);
             while (i + 3 < nl) {
                 pf.step<32, 16>(aa, ab, i, nl, lane);
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): set A has landed (it was issued one half trip ago) ...
                 const d2v_t B0 = ldc<d2v_t>(abv + i + 2), B1 = ldc<d2v_t>(abv + i + 3);  // ... so that B can be issued without A's uses waiting on it
-                const d4v_t Ba0 = ldc<d4v_t>(aav + i + 2), Ba1 = ldc<d4v_t>(aav + i + 3);
+                const d4v_t Ba0 = lda(i + 2), Ba1 = lda(i + 3);
                 __builtin_amdgcn_sched_barrier(0);
                 pair_step(std::false_type(), A0.x, A0.y, A1.x, A1.y, Aa0, Aa1);
                 __builtin_amdgcn_sched_barrier(0);
                 const int ip = min(i + 4, nl - 2);  // clamped: the last prefetch re-reads valid entries
                 __builtin_amdgcn_s_waitcnt(0xC07F);
-                A0 = ldc<d2v_t>(abv + ip); A1 = ldc<d2v_t>(abv + ip + 1); Aa0 = ldc<d4v_t>(aav + ip); Aa1 = ldc<d4v_t>(aav + ip + 1);
+                A0 = ldc<d2v_t>(abv + ip); A1 = ldc<d2v_t>(abv + ip + 1); Aa0 = lda(ip); Aa1 = lda(ip + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 pair_step(std::false_type(), B0.x, B0.y, B1.x, B1.y, Ba0, Ba1);
                 __builtin_amdgcn_sched_barrier(0);
