@@ -925,8 +925,8 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
     const double2 *__restrict__ ab = reinterpret_cast<const double2 *>(S.ab) + base;
     double *__restrict__ out = partial + ((int64_t)g * nent + base) * 4;
     bool all_active = false, any_active = false;
-    int pfa = -1;
-    d8v_t SA0, SA1, SB0, SB1;
+    int pfa = -1;  // tile start whose first coefficient set is already in QA
+    d8v_t QA, QB;
     double acc[16];  // one folded value per l of the tile (see fold4)
     // the 8 FMAs of one (l, ring): sigma_l = +1 for even t (after the swap above), -1 for odd t
     // ring k = 0 starts the four sums with a multiply instead of an FMA onto zero (no zero-initialising moves)
@@ -937,14 +937,15 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
         else { a0 = fma(vn, pa0[k], a0); a1 = fma(vn, pa1[k], a1); a2 = fma(vn, pa2[k], a2); a3 = fma(vn, pa3[k], a3); }
         a0 = fma(vp, pb0[k], a0); a1 = fma(vp, pb1[k], a1); a2 = fma(-vp, pb2[k], a2); a3 = fma(-vp, pb3[k], a3);
     };
-    auto half = [&](auto hc, const d8v_t &c0, const d8v_t &c1, int ib) {
-        constexpr int h = decltype(hc)::value;
-        if (all_active && ib + 8 <= nl) {  // every lane in the IEEE range, all 8 l in range: one branch-free FMA block
+    // one quarter tile: 4 consecutive l with the coefficient set c = 4 (a, b) pairs
+    auto quarter = [&](auto qc, const d8v_t &c, int ib) {
+        constexpr int h = decltype(qc)::value;
+        if (all_active && ib + 4 <= nl) {  // every lane in the IEEE range, all 4 l in range: one branch-free FMA block
 #pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
-                const int t = 8 * h + tt;
-                const double cA = tt < 4 ? c0[2 * tt] : c1[2 * (tt - 4)];
-                const double cB = tt < 4 ? c0[2 * tt + 1] : c1[2 * (tt - 4) + 1];
+            for (int tt = 0; tt < 4; ++tt) {
+                const int t = 4 * h + tt;
+                const double cA = c[2 * tt];
+                const double cB = c[2 * tt + 1];
                 double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
@@ -953,15 +954,15 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
                 }
                 acc[t] = fold4(a0, a1, a2, a3);
             }
-        } else if (ib + 8 <= nl) {  // mixed: fast steps, each ring's terms times its 0/1 masks; rescale check after the 8 l
+        } else if (ib + 4 <= nl) {  // mixed: fast steps, each ring's terms times its 0/1 masks; rescale check after the 4 l
             double mn[R], mp[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) { mn[k] = r[k].scn == 0 ? 1.0 : 0.0; mp[k] = r[k].scp == 0 ? 1.0 : 0.0; }
 #pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
-                const int t = 8 * h + tt;
-                const double cA = tt < 4 ? c0[2 * tt] : c1[2 * (tt - 4)];
-                const double cB = tt < 4 ? c0[2 * tt + 1] : c1[2 * (tt - 4) + 1];
+            for (int tt = 0; tt < 4; ++tt) {
+                const int t = 4 * h + tt;
+                const double cA = c[2 * tt];
+                const double cB = c[2 * tt + 1];
                 double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
@@ -974,13 +975,13 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
             for (int k = 0; k < R; ++k) recs_renorm_up(r[k]);
         } else {  // last, partial tile: one careful step at a time
 #pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
-                const int t = 8 * h + tt;
+            for (int tt = 0; tt < 4; ++tt) {
+                const int t = 4 * h + tt;
                 const int i = ib + tt;
                 double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
                 if (i < nl) {
-                    const double cA = tt < 4 ? c0[2 * tt] : c1[2 * (tt - 4)];
-                    const double cB = tt < 4 ? c0[2 * tt + 1] : c1[2 * (tt - 4) + 1];
+                    const double cA = c[2 * tt];
+                    const double cB = c[2 * tt + 1];
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
                         accum(t, k, recs_value_n(r[k]), recs_value_p(r[k]), a0, a1, a2, a3);
@@ -1033,17 +1034,30 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
                 continue;
             }
         }
-        if (pfa != i0) { SA0 = ld8(ab + i0); SA1 = ld8(ab + i0 + 4); }
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): SA has landed before SB is issued
-        SB0 = ld8(ab + i0 + 8); SB1 = ld8(ab + i0 + 12);
+        // Two coefficient sets of 4 l (QA, QB), each loaded while the other is consumed (~240 VALU instructions): with
+        // sets of 8 l the four live sets took 64 SGPRs and 50 scalars were spilled to VGPR lanes (v_readlane /
+        // v_writelane in the hot loop).  The tables are padded: reads past nl are unused.
+        if (pfa != i0) QA = ld8(ab + i0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): QA has landed before QB is issued
+        QB = ld8(ab + i0 + 4);
         __builtin_amdgcn_sched_barrier(0);
-        half(std::integral_constant<int, 0>(), SA0, SA1, i0);
+        quarter(std::integral_constant<int, 0>(), QA, i0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);
-        SA0 = ld8(ab + i0 + 16); SA1 = ld8(ab + i0 + 20);
+        QA = ld8(ab + i0 + 8);
+        __builtin_amdgcn_sched_barrier(0);
+        quarter(std::integral_constant<int, 1>(), QB, i0 + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        QB = ld8(ab + i0 + 12);
+        __builtin_amdgcn_sched_barrier(0);
+        quarter(std::integral_constant<int, 2>(), QA, i0 + 8);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        QA = ld8(ab + i0 + 16);
         pfa = i0 + 16;
         __builtin_amdgcn_sched_barrier(0);
-        half(std::integral_constant<int, 1>(), SB0, SB1, i0 + 8);
+        quarter(std::integral_constant<int, 3>(), QB, i0 + 12);
         __builtin_amdgcn_sched_barrier(0);
         if (!all_active) {
             bool done = true;
