@@ -280,11 +280,13 @@ def main():
                                        'traffic = FETCH_SIZE + WRITE_SIZE bytes per launch from profiles/ (PMC passes of an earlier run of the same kernel; '
                                        'coefficient-table re-reads by the ring groups are served by L2 / Infinity Cache)'}
         per_kernel = {}
-        # gradient-only synthesis (curl alm = 0, shts.alm2map_spin([G, None])): 8 recurrence + 8 accumulation flop per step
+        # gradient-only synthesis (curl alm = 0, shts.alm2map_spin([G, None])): 8 recurrence + 8 accumulation flop per step;
+        # paired synthesis (general + gradient-only input on one recursion, shts.alm2map_spin_pair): 8 recurrence + 16 + 8
+        # accumulation flop per step (SURVEY's fixed count for the two transforms it replaces would be 48)
         alg = {'leg_synth0': flops_scal, 'leg_synths': flops_spin, 'leg_anal0': flops_scal, 'leg_anals': flops_spin,
-               'leg_synths_grad': flops_spin * 16. / 24.}
+               'leg_synths_grad': flops_spin * 16. / 24., 'leg_synths_pair': flops_spin * 32. / 24.}
         exe = {'leg_synth0': exec_scal, 'leg_synths': exec_spin, 'leg_anal0': exec_scal, 'leg_anals': exec_spin,
-               'leg_synths_grad': exec_spin * 16. / 24.}
+               'leg_synths_grad': exec_spin * 16. / 24., 'leg_synths_pair': exec_spin * 32. / 24.}
         for k, (m_, c_) in prof.items():
             if c_ == 0:
                 continue

@@ -64,6 +64,12 @@ int pl_alm2map_grad(pl_plan *plan, int spin, const double *almG, double *map, co
 
 /* shts.map2alm(iter=0) (shts.py:16-20) / shts.map2alm_spin (shts.py:26-30).  If fl != NULL the
  * result is multiplied by fl_l (hp.almxfl fused; filt_simple.py:400,405-406, qest.py:261-262). */
+/* Two spin-s syntheses on ONE recursion: a general input (G, C) with filter fl and a gradient-only input G2 (curl = 0)
+ * with filter fl2 -- the spin-1 legs of the minimum-variance estimator, alm2map_spin((E^WF, B^WF) w^1) and
+ * alm2map_spin((-sqrt(l(l+1)) T^WF, 0)) (qest.py:453-464,597-638).  maps4_dev = [Q | U | Q2 | U2], 4 npix doubles.
+ * Device pointers only, asynchronous on `stream`.  16 + 4 instead of 12 + 4 + 8 + 4 FMAs per recursion step. */
+int pl_alm2map_pair(pl_plan *plan, int spin, const double *alm_gc_dev, const double *fl_dev, const double *alm_g2_dev, const double *fl2_dev,
+                    double *maps4_dev, void *stream);
 int pl_map2alm(pl_plan *plan, int spin, const double *map, double *alm, const double *fl, int where, void *stream);
 
 /* Stage-level entry points: tests, stage timings, and callers that pipeline independent transforms (the Legendre stage of
@@ -80,9 +86,10 @@ int pl_map2phase(pl_plan *plan, int spin, const double *map_dev, double *phase_d
  * bench.py for the roofline numbers).  Kinds: 0 Legendre synthesis spin 0, 1 Legendre synthesis spin s,
  * 2 Legendre analysis spin 0 (+ reduction), 3 Legendre analysis spin s (+ reduction), 4 ring FFT synthesis,
  * 5 ring FFT analysis, 6 gradient-only Legendre synthesis spin s (pl_legendre_synth_grad: 16 instead of 24 flop
- * per recursion step, kept apart so that kind 1 prices full launches only).  pl_profile_read synchronises the recorded events, returns summed milliseconds and
+ * per recursion step, kept apart so that kind 1 prices full launches only), 7 paired Legendre synthesis (pl_alm2map_pair:
+ * 32 flop per step for two transforms).  pl_profile_read synchronises the recorded events, returns summed milliseconds and
  * launch counts per kind (arrays of PL_PROFILE_KINDS entries) and resets the record. */
-#define PL_PROFILE_KINDS 7
+#define PL_PROFILE_KINDS 8
 int pl_profile_enable(pl_plan *plan, int on);
 int pl_profile_read(pl_plan *plan, double *ms_sum, int64_t *counts);
 

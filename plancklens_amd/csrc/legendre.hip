@@ -316,10 +316,15 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
 // -----------------------------------------------------------------------------------------------------
 // GONLY: the curl input is identically zero (gradient legs of the temperature estimators): An = sg Ap, so the four sums
 // are combinations of Sn Ap and Sp Ap split by the parity of l -- 4 accumulation FMAs per step instead of 8.
-template <int R, bool GONLY>
+// PAIR: a second, gradient-only input (prep2) rides on the same recursion: its phase values go to entries 8 .. 15 of a
+// 16-double phase entry (a four-component phase array).  16 instead of 12 + 8 accumulation + recursion FMAs per step for the
+// two transforms (the spin-1 legs of the MV estimator: gradient of T^WF and the spin-1 leg of P^WF).
+template <int R, bool GONLY, bool PAIR = false>
 __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int spin, const double4 *__restrict__ prep,
-                                                    double *__restrict__ phase)
+                                                    double *__restrict__ phase, const double4 *__restrict__ prep2 = nullptr)
 {
+    static_assert(!(GONLY && PAIR), "PAIR = general + gradient-only");
+    constexpr int EST = PAIR ? 16 : 8;  // doubles per (ring pair, m) phase entry
     constexpr int RG = 64 * R;
     __shared__ double tile[RG * 32];  // [ring][m_local 4][8]
     const int wave = wave_id();
@@ -342,6 +347,10 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
         xn_r[k] = xn_i[k] = yn_r[k] = yn_i[k] = 0.0;
         xe_r[k] = xe_i[k] = ye_r[k] = ye_i[k] = xo_r[k] = xo_i[k] = yo_r[k] = yo_i[k] = 0.0;
     }
+    // PAIR: sums of the second input, Sp Ap2 (gx) and Sn Ap2 (gy) by the parity of l, as in the GONLY kernel
+    double gxe_r[R], gxe_i[R], gye_r[R], gye_i[R], gxo_r[R], gxo_i[R], gyo_r[R], gyo_i[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) gxe_r[k] = gxe_i[k] = gye_r[k] = gye_i[k] = gxo_r[k] = gxo_i[k] = gyo_r[k] = gyo_i[k] = 0.0;
     double sig0 = 1.0;
 
     if (m <= P.mmax && l0 <= P.lmax) {
@@ -366,6 +375,8 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
 #endif
         const d2v_t *__restrict__ abv = reinterpret_cast<const d2v_t *>(ab);
         const d4v_t *__restrict__ aav = reinterpret_cast<const d4v_t *>(aa);
+        const double4 *__restrict__ aa2 = PAIR ? prep2 + base : nullptr;  // gradient-only prep: {sg Ap2, Ap2}, only Ap2 is read
+        const d4v_t *__restrict__ aav2 = reinterpret_cast<const d4v_t *>(aa2);
         int i = 0;
         bool all_done = false;
         {
@@ -378,7 +389,8 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
         pf.start<32, 16>(aa, ab, i, nl, lane);
         double mn[R], mp[R];  // phase B: 0/1 masks of the (n, p) recursions of each ring
         // two consecutive l (even i, odd i); i stays even through phases A, B and C
-        auto pair_step = [&](auto masked, double ca0, double cb0, double ca1, double cb1, const d4v_t &a0, const d4v_t &a1) {
+        auto pair_step = [&](auto masked, double ca0, double cb0, double ca1, double cb1, const d4v_t &a0, const d4v_t &a1,
+                             const d2v_t &g0 = d2v_t{0., 0.}, const d2v_t &g1 = d2v_t{0., 0.}) {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 double vn = r[k].n1, vp = r[k].p1;
@@ -391,6 +403,10 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
                     xe_r[k] = fma(vp, a0.x, xe_r[k]); xe_i[k] = fma(vp, a0.y, xe_i[k]);
                 }
                 ye_r[k] = fma(vn, a0.z, ye_r[k]); ye_i[k] = fma(vn, a0.w, ye_i[k]);
+                if constexpr (PAIR) {
+                    gxe_r[k] = fma(vp, g0.x, gxe_r[k]); gxe_i[k] = fma(vp, g0.y, gxe_i[k]);
+                    gye_r[k] = fma(vn, g0.x, gye_r[k]); gye_i[k] = fma(vn, g0.y, gye_i[k]);
+                }
                 recs_step_fast(r[k], ca0, cb0);
                 vn = r[k].n1; vp = r[k].p1;
                 if constexpr (decltype(masked)::value) { vn *= mn[k]; vp *= mp[k]; }
@@ -402,6 +418,10 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
                     xo_r[k] = fma(vp, a1.x, xo_r[k]); xo_i[k] = fma(vp, a1.y, xo_i[k]);
                 }
                 yo_r[k] = fma(vn, a1.z, yo_r[k]); yo_i[k] = fma(vn, a1.w, yo_i[k]);
+                if constexpr (PAIR) {
+                    gxo_r[k] = fma(vp, g1.x, gxo_r[k]); gxo_i[k] = fma(vp, g1.y, gxo_i[k]);
+                    gyo_r[k] = fma(vn, g1.x, gyo_r[k]); gyo_i[k] = fma(vn, g1.y, gyo_i[k]);
+                }
                 recs_step_fast(r[k], ca1, cb1);
             }
         };
@@ -437,10 +457,12 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
             for (int h = 0; h < 2; ++h) {
                 const d8v_t c = ld8(ab + i + 4 * h);
                 const d8v_t q0 = ldc<d8v_t>(aav + i + 4 * h), q1 = ldc<d8v_t>(aav + i + 4 * h + 2);
+                d8v_t p0 = q0, p1 = q1;  // PAIR: the same four entries of the second input (only z, w are used)
+                if constexpr (PAIR) { p0 = ldc<d8v_t>(aav2 + i + 4 * h); p1 = ldc<d8v_t>(aav2 + i + 4 * h + 2); }
                 pair_step(std::true_type(), c[0], c[1], c[2], c[3], __builtin_shufflevector(q0, q0, 0, 1, 2, 3),
-                          __builtin_shufflevector(q0, q0, 4, 5, 6, 7));
+                          __builtin_shufflevector(q0, q0, 4, 5, 6, 7), d2v_t{p0[2], p0[3]}, d2v_t{p0[6], p0[7]});
                 pair_step(std::true_type(), c[4], c[5], c[6], c[7], __builtin_shufflevector(q1, q1, 0, 1, 2, 3),
-                          __builtin_shufflevector(q1, q1, 4, 5, 6, 7));
+                          __builtin_shufflevector(q1, q1, 4, 5, 6, 7), d2v_t{p1[2], p1[3]}, d2v_t{p1[6], p1[7]});
             }
 #pragma unroll
             for (int k = 0; k < R; ++k) recs_renorm_up(r[k]);
@@ -463,25 +485,31 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
                     return ldc<d4v_t>(aav + idx);
                 }
             };
+            auto ldg = [&](int idx) -> d2v_t {  // Ap2 of entry idx of the second input
+                if constexpr (PAIR) return ldc<d2v_t>(reinterpret_cast<const d2v_t *>(aav2 + idx) + 1);
+                else return d2v_t{0., 0.};
+            };
             d4v_t Aa0 = lda(i), Aa1 = lda(i + 1);
+            d2v_t Ag0 = ldg(i), Ag1 = ldg(i + 1);
             while (i + 3 < nl) {
                 pf.step<32, 16>(aa, ab, i, nl, lane);
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): set A has landed (it was issued one half trip ago) ...
                 const d2v_t B0 = ldc<d2v_t>(abv + i + 2), B1 = ldc<d2v_t>(abv + i + 3);  // ... so that B can be issued without A's uses waiting on it
                 const d4v_t Ba0 = lda(i + 2), Ba1 = lda(i + 3);
+                const d2v_t Bg0 = ldg(i + 2), Bg1 = ldg(i + 3);
                 __builtin_amdgcn_sched_barrier(0);
-                pair_step(std::false_type(), A0.x, A0.y, A1.x, A1.y, Aa0, Aa1);
+                pair_step(std::false_type(), A0.x, A0.y, A1.x, A1.y, Aa0, Aa1, Ag0, Ag1);
                 __builtin_amdgcn_sched_barrier(0);
                 const int ip = min(i + 4, nl - 2);  // clamped: the last prefetch re-reads valid entries
                 __builtin_amdgcn_s_waitcnt(0xC07F);
-                A0 = ldc<d2v_t>(abv + ip); A1 = ldc<d2v_t>(abv + ip + 1); Aa0 = lda(ip); Aa1 = lda(ip + 1);
+                A0 = ldc<d2v_t>(abv + ip); A1 = ldc<d2v_t>(abv + ip + 1); Aa0 = lda(ip); Aa1 = lda(ip + 1); Ag0 = ldg(ip); Ag1 = ldg(ip + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                pair_step(std::false_type(), B0.x, B0.y, B1.x, B1.y, Ba0, Ba1);
+                pair_step(std::false_type(), B0.x, B0.y, B1.x, B1.y, Ba0, Ba1, Bg0, Bg1);
                 __builtin_amdgcn_sched_barrier(0);
                 i += 4;
             }
             if (i + 1 < nl) {
-                pair_step(std::false_type(), A0.x, A0.y, A1.x, A1.y, Aa0, Aa1);
+                pair_step(std::false_type(), A0.x, A0.y, A1.x, A1.y, Aa0, Aa1, Ag0, Ag1);
                 i += 2;
             }
         }
@@ -505,37 +533,61 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
                     xo_r[k] = fma(vp, px, xo_r[k]); xo_i[k] = fma(vp, py, xo_i[k]);
                     yo_r[k] = fma(vn, a.z, yo_r[k]); yo_i[k] = fma(vn, a.w, yo_i[k]);
                 }
+                if constexpr (PAIR) {
+                    const double4 a2 = aa2[i];
+                    if (!odd) {
+                        gxe_r[k] = fma(vp, a2.z, gxe_r[k]); gxe_i[k] = fma(vp, a2.w, gxe_i[k]);
+                        gye_r[k] = fma(vn, a2.z, gye_r[k]); gye_i[k] = fma(vn, a2.w, gye_i[k]);
+                    } else {
+                        gxo_r[k] = fma(vp, a2.z, gxo_r[k]); gxo_i[k] = fma(vp, a2.w, gxo_i[k]);
+                        gyo_r[k] = fma(vn, a2.z, gyo_r[k]); gyo_i[k] = fma(vn, a2.w, gyo_i[k]);
+                    }
+                }
                 recs_step_careful(r[k], c_ab.x, c_ab.y);
             }
         }
         pf.drain();
     }
-    // Q = X + Y, U = i (Y - X)
+    // Q = X + Y, U = i (Y - X) -> LDS tile -> ring-major global phase array (entries of EST doubles, this transform at `off`)
+    auto emit = [&](int k, double xnr, double xni, double ynr, double yni, double xer, double xei, double xor_, double xoi,
+                    double yer, double yei, double yor, double yoi) {
+        double *t = tile + (k * 64 + lane) * 32 + wave * 8;
+        const double xs_r = sig0 * (xer - xor_), xs_i = sig0 * (xei - xoi);
+        const double ys_r = sig0 * (yer - yor), ys_i = sig0 * (yei - yoi);
+        t[0] = xnr + ynr; t[1] = xni + yni;
+        t[2] = xs_r + ys_r; t[3] = xs_i + ys_i;
+        t[4] = -(yni - xni); t[5] = ynr - xnr;
+        t[6] = -(ys_i - xs_i); t[7] = ys_r - xs_r;
+    };
+    auto store = [&](int off) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < RG * 16; c += 256) {
+            const int rl = c >> 4, part = c & 15;
+            const int ip = g * RG + rl;
+            if (ip < P.npairs) {
+                const double2 v = *reinterpret_cast<const double2 *>(tile + rl * 32 + part * 2);
+                // part = 4 m_local + (pair of doubles inside the 8-double block)
+                *reinterpret_cast<double2 *>(phase + ((int64_t)ip * P.mstride + 4 * mg + (part >> 2)) * EST + off + (part & 3) * 2) = v;
+            }
+        }
+    };
+    const double sg = (spin & 1) ? -1.0 : 1.0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        const int rl = k * 64 + lane;
-        double *t = tile + rl * 32 + wave * 8;
-        if constexpr (GONLY) {  // An = sg Ap: X_N = sg sum Sn Ap, Y_N = sum Sp Ap, X_S = sg sum sigma Sp Ap, Y_S = sum sigma Sn Ap
-            const double sg = (spin & 1) ? -1.0 : 1.0;
-            xn_r[k] = sg * (ye_r[k] + yo_r[k]); xn_i[k] = sg * (ye_i[k] + yo_i[k]);
-            yn_r[k] = xe_r[k] + xo_r[k]; yn_i[k] = xe_i[k] + xo_i[k];
-            xe_r[k] *= sg; xe_i[k] *= sg; xo_r[k] *= sg; xo_i[k] *= sg;
-        }
-        const double xs_r = sig0 * (xe_r[k] - xo_r[k]), xs_i = sig0 * (xe_i[k] - xo_i[k]);
-        const double ys_r = sig0 * (ye_r[k] - yo_r[k]), ys_i = sig0 * (ye_i[k] - yo_i[k]);
-        t[0] = xn_r[k] + yn_r[k]; t[1] = xn_i[k] + yn_i[k];
-        t[2] = xs_r + ys_r; t[3] = xs_i + ys_i;
-        t[4] = -(yn_i[k] - xn_i[k]); t[5] = yn_r[k] - xn_r[k];
-        t[6] = -(ys_i - xs_i); t[7] = ys_r - xs_r;
+        if constexpr (GONLY)  // An = sg Ap: X_N = sg sum Sn Ap, Y_N = sum Sp Ap, X_S = sg sum sigma Sp Ap, Y_S = sum sigma Sn Ap
+            emit(k, sg * (ye_r[k] + yo_r[k]), sg * (ye_i[k] + yo_i[k]), xe_r[k] + xo_r[k], xe_i[k] + xo_i[k],
+                 sg * xe_r[k], sg * xe_i[k], sg * xo_r[k], sg * xo_i[k], ye_r[k], ye_i[k], yo_r[k], yo_i[k]);
+        else
+            emit(k, xn_r[k], xn_i[k], yn_r[k], yn_i[k], xe_r[k], xe_i[k], xo_r[k], xo_i[k], ye_r[k], ye_i[k], yo_r[k], yo_i[k]);
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < RG * 16; c += 256) {
-        const int rl = c >> 4, part = c & 15;
-        const int ip = g * RG + rl;
-        if (ip < P.npairs) {
-            double2 v = *reinterpret_cast<const double2 *>(tile + rl * 32 + part * 2);
-            *reinterpret_cast<double2 *>(phase + ((int64_t)ip * P.mstride + 4 * mg) * 8 + part * 2) = v;
-        }
+    store(0);
+    if constexpr (PAIR) {  // the gradient-only input, same formulas as GONLY, into doubles 8 .. 15 of the entries
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+            emit(k, sg * (gye_r[k] + gyo_r[k]), sg * (gye_i[k] + gyo_i[k]), gxe_r[k] + gxo_r[k], gxe_i[k] + gxo_i[k],
+                 sg * gxe_r[k], sg * gxe_i[k], sg * gxo_r[k], sg * gxo_i[k], gye_r[k], gye_i[k], gyo_r[k], gyo_i[k]);
+        store(8);
     }
 }
 
@@ -1174,6 +1226,18 @@ static void launch_synths_r(const DevPlan &P, const DevSpinTab &S, int spin, con
     const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
     hipLaunchKernelGGL((k_leg_synths<R, GONLY>), dim3(ngroups * nmg), dim3(256), 0, st, P, S, spin,
                        reinterpret_cast<const double4 *>(prep), phase);
+}
+
+// general input (prep) + gradient-only input (prep2) on one recursion; phase entries of 16 doubles (four components)
+void launch_synths_pair(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st)
+{
+    const int ngroups1 = (P.npairs + 63) / 64, ngroups2 = (P.npairs + 127) / 128, nmg = (P.mmax + 4) / 4;
+    if (rs_synth(P) == 1)
+        hipLaunchKernelGGL((k_leg_synths<1, false, true>), dim3(ngroups1 * nmg), dim3(256), 0, st, P, S, spin,
+                           reinterpret_cast<const double4 *>(prep), phase, reinterpret_cast<const double4 *>(prep2));
+    else
+        hipLaunchKernelGGL((k_leg_synths<2, false, true>), dim3(ngroups2 * nmg), dim3(256), 0, st, P, S, spin,
+                           reinterpret_cast<const double4 *>(prep), phase, reinterpret_cast<const double4 *>(prep2));
 }
 
 void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st, bool gonly)

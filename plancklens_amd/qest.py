@@ -311,14 +311,17 @@ class library(object):
         ln = (lambda i: shts.lane(i if lanes else 0))
         with ln(1):
             tmap = f2map1.get_irestmap(idx)
-        with ln(2):
-            gt, ct = f2map2.get_gtmap(idx, k='p')
         with ln(3):
             rep, imp = f2map1.get_irespmap(idx)
         with ln(4):
             g3, c3 = f2map2.get_gpmap(idx, 3, k='p')
-        with ln(5):
-            g1, c1 = f2map2.get_gpmap(idx, 1, k='p')
+        if lanes:
+            with ln(2):
+                gt, ct = f2map2.get_gtmap(idx, k='p')
+            with ln(5):
+                g1, c1 = f2map2.get_gpmap(idx, 1, k='p')
+        else:  # the two spin-1 legs share one Legendre recursion
+            (gt, ct), (g1, c1) = f2map2.get_gt_gp1maps(idx, k='p')
         shts.join_lanes()
         dre, dim = dev.qe_lens_product((tmap, gt, ct), (rep, imp, g3, c3, g1, c1))  # all nine leg maps in one pass
         del tmap, gt, ct, rep, imp, g3, c3, g1, c1
@@ -470,12 +473,39 @@ class lib_filt2map(object):
         shts.join_lanes()
         return True
 
+    def _gt_alm(self, idx, k=None, xfilt=None):
+        """gradient alm of the spin-1 temperature leg (its curl is zero), or None when it vanishes identically"""
+        assert xfilt is None, 'not implemented'
+        return self._alm('tmliklm', idx)
+
+    def _gp_alms(self, idx, k=None, xfilt=None):
+        """(G, C) of the spin-1 / spin-3 polarization legs (C may be None: no curl), or None when they vanish identically"""
+        assert xfilt is None, 'not implemented'
+        G, C = self._alm('emliklm', idx), self._alm('bmliklm', idx)
+        assert G.numel() == C.numel()
+        return G, C
+
     def get_gtmap(self, idx, k=None, xfilt=None):
         """alm2map_spin_1(-sqrt(l(l+1)) T^WF_lm, 0) (qest.py:453-464)."""
-        assert xfilt is None, 'not implemented'
-        mlik = self._alm('tmliklm', idx)
+        mlik = self._gt_alm(idx, k=k, xfilt=xfilt)
+        if mlik is None:
+            return self._zeros()
         lmax = self._lmax(mlik)
         return shts.alm2map_spin([mlik, None], self.nside, 1, lmax, fl=_lens_weight(lmax))  # no curl: gradient-only synthesis
+
+    def get_gt_gp1maps(self, idx, k=None):
+        """(gt, ct), (g1, c1): the two spin-1 legs of the minimum-variance estimator, get_gtmap and get_gpmap(spin 1), on one
+        Legendre recursion when both exist with the same band-limit (pl_alm2map_pair)."""
+        mlik, gc = self._gt_alm(idx, k=k), self._gp_alms(idx, k=k)
+        if mlik is None or gc is None or gc[1] is None or self._lmax(mlik) != self._lmax(gc[0]) or shts._lane_active():
+            return self.get_gtmap(idx, k=k), self.get_gpmap(idx, 1, k=k)
+        lmax = self._lmax(mlik)
+        p1, t1 = shts.alm2map_spin_pair(list(gc), mlik, self.nside, 1, lmax, fl=_spin_weight(1, lmax), fl2=_lens_weight(lmax))
+        return t1, p1
+
+    def _zeros(self):
+        z = torch.zeros(hp.nside2npix(self.nside), dtype=torch.float64, device=dev.device())
+        return [z, z.clone()]
 
     def get_tmap(self, idx, joint=False):
         return shts.alm2map(self._alm('tmliklm', idx), self.nside)
@@ -487,11 +517,11 @@ class lib_filt2map(object):
     def get_gpmap(self, idx, spin, k=None, xfilt=None):
         """alm2map_spin_s(w^s_l (E^WF, B^WF)), s = 1, 3 (qest.py:481-504)."""
         assert spin in [1, 3]
-        assert xfilt is None, 'not implemented'
-        G, C = self._alm('emliklm', idx), self._alm('bmliklm', idx)
-        assert G.numel() == C.numel()
-        lmax = self._lmax(G)
-        return shts.alm2map_spin([G, C], self.nside, spin, lmax, fl=_spin_weight(spin, lmax))
+        gc = self._gp_alms(idx, k=k, xfilt=xfilt)
+        if gc is None:
+            return self._zeros()
+        lmax = self._lmax(gc[0])
+        return shts.alm2map_spin(list(gc), self.nside, spin, lmax, fl=_spin_weight(spin, lmax))  # C None: gradient-only synthesis
 
     def get_irestmap(self, idx, xfilt=None):
         if xfilt is not None:
@@ -538,12 +568,8 @@ class lib_filt2map_sepTP(lib_filt2map):
             G = G + dev.almxfl(self._alm('tlm', idx), self.clte)
         return shts.alm2map_spin([G, C], self.nside, 2, self._lmax(G))
 
-    def _zeros(self):
-        z = torch.zeros(hp.nside2npix(self.nside), dtype=torch.float64, device=dev.device())
-        return [z, z.clone()]
-
-    def get_gtmap(self, idx, k=None, xfilt=None):
-        """Spin-1 gradient leg of T^WF (+ C^TE Eb for k = 'p'), with optional 0/1 field selectors (qest.py:566-595)."""
+    def _gt_alm(self, idx, k=None, xfilt=None):
+        """Gradient alm of the spin-1 leg of T^WF (+ C^TE Eb for k = 'p'), with optional 0/1 field selectors (qest.py:566-595)."""
         assert k in ['ptt', 'p'], k
         if xfilt is not None:
             assert isinstance(xfilt, dict) and 't' in xfilt.keys()
@@ -561,14 +587,12 @@ class lib_filt2map_sepTP(lib_filt2map):
                 telm = dev.almxfl(telm, xfilt['e'])
             mlik = telm if mlik is None else mlik + telm
         if mlik is None or (xfilt is not None and not bool(torch.any(mlik != 0))):
-            return self._zeros()
-        lmax = self._lmax(mlik)
-        return shts.alm2map_spin([mlik, None], self.nside, 1, lmax, fl=_lens_weight(lmax))  # no curl: gradient-only synthesis
+            return None
+        return mlik
 
-    def get_gpmap(self, idx, spin, k=None, xfilt=None):
-        """Spin-1 / spin-3 legs of (E^WF (+ C^TE Tb for k = 'p'), B^WF) (qest.py:597-638)."""
+    def _gp_alms(self, idx, k=None, xfilt=None):
+        """(G, C) of the spin-1 / spin-3 legs of (E^WF (+ C^TE Tb for k = 'p'), B^WF) (qest.py:597-638)."""
         assert k in ['p_p', 'p'], k
-        assert spin in [1, 3]
         if xfilt is not None:
             assert isinstance(xfilt, dict) and all(f in xfilt.keys() for f in 'teb')
         need_p = xfilt is None or np.any(xfilt['e']) or np.any(xfilt['b'])
@@ -583,6 +607,5 @@ class lib_filt2map_sepTP(lib_filt2map):
                 G_t = dev.almxfl(G_t, xfilt['t'])
             G = G_t if G is None else G + G_t
         if G is None or (xfilt is not None and not (bool(torch.any(G != 0)) or (C is not None and bool(torch.any(C != 0))))):
-            return self._zeros()
-        lmax = self._lmax(G)
-        return shts.alm2map_spin([G, C], self.nside, spin, lmax, fl=_spin_weight(spin, lmax))  # C None: gradient-only synthesis
+            return None
+        return G, C

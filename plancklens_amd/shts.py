@@ -71,7 +71,7 @@ class Plan(object):
     def phase_doubles(self, spin):
         return int(_lib.lib().pl_plan_phase_doubles(self.h, int(spin)))
 
-    PROFILE_KINDS = ('leg_synth0', 'leg_synths', 'leg_anal0', 'leg_anals', 'fft_synth', 'fft_anal', 'leg_synths_grad')
+    PROFILE_KINDS = ('leg_synth0', 'leg_synths', 'leg_anal0', 'leg_anals', 'fft_synth', 'fft_anal', 'leg_synths_grad', 'leg_synths_pair')
 
     def profile(self, on=True):
         self._profiling = bool(on)
@@ -308,6 +308,23 @@ def alm2map_spin(gclm, nside, spin, lmax, mmax=None, fl=None):
     else:
         out = _synth(int(spin), _stack(gclm), nside, lmax, fl=fl)
     return [out[0], out[1]]
+
+
+def alm2map_spin_pair(gclm, glm2, nside, spin, lmax, fl=None, fl2=None):
+    """Two spin-s syntheses on one Legendre recursion (pl_alm2map_pair, device arrays only): alm2map_spin(gclm, ...) with
+    filter fl and alm2map_spin([glm2, 0], ...) with filter fl2.  Returns ([Q, U], [Q2, U2]); equal to the two separate
+    calls to rounding (the sums are formed in the same order)."""
+    assert spin > 0 and len(gclm) == 2
+    a = _stack(gclm)
+    assert _is_dev(a) and _is_dev(glm2), 'alm2map_spin_pair works on device arrays'
+    plan = get_plan(nside, lmax)
+    a = a.to(torch.complex128).contiguous()
+    g2 = glm2.to(torch.complex128).contiguous()
+    assert a.numel() == 2 * plan.nalm and g2.numel() == plan.nalm, (a.shape, g2.shape, plan.nalm)
+    f, f2 = _fl_arg(fl, lmax, True), _fl_arg(fl2, lmax, True)
+    out = torch.empty((4, plan.npix), dtype=torch.float64, device=a.device)
+    _lib.check(_lib.lib().pl_alm2map_pair(plan.h, int(spin), _ptr(a), _ptr(f), _ptr(g2), _ptr(f2), _ptr(out), _stream()))
+    return [out[0], out[1]], [out[2], out[3]]
 
 
 def map2alm_spin(maps, spin, lmax=None, mmax=None, fl=None):

@@ -216,3 +216,19 @@ def test_gradient_only_synthesis_equals_zero_curl(shts, spin, nside, lmax):
     assert relrms(out, ref) < 1e-13
     outd = shts.alm2map_spin([torch.from_numpy(g).cuda(), None], nside, spin, lmax, fl=fl)
     assert relrms(np.stack([o.cpu().numpy() for o in outd]), ref) < 1e-13
+
+
+@pytest.mark.parametrize('spin', [1, 2, 3])
+@pytest.mark.parametrize('nside,lmax', [(8, 16), (32, 64), (64, 150), (256, 300), (512, 700)])
+def test_paired_synthesis_equals_two_calls(shts, spin, nside, lmax):
+    """pl_alm2map_pair (general + gradient-only input on one recursion) against the two separate transforms."""
+    import torch
+    from plancklens_amd import dev
+    rng = np.random.default_rng(spin * 7 + nside + lmax)
+    g, c, g2 = (dev.to_dev(random_alm(rng, lmax, spin)) for _ in range(3))
+    fl, fl2 = rng.uniform(0.5, 1.5, lmax + 1), rng.uniform(0.5, 1.5, lmax + 1)
+    (q, u), (q2, u2) = shts.alm2map_spin_pair([g, c], g2, nside, spin, lmax, fl=fl, fl2=fl2)
+    rq, ru = shts.alm2map_spin([g, c], nside, spin, lmax, fl=fl)
+    rq2, ru2 = shts.alm2map_spin([g2, None], nside, spin, lmax, fl=fl2)
+    for a, b in ((q, rq), (u, ru), (q2, rq2), (u2, ru2)):
+        assert relrms(dev.to_host(a), dev.to_host(b)) < 1e-13
