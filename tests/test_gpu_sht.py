@@ -232,3 +232,33 @@ def test_paired_synthesis_equals_two_calls(shts, spin, nside, lmax):
     rq2, ru2 = shts.alm2map_spin([g2, None], nside, spin, lmax, fl=fl2)
     for a, b in ((q, rq), (u, ru), (q2, rq2), (u2, ru2)):
         assert relrms(dev.to_host(a), dev.to_host(b)) < 1e-13
+
+
+@pytest.mark.parametrize('nside,lmax', [(256, 767), (512, 1535)])
+def test_adjointness_at_lmax_3nside_minus_1(shts, nside, lmax):
+    """<m, Y a> = npix / 4 pi <Y^t m, a> (the identity opfilt_* relies on) where every ring is aliased (lmax = 3 nside - 1),
+    all spins, and the paired synthesis against its two transforms at the same size."""
+    import torch
+    from plancklens_amd import dev, hp
+    rng = np.random.default_rng(nside + lmax)
+    n, npix = hp.Alm.getsize(lmax), 12 * nside ** 2
+    w = torch.full((n,), 2., dtype=torch.float64, device='cuda')
+    w[:lmax + 1] = 1.
+    for spin in (0, 1, 2, 3):
+        if spin == 0:
+            a = dev.to_dev(random_alm(rng, lmax, 0))
+            m = torch.randn(npix, dtype=torch.float64, device='cuda')
+            lhs = float(torch.dot(m, shts.alm2map(a, nside, lmax=lmax)))
+            rhs = float((w * (a.conj() * shts.map2alm(m, lmax=lmax, iter=0)).real).sum()) * npix / (4 * np.pi)
+        else:
+            g, c = dev.to_dev(random_alm(rng, lmax, spin)), dev.to_dev(random_alm(rng, lmax, spin))
+            m = torch.randn((2, npix), dtype=torch.float64, device='cuda')
+            q, u = shts.alm2map_spin([g, c], nside, spin, lmax)
+            lhs = float(torch.dot(m[0], q) + torch.dot(m[1], u))
+            bg, bc = shts.map2alm_spin([m[0], m[1]], spin, lmax=lmax)
+            rhs = float((w * ((g.conj() * bg).real + (c.conj() * bc).real)).sum()) * npix / (4 * np.pi)
+            (q1, u1), (q2, u2) = shts.alm2map_spin_pair([g, c], c, nside, spin, lmax)
+            r2 = shts.alm2map_spin([c, None], nside, spin, lmax)
+            for x, y in ((q1, q), (u1, u), (q2, r2[0]), (u2, r2[1])):
+                assert float((x - y).abs().max() / y.abs().max()) < 1e-12
+        assert abs(lhs / rhs - 1) < 1e-11, (spin, lhs, rhs)
