@@ -74,7 +74,8 @@ int pl_map2alm(pl_plan *plan, int spin, const double *map, double *alm, const do
 
 /* Stage-level entry points: tests, stage timings, and callers that pipeline independent transforms (the Legendre stage of
  * one on the caller's stream while the ring FFTs of another run on a second stream and a fork of the plan).
- * phase buffer: [npairs][mstride][ncomp][4] doubles = (F_north re, im, F_south re, im). */
+ * phase buffer: [npairs][ncomp][mstride][4] doubles = (F_north re, im, F_south re, im): the orders of one component of
+ * one ring pair are contiguous. */
 int64_t pl_plan_phase_doubles(const pl_plan *plan, int spin);
 int pl_legendre_synth(pl_plan *plan, int spin, const double *alm_dev, const double *fl_dev, double *phase_dev, void *stream);
 int pl_legendre_synth_grad(pl_plan *plan, int spin, const double *almG_dev, const double *fl_dev, double *phase_dev, void *stream); /* see pl_alm2map_grad */

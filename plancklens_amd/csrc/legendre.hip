@@ -312,19 +312,19 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
 }
 
 // -----------------------------------------------------------------------------------------------------
-// synthesis, spin s: phase entry = {Q_N re, im, Q_S re, im, U_N re, im, U_S re, im}
+// synthesis, spin s: LDS tile entry = {Q_N re, im, Q_S re, im, U_N re, im, U_S re, im}; global phase array [pair][Q | U][m][4]
 // -----------------------------------------------------------------------------------------------------
 // GONLY: the curl input is identically zero (gradient legs of the temperature estimators): An = sg Ap, so the four sums
 // are combinations of Sn Ap and Sp Ap split by the parity of l -- 4 accumulation FMAs per step instead of 8.
-// PAIR: a second, gradient-only input (prep2) rides on the same recursion: its phase values go to entries 8 .. 15 of a
-// 16-double phase entry (a four-component phase array).  16 instead of 12 + 8 accumulation + recursion FMAs per step for the
+// PAIR: a second, gradient-only input (prep2) rides on the same recursion: its phase values are components 2 and 3 of a
+// four-component phase array.  16 instead of 12 + 8 accumulation + recursion FMAs per step for the
 // two transforms (the spin-1 legs of the MV estimator: gradient of T^WF and the spin-1 leg of P^WF).
 template <int R, bool GONLY, bool PAIR = false>
 __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int spin, const double4 *__restrict__ prep,
                                                     double *__restrict__ phase, const double4 *__restrict__ prep2 = nullptr)
 {
     static_assert(!(GONLY && PAIR), "PAIR = general + gradient-only");
-    constexpr int EST = PAIR ? 16 : 8;  // doubles per (ring pair, m) phase entry
+    constexpr int EST = PAIR ? 16 : 8;  // 4 doubles x number of components of the phase array
     constexpr int RG = 64 * R;
     __shared__ double tile[RG * 32];  // [ring][m_local 4][8]
     const int wave = wave_id();
@@ -567,7 +567,9 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
             if (ip < P.npairs) {
                 const double2 v = *reinterpret_cast<const double2 *>(tile + rl * 32 + part * 2);
                 // part = 4 m_local + (pair of doubles inside the 8-double block)
-                *reinterpret_cast<double2 *>(phase + ((int64_t)ip * P.mstride + 4 * mg + (part >> 2)) * EST + off + (part & 3) * 2) = v;
+                // phase array [ring pair][component][m][4]: components (off / 4) + 0 (doubles 0-3 of the block) and + 1 (4-7)
+                *reinterpret_cast<double2 *>(phase + ((((int64_t)ip * (EST / 4) + (off >> 2) + ((part >> 1) & 1)) * P.mstride) + 4 * mg + (part >> 2)) * 4 +
+                                             (part & 1) * 2) = v;
             }
         }
     };
@@ -929,7 +931,8 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
         const int rl = c >> 4, part = c & 15;
         const int ip = g * RG + rl;
         double2 v = make_double2(0., 0.);
-        if (ip < P.npairs) v = *reinterpret_cast<const double2 *>(phase + ((int64_t)ip * P.mstride + 4 * mg) * 8 + part * 2);
+        if (ip < P.npairs)  // phase array [ring pair][component 2][m][4] -> tile [ring][m_local 4][Q 4 | U 4]
+            v = *reinterpret_cast<const double2 *>(phase + ((((int64_t)ip * 2 + ((part >> 1) & 1)) * P.mstride) + 4 * mg + (part >> 2)) * 4 + (part & 1) * 2);
         *reinterpret_cast<double2 *>(tile + rl * 32 + part * 2) = v;
     }
     __syncthreads();

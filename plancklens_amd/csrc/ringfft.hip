@@ -274,8 +274,8 @@ __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int
     const int ml = min(mlim[ip], P.mmax);
     const bool shifted = P.phi0[ip] != 0.0;
     const double inv_n = 1.0 / n;
-    const int estride = 4 * ncomp;
-    const double *__restrict__ ph = phase + (int64_t)ip * P.mstride * estride + comp * 4;
+    constexpr int estride = 4;  // phase array [ring pair][component][m][N re, N im, S re, S im]: a component's orders are contiguous
+    const double *__restrict__ ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * estride;
     double2 *twl = F.twl_cap ? ws + (B4 ? 4 : 1) * F.Lmax : nullptr;
     if (twl) fft_build_twl<NT>(twl, M ? M : q, F.tw, F.Mtw);
 
@@ -386,8 +386,8 @@ __global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int
     const int ml = min(mlim[ip], P.mmax);
     const bool shifted = P.phi0[ip] != 0.0;
     const double inv_n = 1.0 / n;
-    const int estride = 4 * ncomp;
-    double *__restrict__ ph = phase + (int64_t)ip * P.mstride * estride + comp * 4;
+    constexpr int estride = 4;  // phase array [ring pair][component][m][N re, N im, S re, S im]
+    double *__restrict__ ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * estride;
     double2 *twl = F.twl_cap ? ws + (B4 ? 4 : 1) * F.Lmax : nullptr;
     if (twl) fft_build_twl<NT>(twl, M ? M : q, F.tw, F.Mtw);
     const double wgt = 0.5 * 4.0 * 3.14159265358979323846 / (double)P.npix;  // includes the 1/2 of the N/S split
@@ -650,8 +650,8 @@ __global__ __launch_bounds__(N / 8, 2) void k_phase2map_fast(DevPlan P, DevFFT F
     const int ml = min(mlim[ip], P.mmax);
     const bool shifted = P.phi0[ip] != 0.0;
     const double inv_n = 1.0 / n;
-    const int estride = 4 * ncomp;
-    const double *__restrict__ ph = phase + (int64_t)ip * P.mstride * estride + comp * 4;
+    constexpr int estride = 4;  // phase array [ring pair][component][m][N re, N im, S re, S im]: a component's orders are contiguous
+    const double *__restrict__ ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * estride;
     Tw8<N> tw;
     tw8_load<N>(tw, tl0, F.tw, F.Mtw);
 
@@ -753,8 +753,8 @@ __global__ __launch_bounds__(N / 8, 2) void k_map2phase_fast(DevPlan P, DevFFT F
     const int ml = min(mlim[ip], P.mmax);
     const bool shifted = P.phi0[ip] != 0.0;
     const double inv_n = 1.0 / n;
-    const int estride = 4 * ncomp;
-    double *ph = phase + (int64_t)ip * P.mstride * estride + comp * 4;
+    constexpr int estride = 4;  // phase array [ring pair][component][m][N re, N im, S re, S im]
+    double *ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * estride;
     const double wgt = 0.5 * 4.0 * 3.14159265358979323846 / (double)P.npix;  // includes the 1/2 of the N/S split
     const double *mp = map + (int64_t)comp * P.npix;  // no __restrict__: see k_phase2map_fast
     const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];

@@ -29,8 +29,8 @@ def ralm(rng, lmax, lmin=0):
 
 
 def gpu_phase_to_oracle(ph, npairs, mstride, ncomp, lmax):
-    """[pair][mstride][ncomp][4] doubles -> [comp][slot=2*pair][m] complex"""
-    p = ph.reshape(npairs, mstride, ncomp, 4)[:, :lmax + 1]
+    """[pair][ncomp][mstride][4] doubles -> [comp][slot=2*pair][m] complex"""
+    p = ph.reshape(npairs, ncomp, mstride, 4).transpose(0, 2, 1, 3)[:, :lmax + 1]
     out = np.zeros((ncomp, 2 * npairs, lmax + 1), dtype=complex)
     for c in range(ncomp):
         out[c, 0::2] = p[:, :, c, 0] + 1j * p[:, :, c, 1]
@@ -45,7 +45,7 @@ def oracle_phase_to_gpu(po, npairs, mstride, ncomp, lmax):
         p[:, :lmax + 1, c, 1] = po[c, 0::2].imag
         p[:, :lmax + 1, c, 2] = po[c, 1::2].real
         p[:, :lmax + 1, c, 3] = po[c, 1::2].imag
-    return p
+    return np.ascontiguousarray(p.transpose(0, 2, 1, 3))  # device layout [pair][ncomp][mstride][4]
 
 
 def stage_tests(nside, lmax, spins=(0, 1, 2, 3)):
