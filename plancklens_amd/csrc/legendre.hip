@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
             emit(k, xn_r[k], xn_i[k], yn_r[k], yn_i[k], xe_r[k], xe_i[k], xo_r[k], xo_i[k], ye_r[k], ye_i[k], yo_r[k], yo_i[k]);
     }
     store(0);
-    if constexpr (PAIR) {  // the gradient-only input, same formulas as GONLY, into doubles 8 .. 15 of the entries
+    if constexpr (PAIR) {  // the gradient-only input, same formulas as GONLY, into components 2 and 3 of the phase array
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < R; ++k)
