@@ -33,8 +33,8 @@ if ROOT not in sys.path:
 FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 vector (= matrix) peak; SURVEY.md 8(d)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 # k_leg_synths, spin 2, nside = lmax = 2048: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), bytes per launch
-# (profiles/round1_g_pmc_traffic.csv; refreshed whenever the kernel changes materially)
-SYNTHS_TRAFFIC_BYTES = (430329 + 373984) * 1024
+# (profiles/round1_h_pmc_traffic.csv; refreshed whenever the kernel changes materially)
+SYNTHS_TRAFFIC_BYTES = (430280 + 373984) * 1024
 
 
 def fma_ceilings():
