@@ -73,6 +73,9 @@ def parse():
     ap.add_argument('--nside', type=int, default=2048)
     ap.add_argument('--lmax', type=int, default=2048)
     ap.add_argument('--key', type=str, default='p')
+    ap.add_argument('--lmax-qlm', type=int, default=None, help='band-limit of the output qlm (default: lmax)')
+    ap.add_argument('--qe-only', action='store_true',
+                    help='time the estimator from filtered alms that are already resident (the cost of a further key in the reference, qest.py:184-185)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     return ap.parse_args()
@@ -181,7 +184,7 @@ def main():
     from plancklens_amd.filt import filt_simple
 
     nside, lmax, key = args.nside, args.lmax, args.key
-    lmax_qlm = lmax
+    lmax_qlm = lmax if args.lmax_qlm is None else args.lmax_qlm
     cl_len = utils.camb_clfile(os.path.join(ROOT, 'plancklens_amd', 'data', 'cls', 'FFP10_wdipole_lensedCls.dat'), lmax=lmax)
     transf = hp.gauss_beam(5. / 60. / 180. * np.pi, lmax=lmax)
     nlev_t, nlev_p, lmin_ivf = 35., 55., 100
@@ -206,11 +209,13 @@ def main():
 
     def step():
         idx = state['idx']
-        state['idx'] += world                      # jobs[rank::size]
+        if not args.qe_only:
+            state['idx'] += world                  # jobs[rank::size]
         G = qlms.get_sim_qlm(key, idx)             # host array: filter + QE + device-to-host copy
         C = qlms.get_sim_qlm('x' + key[1:], idx)   # curl comes out of the same evaluation
         qlms._mem.clear()
-        ivfs._dev_cache.clear()
+        if not args.qe_only:
+            ivfs._dev_cache.clear()
         state['last'] = (G, C)
 
     def sync_all():
@@ -260,7 +265,8 @@ def main():
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': "'%s' MV quadratic estimator from T,Q,U maps: isotropic filter + qest.library_sepTP, "
                                    "nside=%d lmax_ivf=%d lmax_qlm=%d, 9 SHTs (2 scalar + 7 spin pairs) per reconstruction (BASELINE.json headline config)"
-                                   % (key, nside, lmax, lmax_qlm),
+                                   % (key, nside, lmax, lmax_qlm) +
+                                   (' -- QE-ONLY variant: filtered alms already resident, the filter transforms are not timed' if args.qe_only else ''),
                        'nside': nside, 'lmax': lmax, 'lmax_qlm': lmax_qlm, 'key': key, 'sims_per_gpu': args.steps,
                        'parallelism': 'sim-sharded x%d' % world},
         }
