@@ -4,7 +4,8 @@ filtering, the three QE libraries (dd / ds / ss), their spectra libraries -- on 
 What differs from the reference file, and why (hard part 6): the FFP10 simulations live on NERSC
 ($CFS) and hp.pixwin needs a data file packaged inside healpy, neither of which exists here; the skies are seeded
 Gaussian realisations of the fiducial lensed spectra (sims.cmbs.sims_cmb_unl) and the transfer function is the 5'
-beam alone.  nhl / n1 / qresp (analytic 1-D Wigner integrals) are outside the hot path and not instantiated.
+beam alone.  The analytic response and N0 libraries (qresp, nhl) are instantiated as in the reference; the N1 library
+(n1, Fortran kernels outside the hot path) is not.
 Sizes can be reduced through the environment for quick runs: PLENS_NSIDE, PLENS_LMAX, PLENS_NSIMS.
 """
 import os

@@ -201,12 +201,13 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
     rc = rc || upload(p, mlim, &P.mlim0);
     if (rc) { pl_plan_destroy(p); return 1; }
 
-    // FFT tables: ring lengths 4 q, q = 1 .. nside.  In each direction every ring pair is served either by a
-    // register-resident kernel of transform size N = 256 << c (ringfft.hip) or, for the short polar rings, aliased rings
-    // and anything unusual, by the LDS-resident generic kernel.  PLSHTS_FFT_LEGACY=1 sends every pair to the generic kernel.
+    // FFT tables: ring lengths 4 q, q = 1 .. nside.  Every ring pair is served either by a register-resident kernel of
+    // transform size N = 256 << c (ringfft.hip; synthesis and analysis share the class lists and the band-limited
+    // Bluestein tables) or, for the short polar rings, aliased rings and anything unusual, by the LDS-resident generic
+    // kernel.  PLSHTS_FFT_LEGACY=1 sends every pair to the generic kernel.
     DevFFT &F = p->F;
     const bool all_legacy = getenv("PLSHTS_FFT_LEGACY") && atoi(getenv("PLSHTS_FFT_LEGACY")) != 0;
-    std::vector<int> K2of(nside + 1, 0), MofS(nside + 1, 0), MofA(nside + 1, 0), clsS(nside + 1, -1), clsA(nside + 1, -1);
+    std::vector<int> K2of(nside + 1, 0), MofA(nside + 1, 0), clsA(nside + 1, -1);
     {
         std::vector<int> mlmax(nside + 1, 0);
         for (int i = 0; i < g.npairs; ++i) {
@@ -217,17 +218,15 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
                 if (ml > mlmax[q]) mlmax[q] = ml;
             }
         }
-        auto cls_of = [](int N) { int c = -1; if (N >= 256 && N <= 4096) { c = 0; while ((256 << c) < N) ++c; } return c; };
+        auto cls_of = [](int N) { int c = -1; if (N >= 256 && N <= (256 << (kFftClasses - 1))) { c = 0; while ((256 << c) < N) ++c; } return c; };
         for (int q = 1; q <= nside; ++q) {
-            const int K = (mlmax[q] + 3) / 4 + 1;  // analysis: sub-DFT bins c = k1 or k1 - q with 4 |c| <= mlim + 3
+            const int K = (mlmax[q] + 3) / 4 + 1;  // sub-DFT bins c = k1 or k1 - q with 4 |c| <= mlim + 3
             K2of[q] = K;
             if (all_legacy || 2 * K + 1 >= q) continue;                 // aliased ring (mlim >= n / 2 - 5): generic kernel
-            if ((q & (q - 1)) == 0) { clsS[q] = clsA[q] = cls_of(q); continue; }  // the ring's own sub-DFT length
-            int Ns = 256, Na = 256;
-            while (Ns < 2 * q - 1) Ns <<= 1;           // synthesis: every sub-DFT input is non-zero
-            while (Na < q + 2 * K + 1) Na <<= 1;       // analysis: only the 2 K + 1 in-band outputs are needed
-            clsS[q] = cls_of(Ns); clsA[q] = cls_of(Na);
-            if (clsS[q] >= 0) MofS[q] = Ns;
+            if ((q & (q - 1)) == 0) { clsA[q] = cls_of(q); continue; }  // the ring's own sub-DFT length
+            int Na = 256;
+            while (Na < q + 2 * K + 1) Na <<= 1;       // only the 2 K + 1 in-band bins are non-zero (synthesis) / needed (analysis)
+            clsA[q] = cls_of(Na);
             if (clsA[q] >= 0) MofA[q] = Na;
         }
     }
@@ -236,25 +235,23 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
         std::vector<int> npairs_q(nside + 1, 0);
         for (int i = 0; i < g.npairs; ++i) npairs_q[g.nphi[i] / 4] += 1;
         for (int q = 1; q <= nside; ++q)
-            if ((q & (q - 1)) == 0 && npairs_q[q] < 8) clsS[q] = clsA[q] = -1;
+            if ((q & (q - 1)) == 0 && npairs_q[q] < 8) clsA[q] = -1;
     }
-    std::vector<int> listS[5], listA[5], dirS[5], dirA[5], legacyS, legacyA;
+    std::vector<int> listA[kFftClasses], dirA[kFftClasses], legacyA;
     for (int i = g.npairs - 1; i >= 0; --i) {  // longest rings first
         const int q = g.nphi[i] / 4;
         const bool direct = (q & (q - 1)) == 0;
-        if (clsS[q] >= 0) (direct ? dirS : listS)[clsS[q]].push_back(i); else legacyS.push_back(i);
         if (clsA[q] >= 0) (direct ? dirA : listA)[clsA[q]].push_back(i); else legacyA.push_back(i);
     }
-    std::vector<int> Mof(nside + 1, 0), qlist, qlistS, qlistA;
-    std::vector<int64_t> woff(nside + 1, 0), coff(nside + 1, 0), coffS(nside + 1, 0), coffA(nside + 1, 0);
-    int64_t nw = 0, nc = 0, ncS = 0, ncA = 0;
+    std::vector<int> Mof(nside + 1, 0), qlist, qlistA;
+    std::vector<int64_t> woff(nside + 1, 0), coff(nside + 1, 0), coffA(nside + 1, 0);
+    int64_t nw = 0, nc = 0, ncA = 0;
     int Lmax = 1, M2max = 2;
     for (int q = 1; q <= nside; ++q) {
-        const bool generic = clsS[q] < 0 || clsA[q] < 0;  // some direction of this ring length runs in the generic kernel
+        const bool generic = clsA[q] < 0;  // this ring length runs in the generic kernel
         if ((q & (q - 1)) == 0) { if (generic && q > Lmax) Lmax = q; continue; }
         woff[q] = nw; nw += q;
         qlist.push_back(q);
-        if (MofS[q]) { coffS[q] = ncS; ncS += MofS[q]; if (MofS[q] > M2max) M2max = MofS[q]; qlistS.push_back(q); }
         if (MofA[q]) { coffA[q] = ncA; ncA += MofA[q]; if (MofA[q] > M2max) M2max = MofA[q]; qlistA.push_back(q); }
         if (!generic) continue;
         int M = 2;
@@ -265,7 +262,7 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
     F.Lmax = Lmax;
     F.Mtw = Lmax < 2 ? 2 : Lmax;
     if (F.Mtw < M2max) F.Mtw = M2max;
-    for (int c = 0; c < 5; ++c) if ((!listS[c].empty() || !listA[c].empty() || !dirS[c].empty() || !dirA[c].empty()) && F.Mtw < (256 << c)) F.Mtw = 256 << c;
+    for (int c = 0; c < kFftClasses; ++c) if ((!listA[c].empty() || !dirA[c].empty()) && F.Mtw < (256 << c)) F.Mtw = 256 << c;
     if ((size_t)Lmax * 16 > 160 * 1024) { pl_plan_destroy(p); return fail("ring FFT workspace exceeds the 160 KiB LDS of a CU"); }
     {   // LDS twiddle tables of the largest generic transform (radix-8 passes + one radix-4/2 tail), if they fit beside it
         int k = 0; while ((1 << k) < Lmax) ++k;
@@ -274,8 +271,8 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
         for (int64_t L = (int64_t)rt * 8; L <= Lmax; L *= 8) tot += 3 * (int)(L / 8);
         F.twl_cap = ((size_t)(Lmax + tot) * 16 <= 160 * 1024) ? tot : 0;
     }
-    double *tw = nullptr, *chirp = nullptr, *filt = nullptr, *filtS = nullptr, *filtA = nullptr;
-    const int *qlist_dev = nullptr, *qlistS_dev = nullptr, *qlistA_dev = nullptr;
+    double *tw = nullptr, *chirp = nullptr, *filt = nullptr, *filtA = nullptr;
+    const int *qlist_dev = nullptr, *qlistA_dev = nullptr;
     auto dalloc = [&](double **ptr, int64_t nd) -> int {
         if (nd < 2) nd = 2;
         HIPCHK(hipMalloc(reinterpret_cast<void **>(ptr), nd * sizeof(double)));
@@ -283,28 +280,24 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
         p->bytes += nd * 8;
         return 0;
     };
-    rc = dalloc(&tw, F.Mtw) || dalloc(&chirp, 2 * nw) || dalloc(&filt, 2 * nc) || dalloc(&filtS, 2 * ncS) || dalloc(&filtA, 2 * ncA) ||
+    rc = dalloc(&tw, F.Mtw) || dalloc(&chirp, 2 * nw) || dalloc(&filt, 2 * nc) || dalloc(&filtA, 2 * ncA) ||
          upload(p, Mof, &F.Mof) || upload(p, woff, &F.woff) || upload(p, coff, &F.coff) || upload(p, K2of, &F.K2of) ||
-         upload(p, qlist, &qlist_dev) || upload(p, qlistS, &qlistS_dev) || upload(p, qlistA, &qlistA_dev) ||
-         upload(p, MofS, &F.S.Mof) || upload(p, coffS, &F.S.coff) || upload(p, legacyS, &F.S.legacy_pairs) ||
+         upload(p, qlist, &qlist_dev) || upload(p, qlistA, &qlistA_dev) ||
          upload(p, MofA, &F.A.Mof) || upload(p, coffA, &F.A.coff) || upload(p, legacyA, &F.A.legacy_pairs);
-    F.S.legacy_n = (int)legacyS.size(); F.A.legacy_n = (int)legacyA.size();
-    for (int c = 0; c < 5 && !rc; ++c) {
-        rc = upload(p, listS[c], &F.S.cls_pairs[c]) || upload(p, listA[c], &F.A.cls_pairs[c]) ||
-             upload(p, dirS[c], &F.S.dir_pairs[c]) || upload(p, dirA[c], &F.A.dir_pairs[c]);
-        F.S.cls_n[c] = (int)listS[c].size(); F.A.cls_n[c] = (int)listA[c].size();
-        F.S.dir_n[c] = (int)dirS[c].size(); F.A.dir_n[c] = (int)dirA[c].size();
+    F.A.legacy_n = (int)legacyA.size();
+    for (int c = 0; c < kFftClasses && !rc; ++c) {
+        rc = upload(p, listA[c], &F.A.cls_pairs[c]) || upload(p, dirA[c], &F.A.dir_pairs[c]);
+        F.A.cls_n[c] = (int)listA[c].size();
+        F.A.dir_n[c] = (int)dirA[c].size();
     }
     if (rc) { pl_plan_destroy(p); return 1; }
     F.tw = reinterpret_cast<const double2 *>(tw);
     F.chirp = reinterpret_cast<const double2 *>(chirp);
     F.filt = reinterpret_cast<const double2 *>(filt);
-    F.S.filt = reinterpret_cast<const double2 *>(filtS);
     F.A.filt = reinterpret_cast<const double2 *>(filtA);
     hipError_t e = launch_twiddles(tw, F.Mtw, nullptr);
     if (e == hipSuccess) e = launch_bluestein_setup(F, qlist_dev, (int)qlist.size(), chirp, filt, nullptr);
-    if (e == hipSuccess) e = launch_bluestein_setup2(F, 1, qlistS_dev, (int)qlistS.size(), M2max, filtS, nullptr);
-    if (e == hipSuccess) e = launch_bluestein_setup2(F, 0, qlistA_dev, (int)qlistA.size(), M2max, filtA, nullptr);
+    if (e == hipSuccess) e = launch_bluestein_setup2(F, qlistA_dev, (int)qlistA.size(), M2max, filtA, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = fft_streams_create(p->fs);
     if (e != hipSuccess) { pl_plan_destroy(p); return fail(std::string("FFT table setup: ") + hipGetErrorString(e)); }
@@ -332,10 +325,13 @@ int pl_plan_fork(pl_plan *parent, pl_plan **out)
 int pl_plan_destroy(pl_plan *p)
 {
     if (!p) return 0;
+    for (auto &ev : p->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }  // profiling records never read
+    p->events.clear();
     fft_streams_destroy(p->fs);
     for (void *d : p->allocs) (void)hipFree(d);
     if (p->phase) (void)hipFree(p->phase);
     if (p->prep) (void)hipFree(p->prep);
+    if (p->prep2) (void)hipFree(p->prep2);
     if (p->partial) (void)hipFree(p->partial);
     if (p->h_alm) (void)hipFree(p->h_alm);
     if (p->h_map) (void)hipFree(p->h_map);
@@ -355,14 +351,17 @@ int pl_profile_read(pl_plan *p, double *ms_sum, int64_t *counts)
 {
     if (!p) return fail("null plan");
     for (int k = 0; k < PK_NKINDS; ++k) { ms_sum[k] = 0.0; counts[k] = 0; }
-    for (auto &ev : p->events) {
+    hipError_t err = hipSuccess;
+    for (auto &ev : p->events) {  // every event is destroyed, whatever happens to the earlier ones
         float ms = 0.f;
-        HIPCHK(hipEventSynchronize(ev.e1));
-        HIPCHK(hipEventElapsedTime(&ms, ev.e0, ev.e1));
-        ms_sum[ev.kind] += ms; counts[ev.kind] += 1;
+        hipError_t e = hipEventSynchronize(ev.e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev.e0, ev.e1);
+        if (e == hipSuccess) { ms_sum[ev.kind] += ms; counts[ev.kind] += 1; }
+        else if (err == hipSuccess) err = e;
         (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1);
     }
     p->events.clear();
+    if (err != hipSuccess) return fail(std::string("pl_profile_read: ") + hipGetErrorString(err));
     return 0;
 }
 

@@ -7,14 +7,16 @@
 
 namespace plshts {
 
-// Work lists of one direction: every ring pair is in exactly one list.
+// Work lists of the ring-FFT stage (both directions use the same band-limited classes): every ring pair is in exactly one list.
+constexpr int kFftClasses = 5;  // register-resident transform sizes N = 256 << c, c = 0 .. 4 (256 ... 4096)
+
 struct FftSide {
     const int *legacy_pairs; // generic LDS-resident kernel (short polar rings, aliased rings), longest rings first
     int legacy_n;
-    const int *cls_pairs[5]; // register-resident kernels, transform size N = 256 << c: Bluestein rings (q != N)
-    int cls_n[5];
-    const int *dir_pairs[5]; // ... and the rings whose own sub-DFT length is N (q == N, a power of two)
-    int dir_n[5];
+    const int *cls_pairs[kFftClasses]; // register-resident kernels, transform size N = 256 << c: Bluestein rings (q != N)
+    int cls_n[kFftClasses];
+    const int *dir_pairs[kFftClasses]; // ... and the rings whose own sub-DFT length is N (q == N, a power of two)
+    int dir_n[kFftClasses];
     const int *Mof;          // [nside + 1] Bluestein convolution size of q in its class (0: direct, or generic list)
     const int64_t *coff;     // [nside + 1] offset of q's natural-order filter spectrum (Mof[q] entries)
     const double2 *filt;
@@ -32,7 +34,7 @@ struct DevFFT {
     const double2 *filt;     // bit-reversed FFT_M of the wrapped conj chirp, times 1 / M
     // register-resident kernels (ringfft.hip, second half): per-direction class lists and Bluestein tables
     int const *K2of;         // [nside + 1] band half-width of the sub-DFT bins of ring length 4 q: |c| <= K2of[q] (analysis)
-    FftSide S, A;            // synthesis (phase -> map), analysis (map -> phase)
+    FftSide A;               // class lists and band-limited Bluestein tables, shared by synthesis and analysis
 };
 
 // Side streams of a plan: the ring-length classes of one FFT stage are independent kernels of very different sizes
@@ -50,6 +52,6 @@ hipError_t launch_phase2map(const DevPlan &P, const DevFFT &F, const FftStreams 
 hipError_t launch_map2phase(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *map, double *phase, hipStream_t st);
 hipError_t launch_twiddles(double *tw, int Mtw, hipStream_t st);
 hipError_t launch_bluestein_setup(const DevFFT &F, const int *qlist_dev, int nq, double *chirp, double *filt, hipStream_t st);
-hipError_t launch_bluestein_setup2(const DevFFT &F, int synth, const int *qlist_dev, int nq, int Mmax, double *filt2, hipStream_t st);
+hipError_t launch_bluestein_setup2(const DevFFT &F, const int *qlist_dev, int nq, int Mmax, double *filt2, hipStream_t st);
 
 }  // namespace plshts

@@ -1,17 +1,19 @@
 // Fourier stage of the HEALPix SHTs for gfx950: per-ring Fourier coefficients F_m(ring) <-> RING pixels.
 //
-// One workgroup per ring pair (north ring + mirror south ring, identical nphi and phi0).  The two real
-// rings are transformed by ONE complex DFT of length n = nphi = 4 q (z = north + i south).  That DFT is
-// split as 4 sub-DFTs of length q (Cooley-Tukey 4 x q) done in LDS:
-//   * q a power of two (all equatorial rings when nside is): radix-2 DIT on bit-reversed input;
-//   * otherwise (polar caps, q = ring number): Bluestein chirp-z with a power-of-two LDS convolution of size
-//     M >= 2q - 1 whose filter spectrum is precomputed per q at plan creation (bit-reversed order, so the
-//     DIF forward / DIT inverse pair needs no reordering pass).
-// Synthesis gathers the aliased spectrum bins straight from the phase array, keeps the 4 x q partial
-// results in registers and finishes with the radix-4 butterfly while writing pixels; analysis is the exact
-// transpose (radix-4 on register-resident pixels first, sub-DFT outputs un-aliased from LDS).
+// One workgroup per ring pair (north ring + mirror south ring, identical nphi and phi0) and component.  The two real
+// rings are transformed by ONE complex DFT of length n = nphi = 4 q (z = north + i south), split 4 x q: radix-4 on the
+// pixel side (pixel j = j1 + q j2, bin k = 4 k1 + k2) and four sub-DFTs of length q.
+//   * Register-resident kernels (k_phase2map_fast / k_map2phase_fast, second half of this file) serve every ring without
+//     aliasing whose transform size N is 256 ... 4096: Stockham autosort radix-8 passes in registers, one swizzled N-point
+//     LDS exchange buffer; q a power of two runs directly (N = q), any other q as a band-limited Bluestein convolution of
+//     size N >= q + 2 K + 1 (K = in-band sub-DFT bins) with per-q filter spectra precomputed at plan creation.
+//   * The generic kernel (k_phase2map / k_map2phase, first half) keeps a whole sub-DFT in LDS (radix-8/4/2 DIF forward /
+//     DIT inverse, Bluestein size M >= 2 q - 1 with digit-reversed filter spectrum): short polar rings, aliased rings
+//     (lmax >= 2 nside, coarse multigrid levels), and the reference route the register kernels are tested against.
+// Synthesis gathers the spectrum bins straight from the phase array and finishes with the radix-4 butterfly while
+// writing pixels; analysis is the exact transpose.
 //
-// Bound: LDS bandwidth / HBM (the stage does O(npix log n) flops on 8 npix + 32 (mmax+1) nrings bytes).
+// Bound: HBM (8 npix + 32 (mmax + 1) npairs bytes per component) with an FP64 add/mul + LDS-exchange floor close behind.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -852,16 +854,16 @@ __global__ __launch_bounds__(N / 8, 2) void k_map2phase_fast(DevPlan P, DevFFT F
     }
 }
 
-// plan-time: natural-order spectrum (times 1/M) of the wrapped conjugate chirp h_d = e^{-i pi d^2 / q}, d in [-Kn, q-1+Kp]:
-// analysis tables (side A) Kn = Kp = K2of[q] (band-limited outputs), synthesis tables (side S) Kn = q - 1, Kp = 0
+// plan-time: natural-order spectrum (times 1/M) of the wrapped conjugate chirp h_d = e^{-i pi d^2 / q}, d in [-K, q-1+K],
+// K = K2of[q] (band-limited sub-DFT bins)
 template <int NT>
-__global__ __launch_bounds__(NT) void k_bluestein_setup2(DevFFT F, int synth, const int *__restrict__ qlist, double2 *__restrict__ filt_out)
+__global__ __launch_bounds__(NT) void k_bluestein_setup2(DevFFT F, const int *__restrict__ qlist, double2 *__restrict__ filt_out)
 {
     extern __shared__ double2 ws[];
     const int q = qlist[blockIdx.x];
-    const FftSide &sd = synth ? F.S : F.A;
+    const FftSide &sd = F.A;
     const int M = sd.Mof[q];
-    const int Kn = synth ? q - 1 : F.K2of[q], Kp = synth ? 0 : F.K2of[q];
+    const int Kn = F.K2of[q], Kp = F.K2of[q];
     double2 *filt = filt_out + sd.coff[q];
     for (int t = threadIdx.x; t < M; t += NT) ws[t] = make_double2(0., 0.);
     __syncthreads();
@@ -882,6 +884,14 @@ __global__ __launch_bounds__(NT) void k_bluestein_setup2(DevFFT F, int synth, co
 // -----------------------------------------------------------------------------------------------------
 // host launchers
 // -----------------------------------------------------------------------------------------------------
+constexpr int kMaxDevices = 64;
+static int current_device()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+    return d;
+}
+
 static size_t fft_lds_bytes(const DevFFT &F) { return (size_t)(F.Lmax + F.twl_cap) * sizeof(double2); }
 
 template <int NT, int QMAX>
@@ -898,12 +908,13 @@ static hipError_t launch_p2m(const DevPlan &P, const DevFFT &F, const int *mlim,
         return hipGetLastError();
     }
     const size_t lds = fft_lds_bytes(F);
-    static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
+    static bool attr_done[kMaxDevices] = {};  // function attributes are per device
+    const int dv = current_device();
+    if (!attr_done[dv] && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map<NT, QMAX, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done[dv] = true;
     }
     hipLaunchKernelGGL((k_phase2map<NT, QMAX, false>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds, st, P, F, F.A.legacy_pairs, mlim, ncomp, phase,
                        map, dbg);
@@ -923,12 +934,13 @@ static hipError_t launch_m2p(const DevPlan &P, const DevFFT &F, const int *mlim,
         return hipGetLastError();
     }
     const size_t lds = fft_lds_bytes(F);
-    static bool attr_done = false;
-    if (!attr_done && lds > 48 * 1024) {
+    static bool attr_done[kMaxDevices] = {};
+    const int dv = current_device();
+    if (!attr_done[dv] && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_map2phase<NT, QMAX, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_done = true;
+        attr_done[dv] = true;
     }
     hipLaunchKernelGGL((k_map2phase<NT, QMAX, false>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds, st, P, F, F.A.legacy_pairs, mlim, ncomp, map,
                        phase);
@@ -969,12 +981,13 @@ static hipError_t launch_fast_class(const DevPlan &P, const DevFFT &F, int cls, 
     if (n == 0) return hipSuccess;
     const size_t lds = (size_t)N * sizeof(double2);
     if (lds > 48 * 1024) {
-        static bool attr_done = false;
-        if (!attr_done) {
+        static bool attr_done[kMaxDevices] = {};
+        const int dv = current_device();
+        if (!attr_done[dv]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map_fast<N, BLUE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_map2phase_fast<N, BLUE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            attr_done = true;
+            attr_done[dv] = true;
         }
     }
     if (synth) hipLaunchKernelGGL((k_phase2map_fast<N, BLUE>), dim3(n, ncomp), dim3(N / 8), lds, st, P, F, pairs, mlim, ncomp, in, out);
@@ -1093,7 +1106,7 @@ hipError_t launch_bluestein_setup(const DevFFT &F, const int *qlist_dev, int nq,
     return hipGetLastError();
 }
 
-hipError_t launch_bluestein_setup2(const DevFFT &F, int synth, const int *qlist_dev, int nq, int Mmax, double *filt2, hipStream_t st)
+hipError_t launch_bluestein_setup2(const DevFFT &F, const int *qlist_dev, int nq, int Mmax, double *filt2, hipStream_t st)
 {
     if (nq == 0) return hipSuccess;
     const size_t lds = (size_t)Mmax * sizeof(double2);
@@ -1102,7 +1115,7 @@ hipError_t launch_bluestein_setup2(const DevFFT &F, int synth, const int *qlist_
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_bluestein_setup2<256>, dim3(nq), dim3(256), lds, st, F, synth, qlist_dev, reinterpret_cast<double2 *>(filt2));
+    hipLaunchKernelGGL(k_bluestein_setup2<256>, dim3(nq), dim3(256), lds, st, F, qlist_dev, reinterpret_cast<double2 *>(filt2));
     return hipGetLastError();
 }
 

@@ -91,10 +91,16 @@ class Plan(object):
         return ret
 
 
+def _plan_key(nside, lmax):
+    """A plan lives on the device that was current when it was created (tables, workspaces, side streams)."""
+    dev_id = torch.cuda.current_device() if (torch is not None and torch.cuda.is_available()) else 0
+    return (int(nside), int(lmax), dev_id)
+
+
 def get_plan(nside, lmax):
-    key = (int(nside), int(lmax))
+    key = _plan_key(nside, lmax)
     if key not in _PLANS:
-        _PLANS[key] = Plan(*key)
+        _PLANS[key] = Plan(key[0], key[1])
     return _PLANS[key]
 
 

@@ -20,9 +20,10 @@ def shts():
     return s
 
 
-@pytest.mark.parametrize('nside,lmax', [(1, 2), (2, 5), (8, 16), (8, 23), (16, 47), (32, 64), (64, 191), (128, 256)])
+@pytest.mark.parametrize('nside,lmax', [(1, 2), (2, 5), (8, 16), (8, 23), (12, 30), (16, 47), (32, 64), (48, 100), (64, 191), (128, 256)])
 def test_spin0_vs_oracle(shts, oracle, nside, lmax):
-    """includes nside 1-2 (rings of 4 pixels), lmax up to 3 nside - 1 (strong aliasing in the polar caps)"""
+    """includes nside 1-2 (rings of 4 pixels), lmax up to 3 nside - 1 (strong aliasing in the polar caps) and nside that are
+    not powers of two (12, 48: every ring, belt included, is a Bluestein transform in the generic FFT kernel)"""
     rng = np.random.default_rng(nside * 100 + lmax)
     a = random_alm(rng, lmax)
     assert relrms(shts.alm2map(a, nside, lmax=lmax), oracle.alm2map(a, nside, lmax=lmax)) < TOL
@@ -31,7 +32,7 @@ def test_spin0_vs_oracle(shts, oracle, nside, lmax):
 
 
 @pytest.mark.parametrize('spin', [1, 2, 3])
-@pytest.mark.parametrize('nside,lmax', [(2, 5), (8, 16), (16, 47), (32, 64), (64, 150)])
+@pytest.mark.parametrize('nside,lmax', [(2, 5), (8, 16), (12, 30), (16, 47), (32, 64), (48, 100), (64, 150)])
 def test_spin_vs_oracle(shts, oracle, spin, nside, lmax):
     rng = np.random.default_rng(spin * 10000 + nside * 100 + lmax)
     g, c = random_alm(rng, lmax, spin), random_alm(rng, lmax, spin)
@@ -150,7 +151,7 @@ def test_lmax_qlm_differs_from_lmax_ivf(shts, oracle):
 
 
 def _run_with_plan(shts, plan, fn):
-    key = (plan.nside, plan.lmax)
+    key = shts._plan_key(plan.nside, plan.lmax)
     old = shts._PLANS.get(key)
     shts._PLANS[key] = plan
     try:

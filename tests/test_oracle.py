@@ -115,21 +115,52 @@ def test_against_reference_fortran_wigners(oracle, spin):
                        x.ctypes.data_as(dp), ctypes.byref(s1), ctypes.byref(s2))
         return xi * 4 * np.pi / (2 * l + 1)
 
-    lmax = 24
-    x = np.array([-0.93, -0.41, 0.07, 0.55, 0.88])
     sg = (-1.) ** spin
-    for m in (0, 1, 2, 5, 17):
-        for l in range(max(m, spin), lmax, 5):  # wignerpos needs lmax > lmin (SURVEY.md 8(c) caveat)
-            nrm = np.sqrt((2 * l + 1) / (4 * np.pi))
-            lam_p = sg * nrm * wigd(l, m, -spin, x, lmax)
-            lam_m = sg * nrm * wigd(l, m, spin, x, lmax)
-            for ix, xx in enumerate(x):
-                fp, fm = oracle.lambda_lm(spin, m, lmax, xx, np.sqrt(1 - xx * xx))
-                if spin == 0:
-                    assert abs(fp[l] - lam_p[ix]) < 1e-13
-                else:
-                    assert abs(fp[l] - (-0.5) * (lam_p[ix] + sg * lam_m[ix])) < 1e-13
-                    assert abs(fm[l] - (-0.5) * (lam_p[ix] - sg * lam_m[ix])) < 1e-13
+    # (lmax, orders m, step in l, tolerance): the small case of round 1, and lmax = 300 -- every l from max(m, s) on a
+    # coarse grid up to 299 and orders up to m = 290, where the seeds are ~1e-90 at x = 0.88 (the double-precision Fortran
+    # recursion is itself good to ~1e-13 there)
+    for lmax, ms, lstep, tol in ((24, (0, 1, 2, 5, 17), 5, 1e-13), (300, (0, 1, 3, 40, 150, 290), 37, 1e-12)):
+        x = np.array([-0.93, -0.41, 0.07, 0.55, 0.88])
+        for m in ms:
+            for l in range(max(m, spin), lmax, lstep):  # wignerpos needs lmax > lmin (SURVEY.md 8(c) caveat)
+                nrm = np.sqrt((2 * l + 1) / (4 * np.pi))
+                lam_p = sg * nrm * wigd(l, m, -spin, x, lmax)
+                lam_m = sg * nrm * wigd(l, m, spin, x, lmax)
+                for ix, xx in enumerate(x):
+                    fp, fm = oracle.lambda_lm(spin, m, lmax, xx, np.sqrt(1 - xx * xx))
+                    if spin == 0:
+                        assert abs(fp[l] - lam_p[ix]) < tol, (lmax, m, l, xx)
+                    else:
+                        assert abs(fp[l] - (-0.5) * (lam_p[ix] + sg * lam_m[ix])) < tol, (lmax, m, l, xx)
+                        assert abs(fm[l] - (-0.5) * (lam_p[ix] - sg * lam_m[ix])) < tol, (lmax, m, l, xx)
+
+
+def test_healpix_pixel_centres_literal_constants(oracle):
+    """Geometry pinned by constants that do not come from this repository: the base-resolution pixel centres of the HEALPix
+    definition (Gorski et al. 2005: z = 2/3, 0, -2/3; phi = (k + 1/2) pi/2 in the polar rings, k pi/2 on the equator),
+    the nside = 2 ring table written out by hand from the same definition, and the (theta, phi) values printed in healpy's
+    own documentation of pix2ang for nside = 16 (pixels 1440, 427, 1520, 0, 3068).  Both the product's hp.py and the
+    oracle's ring_geometry must reproduce them."""
+    # nside = 1
+    z1 = np.repeat([2. / 3., 0., -2. / 3.], 4)
+    phi1 = np.array([0.25, 0.75, 1.25, 1.75, 0., 0.5, 1., 1.5, 0.25, 0.75, 1.25, 1.75]) * np.pi
+    # nside = 2: rings of 4, 8, 8, 8, 8, 8, 4 pixels at z = 11/12, 2/3, 1/3, 0, -1/3, -2/3, -11/12
+    z2 = np.concatenate([np.full(n, z) for n, z in zip((4, 8, 8, 8, 8, 8, 4), (11. / 12, 2. / 3, 1. / 3, 0., -1. / 3, -2. / 3, -11. / 12))])
+    odd8, even8 = np.arange(1, 16, 2) * np.pi / 8, np.arange(0, 16, 2) * np.pi / 8
+    cap4 = np.array([2., 6., 10., 14.]) * np.pi / 8
+    phi2 = np.concatenate([cap4, odd8, even8, odd8, even8, odd8, cap4])
+    for nside, z, phi in ((1, z1, phi1), (2, z2, phi2)):
+        th, ph = hp.pix2ang(nside)
+        assert np.abs(np.cos(th) - z).max() < 1e-15 and np.abs(ph - phi).max() < 1e-15
+        cth, sth, nphi, phi0, ofs = oracle.ring_geometry(nside)
+        zz = np.repeat(cth, nphi)
+        pp = np.concatenate([p0 + 2 * np.pi * np.arange(n) / n for p0, n in zip(phi0, nphi)])
+        assert np.abs(zz - z).max() < 1e-15 and np.abs(pp - phi).max() < 1e-15
+        assert np.abs(np.repeat(sth, nphi) - np.sqrt(1 - z * z)).max() < 1e-15
+    th, ph = hp.pix2ang(16)
+    idx = [1440, 427, 1520, 0, 3068]
+    assert np.abs(th[idx] - np.array([1.52911759, 0.78550497, 1.57079633, 0.05103658, 3.09055608])).max() < 5e-9
+    assert np.abs(ph[idx] - np.array([0., 0.78539816, 1.61988371, 0.78539816, 0.78539816])).max() < 5e-9
 
 
 def test_gradient_spin1(oracle):
