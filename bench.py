@@ -1,25 +1,36 @@
 """Headline benchmark: minimum-variance ('p') lensing quadratic-estimator reconstructions per second at
-nside = lmax = lmax_qlm = 2048 on MI355X (BASELINE.json metric).
+nside = lmax = lmax_qlm = 2048 on MI355X, and CG iterations per second of the qcinv Wiener filter (BASELINE.json metric;
+SURVEY.md 8(d)).
 
 One step = one reconstruction = T, Q, U maps (resident in HBM) -> isotropic inverse-variance filter
 (filt_simple.py:397-407) -> qest.library_sepTP.get_sim_qlm('p') -> gradient + curl alm copied to host memory.
 9 spherical harmonic transforms per step (2 scalar + 7 spin-weighted pairs), all FP64.
 
     python bench.py --gpus N --steps K --warmup W
-For N > 1 it is launched by torch.distributed.run, one rank per GPU: every rank reconstructs its own
-simulations (weak scaling: jobs[rank::size] of run_qlms.py:72) and the ranks meet in one RCCL all-reduce of the
-mean-field sum and one all-gather of the last gradient alm inside the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (spin-weighted Legendre synthesis):
-achieved = algorithmic flops per launch (24 flop per (l, m, ring pair): SURVEY.md 8(d)) / mean launch
-duration measured with HIP events on the launch stream over the timed region.  The binding ceiling of that
-kernel is FP64 vector-FMA issue, reported under the "mfma" (TFLOP/s) arm of the schema: gfx950's FP64 MFMA peak
-equals its FP64 vector peak and no MFMA is used (a recurrence, not a contraction).  `cpu_baseline` times the
-CPU oracle (oracle/, "port") on a bounded ring sample of the same workload on the host cores of this box.
+N > 1 without a launcher: this process touches no GPU and starts N rank processes of itself (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in their environment), one per GPU.  Under torch.distributed.run the ranks come from the launcher
+and WORLD_SIZE must equal --gpus.  The timed region is the PRODUCT's mean-field evaluation over world x K simulations,
+qest.library.get_sim_qlm_mf: every rank reconstructs its share jobs[rank::size] (K reconstructions per rank, weak
+scaling, run_qlms.py:72), the running sum stays on the device and one RCCL all-reduce completes it
+(plancklens_amd/parallel.py); then the last gradient alm of every rank is all-gathered over xGMI.
+
+Prints ONE JSON line (rank 0).
+ * `roofline`: the Legendre kernel with the largest summed time inside the timed region (HIP events on the launch
+   stream, pl_profile_*).  The binding ceiling is FP64 vector-FMA issue, reported under the "mfma" (TFLOP/s) arm of the
+   schema: gfx950's FP64 MFMA peak equals its FP64 vector peak and no MFMA is used (a recurrence, not a contraction).
+   `achieved` counts EXECUTED flops (the (l, m, ring pair) steps left after libsharp-style polar pruning); the
+   fixed-denominator count of SURVEY.md 8(d) (no pruning credit) is reported beside it as `achieved_fixed_denominator`.
+ * `kernels`: every timed stage (per launch; ring-FFT GB/s per component).
+ * `cg`: BASELINE config 4 (cinv_t + cinv_p, masked sky, 100 top-level iterations, dense preconditioner cached outside
+   the timed region), rank 0 at N = 1 only.
+ * `cpu_baseline`: the CPU oracle (oracle/, "port") on the host cores of this box, rank 0 at N = 1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -32,9 +43,21 @@ if ROOT not in sys.path:
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 vector (= matrix) peak; SURVEY.md 8(d)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
-# k_leg_synths, spin 2, nside = lmax = 2048: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), bytes per launch
-# (profiles/round1_h_pmc_traffic.csv; refreshed whenever the kernel changes materially)
-SYNTHS_TRAFFIC_BYTES = (430280 + 373984) * 1024
+HBM_ACHIEVABLE_GBS = 6300.0  # MI355X_MICROARCH.md chip table: measured streaming rate
+# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), bytes per launch at nside = lmax = 2048, by profile kind
+# (profiles/*_pmc_traffic.csv; refreshed whenever a kernel changes materially).  FETCH_SIZE on gfx950 counts half of the
+# bytes of 16-B-per-lane streaming reads and is uncalibrated for the scalar table streams of these kernels.
+PMC_TRAFFIC_BYTES = {
+    'leg_anals': (477058 + 887049) * 1024,   # profiles/round1_h_pmc_traffic.csv (k_leg_anals<4>)
+    'leg_synths': (430280 + 373984) * 1024,
+    'leg_anal0': (222182 + 311190) * 1024,
+    'leg_synth0': (205142 + 188760) * 1024,
+}
+PMC_TRAFFIC_SOURCE = 'profiles/round1_h_pmc_traffic.csv'
+KERNEL_NAMES = {'leg_synth0': 'k_leg_synth0 (scalar Legendre synthesis)', 'leg_synths': 'k_leg_synths (spin-weighted Legendre synthesis)',
+                'leg_anal0': 'k_leg_anal0 (scalar Legendre analysis)', 'leg_anals': 'k_leg_anals (spin-weighted Legendre analysis)',
+                'leg_synths_grad': 'k_leg_synths<GONLY> (gradient-only spin synthesis)',
+                'leg_synths_pair': 'k_leg_synths<PAIR> (general + gradient-only spin-1 synthesis on one recursion)'}
 
 
 def fma_ceilings():
@@ -65,7 +88,7 @@ def executed_flops(nside, lmax, spin):
     return steps * (24. if spin else 6.)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
@@ -77,8 +100,42 @@ def parse():
     ap.add_argument('--qe-only', action='store_true',
                     help='time the estimator from filtered alms that are already resident (the cost of a further key in the reference, qest.py:184-185)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=20.0)
-    return ap.parse_args()
+    ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU baseline (all repetitions together)')
+    ap.add_argument('--no-cg', action='store_true', help='skip the CG block (BASELINE config 4)')
+    ap.add_argument('--cg-iters', type=int, default=100)
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: N rank processes of this script, started by a parent that never touches a GPU
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """Start n fresh rank processes of this script (never exec from a process that has initialised HIP: the parent imports
+    neither torch nor the HIP library).  Rank 0 inherits stdout (the one JSON line); the other ranks' stdout goes to stderr."""
+    port = os.environ.get('MASTER_PORT') or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:  # one rank failed: the others may be stuck in a collective
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 class resident_sims(object):
@@ -121,57 +178,106 @@ class resident_sims(object):
         return self.qmap, self.umap
 
 
-def cpu_baseline(nside, lmax, target_seconds):
-    """The oracle's Legendre stage (C, OpenMP, all host cores) + numpy ring FFTs on every `stride`-th ring
-    pair of each of the 9 SHTs of one 'p' reconstruction; time x stride = seconds per reconstruction."""
+def cpu_baseline(nside, lmax, budget_seconds, reps=3):
+    """One 'p' reconstruction's 9 SHTs with the CPU oracle: Legendre stage in C (OpenMP over all host cores), ring FFTs
+    with numpy's pocketfft on a thread pool.  Full unit (every ring pair) when 1 warm-up + `reps` repetitions fit the
+    budget; otherwise every stride-th ring pair of each transform, time x stride (stated in the result).  Median of reps."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import sht_oracle as so
     ncores = os.cpu_count() or 1
     c, s, pair, slots = so._pair_geometry(nside, True)
     rng = np.random.default_rng(5)
     nalm = so.alm_size(lmax)
     alm2 = (rng.standard_normal((2, nalm)) + 1j * rng.standard_normal((2, nalm)))
+    maps = rng.standard_normal((2, 12 * nside ** 2))
     synth = [0, 2, 3, 1, 1]   # Tb map, (Qb, Ub), spin-3 leg, spin-1 leg (P), spin-1 gradient leg (T)
-    anal = [0, 2, 1, 1]       # T filter, P filter, two final spin-1 analyses (qest.py:318-322)
+    anal = [0, 2, 1, 1]       # T filter, P filter, the two final spin-1 analyses of the reference (qest.py:318-322)
+    nfft = max(1, min(ncores, 64))
+    pool = ThreadPoolExecutor(max_workers=nfft)
 
     def run(stride):
         sel = np.arange(0, 2 * nside, stride)
         cs, ss, ps = c[sel], s[sel], pair[sel]
-        sl = np.full(2 * sel.size, -1, dtype=np.int64)
-        sl[0::2] = slots[0::2][sel]
-        sl[1::2] = slots[1::2][sel]
-        maps = rng.standard_normal((2, 12 * nside ** 2))
+        # FFT work split into chunks of ring pairs for the thread pool (pocketfft releases the GIL)
+        chunks = np.array_split(np.arange(sel.size), min(sel.size, 4 * nfft))
+        sls = []
+        for ch in chunks:
+            sl = np.full(2 * ch.size, -1, dtype=np.int64)
+            sl[0::2] = slots[0::2][sel[ch]]
+            sl[1::2] = slots[1::2][sel[ch]]
+            sls.append(sl)
+
+        def rows(ch):
+            r = np.empty(2 * ch.size, dtype=np.int64)
+            r[0::2], r[1::2] = 2 * ch, 2 * ch + 1
+            return r
         t0 = time.perf_counter()
         for spin in synth:
             nc = 1 if spin == 0 else 2
             ph = so.legendre(0, 1, spin, lmax, lmax, cs, ss, ps, alm=alm2[:nc], nthreads=ncores)
-            for i in range(nc):
-                so._phase2map(ph[i], nside, lmax, sl)
+            list(pool.map(lambda a: so._phase2map(ph[a[0]][rows(a[1])], nside, lmax, a[2]),
+                          [(i, ch, sl) for i in range(nc) for ch, sl in zip(chunks, sls)]))
         for spin in anal:
             nc = 1 if spin == 0 else 2
-            ph = np.stack([so._map2phase(maps[i], nside, lmax, sl) for i in range(nc)])
+            ph = np.zeros((nc, 2 * sel.size, lmax + 1), dtype=complex)
+
+            def one(a):
+                i, ch, sl = a
+                ph[i][rows(ch)] = so._map2phase(maps[i], nside, lmax, sl)
+            list(pool.map(one, [(i, ch, sl) for i in range(nc) for ch, sl in zip(chunks, sls)]))
             so.legendre(1, 1, spin, lmax, lmax, cs, ss, ps, phase=ph, nthreads=ncores)
         return time.perf_counter() - t0
 
-    stride = 64
-    t = run(stride)  # calibration pass (also warms the library)
-    est_full = t * stride
+    t = run(64)  # calibration pass (also warms the library and the thread pool)
+    est_full = t * 64
     stride = 1
-    while est_full / stride > target_seconds and stride < 64:
+    while est_full / stride * (reps + 1) > budget_seconds and stride < 64:
         stride *= 2
-    t = run(stride)
+    run(stride)  # warm-up at the measured size
+    ts = sorted(run(stride) for _ in range(reps))
+    t = ts[len(ts) // 2]
+    pool.shutdown()
     sec_per_rec = t * stride
+    sample = "all %d ring pairs" % (2 * nside) if stride == 1 else "every %d-th ring pair (of %d), time x %d (EXTRAPOLATED)" % (stride, 2 * nside, stride)
     return {'value': 1.0 / sec_per_rec, 'unit': 'reconstructions/s', 'cores': ncores, 'kind': 'port',
-            'sample': "every %d-th ring pair (of %d) of each of the 9 SHTs (2 scalar + 7 spin pairs) of one 'p' reconstruction at nside=%d lmax=%d, "
-                      "measured %.1f s x %d" % (stride, 2 * nside, nside, lmax, t, stride)}
+            'extrapolated_from_ring_stride': stride, 'repetitions': reps, 'fft_threads': nfft,
+            'sample': "%s of each of the 9 SHTs of one 'p' reconstruction as the reference runs it (2 scalar + 7 spin-weighted pairs, "
+                      "qest.py:318-322) at nside=%d lmax=%d; oracle C Legendre stage with OpenMP on %d threads + "
+                      "numpy ring FFTs on %d threads; 1 warm-up + %d repetitions, median %.2f s (min %.2f, max %.2f); the oracle is a long-double-checked "
+                      "restatement, not a tuned libsharp-class code" % (sample, nside, lmax, ncores, nfft, reps, t, ts[0], ts[-1])}
 
 
-def main():
-    args = parse()
+def stub_rank(args, rank, world):
+    """Launcher self-test (PLBENCH_STUB=1, tests/test_bench_launcher.py): gloo on CPU, no GPU work, no number."""
     import torch
     import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend='gloo')
+    for _ in range(args.warmup + args.steps):
+        time.sleep(0.001)
+    seen = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(seen)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({'metric': 'launcher self-test', 'value': None, 'unit': 'reconstructions/s', 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'ranks_seen': int(seen.item()), 'data': 'STUB (launcher self-test, no GPU work)'}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def run_rank(args):
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus\n' % (args.gpus, world))
+        return 2
+    if os.environ.get('PLBENCH_STUB', '0') == '1':
+        return stub_rank(args, rank, world)
+    import torch
+    import torch.distributed as dist
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU path)'
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -180,7 +286,7 @@ def main():
     from plancklens_amd.helpers import mpi
     mpi.rank, mpi.size = rank, world
 
-    from plancklens_amd import dev, hp, qest, shts, utils
+    from plancklens_amd import hp, parallel, qest, shts, utils
     from plancklens_amd.filt import filt_simple
 
     nside, lmax, key = args.nside, args.lmax, args.key
@@ -197,26 +303,12 @@ def main():
 
     sims = resident_sims(nside, lmax, cl_len, transf, nlev_t, nlev_p, seed=1000 + rank)
     tmp = tempfile.mkdtemp(prefix='plbench_r%d_' % rank)
-    mpi_rank_saved = mpi.rank
     mpi.rank = 0  # every rank owns a private scratch directory: all of them create their hash files
+    mpi.size = 1
     ivfs = filt_simple.library_fullsky_sepTP(os.path.join(tmp, 'ivfs'), sims, nside, transf, cl_len, ftl, fel, fbl, cache=False)
     qlms = qest.library_sepTP(os.path.join(tmp, 'qlms'), ivfs, ivfs, cl_len['te'], nside, lmax_qlm=lmax_qlm, cache=False)
-    mpi.rank = mpi_rank_saved
+    mpi.rank, mpi.size = rank, world
     plan = shts.get_plan(nside, lmax)
-
-    mf_sum = torch.zeros(hp.Alm.getsize(lmax_qlm), dtype=torch.complex128, device='cuda')
-    state = {'idx': rank, 'last': None}
-
-    def step():
-        idx = state['idx']
-        if not args.qe_only:
-            state['idx'] += world                  # jobs[rank::size]
-        G = qlms.get_sim_qlm(key, idx)             # host array: filter + QE + device-to-host copy
-        C = qlms.get_sim_qlm('x' + key[1:], idx)   # curl comes out of the same evaluation
-        qlms._mem.clear()
-        if not args.qe_only:
-            ivfs._dev_cache.clear()
-        state['last'] = (G, C)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -224,32 +316,38 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    K = args.steps
+    # warm-up: W reconstructions per rank on indices outside the timed set
+    for w in range(args.warmup):
+        qlms.get_sim_qlm(key, 10 ** 6 + world * w + rank)
+    if args.qe_only:  # the filtered alms of the timed indices are made resident beforehand
+        for idx in range(rank, world * K, world):
+            for name in ('tlm', 'elm', 'blm'):
+                ivfs.get_sim_alm_dev(name, idx)
+        assert ivfs._dev_slots >= K, 'increase the resident-alm slots for --qe-only with this many steps'
+    qlms._mem.clear()
     sync_all()
     plan.profile(True)
     plan.profile_read()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        if qlms._last_dev is not None:
-            mf_sum += qlms._last_dev[0]            # running mean-field sum stays on the device
-        else:
-            mf_sum += dev.to_dev(state['last'][0])
-    if world > 1:
-        buf = torch.view_as_real(mf_sum)
-        dist.all_reduce(buf)                                     # mean-field sum over ranks (RCCL)
-        last = torch.view_as_real(dev.to_dev(state['last'][0]))
-        gathered = [torch.empty_like(last) for _ in range(world)]
-        dist.all_gather(gathered, last)                          # output qlm all-gather over xGMI
+    # K reconstructions on this rank (jobs[rank::size] of world x K simulations), device-resident sum, RCCL all-reduce
+    mf = qlms.get_sim_qlm_mf(key, np.arange(world * K))
+    gathered = parallel.allgather(qlms._last_dev[0])  # output qlm all-gather over xGMI
     sync_all()
     dt = time.perf_counter() - t0
     prof = plan.profile_read()
     plan.profile(False)
+    assert len(gathered) == world and mf.size == hp.Alm.getsize(lmax_qlm)
+    nrec = sum(1 for (k_, i_) in qlms._mem if k_ == key and isinstance(i_, (int, np.integer)))
+    assert nrec == K, 'timed region ran %d reconstructions on rank %d, expected %d' % (nrec, rank, K)
+    ranks_seen = world
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        one = torch.ones(1, device='cuda')
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
 
     if rank == 0:
         nalm = hp.Alm.getsize(lmax)
@@ -257,35 +355,19 @@ def main():
         flops_spin, flops_scal = 24.0 * steps_leg, 8.0 * steps_leg
         exec_spin, exec_scal = executed_flops(nside, lmax, 2), executed_flops(nside, lmax, 0)
         npix = hp.nside2npix(nside)
-        ms, cnt = prof['leg_synths']
         res = {
-            'metric': "QE reconstructions/sec at nside=%d lmax=%d ('%s' MV)" % (nside, lmax, key),
-            'value': world * args.steps / dt, 'unit': 'reconstructions/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'metric': "QE reconstructions/sec at nside=%d lmax=%d ('%s' MV); CG-iter/sec" % (nside, lmax, key),
+            'value': world * K / dt, 'unit': 'reconstructions/s', 'n_gpus': world, 'steps': K,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / K, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic', 'ranks_seen': ranks_seen,
             'config': {'workload': "'%s' MV quadratic estimator from T,Q,U maps: isotropic filter + qest.library_sepTP, "
-                                   "nside=%d lmax_ivf=%d lmax_qlm=%d, 9 SHTs (2 scalar + 7 spin pairs) per reconstruction (BASELINE.json headline config)"
-                                   % (key, nside, lmax, lmax_qlm) +
+                                   "nside=%d lmax_ivf=%d lmax_qlm=%d, 9 SHTs (2 scalar + 7 spin pairs) per reconstruction (BASELINE.json headline config); "
+                                   "timed region = qest.library.get_sim_qlm_mf over %d simulations (%d per GPU) + all-gather of the last qlm"
+                                   % (key, nside, lmax, lmax_qlm, world * K, K) +
                                    (' -- QE-ONLY variant: filtered alms already resident, the filter transforms are not timed' if args.qe_only else ''),
-                       'nside': nside, 'lmax': lmax, 'lmax_qlm': lmax_qlm, 'key': key, 'sims_per_gpu': args.steps,
+                       'nside': nside, 'lmax': lmax, 'lmax_qlm': lmax_qlm, 'key': key, 'sims_per_gpu': K,
                        'parallelism': 'sim-sharded x%d' % world},
         }
-        if cnt > 0:
-            avg_ms = ms / cnt
-            ach = flops_spin / (avg_ms * 1e-3) / 1e12
-            res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / FP64_PEAK_TFLOPS, 'traffic': SYNTHS_TRAFFIC_BYTES, 'kernel': 'k_leg_synths (spin-weighted Legendre synthesis)',
-                               'avg_launch_ms': avg_ms, 'launches': cnt,
-                               'executed_tflops': exec_spin / (avg_ms * 1e-3) / 1e12,
-                               'fma_issue_ceiling_measured_tflops': fma_ceilings(),
-                               'frac_executed': exec_spin / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                               'note': 'FP64 vector-FMA issue bound (v_fma_f64); gfx950 FP64 MFMA peak = FP64 vector peak; no MFMA used. '
-                                       'achieved = SURVEY 8(d) fixed-denominator count (24 flop x nalm x 2 nside, polar pruning not counted); '
-                                       'executed_tflops counts only the (l, m, ring pair) steps the kernel runs after libsharp-style polar pruning; '
-                                       'fma_issue_ceiling_measured_tflops is what a pure FMA loop sustains on this GPU. '
-                                       'traffic = FETCH_SIZE + WRITE_SIZE bytes per launch from profiles/ (PMC passes of an earlier run of the same kernel; '
-                                       'coefficient-table re-reads by the ring groups are served by L2 / Infinity Cache)'}
-        per_kernel = {}
         # gradient-only synthesis (curl alm = 0, shts.alm2map_spin([G, None])): 8 recurrence + 8 accumulation flop per step;
         # paired synthesis (general + gradient-only input on one recursion, shts.alm2map_spin_pair): 8 recurrence + 16 + 8
         # accumulation flop per step (SURVEY's fixed count for the two transforms it replaces would be 48)
@@ -293,38 +375,97 @@ def main():
                'leg_synths_grad': flops_spin * 16. / 24., 'leg_synths_pair': flops_spin * 32. / 24.}
         exe = {'leg_synth0': exec_scal, 'leg_synths': exec_spin, 'leg_anal0': exec_scal, 'leg_anals': exec_spin,
                'leg_synths_grad': exec_spin * 16. / 24., 'leg_synths_pair': exec_spin * 32. / 24.}
+        # components per ring-FFT stage launch are not recorded by the profile; both directions move, per component,
+        # 8 npix + 32 npairs (mmax + 1) algorithmic bytes.  Launch mix of one 'p' reconstruction (qest._get_sim_MVgclm):
+        # synthesis stages of 1 + 2 + 2 + 4 components in 4 launches, analysis stages of 1 + 2 + 2 in 3 launches.
+        comps_per_launch = {'fft_synth': 9. / 4., 'fft_anal': 5. / 3.} if (key == 'p' and not args.qe_only) else {}
+        fft_bytes_comp = 8.0 * npix + 32.0 * 2 * nside * (lmax + 1)
+        per_kernel = {}
         for k, (m_, c_) in prof.items():
             if c_ == 0:
                 continue
             ent = {'avg_ms': m_ / c_, 'launches': c_, 'share_of_step': m_ / (1e3 * dt)}
             if k in alg:
-                ent['alg_tflops'] = alg[k] / (m_ / c_ * 1e-3) / 1e12
                 ent['executed_tflops'] = exe[k] / (m_ / c_ * 1e-3) / 1e12
-            else:  # ring FFT stage: algorithmic bytes = 8 npix + 32 nrings_pairs (mmax+1) per component
-                ent['alg_gbs'] = (8.0 * npix + 32.0 * 2 * nside * (lmax + 1)) / (m_ / c_ * 1e-3) / 1e9
+                ent['fixed_denominator_tflops'] = alg[k] / (m_ / c_ * 1e-3) / 1e12
+            elif k in comps_per_launch:
+                ent['components_per_launch'] = comps_per_launch[k]
+                ent['ms_per_component'] = m_ / c_ / comps_per_launch[k]
+                ent['alg_gbs_per_component'] = fft_bytes_comp / (ent['ms_per_component'] * 1e-3) / 1e9
+                ent['frac_of_achievable_hbm'] = ent['alg_gbs_per_component'] / HBM_ACHIEVABLE_GBS
             per_kernel[k] = ent
         res['kernels'] = per_kernel
+        leg = [k for k in per_kernel if k in alg]
+        if leg:
+            dom = max(leg, key=lambda k: prof[k][0])  # largest summed time in the timed region
+            ms, cnt = prof[dom]
+            avg_ms = ms / cnt
+            ach = exe[dom] / (avg_ms * 1e-3) / 1e12
+            fixed = alg[dom] / (avg_ms * 1e-3) / 1e12
+            res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP64_PEAK_TFLOPS,
+                               'traffic': PMC_TRAFFIC_BYTES.get(dom) if (nside, lmax) == (2048, 2048) else None,
+                               'kernel': KERNEL_NAMES.get(dom, dom), 'avg_launch_ms': avg_ms, 'launches': cnt,
+                               'share_of_step': ms / (1e3 * dt),
+                               'achieved_fixed_denominator': fixed, 'frac_fixed_denominator': fixed / FP64_PEAK_TFLOPS,
+                               'fma_issue_ceiling_measured_tflops': fma_ceilings(),
+                               'note': 'dominant kernel = largest summed time in the timed region. FP64 vector-FMA issue bound (v_fma_f64); gfx950 FP64 MFMA '
+                                       'peak = FP64 vector peak; no MFMA used. achieved = EXECUTED flops (the (l, m, ring pair) steps the kernel runs after '
+                                       'libsharp-style polar pruning) / mean launch time (HIP events on the launch stream); achieved_fixed_denominator = '
+                                       'SURVEY 8(d) count (24 or 8 flop x nalm x 2 nside, pruning not credited). peak = datasheet 78.6 TF; '
+                                       'fma_issue_ceiling_measured_tflops is what a pure FMA loop sustains on this GPU by operand mix. '
+                                       'traffic = FETCH_SIZE + WRITE_SIZE bytes per launch (%s: PMC passes of the same kernel)' % PMC_TRAFFIC_SOURCE}
         # whole-reconstruction algorithmic traffic (counting rule of SURVEY.md 8(d))
         b_scal = 8.0 * npix + 16.0 * nalm
         b_spin = 2 * b_scal
         bytes_rec = 2 * b_scal + 7 * b_spin   # each map (8 npix B) and alm (16 nalm B) component touched once per transform
         res['hbm'] = {'algorithmic_GB_per_reconstruction': bytes_rec / 1e9,
-                      'achieved_GBs': bytes_rec / 1e9 / (dt / args.steps), 'peak_GBs': HBM_PEAK_GBS,
-                      'frac': bytes_rec / 1e9 / (dt / args.steps) / HBM_PEAK_GBS,
+                      'achieved_GBs': bytes_rec / 1e9 / (dt / K), 'peak_GBs': HBM_PEAK_GBS,
+                      'frac': bytes_rec / 1e9 / (dt / K) / HBM_PEAK_GBS,
                       'note': 'path is FP64-FMA bound (arithmetic intensity ~190 flop/B): a low HBM fraction is a property of the algorithm'}
-        if world == 1 and not args.no_cpu_baseline:
+    # release the QE working set before the CG block
+    del sims, ivfs, qlms, gathered
+    if world == 1 and rank == 0:
+        if not args.no_cg:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, 'tools'))
+                import cg_bench
+                cg = cg_bench.run(nside, lmax, args.cg_iters, kinds=('t', 'p'), peak_tflops=FP64_PEAK_TFLOPS)
+                res['cg'] = {'metric': 'CG-iter/sec: qcinv multigrid Wiener filter, cinv_t + cinv_p, nside=%d lmax=%d, masked sky fsky=%.2f, '
+                                       '%d top-level iterations each (eps_min=0), default chains, dense preconditioner cached outside the timed region'
+                                       % (nside, lmax, cg['fsky'], args.cg_iters),
+                             'T_iters_per_s': cg['t']['iters_per_s'], 'P_iters_per_s': cg['p']['iters_per_s'],
+                             'TP_iters_per_s': cg['tp']['iters_per_s'], 'TP_ms_per_iter': cg['tp']['ms_per_iter'],
+                             'fp64_floor_ms_per_iter': cg['tp'].get('fp64_floor_ms_per_iter'),
+                             'frac_of_fp64_floor': cg['tp'].get('frac_of_fp64_floor'),
+                             'dense_setup_s': {'t': cg['t']['first_call_incl_dense_setup_s'], 'p': cg['p']['first_call_incl_dense_setup_s']},
+                             'residual_first_last': {'t': cg['t']['eps_first_last'], 'p': cg['p']['eps_first_last']}}
+            except Exception as e:  # a report, never a reason to lose the QE number
+                res['cg'] = {'error': repr(e)}
+        if not args.no_cpu_baseline:
             try:
                 res['cpu_baseline'] = cpu_baseline(nside, lmax, args.cpu_seconds)
-            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+            except Exception as e:
                 res['cpu_baseline'] = {'value': None, 'unit': 'reconstructions/s', 'cores': os.cpu_count(), 'kind': 'port',
                                        'sample': 'failed: %r' % (e,)}
-        print(json.dumps(res))
+    if rank == 0:
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
+    return 0
+
+
+def main():
+    args = parse()
+    if args.gpus < 1:
+        sys.stderr.write('bench.py: --gpus must be >= 1\n')
+        return 2
+    if 'RANK' not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus, sys.argv[1:])
+    return run_rank(args)
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

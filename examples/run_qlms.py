@@ -60,12 +60,14 @@ def main():
         qlib.get_sim_qlm(k, idx)
     mpi.barrier()
 
-    # --- mean-fields
+    # --- mean-fields: every rank takes part in every mean field -- the simulations of one mean field are sharded over the
+    # ranks inside get_sim_qlm_mf and summed with one all-reduce (the reference shards the (key, half) jobs instead,
+    # run_qlms.py:92-95, each rank looping over all simulations of its job)
     if args.mfdd:
         keys = list(np.unique(np.concatenate([args.kA, args.kB])))
         jobs = [(k, 0) for k in keys] + [(k, 1) for k in keys]
-        for i, (k, id0) in enumerate(jobs[mpi.rank::mpi.size]):
-            print("rank %s doing %s QE MF %s" % (mpi.rank, k, id0))
+        for i, (k, id0) in enumerate(jobs):
+            print("rank %s doing its share of %s QE MF %s" % (mpi.rank, k, id0))
             par.qlms_dd.get_sim_qlm_mf(k, par.qcls_dd.mc_sims_mf[id0::2])
     mpi.barrier()
 

@@ -28,12 +28,12 @@ def init(backend=None):
         return rank, size
     if not dist.is_initialized():
         import torch
-        if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend is None:  # PLENS_DIST_BACKEND=gloo: several ranks sharing one GPU (tests), collectives staged through the host
+            backend = os.environ.get('PLENS_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        if backend == 'nccl':
-            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)) % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend)
         _initialised_here = True
     rank, size = dist.get_rank(), dist.get_world_size()

@@ -38,6 +38,11 @@ def allreduce_sum(x):
         dist.all_reduce(_as_real(t))
         x[...] = t.cpu().numpy()
         return x
+    if x.is_cuda and dist.get_backend() != 'nccl':  # device tensors over a CPU backend (gloo in the tests): staged through the host
+        h = _as_real(x).cpu()
+        dist.all_reduce(h)
+        _as_real(x).copy_(h)
+        return x
     dist.all_reduce(_as_real(x))
     return x
 
@@ -48,8 +53,13 @@ def allgather(x):
     if dist is None:
         return [x]
     r = _as_real(x.contiguous())
+    staged = r.is_cuda and dist.get_backend() != 'nccl'
+    if staged:
+        r = r.cpu()
     out = [torch.empty_like(r) for _ in range(dist.get_world_size())]
     dist.all_gather(out, r)
+    if staged:
+        out = [o.to(x.device) for o in out]
     return [torch.view_as_complex(o) if x.is_complex() else o for o in out]
 
 

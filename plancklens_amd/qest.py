@@ -117,7 +117,8 @@ class library(object):
                                       'ptt_bh_s', 'ptt_bh_f', 'ptt_bh_d', 'dtt_bh_p', 'stt_bh_p', 'ftt_bh_d', 'p_bh_s']
         self.keys_remaps = {'s': 'stt'}
         self._mem = {}
-        self._last_dev = None  # device tensors (G, C) of the most recent MV evaluation
+        self._last_dev = None  # device tensors (G, C) of the most recent gradient / curl evaluation ...
+        self._last_dev_key = None  # ... and its (gradient key, idx): lets the mean-field sum stay on the device
 
     def hashdict(self):
         return {'f2map1': self.f2map1.hashdict(), 'f2map2': self.f2map2.hashdict()}
@@ -235,19 +236,33 @@ class library(object):
             return ut.alm_copy(self._mem[('mf', fname)], lmax=lmax)
         if not (self.cache and os.path.exists(fname)):
             this_mcs = np.unique(mc_sims)
-            MF = np.zeros(hp.Alm.getsize(lmax), dtype=complex)
             if len(this_mcs) == 0:
-                return MF
-            for i, idx in ut.enumerate_progress(this_mcs, label='calculating %s MF' % k):
-                MF += self.get_sim_qlm(k, idx, lmax=lmax)
-            MF /= len(this_mcs)
+                return np.zeros(hp.Alm.getsize(lmax), dtype=complex)
+            # The simulations are independent: every rank evaluates its share jobs[rank::size] of them, the running sum
+            # stays on the device, one all-reduce (RCCL over xGMI) completes it.  With one rank this is
+            # the reference's loop (qest.py:238-244).  The cache file is written by rank 0 only.
+            from . import parallel
+            like = torch.zeros(hp.Alm.getsize(lmax), dtype=torch.complex128, device='cuda')
+            MF = dev.to_host(parallel.mean_field(lambda idx: self._get_sim_qlm_dev(k, idx, lmax), this_mcs, like))
             if self.cache:
-                _write_alm(fname, MF)
-                print("Cached ", fname)
+                if mpi.rank == 0:
+                    _write_alm(fname, MF)
+                    print("Cached ", fname)
+                mpi.barrier()
             else:
                 self._mem[('mf', fname)] = MF
-                return ut.alm_copy(MF, lmax=lmax)
+            return ut.alm_copy(MF, lmax=lmax)
         return ut.alm_copy(hp.read_alm(fname), lmax=lmax)
+
+    def _get_sim_qlm_dev(self, k, idx, lmax):
+        """get_sim_qlm as a device tensor: the evaluation (and its cache entry) is the public one; when it has just run
+        its device result is handed over instead of uploading the host copy again."""
+        self._last_dev_key = None
+        q = self.get_sim_qlm(k, idx, lmax=lmax)
+        if (self._last_dev is not None and self._last_dev_key == ('p', idx, False) and k in ('p', 'x') and self._same_legs()
+                and self._last_dev[0].numel() == q.size):
+            return self._last_dev[0 if k == 'p' else 1]
+        return dev.to_dev(q, torch.complex128)
 
     # ---- estimators (device) -----------------------------------------------------------------------
     def _legs(self, swapped):
@@ -326,7 +341,7 @@ class library(object):
         dre, dim = dev.qe_lens_product((tmap, gt, ct), (rep, imp, g3, c3, g1, c1))  # all nine leg maps in one pass
         del tmap, gt, ct, rep, imp, g3, c3, g1, c1
         G, C = self._gc_from_product(dre, dim, 'P')
-        self._last_dev = (G, C)
+        self._last_dev, self._last_dev_key = (G, C), ('p', idx, swapped)
         return dev.to_host(G), dev.to_host(C)
 
     def _scalar_from_product(self, prod, fac, lmax_key):

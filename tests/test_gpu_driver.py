@@ -33,6 +33,42 @@ def test_run_qlms_idealized_small(tmp_path):
     assert hp.Alm.getlmax(qlm.size) == 256 and np.all(np.isfinite(qlm.real)) and np.abs(qlm).max() > 0
 
 
+def test_two_ranks_share_the_mean_field(tmp_path):
+    """The product's distributed path on the GPU box: two ranks (gloo rendezvous, both on GPU 0, collectives staged through the
+    host -- RCCL needs one GPU per rank) run the driver with -mfdd.  qest.library.get_sim_qlm_mf shards the simulations of
+    each mean field over the ranks and all-reduces the device-resident sums; the cache files must equal those of a
+    single-process run to rounding, and every simulation must have been reconstructed by exactly one rank."""
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    args = [os.path.join(ROOT, 'examples', 'run_qlms.py'), os.path.join(ROOT, 'params', 'idealized_example.py'),
+            '-imin', '0', '-imax', '5', '-k', 'p', '-kA', 'p', '-kB', 'p', '-ivt', '-ivp', '-dd', '-mfdd']
+    base = dict(os.environ, PLENS_NSIDE='32', PLENS_LMAX='64', PLENS_NSIMS='20')  # mean-field simulations 0..3, halves [0, 2] and [1, 3]
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        base.pop(k, None)
+    one = subprocess.run([sys.executable] + args, env=dict(base, PLENS=str(tmp_path / 'one')), cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=900)
+    assert one.returncode == 0, one.stdout.decode()[-3000:]
+    procs = [subprocess.Popen([sys.executable] + args, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              env=dict(base, PLENS=str(tmp_path / 'two'), RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
+                                       MASTER_PORT=str(port), PLENS_DIST_BACKEND='gloo')) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    # jobs[rank::size]: each rank reconstructed its own simulations only
+    for r, o in enumerate(outs):
+        mine = [int(l.split('QE sim ')[1].split()[0]) for l in o.splitlines() if 'doing QE sim' in l]
+        assert mine == list(range(0, 6))[r::2], (r, mine)
+    sys.path.insert(0, ROOT)
+    from plancklens_amd import hp
+    d1 = os.path.join(str(tmp_path), 'one', 'temp', 'idealized_example', 'qlms_dd')
+    d2 = os.path.join(str(tmp_path), 'two', 'temp', 'idealized_example', 'qlms_dd')
+    mfs = sorted(f for f in os.listdir(d1) if f.startswith('simMF_'))
+    assert len(mfs) == 2 and mfs == sorted(f for f in os.listdir(d2) if f.startswith('simMF_'))
+    for f in mfs + ['sim_p_0003.fits']:
+        a, b = hp.read_alm(os.path.join(d1, f)), hp.read_alm(os.path.join(d2, f))
+        assert np.abs(a).max() > 0 and np.abs(a - b).max() < 1e-12 * np.abs(a).max(), f
+
+
 def test_device_side_simulation_libraries(tmp_path):
     """phases, correlated sky alms, sky maps and noise generated on the GPU (no host arrays on the way):
     reproducible per (seed, field, index), unit variance, right spectra including the TE correlation."""
