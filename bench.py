@@ -100,7 +100,7 @@ def parse(argv=None):
     ap.add_argument('--qe-only', action='store_true',
                     help='time the estimator from filtered alms that are already resident (the cost of a further key in the reference, qest.py:184-185)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU baseline (all repetitions together)')
+    ap.add_argument('--cpu-seconds', type=float, default=45.0, help='budget of the CPU baseline (warm-up and all repetitions together)')
     ap.add_argument('--no-cg', action='store_true', help='skip the CG block (BASELINE config 4)')
     ap.add_argument('--cg-iters', type=int, default=100)
     return ap.parse_args(argv)
@@ -180,8 +180,10 @@ class resident_sims(object):
 
 def cpu_baseline(nside, lmax, budget_seconds, reps=3):
     """One 'p' reconstruction's 9 SHTs with the CPU oracle: Legendre stage in C (OpenMP over all host cores), ring FFTs
-    with numpy's pocketfft on a thread pool.  Full unit (every ring pair) when 1 warm-up + `reps` repetitions fit the
-    budget; otherwise every stride-th ring pair of each transform, time x stride (stated in the result).  Median of reps."""
+    with numpy's pocketfft on a thread pool, output maps preallocated.  Every ring pair of every transform (no
+    extrapolation) whenever 1 warm-up + 1 repetition fit the budget -- then as many repetitions up to `reps` as fit, median
+    reported; otherwise every stride-th ring pair with the time extrapolated through the measured fixed + per-ring cost
+    model (stated in the result)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import sht_oracle as so
     ncores = os.cpu_count() or 1
@@ -190,6 +192,7 @@ def cpu_baseline(nside, lmax, budget_seconds, reps=3):
     nalm = so.alm_size(lmax)
     alm2 = (rng.standard_normal((2, nalm)) + 1j * rng.standard_normal((2, nalm)))
     maps = rng.standard_normal((2, 12 * nside ** 2))
+    outm = np.zeros((2, 12 * nside ** 2))
     synth = [0, 2, 3, 1, 1]   # Tb map, (Qb, Ub), spin-3 leg, spin-1 leg (P), spin-1 gradient leg (T)
     anal = [0, 2, 1, 1]       # T filter, P filter, the two final spin-1 analyses of the reference (qest.py:318-322)
     nfft = max(1, min(ncores, 64))
@@ -215,7 +218,7 @@ def cpu_baseline(nside, lmax, budget_seconds, reps=3):
         for spin in synth:
             nc = 1 if spin == 0 else 2
             ph = so.legendre(0, 1, spin, lmax, lmax, cs, ss, ps, alm=alm2[:nc], nthreads=ncores)
-            list(pool.map(lambda a: so._phase2map(ph[a[0]][rows(a[1])], nside, lmax, a[2]),
+            list(pool.map(lambda a: so._phase2map(ph[a[0]][rows(a[1])], nside, lmax, a[2], out=outm[a[0]]),
                           [(i, ch, sl) for i in range(nc) for ch, sl in zip(chunks, sls)]))
         for spin in anal:
             nc = 1 if spin == 0 else 2
@@ -228,23 +231,35 @@ def cpu_baseline(nside, lmax, budget_seconds, reps=3):
             so.legendre(1, 1, spin, lmax, lmax, cs, ss, ps, phase=ph, nthreads=ncores)
         return time.perf_counter() - t0
 
-    t = run(64)  # calibration pass (also warms the library and the thread pool)
-    est_full = t * 64
-    stride = 1
-    while est_full / stride * (reps + 1) > budget_seconds and stride < 64:
-        stride *= 2
-    run(stride)  # warm-up at the measured size
-    ts = sorted(run(stride) for _ in range(reps))
+    # cost model t(nrings) = fixed + per_ring * nrings from two sparse passes (the per-m table set-up of the Legendre stage
+    # and the Python ring bookkeeping do not shrink with the ring sample)
+    run(64)
+    t64, t16 = run(64), run(16)
+    n64, n16, nfull = len(range(0, 2 * nside, 64)), len(range(0, 2 * nside, 16)), 2 * nside
+    per_ring = max((t16 - t64) / (n16 - n64), 0.)
+    fixed = max(t64 - per_ring * n64, 0.)
+    est_full = fixed + per_ring * nfull
+    if 2 * est_full <= budget_seconds:
+        stride, nrep = 1, int(max(1, min(reps, budget_seconds // est_full - 1)))
+        run(1)  # warm-up at full size
+    else:
+        stride, nrep = 2, reps
+        while (fixed + per_ring * nfull / stride) * (nrep + 1) > budget_seconds and stride < 64:
+            stride *= 2
+        run(stride)
+    ts = sorted(run(stride) for _ in range(nrep))
     t = ts[len(ts) // 2]
     pool.shutdown()
-    sec_per_rec = t * stride
-    sample = "all %d ring pairs" % (2 * nside) if stride == 1 else "every %d-th ring pair (of %d), time x %d (EXTRAPOLATED)" % (stride, 2 * nside, stride)
+    sec_per_rec = t if stride == 1 else fixed + max(t - fixed, 0.05 * t) * stride
+    sample = ("every ring pair (all %d), no extrapolation" % nfull if stride == 1 else
+              "every %d-th ring pair (of %d), EXTRAPOLATED as fixed + (t - fixed) x %d with fixed = %.2f s measured from two sparse passes"
+              % (stride, nfull, stride, fixed))
     return {'value': 1.0 / sec_per_rec, 'unit': 'reconstructions/s', 'cores': ncores, 'kind': 'port',
-            'extrapolated_from_ring_stride': stride, 'repetitions': reps, 'fft_threads': nfft,
-            'sample': "%s of each of the 9 SHTs of one 'p' reconstruction as the reference runs it (2 scalar + 7 spin-weighted pairs, "
-                      "qest.py:318-322) at nside=%d lmax=%d; oracle C Legendre stage with OpenMP on %d threads + "
-                      "numpy ring FFTs on %d threads; 1 warm-up + %d repetitions, median %.2f s (min %.2f, max %.2f); the oracle is a long-double-checked "
-                      "restatement, not a tuned libsharp-class code" % (sample, nside, lmax, ncores, nfft, reps, t, ts[0], ts[-1])}
+            'extrapolated_from_ring_stride': stride, 'repetitions': nrep, 'fft_threads': nfft, 'seconds_per_reconstruction': sec_per_rec,
+            'sample': "%s, of each of the 9 SHTs of one 'p' reconstruction as the reference runs it (2 scalar + 7 spin-weighted pairs, "
+                      "qest.py:318-322) at nside=%d lmax=%d; oracle C Legendre stage with OpenMP on %d threads + numpy ring FFTs on %d threads; "
+                      "1 warm-up + %d repetition(s), median %.2f s (min %.2f, max %.2f); the oracle is a long-double-checked "
+                      "restatement, not a tuned libsharp-class code" % (sample, nside, lmax, ncores, nfft, nrep, t, ts[0], ts[-1])}
 
 
 def stub_rank(args, rank, world):

@@ -125,6 +125,11 @@ int pl_template_project(int64_t npix, int nmodes, double *tmap, const double *n_
                         double *scratch_dev, void *stream);
 int pl_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, void *stream);
 
+/* y = A x, A row-major nrows x ncols with leading dimension lda, all device arrays (x and y must not overlap): the dense
+ * low-l preconditioner of the CG chains applied as one mat-vec (dense.py:118-119,201-202,284-285), and the template
+ * coefficient products of the joint filter.  One wavefront per row, fixed summation tree (bit-reproducible). */
+int pl_gemv(int nrows, int ncols, int64_t lda, const double *A, const double *x, double *y, void *stream);
+
 /* Pixel-space helpers (qest.py:256-257,276-278; opfilt_tt.py:195, opfilt_pp.py:276-299). */
 /* out = a * b (element-wise, n doubles) */
 int pl_map_mul(int64_t n, const double *a, const double *b, double *out, void *stream);

@@ -144,11 +144,13 @@ def _pair_geometry(nside, use_pairs=True):
     return cth, sth, np.zeros(nr, dtype=np.int32), slots
 
 
-def _phase2map(phase, nside, mmax, slots):
-    """phase[slot, m] -> RING map (one component)."""
+def _phase2map(phase, nside, mmax, slots, out=None):
+    """phase[slot, m] -> RING map (one component).  Only the rings listed in `slots` are written (into `out` when given:
+    callers that transform ring subsets share one map)."""
     cth, sth, nphi, phi0, ofs = ring_geometry(nside)
     npix = 12 * nside ** 2
-    out = np.empty(npix)
+    if out is None:
+        out = np.empty(npix)
     ms = np.arange(mmax + 1)
     ring_of_slot = slots
     ok = ring_of_slot >= 0

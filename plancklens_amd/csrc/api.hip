@@ -31,6 +31,7 @@ void launch_axpy_dev(int64_t n, const double *num, const double *den, double sig
 void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st);
 void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st);
 void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st);
+void launch_gemv(int nrows, int ncols, int64_t lda, const double *A, const double *x, double *y, hipStream_t st);
 void launch_map_mul(int64_t n, const double *a, const double *b, double *out, hipStream_t st);
 void launch_qe_lens_product(int64_t n, const double *tmap, const double *gt, const double *ct, const double *rep, const double *imp,
                             const double *g3, const double *c3, const double *g1, const double *c1, double *outr, double *outi, hipStream_t st);
@@ -600,6 +601,15 @@ int pl_almxfl_add(int lmax, const double *a, const double *b, const double *fl, 
 {
     if (lmax < 0 || !a || !b || !fl || !out) return fail("pl_almxfl_add: bad arguments");
     launch_almxfl_add(lmax, a, b, fl, nfl, out, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_gemv(int nrows, int ncols, int64_t lda, const double *A, const double *x, double *y, void *stream)
+{
+    if (nrows < 0 || ncols < 0 || lda < ncols || !A || !x || !y) return fail("pl_gemv: bad arguments");
+    if (nrows == 0) return 0;
+    launch_gemv(nrows, ncols, lda, A, x, y, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -259,6 +259,44 @@ __global__ __launch_bounds__(256) void k_tproj_apply(int64_t n, int nmodes, doub
     }
 }
 
+// ---- dense mat-vec y = A x (the dense coarse preconditioner, dense.py:118-119,201-202,284-285) -------------------------
+// A row-major (nrows x ncols, leading dimension lda).  One wavefront per row: every trip the wave reads 1 KiB of the row
+// with 16-byte loads per lane (VEC = 2), four trips in flight; x comes from L2 / L1 (34 KiB at the 4290-column T block).
+// The 147 MB T matrix lives in the 256 MB Infinity Cache between applications: the floor is its streaming rate, not HBM.
+// Lane partial sums are added in a fixed tree: bit-reproducible.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_gemv(int nrows, int ncols, int64_t lda, const double *__restrict__ A, const double *__restrict__ x,
+                                              double *__restrict__ y)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const double *__restrict__ a = A + (int64_t)row * lda;
+    double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+    if constexpr (VEC == 2) {
+        const double2 *__restrict__ a2 = reinterpret_cast<const double2 *>(a);
+        const double2 *__restrict__ x2 = reinterpret_cast<const double2 *>(x);
+        const int n2 = ncols >> 1;
+        int c = lane;
+        for (; c + 192 < n2; c += 256) {
+            const double2 u0 = a2[c], u1 = a2[c + 64], u2 = a2[c + 128], u3 = a2[c + 192];
+            const double2 v0 = x2[c], v1 = x2[c + 64], v2 = x2[c + 128], v3 = x2[c + 192];
+            s0 = fma(u0.x, v0.x, s0); s0 = fma(u0.y, v0.y, s0);
+            s1 = fma(u1.x, v1.x, s1); s1 = fma(u1.y, v1.y, s1);
+            s2 = fma(u2.x, v2.x, s2); s2 = fma(u2.y, v2.y, s2);
+            s3 = fma(u3.x, v3.x, s3); s3 = fma(u3.y, v3.y, s3);
+        }
+        for (; c < n2; c += 64) { const double2 u = a2[c], v = x2[c]; s0 = fma(u.x, v.x, s0); s0 = fma(u.y, v.y, s0); }
+        if ((ncols & 1) && lane == 0) s1 = fma(a[ncols - 1], x[ncols - 1], s1);
+    } else {
+        for (int c = lane; c < ncols; c += 64) s0 = fma(a[c], x[c], s0);
+    }
+    double v = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) y[row] = v;
+}
+
 // out (band-limit lmax_hi) = alm_lo for l <= lsplit, alm_hi above (util_alm.py:8-24)
 __global__ void k_alm_splice(int lmax_lo, const double2 *__restrict__ lo, int lmax_hi, const double2 *__restrict__ hi, int lsplit,
                              double2 *__restrict__ out)
@@ -307,6 +345,12 @@ void launch_template_project(int64_t n, int nmodes, double *t, const double *n_i
 {
     hipLaunchKernelGGL(k_tproj_coeffs, dim3(kProjParts), dim3(kProjThreads), 0, st, n, nmodes, t, n_inv, pm, parts);
     hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n)), dim3(256), 0, st, n, nmodes, t, rm, parts);
+}
+void launch_gemv(int nrows, int ncols, int64_t lda, const double *A, const double *x, double *y, hipStream_t st)
+{
+    const bool vec = (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(k_gemv<2>, dim3((nrows + 3) / 4), dim3(256), 0, st, nrows, ncols, lda, A, x, y);
+    else hipLaunchKernelGGL(k_gemv<1>, dim3((nrows + 3) / 4), dim3(256), 0, st, nrows, ncols, lda, A, x, y);
 }
 void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st)
 {

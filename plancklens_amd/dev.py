@@ -165,6 +165,17 @@ def template_project(tmap, n_inv, pmat, rmat):
     return tmap
 
 
+def gemv(amat, x, out=None):
+    """y = A x on the device (pl_gemv): A a contiguous (nrows, ncols) float64 tensor, x float64 of ncols entries."""
+    assert amat.dim() == 2 and amat.is_contiguous() and amat.dtype == torch.float64 and x.dtype == torch.float64
+    x = x.contiguous()
+    assert x.numel() == amat.shape[1], (x.shape, amat.shape)
+    if out is None:
+        out = torch.empty(amat.shape[0], dtype=torch.float64, device=amat.device)
+    _lib.check(_lib.lib().pl_gemv(amat.shape[0], amat.shape[1], amat.shape[1], amat.data_ptr(), x.data_ptr(), out.data_ptr(), stream_ptr()))
+    return out
+
+
 def alm2cl(a, b=None):
     lmax = Alm.getlmax(a.numel())
     out = torch.empty(lmax + 1, dtype=torch.float64, device=a.device)

@@ -1,7 +1,7 @@
 """Dense low-l preconditioners, API of plancklens/qcinv/dense.py (`alm2rlm` / `rlm2alm` :16-54, `pre_op_dense_tt`
 :57-119, `pre_op_dense_pp` :123-202, `pre_op_dense_tp` :204-285).  The (lmax+1)^2 k square matrix is filled by applying the coarse fwd_op to unit
-vectors (device SHTs), pseudo-inverted on the host with eigh exactly as the reference does, and applied as a device
-mat-vec."""
+vectors (device SHTs), pseudo-inverted on the host with eigh exactly as the reference does, and applied as one device
+mat-vec (pl_gemv, csrc/elementwise.hip)."""
 from __future__ import print_function
 
 import os
@@ -183,7 +183,7 @@ class _pre_op_dense(object):
 
     def calc(self, talm):
         if isinstance(talm, np.ndarray):
-            return self._to_alm(torch.mv(self.minv, self._to_rlm(talm)))
+            return dev.to_host(self.calc(dev.to_dev(talm, torch.complex128)))  # host array in, host array out (temperature block)
         # device vectors: alm -> rlm, the pseudo-inverse and rlm -> alm as ONE matrix acting on the interleaved (re, im)
         # view of the alm arrays -- the preconditioner is applied dozens of times per top-level iteration at a
         # resolution where a kernel costs less to run than to launch
@@ -191,7 +191,7 @@ class _pre_op_dense(object):
         if getattr(self, '_amat', None) is None:
             self._amat = _flat_matrix(self.minv, self.lmax, len(parts))
         flat = [torch.view_as_real(p).reshape(-1) for p in parts]
-        out = torch.mv(self._amat, flat[0] if len(flat) == 1 else torch.cat(flat))
+        out = dev.gemv(self._amat, flat[0] if len(flat) == 1 else torch.cat(flat))  # pl_gemv: one launch
         n = flat[0].numel()
         res = [torch.view_as_complex(out[k * n:(k + 1) * n].view(-1, 2)) for k in range(len(parts))]
         return res[0] if len(res) == 1 else (eblm(res) if len(res) == 2 else teblm(res))

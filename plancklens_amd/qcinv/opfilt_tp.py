@@ -269,29 +269,34 @@ class alm_filter_ninv(object):
     def apply_map(self, amap):
         """(T, Q, U) <- N^-1 (T, Q, U) with the T templates projected out (in place)."""
         tmap, qmap, umap = amap
-        if len(self.n_inv) == 2:  # TT, QQ = UU
+        if len(self.templates_t) != 0 and getattr(self, '_pmat', None) is None:
+            # all template modes as one device matrix P (nmodes x npix): coefficients, the small solve and the projected
+            # map are device operations, nothing comes back to the host inside a CG iteration
+            rows = []
+            for t in self.templates_t:
+                for i in range(t.nmodes):
+                    row = torch.ones_like(tmap)
+                    t.apply_mode(row, i)
+                    rows.append(row)
+            self._pmat = torch.stack(rows)
+            pinv = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64)
+            # N^-1 P (P^t N^-1 P)^-1 as one matrix: the projection is c = P^t t and t -= R^t c
+            self._rmat = torch.mm(pinv, self._pmat * self.n_inv[0].unsqueeze(0))
+        # temperature: N^-1 weighting and template projection in two launches (pl_template_project), as in opfilt_tt
+        fused_t = len(self.templates_t) != 0 and self._pmat.shape[0] <= dev.TEMPLATE_MAX_MODES and tmap.is_contiguous()
+        if fused_t:
+            dev.template_project(tmap, self.n_inv[0], self._pmat, self._rmat)
+        else:
             tmap *= self.n_inv[0]
+        if len(self.n_inv) == 2:  # TT, QQ = UU
             qmap *= self.n_inv[1]
             umap *= self.n_inv[1]
         else:  # TT, QQ, QU, UU
             qmap_copy = qmap.clone()
-            tmap *= self.n_inv[0]
             qmap *= self.n_inv[1]
             qmap += self.n_inv[2] * umap
             umap *= self.n_inv[3]
             umap += self.n_inv[2] * qmap_copy
-        if len(self.templates_t) != 0:
-            # all template modes as one device matrix P (nmodes x npix): coefficients, the small solve and the projected
-            # map are device operations, nothing comes back to the host inside a CG iteration
-            if getattr(self, '_pmat', None) is None:
-                rows = []
-                for t in self.templates_t:
-                    for i in range(t.nmodes):
-                        row = torch.ones_like(tmap)
-                        t.apply_mode(row, i)
-                        rows.append(row)
-                self._pmat = torch.stack(rows)
-                pinv = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64)
-                # N^-1 P (P^t N^-1 P)^-1 as one matrix: the projection is two mat-vecs, c = P^t t and t -= R^t c
-                self._rmat = torch.mm(pinv, self._pmat * self.n_inv[0].unsqueeze(0))
-            tmap.addmv_(self._rmat.t(), torch.mv(self._pmat, tmap), alpha=-1.0)
+        if len(self.templates_t) != 0 and not fused_t:  # more modes than pl_template_project takes: two mat-vecs (pl_gemv) + rank update
+            coeffs = dev.gemv(self._pmat, tmap)
+            tmap.addmv_(self._rmat.t(), coeffs, alpha=-1.0)

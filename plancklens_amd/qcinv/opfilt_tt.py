@@ -197,4 +197,4 @@ class alm_filter_ninv(object):
                 dev.template_project(tmap, self.n_inv, self._pmat, self._rmat)  # N^-1 weighting + projection, two launches
             else:
                 tmap *= self.n_inv
-                tmap.addmv_(self._rmat.t(), torch.mv(self._pmat, tmap), alpha=-1.0)
+                tmap.addmv_(self._rmat.t(), dev.gemv(self._pmat, tmap), alpha=-1.0)  # more modes than pl_template_project takes

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_contract():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--nside', '64', '--lmax', '64', '--steps', '2', '--warmup', '1',
-                          '--cpu-seconds', '1'], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                          '--cpu-seconds', '1', '--no-cg'], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith('{')]
     assert len(lines) == 1, out.stdout  # exactly one JSON line on stdout
@@ -32,3 +32,4 @@ def test_bench_line_contract():
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in c, k
     assert c['kind'] in ('reference', 'port') and c['value'] > 0 and c['cores'] >= 1
+    assert d['ranks_seen'] == 1 and 'kernels' in d and 'leg_anals' in d['kernels']

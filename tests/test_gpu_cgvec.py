@@ -104,3 +104,26 @@ def test_template_project(npix, nmodes):
     dt2 = dev.to_dev(t)
     dev.template_project(dt2, dev.to_dev(ninv), dev.to_dev(pm), dev.to_dev(rm))
     assert torch.equal(dt, dt2)  # bit-reproducible
+
+
+@pytest.mark.parametrize('nrows,ncols', [(1, 1), (7, 5), (64, 257), (130, 4290), (4290, 4290), (33, 1000)])
+def test_gemv_vs_numpy(nrows, ncols):
+    """pl_gemv (the dense preconditioner mat-vec, dense.py:118-119): against numpy on the host, odd and even sizes (the
+    16-byte and the scalar load variants), and bit-reproducible from call to call."""
+    import torch
+    from plancklens_amd import dev
+    rng = np.random.default_rng(nrows * 7 + ncols)
+    a = rng.standard_normal((nrows, ncols))
+    x = rng.standard_normal(ncols)
+    ad, xd = dev.to_dev(a), dev.to_dev(x)
+    y = dev.gemv(ad, xd)
+    ref = a @ x
+    assert np.abs(dev.to_host(y) - ref).max() < 1e-13 * np.sqrt(ncols) * max(1., np.abs(ref).max())
+    assert bool((dev.gemv(ad, xd) == y).all())
+    if ncols > 3:  # a view with an odd leading dimension takes the scalar-load kernel
+        sub = ad[:, :ncols - 1]
+        y2 = torch.empty(nrows, dtype=torch.float64, device='cuda')
+        from plancklens_amd import _lib
+        _lib.check(_lib.lib().pl_gemv(nrows, ncols - 1, ncols, sub.data_ptr(), xd.data_ptr(), y2.data_ptr(), dev.stream_ptr()))
+        ref2 = a[:, :ncols - 1] @ x[:ncols - 1]
+        assert np.abs(dev.to_host(y2) - ref2).max() < 1e-13 * np.sqrt(ncols) * max(1., np.abs(ref2).max())

@@ -6,8 +6,18 @@ and ring FFTs take a ring subset, so the kernels that only run at full size -- r
 scaling phases with the L2 coefficient prefetch, every register-resident FFT class and the Bluestein class boundaries --
 are compared with the oracle directly on ~70 ring pairs: the first polar rings, the rings around every power-of-two and
 Bluestein-class boundary, the cap / belt transition, the equator, and a seeded random set.  All orders m.
-Tolerance 1e-11 relative rms per ring (observed ~1e-15 ... 1e-13).
+
+Tolerance, per ring: 1e-11 relative rms (observed 1e-15 ... 1e-13) plus the conditioning of the problem in its own input:
+every FP64 implementation (libsharp, the oracle, these kernels) takes the ring colatitude as the double cos(theta), and
+d lambda_lm / d cos(theta) ~ l min(l, 1 / sin(theta)) lambda_lm, so two correct implementations that round cos(theta) (or its
+square, as the two-l-step recursion of the spin-0 kernels does) differently by one ulp differ by up to
+~1.1e-16 l min(l, 1 / sin(theta)) -- 4.6e-10 at the first polar ring for l = 2048, 1e-13 in the belt.  That bound is allowed
+on top of 1e-11 (observed: spin 0, whose kernels square cos(theta), 2e-11 ... 8e-11 on the first four rings at nside = lmax =
+2048 and 6e-10 at 4096 -- the oracle run in long double on the same double cos(theta) differs from exact geometry by as
+much; spins 1-3 stay below a third of it).  Observed values are appended to gpurun_out/fullsize_parity.txt when that
+directory exists.
 """
+import os
 import ctypes
 
 import numpy as np
@@ -18,6 +28,21 @@ from helpers import random_alm, relrms
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-11
+EPS = 1.1e-16
+
+
+def ring_tol(lmax, sth):
+    """see the module docstring"""
+    return TOL + EPS * lmax * np.minimum(lmax, 1. / np.maximum(sth, 1e-300))
+
+
+def _note(line):
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(d):
+        with open(os.path.join(d, 'fullsize_parity.txt'), 'a') as f:
+            f.write(line + '\n')
+
+
 SIZES = [(2048, 2048), (4096, 4096)]
 
 
@@ -90,6 +115,8 @@ def test_legendre_stage_vs_oracle_on_ring_sample(env, oracle, nside, lmax, spin)
     view, _ = _phase_view(torch, plan, ph_d, ncomp)
     got = view[torch.from_numpy(sel).cuda()][:, :, :lmax + 1, :].cpu().numpy()   # (nsel, ncomp, lmax + 1, 4)
     ref = oracle.legendre(0, 1, spin, lmax, lmax, cs, ss, ps, alm=alm)           # (ncomp, 2 nsel, lmax + 1)
+    tols = ring_tol(lmax, ss)
+    worst = 0.
     for c in range(ncomp):
         gn = got[:, c, :, 0] + 1j * got[:, c, :, 1]
         gs = got[:, c, :, 2] + 1j * got[:, c, :, 3]
@@ -97,12 +124,15 @@ def test_legendre_stage_vs_oracle_on_ring_sample(env, oracle, nside, lmax, spin)
         for i in range(sel.size):
             k = keep[i]
             scale = np.sqrt(np.mean(np.abs(rn[i]) ** 2))
-            assert np.sqrt(np.mean(np.abs(gn[i, k] - rn[i, k]) ** 2)) < TOL * scale, (spin, c, sel[i], 'north')
-            if ps[i]:
-                assert np.sqrt(np.mean(np.abs(gs[i, k] - rs[i, k]) ** 2)) < TOL * scale, (spin, c, sel[i], 'south')
+            en = np.sqrt(np.mean(np.abs(gn[i, k] - rn[i, k]) ** 2)) / scale
+            es = np.sqrt(np.mean(np.abs(gs[i, k] - rs[i, k]) ** 2)) / scale if ps[i] else 0.
+            worst = max(worst, en / tols[i], es / tols[i])
+            assert en < tols[i], (spin, c, sel[i], 'north', en, tols[i])
+            assert es < tols[i], (spin, c, sel[i], 'south', es, tols[i])
             # what the polar pruning leaves out is far below double precision of what it keeps
             if (~k).any():
                 assert np.max(np.abs(rn[i, ~k])) < 1e-14 * scale, (spin, c, sel[i], 'pruned orders are not negligible')
+    _note('legendre synth nside %d lmax %d spin %d: worst error / tolerance over %d ring pairs = %.3f' % (nside, lmax, spin, sel.size, worst))
     del ph_d, view
 
     # ---- analysis: phase rows on the sampled ring pairs only (zero elsewhere) -> alm
@@ -119,7 +149,10 @@ def test_legendre_stage_vs_oracle_on_ring_sample(env, oracle, nside, lmax, spin)
     out = torch.empty((ncomp, plan.nalm), dtype=torch.complex128, device='cuda')
     _lib.check(L.pl_legendre_anal(plan.h, spin, shts._ptr(ph_d), shts._ptr(out), None, shts._stream()))
     ref = oracle.legendre(1, 1, spin, lmax, lmax, cs, ss, ps, phase=ph)
-    assert relrms(out.cpu().numpy(), ref) < TOL, spin
+    err = relrms(out.cpu().numpy(), ref)
+    _note('legendre anal  nside %d lmax %d spin %d: relative rms error of the alm = %.3e' % (nside, lmax, spin, err))
+    # the sample contains the first polar rings: their share of the alm carries the conditioning error of those rings
+    assert err < TOL + EPS * lmax * np.sqrt(np.mean(np.minimum(lmax, 1. / ss) ** 2)), (spin, err)
 
 
 @pytest.mark.parametrize('spin', [0, 2])
@@ -139,8 +172,11 @@ def test_ring_fft_stage_vs_oracle_on_ring_sample(env, oracle, nside, lmax, spin)
     gen.manual_seed(nside + spin)
 
     # ---- synthesis side: phase -> pixels of the sampled rings
+    worst = 0.
     ph_d = torch.randn(plan.phase_doubles(spin), generator=gen, dtype=torch.float64, device='cuda')
     view, _ = _phase_view(torch, plan, ph_d, ncomp)
+    view[:, :, 0, 1] = 0.  # the m = 0 coefficients of a real field are real (the kernels, like libsharp, rely on it)
+    view[:, :, 0, 3] = 0.
     rows = view[torch.from_numpy(sel).cuda()][:, :, :lmax + 1, :].cpu().numpy()
     maps = torch.empty((ncomp, npix), dtype=torch.float64, device='cuda')
     _lib.check(L.pl_phase2map(plan.h, spin, shts._ptr(ph_d), shts._ptr(maps), shts._stream()))
@@ -152,11 +188,15 @@ def test_ring_fft_stage_vs_oracle_on_ring_sample(env, oracle, nside, lmax, spin)
         ref = oracle._phase2map(ph, nside, lmax, sl)
         for r in sl[sl >= 0]:
             a, b = int(ofs[r]), int(ofs[r] + nphi[r])
-            assert relrms(maps[c, a:b].cpu().numpy(), ref[a:b]) < TOL, (spin, c, int(r), int(nphi[r]))
+            e = relrms(maps[c, a:b].cpu().numpy(), ref[a:b])
+            worst = max(worst, e)
+            assert e < TOL, (spin, c, int(r), int(nphi[r]), e)
+    _note('ring fft synth nside %d lmax %d spin %d: worst relative rms error per ring = %.3e' % (nside, lmax, spin, worst))
     del ph_d, view
 
     # ---- analysis side: pixels -> phase rows of the sampled rings
     maps = torch.randn((ncomp, npix), generator=gen, dtype=torch.float64, device='cuda')
+    worst = 0.
     ph_d = torch.zeros(plan.phase_doubles(spin), dtype=torch.float64, device='cuda')
     _lib.check(L.pl_map2phase(plan.h, spin, shts._ptr(maps), shts._ptr(ph_d), shts._stream()))
     view, _ = _phase_view(torch, plan, ph_d, ncomp)
@@ -167,9 +207,11 @@ def test_ring_fft_stage_vs_oracle_on_ring_sample(env, oracle, nside, lmax, spin)
         gs = rows[:, c, :, 2] + 1j * rows[:, c, :, 3]
         for i in range(sel.size):
             k = keep[i]
-            assert relrms(gn[i, k], ref[2 * i, k]) < TOL, (spin, c, sel[i], 'north')
-            if ps[i]:
-                assert relrms(gs[i, k], ref[2 * i + 1, k]) < TOL, (spin, c, sel[i], 'south')
+            en = relrms(gn[i, k], ref[2 * i, k])
+            es = relrms(gs[i, k], ref[2 * i + 1, k]) if ps[i] else 0.
+            worst = max(worst, en, es)
+            assert en < TOL and es < TOL, (spin, c, sel[i], en, es)
+    _note('ring fft anal  nside %d lmax %d spin %d: worst relative rms error per ring = %.3e' % (nside, lmax, spin, worst))
 
 
 def test_full_transform_equals_its_stages_at_4096(env):
