@@ -644,7 +644,7 @@ double pl_fma64_rate_tflops(int mode, int iters, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
     double *out = nullptr;
-    if (mode < 0 || mode > 2) return -1.0;
+    if (mode < 0 || mode > 4) return -1.0;
     if (hipMalloc(reinterpret_cast<void **>(&out), 8) != hipSuccess) return -1.0;
     const int nblk = 256 * 8;
     hipEvent_t e0, e1;
@@ -658,7 +658,9 @@ double pl_fma64_rate_tflops(int mode, int iters, void *stream)
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(out);
     if (!ok || ms <= 0.f) return -1.0;
-    const double flops = 2.0 * 16.0 * (double)iters * 256.0 * nblk;
+    // per trip and wave: modes 0-2 16 v_fma_f64 (128 flop each); mode 3 four 16x16x4 MFMAs (2048 flop each); mode 4 both (4 x 16 FMAs)
+    const double per_wave = mode <= 2 ? 16.0 * 128.0 : (4.0 * 2048.0 + (mode == 4 ? 64.0 * 128.0 : 0.0));
+    const double flops = per_wave * (double)iters * 4.0 * nblk;
     return flops / (ms * 1e-3) / 1e12;
 }
 

@@ -30,19 +30,67 @@ def to_dev(x, dtype=None):
     return t if dtype is None else t.to(dtype)
 
 
+_PINNED_FREE = {}
+_COPY_STREAMS = {}
+
+
+def _copy_stream():
+    d = torch.cuda.current_device()
+    if d not in _COPY_STREAMS:
+        _COPY_STREAMS[d] = torch.cuda.Stream()
+    return _COPY_STREAMS[d]
+
+
+class host_future(object):
+    """A device -> host copy in flight: issued on a copy stream into a pinned staging buffer from a small recycled pool
+    (hipHostMalloc of a 33 MB alm costs milliseconds and synchronises: never on the per-result path), so the caller's
+    stream goes on with the next reconstruction while the result crosses PCIe.  result() waits for the copy, moves the data
+    into an ordinary numpy array (which then owns it) and hands the staging buffer back."""
+    MAX_IN_FLIGHT = 4
+    _in_flight = []
+
+    def __init__(self, t):
+        from . import shts
+        shts.join_lanes()  # results of transforms still running on side lanes
+        t = t.detach().contiguous()
+        while len(host_future._in_flight) >= host_future.MAX_IN_FLIGHT:
+            host_future._in_flight[0].result()
+        key = (tuple(t.shape), t.dtype)
+        free = _PINNED_FREE.setdefault(key, [])
+        self._key = key
+        self._h = free.pop() if free else torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        cs = _copy_stream()
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
+            self._h.copy_(t, non_blocking=True)
+            self._ev = torch.cuda.Event()
+            self._ev.record(cs)
+        t.record_stream(cs)
+        self._arr = None
+        host_future._in_flight.append(self)
+
+    def result(self):
+        if self._arr is None:
+            self._ev.synchronize()
+            self._arr = self._h.numpy().copy()
+            _PINNED_FREE[self._key].append(self._h)
+            self._h = None
+            host_future._in_flight.remove(self)
+        return self._arr
+
+
 def to_host(t):
-    """Device tensor -> numpy array through a pinned staging tensor (PCIe at full rate; torch's host allocator
-    recycles the pinned blocks).  The returned array owns its memory (a view of a private pinned tensor)."""
+    """Device tensor -> numpy array (blocking) through the pinned staging pool; the returned array owns its memory."""
     if not isinstance(t, torch.Tensor):
         return np.asarray(t)
     if not t.is_cuda:
         return t.detach().numpy()
-    from . import shts
-    shts.join_lanes()  # results of transforms still running on side lanes
-    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-    h.copy_(t.detach(), non_blocking=True)
-    torch.cuda.current_stream().synchronize()
-    return h.numpy()
+    return host_future(t).result()
+
+
+def resolve(x):
+    """numpy array of a result that may still be a host_future"""
+    return x.result() if isinstance(x, host_future) else x
 
 
 def lidx(lmax):

@@ -129,10 +129,28 @@ def gauss_beam(fwhm, lmax=512, pol=False):
     return np.stack([g, g * f2, g * f2, g * f1], axis=1)
 
 
-def pixwin(nside, pol=False, lmax=None):
-    """healpy.pixwin reads a data file packaged inside healpy which cannot be reproduced here
-    (hard part 6)."""
-    raise NotImplementedError('pixwin needs the window-function tables shipped with healpy')
+def pixwin(nside, pol=False, lmax=None, datapath=None):
+    """healpy.pixwin: the HEALPix pixel window function, read from the `pixel_window_n%04d.fits` tables that ship with
+    healpy / HEALPix (columns TEMPERATURE, POLARIZATION).  The tables are data, not code, and cannot be regenerated here
+    (they come from the HEALPix facility, extrapolated above nside 128); they are looked for in `datapath`,
+    $PLENS_HEALPIX_DATA, $HEALPY_DATAPATH and $HEALPIX/data.  Without them this raises (hard part 6)."""
+    import os
+    from . import fitsio
+    fname = 'pixel_window_n%04d.fits' % nside
+    dirs = [datapath, os.environ.get('PLENS_HEALPIX_DATA'), os.environ.get('HEALPY_DATAPATH')]
+    if os.environ.get('HEALPIX'):
+        dirs.append(os.path.join(os.environ['HEALPIX'], 'data'))
+    for d in dirs:
+        if d and os.path.exists(os.path.join(d, fname)):
+            cols, _ = fitsio.read_bintable(os.path.join(d, fname), hdu=1)
+            low = {k.upper(): v for k, v in cols.items()}
+            pw_t = np.asarray(low['TEMPERATURE'], dtype=np.float64).ravel()
+            pw_p = np.asarray(low.get('POLARIZATION', low['TEMPERATURE']), dtype=np.float64).ravel()
+            n = (3 * nside - 1 if lmax is None else lmax) + 1
+            assert n <= pw_t.size, 'pixel window table of nside %d stops at l = %d' % (nside, pw_t.size - 1)
+            return (pw_t[:n], pw_p[:n]) if pol else pw_t[:n]
+    raise NotImplementedError('pixwin needs the window-function tables shipped with healpy (%s): point PLENS_HEALPIX_DATA, '
+                              'HEALPY_DATAPATH or HEALPIX to a directory that holds them' % fname)
 
 
 # ---------------------------------------------------------------------------------------------

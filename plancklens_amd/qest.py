@@ -165,7 +165,7 @@ class library(object):
 
     def _load(self, k, idx):
         if (k, idx) in self._mem:
-            return self._mem[(k, idx)]
+            return dev.resolve(self._mem[(k, idx)])  # may still be on its way to the host (dev.host_future)
         return hp.read_alm(self._fname(k, idx))
 
     # ---- public getters ----------------------------------------------------------------------------
@@ -255,14 +255,16 @@ class library(object):
         return ut.alm_copy(hp.read_alm(fname), lmax=lmax)
 
     def _get_sim_qlm_dev(self, k, idx, lmax):
-        """get_sim_qlm as a device tensor: the evaluation (and its cache entry) is the public one; when it has just run
-        its device result is handed over instead of uploading the host copy again."""
-        self._last_dev_key = None
-        q = self.get_sim_qlm(k, idx, lmax=lmax)
-        if (self._last_dev is not None and self._last_dev_key == ('p', idx, False) and k in ('p', 'x') and self._same_legs()
-                and self._last_dev[0].numel() == q.size):
-            return self._last_dev[0 if k == 'p' else 1]
-        return dev.to_dev(q, torch.complex128)
+        """get_sim_qlm as a device tensor: the evaluation (and its cache entry) is the public one; when it has just run its
+        device result is handed over instead of waiting for the host copy and uploading it again."""
+        k = self.keys_remaps.get(k, k)
+        if k in ('p', 'x') and k in self.keys_fund and lmax == self.get_lmax_qlm(k) and self._same_legs():
+            if not self._has(k, idx):
+                self._last_dev_key = None
+                self._build_sim_MVgclm(idx)
+                if self._last_dev_key == ('p', idx, False):
+                    return self._last_dev[0 if k == 'p' else 1]
+        return dev.to_dev(self.get_sim_qlm(k, idx, lmax=lmax), torch.complex128)
 
     # ---- estimators (device) -----------------------------------------------------------------------
     def _legs(self, swapped):
@@ -313,10 +315,11 @@ class library(object):
         G, C = self._get_sim_Pgclm_dev(idx, k, swapped=swapped, xfilt1=xfilt1, xfilt2=xfilt2)
         return dev.to_host(G), dev.to_host(C)
 
-    def _get_sim_MVgclm(self, idx, k, swapped=False):
+    def _get_sim_MVgclm(self, idx, k, swapped=False, defer=False):
         """Minimum-variance estimator = P part + T part (qest.py:318-322).  The reference analyses the two
         product maps separately and adds the alms; map2alm_spin is linear, so the product maps are summed on the
-        device and analysed once (one spin-1 transform less, results equal to rounding)."""
+        device and analysed once (one spin-1 transform less, results equal to rounding).
+        defer: return the host copies as dev.host_future objects (the copies overlap whatever is issued next)."""
         assert k == 'p'
         f2map1, f2map2 = self._legs(swapped)
         # The five leg syntheses are independent: inside a lane the FFT stage of a synthesis runs on a side stream (own plan
@@ -342,6 +345,8 @@ class library(object):
         del tmap, gt, ct, rep, imp, g3, c3, g1, c1
         G, C = self._gc_from_product(dre, dim, 'P')
         self._last_dev, self._last_dev_key = (G, C), ('p', idx, swapped)
+        if defer:
+            return dev.host_future(G), dev.host_future(C)
         return dev.to_host(G), dev.to_host(C)
 
     def _scalar_from_product(self, prod, fac, lmax_key):
@@ -401,7 +406,10 @@ class library(object):
         self._store('x_p', idx, C)
 
     def _build_sim_MVgclm(self, idx):
-        G, C = self._sym_gc(self._get_sim_MVgclm, idx, 'p')
+        if self._same_legs() and not self.cache:  # in-memory results: stored while still crossing PCIe, resolved by _load
+            G, C = self._get_sim_MVgclm(idx, 'p', defer=True)
+        else:
+            G, C = self._sym_gc(self._get_sim_MVgclm, idx, 'p')
         self._store('p', idx, G)
         self._store('x', idx, C)
 
