@@ -150,6 +150,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'qe_golden.npz'), **out)
     make_cg_golden()
     make_resp_golden()
+    make_lib_golden()
     print('wrote qe_golden.npz with %d arrays' % len(out))
     for k in ['ptt', 'p_p', 'p']:
         d = np.abs(out['gen_%s_G' % k] - out['dd_%s_0' % k]).max() / np.abs(out['dd_%s_0' % k]).max()
@@ -326,12 +327,104 @@ def make_resp_golden():
     print('wrote resp_golden.npz with %d arrays' % len(out))
 
 
+def make_lib_golden():
+    """Library classes the first fixture set did not reach, on the same tiny configuration (nside 16, lmax_ivf 40, lmax_qlm 47):
+    qest.library_jtTP over a jointly filtered library (lib_filt2map, qest.py:441-530), the 'ntt' estimator, one bias-hardened
+    key (qest.py:155-201, with the reference's resp_lib_simple on its own Fortran Wigner module), filt_simple.library_apo_sepTP
+    (filt_simple.py:473-535) and filt_util.library_ftl (filt_util.py:39-103)."""
+    install_fortran_wigners()
+    from plancklens import qest, qresp, utils
+    from plancklens.filt import filt_simple, filt_util
+    import healpy as hp  # the stand-in installed by install_healpy_standin()
+
+    nside, lmax_ivf, lmax_qlm, lmin_ivf = 16, 40, 47, 4
+    cls_path = os.path.join(ROOT, 'plancklens_amd', 'data', 'cls', 'FFP10_wdipole_lensedCls.dat')
+    cl_len = utils.camb_clfile(cls_path, lmax=lmax_ivf)
+    nlev_t, nlev_p = 1200., 35.
+    transf = myhp.gauss_beam(4. / 180. * np.pi, lmax=lmax_ivf)
+    sims = tiny_sims(nside, lmax_ivf, cl_len, transf, nlev_t, nlev_p)
+    arcmin = np.pi / 180. / 60.
+    ftl = utils.cli(cl_len['tt'][:lmax_ivf + 1] + (nlev_t * arcmin) ** 2 * utils.cli(transf ** 2))
+    fel = utils.cli(cl_len['ee'][:lmax_ivf + 1] + (nlev_p * arcmin) ** 2 * utils.cli(transf ** 2))
+    fbl = utils.cli(cl_len['bb'][:lmax_ivf + 1] + (nlev_p * arcmin) ** 2 * utils.cli(transf ** 2))
+    ftl[:lmin_ivf] = 0; fel[:lmin_ivf] = 0; fbl[:lmin_ivf] = 0
+    out = {'nside': nside, 'lmax_ivf': lmax_ivf, 'lmax_qlm': lmax_qlm, 'nlev_t': nlev_t, 'nlev_p': nlev_p, 'transf': transf,
+           'ftl': ftl, 'fel': fel, 'fbl': fbl}
+    for k in ['tt', 'ee', 'bb', 'te']:
+        out['cl_' + k] = cl_len[k]
+    tmp = tempfile.mkdtemp(prefix='plgolden_lib_')
+    try:
+        # ---- joint T-P filtering: an isotropic 3 x 3 filter with a TE block, as a subclass of the reference's template
+        fal = {'tt': ftl.copy(), 'ee': fel.copy(), 'bb': fbl.copy(), 'te': -0.3 * np.sqrt(ftl * fel)}
+
+        class iso_jTP(filt_simple.library_jTP):
+            def hashdict(self):
+                return {'sims': self.sim_lib.hashdict(), 'fal': {k: utils.clhash(v) for k, v in fal.items()}}
+
+            def get_fmask(self):
+                return np.ones(12 * nside ** 2)
+
+            def get_fal(self):
+                return {k: v.copy() for k, v in fal.items()}
+
+            def _apply_ivf(self, tqumap, soltn=None):
+                bi = utils.cli(transf)
+                t = hp.almxfl(hp.map2alm(tqumap[0], lmax=lmax_ivf, iter=0), bi)
+                e, b = hp.map2alm_spin([tqumap[1], tqumap[2]], 2, lmax=lmax_ivf)
+                e, b = hp.almxfl(e, bi), hp.almxfl(b, bi)
+                return (hp.almxfl(t, fal['tt']) + hp.almxfl(e, fal['te']), hp.almxfl(t, fal['te']) + hp.almxfl(e, fal['ee']),
+                        hp.almxfl(b, fal['bb']))
+        for k in fal:
+            out['jt_fal_' + k] = fal[k]
+        ivfs_j = iso_jTP(os.path.join(tmp, 'ivfs_j'), sims, {k: cl_len[k] for k in ['tt', 'ee', 'bb', 'te']}, cache=True)
+        out['jt_tlm_0'], out['jt_elm_0'], out['jt_blm_0'] = ivfs_j.get_sim_tlm(0), ivfs_j.get_sim_elm(0), ivfs_j.get_sim_blm(0)
+        out['jt_tmliklm_0'], out['jt_emliklm_0'] = ivfs_j.get_sim_tmliklm(0), ivfs_j.get_sim_emliklm(0)
+        qlms_j = qest.library_jtTP(os.path.join(tmp, 'qlms_j'), ivfs_j, ivfs_j, nside, lmax_qlm=lmax_qlm)
+        for k in ['p', 'x', 'ptt', 'p_p', 'stt']:  # ('f' raises inside the reference for jointly filtered libraries)
+            out['jt_%s_0' % k] = qlms_j.get_sim_qlm(k, 0)
+        # ---- sepTP: noise-inhomogeneity estimator and a bias-hardened key
+        ivfs = filt_simple.library_fullsky_sepTP(os.path.join(tmp, 'ivfs'), sims, nside, transf, cl_len, ftl, fel, fbl, cache=False)
+        resp = qresp.resp_lib_simple(os.path.join(tmp, 'resp'), lmax_ivf, cl_len, cl_len, {'t': ftl, 'e': fel, 'b': fbl}, lmax_qlm)
+        qlms = qest.library_sepTP(os.path.join(tmp, 'qlms'), ivfs, ivfs, cl_len['te'], nside, lmax_qlm=lmax_qlm, resplib=resp)
+        out['dd_ntt_0'] = qlms.get_sim_qlm('ntt', 0)
+        out['dd_ptt_bh_s_0'] = qlms.get_sim_qlm('ptt_bh_s', 0)
+        out['dd_mf_ptt_bh_s'] = qlms.get_sim_qlm_mf('ptt_bh_s', np.array([0, 1]))
+        # ---- apodised-mask isotropic filtering
+        th, ph = myhp.pix2ang(nside)
+        apo = np.clip((np.abs(np.cos(th)) - 0.15) / 0.3, 0., 1.) ** 2 * (1. + 0.1 * np.cos(ph))
+        apo_path = os.path.join(tmp, 'apomask.fits')
+        hp.write_map(apo_path, apo)
+        out['apomask'] = apo
+        ivfs_a = filt_simple.library_apo_sepTP(os.path.join(tmp, 'ivfs_apo'), sims, apo_path, cl_len, transf, ftl, fel, fbl, cache=False)
+        out['apo_tlm_1'], out['apo_elm_1'], out['apo_blm_1'] = ivfs_a.get_sim_tlm(1), ivfs_a.get_sim_elm(1), ivfs_a.get_sim_blm(1)
+        out['apo_tmliklm_1'] = ivfs_a.get_sim_tmliklm(1)
+        # ---- a-posteriori rescaling of a filtering library, to a smaller band-limit
+        lmax_f = 33
+        lt, le, lb = 1. / (1. + np.arange(lmax_f + 3.)), np.cos(0.1 * np.arange(lmax_f + 3.)), np.ones(lmax_f + 3) * 0.7
+        out['ftl_lmax'], out['ftl_lt'], out['ftl_le'], out['ftl_lb'] = lmax_f, lt, le, lb
+        ivfs_f = filt_util.library_ftl(ivfs, lmax_f, lt, le, lb)
+        out['ftl_tlm_0'], out['ftl_elm_0'], out['ftl_blm_0'] = ivfs_f.get_sim_tlm(0), ivfs_f.get_sim_elm(0), ivfs_f.get_sim_blm(0)
+        out['ftl_emliklm_0'] = ivfs_f.get_sim_emliklm(0)
+        out['ftl_get_fel'] = ivfs_f.get_fel()
+        qlms_f = qest.library_sepTP(os.path.join(tmp, 'qlms_f'), ivfs_f, ivfs_f, cl_len['te'], nside, lmax_qlm=lmax_qlm)
+        out['ftl_p_0'] = qlms_f.get_sim_qlm('p', 0)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    np.savez_compressed(os.path.join(HERE, 'lib_golden.npz'), **out)
+    print('wrote lib_golden.npz with %d arrays' % len(out))
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'resp':   # only the response / N0 fixtures
         assert os.path.isdir(REF), 'the reference is only present in the build container'
         install_healpy_standin()
         sys.path.insert(0, REF)
         make_resp_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'lib':   # only the fixtures of the further library classes
+        assert os.path.isdir(REF), 'the reference is only present in the build container'
+        install_healpy_standin()
+        sys.path.insert(0, REF)
+        make_lib_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == 'cg':   # only the CG fixtures
         assert os.path.isdir(REF), 'the reference is only present in the build container'
         install_healpy_standin()
