@@ -130,6 +130,12 @@ int pl_almxfl_add(int lmax, const double *a, const double *b, const double *fl, 
  * coefficient products of the joint filter.  One wavefront per row, fixed summation tree (bit-reproducible). */
 int pl_gemv(int nrows, int ncols, int64_t lda, const double *A, const double *x, double *y, void *stream);
 
+/* Copy of ndoubles doubles from device memory to `dst` -- device memory or pinned (device-mapped) host memory -- by a kernel of
+ * `nblocks` workgroups on `stream` (16-byte aligned pointers).  Used for the estimator outputs (the reference writes them
+ * to disk, qest.py:325-331): a few workgroups saturate PCIe with posted writes and leave the compute units to the kernels of the
+ * next reconstruction, which the runtime's own blit copy does not. */
+int pl_copy_slim(const double *src_dev, double *dst, int64_t ndoubles, int nblocks, void *stream);
+
 /* Pixel-space helpers (qest.py:256-257,276-278; opfilt_tt.py:195, opfilt_pp.py:276-299). */
 /* out = a * b (element-wise, n doubles) */
 int pl_map_mul(int64_t n, const double *a, const double *b, double *out, void *stream);

@@ -32,6 +32,7 @@ void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double 
 void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st);
 void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st);
 void launch_gemv(int nrows, int ncols, int64_t lda, const double *A, const double *x, double *y, hipStream_t st);
+void launch_copy_slim(const double *src, double *dst, int64_t ndoubles, int nblocks, hipStream_t st);
 void launch_map_mul(int64_t n, const double *a, const double *b, double *out, hipStream_t st);
 void launch_qe_lens_product(int64_t n, const double *tmap, const double *gt, const double *ct, const double *rep, const double *imp,
                             const double *g3, const double *c3, const double *g1, const double *c1, double *outr, double *outi, hipStream_t st);
@@ -610,6 +611,16 @@ int pl_gemv(int nrows, int ncols, int64_t lda, const double *A, const double *x,
     if (nrows < 0 || ncols < 0 || lda < ncols || !A || !x || !y) return fail("pl_gemv: bad arguments");
     if (nrows == 0) return 0;
     launch_gemv(nrows, ncols, lda, A, x, y, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_copy_slim(const double *src_dev, double *dst, int64_t ndoubles, int nblocks, void *stream)
+{
+    if (!src_dev || !dst || ndoubles < 0) return fail("pl_copy_slim: bad arguments");
+    if (((reinterpret_cast<uintptr_t>(src_dev) | reinterpret_cast<uintptr_t>(dst)) & 15) != 0) return fail("pl_copy_slim: pointers must be 16-byte aligned");
+    if (ndoubles == 0) return 0;
+    launch_copy_slim(src_dev, dst, ndoubles, nblocks, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return 0;
 }

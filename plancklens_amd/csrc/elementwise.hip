@@ -118,6 +118,16 @@ __global__ __launch_bounds__(256) void k_fma_peak(int iters, double xs, double y
     if (s == 12345.678) out[0] = s;
 }
 
+// Device -> pinned-host copy on a handful of workgroups (results crossing PCIe while the next reconstruction computes).
+// The runtime's own blit kernel for hipMemcpyAsync fills the GPU with workgroups that sit on PCIe latency and slowed the
+// concurrently running ring-FFT kernels by 40 %; posted PCIe writes need only a few waves in flight to saturate the link.
+__global__ __launch_bounds__(256) void k_copy_slim(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t n2, const double *__restrict__ src_tail,
+                                                   double *__restrict__ dst_tail, int ntail)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
 // Probe (not used by any transform): does the FP64 matrix pipe run beside the FP64 vector pipe?  MODE 3: four independent
 // v_mfma_f64_16x16x4 accumulation chains only; MODE 4: the same plus 64 independent-chain v_fma_f64 per trip (equal pipe time
 // if one MFMA occupies 64 cycles and one FMA 4).  The combined rate tells whether work moved to MFMA would add throughput.
@@ -388,6 +398,12 @@ void launch_template_project(int64_t n, int nmodes, double *t, const double *n_i
 {
     hipLaunchKernelGGL(k_tproj_coeffs, dim3(kProjParts), dim3(kProjThreads), 0, st, n, nmodes, t, n_inv, pm, parts);
     hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n)), dim3(256), 0, st, n, nmodes, t, rm, parts);
+}
+void launch_copy_slim(const double *src, double *dst, int64_t ndoubles, int nblocks, hipStream_t st)
+{
+    const int64_t n2 = ndoubles / 2;
+    hipLaunchKernelGGL(k_copy_slim, dim3(nblocks < 1 ? 1 : nblocks), dim3(256), 0, st, reinterpret_cast<const double2 *>(src),
+                       reinterpret_cast<double2 *>(dst), n2, src + 2 * n2, dst + 2 * n2, (int)(ndoubles - 2 * n2));
 }
 void launch_gemv(int nrows, int ncols, int64_t lda, const double *A, const double *x, double *y, hipStream_t st)
 {

@@ -2,6 +2,7 @@
 (complex128) in HBM; the arithmetic is done by the HIP kernels of plancklens_amd/csrc (through shts /
 _lib), torch only allocates, copies and launches trivial element-wise glue on its current stream."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -44,48 +45,87 @@ def _copy_stream():
 class host_future(object):
     """A device -> host copy in flight: issued on a copy stream into a pinned staging buffer from a small recycled pool
     (hipHostMalloc of a 33 MB alm costs milliseconds and synchronises: never on the per-result path), so the caller's
-    stream goes on with the next reconstruction while the result crosses PCIe.  result() waits for the copy, moves the data
-    into an ordinary numpy array (which then owns it) and hands the staging buffer back."""
+    stream goes on with the next reconstruction while the result crosses PCIe.  A helper thread waits for the copy, moves
+    the data into an ordinary numpy array (which then owns it) and hands the staging buffer back; result() returns that
+    array, waiting for the helper if it has not finished."""
     MAX_IN_FLIGHT = 4
     _in_flight = []
+    _pool = None
 
     def __init__(self, t):
         from . import shts
         shts.join_lanes()  # results of transforms still running on side lanes
         t = t.detach().contiguous()
-        while len(host_future._in_flight) >= host_future.MAX_IN_FLIGHT:
-            host_future._in_flight[0].result()
+        host_future._in_flight[:] = [f for f in host_future._in_flight if not f._job.done()]
+        while len(host_future._in_flight) >= host_future.MAX_IN_FLIGHT:  # staging buffers all busy: wait for the oldest copy
+            host_future._in_flight.pop(0)._job.result()
         key = (tuple(t.shape), t.dtype)
         free = _PINNED_FREE.setdefault(key, [])
-        self._key = key
-        self._h = free.pop() if free else torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h = free.pop() if free else torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         cs = _copy_stream()
         cs.wait_stream(torch.cuda.current_stream())
+        nblk = int(os.environ.get('PLENS_D2H_BLOCKS', '16'))
         with torch.cuda.stream(cs):
-            self._h.copy_(t, non_blocking=True)
-            self._ev = torch.cuda.Event()
-            self._ev.record(cs)
+            if nblk > 0 and t.element_size() * t.numel() % 8 == 0 and t.data_ptr() % 16 == 0:
+                # pl_copy_slim: a few workgroups writing straight into the pinned (device-mapped) buffer
+                _lib.check(_lib.lib().pl_copy_slim(t.data_ptr(), h.data_ptr(), t.element_size() * t.numel() // 8, nblk,
+                                                   ctypes.c_void_p(cs.cuda_stream)))
+            else:
+                h.copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(cs)
         t.record_stream(cs)
+        if host_future._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            host_future._pool = ThreadPoolExecutor(max_workers=2, thread_name_prefix='plens_d2h')
+
+        def finish():
+            ev.synchronize()
+            arr = h.numpy().copy()
+            free.append(h)
+            return arr
+        self._job = host_future._pool.submit(finish)
         self._arr = None
         host_future._in_flight.append(self)
 
     def result(self):
         if self._arr is None:
-            self._ev.synchronize()
-            self._arr = self._h.numpy().copy()
-            _PINNED_FREE[self._key].append(self._h)
-            self._h = None
-            host_future._in_flight.remove(self)
+            self._arr = self._job.result()
         return self._arr
 
 
+def _release_staging():
+    """pending copies, pinned buffers and copy streams go before the interpreter (and the HIP runtime) shut down"""
+    try:
+        for f in list(host_future._in_flight):
+            f._job.result()
+        del host_future._in_flight[:]
+        if host_future._pool is not None:
+            host_future._pool.shutdown(wait=True)
+            host_future._pool = None
+        _PINNED_FREE.clear()
+        _COPY_STREAMS.clear()
+    except Exception:
+        pass
+
+
+import atexit  # noqa: E402
+atexit.register(_release_staging)
+
+
 def to_host(t):
-    """Device tensor -> numpy array (blocking) through the pinned staging pool; the returned array owns its memory."""
+    """Device tensor -> numpy array (blocking).  The array is a view of a pinned tensor of its own (torch's host allocator
+    recycles the pinned blocks of arrays that have been dropped): one PCIe copy, no second pass over the data."""
     if not isinstance(t, torch.Tensor):
         return np.asarray(t)
     if not t.is_cuda:
         return t.detach().numpy()
-    return host_future(t).result()
+    from . import shts
+    shts.join_lanes()  # results of transforms still running on side lanes
+    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    h.copy_(t.detach(), non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return h.numpy()
 
 
 def resolve(x):

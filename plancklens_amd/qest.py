@@ -406,7 +406,8 @@ class library(object):
         self._store('x_p', idx, C)
 
     def _build_sim_MVgclm(self, idx):
-        if self._same_legs() and not self.cache:  # in-memory results: stored while still crossing PCIe, resolved by _load
+        # in-memory results: stored while still crossing PCIe, resolved by _load (PLENS_ASYNC_D2H=0: blocking copies)
+        if self._same_legs() and not self.cache and os.environ.get('PLENS_ASYNC_D2H', '1') != '0':
             G, C = self._get_sim_MVgclm(idx, 'p', defer=True)
         else:
             G, C = self._sym_gc(self._get_sim_MVgclm, idx, 'p')

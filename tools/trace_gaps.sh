@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/trace_gaps
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/trace_gaps -o t -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-cg > gpurun_out/trace_gaps.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace_gaps -o t -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-cg > gpurun_out/trace_gaps.log 2>&1
 python3 - <<'PY'
 import csv, glob
 kt = glob.glob('gpurun_out/trace_gaps/**/*kernel_trace.csv', recursive=True)[0]
@@ -45,6 +45,19 @@ for g, a, b, t in sorted(gaps, reverse=True)[:40]:
 p('gap histogram: >1ms %d, 100us-1ms %d, 20-100us %d, <20us %d (sum %.2f ms)' % (
     sum(g[0] > 1e6 for g in gaps), sum(1e5 < g[0] <= 1e6 for g in gaps), sum(2e4 < g[0] <= 1e5 for g in gaps), sum(g[0] <= 2e4 for g in gaps),
     sum(g[0] for g in gaps if g[0] <= 2e4) / 1e6))
+import collections
+tot = collections.defaultdict(lambda: [0, 0])
+tend = [s_ for s_, e_, n_ in ev if 'k_fma_peak' in n_]
+tend = tend[0] if tend else ev[-1][1]
+for s_, e_, n_ in ev:
+    if s_ < tend:
+        tot[n_][0] += e_ - s_; tot[n_][1] += 1
+p('per-kernel totals inside the 4 timed reconstructions (ms per reconstruction, launches per reconstruction):')
+acc = 0.
+for n_, (t_, c_) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:32]:
+    acc += t_ / 4e6
+    p('%8.3f %6.1f  %s' % (t_ / 4e6, c_ / 4., n_))
+p('sum of all kernel durations per reconstruction: %.2f ms' % (sum(t_ for t_, c_ in tot.values()) / 4e6))
 for c in copies[-12:]:
     p('copy %.3f ms %s' % ((c[1] - c[0]) / 1e6, c[2]))
 PY
