@@ -179,12 +179,11 @@ class resident_sims(object):
 
 
 def cpu_baseline(nside, lmax, budget_seconds, reps=3):
-    """One 'p' reconstruction's 9 SHTs with the CPU oracle: Legendre stage in C (OpenMP over all host cores), ring FFTs
-    with numpy's pocketfft on a thread pool, output maps preallocated.  Every ring pair of every transform (no
-    extrapolation) whenever 1 warm-up + 1 repetition fit the budget -- then as many repetitions up to `reps` as fit, median
-    reported; otherwise every stride-th ring pair with the time extrapolated through the measured fixed + per-ring cost
-    model (stated in the result)."""
-    from concurrent.futures import ThreadPoolExecutor
+    """One 'p' reconstruction's 9 SHTs with the CPU oracle, both stages in C with OpenMP over all host cores (Legendre stage
+    threaded over m, ring FFTs over rings), maps preallocated.  Every ring pair of every transform (no extrapolation)
+    whenever 1 warm-up + 1 repetition fit the budget -- then as many repetitions up to `reps` as fit, median reported;
+    otherwise every stride-th ring pair with the time extrapolated through the measured fixed + per-ring cost model (stated
+    in the result)."""
     from oracle import sht_oracle as so
     ncores = os.cpu_count() or 1
     c, s, pair, slots = so._pair_geometry(nside, True)
@@ -195,44 +194,27 @@ def cpu_baseline(nside, lmax, budget_seconds, reps=3):
     outm = np.zeros((2, 12 * nside ** 2))
     synth = [0, 2, 3, 1, 1]   # Tb map, (Qb, Ub), spin-3 leg, spin-1 leg (P), spin-1 gradient leg (T)
     anal = [0, 2, 1, 1]       # T filter, P filter, the two final spin-1 analyses of the reference (qest.py:318-322)
-    nfft = max(1, min(ncores, 64))
-    pool = ThreadPoolExecutor(max_workers=nfft)
 
     def run(stride):
         sel = np.arange(0, 2 * nside, stride)
         cs, ss, ps = c[sel], s[sel], pair[sel]
-        # FFT work split into chunks of ring pairs for the thread pool (pocketfft releases the GIL)
-        chunks = np.array_split(np.arange(sel.size), min(sel.size, 4 * nfft))
-        sls = []
-        for ch in chunks:
-            sl = np.full(2 * ch.size, -1, dtype=np.int64)
-            sl[0::2] = slots[0::2][sel[ch]]
-            sl[1::2] = slots[1::2][sel[ch]]
-            sls.append(sl)
-
-        def rows(ch):
-            r = np.empty(2 * ch.size, dtype=np.int64)
-            r[0::2], r[1::2] = 2 * ch, 2 * ch + 1
-            return r
+        sl = np.full(2 * sel.size, -1, dtype=np.int64)
+        sl[0::2] = slots[0::2][sel]
+        sl[1::2] = slots[1::2][sel]
         t0 = time.perf_counter()
         for spin in synth:
             nc = 1 if spin == 0 else 2
             ph = so.legendre(0, 1, spin, lmax, lmax, cs, ss, ps, alm=alm2[:nc], nthreads=ncores)
-            list(pool.map(lambda a: so._phase2map(ph[a[0]][rows(a[1])], nside, lmax, a[2], out=outm[a[0]]),
-                          [(i, ch, sl) for i in range(nc) for ch, sl in zip(chunks, sls)]))
+            for i in range(nc):
+                so.ring_fft_c(0, nside, lmax, sl, phase=ph[i], out=outm[i], nthreads=ncores)
         for spin in anal:
             nc = 1 if spin == 0 else 2
-            ph = np.zeros((nc, 2 * sel.size, lmax + 1), dtype=complex)
-
-            def one(a):
-                i, ch, sl = a
-                ph[i][rows(ch)] = so._map2phase(maps[i], nside, lmax, sl)
-            list(pool.map(one, [(i, ch, sl) for i in range(nc) for ch, sl in zip(chunks, sls)]))
+            ph = np.stack([so.ring_fft_c(1, nside, lmax, sl, m=maps[i], nthreads=ncores) for i in range(nc)])
             so.legendre(1, 1, spin, lmax, lmax, cs, ss, ps, phase=ph, nthreads=ncores)
         return time.perf_counter() - t0
 
     # cost model t(nrings) = fixed + per_ring * nrings from two sparse passes (the per-m table set-up of the Legendre stage
-    # and the Python ring bookkeeping do not shrink with the ring sample)
+    # does not shrink with the ring sample)
     run(64)
     t64, t16 = run(64), run(16)
     n64, n16, nfull = len(range(0, 2 * nside, 64)), len(range(0, 2 * nside, 16)), 2 * nside
@@ -249,17 +231,16 @@ def cpu_baseline(nside, lmax, budget_seconds, reps=3):
         run(stride)
     ts = sorted(run(stride) for _ in range(nrep))
     t = ts[len(ts) // 2]
-    pool.shutdown()
     sec_per_rec = t if stride == 1 else fixed + max(t - fixed, 0.05 * t) * stride
     sample = ("every ring pair (all %d), no extrapolation" % nfull if stride == 1 else
               "every %d-th ring pair (of %d), EXTRAPOLATED as fixed + (t - fixed) x %d with fixed = %.2f s measured from two sparse passes"
               % (stride, nfull, stride, fixed))
     return {'value': 1.0 / sec_per_rec, 'unit': 'reconstructions/s', 'cores': ncores, 'kind': 'port',
-            'extrapolated_from_ring_stride': stride, 'repetitions': nrep, 'fft_threads': nfft, 'seconds_per_reconstruction': sec_per_rec,
+            'extrapolated_from_ring_stride': stride, 'repetitions': nrep, 'seconds_per_reconstruction': sec_per_rec,
             'sample': "%s, of each of the 9 SHTs of one 'p' reconstruction as the reference runs it (2 scalar + 7 spin-weighted pairs, "
-                      "qest.py:318-322) at nside=%d lmax=%d; oracle C Legendre stage with OpenMP on %d threads + numpy ring FFTs on %d threads; "
+                      "qest.py:318-322) at nside=%d lmax=%d; oracle Legendre stage and ring FFTs in C with OpenMP on %d threads; "
                       "1 warm-up + %d repetition(s), median %.2f s (min %.2f, max %.2f); the oracle is a long-double-checked "
-                      "restatement, not a tuned libsharp-class code" % (sample, nside, lmax, ncores, nfft, nrep, t, ts[0], ts[-1])}
+                      "restatement, not a tuned libsharp-class code" % (sample, nside, lmax, ncores, nrep, t, ts[0], ts[-1])}
 
 
 def stub_rank(args, rank, world):

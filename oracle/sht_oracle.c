@@ -402,3 +402,124 @@ int orc_legendre(int direction, int mode, int spin, int lmax, int mmax, int nrin
     free(mlim);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------- */
+/* Fourier stage in C (the numpy route of sht_oracle.py stays the default of the tests; this one   */
+/* is threaded over rings for bench.py's cpu_baseline and is checked against the numpy route)      */
+/* ------------------------------------------------------------------------------------------- */
+/* In-place complex FFT of power-of-two length n (iterative radix 2); sign = -1 forward, +1 inverse (unnormalised). */
+static void fft_pow2(double *re, double *im, int n, int sign, const double *twr, const double *twi /* e^{-2 pi i k / n}, k < n/2 */)
+{
+    for (int i = 1, j = 0; i < n; ++i) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { double t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        int half = len >> 1, step = n / len;
+        for (int i = 0; i < n; i += len)
+            for (int k = 0; k < half; ++k) {
+                double wr = twr[k * step], wi = sign < 0 ? twi[k * step] : -twi[k * step];
+                double xr = re[i + k + half] * wr - im[i + k + half] * wi, xi = re[i + k + half] * wi + im[i + k + half] * wr;
+                re[i + k + half] = re[i + k] - xr; im[i + k + half] = im[i + k] - xi;
+                re[i + k] += xr; im[i + k] += xi;
+            }
+    }
+}
+
+typedef struct { int n, M; double *twr, *twi, *cr, *ci, *fr, *fi, *ar, *ai; } ringfft_plan;
+
+/* plan for length n: direct when n is a power of two, otherwise Bluestein (chirp e^{-i pi k^2 / n}, convolution size M >= 2n - 1) */
+static void ringfft_make(ringfft_plan *p, int n)
+{
+    p->n = n;
+    int M = 1;
+    if ((n & (n - 1)) == 0) M = n; else { while (M < 2 * n - 1) M <<= 1; }
+    p->M = M;
+    p->twr = malloc(sizeof(double) * 8 * (size_t)M); p->twi = p->twr + M;
+    p->cr = p->twi + M; p->ci = p->cr + M; p->fr = p->ci + M; p->fi = p->fr + M; p->ar = p->fi + M; p->ai = p->ar + M;
+    for (int k = 0; k < M / 2; ++k) { double a = -2.0 * (double)ORC_PI * k / M; p->twr[k] = cos(a); p->twi[k] = sin(a); }
+    if (M == n) return;
+    for (int k = 0; k < n; ++k) {
+        long long k2 = ((long long)k * k) % (2LL * n);
+        double a = (double)ORC_PI * (double)k2 / n;
+        p->cr[k] = cos(a); p->ci[k] = -sin(a);   /* chirp w_k = e^{-i pi k^2 / n} */
+    }
+    for (int k = 0; k < M; ++k) { p->fr[k] = 0; p->fi[k] = 0; }
+    for (int k = 0; k < n; ++k) {                 /* filter conj(w) wrapped, transformed once */
+        p->fr[k] = p->cr[k]; p->fi[k] = -p->ci[k];
+        if (k) { p->fr[M - k] = p->cr[k]; p->fi[M - k] = -p->ci[k]; }
+    }
+    fft_pow2(p->fr, p->fi, M, -1, p->twr, p->twi);
+}
+
+static void ringfft_free(ringfft_plan *p) { free(p->twr); p->twr = NULL; }
+
+/* X_k = sum_j x_j e^{sign 2 pi i jk/n}, in place on (re, im) of length n; sign = -1 forward, +1 inverse (unnormalised) */
+static void ringfft_run(ringfft_plan *p, double *re, double *im, int sign)
+{
+    const int n = p->n, M = p->M;
+    if (M == n) { fft_pow2(re, im, n, sign, p->twr, p->twi); return; }
+    if (sign > 0) for (int k = 0; k < n; ++k) im[k] = -im[k];   /* inverse = conj(forward(conj(x))) */
+    for (int k = 0; k < n; ++k) { p->ar[k] = re[k] * p->cr[k] - im[k] * p->ci[k]; p->ai[k] = re[k] * p->ci[k] + im[k] * p->cr[k]; }
+    for (int k = n; k < M; ++k) { p->ar[k] = 0; p->ai[k] = 0; }
+    fft_pow2(p->ar, p->ai, M, -1, p->twr, p->twi);
+    for (int k = 0; k < M; ++k) { double r = p->ar[k] * p->fr[k] - p->ai[k] * p->fi[k]; p->ai[k] = p->ar[k] * p->fi[k] + p->ai[k] * p->fr[k]; p->ar[k] = r; }
+    fft_pow2(p->ar, p->ai, M, +1, p->twr, p->twi);
+    const double inv = 1.0 / M;
+    for (int k = 0; k < n; ++k) {
+        double r = p->ar[k] * inv, i = p->ai[k] * inv;
+        re[k] = r * p->cr[k] - i * p->ci[k]; im[k] = r * p->ci[k] + i * p->cr[k];
+    }
+    if (sign > 0) for (int k = 0; k < n; ++k) im[k] = -im[k];
+}
+
+/* direction 0: phase[slot][m] -> ring pixels (x_j = sum_m w_m Re(F_m e^{i m phi_j}), aliasing folded explicitly);
+ * direction 1: ring pixels -> phase[slot][m] = (4 pi / npix) sum_j x_j e^{-i m phi_j}.
+ * ring[slot] = ring index (0 .. 4 nside - 2) or -1; nphi / phi0 / ofs per ring index as sht_oracle.ring_geometry. */
+int orc_ring_fft(int direction, int64_t npix, int mmax, int nslot, const int64_t *ring, const int64_t *nphi, const double *phi0,
+                 const int64_t *ofs, double *phase, double *map, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    const double w = 4.0 * (double)ORC_PI / (double)npix;
+#pragma omp parallel
+    {
+        ringfft_plan pl; pl.twr = NULL; pl.n = 0;
+        double *re = NULL, *im = NULL; int cap = 0;
+#pragma omp for schedule(dynamic, 4)
+        for (int s = 0; s < nslot; ++s) {
+            const int64_t r = ring[s];
+            if (r < 0) continue;
+            const int n = (int)nphi[r];
+            if (pl.twr == NULL || pl.n != n) { if (pl.twr) ringfft_free(&pl); ringfft_make(&pl, n); }
+            if (n > cap) { free(re); free(im); re = malloc(sizeof(double) * n); im = malloc(sizeof(double) * n); cap = n; }
+            double *ph = phase + 2 * (int64_t)s * (mmax + 1);
+            double *px = map + ofs[r];
+            if (direction == 0) {
+                for (int k = 0; k < n; ++k) { re[k] = 0; im[k] = 0; }
+                for (int m = 0; m <= mmax; ++m) {
+                    double a = phi0[r] * m, c = cos(a), sn = sin(a);
+                    double fr = ph[2 * m] * c - ph[2 * m + 1] * sn, fi = ph[2 * m] * sn + ph[2 * m + 1] * c;
+                    re[m % n] += fr; im[m % n] += fi;
+                    if (m) { int k = (n - m % n) % n; re[k] += fr; im[k] -= fi; }
+                }
+                ringfft_run(&pl, re, im, +1);
+                for (int j = 0; j < n; ++j) px[j] = re[j];
+            } else {
+                for (int j = 0; j < n; ++j) { re[j] = px[j]; im[j] = 0; }
+                ringfft_run(&pl, re, im, -1);
+                for (int m = 0; m <= mmax; ++m) {
+                    double a = -phi0[r] * m, c = cos(a), sn = sin(a);
+                    double zr = re[m % n], zi = im[m % n];
+                    ph[2 * m] = (zr * c - zi * sn) * w; ph[2 * m + 1] = (zr * sn + zi * c) * w;
+                }
+            }
+        }
+        if (pl.twr) ringfft_free(&pl);
+        free(re); free(im);
+    }
+    return 0;
+}

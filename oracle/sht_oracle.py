@@ -66,6 +66,9 @@ def _lib():
         _LIB.orc_legendre.restype = ctypes.c_int
         _LIB.orc_lambda.argtypes = [ctypes.c_int] * 3 + [ctypes.c_double] * 2 + [dp, dp]
         _LIB.orc_lambda.restype = None
+        lp = ctypes.POINTER(ctypes.c_int64)
+        _LIB.orc_ring_fft.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, lp, lp, dp, lp, dp, dp, ctypes.c_int]
+        _LIB.orc_ring_fft.restype = ctypes.c_int
     return _LIB
 
 
@@ -200,6 +203,33 @@ def _map2phase(m, nside, mmax, slots):
         Z = np.fft.fft(x, axis=1)
         phase[sl[b0:b1], :] = Z[:, ms % n] * np.exp(-1j * np.outer(phi0[rr], ms)) * w
     return phase
+
+
+def ring_fft_c(direction, nside, mmax, slots, phase=None, m=None, out=None, nthreads=0):
+    """The Fourier stage in C, threaded over rings (oracle/sht_oracle.c orc_ring_fft: radix-2 / Bluestein FFTs written out
+    in full): same contract as _phase2map (direction 0; returns / fills the map) and _map2phase (direction 1; returns
+    phase[slot, m]).  bench.py's cpu_baseline uses it; tests/test_oracle.py checks it against the numpy route."""
+    cth, sth, nphi, phi0, ofs = ring_geometry(nside)
+    npix = 12 * nside ** 2
+    slots = np.ascontiguousarray(slots, dtype=np.int64)
+    nphi = np.ascontiguousarray(nphi, dtype=np.int64)
+    ofs = np.ascontiguousarray(ofs, dtype=np.int64)
+    phi0 = np.ascontiguousarray(phi0, dtype=np.float64)
+    lp = ctypes.POINTER(ctypes.c_int64)
+    if direction == 0:
+        ph = np.ascontiguousarray(phase, dtype=np.complex128)
+        assert ph.shape == (slots.size, mmax + 1)
+        if out is None:
+            out = np.empty(npix)
+        assert out.dtype == np.float64 and out.flags.c_contiguous and out.size == npix
+        mp = out
+    else:
+        mp = np.ascontiguousarray(m, dtype=np.float64)
+        assert mp.size == npix
+        ph = np.zeros((slots.size, mmax + 1), dtype=np.complex128)
+    _lib().orc_ring_fft(direction, npix, mmax, slots.size, slots.ctypes.data_as(lp), nphi.ctypes.data_as(lp), _dp(phi0),
+                        ofs.ctypes.data_as(lp), _dp(ph.view(np.float64)), _dp(mp), nthreads)
+    return mp if direction == 0 else ph
 
 
 def alm2map(alm, nside, lmax=None, mmax=None, mode=1, use_pairs=True, nthreads=0, **kwargs):

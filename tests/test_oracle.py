@@ -182,3 +182,19 @@ def test_gradient_spin1(oracle):
     g = hp.almxfl(alm, fl)
     re, im = oracle.alm2map_spin([g, np.zeros_like(g)], nside, 1, lmax)
     assert np.abs(re + np.cos(th) * np.cos(ph)).max() < 1e-13 and np.abs(im - np.sin(ph)).max() < 1e-13
+
+
+@pytest.mark.parametrize('nside,lmax', [(1, 2), (4, 11), (6, 20), (8, 16), (16, 47)])
+def test_c_ring_fft_stage_equals_numpy_stage(oracle, nside, lmax):
+    """oracle.ring_fft_c (threaded C radix-2 / Bluestein, used by the CPU baseline) against the numpy pocketfft route the
+    other tests pin, both directions, incl. aliasing (lmax = 3 nside - 1) and a ring count that is not a power of two."""
+    rng = np.random.default_rng(nside + lmax)
+    c, s, pair, slots = oracle._pair_geometry(nside, True)
+    ph = rng.standard_normal((slots.size, lmax + 1)) + 1j * rng.standard_normal((slots.size, lmax + 1))
+    ph[:, 0] = ph[:, 0].real
+    ph[slots < 0] = 0.
+    a, b = oracle._phase2map(ph, nside, lmax, slots), oracle.ring_fft_c(0, nside, lmax, slots, phase=ph, nthreads=2)
+    assert relrms(b, a) < 1e-13
+    m = rng.standard_normal(12 * nside ** 2)
+    a, b = oracle._map2phase(m, nside, lmax, slots), oracle.ring_fft_c(1, nside, lmax, slots, m=m, nthreads=2)
+    assert relrms(b[slots >= 0], a[slots >= 0]) < 1e-13
