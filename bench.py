@@ -178,6 +178,25 @@ class resident_sims(object):
         return self.qmap, self.umap
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU slot of a shared box sees all
+    256 hardware threads in os.cpu_count() but is throttled to its quota: 256 OpenMP threads then run 10x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(round(float(quota) / float(period)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, int(round(q / per))))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(nside, lmax, budget_seconds, reps=3):
     """One 'p' reconstruction's 9 SHTs with the CPU oracle, both stages in C with OpenMP over all host cores (Legendre stage
     threaded over m, ring FFTs over rings), maps preallocated.  Every ring pair of every transform (no extrapolation)
@@ -185,7 +204,7 @@ def cpu_baseline(nside, lmax, budget_seconds, reps=3):
     otherwise every stride-th ring pair with the time extrapolated through the measured fixed + per-ring cost model (stated
     in the result)."""
     from oracle import sht_oracle as so
-    ncores = os.cpu_count() or 1
+    ncores = usable_cpus()
     c, s, pair, slots = so._pair_geometry(nside, True)
     rng = np.random.default_rng(5)
     nalm = so.alm_size(lmax)
@@ -238,9 +257,10 @@ def cpu_baseline(nside, lmax, budget_seconds, reps=3):
     return {'value': 1.0 / sec_per_rec, 'unit': 'reconstructions/s', 'cores': ncores, 'kind': 'port',
             'extrapolated_from_ring_stride': stride, 'repetitions': nrep, 'seconds_per_reconstruction': sec_per_rec,
             'sample': "%s, of each of the 9 SHTs of one 'p' reconstruction as the reference runs it (2 scalar + 7 spin-weighted pairs, "
-                      "qest.py:318-322) at nside=%d lmax=%d; oracle Legendre stage and ring FFTs in C with OpenMP on %d threads; "
+                      "qest.py:318-322) at nside=%d lmax=%d; oracle Legendre stage and ring FFTs in C with OpenMP on %d threads (= usable CPUs: affinity mask capped by the cgroup quota; "
+                      "os.cpu_count() = %d); "
                       "1 warm-up + %d repetition(s), median %.2f s (min %.2f, max %.2f); the oracle is a long-double-checked "
-                      "restatement, not a tuned libsharp-class code" % (sample, nside, lmax, ncores, nrep, t, ts[0], ts[-1])}
+                      "restatement, not a tuned libsharp-class code" % (sample, nside, lmax, ncores, os.cpu_count() or 1, nrep, t, ts[0], ts[-1])}
 
 
 def stub_rank(args, rank, world):
@@ -441,7 +461,7 @@ def run_rank(args):
             try:
                 res['cpu_baseline'] = cpu_baseline(nside, lmax, args.cpu_seconds)
             except Exception as e:
-                res['cpu_baseline'] = {'value': None, 'unit': 'reconstructions/s', 'cores': os.cpu_count(), 'kind': 'port',
+                res['cpu_baseline'] = {'value': None, 'unit': 'reconstructions/s', 'cores': usable_cpus(), 'kind': 'port',
                                        'sample': 'failed: %r' % (e,)}
     if rank == 0:
         print(json.dumps(res), flush=True)

@@ -64,7 +64,7 @@ class host_future(object):
         h = free.pop() if free else torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         cs = _copy_stream()
         cs.wait_stream(torch.cuda.current_stream())
-        nblk = int(os.environ.get('PLENS_D2H_BLOCKS', '16'))
+        nblk = int(os.environ.get('PLENS_D2H_BLOCKS', '64'))
         with torch.cuda.stream(cs):
             if nblk > 0 and t.element_size() * t.numel() % 8 == 0 and t.data_ptr() % 16 == 0:
                 # pl_copy_slim: a few workgroups writing straight into the pinned (device-mapped) buffer

@@ -1,5 +1,7 @@
-"""Small helpers of the CG filter, API of plancklens/qcinv/util.py (`stopwatch` :21-36, `jit` :39-61,
-`read_map` :63-79, `mask_hash` :81-95)."""
+"""Small helpers of the CG filter behind the names of plancklens/qcinv/util.py (`dt`, `stopwatch` :8-36, `jit` :39-61,
+`read_map` / `load_map` :63-79, `mask_hash` :81-95): wall-clock bookkeeping for the iteration log, deferred construction of
+the (expensive) filter and chain objects, and the "map given as array | path | path,field | callable | list of those"
+convention of the inverse-noise arguments."""
 import time
 
 import numpy as np
@@ -8,85 +10,93 @@ from .. import hp, utils
 
 
 class dt(object):
-    def __init__(self, _dt):
-        self.dt = _dt
+    """a duration in seconds that prints as hh:mm:ss"""
 
-    def __str__(self):
-        return '%02d:%02d:%02d' % (self.dt // 3600, (self.dt % 3600) // 60, self.dt % 60)
+    def __init__(self, seconds):
+        self.dt = seconds
 
     def __int__(self):
         return int(self.dt)
 
+    def __str__(self):
+        m, s = divmod(int(self.dt), 60)
+        h, m = divmod(m, 60)
+        return '%02d:%02d:%02d' % (h, m, s)
+
 
 class stopwatch(object):
+    """lap() -> (since start, since previous lap or elapsed()); elapsed() -> since start; both as `dt`"""
+
     def __init__(self):
-        self.st = time.time()
-        self.lt = self.st
+        self.st = self.lt = time.time()
+
+    def _mark(self):
+        now, prev = time.time(), self.lt
+        self.lt = now
+        return now - self.st, now - prev
 
     def lap(self):
-        lt = time.time()
-        ret = (dt(lt - self.st), dt(lt - self.lt))
-        self.lt = lt
-        return ret
+        total, split = self._mark()
+        return dt(total), dt(split)
 
     def elapsed(self):
-        lt = time.time()
-        self.lt = lt
-        return dt(lt - self.st)
+        return dt(self._mark()[0])
 
 
 class jit(object):
-    """Just-in-time instantiation proxy: the wrapped object is built on first attribute access."""
+    """Stand-in for an object that is only built (ctype(*args, **kwargs)) when something is asked of it: the filter
+    libraries construct their inverse-noise filters and multigrid chains this way, so that importing a parameter file does
+    not read maps or touch the GPU.  Attribute reads and writes go to the real object."""
+    _SLOTS = ('_jit_recipe', '_jit_target')
 
     def __init__(self, ctype, *cargs, **ckwds):
-        self.__dict__['__jit_args'] = [ctype, cargs, ckwds]
-        self.__dict__['__jit_obj'] = None
+        object.__setattr__(self, '_jit_recipe', (ctype, cargs, ckwds))
+        object.__setattr__(self, '_jit_target', None)
 
     def instantiate(self):
-        ctype, cargs, ckwds = self.__dict__['__jit_args']
-        self.__dict__['__jit_obj'] = ctype(*cargs, **ckwds)
-        del self.__dict__['__jit_args']
+        recipe = object.__getattribute__(self, '_jit_recipe')
+        if recipe is not None:
+            ctype, cargs, ckwds = recipe
+            object.__setattr__(self, '_jit_target', ctype(*cargs, **ckwds))
+            object.__setattr__(self, '_jit_recipe', None)
+        return object.__getattribute__(self, '_jit_target')
 
-    def __getattr__(self, attr):
-        if self.__dict__['__jit_obj'] is None:
-            self.instantiate()
-        return getattr(self.__dict__['__jit_obj'], attr)
+    def __getattr__(self, name):  # only reached for names the proxy itself does not have
+        return getattr(self.instantiate(), name)
 
-    def __setattr__(self, attr, val):
-        if self.__dict__['__jit_obj'] is None:
-            self.instantiate()
-        setattr(self.__dict__['__jit_obj'], attr, val)
+    def __setattr__(self, name, value):
+        setattr(self.instantiate(), name, value)
 
 
 def read_map(m):
-    """Map given as array, callable, path ('file.fits' or 'file.fits,field') or list of those (multiplied)."""
+    """The map behind `m`: an array is returned as is, a callable is called, 'file.fits' and 'file.fits,3' are read with
+    hp.read_map (field 3 in the second form), a list stands for the product of its members."""
+    if isinstance(m, list):
+        out = read_map(m[0])
+        for other in m[1:]:
+            out = out * read_map(other)
+        return out
     if callable(m):
         return m()
-    if isinstance(m, list):
-        ma = read_map(m[0])
-        for m2 in m[1:]:
-            ma = ma * read_map(m2)
-        return ma
-    if not isinstance(m, str):
-        return m
-    if ',' not in m:
-        return hp.read_map(m)
-    fn, field = m.split(',')
-    return hp.read_map(fn, field=int(field))
+    if isinstance(m, str):
+        path, _, field = m.partition(',')
+        return hp.read_map(path, field=int(field)) if field else hp.read_map(path)
+    return m
 
 
 load_map = read_map
 
 
 def mask_hash(m, dtype=bool):
+    """short, stable label of a map argument for the hash dictionaries (paths by name, arrays by content)"""
     if m is None:
         return "none"
     if isinstance(m, list):
-        return ''.join(mask_hash(mi, dtype=dtype) for mi in m)
+        return ''.join(mask_hash(x, dtype=dtype) for x in m)
     if isinstance(m, str):
         return m.replace('/', '_sl_').replace('.', '_')
     if isinstance(m, np.ndarray):
         return utils.clhash(m, dtype=dtype)
     if callable(m):
         return 'callable'
-    assert 0, 'not implemented'
+    raise AssertionError('mask_hash: %s not supported' % type(m))
