@@ -199,7 +199,8 @@ def qe_compress(qes, verbose=True):
     for t in qes:
         key = (t.leg_a.signature(), t.leg_b.spin_ou)
         if key in groups:
-            groups[key][1] += t.leg_b
+            legb = groups[key][1]
+            legb += t.leg_b  # in place: one more input of the same transform
         else:
             groups[key] = (qeleg_multi([t.leg_a.spin_in], t.leg_a.spin_ou, [t.leg_a.cl]),
                            qeleg_multi([t.leg_b.spin_in], t.leg_b.spin_ou, [t.leg_b.cl]), t.cL)
