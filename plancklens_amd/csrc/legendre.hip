@@ -1252,7 +1252,10 @@ static void launch_synths_r(const DevPlan &P, const DevSpinTab &S, int spin, con
 {
     constexpr int RG = 64 * R;
     const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
-    hipLaunchKernelGGL((k_leg_synths<R, GONLY>), dim3(ngroups * nmg), dim3(256), 0, st, P, S, spin,
+    // PLSHTS_SYNTH_LDS_PAD (bytes, experiments): dynamic LDS nobody touches, to cap the workgroups per CU and leave room for the
+    // ring-FFT kernels of another transform running on a second stream
+    static const int pad = env_int("PLSHTS_SYNTH_LDS_PAD", 0);
+    hipLaunchKernelGGL((k_leg_synths<R, GONLY>), dim3(ngroups * nmg), dim3(256), pad, st, P, S, spin,
                        reinterpret_cast<const double4 *>(prep), phase);
 }
 

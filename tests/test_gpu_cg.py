@@ -200,3 +200,47 @@ def test_cinv_tp_fullsky_white_noise_known_answer(tmp_path):
     sel = (ls >= 2) & (ls <= 800)
     assert relrms(st[sel], rt[sel]) < 2e-3 and relrms(se[sel], re[sel]) < 2e-3 and relrms(sb[sel], rb[sel]) < 2e-2
     assert os.path.exists(str(tmp_path / 'cinv_tp' / 'fal.pk')) and os.path.exists(str(tmp_path / 'cinv_tp' / 'dense_tp.pk'))
+
+
+def test_masked_cg_at_baseline_size_graph_replay_equals_eager(tmp_path):
+    """BASELINE config 4 at full size (nside = lmax = 2048, masked sky, default 4-stage chain): the captured HIP graph of the
+    nested preconditioner must reproduce the eager solve -- same iterates to rounding -- and the residual must fall.  Few
+    top-level iterations; the dense block (4225 coarse operator applications) is built once and shared through its cache."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tools'))
+import cg_bench
+from plancklens_amd import dev, hp, shts, utils
+from plancklens_amd.filt import filt_cinv
+nside = lmax = 2048
+rng = np.random.default_rng(7)
+cl = utils.camb_clfile(os.path.join(%r, 'plancklens_amd', 'data', 'cls', 'FFP10_wdipole_lensedCls.dat'), lmax=lmax)
+transf = hp.gauss_beam(5. / 60. / 180. * np.pi, lmax=lmax)
+mask = cg_bench.make_mask(nside, rng)
+vamin = np.sqrt(hp.nside2pixarea(nside, degrees=True)) * 60
+tmap = shts.alm2map(hp.almxfl(hp.synalm(cl['tt'], lmax, rng), transf), nside) + 35. / vamin * rng.standard_normal(12 * nside ** 2)
+tmp = sys.argv[1]
+f = filt_cinv.cinv_t(os.path.join(tmp, 'cinv_t'), lmax, nside, cl, transf, [np.array([3. / 35. ** 2]) * mask],
+                     chain_descr=cg_bench.chain('t', 6, lmax, nside, os.path.join(tmp, 'dense_t.pk')))
+trace = []
+log0 = f.chain.log
+f.chain.log = lambda stage, it, eps, **kw: (trace.append(float(eps)) if stage.depth == 0 else None, log0(stage, it, eps, **kw))
+out = dev.to_host(dev.to_dev(f.apply_ivf(dev.to_dev(tmap))))
+np.save(os.path.join(tmp, 'sol_%%s.npy' %% os.environ.get('PLENS_CG_GRAPH', '1')), out)
+np.save(os.path.join(tmp, 'eps_%%s.npy' %% os.environ.get('PLENS_CG_GRAPH', '1')), np.array(trace))
+''' % (ROOT, ROOT, ROOT)
+    script = tmp_path / 'cg_full.py'
+    script.write_text(code)
+    for graph in ('0', '1'):  # the second run reads the dense block cached by the first
+        out = subprocess.run([sys.executable, str(script), str(tmp_path)], env=dict(os.environ, PLENS_CG_GRAPH=graph), stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, timeout=1500)
+        assert out.returncode == 0, out.stdout.decode()[-3000:]
+    a, b = np.load(tmp_path / 'sol_0.npy'), np.load(tmp_path / 'sol_1.npy')
+    assert np.all(np.isfinite(a)) and np.abs(a).max() > 0
+    assert np.sqrt(np.sum(np.abs(a - b) ** 2) / np.sum(np.abs(a) ** 2)) < 1e-10
+    ea, eb = np.load(tmp_path / 'eps_0.npy'), np.load(tmp_path / 'eps_1.npy')
+    if ea.size and eb.size:  # residual norms are only evaluated when the top level logs them
+        assert ea[-1] < 1e-2 * ea[0] and np.allclose(ea, eb, rtol=1e-6)
