@@ -258,15 +258,19 @@ __global__ void k_axpy_dev(int64_t n, const double *__restrict__ num, const doub
 // t <- N^-1 t - N^-1 P (P^t N^-1 P)^-1 P^t N^-1 t with P (nmodes x n) and R = (P^t N^-1 P)^-1 (P . N^-1) (nmodes x n) given:
 //   pass 1: t <- n_inv t and the per-workgroup partial sums of c_k = sum_i P_ki t_i;  pass 2: t_i -= sum_k R_ki c_k.
 // The partial sums are added in index order by every workgroup of pass 2: bit-reproducible, no atomics.
-constexpr int kProjParts = 256, kProjMaxModes = 16, kProjThreads = 1024;
-__global__ __launch_bounds__(kProjThreads) void k_tproj_coeffs(int64_t n, int nmodes, double *__restrict__ t, const double *__restrict__ n_inv,
-                                                               const double *__restrict__ pm, double *__restrict__ parts)
+constexpr int kProjParts = 256, kProjMaxModes = 16;
+// NT threads per workgroup, gridDim.x = nparts <= kProjParts workgroups: one partial sum per workgroup and mode.  Small maps (the
+// coarse multigrid levels, where this pair of kernels runs dozens of times per CG iteration) take fewer, smaller workgroups:
+// the work is a few microseconds and the cost is the launch and the reduction tail.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_tproj_coeffs(int64_t n, int nmodes, double *__restrict__ t, const double *__restrict__ n_inv,
+                                                     const double *__restrict__ pm, double *__restrict__ parts)
 {
-    __shared__ double red[kProjMaxModes][kProjThreads / 64];
+    __shared__ double red[kProjMaxModes][NT / 64];
     double acc[kProjMaxModes];
 #pragma unroll
     for (int k = 0; k < kProjMaxModes; ++k) acc[k] = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * kProjThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kProjThreads) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
         const double u = t[i] * n_inv[i];
         t[i] = u;
 #pragma unroll
@@ -286,25 +290,25 @@ __global__ __launch_bounds__(kProjThreads) void k_tproj_coeffs(int64_t n, int nm
     __syncthreads();
     if ((int)threadIdx.x < nmodes) {
         double v = 0.0;
-        for (int w = 0; w < kProjThreads / 64; ++w) v += red[threadIdx.x][w];
+        for (int w = 0; w < NT / 64; ++w) v += red[threadIdx.x][w];
         parts[threadIdx.x * kProjParts + blockIdx.x] = v;
     }
 }
-__global__ __launch_bounds__(256) void k_tproj_apply(int64_t n, int nmodes, double *__restrict__ t, const double *__restrict__ rm,
+// c_k = sum of the nparts partial sums of mode k, by one wavefront per mode in a fixed order (lane j takes parts j, j + 64, ...,
+// then a fixed shuffle tree): one barrier instead of a shared-memory tree per mode
+__global__ __launch_bounds__(256) void k_tproj_apply(int64_t n, int nmodes, int nparts, double *__restrict__ t, const double *__restrict__ rm,
                                                      const double *__restrict__ parts)
 {
     __shared__ double c[kProjMaxModes];
-    __shared__ double red[kProjParts];
-    for (int k = 0; k < nmodes; ++k) {
-        red[threadIdx.x] = parts[k * kProjParts + threadIdx.x];
-        __syncthreads();
-        for (int h = kProjParts / 2; h > 0; h >>= 1) {
-            if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) c[k] = red[0];
-        __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < nmodes; k += 4) {
+        double v = 0.0;
+        for (int j = lane; j < nparts; j += 64) v += parts[k * kProjParts + j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) c[k] = v;
     }
+    __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         double v = t[i];
         for (int k = 0; k < nmodes; ++k) v = fma(-rm[(int64_t)k * n + i], c[k], v);
@@ -396,8 +400,16 @@ void launch_axpy_dev(int64_t n, const double *num, const double *den, double sig
 }
 void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_tproj_coeffs, dim3(kProjParts), dim3(kProjThreads), 0, st, n, nmodes, t, n_inv, pm, parts);
-    hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n)), dim3(256), 0, st, n, nmodes, t, rm, parts);
+    if (n >= (int64_t)kProjParts * 4096) {  // fine grids: 256 workgroups of 1024 threads
+        hipLaunchKernelGGL(k_tproj_coeffs<1024>, dim3(kProjParts), dim3(1024), 0, st, n, nmodes, t, n_inv, pm, parts);
+        hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n)), dim3(256), 0, st, n, nmodes, kProjParts, t, rm, parts);
+    } else {  // coarse grids: workgroups of 256 threads, 8 pixels per thread
+        int nparts = (int)((n + 2047) / 2048);
+        if (nparts < 1) nparts = 1;
+        if (nparts > kProjParts) nparts = kProjParts;
+        hipLaunchKernelGGL(k_tproj_coeffs<256>, dim3(nparts), dim3(256), 0, st, n, nmodes, t, n_inv, pm, parts);
+        hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n)), dim3(256), 0, st, n, nmodes, nparts, t, rm, parts);
+    }
 }
 void launch_copy_slim(const double *src, double *dst, int64_t ndoubles, int nblocks, hipStream_t st)
 {

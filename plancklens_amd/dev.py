@@ -60,7 +60,9 @@ class host_future(object):
         while len(host_future._in_flight) >= host_future.MAX_IN_FLIGHT:  # staging buffers all busy: wait for the oldest copy
             host_future._in_flight.pop(0)._job.result()
         key = (tuple(t.shape), t.dtype)
-        free = _PINNED_FREE.setdefault(key, [])
+        if key not in _PINNED_FREE:  # the whole staging pool of this shape at once, on first use (i.e. during warm-up)
+            _PINNED_FREE[key] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for _ in range(host_future.MAX_IN_FLIGHT)]
+        free = _PINNED_FREE[key]
         h = free.pop() if free else torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         cs = _copy_stream()
         cs.wait_stream(torch.cuda.current_stream())
