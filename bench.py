@@ -296,7 +296,8 @@ def run_rank(args):
     import torch.distributed as dist
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU path)'
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or ('RANK' in os.environ and os.environ.get('PLENS_DIST_FORCE', '0') == '1')
+    if use_dist:  # (PLENS_DIST_FORCE=1 under a launcher: RCCL collectives with a single rank, tests/test_gpu_bench.py)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='nccl')
     from plancklens_amd.helpers import mpi
@@ -328,7 +329,7 @@ def run_rank(args):
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -348,6 +349,7 @@ def run_rank(args):
     t0 = time.perf_counter()
     # K reconstructions on this rank (jobs[rank::size] of world x K simulations), device-resident sum, RCCL all-reduce
     mf = qlms.get_sim_qlm_mf(key, np.arange(world * K))
+    assert qlms._last_dev is not None, 'the estimator library kept no device result for key %s' % key
     gathered = parallel.allgather(qlms._last_dev[0])  # output qlm all-gather over xGMI
     sync_all()
     dt = time.perf_counter() - t0
@@ -357,7 +359,7 @@ def run_rank(args):
     nrec = sum(1 for (k_, i_) in qlms._mem if k_ == key and isinstance(i_, (int, np.integer)))
     assert nrec == K, 'timed region ran %d reconstructions on rank %d, expected %d' % (nrec, rank, K)
     ranks_seen = world
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -465,7 +467,7 @@ def run_rank(args):
                                        'sample': 'failed: %r' % (e,)}
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     import shutil

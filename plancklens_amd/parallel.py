@@ -18,8 +18,13 @@ def shard(jobs):
 
 
 def _dist():
+    """torch.distributed when a process group of more than one rank is up (PLENS_DIST_FORCE=1: also with a single rank, so that
+    the collectives can be exercised on a one-GPU box)"""
+    import os
     import torch.distributed as dist
-    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    return dist if (dist.get_world_size() > 1 or os.environ.get('PLENS_DIST_FORCE', '0') == '1') else None
 
 
 def _as_real(t):

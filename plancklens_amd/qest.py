@@ -254,16 +254,19 @@ class library(object):
             return ut.alm_copy(MF, lmax=lmax)
         return ut.alm_copy(hp.read_alm(fname), lmax=lmax)
 
+    # gradient key of the evaluation that serves (gradient, curl) key pairs: ('p', 'x') come out of one MV evaluation, ...
+    _GC_FAMILY = {'p': ('p', 0), 'x': ('p', 1), 'ptt': ('ptt', 0), 'xtt': ('ptt', 1), 'p_p': ('p_p', 0), 'x_p': ('p_p', 1)}
+
     def _get_sim_qlm_dev(self, k, idx, lmax):
         """get_sim_qlm as a device tensor: the evaluation (and its cache entry) is the public one; when it has just run its
         device result is handed over instead of waiting for the host copy and uploading it again."""
         k = self.keys_remaps.get(k, k)
-        if k in ('p', 'x') and k in self.keys_fund and lmax == self.get_lmax_qlm(k) and self._same_legs():
-            if not self._has(k, idx):
-                self._last_dev_key = None
-                self._build_sim_MVgclm(idx)
-                if self._last_dev_key == ('p', idx, False):
-                    return self._last_dev[0 if k == 'p' else 1]
+        fam = self._GC_FAMILY.get(k)
+        if fam is not None and k in self.keys_fund and lmax == self.get_lmax_qlm(k) and self._same_legs() and not self._has(k, idx):
+            self._last_dev_key = None
+            {'p': self._build_sim_MVgclm, 'ptt': self._build_sim_Tgclm, 'p_p': self._build_sim_Pgclm}[fam[0]](idx)
+            if self._last_dev_key == (fam[0], idx, False):
+                return self._last_dev[fam[1]]
         return dev.to_dev(self.get_sim_qlm(k, idx, lmax=lmax), torch.complex128)
 
     # ---- estimators (device) -----------------------------------------------------------------------
@@ -305,14 +308,22 @@ class library(object):
         dre, dim = self._p_product(idx, k, swapped=swapped, xfilt1=xfilt1, xfilt2=xfilt2)
         return self._gc_from_product(dre, dim, 'P')
 
-    def _get_sim_Tgclm(self, idx, k, swapped=False, xfilt1=None, xfilt2=None):
-        """T-only lensing gradient / curl (qest.py:248-263)."""
+    def _get_sim_Tgclm(self, idx, k, swapped=False, xfilt1=None, xfilt2=None, defer=False):
+        """T-only lensing gradient / curl (qest.py:248-263).  defer: host copies as dev.host_future objects."""
         G, C = self._get_sim_Tgclm_dev(idx, k, swapped=swapped, xfilt1=xfilt1, xfilt2=xfilt2)
+        if xfilt1 is None and xfilt2 is None:
+            self._last_dev, self._last_dev_key = (G, C), ('ptt', idx, swapped)
+        if defer and G.numel() >= self._DEFER_MIN_ENTRIES:
+            return dev.host_future(G), dev.host_future(C)
         return dev.to_host(G), dev.to_host(C)
 
-    def _get_sim_Pgclm(self, idx, k, swapped=False, xfilt1=None, xfilt2=None):
-        """Polarization-only lensing gradient / curl (qest.py:265-285)."""
+    def _get_sim_Pgclm(self, idx, k, swapped=False, xfilt1=None, xfilt2=None, defer=False):
+        """Polarization-only lensing gradient / curl (qest.py:265-285).  defer: host copies as dev.host_future objects."""
         G, C = self._get_sim_Pgclm_dev(idx, k, swapped=swapped, xfilt1=xfilt1, xfilt2=xfilt2)
+        if xfilt1 is None and xfilt2 is None:
+            self._last_dev, self._last_dev_key = (G, C), ('p_p', idx, swapped)
+        if defer and G.numel() >= self._DEFER_MIN_ENTRIES:
+            return dev.host_future(G), dev.host_future(C)
         return dev.to_host(G), dev.to_host(C)
 
     def _get_sim_MVgclm(self, idx, k, swapped=False, defer=False):
@@ -345,7 +356,7 @@ class library(object):
         del tmap, gt, ct, rep, imp, g3, c3, g1, c1
         G, C = self._gc_from_product(dre, dim, 'P')
         self._last_dev, self._last_dev_key = (G, C), ('p', idx, swapped)
-        if defer:
+        if defer and G.numel() >= self._DEFER_MIN_ENTRIES:
             return dev.host_future(G), dev.host_future(C)
         return dev.to_host(G), dev.to_host(C)
 
@@ -395,19 +406,28 @@ class library(object):
             G, C = 0.5 * (G + _G), 0.5 * (C + _C)
         return G, C
 
+    # results smaller than this (complex entries) are copied with a blocking call: below ~lmax 700 a reconstruction is a
+    # millisecond of launch-bound work and the copy-stream / helper-thread hand-off costs more than the 2 MB copy it hides
+    # (nside = lmax = 512 'ptt': 1.65 ms per reconstruction blocking, 4.2 ms deferred)
+    _DEFER_MIN_ENTRIES = 1 << 18
+
+    def _defer_ok(self):
+        """in-memory results of a same-legs library may be stored while still crossing PCIe (resolved by _load);
+        PLENS_ASYNC_D2H=0: blocking copies"""
+        return self._same_legs() and not self.cache and os.environ.get('PLENS_ASYNC_D2H', '1') != '0'
+
     def _build_sim_Tgclm(self, idx):
-        G, C = self._sym_gc(self._get_sim_Tgclm, idx, 'ptt')
+        G, C = self._get_sim_Tgclm(idx, 'ptt', defer=True) if self._defer_ok() else self._sym_gc(self._get_sim_Tgclm, idx, 'ptt')
         self._store('ptt', idx, G)
         self._store('xtt', idx, C)
 
     def _build_sim_Pgclm(self, idx):
-        G, C = self._sym_gc(self._get_sim_Pgclm, idx, 'p_p')
+        G, C = self._get_sim_Pgclm(idx, 'p_p', defer=True) if self._defer_ok() else self._sym_gc(self._get_sim_Pgclm, idx, 'p_p')
         self._store('p_p', idx, G)
         self._store('x_p', idx, C)
 
     def _build_sim_MVgclm(self, idx):
-        # in-memory results: stored while still crossing PCIe, resolved by _load (PLENS_ASYNC_D2H=0: blocking copies)
-        if self._same_legs() and not self.cache and os.environ.get('PLENS_ASYNC_D2H', '1') != '0':
+        if self._defer_ok():
             G, C = self._get_sim_MVgclm(idx, 'p', defer=True)
         else:
             G, C = self._sym_gc(self._get_sim_MVgclm, idx, 'p')

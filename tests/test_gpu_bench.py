@@ -33,3 +33,18 @@ def test_bench_line_contract():
         assert k in c, k
     assert c['kind'] in ('reference', 'port') and c['value'] > 0 and c['cores'] >= 1
     assert d['ranks_seen'] == 1 and 'kernels' in d and 'leg_anals' in d['kernels']
+
+
+def test_bench_under_launcher_with_rccl_collectives():
+    """The driver's launch line (torch.distributed.run, here with one rank -- the box has one GPU): RANK / WORLD_SIZE from the
+    launcher, process group on nccl (= RCCL), and with PLENS_DIST_FORCE=1 the mean-field all-reduce and the qlm all-gather of
+    the timed region really go through RCCL."""
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--nside', '64', '--lmax', '64', '--steps', '2',
+           '--warmup', '1', '--no-cg', '--no-cpu-baseline']
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, PLENS_DIST_FORCE='1'))
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+    assert d['n_gpus'] == 1 and d['ranks_seen'] == 1 and d['value'] > 0
