@@ -164,8 +164,10 @@ class resident_sims(object):
         npix = hp.nside2npix(nside)
         self.tmap = shts.alm2map(dev.to_dev(tlm), nside, fl=transf) + nlev_t / vamin * torch.randn(npix, generator=gen, dtype=torch.float64, device='cuda')
         q, u = shts.alm2map_spin([dev.to_dev(elm), dev.to_dev(blm)], nside, 2, lmax, fl=transf)
-        self.qmap = q + nlev_p / vamin * torch.randn(npix, generator=gen, dtype=torch.float64, device='cuda')
-        self.umap = u + nlev_p / vamin * torch.randn(npix, generator=gen, dtype=torch.float64, device='cuda')
+        qu = torch.empty((2, npix), dtype=torch.float64, device='cuda')  # (Q, U) as the two rows of one array: what map2alm_spin takes
+        qu[0] = q + nlev_p / vamin * torch.randn(npix, generator=gen, dtype=torch.float64, device='cuda')
+        qu[1] = u + nlev_p / vamin * torch.randn(npix, generator=gen, dtype=torch.float64, device='cuda')
+        self.qmap, self.umap = qu[0], qu[1]
         self.seed = seed
 
     def hashdict(self):

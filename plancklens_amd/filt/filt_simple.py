@@ -103,8 +103,14 @@ class library_sepTP(object):
                     hp.write_alm(self._fn('t', idx), dev.to_host(ent['t']), overwrite=True)
             else:
                 pmap = self.sim_lib.get_sim_pmap(idx)
-                e, b = self._apply_ivf_p([dev.to_dev(pmap[0], torch.float64), dev.to_dev(pmap[1], torch.float64)],
-                                         soltn=self._soltn_p(idx))
+                if isinstance(pmap[0], torch.Tensor):
+                    qu = [dev.to_dev(pmap[0], torch.float64), dev.to_dev(pmap[1], torch.float64)]
+                else:  # host arrays land in the two rows of one device array: the layout the spin transform takes, no stacking copy
+                    buf = torch.empty((2, np.size(pmap[0])), dtype=torch.float64, device=dev.device())
+                    buf[0].copy_(torch.from_numpy(np.ascontiguousarray(pmap[0], dtype=np.float64)))
+                    buf[1].copy_(torch.from_numpy(np.ascontiguousarray(pmap[1], dtype=np.float64)))
+                    qu = [buf[0], buf[1]]
+                e, b = self._apply_ivf_p(qu, soltn=self._soltn_p(idx))
                 ent['e'], ent['b'] = dev.to_dev(e), dev.to_dev(b)
                 if self.cache:
                     hp.write_alm(self._fn('e', idx), dev.to_host(ent['e']), overwrite=True)

@@ -626,10 +626,11 @@ class lib_filt2map_sepTP(lib_filt2map):
             if xfilt is not None:
                 mlik = dev.almxfl(mlik, xfilt['t'])
         if k == 'p' and (xfilt is None or np.any(xfilt['e'])):
-            telm = dev.almxfl(self._alm('elm', idx), self.clte)
-            if xfilt is not None:
-                telm = dev.almxfl(telm, xfilt['e'])
-            mlik = telm if mlik is None else mlik + telm
+            if xfilt is None:  # T^WF + C^TE Eb in one pass
+                mlik = dev.almxfl_add(mlik, self._alm('elm', idx), self.clte)
+            else:
+                telm = dev.almxfl(dev.almxfl(self._alm('elm', idx), self.clte), xfilt['e'])
+                mlik = telm if mlik is None else mlik + telm
         if mlik is None or (xfilt is not None and not bool(torch.any(mlik != 0))):
             return None
         return mlik
@@ -646,10 +647,11 @@ class lib_filt2map_sepTP(lib_filt2map):
             if xfilt is not None:
                 G, C = dev.almxfl(G, xfilt['e']), dev.almxfl(C, xfilt['b'])
         if k == 'p' and (xfilt is None or np.any(xfilt['t'])):
-            G_t = dev.almxfl(self._alm('tlm', idx), self.clte)
-            if xfilt is not None:
-                G_t = dev.almxfl(G_t, xfilt['t'])
-            G = G_t if G is None else G + G_t
+            if xfilt is None:  # E^WF + C^TE Tb in one pass
+                G = dev.almxfl_add(G, self._alm('tlm', idx), self.clte)
+            else:
+                G_t = dev.almxfl(dev.almxfl(self._alm('tlm', idx), self.clte), xfilt['t'])
+                G = G_t if G is None else G + G_t
         if G is None or (xfilt is not None and not (bool(torch.any(G != 0)) or (C is not None and bool(torch.any(C != 0))))):
             return None
         return G, C

@@ -89,3 +89,16 @@ def test_camb_clfile_and_hash():
     with pytest.raises(AssertionError):
         utils.hash_check({'a': 1}, {'a': 2})
     assert utils.mchash([3, 1, 2]) == utils.mchash([1, 2, 3])
+
+
+def test_bench_cpu_baseline_leg_runs_on_the_host():
+    """bench.py's cpu_baseline leg (oracle, both stages in C) on a tiny configuration: the contract keys, a positive rate, every
+    ring pair measured (no extrapolation when it fits the budget), and the usable-CPU count honours affinity / cgroup quota."""
+    import bench
+    n = bench.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    r = bench.cpu_baseline(16, 32, 20.)
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in r
+    assert r['kind'] == 'port' and r['value'] > 0 and r['cores'] == n and r['extrapolated_from_ring_stride'] == 1
+    assert bench.executed_flops(64, 64, 2) <= 24. * (65 * 66 // 2) * 128 and bench.executed_flops(64, 64, 0) > 0

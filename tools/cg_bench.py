@@ -91,6 +91,11 @@ def _run(nside, lmax, iters, kinds, joint, verbose, peak_tflops):
             log0 = f.chain.log
             f.chain.log = lambda stage, it, eps, **kw: (trace.append(float(eps)) if stage.depth == 0 else None, log0(stage, it, eps, **kw))
             torch.cuda.synchronize()
+            bdir = os.environ.get('CG_BENCH_BARRIER_DIR')  # concurrency probe: wait until the other process is here too
+            if bdir:
+                open(os.path.join(bdir, 'ready_%d' % os.getpid()), 'w').close()
+                while len([x for x in os.listdir(bdir) if x.startswith('ready_')]) < int(os.environ.get('CG_BENCH_BARRIER_N', '2')):
+                    time.sleep(0.001)
             t0 = time.time()
             f.apply_ivf(dmap)
             torch.cuda.synchronize()
