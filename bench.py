@@ -13,7 +13,9 @@ WORLD_SIZE / MASTER_* in their environment), one per GPU.  Under torch.distribut
 and WORLD_SIZE must equal --gpus.  The timed region is the PRODUCT's mean-field evaluation over world x K simulations,
 qest.library.get_sim_qlm_mf: every rank reconstructs its share jobs[rank::size] (K reconstructions per rank, weak
 scaling, run_qlms.py:72), the running sum stays on the device and one RCCL all-reduce completes it
-(plancklens_amd/parallel.py); then the last gradient alm of every rank is all-gathered over xGMI.
+(plancklens_amd/parallel.py); then the last gradient alm of every rank is all-gathered over xGMI.  The library serves
+its share two simulations at a time (the spin-2 and spin-3 leg syntheses of a pair share one Legendre recursion each,
+pl_alm2map_batch2; PLENS_BATCH2=0 evaluates them one by one): a step is still one reconstruction.
 
 Prints ONE JSON line (rank 0).
  * `roofline`: the Legendre kernel with the largest summed time inside the timed region (HIP events on the launch
@@ -57,7 +59,8 @@ PMC_TRAFFIC_SOURCE = 'profiles/round1_h_pmc_traffic.csv'
 KERNEL_NAMES = {'leg_synth0': 'k_leg_synth0 (scalar Legendre synthesis)', 'leg_synths': 'k_leg_synths (spin-weighted Legendre synthesis)',
                 'leg_anal0': 'k_leg_anal0 (scalar Legendre analysis)', 'leg_anals': 'k_leg_anals (spin-weighted Legendre analysis)',
                 'leg_synths_grad': 'k_leg_synths<GONLY> (gradient-only spin synthesis)',
-                'leg_synths_pair': 'k_leg_synths<PAIR> (general + gradient-only spin-1 synthesis on one recursion)'}
+                'leg_synths_pair': 'k_leg_synths<IN2=1> (general + gradient-only spin-1 synthesis on one recursion)',
+                'leg_synths_batch2': 'k_leg_synths<IN2=2> (the same spin synthesis of two simulations on one recursion)'}
 
 
 def fma_ceilings():
@@ -391,14 +394,20 @@ def run_rank(args):
         # gradient-only synthesis (curl alm = 0, shts.alm2map_spin([G, None])): 8 recurrence + 8 accumulation flop per step;
         # paired synthesis (general + gradient-only input on one recursion, shts.alm2map_spin_pair): 8 recurrence + 16 + 8
         # accumulation flop per step (SURVEY's fixed count for the two transforms it replaces would be 48)
+        # batched synthesis (two simulations on one recursion, shts.alm2map_spin_batch2): 8 recurrence + 2 x 16 accumulation flop per
+        # step for TWO maps (the fixed count of the two transforms it replaces is 48)
         alg = {'leg_synth0': flops_scal, 'leg_synths': flops_spin, 'leg_anal0': flops_scal, 'leg_anals': flops_spin,
-               'leg_synths_grad': flops_spin * 16. / 24., 'leg_synths_pair': flops_spin * 32. / 24.}
+               'leg_synths_grad': flops_spin * 16. / 24., 'leg_synths_pair': flops_spin * 32. / 24., 'leg_synths_batch2': flops_spin * 40. / 24.}
         exe = {'leg_synth0': exec_scal, 'leg_synths': exec_spin, 'leg_anal0': exec_scal, 'leg_anals': exec_spin,
-               'leg_synths_grad': exec_spin * 16. / 24., 'leg_synths_pair': exec_spin * 32. / 24.}
+               'leg_synths_grad': exec_spin * 16. / 24., 'leg_synths_pair': exec_spin * 32. / 24., 'leg_synths_batch2': exec_spin * 40. / 24.}
         # components per ring-FFT stage launch are not recorded by the profile; both directions move, per component,
         # 8 npix + 32 npairs (mmax + 1) algorithmic bytes.  Launch mix of one 'p' reconstruction (qest._get_sim_MVgclm):
         # synthesis stages of 1 + 2 + 2 + 4 components in 4 launches, analysis stages of 1 + 2 + 2 in 3 launches.
+        # With paired simulations (leg_synths_batch2 present) two reconstructions issue 6 synthesis stages of 1 + 1 + 4 + 4 + 4 + 4.
         comps_per_launch = {'fft_synth': 9. / 4., 'fft_anal': 5. / 3.} if (key == 'p' and not args.qe_only) else {}
+        if comps_per_launch and prof.get('leg_synths_batch2', (0., 0))[1] > 0:
+            nsyn = prof['fft_synth'][1]
+            comps_per_launch['fft_synth'] = 9. * K / nsyn if nsyn else 3.
         fft_bytes_comp = 8.0 * npix + 32.0 * 2 * nside * (lmax + 1)
         per_kernel = {}
         for k, (m_, c_) in prof.items():

@@ -70,6 +70,11 @@ int pl_alm2map_grad(pl_plan *plan, int spin, const double *almG, double *map, co
  * Device pointers only, asynchronous on `stream`.  16 + 4 instead of 12 + 4 + 8 + 4 FMAs per recursion step. */
 int pl_alm2map_pair(pl_plan *plan, int spin, const double *alm_gc_dev, const double *fl_dev, const double *alm_g2_dev, const double *fl2_dev,
                     double *maps4_dev, void *stream);
+/* The same spin-s synthesis of TWO general inputs (two simulations) on ONE recursion: 4 + 8 + 8 instead of 2 x (4 + 8) FMAs per
+ * recursion step (batching independent maps).  alm_gc_k_dev = [G_k | C_k], one filter fl for both;
+ * maps4_dev = [Q1 | U1 | Q2 | U2].  Device pointers only, asynchronous on `stream`.  Bit-identical to two pl_alm2map calls. */
+int pl_alm2map_batch2(pl_plan *plan, int spin, const double *alm_gc_1_dev, const double *alm_gc_2_dev, const double *fl_dev, double *maps4_dev,
+                      void *stream);
 int pl_map2alm(pl_plan *plan, int spin, const double *map, double *alm, const double *fl, int where, void *stream);
 
 /* Stage-level entry points: tests, stage timings, and callers that pipeline independent transforms (the Legendre stage of
@@ -88,9 +93,9 @@ int pl_map2phase(pl_plan *plan, int spin, const double *map_dev, double *phase_d
  * 2 Legendre analysis spin 0 (+ reduction), 3 Legendre analysis spin s (+ reduction), 4 ring FFT synthesis,
  * 5 ring FFT analysis, 6 gradient-only Legendre synthesis spin s (pl_legendre_synth_grad: 16 instead of 24 flop
  * per recursion step, kept apart so that kind 1 prices full launches only), 7 paired Legendre synthesis (pl_alm2map_pair:
- * 32 flop per step for two transforms).  pl_profile_read synchronises the recorded events, returns summed milliseconds and
+ * 32 flop per step for two transforms), 8 batched Legendre synthesis (pl_alm2map_batch2: 40 flop per step for two maps).  pl_profile_read synchronises the recorded events, returns summed milliseconds and
  * launch counts per kind (arrays of PL_PROFILE_KINDS entries) and resets the record. */
-#define PL_PROFILE_KINDS 8
+#define PL_PROFILE_KINDS 9
 int pl_profile_enable(pl_plan *plan, int on);
 int pl_profile_read(pl_plan *plan, double *ms_sum, int64_t *counts);
 

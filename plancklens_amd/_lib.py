@@ -11,7 +11,7 @@ from . import _build
 _LIB = None
 
 SYMBOLS = ['pl_version', 'pl_last_error', 'pl_device_count', 'pl_plan_create', 'pl_plan_fork', 'pl_plan_destroy', 'pl_plan_npix',
-           'pl_plan_nalm', 'pl_plan_bytes', 'pl_alm2map', 'pl_alm2map_grad', 'pl_alm2map_pair', 'pl_map2alm', 'pl_plan_phase_doubles', 'pl_legendre_synth', 'pl_legendre_synth_grad',
+           'pl_plan_nalm', 'pl_plan_bytes', 'pl_alm2map', 'pl_alm2map_grad', 'pl_alm2map_pair', 'pl_alm2map_batch2', 'pl_map2alm', 'pl_plan_phase_doubles', 'pl_legendre_synth', 'pl_legendre_synth_grad',
            'pl_legendre_anal', 'pl_phase2map', 'pl_map2phase', 'pl_almxfl', 'pl_alm2cl', 'pl_alm_copy', 'pl_axpy',
            'pl_alm_dot', 'pl_axpy_dev', 'pl_alm_splice', 'pl_almxfl_add', 'pl_template_project', 'pl_gemv', 'pl_copy_slim',
            'pl_map_mul', 'pl_map_cmul', 'pl_qe_lens_product', 'pl_fma64_peak_tflops', 'pl_fma64_rate_tflops', 'pl_profile_enable', 'pl_profile_read']
@@ -47,6 +47,7 @@ def lib():
     L.pl_alm2map.argtypes = [vp, i32, vp, vp, vp, i32, vp]
     L.pl_alm2map_grad.argtypes = [vp, i32, vp, vp, vp, i32, vp]
     L.pl_alm2map_pair.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+    L.pl_alm2map_batch2.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.pl_legendre_synth_grad.argtypes = [vp, i32, vp, vp, vp, vp]
     L.pl_map2alm.argtypes = [vp, i32, vp, vp, vp, i32, vp]
     L.pl_legendre_synth.argtypes = [vp, i32, vp, vp, vp, vp]

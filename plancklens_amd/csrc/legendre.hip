@@ -323,15 +323,19 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
 // -----------------------------------------------------------------------------------------------------
 // GONLY: the curl input is identically zero (gradient legs of the temperature estimators): An = sg Ap, so the four sums
 // are combinations of Sn Ap and Sp Ap split by the parity of l -- 4 accumulation FMAs per step instead of 8.
-// PAIR: a second, gradient-only input (prep2) rides on the same recursion: its phase values are components 2 and 3 of a
-// four-component phase array.  16 instead of 12 + 8 accumulation + recursion FMAs per step for the
-// two transforms (the spin-1 legs of the MV estimator: gradient of T^WF and the spin-1 leg of P^WF).
-template <int R, bool GONLY, bool PAIR = false>
+// IN2 = 1 ("pair"): a second, gradient-only input (prep2) rides on the same recursion: its phase values are components 2 and 3
+// of a four-component phase array.  16 instead of 12 + 8 accumulation + recursion FMAs per step for the two transforms (the
+// spin-1 legs of the MV estimator: gradient of T^WF and the spin-1 leg of P^WF).
+// IN2 = 2 ("batch"): the second input is a general one (G2, C2) -- the same transform of a second simulation: 4 + 8 + 8 = 20 FMAs
+// per step for two maps instead of 24 (batching independent maps through one recursion).  The sums of each
+// input are formed in the same order as by the single-input kernel: the results are bit-identical.
+template <int R, bool GONLY, int IN2 = 0>
 __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int spin, const double4 *__restrict__ prep,
                                                     double *__restrict__ phase, const double4 *__restrict__ prep2 = nullptr)
 {
-    static_assert(!(GONLY && PAIR), "PAIR = general + gradient-only");
-    constexpr int EST = PAIR ? 16 : 8;  // 4 doubles x number of components of the phase array
+    static_assert(!(GONLY && IN2 != 0), "a second input rides on a general first one");
+    constexpr bool PAIR = IN2 == 1, BATCH = IN2 == 2;
+    constexpr int EST = IN2 ? 16 : 8;  // 4 doubles x number of components of the phase array
     constexpr int RG = 64 * R;
     __shared__ double tile[RG * 32];  // [ring][m_local 4][8]
     const int wave = wave_id();
@@ -358,6 +362,10 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
     double gxe_r[R], gxe_i[R], gye_r[R], gye_i[R], gxo_r[R], gxo_i[R], gyo_r[R], gyo_i[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) gxe_r[k] = gxe_i[k] = gye_r[k] = gye_i[k] = gxo_r[k] = gxo_i[k] = gyo_r[k] = gyo_i[k] = 0.0;
+    // BATCH: the twelve sums of the second general input
+    double zn_r[R], zn_i[R], wn_r[R], wn_i[R], ze_r[R], ze_i[R], we_r[R], we_i[R], zo_r[R], zo_i[R], wo_r[R], wo_i[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) zn_r[k] = zn_i[k] = wn_r[k] = wn_i[k] = ze_r[k] = ze_i[k] = we_r[k] = we_i[k] = zo_r[k] = zo_i[k] = wo_r[k] = wo_i[k] = 0.0;
     double sig0 = 1.0;
 
     if (m <= P.mmax && l0 <= P.lmax) {
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
 #endif
         const d2v_t *__restrict__ abv = reinterpret_cast<const d2v_t *>(ab);
         const d4v_t *__restrict__ aav = reinterpret_cast<const d4v_t *>(aa);
-        const double4 *__restrict__ aa2 = PAIR ? prep2 + base : nullptr;  // gradient-only prep: {sg Ap2, Ap2}, only Ap2 is read
+        const double4 *__restrict__ aa2 = IN2 ? prep2 + base : nullptr;  // pair: gradient-only prep {sg Ap2, Ap2}, only Ap2 is read; batch: {An2, Ap2}
         const d4v_t *__restrict__ aav2 = reinterpret_cast<const d4v_t *>(aa2);
         int i = 0;
         bool all_done = false;
@@ -396,8 +404,9 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
         pf.start<32, 16>(aa, ab, i, nl, lane);
         double mn[R], mp[R];  // phase B: 0/1 masks of the (n, p) recursions of each ring
         // two consecutive l (even i, odd i); i stays even through phases A, B and C
+        // g0, g1: the entries of the second input for the two l -- pair: (Ap2.re, Ap2.im, -, -); batch: (An2, Ap2) like a0, a1
         auto pair_step = [&](auto masked, double ca0, double cb0, double ca1, double cb1, const d4v_t &a0, const d4v_t &a1,
-                             const d2v_t &g0 = d2v_t{0., 0.}, const d2v_t &g1 = d2v_t{0., 0.}) {
+                             const d4v_t &g0 = d4v_t{0., 0., 0., 0.}, const d4v_t &g1 = d4v_t{0., 0., 0., 0.}) {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 double vn = r[k].n1, vp = r[k].p1;
@@ -414,6 +423,12 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
                     gxe_r[k] = fma(vp, g0.x, gxe_r[k]); gxe_i[k] = fma(vp, g0.y, gxe_i[k]);
                     gye_r[k] = fma(vn, g0.x, gye_r[k]); gye_i[k] = fma(vn, g0.y, gye_i[k]);
                 }
+                if constexpr (BATCH) {
+                    zn_r[k] = fma(vn, g0.x, zn_r[k]); zn_i[k] = fma(vn, g0.y, zn_i[k]);
+                    wn_r[k] = fma(vp, g0.z, wn_r[k]); wn_i[k] = fma(vp, g0.w, wn_i[k]);
+                    ze_r[k] = fma(vp, g0.x, ze_r[k]); ze_i[k] = fma(vp, g0.y, ze_i[k]);
+                    we_r[k] = fma(vn, g0.z, we_r[k]); we_i[k] = fma(vn, g0.w, we_i[k]);
+                }
                 recs_step_fast(r[k], ca0, cb0);
                 vn = r[k].n1; vp = r[k].p1;
                 if constexpr (decltype(masked)::value) { vn *= mn[k]; vp *= mp[k]; }
@@ -428,6 +443,12 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
                 if constexpr (PAIR) {
                     gxo_r[k] = fma(vp, g1.x, gxo_r[k]); gxo_i[k] = fma(vp, g1.y, gxo_i[k]);
                     gyo_r[k] = fma(vn, g1.x, gyo_r[k]); gyo_i[k] = fma(vn, g1.y, gyo_i[k]);
+                }
+                if constexpr (BATCH) {
+                    zn_r[k] = fma(vn, g1.x, zn_r[k]); zn_i[k] = fma(vn, g1.y, zn_i[k]);
+                    wn_r[k] = fma(vp, g1.z, wn_r[k]); wn_i[k] = fma(vp, g1.w, wn_i[k]);
+                    zo_r[k] = fma(vp, g1.x, zo_r[k]); zo_i[k] = fma(vp, g1.y, zo_i[k]);
+                    wo_r[k] = fma(vn, g1.z, wo_r[k]); wo_i[k] = fma(vn, g1.w, wo_i[k]);
                 }
                 recs_step_fast(r[k], ca1, cb1);
             }
@@ -464,12 +485,16 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
             for (int h = 0; h < 2; ++h) {
                 const d8v_t c = ld8(ab + i + 4 * h);
                 const d8v_t q0 = ldc<d8v_t>(aav + i + 4 * h), q1 = ldc<d8v_t>(aav + i + 4 * h + 2);
-                d8v_t p0 = q0, p1 = q1;  // PAIR: the same four entries of the second input (only z, w are used)
-                if constexpr (PAIR) { p0 = ldc<d8v_t>(aav2 + i + 4 * h); p1 = ldc<d8v_t>(aav2 + i + 4 * h + 2); }
+                d8v_t p0 = q0, p1 = q1;  // the same four entries of the second input (pair: only z, w are used)
+                if constexpr (IN2 != 0) { p0 = ldc<d8v_t>(aav2 + i + 4 * h); p1 = ldc<d8v_t>(aav2 + i + 4 * h + 2); }
+                auto in2 = [](const d8v_t &p, int o) -> d4v_t {  // entry o (0 or 4) of p in the form pair_step takes
+                    if constexpr (BATCH) return d4v_t{p[o], p[o + 1], p[o + 2], p[o + 3]};
+                    else return d4v_t{p[o + 2], p[o + 3], 0., 0.};
+                };
                 pair_step(std::true_type(), c[0], c[1], c[2], c[3], __builtin_shufflevector(q0, q0, 0, 1, 2, 3),
-                          __builtin_shufflevector(q0, q0, 4, 5, 6, 7), d2v_t{p0[2], p0[3]}, d2v_t{p0[6], p0[7]});
+                          __builtin_shufflevector(q0, q0, 4, 5, 6, 7), in2(p0, 0), in2(p0, 4));
                 pair_step(std::true_type(), c[4], c[5], c[6], c[7], __builtin_shufflevector(q1, q1, 0, 1, 2, 3),
-                          __builtin_shufflevector(q1, q1, 4, 5, 6, 7), d2v_t{p1[2], p1[3]}, d2v_t{p1[6], p1[7]});
+                          __builtin_shufflevector(q1, q1, 4, 5, 6, 7), in2(p1, 0), in2(p1, 4));
             }
 #pragma unroll
             for (int k = 0; k < R; ++k) recs_renorm_up(r[k]);
@@ -492,18 +517,24 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
                     return ldc<d4v_t>(aav + idx);
                 }
             };
-            auto ldg = [&](int idx) -> d2v_t {  // Ap2 of entry idx of the second input
-                if constexpr (PAIR) return ldc<d2v_t>(reinterpret_cast<const d2v_t *>(aav2 + idx) + 1);
-                else return d2v_t{0., 0.};
+            auto ldg = [&](int idx) -> d4v_t {  // entry idx of the second input: pair (Ap2, -), batch (An2, Ap2)
+                if constexpr (PAIR) {
+                    const d2v_t h = ldc<d2v_t>(reinterpret_cast<const d2v_t *>(aav2 + idx) + 1);
+                    return d4v_t{h.x, h.y, 0., 0.};
+                } else if constexpr (BATCH) {
+                    return ldc<d4v_t>(aav2 + idx);
+                } else {
+                    return d4v_t{0., 0., 0., 0.};
+                }
             };
             d4v_t Aa0 = lda(i), Aa1 = lda(i + 1);
-            d2v_t Ag0 = ldg(i), Ag1 = ldg(i + 1);
+            d4v_t Ag0 = ldg(i), Ag1 = ldg(i + 1);
             while (i + 3 < nl) {
                 pf.step<32, 16>(aa, ab, i, nl, lane);
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): set A has landed (it was issued one half trip ago) ...
                 const d2v_t B0 = ldc<d2v_t>(abv + i + 2), B1 = ldc<d2v_t>(abv + i + 3);  // ... so that B can be issued without A's uses waiting on it
                 const d4v_t Ba0 = lda(i + 2), Ba1 = lda(i + 3);
-                const d2v_t Bg0 = ldg(i + 2), Bg1 = ldg(i + 3);
+                const d4v_t Bg0 = ldg(i + 2), Bg1 = ldg(i + 3);
                 __builtin_amdgcn_sched_barrier(0);
                 pair_step(std::false_type(), A0.x, A0.y, A1.x, A1.y, Aa0, Aa1, Ag0, Ag1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -548,6 +579,18 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
                     } else {
                         gxo_r[k] = fma(vp, a2.z, gxo_r[k]); gxo_i[k] = fma(vp, a2.w, gxo_i[k]);
                         gyo_r[k] = fma(vn, a2.z, gyo_r[k]); gyo_i[k] = fma(vn, a2.w, gyo_i[k]);
+                    }
+                }
+                if constexpr (BATCH) {
+                    const double4 a2 = aa2[i];
+                    zn_r[k] = fma(vn, a2.x, zn_r[k]); zn_i[k] = fma(vn, a2.y, zn_i[k]);
+                    wn_r[k] = fma(vp, a2.z, wn_r[k]); wn_i[k] = fma(vp, a2.w, wn_i[k]);
+                    if (!odd) {
+                        ze_r[k] = fma(vp, a2.x, ze_r[k]); ze_i[k] = fma(vp, a2.y, ze_i[k]);
+                        we_r[k] = fma(vn, a2.z, we_r[k]); we_i[k] = fma(vn, a2.w, we_i[k]);
+                    } else {
+                        zo_r[k] = fma(vp, a2.x, zo_r[k]); zo_i[k] = fma(vp, a2.y, zo_i[k]);
+                        wo_r[k] = fma(vn, a2.z, wo_r[k]); wo_i[k] = fma(vn, a2.w, wo_i[k]);
                     }
                 }
                 recs_step_careful(r[k], c_ab.x, c_ab.y);
@@ -596,6 +639,13 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
         for (int k = 0; k < R; ++k)
             emit(k, sg * (gye_r[k] + gyo_r[k]), sg * (gye_i[k] + gyo_i[k]), gxe_r[k] + gxo_r[k], gxe_i[k] + gxo_i[k],
                  sg * gxe_r[k], sg * gxe_i[k], sg * gxo_r[k], sg * gxo_i[k], gye_r[k], gye_i[k], gyo_r[k], gyo_i[k]);
+        store(8);
+    }
+    if constexpr (BATCH) {  // the second general input, same formulas as the first, into components 2 and 3
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+            emit(k, zn_r[k], zn_i[k], wn_r[k], wn_i[k], ze_r[k], ze_i[k], zo_r[k], zo_i[k], we_r[k], we_i[k], wo_r[k], wo_i[k]);
         store(8);
     }
 }
@@ -1255,7 +1305,7 @@ static void launch_synths_r(const DevPlan &P, const DevSpinTab &S, int spin, con
     // PLSHTS_SYNTH_LDS_PAD (bytes, experiments): dynamic LDS nobody touches, to cap the workgroups per CU and leave room for the
     // ring-FFT kernels of another transform running on a second stream
     static const int pad = env_int("PLSHTS_SYNTH_LDS_PAD", 0);
-    hipLaunchKernelGGL((k_leg_synths<R, GONLY>), dim3(ngroups * nmg), dim3(256), pad, st, P, S, spin,
+    hipLaunchKernelGGL((k_leg_synths<R, GONLY, 0>), dim3(ngroups * nmg), dim3(256), pad, st, P, S, spin,
                        reinterpret_cast<const double4 *>(prep), phase);
 }
 
@@ -1264,10 +1314,25 @@ void launch_synths_pair(const DevPlan &P, const DevSpinTab &S, int spin, const d
 {
     const int ngroups1 = (P.npairs + 63) / 64, ngroups2 = (P.npairs + 127) / 128, nmg = (P.mmax + 4) / 4;
     if (rs_synth(P) == 1)
-        hipLaunchKernelGGL((k_leg_synths<1, false, true>), dim3(ngroups1 * nmg), dim3(256), 0, st, P, S, spin,
+        hipLaunchKernelGGL((k_leg_synths<1, false, 1>), dim3(ngroups1 * nmg), dim3(256), 0, st, P, S, spin,
                            reinterpret_cast<const double4 *>(prep), phase, reinterpret_cast<const double4 *>(prep2));
     else
-        hipLaunchKernelGGL((k_leg_synths<2, false, true>), dim3(ngroups2 * nmg), dim3(256), 0, st, P, S, spin,
+        hipLaunchKernelGGL((k_leg_synths<2, false, 1>), dim3(ngroups2 * nmg), dim3(256), 0, st, P, S, spin,
+                           reinterpret_cast<const double4 *>(prep), phase, reinterpret_cast<const double4 *>(prep2));
+}
+
+// two general inputs (two simulations) on one recursion; phase entries of 16 doubles: components (Q1, U1, Q2, U2).
+// PLSHTS_RSB overrides the rings per lane (1 or 2)
+void launch_synths_batch2(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st)
+{
+    const int ngroups1 = (P.npairs + 63) / 64, ngroups2 = (P.npairs + 127) / 128, nmg = (P.mmax + 4) / 4;
+    int r = env_int("PLSHTS_RSB", 0);
+    if (r != 1 && r != 2) r = rs_synth(P) == 1 ? 1 : 2;
+    if (r == 1)
+        hipLaunchKernelGGL((k_leg_synths<1, false, 2>), dim3(ngroups1 * nmg), dim3(256), 0, st, P, S, spin,
+                           reinterpret_cast<const double4 *>(prep), phase, reinterpret_cast<const double4 *>(prep2));
+    else
+        hipLaunchKernelGGL((k_leg_synths<2, false, 2>), dim3(ngroups2 * nmg), dim3(256), 0, st, P, S, spin,
                            reinterpret_cast<const double4 *>(prep), phase, reinterpret_cast<const double4 *>(prep2));
 }
 

@@ -68,14 +68,23 @@ def allgather(x):
     return [torch.view_as_complex(o) if x.is_complex() else o for o in out]
 
 
-def mean_field(get_qlm, idxs, like):
+def mean_field(get_qlm, idxs, like, get_pair=None):
     """Mean of get_qlm(idx) over ALL idxs, each rank evaluating only its shard: sum locally, all-reduce, divide.
-    `like` is a zero tensor giving shape / dtype / device of the accumulator."""
+    `like` is a zero tensor giving shape / dtype / device of the accumulator.  get_pair(idx0, idx1) -> (q0, q1), when given, serves
+    the shard two simulations at a time (their transforms share Legendre recursions); the terms are added in index order either way."""
     idxs = list(np.unique(np.asarray(idxs)))
     acc = torch.zeros_like(like)
-    for idx in shard(idxs):
-        q = get_qlm(idx)
-        acc += q if isinstance(q, torch.Tensor) else torch.as_tensor(q).to(acc.device)
+    mine = shard(idxs)
+
+    def add(q):
+        acc.add_(q if isinstance(q, torch.Tensor) else torch.as_tensor(q).to(acc.device))
+    n2 = len(mine) - len(mine) % 2 if get_pair is not None else 0
+    for i in range(0, n2, 2):
+        q0, q1 = get_pair(mine[i], mine[i + 1])
+        add(q0)
+        add(q1)
+    for idx in mine[n2:]:
+        add(get_qlm(idx))
     allreduce_sum(acc)
     if len(idxs) > 0:
         acc /= len(idxs)

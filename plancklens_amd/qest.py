@@ -243,7 +243,8 @@ class library(object):
             # the reference's loop (qest.py:238-244).  The cache file is written by rank 0 only.
             from . import parallel
             like = torch.zeros(hp.Alm.getsize(lmax), dtype=torch.complex128, device='cuda')
-            MF = dev.to_host(parallel.mean_field(lambda idx: self._get_sim_qlm_dev(k, idx, lmax), this_mcs, like))
+            MF = dev.to_host(parallel.mean_field(lambda idx: self._get_sim_qlm_dev(k, idx, lmax), this_mcs, like,
+                                                 get_pair=self._pair_getter(k, lmax)))
             if self.cache:
                 if mpi.rank == 0:
                     _write_alm(fname, MF)
@@ -253,6 +254,22 @@ class library(object):
                 self._mem[('mf', fname)] = MF
             return ut.alm_copy(MF, lmax=lmax)
         return ut.alm_copy(hp.read_alm(fname), lmax=lmax)
+
+    def _pair_getter(self, k, lmax):
+        """(idx0, idx1) -> the two device estimates, evaluated together (pl_alm2map_batch2 for the leg syntheses), or None when this
+        key / library does not pair: minimum-variance keys of a same-legs library at its full band-limit.  PLENS_BATCH2=0 disables."""
+        k = self.keys_remaps.get(k, k)
+        if (k not in ('p', 'x') or k not in self.keys_fund or lmax != self.get_lmax_qlm(k) or not self._same_legs()
+                or os.environ.get('PLENS_BATCH2', '1') == '0'):
+            return None
+        which = 0 if k == 'p' else 1
+
+        def get_pair(idx0, idx1):
+            if self._has(k, idx0) or self._has(k, idx1):
+                return self._get_sim_qlm_dev(k, idx0, lmax), self._get_sim_qlm_dev(k, idx1, lmax)
+            (r0, r1) = self._build_sim_MVgclm_pair(idx0, idx1)
+            return r0[which], r1[which]
+        return get_pair
 
     # gradient key of the evaluation that serves (gradient, curl) key pairs: ('p', 'x') come out of one MV evaluation, ...
     _GC_FAMILY = {'p': ('p', 0), 'x': ('p', 1), 'ptt': ('ptt', 0), 'xtt': ('ptt', 1), 'p_p': ('p_p', 0), 'x_p': ('p_p', 1)}
@@ -360,6 +377,28 @@ class library(object):
             return dev.host_future(G), dev.host_future(C)
         return dev.to_host(G), dev.to_host(C)
 
+    def _get_sim_MVgclm_pair(self, idx0, idx1, defer=False):
+        """_get_sim_MVgclm of two simulations whose spin-2 and spin-3 leg syntheses share their Legendre recursions
+        (lib_filt2map.get_irespmap_batch2 / get_gpmap_batch2; same legs on both sides only).  Returns, per simulation,
+        (G host, C host, G device, C device); the host entries are dev.host_future objects when `defer`."""
+        f2map1, f2map2 = self._legs(False)
+        idxs = (idx0, idx1)
+        tmaps = [f2map1.get_irestmap(i) for i in idxs]
+        resp = f2map1.get_irespmap_batch2(idx0, idx1)
+        gp3 = f2map2.get_gpmap_batch2(idx0, idx1, 3, k='p')
+        out = []
+        for j, idx in enumerate(idxs):
+            (gt, ct), (g1, c1) = f2map2.get_gt_gp1maps(idx, k='p')
+            dre, dim = dev.qe_lens_product((tmaps[j], gt, ct), (resp[j][0], resp[j][1], gp3[j][0], gp3[j][1], g1, c1))
+            del gt, ct, g1, c1
+            G, C = self._gc_from_product(dre, dim, 'P')
+            if defer and G.numel() >= self._DEFER_MIN_ENTRIES:
+                out.append((dev.host_future(G), dev.host_future(C), G, C))
+            else:
+                out.append((dev.to_host(G), dev.to_host(C), G, C))
+        self._last_dev, self._last_dev_key = (out[1][2], out[1][3]), ('p', idx1, False)
+        return out
+
     def _scalar_from_product(self, prod, fac, lmax_key):
         lmax = self.get_lmax_qlm(lmax_key)
         return dev.to_host(shts.map2alm(prod, lmax=lmax, iter=0)) * fac
@@ -433,6 +472,14 @@ class library(object):
             G, C = self._sym_gc(self._get_sim_MVgclm, idx, 'p')
         self._store('p', idx, G)
         self._store('x', idx, C)
+
+    def _build_sim_MVgclm_pair(self, idx0, idx1):
+        """both simulations' ('p', 'x') entries from one paired evaluation; returns their device (G, C)"""
+        res = self._get_sim_MVgclm_pair(idx0, idx1, defer=self._defer_ok())
+        for idx, (G, C, _, _) in zip((idx0, idx1), res):
+            self._store('p', idx, G)
+            self._store('x', idx, C)
+        return [(r[2], r[3]) for r in res]
 
     def _build_sim_f(self, idx):
         G = self._get_sim_f_p(idx, joint=True)
@@ -588,6 +635,24 @@ class lib_filt2map(object):
             assert isinstance(xfilt, dict) and 'e' in xfilt.keys() and 'b' in xfilt.keys()
             e, b = dev.almxfl(e, xfilt['e']), dev.almxfl(b, xfilt['b'])
         return shts.alm2map_spin([e, b], self.nside, 2, lmax, fl=0.5 * np.ones(lmax + 1))
+
+    # ---- two simulations on one Legendre recursion (pl_alm2map_batch2): same maps, bit for bit, at 0.8 of the time -----------
+    def get_irespmap_batch2(self, idx0, idx1):
+        """get_irespmap of two simulations: ((Qb0, Ub0), (Qb1, Ub1))"""
+        eb = [(self._alm('elm', i), self._alm('blm', i)) for i in (idx0, idx1)]
+        lmax = self._lmax(eb[0][0])
+        if any(self._lmax(x) != lmax for pair in eb for x in pair):
+            return self.get_irespmap(idx0), self.get_irespmap(idx1)
+        return shts.alm2map_spin_batch2(list(eb[0]), list(eb[1]), self.nside, 2, lmax, fl=0.5 * np.ones(lmax + 1))
+
+    def get_gpmap_batch2(self, idx0, idx1, spin, k=None):
+        """get_gpmap of two simulations: ((G0, C0), (G1, C1)) spin-s maps"""
+        assert spin in [1, 3]
+        gcs = [self._gp_alms(i, k=k) for i in (idx0, idx1)]
+        if any(gc is None or gc[1] is None for gc in gcs) or self._lmax(gcs[0][0]) != self._lmax(gcs[1][0]):
+            return self.get_gpmap(idx0, spin, k=k), self.get_gpmap(idx1, spin, k=k)
+        lmax = self._lmax(gcs[0][0])
+        return shts.alm2map_spin_batch2(list(gcs[0]), list(gcs[1]), self.nside, spin, lmax, fl=_spin_weight(spin, lmax))
 
 
 class lib_filt2map_sepTP(lib_filt2map):

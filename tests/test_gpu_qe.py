@@ -208,3 +208,27 @@ def test_mv_estimator_with_pipelined_lanes(setup, monkeypatch):
     monkeypatch.setenv('PLENS_LANES', '1')
     out = q.get_sim_qlm('p', 0)
     assert out is not ref and relrms(out, ref) < 1e-14 and relrms(out, g['dd_p_0']) < TOL
+
+
+def test_paired_simulations_equal_single_evaluations(setup, tmp_path):
+    """The mean-field loop serves a same-legs library two simulations at a time (their spin-2 and spin-3 leg syntheses share
+    Legendre recursions, pl_alm2map_batch2): estimates and mean field must equal the one-at-a-time evaluation bit for bit."""
+    import os
+    from plancklens_amd import qest
+    from plancklens_amd.filt import filt_simple
+    g, cl = setup[0], setup[4]
+    nside, lmax_qlm = int(g['nside']), int(g['lmax_qlm'])
+    res = {}
+    for tag, env in (('pair', '1'), ('single', '0')):
+        os.environ['PLENS_BATCH2'] = env
+        try:
+            ivfs = filt_simple.library_fullsky_sepTP(str(tmp_path / ('ivfs_' + tag)), _gold_sims(g), nside, g['transf'], cl, g['ftl'], g['fel'],
+                                                     g['fbl'], cache=False)
+            q = qest.library_sepTP(str(tmp_path / ('q_' + tag)), ivfs, ivfs, cl['te'], nside, lmax_qlm=lmax_qlm, cache=False)
+            mf = q.get_sim_qlm_mf('p', np.array([0, 1]))
+            res[tag] = (mf, q.get_sim_qlm('p', 0), q.get_sim_qlm('p', 1), q.get_sim_qlm('x', 1))
+        finally:
+            del os.environ['PLENS_BATCH2']
+    for a, b in zip(res['pair'], res['single']):
+        assert np.array_equal(a, b)
+    assert relrms(res['pair'][0], g['dd_mf_p']) < TOL and relrms(res['pair'][2], g['dd_p_1']) < TOL

@@ -263,3 +263,21 @@ def test_adjointness_at_lmax_3nside_minus_1(shts, nside, lmax):
             for x, y in ((q1, q), (u1, u), (q2, r2[0]), (u2, r2[1])):
                 assert float((x - y).abs().max() / y.abs().max()) < 1e-12
         assert abs(lhs / rhs - 1) < 1e-11, (spin, lhs, rhs)
+
+
+@pytest.mark.parametrize('spin', [1, 2, 3])
+@pytest.mark.parametrize('nside,lmax', [(8, 16), (32, 64), (64, 150), (256, 300), (512, 700), (2048, 2048)])
+def test_batched_synthesis_is_bit_identical_to_two_calls(shts, spin, nside, lmax):
+    """pl_alm2map_batch2 (two simulations on one recursion) against two pl_alm2map calls: every sum is formed in the same order,
+    so the maps are equal bit for bit -- including nside = lmax = 2048, where the rings-per-lane 2 kernel with the three
+    scaling phases runs."""
+    import torch
+    from plancklens_amd import dev
+    rng = np.random.default_rng(spin * 11 + nside + lmax)
+    g1, c1, g2, c2 = (dev.to_dev(random_alm(rng, lmax, spin)) for _ in range(4))
+    fl = rng.uniform(0.5, 1.5, lmax + 1)
+    (q1, u1), (q2, u2) = shts.alm2map_spin_batch2([g1, c1], [g2, c2], nside, spin, lmax, fl=fl)
+    r1 = shts.alm2map_spin([g1, c1], nside, spin, lmax, fl=fl)
+    r2 = shts.alm2map_spin([g2, c2], nside, spin, lmax, fl=fl)
+    for a, b in ((q1, r1[0]), (u1, r1[1]), (q2, r2[0]), (u2, r2[1])):
+        assert bool((a == b).all()), float((a - b).abs().max())
