@@ -55,9 +55,19 @@ def main():
     # --- unnormalized QE calculation
     qlibs = [par.qlms_dd] * args.dd + [par.qlms_ss] * args.ss + [par.qlms_ds] * args.ds
     jobs = [(qlib, idx, k) for qlib in qlibs for k in args.k for idx in range(args.imin, args.imax + 1)]
-    for i, (qlib, idx, k) in enumerate(jobs[mpi.rank::mpi.size]):
-        print('rank %s doing QE sim %s %s, qlm_lib %s, job %s in %s' % (mpi.rank, idx, k, qlib.lib_dir, i, len(jobs)))
-        qlib.get_sim_qlm(k, idx)
+    mine = jobs[mpi.rank::mpi.size]
+    # this rank's jobs, library by library and key by key: get_sim_qlms evaluates the simulations that are not cached yet two at
+    # a time where the library can (two simulations on one Legendre recursion); results and cache files are the same
+    groups = {}
+    for qlib, idx, k in mine:
+        groups.setdefault((id(qlib), k), (qlib, k, []))[2].append(idx)
+    for qlib, k, idxs in groups.values():
+        print('rank %s doing QE sims %s %s, qlm_lib %s (%s of %s jobs)' % (mpi.rank, idxs, k, qlib.lib_dir, len(mine), len(jobs)))
+        if hasattr(qlib, 'get_sim_qlms'):
+            qlib.get_sim_qlms(k, idxs)
+        else:
+            for idx in idxs:
+                qlib.get_sim_qlm(k, idx)
     mpi.barrier()
 
     # --- mean-fields: every rank takes part in every mean field -- the simulations of one mean field are sharded over the

@@ -203,6 +203,19 @@ class library(object):
             return self._load(k, idx)  # in-memory mode: the stored array is handed over as is
         return ut.alm_copy(self._load(k, idx), lmax=lmax)
 
+    def get_sim_qlms(self, k, idxs, lmax=None):
+        """[get_sim_qlm(k, idx) for idx in idxs] (an addition to the reference's API for Monte-Carlo loops): simulations that are
+        not cached yet are evaluated two at a time where the library can pair them (see _pair_getter), results as usual."""
+        idxs = list(idxs)
+        k_ = self.keys_remaps.get(k, k)
+        full = self.get_lmax_qlm(k_) if lmax is None else lmax
+        pair = self._pair_getter(k_, full)
+        if pair is not None:
+            todo = [i for i in idxs if not self._has(k_, i)]
+            for a, b in zip(todo[0::2], todo[1::2]):
+                self._build_sim_MVgclm_pair(a, b)
+        return [self.get_sim_qlm(k, i, lmax=lmax) for i in idxs]
+
     def get_dat_qlm(self, k, **kwargs):
         return self.get_sim_qlm(k, -1, **kwargs)
 

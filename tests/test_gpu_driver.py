@@ -56,7 +56,8 @@ def test_two_ranks_share_the_mean_field(tmp_path):
         assert p.returncode == 0, o[-3000:]
     # jobs[rank::size]: each rank reconstructed its own simulations only
     for r, o in enumerate(outs):
-        mine = [int(l.split('QE sim ')[1].split()[0]) for l in o.splitlines() if 'doing QE sim' in l]
+        line = [l for l in o.splitlines() if 'doing QE sims' in l][0]
+        mine = [int(x) for x in line.split('QE sims [')[1].split(']')[0].split(',')]
         assert mine == list(range(0, 6))[r::2], (r, mine)
     sys.path.insert(0, ROOT)
     from plancklens_amd import hp
