@@ -130,6 +130,17 @@ int pl_template_project(int64_t npix, int nmodes, double *tmap, const double *n_
                         double *scratch_dev, void *stream);
 int pl_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, void *stream);
 
+/* The temperature CG operator x -> S^-1 x + B^t Y^t N^-1 Y B x (fwd_op.calc, opfilt_tt.py:67-73, with apply_alm :184-194 and the
+ * template-marginalised apply_map :196-205 inside) as one call on the plan's grid:
+ *   alm_out = fl_out * Y^t [n_inv t - sum_k rmat[k] c_k],  t = Y (fl_in * alm_in),  c_k = sum_i pmat[k][i] n_inv[i] t[i],
+ * plus fl_add * alm_add when alm_add is given (alm_out may be neither input).  nmodes = 0: plain N^-1 weighting (pmat, rmat,
+ * scratch_dev unused).  On grids whose rings all run in the generic ring-FFT kernel and nmodes <= 4 the weighting and the projection
+ * ride in the two FFT launches; otherwise they are the pl_template_project launches.  All arrays in device memory; fl_* have
+ * lmax + 1 entries (null: 1); scratch_dev as pl_template_project.  Bit-reproducible. */
+int pl_cg_fwd_tt(pl_plan *plan, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *pmat,
+                 const double *rmat, double *scratch_dev, const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out,
+                 void *stream);
+
 /* y = A x, A row-major nrows x ncols with leading dimension lda, all device arrays (x and y must not overlap): the dense
  * low-l preconditioner of the CG chains applied as one mat-vec (dense.py:118-119,201-202,284-285), and the template
  * coefficient products of the joint filter.  One wavefront per row, fixed summation tree (bit-reproducible). */

@@ -20,7 +20,8 @@ void launch_synth0(const DevPlan &P, const double *prep, double *phase, hipStrea
 void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st, bool gonly);
 void launch_synths_pair(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st);
 void launch_synths_batch2(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st);
-void launch_anal0(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st);
+void launch_anal0(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st,
+                  const double *add = nullptr, const double *fl_add = nullptr);
 void launch_anals(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
                   const double *fl, double *alm, hipStream_t st);
 void launch_almxfl(int lmax, const double *in, const double *fl, int nfl, double *out, hipStream_t st);
@@ -71,6 +72,8 @@ struct pl_plan {
     double *phase = nullptr; int64_t phase_cap = 0;
     double *prep = nullptr; int64_t prep_cap = 0;
     double *prep2 = nullptr; int64_t prep2_cap = 0;  // second input of pl_alm2map_pair
+    double *wmap = nullptr; int64_t wmap_cap = 0;    // pl_cg_fwd_tt: the weighted map between the two transforms
+    double *tparts = nullptr; int64_t tparts_cap = 0;  // pl_cg_fwd_tt: per ring pair partial sums of the template coefficients
     double *partial = nullptr; int64_t partial_cap = 0;
     double *h_alm = nullptr; int64_t h_alm_cap = 0;   // device staging for host-pointer calls
     double *h_map = nullptr; int64_t h_map_cap = 0;
@@ -335,6 +338,8 @@ int pl_plan_destroy(pl_plan *p)
     if (p->phase) (void)hipFree(p->phase);
     if (p->prep) (void)hipFree(p->prep);
     if (p->prep2) (void)hipFree(p->prep2);
+    if (p->wmap) (void)hipFree(p->wmap);
+    if (p->tparts) (void)hipFree(p->tparts);
     if (p->partial) (void)hipFree(p->partial);
     if (p->h_alm) (void)hipFree(p->h_alm);
     if (p->h_map) (void)hipFree(p->h_map);
@@ -608,6 +613,49 @@ int pl_template_project(int64_t npix, int nmodes, double *tmap, const double *n_
     if (npix <= 0 || nmodes < 1 || nmodes > PL_TEMPLATE_MAX_MODES || !tmap || !n_inv || !pmat || !rmat || !scratch)
         return fail("pl_template_project: bad arguments (1 <= nmodes <= PL_TEMPLATE_MAX_MODES)");
     launch_template_project(npix, nmodes, tmap, n_inv, pmat, rmat, scratch, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// The temperature CG operator in one call (plancklens/qcinv/opfilt_tt.py:54-73 with :196-205 inside):
+//   alm_out = fl_out * Y^t [N^-1 - N^-1 P (P^t N^-1 P)^-1 P^t N^-1] Y (fl_in * alm_in)  +  fl_add * alm_add.
+// On grids whose rings all run in the generic ring-FFT kernel (the coarse levels of the multigrid chain) the weighting and the projection
+// ride in the two FFT launches (NinvProj); on the finer grids they are the two pl_template_project launches between the transforms.
+int pl_cg_fwd_tt(pl_plan *p, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *pmat, const double *rmat,
+                 double *scratch, const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out, void *stream)
+{
+    if (!p) return fail("null plan");
+    if (!alm_in || !alm_out || !n_inv) return fail("pl_cg_fwd_tt: null alm / n_inv pointer");
+    if (nmodes < 0 || nmodes > PL_TEMPLATE_MAX_MODES || (nmodes > 0 && (!pmat || !rmat || !scratch))) return fail("pl_cg_fwd_tt: bad template arguments");
+    if ((alm_add == nullptr) != (fl_add == nullptr)) return fail("pl_cg_fwd_tt: alm_add and fl_add come together");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const DevPlan &P = p->P;
+    if (grow(p, &p->phase, &p->phase_cap, pl_plan_phase_doubles(p, 0)) || grow(p, &p->wmap, &p->wmap_cap, P.npix)) return 1;
+    if (legendre_synth_impl(p, 0, alm_in, fl_in, p->phase, stream, false)) return 1;
+    const bool fused = fft_all_generic(P, p->F) && nmodes <= kFuseModes;
+    NinvProj W;
+    if (fused) {
+        if (nmodes > 0 && grow(p, &p->tparts, &p->tparts_cap, (int64_t)nmodes * P.npairs)) return 1;
+        W.n_inv = n_inv; W.nmodes = nmodes; W.nparts = P.npairs; W.parts = p->tparts;
+        if (nmodes > 0) { W.pm = pmat; W.rm = rmat; }
+    }
+    {
+        ProfScope ps(p, PK_FFT_SYNTH, st);
+        HIPCHK(launch_phase2map(P, p->F, p->fs, mlim_of(p, 0), 1, p->phase, p->wmap, st, fused ? &W : nullptr));
+    }
+    if (!fused) {
+        if (nmodes > 0) launch_template_project(P.npix, nmodes, p->wmap, n_inv, pmat, rmat, scratch, st);
+        else launch_map_mul(P.npix, p->wmap, n_inv, p->wmap, st);
+        HIPCHK(hipGetLastError());
+    }
+    {
+        ProfScope ps(p, PK_FFT_ANAL, st);
+        HIPCHK(launch_map2phase(P, p->F, p->fs, mlim_of(p, 0), 1, p->wmap, p->phase, st, (fused && nmodes > 0) ? &W : nullptr));
+    }
+    const int RG = rings_per_group(0, P);
+    const int ngroups = (P.npairs + RG - 1) / RG;
+    if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * P.nent0 * 4)) return 1;
+    { ProfScope ps(p, PK_LEG_ANAL0, st); launch_anal0(P, p->phase, p->partial, fl_out, alm_out, st, alm_add, fl_add); }
     HIPCHK(hipGetLastError());
     return 0;
 }

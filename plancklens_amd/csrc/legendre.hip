@@ -923,7 +923,9 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
 }
 
 // reduce partials over ring groups and convert (C, D) -> a_lm (fused hp.almxfl)
-__global__ void k_post0(DevPlan P, int RG, const double4 *__restrict__ partial, const double *__restrict__ fl, double2 *__restrict__ alm)
+// add / fl_add (optional): alm = fl * (analysis) + fl_add * add, the S^-1 x term of the CG operator folded in
+__global__ void k_post0(DevPlan P, int RG, const double4 *__restrict__ partial, const double *__restrict__ fl, double2 *__restrict__ alm,
+                        const double2 *__restrict__ add, const double *__restrict__ fl_add)
 {
     const int m = blockIdx.y;
     const int nil = (P.lmax - m) / 2 + 1;
@@ -952,11 +954,13 @@ __global__ void k_post0(DevPlan P, int RG, const double4 *__restrict__ partial, 
         a.x = f0 * c0r + f1 * c1r;
         a.y = f0 * c0i + f1 * c1i;
         if (fl) { a.x *= fl[l]; a.y *= fl[l]; }
+        if (add) { const double2 t = add[abase + l]; a.x = fma(fl_add[l], t.x, a.x); a.y = fma(fl_add[l], t.y, a.y); }
         alm[abase + l] = a;
         if (l + 1 <= P.lmax) {
             double2 b;
             b.x = al * dr; b.y = al * di;
             if (fl) { b.x *= fl[l + 1]; b.y *= fl[l + 1]; }
+            if (add) { const double2 t = add[abase + l + 1]; b.x = fma(fl_add[l + 1], t.x, b.x); b.y = fma(fl_add[l + 1], t.y, b.y); }
             alm[abase + l + 1] = b;
         }
     }
@@ -1357,25 +1361,27 @@ void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double
 }
 
 template <int R>
-static void launch_anal0_r(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st)
+static void launch_anal0_r(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st,
+                           const double *add, const double *fl_add)
 {
     constexpr int RG = 64 * R;
     const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
     hipLaunchKernelGGL(k_leg_anal0<R>, dim3(ngroups * nmg), dim3(256), 0, st, P, phase, partial);
     dim3 grid(4, P.mmax + 1);
     hipLaunchKernelGGL(k_post0, grid, dim3(256), 0, st, P, RG, reinterpret_cast<const double4 *>(partial), fl,
-                       reinterpret_cast<double2 *>(alm));
+                       reinterpret_cast<double2 *>(alm), reinterpret_cast<const double2 *>(add), fl_add);
 }
 
-void launch_anal0(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st)
+void launch_anal0(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st, const double *add,
+                  const double *fl_add)
 {
     switch (r0_anal(P)) {
-    case 1: launch_anal0_r<1>(P, phase, partial, fl, alm, st); break;
-    case 2: launch_anal0_r<2>(P, phase, partial, fl, alm, st); break;
-    case 3: launch_anal0_r<3>(P, phase, partial, fl, alm, st); break;
-    case 5: launch_anal0_r<5>(P, phase, partial, fl, alm, st); break;
-    case 6: launch_anal0_r<6>(P, phase, partial, fl, alm, st); break;
-    default: launch_anal0_r<4>(P, phase, partial, fl, alm, st); break;
+    case 1: launch_anal0_r<1>(P, phase, partial, fl, alm, st, add, fl_add); break;
+    case 2: launch_anal0_r<2>(P, phase, partial, fl, alm, st, add, fl_add); break;
+    case 3: launch_anal0_r<3>(P, phase, partial, fl, alm, st, add, fl_add); break;
+    case 5: launch_anal0_r<5>(P, phase, partial, fl, alm, st, add, fl_add); break;
+    case 6: launch_anal0_r<6>(P, phase, partial, fl, alm, st, add, fl_add); break;
+    default: launch_anal0_r<4>(P, phase, partial, fl, alm, st, add, fl_add); break;
     }
 }
 

@@ -37,6 +37,19 @@ struct DevFFT {
     FftSide A;               // class lists and band-limited Bluestein tables, shared by synthesis and analysis
 };
 
+// Optional inverse-noise weighting with template marginalisation folded into the generic ring-FFT kernels (the CG operator of
+// opfilt_tt.py:196-205 on the coarse multigrid grids, where every ring runs in the generic kernel):
+//   synthesis side:  pixel u = n_inv t is stored instead of t, and the ring pair's share of c_k = sum_i pm[k][i] u_i goes to parts;
+//   analysis side:   the pixels are read as u_i - sum_k rm[k][i] c_k, c_k = the sum of parts in ring-pair order (bit-reproducible).
+constexpr int kFuseModes = 4;  // monopole + dipole; more template modes take the separate projection kernels
+struct NinvProj {
+    const double *n_inv = nullptr;  // [npix]; null: plain transform
+    const double *pm = nullptr;     // [nmodes][npix]
+    const double *rm = nullptr;     // [nmodes][npix]
+    double *parts = nullptr;        // [nmodes][nparts]
+    int nmodes = 0, nparts = 0;
+};
+
 // Side streams of a plan: the ring-length classes of one FFT stage are independent kernels of very different sizes
 // (the short-ring ones are latency-bound), so they are forked from the caller's stream and joined back with events.
 struct FftStreams {
@@ -48,8 +61,11 @@ struct FftStreams {
 hipError_t fft_streams_create(FftStreams &fs);
 void fft_streams_destroy(FftStreams &fs);
 
-hipError_t launch_phase2map(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *phase, double *map, hipStream_t st);
-hipError_t launch_map2phase(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *map, double *phase, hipStream_t st);
+hipError_t launch_phase2map(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *phase, double *map, hipStream_t st,
+                            const NinvProj *W = nullptr);
+hipError_t launch_map2phase(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *map, double *phase, hipStream_t st,
+                            const NinvProj *W = nullptr);
+bool fft_all_generic(const DevPlan &P, const DevFFT &F);  // every ring pair runs in the generic kernel: NinvProj can be fused
 hipError_t launch_twiddles(double *tw, int Mtw, hipStream_t st);
 hipError_t launch_bluestein_setup(const DevFFT &F, const int *qlist_dev, int nq, double *chirp, double *filt, hipStream_t st);
 hipError_t launch_bluestein_setup2(const DevFFT &F, const int *qlist_dev, int nq, int Mmax, double *filt2, hipStream_t st);

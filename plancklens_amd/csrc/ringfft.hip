@@ -264,7 +264,7 @@ __global__ void k_twiddles(double2 *tw, int Mtw)
 // multigrid, where one short transform leaves most of the workgroup idle and the chain of barriers is the cost.
 template <int NT, int QMAX, bool B4>
 __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim, int ncomp,
-                                                  const double *__restrict__ phase, double *__restrict__ map, int dbg)
+                                                  const double *__restrict__ phase, double *__restrict__ map, int dbg, NinvProj W)
 {
     extern __shared__ double2 ws[];
     const int ip = pairs[blockIdx.x];  // largest rings first
@@ -357,6 +357,7 @@ __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int
     }
     double *__restrict__ mp = map + (int64_t)comp * P.npix;
     const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
+    double cw[kFuseModes] = {0., 0., 0., 0.};  // NinvProj: this thread's share of the template coefficients
 #pragma unroll
     for (int j2 = 0; j2 < 4; ++j2) {
 #pragma unroll
@@ -364,9 +365,41 @@ __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int
             const int j1 = threadIdx.x + NT * qq;
             if (j1 < q) {
                 const int j = j1 + q * j2;
-                mp[on + j] = acc[j2][qq].x;
-                if (os >= 0) mp[os + j] = acc[j2][qq].y;
+                double xn = acc[j2][qq].x, xs = acc[j2][qq].y;
+                if (W.n_inv) {
+                    xn *= W.n_inv[on + j];
+                    if (os >= 0) xs *= W.n_inv[os + j];
+#pragma unroll
+                    for (int k = 0; k < kFuseModes; ++k) {
+                        if (k < W.nmodes) {
+                            cw[k] = fma(W.pm[(int64_t)k * P.npix + on + j], xn, cw[k]);
+                            if (os >= 0) cw[k] = fma(W.pm[(int64_t)k * P.npix + os + j], xs, cw[k]);
+                        }
+                    }
+                }
+                mp[on + j] = xn;
+                if (os >= 0) mp[os + j] = xs;
             }
+        }
+    }
+    if (W.n_inv && W.nmodes > 0) {  // wave-uniform: the ring pair's partial sums, reduced in a fixed order
+        __syncthreads();  // the FFT workspace is free now
+        double *red = reinterpret_cast<double *>(ws);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < kFuseModes; ++k) {
+            if (k < W.nmodes) {
+                double v = cw[k];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                if (lane == 0) red[k * (NT / 64) + wave] = v;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < W.nmodes) {
+            double v = 0.0;
+            for (int w = 0; w < NT / 64; ++w) v += red[threadIdx.x * (NT / 64) + w];
+            W.parts[threadIdx.x * W.nparts + blockIdx.x] = v;
         }
     }
 }
@@ -376,9 +409,21 @@ __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int
 // -----------------------------------------------------------------------------------------------------
 template <int NT, int QMAX, bool B4>
 __global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim, int ncomp,
-                                                  const double *__restrict__ map, double *__restrict__ phase)
+                                                  const double *__restrict__ map, double *__restrict__ phase, NinvProj W)
 {
     extern __shared__ double2 ws[];
+    __shared__ double cproj[kFuseModes];
+    if (W.rm) {  // NinvProj: template coefficients = the partial sums of the synthesis side in ring-pair order
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int k = wave; k < W.nmodes; k += NT / 64) {
+            double v = 0.0;
+            for (int j = lane; j < W.nparts; j += 64) v += W.parts[k * W.nparts + j];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) cproj[k] = v;
+        }
+        __syncthreads();
+    }
     const int ip = pairs[blockIdx.x];
     const int comp = blockIdx.y;
     const int n = P.nphi[ip], q = n >> 2;
@@ -409,8 +454,15 @@ __global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int
             double2 v = make_double2(0., 0.);
             if (j1 < q) {
                 const int j = j1 + q * j2;
-                v.x = mp[on + j];
-                v.y = has_s ? -mp[os + j] : 0.0;
+                double xn = mp[on + j], xs = has_s ? mp[os + j] : 0.0;
+                if (W.rm) {
+                    for (int k = 0; k < W.nmodes; ++k) {
+                        xn = fma(-W.rm[(int64_t)k * P.npix + on + j], cproj[k], xn);
+                        if (has_s) xs = fma(-W.rm[(int64_t)k * P.npix + os + j], cproj[k], xs);
+                    }
+                }
+                v.x = xn;
+                v.y = -xs;
             }
             zc[j2][qq] = v;
         }
@@ -896,7 +948,7 @@ static size_t fft_lds_bytes(const DevFFT &F) { return (size_t)(F.Lmax + F.twl_ca
 
 template <int NT, int QMAX>
 static hipError_t launch_p2m(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *phase, double *map,
-                             hipStream_t st)
+                             hipStream_t st, const NinvProj &W)
 {
     if (F.A.legacy_n == 0) return hipSuccess;
     static int dbg = getenv("PLSHTS_FFTDBG") ? atoi(getenv("PLSHTS_FFTDBG")) : 0;
@@ -904,7 +956,7 @@ static hipError_t launch_p2m(const DevPlan &P, const DevFFT &F, const int *mlim,
     const size_t lds4 = (size_t)(4 * F.Lmax + F.twl_cap) * sizeof(double2);
     if (!no_b4 && lds4 <= 48 * 1024) {  // short transforms (coarse grids): the four sub-DFTs side by side
         hipLaunchKernelGGL((k_phase2map<NT, QMAX, true>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds4, st, P, F, F.A.legacy_pairs, mlim, ncomp,
-                           phase, map, dbg);
+                           phase, map, dbg, W);
         return hipGetLastError();
     }
     const size_t lds = fft_lds_bytes(F);
@@ -917,20 +969,20 @@ static hipError_t launch_p2m(const DevPlan &P, const DevFFT &F, const int *mlim,
         attr_done[dv] = true;
     }
     hipLaunchKernelGGL((k_phase2map<NT, QMAX, false>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds, st, P, F, F.A.legacy_pairs, mlim, ncomp, phase,
-                       map, dbg);
+                       map, dbg, W);
     return hipGetLastError();
 }
 
 template <int NT, int QMAX>
 static hipError_t launch_m2p(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *map, double *phase,
-                             hipStream_t st)
+                             hipStream_t st, const NinvProj &W)
 {
     if (F.A.legacy_n == 0) return hipSuccess;
     static const bool no_b4 = getenv("PLSHTS_FFT_NOB4") && atoi(getenv("PLSHTS_FFT_NOB4")) != 0;
     const size_t lds4 = (size_t)(4 * F.Lmax + F.twl_cap) * sizeof(double2);
     if (!no_b4 && lds4 <= 48 * 1024) {  // short transforms (coarse grids): the four sub-DFTs side by side
         hipLaunchKernelGGL((k_map2phase<NT, QMAX, true>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds4, st, P, F, F.A.legacy_pairs, mlim, ncomp,
-                           map, phase);
+                           map, phase, W);
         return hipGetLastError();
     }
     const size_t lds = fft_lds_bytes(F);
@@ -943,7 +995,7 @@ static hipError_t launch_m2p(const DevPlan &P, const DevFFT &F, const int *mlim,
         attr_done[dv] = true;
     }
     hipLaunchKernelGGL((k_map2phase<NT, QMAX, false>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds, st, P, F, F.A.legacy_pairs, mlim, ncomp, map,
-                       phase);
+                       phase, W);
     return hipGetLastError();
 }
 
@@ -960,15 +1012,15 @@ static hipError_t launch_m2p(const DevPlan &P, const DevFFT &F, const int *mlim,
     } while (0)
 
 static hipError_t launch_phase2map_legacy(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *phase, double *map,
-                                          hipStream_t st)
+                                          hipStream_t st, const NinvProj &W)
 {
-    PL_FFT_DISPATCH(launch_p2m, P, F, mlim, ncomp, phase, map, st);
+    PL_FFT_DISPATCH(launch_p2m, P, F, mlim, ncomp, phase, map, st, W);
 }
 
 static hipError_t launch_map2phase_legacy(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *map, double *phase,
-                                          hipStream_t st)
+                                          hipStream_t st, const NinvProj &W)
 {
-    PL_FFT_DISPATCH(launch_m2p, P, F, mlim, ncomp, map, phase, st);
+    PL_FFT_DISPATCH(launch_m2p, P, F, mlim, ncomp, map, phase, st, W);
 }
 
 template <int N, bool BLUE>
@@ -1020,7 +1072,7 @@ void fft_streams_destroy(FftStreams &fs)
 // One FFT stage = up to six independent kernels (five register classes + the generic kernel).  The biggest one runs on
 // the caller's stream, the others on the plan's side streams between a fork and a join event.
 static hipError_t launch_stage(const DevPlan &P, const DevFFT &F, const FftStreams &fs, bool synth, const int *mlim, int ncomp,
-                               const double *in, double *out, hipStream_t st)
+                               const double *in, double *out, hipStream_t st, const NinvProj &W)
 {
     const bool par = fs.ok && !(getenv("PLSHTS_FFT_SERIAL") && atoi(getenv("PLSHTS_FFT_SERIAL")) != 0);
     // work items: (class c, Bluestein or direct); the one with the most work stays on the caller's stream
@@ -1063,7 +1115,7 @@ static hipError_t launch_stage(const DevPlan &P, const DevFFT &F, const FftStrea
     for (int w = 9; w >= 0 && e == hipSuccess; --w) e = run(w);  // longest transforms first
     if (e == hipSuccess && F.A.legacy_n > 0) {
         hipStream_t s = big < 0 ? st : side(-1);
-        e = synth ? launch_phase2map_legacy(P, F, mlim, ncomp, in, out, s) : launch_map2phase_legacy(P, F, mlim, ncomp, in, out, s);
+        e = synth ? launch_phase2map_legacy(P, F, mlim, ncomp, in, out, s, W) : launch_map2phase_legacy(P, F, mlim, ncomp, in, out, s, W);
     }
     for (int i = 0; i < FftStreams::kN; ++i) {
         if (!joined[i]) continue;
@@ -1074,16 +1126,20 @@ static hipError_t launch_stage(const DevPlan &P, const DevFFT &F, const FftStrea
     return e;
 }
 
+bool fft_all_generic(const DevPlan &P, const DevFFT &F) { return F.A.legacy_n == P.npairs; }
+
 hipError_t launch_phase2map(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *phase,
-                            double *map, hipStream_t st)
+                            double *map, hipStream_t st, const NinvProj *W)
 {
-    return launch_stage(P, F, fs, true, mlim, ncomp, phase, map, st);
+    if (W && W->n_inv && !(fft_all_generic(P, F) && ncomp == 1 && W->nmodes <= kFuseModes && W->nparts >= F.A.legacy_n)) return hipErrorInvalidValue;
+    return launch_stage(P, F, fs, true, mlim, ncomp, phase, map, st, W ? *W : NinvProj());
 }
 
 hipError_t launch_map2phase(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *map,
-                            double *phase, hipStream_t st)
+                            double *phase, hipStream_t st, const NinvProj *W)
 {
-    return launch_stage(P, F, fs, false, mlim, ncomp, map, phase, st);
+    if (W && W->rm && !(fft_all_generic(P, F) && ncomp == 1 && W->nmodes <= kFuseModes && W->nparts >= F.A.legacy_n)) return hipErrorInvalidValue;
+    return launch_stage(P, F, fs, false, mlim, ncomp, map, phase, st, W ? *W : NinvProj());
 }
 
 hipError_t launch_twiddles(double *tw, int Mtw, hipStream_t st)

@@ -241,17 +241,22 @@ TEMPLATE_MAX_MODES = 16  # PL_TEMPLATE_MAX_MODES of include/plshts.h
 _TPROJ_SCRATCH = {}
 
 
-def template_project(tmap, n_inv, pmat, rmat):
-    """tmap <- n_inv tmap - rmat^t (pmat (n_inv tmap)) in place, two launches (pl_template_project); pmat, rmat: (nmodes, npix)."""
-    nmodes, npix = pmat.shape
-    assert rmat.shape == pmat.shape and tmap.numel() == npix and n_inv.numel() == npix and pmat.is_contiguous() and rmat.is_contiguous()
+def tproj_scratch():
+    """the per-device scratch of pl_template_project / pl_cg_fwd_tt"""
     d = torch.cuda.current_device()
     if d not in _TPROJ_SCRATCH:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError('template-projection scratch requested while a HIP graph is being captured')
         _TPROJ_SCRATCH[d] = torch.empty(TEMPLATE_MAX_MODES * 256, dtype=torch.float64, device=device())
+    return _TPROJ_SCRATCH[d]
+
+
+def template_project(tmap, n_inv, pmat, rmat):
+    """tmap <- n_inv tmap - rmat^t (pmat (n_inv tmap)) in place, two launches (pl_template_project); pmat, rmat: (nmodes, npix)."""
+    nmodes, npix = pmat.shape
+    assert rmat.shape == pmat.shape and tmap.numel() == npix and n_inv.numel() == npix and pmat.is_contiguous() and rmat.is_contiguous()
     _lib.check(_lib.lib().pl_template_project(npix, nmodes, tmap.data_ptr(), n_inv.data_ptr(), pmat.data_ptr(), rmat.data_ptr(),
-                                             _TPROJ_SCRATCH[d].data_ptr(), stream_ptr()))
+                                             tproj_scratch().data_ptr(), stream_ptr()))
     return tmap
 
 

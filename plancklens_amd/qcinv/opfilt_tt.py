@@ -73,7 +73,10 @@ class fwd_op(object):
         return self.calc(talm)
 
     def calc(self, talm):
-        alm = self.n_inv_filt.apply_alm_new(talm)
+        f = self.n_inv_filt
+        if isinstance(f, alm_filter_ninv) and f.one_call_ok(talm):  # the whole operator in pl_cg_fwd_tt
+            return f.apply_alm_new(talm, alm_add=talm, fl_add=self.cltt_inv)
+        alm = f.apply_alm_new(talm)
         return dev.almxfl_add(alm, talm, self.cltt_inv, out=alm)
 
 
@@ -168,33 +171,50 @@ class alm_filter_ninv(object):
         """alm <- B^t Y^t N^-1 Y B alm (in place)."""
         alm.copy_(self.apply_alm_new(alm))
 
-    def apply_alm_new(self, alm):
-        """B^t Y^t N^-1 Y B alm as a new array (the input is left alone)."""
+    def one_call_ok(self, alm):
+        """pl_cg_fwd_tt applies: device input, the module's transforms not replaced, few enough template modes."""
+        nmodes = sum(t.nmodes for t in self.templates)
+        return (isinstance(alm, torch.Tensor) and alm.is_cuda and alm2map is shts.alm2map and map2alm is shts.map2alm and not shts.lane_active()
+                and nmodes <= dev.TEMPLATE_MAX_MODES)
+
+    def apply_alm_new(self, alm, alm_add=None, fl_add=None):
+        """B^t Y^t N^-1 Y B alm (+ fl_add alm_add) as a new array (the input is left alone)."""
         lmax = hp.Alm.getlmax(alm.numel())
+        fl_out = self.b_transf * (self.npix / (4. * np.pi))
+        if self.one_call_ok(alm):
+            pmat, rmat = self._proj_matrices()
+            return shts.cg_fwd_tt(alm, self.nside, lmax, self.n_inv, fl_in=self.b_transf, fl_out=fl_out, pmat=pmat, rmat=rmat,
+                                  scratch=dev.tproj_scratch() if pmat is not None else None, alm_add=alm_add, fl_add=fl_add)
         tmap = alm2map(alm, self.nside, lmax=lmax, fl=self.b_transf)
         self.apply_map(tmap)
-        return map2alm(tmap, lmax=lmax, iter=0, fl=self.b_transf * (self.npix / (4. * np.pi)))
+        ret = map2alm(tmap, lmax=lmax, iter=0, fl=fl_out)
+        return ret if alm_add is None else dev.almxfl_add(ret, alm_add, fl_add, out=ret)
+
+    def _proj_matrices(self):
+        """All template modes as one device matrix P (nmodes x npix) and R = (P^t N^-1 P)^-1 P^t N^-1: the projection is two
+        mat-vecs, c = P^t (N^-1 t) and t -= R^t c; coefficients, the small solve and the projected map are device operations,
+        nothing comes back to the host inside a CG iteration."""
+        if len(self.templates) == 0:
+            return None, None
+        if getattr(self, '_pmat', None) is None:
+            rows = []
+            for t in self.templates:
+                for i in range(t.nmodes):
+                    row = torch.ones_like(self.n_inv)
+                    t.apply_mode(row, i)
+                    rows.append(row)
+            self._pmat = torch.stack(rows).contiguous()
+            pinv = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64)
+            self._rmat = torch.mm(pinv, self._pmat * self.n_inv.unsqueeze(0)).contiguous()
+        return self._pmat, self._rmat
 
     def apply_map(self, tmap):
         """tmap <- N^-1 tmap with the templates projected out (in place)."""
-        if len(self.templates) == 0:
+        pmat, rmat = self._proj_matrices()
+        if pmat is None:
             tmap *= self.n_inv
+        elif pmat.shape[0] <= dev.TEMPLATE_MAX_MODES and tmap.is_contiguous():
+            dev.template_project(tmap, self.n_inv, pmat, rmat)  # N^-1 weighting + projection, two launches
         else:
-            # all template modes as one device matrix P (nmodes x npix): coefficients, the small solve and the projected
-            # map are device operations, nothing comes back to the host inside a CG iteration
-            if getattr(self, '_pmat', None) is None:
-                rows = []
-                for t in self.templates:
-                    for i in range(t.nmodes):
-                        row = torch.ones_like(tmap)
-                        t.apply_mode(row, i)
-                        rows.append(row)
-                self._pmat = torch.stack(rows)
-                pinv = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64)
-                # N^-1 P (P^t N^-1 P)^-1 as one matrix: the projection is two mat-vecs, c = P^t t and t -= R^t c
-                self._rmat = torch.mm(pinv, self._pmat * self.n_inv.unsqueeze(0))
-            if self._pmat.shape[0] <= dev.TEMPLATE_MAX_MODES and tmap.is_contiguous():
-                dev.template_project(tmap, self.n_inv, self._pmat, self._rmat)  # N^-1 weighting + projection, two launches
-            else:
-                tmap *= self.n_inv
-                tmap.addmv_(self._rmat.t(), dev.gemv(self._pmat, tmap), alpha=-1.0)  # more modes than pl_template_project takes
+            tmap *= self.n_inv
+            tmap.addmv_(rmat.t(), dev.gemv(pmat, tmap), alpha=-1.0)  # more modes than pl_template_project takes

@@ -236,6 +236,31 @@ def _synth(spin, alm, nside, lmax, fl=None, grad_only=False):
     return out
 
 
+def lane_active():
+    """True inside a `lane` context: transforms are split over two streams there, and the one-call operators are not used."""
+    return _lane_active()
+
+
+def cg_fwd_tt(alm, nside, lmax, n_inv, fl_in=None, fl_out=None, pmat=None, rmat=None, scratch=None, alm_add=None, fl_add=None):
+    """fl_out Y^t [N^-1 - N^-1 P (P^t N^-1 P)^-1 P^t N^-1] Y (fl_in alm) + fl_add alm_add on the device, one call (pl_cg_fwd_tt):
+    fwd_op.calc of plancklens/qcinv/opfilt_tt.py:67-73.  pmat, rmat: (nmodes, npix) device matrices or None."""
+    plan = get_plan(nside, lmax)
+    a = alm.to(torch.complex128).contiguous()
+    assert a.numel() == plan.nalm and n_inv.numel() == plan.npix and n_inv.is_contiguous(), (a.shape, plan.nalm)
+    nmodes = 0 if pmat is None else pmat.shape[0]
+    if nmodes:
+        assert pmat.shape == (nmodes, plan.npix) and rmat.shape == pmat.shape and pmat.is_contiguous() and rmat.is_contiguous()
+    out = torch.empty(plan.nalm, dtype=torch.complex128, device=a.device)
+    fi, fo = _fl_arg(fl_in, lmax, True), _fl_arg(fl_out, lmax, True)
+    fa = _fl_arg(fl_add, lmax, True) if alm_add is not None else None
+    if alm_add is not None:
+        alm_add = alm_add.contiguous()
+        assert alm_add.numel() == plan.nalm and alm_add.dtype == torch.complex128
+    _lib.check(_lib.lib().pl_cg_fwd_tt(plan.h, _ptr(a), _ptr(fi), _ptr(n_inv), nmodes, _ptr(pmat), _ptr(rmat), _ptr(scratch), _ptr(alm_add),
+                                       _ptr(fa), _ptr(out), _ptr(fo), _stream()))
+    return out
+
+
 def _anal(spin, maps, lmax, fl=None):
     dev = _is_dev(maps)
     ncomp = 1 if spin == 0 else 2

@@ -244,3 +244,36 @@ np.save(os.path.join(tmp, 'eps_%%s.npy' %% os.environ.get('PLENS_CG_GRAPH', '1')
     ea, eb = np.load(tmp_path / 'eps_0.npy'), np.load(tmp_path / 'eps_1.npy')
     if ea.size and eb.size:  # residual norms are only evaluated when the top level logs them
         assert ea[-1] < 1e-2 * ea[0] and np.allclose(ea, eb, rtol=1e-6)
+
+
+@pytest.mark.parametrize('nside,lmax,marge', [(32, 64, 'md'), (128, 256, 'md'), (256, 400, 'm'), (256, 512, ''), (512, 700, 'md'), (64, 100, 'maps')])
+def test_tt_one_call_operator(nside, lmax, marge):
+    """pl_cg_fwd_tt (weighting and projection inside the ring-FFT launches on the all-generic grids, nside <= 256 here; the separate
+    projection launches above) against the operator assembled from alm2map / apply_map / map2alm / almxfl_add."""
+    import torch
+    from plancklens_amd import dev, hp, shts
+    from plancklens_amd.qcinv import opfilt_tt
+    rng = np.random.default_rng(nside + lmax)
+    npix = 12 * nside ** 2
+    ninv = rng.uniform(0.5, 1.5, npix) * (rng.uniform(size=npix) > 0.2)
+    maps = [rng.standard_normal(npix) for _ in range(6)] if marge == 'maps' else []
+    bl = hp.gauss_beam(np.radians(0.3), lmax=lmax)
+    nf = opfilt_tt.alm_filter_ninv(ninv, bl, marge_monopole='m' in marge and marge != 'maps', marge_dipole='d' in marge, marge_maps=maps)
+    cl = {'tt': 1e3 / (np.arange(lmax + 1) + 10.) ** 2}
+    cl['tt'][:2] = 0.
+    x = rng.standard_normal(hp.Alm.getsize(lmax)) + 1j * rng.standard_normal(hp.Alm.getsize(lmax))
+    x[:lmax + 1] = x[:lmax + 1].real
+    x = dev.to_dev(x)
+    x0 = x.clone()
+    op = opfilt_tt.fwd_op(cl, nf)
+    assert nf.one_call_ok(x)
+    got = op(x)
+    tmap = shts.alm2map(x, nside, lmax=lmax, fl=bl)
+    nf.apply_map(tmap)
+    ref = shts.map2alm(tmap, lmax=lmax, iter=0, fl=bl * (npix / (4. * np.pi)))
+    ref = dev.almxfl_add(ref, x, op.cltt_inv)
+    assert bool((x == x0).all())
+    assert relrms(dev.to_host(got), dev.to_host(ref)) < 1e-13
+    assert bool((op(x) == got).all())  # bit-reproducible
+    got2 = nf.apply_alm_new(x)  # without the S^-1 term
+    assert relrms(dev.to_host(got2), dev.to_host(shts.map2alm(tmap, lmax=lmax, iter=0, fl=bl * (npix / (4. * np.pi))))) < 1e-13
