@@ -119,8 +119,11 @@ def read_bintable(fname, hdu=1):
             tf = str(hdr['TFORM%d' % i]).strip()
             code = tf[-1]
             rep = int(tf[:-1]) if tf[:-1] else 1
-            dt = {'J': '>i4', 'K': '>i8', 'E': '>f4', 'D': '>f8', 'I': '>i2', 'B': 'u1'}[code]
             name = str(hdr.get('TTYPE%d' % i, 'col%d' % i)).strip()
+            if code == 'A':  # character field of `rep` bytes
+                fields.append((name, 'S%d' % rep))
+                continue
+            dt = {'J': '>i4', 'K': '>i8', 'E': '>f4', 'D': '>f8', 'I': '>i2', 'B': 'u1', 'L': 'S1'}[code]
             fields.append((name, dt, (rep,)) if rep > 1 else (name, dt))
         rec = np.frombuffer(f.read(hdr['NAXIS1'] * hdr['NAXIS2']), dtype=np.dtype(fields), count=hdr['NAXIS2'])
     return {n: np.ascontiguousarray(rec[n]) for n in rec.dtype.names}, hdr

@@ -102,3 +102,21 @@ def test_bench_cpu_baseline_leg_runs_on_the_host():
         assert k in r
     assert r['kind'] == 'port' and r['value'] > 0 and r['cores'] == n and r['extrapolated_from_ring_stride'] == 1
     assert bench.executed_flops(64, 64, 2) <= 24. * (65 * 66 // 2) * 128 and bench.executed_flops(64, 64, 0) > 0
+
+
+def test_fits_reader_on_a_file_written_elsewhere():
+    """The FITS reader against a binary table that this repository did not write: the STSDAS-written table shipped with
+    numpy's test data (three rows of 1D, 1J, 5A columns), decoded independently by np.rec.fromfile as numpy's own test does."""
+    import numpy
+    from plancklens_amd import fitsio
+    fname = os.path.join(os.path.dirname(numpy.__file__), '_core', 'tests', 'data', 'recarray_from_file.fits')
+    if not os.path.exists(fname):
+        pytest.skip('numpy test data not installed')
+    cols, hdr = fitsio.read_bintable(fname)
+    with open(fname, 'rb') as fd:
+        fd.seek(2880 * 2)
+        ref = np.rec.fromfile(fd, formats='f8,i4,S5', shape=3, byteorder='big')
+    assert hdr['TFIELDS'] == 3 and hdr['NAXIS2'] == 3 and hdr['TFORM3'] == '5A'
+    assert np.array_equal(cols['a'], ref['f0']) and np.allclose(cols['a'], [5.1, 5.2, 5.3])
+    assert np.array_equal(cols['b'], ref['f1']) and list(cols['b']) == [61, 62, 63]
+    assert [c.decode().strip() for c in cols['c']] == ['abcde', 'fghij', 'kl']
