@@ -269,13 +269,13 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
     F.Mtw = Lmax < 2 ? 2 : Lmax;
     if (F.Mtw < M2max) F.Mtw = M2max;
     for (int c = 0; c < kFftClasses; ++c) if ((!listA[c].empty() || !dirA[c].empty()) && F.Mtw < (256 << c)) F.Mtw = 256 << c;
-    if ((size_t)Lmax * 16 > 160 * 1024) { pl_plan_destroy(p); return fail("ring FFT workspace exceeds the 160 KiB LDS of a CU"); }
+    if ((size_t)Lmax * 16 > 160 * 1024 - 256) { pl_plan_destroy(p); return fail("ring FFT workspace exceeds the 160 KiB LDS of a CU"); }
     {   // LDS twiddle tables of the largest generic transform (radix-8 passes + one radix-4/2 tail), if they fit beside it
         int k = 0; while ((1 << k) < Lmax) ++k;
         const int rt = (k % 3 == 0) ? 8 : (k % 3 == 2 ? 4 : 2);
         int tot = (rt == 8 ? 3 : rt == 4 ? 2 : 1);
         for (int64_t L = (int64_t)rt * 8; L <= Lmax; L *= 8) tot += 3 * (int)(L / 8);
-        F.twl_cap = ((size_t)(Lmax + tot) * 16 <= 160 * 1024) ? tot : 0;
+        F.twl_cap = ((size_t)(Lmax + tot) * 16 <= 160 * 1024 - 256) ? tot : 0;
     }
     double *tw = nullptr, *chirp = nullptr, *filt = nullptr, *filtA = nullptr;
     const int *qlist_dev = nullptr, *qlistA_dev = nullptr;

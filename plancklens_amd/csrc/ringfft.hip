@@ -944,6 +944,10 @@ static int current_device()
     return d;
 }
 
+// dynamic LDS ceiling of the generic kernels: the CU's 160 KiB less their static allocations (k_map2phase keeps the template coefficients there)
+static constexpr int kGenericMaxLds = 160 * 1024 - 256;
+// largest LDS footprint for which the generic kernel transforms the four sub-DFTs of a ring side by side (PLSHTS_FFT_B4_KB overrides)
+static const size_t kB4MaxLds = getenv("PLSHTS_FFT_B4_KB") ? (size_t)atoi(getenv("PLSHTS_FFT_B4_KB")) * 1024 : (size_t)kGenericMaxLds;
 static size_t fft_lds_bytes(const DevFFT &F) { return (size_t)(F.Lmax + F.twl_cap) * sizeof(double2); }
 
 template <int NT, int QMAX>
@@ -954,7 +958,15 @@ static hipError_t launch_p2m(const DevPlan &P, const DevFFT &F, const int *mlim,
     static int dbg = getenv("PLSHTS_FFTDBG") ? atoi(getenv("PLSHTS_FFTDBG")) : 0;
     static const bool no_b4 = getenv("PLSHTS_FFT_NOB4") && atoi(getenv("PLSHTS_FFT_NOB4")) != 0;
     const size_t lds4 = (size_t)(4 * F.Lmax + F.twl_cap) * sizeof(double2);
-    if (!no_b4 && lds4 <= 48 * 1024) {  // short transforms (coarse grids): the four sub-DFTs side by side
+    if (!no_b4 && lds4 <= kB4MaxLds) {  // short transforms (coarse grids, short cap rings): the four sub-DFTs side by side
+        static bool attr4_done[kMaxDevices] = {};
+        const int dv4 = current_device();
+        if (!attr4_done[dv4] && lds4 > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map<NT, QMAX, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kGenericMaxLds);
+            if (e != hipSuccess) return e;
+            attr4_done[dv4] = true;
+        }
         hipLaunchKernelGGL((k_phase2map<NT, QMAX, true>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds4, st, P, F, F.A.legacy_pairs, mlim, ncomp,
                            phase, map, dbg, W);
         return hipGetLastError();
@@ -964,7 +976,7 @@ static hipError_t launch_p2m(const DevPlan &P, const DevFFT &F, const int *mlim,
     const int dv = current_device();
     if (!attr_done[dv] && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map<NT, QMAX, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kGenericMaxLds);
         if (e != hipSuccess) return e;
         attr_done[dv] = true;
     }
@@ -980,7 +992,15 @@ static hipError_t launch_m2p(const DevPlan &P, const DevFFT &F, const int *mlim,
     if (F.A.legacy_n == 0) return hipSuccess;
     static const bool no_b4 = getenv("PLSHTS_FFT_NOB4") && atoi(getenv("PLSHTS_FFT_NOB4")) != 0;
     const size_t lds4 = (size_t)(4 * F.Lmax + F.twl_cap) * sizeof(double2);
-    if (!no_b4 && lds4 <= 48 * 1024) {  // short transforms (coarse grids): the four sub-DFTs side by side
+    if (!no_b4 && lds4 <= kB4MaxLds) {  // short transforms (coarse grids, short cap rings): the four sub-DFTs side by side
+        static bool attr4_done[kMaxDevices] = {};
+        const int dv4 = current_device();
+        if (!attr4_done[dv4] && lds4 > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_map2phase<NT, QMAX, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kGenericMaxLds);
+            if (e != hipSuccess) return e;
+            attr4_done[dv4] = true;
+        }
         hipLaunchKernelGGL((k_map2phase<NT, QMAX, true>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds4, st, P, F, F.A.legacy_pairs, mlim, ncomp,
                            map, phase, W);
         return hipGetLastError();
@@ -990,7 +1010,7 @@ static hipError_t launch_m2p(const DevPlan &P, const DevFFT &F, const int *mlim,
     const int dv = current_device();
     if (!attr_done[dv] && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_map2phase<NT, QMAX, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kGenericMaxLds);
         if (e != hipSuccess) return e;
         attr_done[dv] = true;
     }
@@ -1154,7 +1174,7 @@ hipError_t launch_bluestein_setup(const DevFFT &F, const int *qlist_dev, int nq,
     const size_t lds = fft_lds_bytes(F);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bluestein_setup<256>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kGenericMaxLds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_bluestein_setup<256>, dim3(nq), dim3(256), lds, st, F, qlist_dev, reinterpret_cast<double2 *>(chirp),
@@ -1168,7 +1188,7 @@ hipError_t launch_bluestein_setup2(const DevFFT &F, const int *qlist_dev, int nq
     const size_t lds = (size_t)Mmax * sizeof(double2);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bluestein_setup2<256>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kGenericMaxLds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_bluestein_setup2<256>, dim3(nq), dim3(256), lds, st, F, qlist_dev, reinterpret_cast<double2 *>(filt2));
