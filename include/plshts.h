@@ -140,6 +140,13 @@ int pl_almxfl_add(int lmax, const double *a, const double *b, const double *fl, 
 int pl_cg_fwd_tt(pl_plan *plan, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *pmat,
                  const double *rmat, double *scratch_dev, const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out,
                  void *stream);
+/* The polarization counterpart (fwd_op.calc, opfilt_pp.py:69-78 with apply_alm :190-205 and the one-map apply_map :207-215):
+ *   (E, B)_out = fl_out * Y2^t [n_inv * Y2 (fl_in * (E, B)_in)]  +  (fl_add_e * E_add, fl_add_b * B_add),
+ * E and B as separate arrays of nalm complex numbers, n_inv the single inverse-noise map shared by Q and U; the weighting rides in the
+ * synthesis-side ring-FFT launches, the add terms in the post-processing of the analysis.  elm_add / blm_add may both be null. */
+int pl_cg_fwd_pp(pl_plan *plan, const double *elm_in, const double *blm_in, const double *fl_in, const double *n_inv, const double *elm_add,
+                 const double *blm_add, const double *fl_add_e, const double *fl_add_b, double *elm_out, double *blm_out,
+                 const double *fl_out, void *stream);
 
 /* y = A x, A row-major nrows x ncols with leading dimension lda, all device arrays (x and y must not overlap): the dense
  * low-l preconditioner of the CG chains applied as one mat-vec (dense.py:118-119,201-202,284-285), and the template

@@ -24,6 +24,10 @@ void launch_anal0(const DevPlan &P, const double *phase, double *partial, const 
                   const double *add = nullptr, const double *fl_add = nullptr);
 void launch_anals(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
                   const double *fl, double *alm, hipStream_t st);
+void launch_anals_gc(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial, const double *fl,
+                     double *almG, double *almC, hipStream_t st, const double *addG, const double *addC, const double *flG, const double *flC);
+void launch_preps_gc(const DevPlan &P, const DevSpinTab &S, int spin, const double *almG, const double *almC, const double *fl, double *prep,
+                     hipStream_t st);
 void launch_almxfl(int lmax, const double *in, const double *fl, int nfl, double *out, hipStream_t st);
 void launch_alm_copy(int lmax_in, const double *in, int lmax_out, double *out, hipStream_t st);
 void launch_alm2cl(int lmax, const double *a, const double *b, double *cl, hipStream_t st);
@@ -632,7 +636,7 @@ int pl_cg_fwd_tt(pl_plan *p, const double *alm_in, const double *fl_in, const do
     const DevPlan &P = p->P;
     if (grow(p, &p->phase, &p->phase_cap, pl_plan_phase_doubles(p, 0)) || grow(p, &p->wmap, &p->wmap_cap, P.npix)) return 1;
     if (legendre_synth_impl(p, 0, alm_in, fl_in, p->phase, stream, false)) return 1;
-    const bool fused = fft_all_generic(P, p->F) && nmodes <= kFuseModes;
+    const bool fused = nmodes == 0 || (fft_all_generic(P, p->F) && nmodes <= kFuseModes);
     NinvProj W;
     if (fused) {
         if (nmodes > 0 && grow(p, &p->tparts, &p->tparts_cap, (int64_t)nmodes * P.npairs)) return 1;
@@ -656,6 +660,49 @@ int pl_cg_fwd_tt(pl_plan *p, const double *alm_in, const double *fl_in, const do
     const int ngroups = (P.npairs + RG - 1) / RG;
     if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * P.nent0 * 4)) return 1;
     { ProfScope ps(p, PK_LEG_ANAL0, st); launch_anal0(P, p->phase, p->partial, fl_out, alm_out, st, alm_add, fl_add); }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// The polarization CG operator (fwd_op.calc, plancklens/qcinv/opfilt_pp.py:69-78, apply_alm :190-205 with the single-map apply_map
+// :207-215): (E, B)_out = fl_out * Y2^t [n_inv * Y2 (fl_in * (E, B)_in)] + (fl_add_e E_add, fl_add_b B_add).  E and B are separate arrays.
+// The weighting rides in the synthesis-side ring-FFT launches (every kernel class), the add terms in k_posts.
+int pl_cg_fwd_pp(pl_plan *p, const double *elm_in, const double *blm_in, const double *fl_in, const double *n_inv, const double *elm_add,
+                 const double *blm_add, const double *fl_add_e, const double *fl_add_b, double *elm_out, double *blm_out, const double *fl_out,
+                 void *stream)
+{
+    if (!p) return fail("null plan");
+    if (!elm_in || !blm_in || !elm_out || !blm_out || !n_inv) return fail("pl_cg_fwd_pp: null alm / n_inv pointer");
+    if ((elm_add == nullptr) != (blm_add == nullptr) || (elm_add && (!fl_add_e || !fl_add_b)))
+        return fail("pl_cg_fwd_pp: elm_add, blm_add, fl_add_e and fl_add_b come together");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const DevPlan &P = p->P;
+    const int spin = 2;
+    if (ensure_spin(p, spin)) return 1;
+    if (grow(p, &p->phase, &p->phase_cap, pl_plan_phase_doubles(p, spin)) || grow(p, &p->wmap, &p->wmap_cap, 2 * P.npix) ||
+        grow(p, &p->prep, &p->prep_cap, p->nent[spin] * 4))
+        return 1;
+    launch_preps_gc(P, p->S[spin], spin, elm_in, blm_in, fl_in, p->prep, st);
+    { ProfScope ps(p, PK_LEG_SYNTHS, st); launch_synths(P, p->S[spin], spin, p->prep, p->phase, st, false); }
+    HIPCHK(hipGetLastError());
+    NinvProj W;
+    W.n_inv = n_inv;
+    {
+        ProfScope ps(p, PK_FFT_SYNTH, st);
+        HIPCHK(launch_phase2map(P, p->F, p->fs, mlim_of(p, spin), 2, p->phase, p->wmap, st, &W));
+    }
+    {
+        ProfScope ps(p, PK_FFT_ANAL, st);
+        HIPCHK(launch_map2phase(P, p->F, p->fs, mlim_of(p, spin), 2, p->wmap, p->phase, st));
+    }
+    const int RG = rings_per_group(spin, P);
+    const int ngroups = (P.npairs + RG - 1) / RG;
+    if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * p->nent[spin] * 4)) return 1;
+    {
+        ProfScope ps(p, PK_LEG_ANALS, st);
+        launch_anals_gc(P, p->S[spin], spin, p->nent[spin], p->phase, p->partial, fl_out, elm_out, blm_out, st, elm_add, blm_add, fl_add_e,
+                        fl_add_b);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

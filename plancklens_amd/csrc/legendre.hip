@@ -1206,16 +1206,25 @@ __global__ __launch_bounds__(256) PL_ANALS_ATTR void k_leg_anals(DevPlan P, DevS
 }
 
 // G_l = -1/2 beta_l G'_l,  C_l = i/2 beta_l C'_l
+// addG / addC with flG / flC (optional): almG += flG * addG, almC += flC * addC -- the S^-1 x term of the CG operator folded in
 __global__ void k_posts(DevPlan P, DevSpinTab S, int spin, int RG, int64_t nent, const double4 *__restrict__ partial,
-                        const double *__restrict__ fl, double2 *__restrict__ almG, double2 *__restrict__ almC)
+                        const double *__restrict__ fl, double2 *__restrict__ almG, double2 *__restrict__ almC,
+                        const double2 *__restrict__ addG, const double2 *__restrict__ addC, const double *__restrict__ flG,
+                        const double *__restrict__ flC)
 {
     const int m = blockIdx.y;
     const int l0 = m > spin ? m : spin;
     const int64_t abase = (int64_t)m * (2 * P.lmax + 1 - m) / 2;
     // entries below the spin are zero
     for (int l = m + blockIdx.x * blockDim.x + threadIdx.x; l < l0 && l <= P.lmax; l += gridDim.x * blockDim.x) {
-        almG[abase + l] = make_double2(0., 0.);
-        almC[abase + l] = make_double2(0., 0.);
+        double2 g = make_double2(0., 0.), c = g;
+        if (addG) {
+            const double2 tg = addG[abase + l], tc = addC[abase + l];
+            g = make_double2(flG[l] * tg.x, flG[l] * tg.y);
+            c = make_double2(flC[l] * tc.x, flC[l] * tc.y);
+        }
+        almG[abase + l] = g;
+        almC[abase + l] = c;
     }
     const int nl = P.lmax - l0 + 1;
     if (nl <= 0) return;
@@ -1234,8 +1243,15 @@ __global__ void k_posts(DevPlan P, DevSpinTab S, int spin, int RG, int64_t nent,
         const int l = l0 + i;
         double f = 0.5 * S.beta[e];
         if (fl) f *= fl[l];
-        almG[abase + l] = make_double2(-f * gr, -f * gi);   // G = -1/2 beta G'
-        almC[abase + l] = make_double2(-f * ci, f * cr);    // C = i/2 beta C'
+        double2 g = make_double2(-f * gr, -f * gi);   // G = -1/2 beta G'
+        double2 c = make_double2(-f * ci, f * cr);    // C = i/2 beta C'
+        if (addG) {
+            const double2 tg = addG[abase + l], tc = addC[abase + l];
+            g.x = fma(flG[l], tg.x, g.x); g.y = fma(flG[l], tg.y, g.y);
+            c.x = fma(flC[l], tc.x, c.x); c.y = fma(flC[l], tc.y, c.y);
+        }
+        almG[abase + l] = g;
+        almC[abase + l] = c;
     }
 }
 
@@ -1274,11 +1290,18 @@ void launch_prep0(const DevPlan &P, const double *alm, const double *fl, double 
                        reinterpret_cast<double4 *>(prep));
 }
 
-void launch_preps(const DevPlan &P, const DevSpinTab &S, int spin, const double *alm, const double *fl, double *prep, hipStream_t st, bool gonly)
+// gradient and curl coefficients as two arrays (almC null: gradient only)
+void launch_preps_gc(const DevPlan &P, const DevSpinTab &S, int spin, const double *almG, const double *almC, const double *fl, double *prep,
+                     hipStream_t st)
 {
     dim3 grid(4, P.mmax + 1);
-    hipLaunchKernelGGL(k_preps, grid, dim3(256), 0, st, P, S, spin, reinterpret_cast<const double2 *>(alm),
-                       gonly ? nullptr : reinterpret_cast<const double2 *>(alm) + P.nalm, fl, reinterpret_cast<double4 *>(prep));
+    hipLaunchKernelGGL(k_preps, grid, dim3(256), 0, st, P, S, spin, reinterpret_cast<const double2 *>(almG),
+                       reinterpret_cast<const double2 *>(almC), fl, reinterpret_cast<double4 *>(prep));
+}
+
+void launch_preps(const DevPlan &P, const DevSpinTab &S, int spin, const double *alm, const double *fl, double *prep, hipStream_t st, bool gonly)
+{
+    launch_preps_gc(P, S, spin, alm, gonly ? nullptr : alm + 2 * P.nalm, fl, prep, st);
 }
 
 template <int R>
@@ -1387,24 +1410,36 @@ void launch_anal0(const DevPlan &P, const double *phase, double *partial, const 
 
 template <int R>
 static void launch_anals_r(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
-                           const double *fl, double *alm, hipStream_t st)
+                           const double *fl, double *almG, double *almC, hipStream_t st, const double *addG, const double *addC,
+                           const double *flG, const double *flC)
 {
     constexpr int RG = 64 * R;
     const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
     hipLaunchKernelGGL(k_leg_anals<R>, dim3(ngroups * nmg), dim3(256), 0, st, P, S, spin, phase, partial, nent);
     dim3 grid(4, P.mmax + 1);
     hipLaunchKernelGGL(k_posts, grid, dim3(256), 0, st, P, S, spin, RG, nent, reinterpret_cast<const double4 *>(partial), fl,
-                       reinterpret_cast<double2 *>(alm), reinterpret_cast<double2 *>(alm) + P.nalm);
+                       reinterpret_cast<double2 *>(almG), reinterpret_cast<double2 *>(almC), reinterpret_cast<const double2 *>(addG),
+                       reinterpret_cast<const double2 *>(addC), flG, flC);
 }
+
+void launch_anals_gc(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial, const double *fl,
+                     double *almG, double *almC, hipStream_t st, const double *addG, const double *addC, const double *flG, const double *flC);
 
 void launch_anals(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
                   const double *fl, double *alm, hipStream_t st)
 {
+    launch_anals_gc(P, S, spin, nent, phase, partial, fl, alm, alm + 2 * P.nalm, st, nullptr, nullptr, nullptr, nullptr);
+}
+
+// gradient / curl outputs as two arrays, with the optional add terms of k_posts
+void launch_anals_gc(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial, const double *fl,
+                     double *almG, double *almC, hipStream_t st, const double *addG, const double *addC, const double *flG, const double *flC)
+{
     switch (rs_anal(P)) {
-    case 1: launch_anals_r<1>(P, S, spin, nent, phase, partial, fl, alm, st); break;
-    case 2: launch_anals_r<2>(P, S, spin, nent, phase, partial, fl, alm, st); break;
-    case 4: launch_anals_r<4>(P, S, spin, nent, phase, partial, fl, alm, st); break;
-    default: launch_anals_r<3>(P, S, spin, nent, phase, partial, fl, alm, st); break;
+    case 1: launch_anals_r<1>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC); break;
+    case 2: launch_anals_r<2>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC); break;
+    case 4: launch_anals_r<4>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC); break;
+    default: launch_anals_r<3>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC); break;
     }
 }
 

@@ -688,9 +688,11 @@ __device__ __forceinline__ FastBin fast_bin(bool blue, int idx, int N, int q, in
 // All four sub-DFTs stay resident (d[4][8]) because every pixel needs all of them; the workgroup keeps to 256 registers
 // per thread (two workgroups per CU).  The sub-DFT inputs are band-limited (|c| <= K), so the Bluestein classes use the
 // same convolution sizes and filter tables as the analysis (side A lists and tables).
-template <int N, bool BLUE>
+// WGT: every pixel is multiplied by wgt (one map for all components) on the way out -- the inverse-noise weighting of the CG operators.
+template <int N, bool BLUE, bool WGT = false>
 __global__ __launch_bounds__(N / 8, 2) void k_phase2map_fast(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim,
-                                                             int ncomp, const double *__restrict__ phase, double *__restrict__ map)
+                                                             int ncomp, const double *__restrict__ phase, double *__restrict__ map,
+                                                             const double *__restrict__ wgt)
 {
     extern __shared__ double2 lds[];
     constexpr int G = N / 8;
@@ -779,8 +781,13 @@ __global__ __launch_bounds__(N / 8, 2) void k_phase2map_fast(DevPlan P, DevFFT F
 #pragma unroll
             for (int j2 = 0; j2 < 4; ++j2) {
                 if ((PL_FFT_ABL & 4) && y[j2].x != 1.2345) continue;
-                mp[on + j1 + q * j2] = y[j2].x;
-                if (os >= 0) mp[os + j1 + q * j2] = y[j2].y;
+                if constexpr (WGT) {
+                    mp[on + j1 + q * j2] = y[j2].x * wgt[on + j1 + q * j2];
+                    if (os >= 0) mp[os + j1 + q * j2] = y[j2].y * wgt[os + j1 + q * j2];
+                } else {
+                    mp[on + j1 + q * j2] = y[j2].x;
+                    if (os >= 0) mp[os + j1 + q * j2] = y[j2].y;
+                }
             }
         }
         e1 = cmul(e1, estep);
@@ -1045,7 +1052,7 @@ static hipError_t launch_map2phase_legacy(const DevPlan &P, const DevFFT &F, con
 
 template <int N, bool BLUE>
 static hipError_t launch_fast_class(const DevPlan &P, const DevFFT &F, int cls, bool synth, const int *mlim, int ncomp, const double *in,
-                                    double *out, hipStream_t st)
+                                    double *out, hipStream_t st, const double *wgt)
 {
     const FftSide &sd = F.A;  // both directions use the band-limited classes
     const int n = BLUE ? sd.cls_n[cls] : sd.dir_n[cls];
@@ -1056,13 +1063,15 @@ static hipError_t launch_fast_class(const DevPlan &P, const DevFFT &F, int cls, 
         static bool attr_done[kMaxDevices] = {};
         const int dv = current_device();
         if (!attr_done[dv]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map_fast<N, BLUE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map_fast<N, BLUE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map_fast<N, BLUE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_map2phase_fast<N, BLUE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             attr_done[dv] = true;
         }
     }
-    if (synth) hipLaunchKernelGGL((k_phase2map_fast<N, BLUE>), dim3(n, ncomp), dim3(N / 8), lds, st, P, F, pairs, mlim, ncomp, in, out);
+    if (synth && wgt) hipLaunchKernelGGL((k_phase2map_fast<N, BLUE, true>), dim3(n, ncomp), dim3(N / 8), lds, st, P, F, pairs, mlim, ncomp, in, out, wgt);
+    else if (synth) hipLaunchKernelGGL((k_phase2map_fast<N, BLUE, false>), dim3(n, ncomp), dim3(N / 8), lds, st, P, F, pairs, mlim, ncomp, in, out, wgt);
     else hipLaunchKernelGGL((k_map2phase_fast<N, BLUE>), dim3(n, ncomp), dim3(N / 8), lds, st, P, F, pairs, mlim, ncomp, in, out);
     return hipGetLastError();
 }
@@ -1120,16 +1129,16 @@ static hipError_t launch_stage(const DevPlan &P, const DevFFT &F, const FftStrea
         if ((blue ? F.A.cls_n[c] : F.A.dir_n[c]) == 0) return hipSuccess;
         hipStream_t s = side(w);
         switch (w) {
-        case 9: return launch_fast_class<4096, true>(P, F, 4, synth, mlim, ncomp, in, out, s);
-        case 8: return launch_fast_class<4096, false>(P, F, 4, synth, mlim, ncomp, in, out, s);
-        case 7: return launch_fast_class<2048, true>(P, F, 3, synth, mlim, ncomp, in, out, s);
-        case 6: return launch_fast_class<2048, false>(P, F, 3, synth, mlim, ncomp, in, out, s);
-        case 5: return launch_fast_class<1024, true>(P, F, 2, synth, mlim, ncomp, in, out, s);
-        case 4: return launch_fast_class<1024, false>(P, F, 2, synth, mlim, ncomp, in, out, s);
-        case 3: return launch_fast_class<512, true>(P, F, 1, synth, mlim, ncomp, in, out, s);
-        case 2: return launch_fast_class<512, false>(P, F, 1, synth, mlim, ncomp, in, out, s);
-        case 1: return launch_fast_class<256, true>(P, F, 0, synth, mlim, ncomp, in, out, s);
-        default: return launch_fast_class<256, false>(P, F, 0, synth, mlim, ncomp, in, out, s);
+        case 9: return launch_fast_class<4096, true>(P, F, 4, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
+        case 8: return launch_fast_class<4096, false>(P, F, 4, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
+        case 7: return launch_fast_class<2048, true>(P, F, 3, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
+        case 6: return launch_fast_class<2048, false>(P, F, 3, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
+        case 5: return launch_fast_class<1024, true>(P, F, 2, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
+        case 4: return launch_fast_class<1024, false>(P, F, 2, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
+        case 3: return launch_fast_class<512, true>(P, F, 1, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
+        case 2: return launch_fast_class<512, false>(P, F, 1, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
+        case 1: return launch_fast_class<256, true>(P, F, 0, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
+        default: return launch_fast_class<256, false>(P, F, 0, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
         }
     };
     for (int w = 9; w >= 0 && e == hipSuccess; --w) e = run(w);  // longest transforms first
@@ -1151,7 +1160,9 @@ bool fft_all_generic(const DevPlan &P, const DevFFT &F) { return F.A.legacy_n ==
 hipError_t launch_phase2map(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *phase,
                             double *map, hipStream_t st, const NinvProj *W)
 {
-    if (W && W->n_inv && !(fft_all_generic(P, F) && ncomp == 1 && W->nmodes <= kFuseModes && W->nparts >= F.A.legacy_n)) return hipErrorInvalidValue;
+    // plain weighting (nmodes = 0) rides in every kernel and for any number of components; the template sums need the generic kernel
+    if (W && W->n_inv && W->nmodes > 0 && !(fft_all_generic(P, F) && ncomp == 1 && W->nmodes <= kFuseModes && W->nparts >= F.A.legacy_n))
+        return hipErrorInvalidValue;
     return launch_stage(P, F, fs, true, mlim, ncomp, phase, map, st, W ? *W : NinvProj());
 }
 

@@ -50,8 +50,11 @@ class fwd_op(object):
         return self.calc(alm)
 
     def calc(self, alm):
-        nlm = self.n_inv_filt.apply_alm_new(alm)
-        return _apply_2x2(self.s_inv_filt.slinv, alm, add_to=nlm)
+        f, sl = self.n_inv_filt, self.s_inv_filt.slinv
+        if isinstance(f, alm_filter_ninv) and f.one_call_ok(alm) and not np.any(sl[:, 0, 1]) and not np.any(sl[:, 1, 0]):
+            return f.apply_alm_new(alm, add=alm, fl_add_e=sl[:, 0, 0], fl_add_b=sl[:, 1, 1])  # the whole operator in pl_cg_fwd_pp
+        nlm = f.apply_alm_new(alm)
+        return _apply_2x2(sl, alm, add_to=nlm)
 
 
 def _apply_2x2(tmat, alm, add_to=None):
@@ -208,9 +211,31 @@ class alm_filter_ninv(object):
         alm.elm.copy_(ret.elm)
         alm.blm.copy_(ret.blm)
 
-    def apply_alm_new(self, alm):
-        """B^t Y^t N^-1 Y B (E, B) as a new eblm (the input is left alone)."""
+    def one_call_ok(self, alm):
+        """pl_cg_fwd_pp applies: device vectors, one inverse-noise map, no templates, one beam, the module's transforms not replaced."""
         self._load_ninv()
+        same_b = self.b_transf_b is self.b_transf_e or np.array_equal(self.b_transf_e, self.b_transf_b)
+        return (isinstance(alm.elm, torch.Tensor) and alm.elm.is_cuda and len(self.n_inv) == 1 and not self.wmarg and same_b
+                and alm2map_spin is shts.alm2map_spin and map2alm_spin is shts.map2alm_spin and not shts.lane_active()
+                and self.n_inv[0].is_contiguous())
+
+    def apply_alm_new(self, alm, add=None, fl_add_e=None, fl_add_b=None):
+        """B^t Y^t N^-1 Y B (E, B) (+ (fl_add_e E', fl_add_b B') for add = (E', B')) as a new eblm (the input is left alone)."""
+        self._load_ninv()
+        lmax = alm.lmax
+        if self.one_call_ok(alm):
+            npix = self.n_inv[0].numel()
+            elm, blm = shts.cg_fwd_pp(alm.elm, alm.blm, self.nside, lmax, self.n_inv[0], fl_in=self.b_transf_e,
+                                      fl_out=self.b_transf_e * (npix / (4. * np.pi)),
+                                      add=None if add is None else (add.elm, add.blm), fl_add_e=fl_add_e, fl_add_b=fl_add_b)
+            return eblm([elm, blm])
+        ret = self._apply_alm_steps(alm)
+        if add is not None:
+            dev.almxfl_add(ret.elm, add.elm, fl_add_e, out=ret.elm)
+            dev.almxfl_add(ret.blm, add.blm, fl_add_b, out=ret.blm)
+        return ret
+
+    def _apply_alm_steps(self, alm):
         lmax = alm.lmax
         same_b = self.b_transf_b is self.b_transf_e or np.array_equal(self.b_transf_e, self.b_transf_b)
         if same_b:

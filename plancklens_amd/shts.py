@@ -261,6 +261,25 @@ def cg_fwd_tt(alm, nside, lmax, n_inv, fl_in=None, fl_out=None, pmat=None, rmat=
     return out
 
 
+def cg_fwd_pp(elm, blm, nside, lmax, n_inv, fl_in=None, fl_out=None, add=None, fl_add_e=None, fl_add_b=None):
+    """fl_out Y2^t [n_inv Y2 (fl_in (E, B))] + (fl_add_e E_add, fl_add_b B_add) on the device, one call (pl_cg_fwd_pp): fwd_op.calc of
+    plancklens/qcinv/opfilt_pp.py:69-78 for a single inverse-noise map.  Returns (elm, blm), two views of one (2, nalm) tensor."""
+    plan = get_plan(nside, lmax)
+    e, b = elm.contiguous(), blm.contiguous()
+    assert e.numel() == plan.nalm and b.numel() == plan.nalm and e.dtype == torch.complex128 and b.dtype == torch.complex128
+    assert n_inv.numel() == plan.npix and n_inv.is_contiguous() and n_inv.dtype == torch.float64
+    out = torch.empty((2, plan.nalm), dtype=torch.complex128, device=e.device)
+    fi, fo = _fl_arg(fl_in, lmax, True), _fl_arg(fl_out, lmax, True)
+    ae = ab = fe = fb = None
+    if add is not None:
+        ae, ab = add[0].contiguous(), add[1].contiguous()
+        assert ae.numel() == plan.nalm and ab.numel() == plan.nalm and ae.dtype == torch.complex128 and ab.dtype == torch.complex128
+        fe, fb = _fl_arg(fl_add_e, lmax, True), _fl_arg(fl_add_b, lmax, True)
+    _lib.check(_lib.lib().pl_cg_fwd_pp(plan.h, _ptr(e), _ptr(b), _ptr(fi), _ptr(n_inv), _ptr(ae), _ptr(ab), _ptr(fe), _ptr(fb),
+                                       _ptr(out[0]), _ptr(out[1]), _ptr(fo), _stream()))
+    return out[0], out[1]
+
+
 def _anal(spin, maps, lmax, fl=None):
     dev = _is_dev(maps)
     ncomp = 1 if spin == 0 else 2

@@ -277,3 +277,41 @@ def test_tt_one_call_operator(nside, lmax, marge):
     assert bool((op(x) == got).all())  # bit-reproducible
     got2 = nf.apply_alm_new(x)  # without the S^-1 term
     assert relrms(dev.to_host(got2), dev.to_host(shts.map2alm(tmap, lmax=lmax, iter=0, fl=bl * (npix / (4. * np.pi))))) < 1e-13
+
+
+@pytest.mark.parametrize('nside,lmax', [(32, 64), (128, 256), (256, 400), (512, 700), (1024, 1500)])
+def test_pp_one_call_operator(nside, lmax):
+    """pl_cg_fwd_pp (inverse-noise weighting inside the synthesis-side ring-FFT launches of every kernel class, S^-1 term inside the
+    analysis post-processing) against the operator assembled from alm2map_spin / apply_map / map2alm_spin / almxfl_add."""
+    from plancklens_amd import dev, hp, shts
+    from plancklens_amd.qcinv import opfilt_pp
+    from plancklens_amd.qcinv.util_alm import eblm
+    rng = np.random.default_rng(nside + lmax)
+    npix = 12 * nside ** 2
+    ninv = rng.uniform(0.5, 1.5, npix) * (rng.uniform(size=npix) > 0.2)
+    bl = hp.gauss_beam(np.radians(0.3), lmax=lmax)
+    nf = opfilt_pp.alm_filter_ninv([ninv], bl)
+    cl = {'ee': 1e2 / (np.arange(lmax + 1) + 10.) ** 2, 'bb': 1e1 / (np.arange(lmax + 1) + 10.) ** 2}
+    cl['ee'][:2] = 0.
+    cl['bb'][:2] = 0.
+
+    def ralm():
+        x = rng.standard_normal(hp.Alm.getsize(lmax)) + 1j * rng.standard_normal(hp.Alm.getsize(lmax))
+        x[:lmax + 1] = x[:lmax + 1].real
+        return dev.to_dev(x)
+    x = eblm([ralm(), ralm()])
+    e0, b0 = x.elm.clone(), x.blm.clone()
+    op = opfilt_pp.fwd_op(cl, nf)
+    assert nf.one_call_ok(x)
+    got = op(x)
+    ref = nf._apply_alm_steps(x)
+    sl = op.s_inv_filt.slinv
+    ref_e = dev.almxfl_add(ref.elm, x.elm, sl[:, 0, 0])
+    ref_b = dev.almxfl_add(ref.blm, x.blm, sl[:, 1, 1])
+    assert bool((x.elm == e0).all()) and bool((x.blm == b0).all())
+    assert relrms(dev.to_host(got.elm), dev.to_host(ref_e)) < 1e-13
+    assert relrms(dev.to_host(got.blm), dev.to_host(ref_b)) < 1e-13
+    again = op(x)
+    assert bool((again.elm == got.elm).all()) and bool((again.blm == got.blm).all())
+    got2 = nf.apply_alm_new(x)  # without the S^-1 term
+    assert relrms(dev.to_host(got2.elm), dev.to_host(ref.elm)) < 1e-13 and relrms(dev.to_host(got2.blm), dev.to_host(ref.blm)) < 1e-13
