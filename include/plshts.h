@@ -120,6 +120,18 @@ int pl_axpy(int64_t n, double a, const double *x, const double *y, double *out, 
 int pl_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *parts_dev, void *stream);
 int pl_axpy_dev(int64_t n, const double *num_parts_dev, const double *den_parts_dev, double sign, const double *x, double *y, void *stream);
 int pl_alm_splice(int lmax_lo, const double *alm_lo, int lmax_hi, const double *alm_hi, int lsplit, double *out, void *stream);
+/* Scalar products and the updates they scale in ONE launch, over nf <= 3 fields (host arrays of nf device pointers / band-limits):
+ *   parts1 = <a, b1>, parts2 = <a, b2> (b2 given), left in parts*_dev as pl_alm_dot leaves them (summed over the fields);
+ *   c = parts2 / parts1 (b2 given) or parts1 / den_parts_dev (den given; exactly one of b2, den_parts_dev);
+ *   y1 += sign1 c x1 and, when y2 is given, y2 += sign2 c x2 (signs +-1).
+ * With (a, b1, b2, y1, x1, y2, x2) = (d, Ad, r, x, d, r, Ad), signs (+1, -1) this is one conjugate-directions update
+ * (cd_solve.py:66-84); with (s, Ad', -, s, d') and den = d'^t A d', sign -1 the re-orthogonalisation (cd_solve.py:96-103).
+ * Same arithmetic as pl_alm_dot + pl_axpy_dev (bit-identical).  barrier_dev: 4 zero-initialised 32-bit words in device memory
+ * owned by the caller (a grid-wide barrier separates the products from the updates; barrier_dev[2] != 0 afterwards reports a
+ * barrier that timed out, results invalid).  Launches on one stream only may share a barrier. */
+int pl_cg_dot_axpy(int nf, const int *lmax, int lmin, const double *const *a, const double *const *b1, const double *const *b2,
+                   double *parts1_dev, double *parts2_dev, const double *den_parts_dev, double *const *y1, const double *const *x1,
+                   double sign1, double *const *y2, const double *const *x2, double sign2, unsigned *barrier_dev, void *stream);
 
 /* Inverse-noise weighting with template marginalisation (alm_filter_ninv.apply_map, opfilt_tt.py:196-205) in two
  * launches: tmap <- n_inv tmap - sum_k rmat[k] c_k, c_k = sum_i pmat[k][i] n_inv[i] tmap[i], with pmat (nmodes x npix,

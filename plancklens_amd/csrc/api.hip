@@ -34,6 +34,9 @@ void launch_alm2cl(int lmax, const double *a, const double *b, double *cl, hipSt
 void launch_axpy(int64_t n, double a, const double *x, const double *y, double *out, hipStream_t st);
 void launch_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *parts, hipStream_t st);
 void launch_axpy_dev(int64_t n, const double *num, const double *den, double sign, const double *x, double *y, hipStream_t st);
+void launch_cg_fused(int nf, const int *lmax, int lmin, const double *const *a, const double *const *b1, const double *const *b2, double *parts1,
+                     double *parts2, const double *den, double *const *y1, const double *const *x1, double sign1, double *const *y2,
+                     const double *const *x2, double sign2, unsigned *bar, hipStream_t st);
 void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st);
 void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st);
 void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st);
@@ -608,6 +611,23 @@ int pl_axpy_dev(int64_t n, const double *num_parts_dev, const double *den_parts_
     if (n < 0 || !num_parts_dev || !x || !y) return fail("pl_axpy_dev: bad arguments");
     if (n == 0) return 0;
     launch_axpy_dev(n, num_parts_dev, den_parts_dev, sign, x, y, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_cg_dot_axpy(int nf, const int *lmax, int lmin, const double *const *a, const double *const *b1, const double *const *b2,
+                   double *parts1_dev, double *parts2_dev, const double *den_parts_dev, double *const *y1, const double *const *x1, double sign1,
+                   double *const *y2, const double *const *x2, double sign2, unsigned *barrier_dev, void *stream)
+{
+    if (nf < 1 || nf > 3 || !lmax || !a || !b1 || !parts1_dev || !y1 || !x1 || !barrier_dev) return fail("pl_cg_dot_axpy: bad arguments");
+    if (!b2 && !den_parts_dev) return fail("pl_cg_dot_axpy: either a second scalar product (b2) or a denominator (den_parts_dev) is needed");
+    if (b2 && (!parts2_dev || den_parts_dev)) return fail("pl_cg_dot_axpy: b2 needs parts2_dev and excludes den_parts_dev");
+    if ((y2 == nullptr) != (x2 == nullptr)) return fail("pl_cg_dot_axpy: y2 and x2 come together");
+    if ((sign1 != 1.0 && sign1 != -1.0) || (sign2 != 1.0 && sign2 != -1.0)) return fail("pl_cg_dot_axpy: signs are +1 or -1");
+    for (int k = 0; k < nf; ++k)
+        if (lmax[k] < 0 || !a[k] || !b1[k] || (b2 && !b2[k]) || !y1[k] || !x1[k] || (y2 && (!y2[k] || !x2[k]))) return fail("pl_cg_dot_axpy: null field");
+    launch_cg_fused(nf, lmax, lmin < 0 ? 0 : lmin, a, b1, b2, parts1_dev, parts2_dev, den_parts_dev, y1, x1, sign1, y2, x2, sign2, barrier_dev,
+                    static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return 0;
 }

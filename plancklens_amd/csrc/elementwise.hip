@@ -254,6 +254,97 @@ __global__ void k_axpy_dev(int64_t n, const double *__restrict__ num, const doub
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = fma(c, x[n - 1], y[n - 1]);
 }
 
+// ---- scalar products and the vector updates that consume them in ONE launch ---------------------------------------------------
+// cd_solve.py:66-84 is  dTAd = <d, q>, delta = <d, r>, x += (delta / dTAd) d, r -= (delta / dTAd) q  and :96-103 is
+// s -= (<s, q'> / dTAd') d'.  Each is "scalar products over all fields, then updates scaled by their ratio": the first kDotParts
+// workgroups form the partial sums exactly as k_alm_dot_parts does, a grid-wide barrier makes them visible, and every workgroup
+// applies the updates as k_axpy_dev does (same arithmetic, bit-identical results).  The barrier is an arrival counter + generation
+// word in device memory (agent-scope atomics; the release / acquire fences write back and invalidate the XCD-private L2s); all
+// workgroups are co-resident (at most one per CU).  A waiter gives up after ~0.5 s and raises bar[2] instead of hanging the GPU.
+struct CgFused {
+    int nf, lmin;
+    int lmax[3];
+    const double2 *a[3], *b1[3], *b2[3];
+    double2 *y1[3], *y2[3];
+    const double2 *x1[3], *x2[3];
+};
+constexpr int kCgBlocks = 256;
+__device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned nblocks)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // one release (L2 write-back) on arrival, relaxed polling, one acquire (invalidate) on the way out
+        const unsigned gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned prev = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == nblocks - 1) {
+            __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            int spins = 0;
+            while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 24)) { __hip_atomic_store(&bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ double dot_parts_sum_coherent(const double *parts)
+{
+    double s = 0.0;
+    for (int i = 0; i < kDotParts; ++i) s += __hip_atomic_load(&parts[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return s;
+}
+__global__ __launch_bounds__(kDotThreads) void k_cg_fused(CgFused f, double *__restrict__ parts1, double *__restrict__ parts2,
+                                                          const double *__restrict__ den, double sign1, double sign2, unsigned *bar)
+{
+    __shared__ double red[kDotThreads];
+    __shared__ double cs;
+    if (blockIdx.x < kDotParts) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int k = 0; k < f.nf; ++k) {
+            const int64_t nalm = (int64_t)(f.lmax[k] + 1) * (f.lmax[k] + 2) / 2;
+            const int64_t first = (int64_t)blockIdx.x * kDotThreads + threadIdx.x, stride = (int64_t)kDotParts * kDotThreads;
+            const double u1 = block_sum_1024(alm_dot_partial(f.lmax[k], f.lmin, f.a[k], f.b1[k], first, stride, nalm), red);
+            t1 = k == 0 ? u1 : t1 + u1;
+            __syncthreads();
+            if (f.b2[0]) {
+                const double u2 = block_sum_1024(alm_dot_partial(f.lmax[k], f.lmin, f.a[k], f.b2[k], first, stride, nalm), red);
+                t2 = k == 0 ? u2 : t2 + u2;
+                __syncthreads();
+            }
+        }
+        if (threadIdx.x == 0) {
+            parts1[blockIdx.x] = t1;
+            if (f.b2[0]) parts2[blockIdx.x] = t2;
+        }
+    }
+    grid_barrier(bar, gridDim.x);
+    if (threadIdx.x == 0) {
+        const double num = den ? dot_parts_sum_coherent(parts1) : dot_parts_sum_coherent(parts2);
+        const double dn = den ? dot_parts_sum_coherent(den) : dot_parts_sum_coherent(parts1);
+        cs = num * (1.0 / dn);
+    }
+    __syncthreads();
+    const double c1 = sign1 * cs, c2 = sign2 * cs;  // sign = +-1: same value as k_axpy_dev's sign * num * (1 / den)
+    for (int k = 0; k < f.nf; ++k) {
+        const int64_t nalm = (int64_t)(f.lmax[k] + 1) * (f.lmax[k] + 2) / 2;
+        for (int64_t i = (int64_t)blockIdx.x * kDotThreads + threadIdx.x; i < nalm; i += (int64_t)gridDim.x * kDotThreads) {
+            const double2 u = f.x1[k][i];
+            double2 v = f.y1[k][i];
+            v.x = fma(c1, u.x, v.x); v.y = fma(c1, u.y, v.y);
+            f.y1[k][i] = v;
+            if (f.y2[0]) {
+                const double2 u2 = f.x2[k][i];
+                double2 w = f.y2[k][i];
+                w.x = fma(c2, u2.x, w.x); w.y = fma(c2, u2.y, w.y);
+                f.y2[k][i] = w;
+            }
+        }
+    }
+}
+
 // ---- N^-1 with template marginalisation in two launches (opfilt_tt.py:196-205) ----------------------------------------
 // t <- N^-1 t - N^-1 P (P^t N^-1 P)^-1 P^t N^-1 t with P (nmodes x n) and R = (P^t N^-1 P)^-1 (P . N^-1) (nmodes x n) given:
 //   pass 1: t <- n_inv t and the per-workgroup partial sums of c_k = sum_i P_ki t_i;  pass 2: t_i -= sum_k R_ki c_k.
@@ -397,6 +488,31 @@ void launch_alm_dot(int lmax, int lmin, const double *a, const double *b, int ac
 void launch_axpy_dev(int64_t n, const double *num, const double *den, double sign, const double *x, double *y, hipStream_t st)
 {
     hipLaunchKernelGGL(k_axpy_dev, dim3(nblocks((n + 1) / 2)), dim3(256), 0, st, n, num, den, sign, x, y);
+}
+void launch_cg_fused(int nf, const int *lmax, int lmin, const double *const *a, const double *const *b1, const double *const *b2, double *parts1,
+                     double *parts2, const double *den, double *const *y1, const double *const *x1, double sign1, double *const *y2,
+                     const double *const *x2, double sign2, unsigned *bar, hipStream_t st)
+{
+    CgFused f = {};
+    f.nf = nf; f.lmin = lmin;
+    int64_t nmax = 0;
+    for (int k = 0; k < nf; ++k) {
+        f.lmax[k] = lmax[k];
+        f.a[k] = reinterpret_cast<const double2 *>(a[k]);
+        f.b1[k] = reinterpret_cast<const double2 *>(b1[k]);
+        f.b2[k] = b2 ? reinterpret_cast<const double2 *>(b2[k]) : nullptr;
+        f.y1[k] = reinterpret_cast<double2 *>(y1[k]);
+        f.x1[k] = reinterpret_cast<const double2 *>(x1[k]);
+        f.y2[k] = y2 ? reinterpret_cast<double2 *>(y2[k]) : nullptr;
+        f.x2[k] = x2 ? reinterpret_cast<const double2 *>(x2[k]) : nullptr;
+        const int64_t nalm = (int64_t)(lmax[k] + 1) * (lmax[k] + 2) / 2;
+        if (nalm > nmax) nmax = nalm;
+    }
+    // the scalar products always use kDotParts workgroups; long vectors get more for the updates (never more than one per CU)
+    int nb = (int)((nmax + 4 * kDotThreads - 1) / (4 * kDotThreads));
+    if (nb < kDotParts) nb = kDotParts;
+    if (nb > kCgBlocks) nb = kCgBlocks;
+    hipLaunchKernelGGL(k_cg_fused, dim3(nb), dim3(kDotThreads), 0, st, f, parts1, parts2, den, sign1, sign2, bar);
 }
 void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st)
 {

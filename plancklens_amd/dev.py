@@ -237,6 +237,51 @@ def axpy_dev(y, x, num, den=None, sign=1.0):
     return y
 
 
+_CG_BARRIER = {}
+
+
+def cg_barrier():
+    """the per-device grid-barrier words of pl_cg_dot_axpy (every solver of this process launches on one stream at a time)"""
+    d = torch.cuda.current_device()
+    if d not in _CG_BARRIER:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('CG barrier words requested while a HIP graph is being captured')
+        _CG_BARRIER[d] = torch.zeros(4, dtype=torch.int32, device=device())
+    return _CG_BARRIER[d]
+
+
+def cg_barrier_timed_out():
+    """True if a grid barrier of pl_cg_dot_axpy gave up on this device (results after that are invalid); synchronises."""
+    d = torch.cuda.current_device()
+    return d in _CG_BARRIER and int(_CG_BARRIER[d][2]) != 0
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def cg_dot_axpy(a, b1, y1, x1, sign1, b2=None, den=None, y2=None, x2=None, sign2=-1.0, lmin=0):
+    """Scalar products and the updates they scale in one launch (pl_cg_dot_axpy) over the fields of the lists a, b1, ...:
+    parts1 = <a, b1>, parts2 = <a, b2>; c = parts2 / parts1 (b2 given) or parts1 / den; y1 += sign1 c x1, y2 += sign2 c x2.
+    Returns (parts1, parts2), device tensors of DOT_PARTS partial sums as alm_dot returns them."""
+    nf = len(a)
+    for group in (b1, y1, x1, b2, y2, x2):
+        assert group is None or len(group) == nf
+    for k in range(nf):
+        for group in (a, b1, y1, x1, b2, y2, x2):
+            assert group is None or (group[k].dtype == torch.complex128 and group[k].is_contiguous() and group[k].numel() == a[k].numel())
+    lmax = (ctypes.c_int * nf)(*[Alm.getlmax(t.numel()) for t in a])
+    parts1 = torch.empty(DOT_PARTS, dtype=torch.float64, device=device())
+    parts2 = torch.empty(DOT_PARTS, dtype=torch.float64, device=device()) if b2 is not None else None
+    assert (b2 is None) != (den is None) and (den is None or den.numel() == DOT_PARTS)
+    _lib.check(_lib.lib().pl_cg_dot_axpy(nf, lmax, int(lmin), _ptr_array(a), _ptr_array(b1), None if b2 is None else _ptr_array(b2),
+                                         parts1.data_ptr(), None if parts2 is None else parts2.data_ptr(),
+                                         None if den is None else den.data_ptr(), _ptr_array(y1), _ptr_array(x1), float(sign1),
+                                         None if y2 is None else _ptr_array(y2), None if x2 is None else _ptr_array(x2), float(sign2),
+                                         cg_barrier().data_ptr(), stream_ptr()))
+    return parts1, parts2
+
+
 TEMPLATE_MAX_MODES = 16  # PL_TEMPLATE_MAX_MODES of include/plshts.h
 _TPROJ_SCRATCH = {}
 

@@ -33,6 +33,20 @@ class dot_op(object):
         dev.axpy_dev(y.elm, x.elm, num, den, sign)
         dev.axpy_dev(y.blm, x.blm, num, den, sign)
 
+    @staticmethod
+    def step(x, d, r, q, update_r=True):
+        """one conjugate-directions update in one launch: dTAd = <d, q>, delta = <d, r>, x += (delta / dTAd) d and, if update_r,
+        r -= (delta / dTAd) q; returns (dTAd, delta) as `parts` does"""
+        f = (lambda v: [v.elm, v.blm])
+        return dev.cg_dot_axpy(f(d), f(q), f(x), f(d), 1.0, b2=f(r), y2=f(r) if update_r else None, x2=f(q) if update_r else None,
+                               sign2=-1.0, lmin=2)
+
+    @staticmethod
+    def ortho(s, pq, pd, prev_dtad):
+        """s -= (<s, pq> / prev_dtad) pd in one launch"""
+        f = (lambda v: [v.elm, v.blm])
+        dev.cg_dot_axpy(f(s), f(pq), f(s), f(pd), -1.0, den=prev_dtad, lmin=2)
+
     def __call__(self, alm1, alm2):
         return float(self.parts(alm1, alm2).sum())
 
