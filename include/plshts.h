@@ -126,9 +126,10 @@ int pl_alm_splice(int lmax_lo, const double *alm_lo, int lmax_hi, const double *
  *   y1 += sign1 c x1 and, when y2 is given, y2 += sign2 c x2 (signs +-1).
  * With (a, b1, b2, y1, x1, y2, x2) = (d, Ad, r, x, d, r, Ad), signs (+1, -1) this is one conjugate-directions update
  * (cd_solve.py:66-84); with (s, Ad', -, s, d') and den = d'^t A d', sign -1 the re-orthogonalisation (cd_solve.py:96-103).
- * Same arithmetic as pl_alm_dot + pl_axpy_dev (bit-identical).  barrier_dev: 4 zero-initialised 32-bit words in device memory
- * owned by the caller (a grid-wide barrier separates the products from the updates; barrier_dev[2] != 0 afterwards reports a
- * barrier that timed out, results invalid).  Launches on one stream only may share a barrier. */
+ * Same arithmetic as pl_alm_dot + pl_axpy_dev (bit-identical).  barrier_dev NULL: two launches (all products, then all updates).
+ * barrier_dev given: ONE launch, a grid-wide barrier separating the products from the updates -- 4 zero-initialised 32-bit words in
+ * device memory owned by the caller (barrier_dev[2] != 0 afterwards reports a barrier that timed out, results invalid; launches on
+ * one stream only may share the words).  On MI355X the barrier costs what the kernel boundary costs: the two forms run equally fast. */
 int pl_cg_dot_axpy(int nf, const int *lmax, int lmin, const double *const *a, const double *const *b1, const double *const *b2,
                    double *parts1_dev, double *parts2_dev, const double *den_parts_dev, double *const *y1, const double *const *x1,
                    double sign1, double *const *y2, const double *const *x2, double sign2, unsigned *barrier_dev, void *stream);

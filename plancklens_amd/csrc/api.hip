@@ -619,7 +619,7 @@ int pl_cg_dot_axpy(int nf, const int *lmax, int lmin, const double *const *a, co
                    double *parts1_dev, double *parts2_dev, const double *den_parts_dev, double *const *y1, const double *const *x1, double sign1,
                    double *const *y2, const double *const *x2, double sign2, unsigned *barrier_dev, void *stream)
 {
-    if (nf < 1 || nf > 3 || !lmax || !a || !b1 || !parts1_dev || !y1 || !x1 || !barrier_dev) return fail("pl_cg_dot_axpy: bad arguments");
+    if (nf < 1 || nf > 3 || !lmax || !a || !b1 || !parts1_dev || !y1 || !x1) return fail("pl_cg_dot_axpy: bad arguments");
     if (!b2 && !den_parts_dev) return fail("pl_cg_dot_axpy: either a second scalar product (b2) or a denominator (den_parts_dev) is needed");
     if (b2 && (!parts2_dev || den_parts_dev)) return fail("pl_cg_dot_axpy: b2 needs parts2_dev and excludes den_parts_dev");
     if ((y2 == nullptr) != (x2 == nullptr)) return fail("pl_cg_dot_axpy: y2 and x2 come together");

@@ -296,12 +296,15 @@ __device__ __forceinline__ double dot_parts_sum_coherent(const double *parts)
     for (int i = 0; i < kDotParts; ++i) s += __hip_atomic_load(&parts[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return s;
 }
+// MODE 0: products, barrier, updates; 1: products only; 2: updates only (launched after a MODE 1 launch: no barrier, and the
+// updates of all fields still share one launch)
+template <int MODE>
 __global__ __launch_bounds__(kDotThreads) void k_cg_fused(CgFused f, double *__restrict__ parts1, double *__restrict__ parts2,
                                                           const double *__restrict__ den, double sign1, double sign2, unsigned *bar)
 {
     __shared__ double red[kDotThreads];
     __shared__ double cs;
-    if (blockIdx.x < kDotParts) {
+    if (MODE != 2 && blockIdx.x < kDotParts) {
         double t1 = 0.0, t2 = 0.0;
         for (int k = 0; k < f.nf; ++k) {
             const int64_t nalm = (int64_t)(f.lmax[k] + 1) * (f.lmax[k] + 2) / 2;
@@ -320,10 +323,17 @@ __global__ __launch_bounds__(kDotThreads) void k_cg_fused(CgFused f, double *__r
             if (f.b2[0]) parts2[blockIdx.x] = t2;
         }
     }
-    grid_barrier(bar, gridDim.x);
+    if (MODE == 1) return;
+    if (MODE == 0) grid_barrier(bar, gridDim.x);
     if (threadIdx.x == 0) {
-        const double num = den ? dot_parts_sum_coherent(parts1) : dot_parts_sum_coherent(parts2);
-        const double dn = den ? dot_parts_sum_coherent(den) : dot_parts_sum_coherent(parts1);
+        double num, dn;
+        if (MODE == 0) {
+            num = den ? dot_parts_sum_coherent(parts1) : dot_parts_sum_coherent(parts2);
+            dn = den ? dot_parts_sum_coherent(den) : dot_parts_sum_coherent(parts1);
+        } else {
+            num = den ? dot_parts_sum(parts1) : dot_parts_sum(parts2);
+            dn = den ? dot_parts_sum(den) : dot_parts_sum(parts1);
+        }
         cs = num * (1.0 / dn);
     }
     __syncthreads();
@@ -493,6 +503,7 @@ void launch_cg_fused(int nf, const int *lmax, int lmin, const double *const *a, 
                      double *parts2, const double *den, double *const *y1, const double *const *x1, double sign1, double *const *y2,
                      const double *const *x2, double sign2, unsigned *bar, hipStream_t st)
 {
+    // bar null: two launches (products, then updates); else one launch with a grid barrier in between
     CgFused f = {};
     f.nf = nf; f.lmin = lmin;
     int64_t nmax = 0;
@@ -512,7 +523,14 @@ void launch_cg_fused(int nf, const int *lmax, int lmin, const double *const *a, 
     int nb = (int)((nmax + 4 * kDotThreads - 1) / (4 * kDotThreads));
     if (nb < kDotParts) nb = kDotParts;
     if (nb > kCgBlocks) nb = kCgBlocks;
-    hipLaunchKernelGGL(k_cg_fused, dim3(nb), dim3(kDotThreads), 0, st, f, parts1, parts2, den, sign1, sign2, bar);
+    if (bar) {
+        hipLaunchKernelGGL(k_cg_fused<0>, dim3(nb), dim3(kDotThreads), 0, st, f, parts1, parts2, den, sign1, sign2, bar);
+    } else {
+        hipLaunchKernelGGL(k_cg_fused<1>, dim3(kDotParts), dim3(kDotThreads), 0, st, f, parts1, parts2, den, sign1, sign2, bar);
+        const int nb2 = (int)((nmax + kDotThreads - 1) / kDotThreads);  // updates: one entry per thread up to 1024 workgroups
+        hipLaunchKernelGGL(k_cg_fused<2>, dim3(nb2 < 1 ? 1 : (nb2 > 1024 ? 1024 : nb2)), dim3(kDotThreads), 0, st, f, parts1, parts2, den, sign1,
+                           sign2, bar);
+    }
 }
 void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st)
 {

@@ -260,8 +260,9 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-def cg_dot_axpy(a, b1, y1, x1, sign1, b2=None, den=None, y2=None, x2=None, sign2=-1.0, lmin=0):
-    """Scalar products and the updates they scale in one launch (pl_cg_dot_axpy) over the fields of the lists a, b1, ...:
+def cg_dot_axpy(a, b1, y1, x1, sign1, b2=None, den=None, y2=None, x2=None, sign2=-1.0, lmin=0, one_launch=False):
+    """Scalar products and the updates they scale (pl_cg_dot_axpy: two launches for all fields, or one with a grid barrier inside
+    when `one_launch`) over the fields of the lists a, b1, ...:
     parts1 = <a, b1>, parts2 = <a, b2>; c = parts2 / parts1 (b2 given) or parts1 / den; y1 += sign1 c x1, y2 += sign2 c x2.
     Returns (parts1, parts2), device tensors of DOT_PARTS partial sums as alm_dot returns them."""
     nf = len(a)
@@ -278,7 +279,7 @@ def cg_dot_axpy(a, b1, y1, x1, sign1, b2=None, den=None, y2=None, x2=None, sign2
                                          parts1.data_ptr(), None if parts2 is None else parts2.data_ptr(),
                                          None if den is None else den.data_ptr(), _ptr_array(y1), _ptr_array(x1), float(sign1),
                                          None if y2 is None else _ptr_array(y2), None if x2 is None else _ptr_array(x2), float(sign2),
-                                         cg_barrier().data_ptr(), stream_ptr()))
+                                         cg_barrier().data_ptr() if one_launch else None, stream_ptr()))
     return parts1, parts2
 
 

@@ -48,16 +48,18 @@ def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=
         stay on the device: no host synchronisation inside an iteration, same arithmetic.  If the dot_op also offers
         `parts(a, b)` (the scalar product in whatever device-resident form `axpy` accepts) and `axpy(y, x, num, den, sign)`
         (y += sign num / den x in place) every scalar product and vector update is one launch and the cache holds
-        d^t A d instead of its inverse; with `step` and `ortho` as well the two scalar products and two updates of an iteration
-        can be one launch, and so can the re-orthogonalisation (pl_cg_dot_axpy, PLENS_CG_ONE_LAUNCH=1).  Off by default: measured on
-        MI355X the grid-wide barrier inside that launch costs as much as the two kernel boundaries it replaces.
+        d^t A d instead of its inverse; with `step` and `ortho` as well the two scalar products of an iteration are one launch for
+        all fields and its two updates another (pl_cg_dot_axpy; PLENS_CG_MERGED=0 keeps them apart), likewise the
+        re-orthogonalisation.  PLENS_CG_ONE_LAUNCH=1 joins each pair with a grid-wide barrier: measured on MI355X that barrier costs
+        what the kernel boundary costs, so it is off by default.
     """
     if cache is None:
         cache = cache_mem()
     n_pre = len(pre_ops)
     on_dev = n_pre == 1 and hasattr(dot_op, 'dev')
     fused = on_dev and hasattr(dot_op, 'axpy') and hasattr(dot_op, 'parts')
-    one_launch = fused and hasattr(dot_op, 'step') and hasattr(dot_op, 'ortho') and os.environ.get('PLENS_CG_ONE_LAUNCH', '0') == '1'
+    merged = fused and hasattr(dot_op, 'step') and hasattr(dot_op, 'ortho') and os.environ.get('PLENS_CG_MERGED', '1') != '0'
+    one_launch = os.environ.get('PLENS_CG_ONE_LAUNCH', '0') == '1'
     residual = b * 1.0 if x_is_zero else b - fwd_op(x)
     searchdirs = [op(residual) for op in pre_ops]
     it = 0
@@ -65,8 +67,8 @@ def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=
         searchfwds = [fwd_op(d) for d in searchdirs]
         if fused:
             fresh_residual = np.mod(it + 1, roundoff) == 0
-            if one_launch:  # both scalar products and both updates in one launch
-                dTAd, delta = dot_op.step(x, searchdirs[0], residual, searchfwds[0], update_r=not fresh_residual)
+            if merged:  # both scalar products in one launch, both updates of all fields in another (or all in one)
+                dTAd, delta = dot_op.step(x, searchdirs[0], residual, searchfwds[0], update_r=not fresh_residual, one_launch=one_launch)
             else:
                 dTAd = dot_op.parts(searchdirs[0], searchfwds[0])
                 delta = dot_op.parts(searchdirs[0], residual)
@@ -80,8 +82,8 @@ def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=
             searchdirs = [op(residual) for op in pre_ops]
             for titer in range(tr(it), it):
                 prev_dTAd, prev_dirs, prev_fwds = cache.restore(titer)
-                if one_launch:
-                    dot_op.ortho(searchdirs[0], prev_fwds[0], prev_dirs[0], prev_dTAd)
+                if merged:
+                    dot_op.ortho(searchdirs[0], prev_fwds[0], prev_dirs[0], prev_dTAd, one_launch=one_launch)
                 else:
                     dot_op.axpy(searchdirs[0], prev_dirs[0], dot_op.parts(searchdirs[0], prev_fwds[0]), prev_dTAd, -1.0)
             cache.trim(range(tr(it + 1), it))

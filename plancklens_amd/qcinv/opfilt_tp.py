@@ -67,18 +67,18 @@ class dot_op(object):
         dev.axpy_dev(y.blm, x.blm, num, den, sign)
 
     @staticmethod
-    def step(x, d, r, q, update_r=True):
-        """one conjugate-directions update in one launch: dTAd = <d, q>, delta = <d, r>, x += (delta / dTAd) d and, if update_r,
-        r -= (delta / dTAd) q; returns (dTAd, delta) as `parts` does"""
+    def step(x, d, r, q, update_r=True, one_launch=False):
+        """one conjugate-directions update, all fields in two launches (or one with a grid barrier): dTAd = <d, q>, delta = <d, r>,
+        x += (delta / dTAd) d and, if update_r, r -= (delta / dTAd) q; returns (dTAd, delta) as `parts` does"""
         f = (lambda v: [v.tlm, v.elm, v.blm])
         return dev.cg_dot_axpy(f(d), f(q), f(x), f(d), 1.0, b2=f(r), y2=f(r) if update_r else None, x2=f(q) if update_r else None,
-                               sign2=-1.0, lmin=0)
+                               sign2=-1.0, lmin=0, one_launch=one_launch)
 
     @staticmethod
-    def ortho(s, pq, pd, prev_dtad):
-        """s -= (<s, pq> / prev_dtad) pd in one launch"""
+    def ortho(s, pq, pd, prev_dtad, one_launch=False):
+        """s -= (<s, pq> / prev_dtad) pd, all fields in two launches (or one with a grid barrier)"""
         f = (lambda v: [v.tlm, v.elm, v.blm])
-        dev.cg_dot_axpy(f(s), f(pq), f(s), f(pd), -1.0, den=prev_dtad, lmin=0)
+        dev.cg_dot_axpy(f(s), f(pq), f(s), f(pd), -1.0, den=prev_dtad, lmin=0, one_launch=one_launch)
 
     def __call__(self, alm1, alm2):
         return float(self.parts(alm1, alm2).sum())

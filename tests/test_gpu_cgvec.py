@@ -131,7 +131,7 @@ def test_gemv_vs_numpy(nrows, ncols):
 
 @pytest.mark.parametrize('lmaxs,lmin', [((32,), 0), ((256,), 0), ((2048,), 0), ((100, 100), 2), ((2048, 2048), 2), ((300, 200, 200), 0)])
 def test_cg_dot_axpy_one_launch(lmaxs, lmin):
-    """pl_cg_dot_axpy (scalar products, grid barrier, updates in one launch) against pl_alm_dot + pl_axpy_dev: bit-identical partial
+    """pl_cg_dot_axpy (two launches for all fields, or one with a grid barrier inside) against pl_alm_dot + pl_axpy_dev: bit-identical partial
     sums and vectors, in the conjugate-directions form (two products, two updates) and the re-orthogonalisation form (one, one)."""
     import torch
     from plancklens_amd import dev, hp
@@ -140,9 +140,10 @@ def test_cg_dot_axpy_one_launch(lmaxs, lmin):
     def vec():
         return [dev.to_dev(rng.standard_normal(hp.Alm.getsize(l)) + 1j * rng.standard_normal(hp.Alm.getsize(l))) for l in lmaxs]
     d, q, r, x = vec(), vec(), vec(), vec()
-    for update_r in (True, False):
+    for update_r, one in ((True, False), (False, False), (True, True), (False, True)):
         x1, r1 = [t.clone() for t in x], [t.clone() for t in r]
-        p1, p2 = dev.cg_dot_axpy(d, q, x1, d, 1.0, b2=r1, y2=r1 if update_r else None, x2=q if update_r else None, sign2=-1.0, lmin=lmin)
+        p1, p2 = dev.cg_dot_axpy(d, q, x1, d, 1.0, b2=r1, y2=r1 if update_r else None, x2=q if update_r else None, sign2=-1.0, lmin=lmin,
+                                 one_launch=one)
         dtad = dev.alm_dot(list(zip(d, q)), lmin=lmin)
         delta = dev.alm_dot(list(zip(d, r)), lmin=lmin)
         x2, r2 = [t.clone() for t in x], [t.clone() for t in r]
@@ -154,15 +155,16 @@ def test_cg_dot_axpy_one_launch(lmaxs, lmin):
         for k in range(len(lmaxs)):
             assert torch.equal(x1[k], x2[k]) and torch.equal(r1[k], r2[k])
             assert not torch.equal(x1[k], x[k]) and (torch.equal(r1[k], r[k]) != update_r)
-    s1, s2 = [t.clone() for t in x], [t.clone() for t in x]
-    p1, none = dev.cg_dot_axpy(s1, q, s1, d, -1.0, den=dtad, lmin=lmin)
-    assert none is None
-    num = dev.alm_dot(list(zip(s2, q)), lmin=lmin)
-    for k in range(len(lmaxs)):
-        dev.axpy_dev(s2[k], d[k], num, dtad, -1.0)
-    assert torch.equal(p1, num)
-    for k in range(len(lmaxs)):
-        assert torch.equal(s1[k], s2[k])
+    for one in (False, True):
+        s1, s2 = [t.clone() for t in x], [t.clone() for t in x]
+        p1, none = dev.cg_dot_axpy(s1, q, s1, d, -1.0, den=dtad, lmin=lmin, one_launch=one)
+        assert none is None
+        num = dev.alm_dot(list(zip(s2, q)), lmin=lmin)
+        for k in range(len(lmaxs)):
+            dev.axpy_dev(s2[k], d[k], num, dtad, -1.0)
+        assert torch.equal(p1, num)
+        for k in range(len(lmaxs)):
+            assert torch.equal(s1[k], s2[k])
     for _ in range(200):  # the barrier words are reusable back to back
-        dev.cg_dot_axpy(s1, q, s1, d, -1.0, den=dtad, lmin=lmin)
+        dev.cg_dot_axpy(s1, q, s1, d, -1.0, den=dtad, lmin=lmin, one_launch=True)
     assert not dev.cg_barrier_timed_out()
