@@ -120,6 +120,10 @@ int pl_axpy(int64_t n, double a, const double *x, const double *y, double *out, 
 int pl_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *parts_dev, void *stream);
 int pl_axpy_dev(int64_t n, const double *num_parts_dev, const double *den_parts_dev, double sign, const double *x, double *y, void *stream);
 int pl_alm_splice(int lmax_lo, const double *alm_lo, int lmax_hi, const double *alm_hi, int lsplit, double *out, void *stream);
+/* the same with the high part multiplied by fl_hi[l] (lmax_hi + 1 entries, device): pre_op_split with a diagonal high-l
+ * preconditioner (multigrid.py:163-182, opfilt_tt.py:76-93) in one launch */
+int pl_alm_splice_fl(int lmax_lo, const double *alm_lo, int lmax_hi, const double *alm_hi, const double *fl_hi, int lsplit, double *out,
+                     void *stream);
 /* Scalar products and the updates they scale in ONE launch, over nf <= 3 fields (host arrays of nf device pointers / band-limits):
  *   parts1 = <a, b1>, parts2 = <a, b2> (b2 given), left in parts*_dev as pl_alm_dot leaves them (summed over the fields);
  *   c = parts2 / parts1 (b2 given) or parts1 / den_parts_dev (den given; exactly one of b2, den_parts_dev);

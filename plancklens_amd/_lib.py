@@ -13,7 +13,7 @@ _LIB = None
 SYMBOLS = ['pl_version', 'pl_last_error', 'pl_device_count', 'pl_plan_create', 'pl_plan_fork', 'pl_plan_destroy', 'pl_plan_npix',
            'pl_plan_nalm', 'pl_plan_bytes', 'pl_alm2map', 'pl_alm2map_grad', 'pl_alm2map_pair', 'pl_alm2map_batch2', 'pl_map2alm', 'pl_plan_phase_doubles', 'pl_legendre_synth', 'pl_legendre_synth_grad',
            'pl_legendre_anal', 'pl_phase2map', 'pl_map2phase', 'pl_almxfl', 'pl_alm2cl', 'pl_alm_copy', 'pl_axpy',
-           'pl_alm_dot', 'pl_axpy_dev', 'pl_alm_splice', 'pl_cg_dot_axpy', 'pl_almxfl_add', 'pl_template_project', 'pl_cg_fwd_tt', 'pl_cg_fwd_pp', 'pl_gemv', 'pl_copy_slim',
+           'pl_alm_dot', 'pl_axpy_dev', 'pl_alm_splice', 'pl_alm_splice_fl', 'pl_cg_dot_axpy', 'pl_almxfl_add', 'pl_template_project', 'pl_cg_fwd_tt', 'pl_cg_fwd_pp', 'pl_gemv', 'pl_copy_slim',
            'pl_map_mul', 'pl_map_cmul', 'pl_qe_lens_product', 'pl_fma64_peak_tflops', 'pl_fma64_rate_tflops', 'pl_profile_enable', 'pl_profile_read']
 
 PL_HOST, PL_DEVICE = 0, 1
@@ -61,6 +61,7 @@ def lib():
     L.pl_alm_dot.argtypes = [i32, i32, vp, vp, i32, vp, vp]
     L.pl_axpy_dev.argtypes = [i64, vp, vp, dbl, vp, vp, vp]
     L.pl_alm_splice.argtypes = [i32, vp, i32, vp, i32, vp, vp]
+    L.pl_alm_splice_fl.argtypes = [i32, vp, i32, vp, vp, i32, vp, vp]
     L.pl_cg_dot_axpy.argtypes = [i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, dbl, vp, vp, dbl, vp, vp]
     L.pl_almxfl_add.argtypes = [i32, vp, vp, vp, i32, vp, vp]
     L.pl_gemv.argtypes = [i32, i32, i64, vp, vp, vp, vp]

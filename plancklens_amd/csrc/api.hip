@@ -37,7 +37,8 @@ void launch_axpy_dev(int64_t n, const double *num, const double *den, double sig
 void launch_cg_fused(int nf, const int *lmax, int lmin, const double *const *a, const double *const *b1, const double *const *b2, double *parts1,
                      double *parts2, const double *den, double *const *y1, const double *const *x1, double sign1, double *const *y2,
                      const double *const *x2, double sign2, unsigned *bar, hipStream_t st);
-void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st);
+void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st,
+                       const double *fl_hi = nullptr);
 void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st);
 void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st);
 void launch_gemv(int nrows, int ncols, int64_t lda, const double *A, const double *x, double *y, hipStream_t st);
@@ -731,6 +732,14 @@ int pl_alm_splice(int lmax_lo, const double *alm_lo, int lmax_hi, const double *
 {
     if (lsplit > lmax_lo || lsplit > lmax_hi || lmax_hi < 0) return fail("pl_alm_splice: lsplit exceeds a band-limit");
     launch_alm_splice(lmax_lo, alm_lo, lmax_hi, alm_hi, lsplit, out, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_alm_splice_fl(int lmax_lo, const double *alm_lo, int lmax_hi, const double *alm_hi, const double *fl_hi, int lsplit, double *out, void *stream)
+{
+    if (lsplit > lmax_lo || lsplit > lmax_hi || lmax_hi < 0 || !fl_hi) return fail("pl_alm_splice_fl: lsplit exceeds a band-limit, or null filter");
+    launch_alm_splice(lmax_lo, alm_lo, lmax_hi, alm_hi, lsplit, out, static_cast<hipStream_t>(stream), fl_hi);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -456,14 +456,23 @@ __global__ __launch_bounds__(256) void k_gemv(int nrows, int ncols, int64_t lda,
 }
 
 // out (band-limit lmax_hi) = alm_lo for l <= lsplit, alm_hi above (util_alm.py:8-24)
+// fl_hi (optional, lmax_hi + 1 entries): the high part is fl_hi[l] * alm_hi -- the diagonal preconditioner of pre_op_split's high
+// multipoles (multigrid.py:163-182 with opfilt_tt.py:76-93) applied on the way
 __global__ void k_alm_splice(int lmax_lo, const double2 *__restrict__ lo, int lmax_hi, const double2 *__restrict__ hi, int lsplit,
-                             double2 *__restrict__ out)
+                             double2 *__restrict__ out, const double *__restrict__ fl_hi)
 {
     const int m = blockIdx.y;
     const int64_t bh = (int64_t)m * (2 * lmax_hi + 1 - m) / 2;
     const int64_t bl = (int64_t)m * (2 * lmax_lo + 1 - m) / 2;
-    for (int l = m + blockIdx.x * blockDim.x + threadIdx.x; l <= lmax_hi; l += gridDim.x * blockDim.x)
-        out[bh + l] = (l <= lsplit) ? lo[bl + l] : hi[bh + l];
+    for (int l = m + blockIdx.x * blockDim.x + threadIdx.x; l <= lmax_hi; l += gridDim.x * blockDim.x) {
+        double2 v;
+        if (l <= lsplit) v = lo[bl + l];
+        else {
+            v = hi[bh + l];
+            if (fl_hi) { v.x *= fl_hi[l]; v.y *= fl_hi[l]; }
+        }
+        out[bh + l] = v;
+    }
 }
 
 // out = a + f_l b (fwd_op: N-part + S^-1 x, opfilt_tt.py:67-73); out may alias a
@@ -557,10 +566,11 @@ void launch_gemv(int nrows, int ncols, int64_t lda, const double *A, const doubl
     if (vec) hipLaunchKernelGGL(k_gemv<2>, dim3((nrows + 3) / 4), dim3(256), 0, st, nrows, ncols, lda, A, x, y);
     else hipLaunchKernelGGL(k_gemv<1>, dim3((nrows + 3) / 4), dim3(256), 0, st, nrows, ncols, lda, A, x, y);
 }
-void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st)
+void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st,
+                       const double *fl_hi)
 {
     hipLaunchKernelGGL(k_alm_splice, dim3(4, lmax_hi + 1), dim3(256), 0, st, lmax_lo, reinterpret_cast<const double2 *>(lo), lmax_hi,
-                       reinterpret_cast<const double2 *>(hi), lsplit, reinterpret_cast<double2 *>(out));
+                       reinterpret_cast<const double2 *>(hi), lsplit, reinterpret_cast<double2 *>(out), fl_hi);
 }
 void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st)
 {

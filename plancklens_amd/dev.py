@@ -202,6 +202,16 @@ def alm_splice(alm_lo, alm_hi, lsplit):
     return out
 
 
+def alm_splice_fl(alm_lo, alm_hi, fl_hi, lsplit):
+    """alm_lo for l <= lsplit, fl_hi[l] * alm_hi above; band-limit of alm_hi (pl_alm_splice_fl)."""
+    lmax_lo, lmax_hi = Alm.getlmax(alm_lo.numel()), Alm.getlmax(alm_hi.numel())
+    assert lmax_lo >= lsplit and lmax_hi >= lsplit, (lmax_lo, lmax_hi, lsplit)
+    out = torch.empty_like(alm_hi)
+    _lib.check(_lib.lib().pl_alm_splice_fl(lmax_lo, alm_lo.data_ptr(), lmax_hi, alm_hi.data_ptr(), fl_dev(fl_hi, lmax_hi).data_ptr(),
+                                          int(lsplit), out.data_ptr(), stream_ptr()))
+    return out
+
+
 def almxfl_add(a, b, fl, out=None):
     """a + f_l b in one pass (pl_almxfl_add); out may be a."""
     lmax = Alm.getlmax(a.numel())

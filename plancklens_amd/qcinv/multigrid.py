@@ -138,6 +138,10 @@ class pre_op_split(object):
     def calc(self, talm):
         self.iter += 1
         talm_low = self.pre_op_low(util_alm.alm_copy(talm, lmax=self.lsplit))
+        if hasattr(self.pre_op_hgh, 'splice_above') and _lmax_of(talm) == self.lmax:
+            ret = self.pre_op_hgh.splice_above(talm_low, talm, self.lsplit)  # diagonal high-l part applied inside the splice
+            if ret is not None:
+                return ret
         # preconditioners do not modify their argument (cd_solve's contract): no copy when the band-limit already matches
         talm_hgh = self.pre_op_hgh(talm if _lmax_of(talm) == self.lmax else util_alm.alm_copy(talm, lmax=self.lmax))
         return util_alm.alm_splice(talm_low, talm_hgh, self.lsplit)

@@ -103,6 +103,14 @@ class pre_op_diag(object):
     def calc(self, alm):
         return _apply_2x2(self.flmat, alm)
 
+    def splice_above(self, alm_low, alm, lsplit):
+        """alm_low for l <= lsplit, this preconditioner applied to alm above: pre_op_split's result in one launch per field
+        (None: not here -- host vectors, or E-B coupling in the spectra)"""
+        fm = self.flmat
+        if np.any(fm[:, 0, 1]) or np.any(fm[:, 1, 0]) or not (isinstance(alm.elm, torch.Tensor) and alm.elm.is_cuda):
+            return None
+        return eblm([dev.alm_splice_fl(alm_low.elm, alm.elm, fm[:, 0, 0], lsplit), dev.alm_splice_fl(alm_low.blm, alm.blm, fm[:, 1, 1], lsplit)])
+
 
 def pre_op_dense(lmax, fwd_op, cache_fname=None):
     return dense.pre_op_dense_pp(lmax, fwd_op, cache_fname=cache_fname)

@@ -112,6 +112,12 @@ class pre_op_diag(object):
     def calc(self, talm):
         return dev.almxfl(talm, self.filt)
 
+    def splice_above(self, alm_low, talm, lsplit):
+        """alm_low for l <= lsplit, this preconditioner applied to talm above: pre_op_split's result in one launch (None: not here)"""
+        if not (isinstance(talm, torch.Tensor) and talm.is_cuda and talm.dtype == torch.complex128 and alm_low.dtype == torch.complex128):
+            return None
+        return dev.alm_splice_fl(alm_low, talm, self.filt, lsplit)
+
 
 def pre_op_dense(lmax, fwd_op, cache_fname=None):
     return dense.pre_op_dense_tt(lmax, fwd_op, cache_fname=cache_fname)

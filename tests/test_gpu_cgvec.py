@@ -57,6 +57,10 @@ def test_alm_splice_and_copy(lmax_lo, lmax_hi, lsplit):
     assert np.array_equal(ref, got)
     if lsplit < lmax_hi:
         assert np.array_equal(util_alm.alm_copy(hi, lsplit), dev.to_host(util_alm.alm_copy(dev.to_dev(hi), lsplit)))
+    # pl_alm_splice_fl: the diagonal high-l preconditioner applied inside the splice = almxfl, then splice (bit-identical)
+    fl = rng.uniform(0.5, 2., lmax_hi + 1)
+    two = util_alm.alm_splice(dev.to_dev(lo), dev.almxfl(dev.to_dev(hi), fl), lsplit)
+    assert np.array_equal(dev.to_host(two), dev.to_host(dev.alm_splice_fl(dev.to_dev(lo), dev.to_dev(hi), fl, lsplit)))
 
 
 @pytest.mark.parametrize('nfields', [1, 2, 3])
