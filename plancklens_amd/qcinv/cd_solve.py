@@ -36,13 +36,17 @@ class cache_mem(dict):
             del self[key]
 
 
-def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=25, x_is_zero=False):
+ROUNDOFF = 25  # iterations between residual refreshes (cd_solve.py:35)
+
+
+def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=ROUNDOFF, x_is_zero=False, b_scratch=False):
     """Solves fwd_op(x) = b in place on x by preconditioned conjugate directions; returns the iteration count.
 
         fwd_op, the pre_ops and dot_op must not modify their arguments.  `tr` selects how many past search
         directions each new one is orthogonalised against (tr_cg: the last one).  The residual is recomputed
         from scratch every `roundoff` iterations.  x_is_zero: the caller guarantees x = 0 on entry (the nested
-        multigrid solves), which saves the first fwd_op.
+        multigrid solves), which saves the first fwd_op.  b_scratch (with x_is_zero): b may be overwritten and the solve ends
+        before the first residual refresh -- b itself becomes the residual.
 
         With a single preconditioner and a dot_op that offers `dev(a, b)` (a 0-dim device tensor) the step lengths
         stay on the device: no host synchronisation inside an iteration, same arithmetic.  If the dot_op also offers
@@ -60,7 +64,10 @@ def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=
     fused = on_dev and hasattr(dot_op, 'axpy') and hasattr(dot_op, 'parts')
     merged = fused and hasattr(dot_op, 'step') and hasattr(dot_op, 'ortho') and os.environ.get('PLENS_CG_MERGED', '1') != '0'
     one_launch = os.environ.get('PLENS_CG_ONE_LAUNCH', '0') == '1'
-    residual = b * 1.0 if x_is_zero else b - fwd_op(x)
+    if x_is_zero and b_scratch:
+        residual, b = b, None
+    else:
+        residual = b * 1.0 if x_is_zero else b - fwd_op(x)
     searchdirs = [op(residual) for op in pre_ops]
     it = 0
     while not criterion(it, x, residual):
@@ -78,6 +85,7 @@ def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=
             cache.store(it, [dTAd, searchdirs, searchfwds])
             it += 1
             if fresh_residual:
+                assert b is not None, 'b_scratch: the solve ran into a residual refresh'
                 residual = b - fwd_op(x)
             searchdirs = [op(residual) for op in pre_ops]
             for titer in range(tr(it), it):
@@ -104,6 +112,7 @@ def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=
         cache.store(it, [dTAd_inv, searchdirs, searchfwds])
         it += 1
         if np.mod(it, roundoff) == 0:
+            assert b is not None, 'b_scratch: the solve ran into a residual refresh'
             residual = b - fwd_op(x)
         else:
             for q, alpha in zip(searchfwds, alphas):

@@ -229,8 +229,12 @@ class pre_op_multigrid(object):
         monitor = cd_monitors.monitor_basic(self.opfilt.dot_op(), iter_max=self.iter_max, eps_min=self.eps_min, logger=self.logger,
                                             quiet=bool(self.quiet is not None and self.quiet()))
         soltn = _like(talm, [torch.zeros_like(p) for p in _parts(talm)]) if all(isinstance(p, torch.Tensor) for p in _parts(talm)) else talm * 0.0
+        # the right-hand side is a private copy: with fewer iterations than the residual refresh period cd_solve may use it as
+        # its residual (one copy less); a solution at the band-limit of the input needs no splice
         cd_solve.cd_solve(soltn, util_alm.alm_copy(talm, lmax=self.lmax), self.fwd_op, self.pre_ops, self.opfilt.dot_op(),
-                          monitor, tr=self.tr, cache=self.cache, x_is_zero=True)
+                          monitor, tr=self.tr, cache=self.cache, x_is_zero=True, b_scratch=self.iter_max < cd_solve.ROUNDOFF)
+        if _lmax_of(talm) == self.lmax:
+            return soltn
         return util_alm.alm_splice(soltn, talm, self.lmax)
 
 
