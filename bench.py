@@ -130,14 +130,22 @@ def launch_ranks(n, argv):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else sys.stderr))
+    # poll all ranks: one that dies leaves the others waiting in the rendezvous or a collective (up to 10 minutes) -- end them at once
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
-    if rc:  # one rank failed: the others may be stuck in a collective
+    live = list(procs)
+    while live and not rc:
+        time.sleep(0.2)
+        for p in list(live):
+            if p.poll() is not None:
+                live.remove(p)
+                rc = rc or p.returncode
+    if rc:
+        time.sleep(2.0)  # let the failing rank's siblings print their own errors, if any
         for p in procs:
             if p.poll() is None:
                 p.kill()
+        for p in procs:
+            p.wait()
     return rc
 
 
@@ -272,6 +280,9 @@ def stub_rank(args, rank, world):
     """Launcher self-test (PLBENCH_STUB=1, tests/test_bench_launcher.py): gloo on CPU, no GPU work, no number."""
     import torch
     import torch.distributed as dist
+    if os.environ.get('PLBENCH_STUB_FAIL_RANK') == str(rank):  # a rank that dies before the rendezvous (launcher test)
+        sys.stderr.write('bench.py stub: rank %d fails on request\n' % rank)
+        return 3
     if world > 1:
         dist.init_process_group(backend='gloo')
     for _ in range(args.warmup + args.steps):

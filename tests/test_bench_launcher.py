@@ -36,3 +36,16 @@ def test_single_rank_and_launcher_mismatch():
     # under an external launcher WORLD_SIZE must agree with --gpus: fail loudly instead of silently running on one GPU
     rc, out, err = _run(['--gpus', '4'], {'RANK': '0', 'WORLD_SIZE': '1', 'LOCAL_RANK': '0'})
     assert rc != 0 and 'WORLD_SIZE' in err and out.strip() == ''
+
+
+def test_launcher_ends_the_job_when_a_rank_dies(tmp_path):
+    """A rank that exits with an error must end the whole job promptly (its siblings would wait in the rendezvous for minutes)."""
+    import time
+    env = dict(os.environ, PLBENCH_STUB='1', PLBENCH_STUB_FAIL_RANK='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0
+    assert time.time() - t0 < 60
