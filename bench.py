@@ -311,6 +311,9 @@ def run_rank(args):
     import torch
     import torch.distributed as dist
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU path)'
+    if local_rank >= torch.cuda.device_count():  # (device_count does not initialise the GPU)
+        sys.stderr.write('bench.py: rank %d of %d has no GPU of its own (%d visible): one rank per GPU\n' % (rank, world, torch.cuda.device_count()))
+        return 2
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or ('RANK' in os.environ and os.environ.get('PLENS_DIST_FORCE', '0') == '1')
     if use_dist:  # (PLENS_DIST_FORCE=1 under a launcher: RCCL collectives with a single rank, tests/test_gpu_bench.py)
