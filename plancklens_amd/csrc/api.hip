@@ -221,7 +221,9 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
     // kernel.  PLSHTS_FFT_LEGACY=1 sends every pair to the generic kernel.
     DevFFT &F = p->F;
     const bool all_legacy = getenv("PLSHTS_FFT_LEGACY") && atoi(getenv("PLSHTS_FFT_LEGACY")) != 0;
-    std::vector<int> K2of(nside + 1, 0), MofA(nside + 1, 0), clsA(nside + 1, -1);
+    std::vector<int> K2of(nside + 1, 0), MofA(nside + 1, 0), clsA(nside + 1, -1), splitA(nside + 1, 0);
+    // smallest half-size for which a Bluestein ring is split into two half-size convolutions (PLSHTS_FFT_SPLIT: 0 = never)
+    const int split_min = getenv("PLSHTS_FFT_SPLIT") ? atoi(getenv("PLSHTS_FFT_SPLIT")) : 1024;
     {
         std::vector<int> mlmax(nside + 1, 0);
         for (int i = 0; i < g.npairs; ++i) {
@@ -240,6 +242,13 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
             if ((q & (q - 1)) == 0) { clsA[q] = cls_of(q); continue; }  // the ring's own sub-DFT length
             int Na = 256;
             while (Na < q + 2 * K + 1) Na <<= 1;       // only the 2 K + 1 in-band bins are non-zero (synthesis) / needed (analysis)
+            // Two half-size convolutions instead (ringfft.hip, SPLIT): output / input halves [0, Nh / 2) and [Nh / 2, q) with
+            // Nh = Na / 2 -- 3 transforms of size Nh for 2 of size Na, and the only register route for Na = 2 * (largest class)
+            const int Nh = Na / 2, hh = Nh / 2;
+            if (split_min > 0 && Nh >= split_min && cls_of(Nh) >= 0 && q > hh && q <= Nh && hh + 2 * K + 1 <= Nh && q - hh + 2 * K + 1 <= Nh) {  // (q <= Nh: a thread owns the pixels tl + G j, j < 8)
+                clsA[q] = cls_of(Nh); MofA[q] = Nh; splitA[q] = 1;
+                continue;
+            }
             clsA[q] = cls_of(Na);
             if (clsA[q] >= 0) MofA[q] = Na;
         }
@@ -251,11 +260,11 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
         for (int q = 1; q <= nside; ++q)
             if ((q & (q - 1)) == 0 && npairs_q[q] < 8) clsA[q] = -1;
     }
-    std::vector<int> listA[kFftClasses], dirA[kFftClasses], legacyA;
+    std::vector<int> listA[kFftClasses], dirA[kFftClasses], splA[kFftClasses], legacyA;
     for (int i = g.npairs - 1; i >= 0; --i) {  // longest rings first
         const int q = g.nphi[i] / 4;
         const bool direct = (q & (q - 1)) == 0;
-        if (clsA[q] >= 0) (direct ? dirA : listA)[clsA[q]].push_back(i); else legacyA.push_back(i);
+        if (clsA[q] >= 0) (direct ? dirA : (splitA[q] ? splA : listA))[clsA[q]].push_back(i); else legacyA.push_back(i);
     }
     std::vector<int> Mof(nside + 1, 0), qlist, qlistA;
     std::vector<int64_t> woff(nside + 1, 0), coff(nside + 1, 0), coffA(nside + 1, 0);
@@ -266,7 +275,7 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
         if ((q & (q - 1)) == 0) { if (generic && q > Lmax) Lmax = q; continue; }
         woff[q] = nw; nw += q;
         qlist.push_back(q);
-        if (MofA[q]) { coffA[q] = ncA; ncA += MofA[q]; if (MofA[q] > M2max) M2max = MofA[q]; qlistA.push_back(q); }
+        if (MofA[q]) { coffA[q] = ncA; ncA += (splitA[q] ? 2 : 1) * MofA[q]; if (MofA[q] > M2max) M2max = MofA[q]; qlistA.push_back(q); }
         if (!generic) continue;
         int M = 2;
         while (M < 2 * q - 1) M <<= 1;
@@ -276,7 +285,7 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
     F.Lmax = Lmax;
     F.Mtw = Lmax < 2 ? 2 : Lmax;
     if (F.Mtw < M2max) F.Mtw = M2max;
-    for (int c = 0; c < kFftClasses; ++c) if ((!listA[c].empty() || !dirA[c].empty()) && F.Mtw < (256 << c)) F.Mtw = 256 << c;
+    for (int c = 0; c < kFftClasses; ++c) if ((!listA[c].empty() || !dirA[c].empty() || !splA[c].empty()) && F.Mtw < (256 << c)) F.Mtw = 256 << c;
     if ((size_t)Lmax * 16 > 160 * 1024 - 256) { pl_plan_destroy(p); return fail("ring FFT workspace exceeds the 160 KiB LDS of a CU"); }
     {   // LDS twiddle tables of the largest generic transform (radix-8 passes + one radix-4/2 tail), if they fit beside it
         int k = 0; while ((1 << k) < Lmax) ++k;
@@ -297,12 +306,13 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
     rc = dalloc(&tw, F.Mtw) || dalloc(&chirp, 2 * nw) || dalloc(&filt, 2 * nc) || dalloc(&filtA, 2 * ncA) ||
          upload(p, Mof, &F.Mof) || upload(p, woff, &F.woff) || upload(p, coff, &F.coff) || upload(p, K2of, &F.K2of) ||
          upload(p, qlist, &qlist_dev) || upload(p, qlistA, &qlistA_dev) ||
-         upload(p, MofA, &F.A.Mof) || upload(p, coffA, &F.A.coff) || upload(p, legacyA, &F.A.legacy_pairs);
+         upload(p, MofA, &F.A.Mof) || upload(p, coffA, &F.A.coff) || upload(p, splitA, &F.A.split) || upload(p, legacyA, &F.A.legacy_pairs);
     F.A.legacy_n = (int)legacyA.size();
     for (int c = 0; c < kFftClasses && !rc; ++c) {
-        rc = upload(p, listA[c], &F.A.cls_pairs[c]) || upload(p, dirA[c], &F.A.dir_pairs[c]);
+        rc = upload(p, listA[c], &F.A.cls_pairs[c]) || upload(p, dirA[c], &F.A.dir_pairs[c]) || upload(p, splA[c], &F.A.split_pairs[c]);
         F.A.cls_n[c] = (int)listA[c].size();
         F.A.dir_n[c] = (int)dirA[c].size();
+        F.A.split_n[c] = (int)splA[c].size();
     }
     if (rc) { pl_plan_destroy(p); return 1; }
     F.tw = reinterpret_cast<const double2 *>(tw);

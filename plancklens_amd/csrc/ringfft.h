@@ -17,8 +17,13 @@ struct FftSide {
     int cls_n[kFftClasses];
     const int *dir_pairs[kFftClasses]; // ... and the rings whose own sub-DFT length is N (q == N, a power of two)
     int dir_n[kFftClasses];
+    // split Bluestein rings: the convolution of size 2 N runs as two halves of size N = 256 << c sharing one transform -- synthesis
+    // 1 forward + 2 inverse (output halves j1 < N / 2 and j1 >= N / 2), analysis 2 forward + 1 inverse (input halves)
+    const int *split_pairs[kFftClasses];
+    int split_n[kFftClasses];
     const int *Mof;          // [nside + 1] Bluestein convolution size of q in its class (0: direct, or generic list)
-    const int64_t *coff;     // [nside + 1] offset of q's natural-order filter spectrum (Mof[q] entries)
+    const int64_t *coff;     // [nside + 1] offset of q's natural-order filter spectrum (Mof[q] entries; split rings: two spectra)
+    const int *split;        // [nside + 1] 1: q is a split ring
     const double2 *filt;
 };
 

@@ -689,7 +689,10 @@ __device__ __forceinline__ FastBin fast_bin(bool blue, int idx, int N, int q, in
 // per thread (two workgroups per CU).  The sub-DFT inputs are band-limited (|c| <= K), so the Bluestein classes use the
 // same convolution sizes and filter tables as the analysis (side A lists and tables).
 // WGT: every pixel is multiplied by wgt (one map for all components) on the way out -- the inverse-noise weighting of the CG operators.
-template <int N, bool BLUE, bool WGT = false>
+// SPLIT (Bluestein only): the ring's convolution of size 2 N as two of size N that share the forward transform -- pixels
+// j1 < N / 2 from the first filter spectrum, j1 >= N / 2 from the second (thread tl owns j1 = tl + G j either way: j < 4 and
+// j >= 4).  The forward spectrum waits in a thread-private LDS slot while the first half is transformed back.
+template <int N, bool BLUE, bool WGT = false, bool SPLIT = false>
 __global__ __launch_bounds__(N / 8, 2) void k_phase2map_fast(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim,
                                                              int ncomp, const double *__restrict__ phase, double *__restrict__ map,
                                                              const double *__restrict__ wgt)
@@ -753,7 +756,32 @@ __global__ __launch_bounds__(N / 8, 2) void k_phase2map_fast(DevPlan P, DevFFT F
     // the four sub-DFTs, in place
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) {
-        if (blue) {
+        if constexpr (SPLIT) {
+            fft8<N, true>(d[k2], lds, tl0, tw);
+            double2 *stash = lds + N;  // thread-private slots (the forward spectrum, then the first half of the pixels): no barrier
+            {
+                const int tl = fresh(tl0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { stash[tl + G * j] = d[k2][j]; d[k2][j] = cmul(d[k2][j], filt[tl + G * j]); }
+            }
+            fft8<N, false>(d[k2], lds, tl0, tw);
+            {
+                const int tl = fresh(tl0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double2 a = stash[tl + G * j];
+                    if (j < 4) stash[tl + G * j] = d[k2][j];  // pixels j1 < N / 2 wait in the slots the spectrum has left
+                    d[k2][j] = cmul(a, filt[N + tl + G * j]);
+                    if ((j & 1) == 1) phase_fence();
+                }
+            }
+            fft8<N, false>(d[k2], lds, tl0, tw);
+            {
+                const int tl = fresh(tl0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { d[k2][j + 4] = d[k2][j]; d[k2][j] = stash[tl + G * j]; }
+            }
+        } else if (blue) {
             fft8<N, true>(d[k2], lds, tl0, tw);
             const int tl = fresh(tl0);
 #pragma unroll
@@ -798,7 +826,9 @@ __global__ __launch_bounds__(N / 8, 2) void k_phase2map_fast(DevPlan P, DevFFT F
 // pixel j = j1 + q j2, bin k = 4 k1 + k2: V_(4 k1 + k2) = sum_j1 e^{2 pi i j1 k1 / q} [e^{2 pi i j1 k2 / n} sum_j2 i^(j2 k2) conj(z)_(j1 + q j2)].
 // Sub-DFTs are processed as the pairs (k2 = 0, 2) and (1, 3) -- the mirror bin n - k of k2 lives in sub-DFT (4 - k2) mod 4,
 // so each pair is self-contained -- with the ring pixels loaded again for the second pair (coalesced, from L2).
-template <int N, bool BLUE>
+// SPLIT (Bluestein only): the convolution of size 2 N as two of size N that share the inverse transform -- the pixels j1 < N / 2
+// (the thread's points j < 4) and j1 >= N / 2 (j >= 4) are transformed separately, multiplied by their own filter spectra, added.
+template <int N, bool BLUE, bool SPLIT = false>
 __global__ __launch_bounds__(N / 8, 2) void k_map2phase_fast(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim,
                                                           int ncomp, const double *map, double *phase)
 {
@@ -892,7 +922,27 @@ __global__ __launch_bounds__(N / 8, 2) void k_map2phase_fast(DevPlan P, DevFFT F
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (blue) {
+            if constexpr (SPLIT) {
+                double2 hi[8] = {d[h][4], d[h][5], d[h][6], d[h][7], make_double2(0., 0.), make_double2(0., 0.), make_double2(0., 0.),
+                                 make_double2(0., 0.)};
+#pragma unroll
+                for (int j = 4; j < 8; ++j) d[h][j] = make_double2(0., 0.);
+                fft8<N, true>(d[h], lds, tl, tw);
+                phase_fence();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[h][j] = cmul(d[h][j], filt[(N - (tl + G * j)) & (N - 1)]);
+                fft8<N, true>(hi, lds, tl, tw);
+                phase_fence();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[h][j] = cadd(d[h][j], cmul(hi[j], filt[N + ((N - (tl + G * j)) & (N - 1))]));
+                fft8<N, false>(d[h], lds, tl, tw);
+                phase_fence();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
+                    d[h][j] = cmul(d[h][j], chirp[b.cabs]);
+                }
+            } else if (blue) {
                 fft8<N, true>(d[h], lds, tl, tw);
                 phase_fence();
 #pragma unroll
@@ -923,20 +973,29 @@ __global__ __launch_bounds__(NT) void k_bluestein_setup2(DevFFT F, const int *__
     const FftSide &sd = F.A;
     const int M = sd.Mof[q];
     const int Kn = F.K2of[q], Kp = F.K2of[q];
-    double2 *filt = filt_out + sd.coff[q];
-    for (int t = threadIdx.x; t < M; t += NT) ws[t] = make_double2(0., 0.);
-    __syncthreads();
-    for (int t = threadIdx.x; t < q + Kn + Kp; t += NT) {
-        const int dd = t - Kn;  // -Kn .. q - 1 + Kp
-        const long long t2 = ((long long)dd * dd) % (2LL * q);
-        const double2 w = cispi((double)t2 / (double)q);
-        ws[(dd + M) & (M - 1)] = cconj(w);
-    }
-    fft_dif_fwd<NT>(ws, M, nullptr, F.tw, F.Mtw);
-    const double inv = 1.0 / M;
-    for (int t = threadIdx.x; t < M; t += NT) {
-        const double2 v = ws[digit_reverse(t, M)];
-        filt[t] = make_double2(v.x * inv, v.y * inv);
+    // split rings: two spectra, of h_d for d in [-K, M / 2 - 1 + K] (first half of the pixels) and of h_(d + M / 2) for
+    // d in [-K, q - 1 - M / 2 + K] (the others)
+    const int nparts = sd.split[q] ? 2 : 1;
+    for (int part = 0; part < nparts; ++part) {
+        double2 *filt = filt_out + sd.coff[q] + (int64_t)part * M;
+        const int shift = part * (M / 2);
+        const int len = sd.split[q] ? (part == 0 ? M / 2 : q - M / 2) : q;  // pixels served by this spectrum
+        __syncthreads();
+        for (int t = threadIdx.x; t < M; t += NT) ws[t] = make_double2(0., 0.);
+        __syncthreads();
+        for (int t = threadIdx.x; t < len + Kn + Kp; t += NT) {
+            const int dd = t - Kn;  // -Kn .. len - 1 + Kp
+            const long long da = dd + shift;
+            const long long t2 = (da * da) % (2LL * q);
+            const double2 w = cispi((double)t2 / (double)q);
+            ws[(dd + M) & (M - 1)] = cconj(w);
+        }
+        fft_dif_fwd<NT>(ws, M, nullptr, F.tw, F.Mtw);
+        const double inv = 1.0 / M;
+        for (int t = threadIdx.x; t < M; t += NT) {
+            const double2 v = ws[digit_reverse(t, M)];
+            filt[t] = make_double2(v.x * inv, v.y * inv);
+        }
     }
 }
 
@@ -1100,16 +1159,41 @@ void fft_streams_destroy(FftStreams &fs)
 
 // One FFT stage = up to six independent kernels (five register classes + the generic kernel).  The biggest one runs on
 // the caller's stream, the others on the plan's side streams between a fork and a join event.
+template <int N>
+static hipError_t launch_split_class(const DevPlan &P, const DevFFT &F, int cls, bool synth, const int *mlim, int ncomp, const double *in,
+                                     double *out, hipStream_t st, const double *wgt)
+{
+    const int n = F.A.split_n[cls];
+    if (n == 0) return hipSuccess;
+    const size_t lds = (size_t)N * sizeof(double2) * (synth ? 2 : 1);  // synthesis: exchange buffer + the parked forward spectrum
+    static bool attr_done[kMaxDevices] = {};
+    const int dv = current_device();
+    if (!attr_done[dv]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map_fast<N, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * N * sizeof(double2)));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map_fast<N, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * N * sizeof(double2)));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_map2phase_fast<N, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(N * sizeof(double2)));
+        if (e != hipSuccess) return e;
+        attr_done[dv] = true;
+    }
+    const int *pairs = F.A.split_pairs[cls];
+    if (synth && wgt) hipLaunchKernelGGL((k_phase2map_fast<N, true, true, true>), dim3(n, ncomp), dim3(N / 8), lds, st, P, F, pairs, mlim, ncomp, in, out, wgt);
+    else if (synth) hipLaunchKernelGGL((k_phase2map_fast<N, true, false, true>), dim3(n, ncomp), dim3(N / 8), lds, st, P, F, pairs, mlim, ncomp, in, out, wgt);
+    else hipLaunchKernelGGL((k_map2phase_fast<N, true, true>), dim3(n, ncomp), dim3(N / 8), lds, st, P, F, pairs, mlim, ncomp, in, out);
+    return hipGetLastError();
+}
+
 static hipError_t launch_stage(const DevPlan &P, const DevFFT &F, const FftStreams &fs, bool synth, const int *mlim, int ncomp,
                                const double *in, double *out, hipStream_t st, const NinvProj &W)
 {
     const bool par = fs.ok && !(getenv("PLSHTS_FFT_SERIAL") && atoi(getenv("PLSHTS_FFT_SERIAL")) != 0);
-    // work items: (class c, Bluestein or direct); the one with the most work stays on the caller's stream
+    // work items w = 3 c + kind of class c (kind 0: direct, 1: Bluestein, 2: split Bluestein); the one with the most work stays
+    // on the caller's stream
+    auto count = [&](int w) { const int c = w / 3, k = w % 3; return k == 0 ? F.A.dir_n[c] : (k == 1 ? F.A.cls_n[c] : F.A.split_n[c]); };
     int big = -1;
     { int64_t best = -1;
-      for (int w = 0; w < 10; ++w) {
-          const int c = w >> 1, n = (w & 1) ? F.A.cls_n[c] : F.A.dir_n[c];
-          const int64_t work = (int64_t)n * (256 << c) * ((w & 1) ? 2 : 1);
+      for (int w = 0; w < 3 * kFftClasses; ++w) {
+          const int n = count(w);
+          const int64_t work = (int64_t)n * (256 << (w / 3)) * (w % 3 + 1);
           if (n > 0 && work > best) { best = work; big = w; }
       } }
     hipError_t e = hipSuccess;
@@ -1123,25 +1207,29 @@ static hipError_t launch_stage(const DevPlan &P, const DevFFT &F, const FftStrea
         joined[i] = true;
         return fs.s[i];
     };
+    const double *wgt = synth ? W.n_inv : nullptr;
     auto run = [&](int w) -> hipError_t {
-        const int c = w >> 1;
-        const bool blue = w & 1;
-        if ((blue ? F.A.cls_n[c] : F.A.dir_n[c]) == 0) return hipSuccess;
+        if (count(w) == 0) return hipSuccess;
         hipStream_t s = side(w);
         switch (w) {
-        case 9: return launch_fast_class<4096, true>(P, F, 4, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
-        case 8: return launch_fast_class<4096, false>(P, F, 4, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
-        case 7: return launch_fast_class<2048, true>(P, F, 3, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
-        case 6: return launch_fast_class<2048, false>(P, F, 3, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
-        case 5: return launch_fast_class<1024, true>(P, F, 2, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
-        case 4: return launch_fast_class<1024, false>(P, F, 2, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
-        case 3: return launch_fast_class<512, true>(P, F, 1, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
-        case 2: return launch_fast_class<512, false>(P, F, 1, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
-        case 1: return launch_fast_class<256, true>(P, F, 0, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
-        default: return launch_fast_class<256, false>(P, F, 0, synth, mlim, ncomp, in, out, s, synth ? W.n_inv : nullptr);
+        case 14: return launch_split_class<4096>(P, F, 4, synth, mlim, ncomp, in, out, s, wgt);
+        case 13: return launch_fast_class<4096, true>(P, F, 4, synth, mlim, ncomp, in, out, s, wgt);
+        case 12: return launch_fast_class<4096, false>(P, F, 4, synth, mlim, ncomp, in, out, s, wgt);
+        case 11: return launch_split_class<2048>(P, F, 3, synth, mlim, ncomp, in, out, s, wgt);
+        case 10: return launch_fast_class<2048, true>(P, F, 3, synth, mlim, ncomp, in, out, s, wgt);
+        case 9: return launch_fast_class<2048, false>(P, F, 3, synth, mlim, ncomp, in, out, s, wgt);
+        case 8: return launch_split_class<1024>(P, F, 2, synth, mlim, ncomp, in, out, s, wgt);
+        case 7: return launch_fast_class<1024, true>(P, F, 2, synth, mlim, ncomp, in, out, s, wgt);
+        case 6: return launch_fast_class<1024, false>(P, F, 2, synth, mlim, ncomp, in, out, s, wgt);
+        case 5: return launch_split_class<512>(P, F, 1, synth, mlim, ncomp, in, out, s, wgt);
+        case 4: return launch_fast_class<512, true>(P, F, 1, synth, mlim, ncomp, in, out, s, wgt);
+        case 3: return launch_fast_class<512, false>(P, F, 1, synth, mlim, ncomp, in, out, s, wgt);
+        case 2: return launch_split_class<256>(P, F, 0, synth, mlim, ncomp, in, out, s, wgt);
+        case 1: return launch_fast_class<256, true>(P, F, 0, synth, mlim, ncomp, in, out, s, wgt);
+        default: return launch_fast_class<256, false>(P, F, 0, synth, mlim, ncomp, in, out, s, wgt);
         }
     };
-    for (int w = 9; w >= 0 && e == hipSuccess; --w) e = run(w);  // longest transforms first
+    for (int w = 3 * kFftClasses - 1; w >= 0 && e == hipSuccess; --w) e = run(w);  // longest transforms first
     if (e == hipSuccess && F.A.legacy_n > 0) {
         hipStream_t s = big < 0 ? st : side(-1);
         e = synth ? launch_phase2map_legacy(P, F, mlim, ncomp, in, out, s, W) : launch_map2phase_legacy(P, F, mlim, ncomp, in, out, s, W);
