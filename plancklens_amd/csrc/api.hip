@@ -223,7 +223,7 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
     const bool all_legacy = getenv("PLSHTS_FFT_LEGACY") && atoi(getenv("PLSHTS_FFT_LEGACY")) != 0;
     std::vector<int> K2of(nside + 1, 0), MofA(nside + 1, 0), clsA(nside + 1, -1), splitA(nside + 1, 0);
     // smallest half-size for which a Bluestein ring is split into two half-size convolutions (PLSHTS_FFT_SPLIT: 0 = never)
-    const int split_min = getenv("PLSHTS_FFT_SPLIT") ? atoi(getenv("PLSHTS_FFT_SPLIT")) : 1024;
+    const int split_min = getenv("PLSHTS_FFT_SPLIT") ? atoi(getenv("PLSHTS_FFT_SPLIT")) : 512;
     {
         std::vector<int> mlmax(nside + 1, 0);
         for (int i = 0; i < g.npairs; ++i) {
