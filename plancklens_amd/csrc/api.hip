@@ -253,13 +253,8 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
             if (clsA[q] >= 0) MofA[q] = Na;
         }
     }
-    {   // a power-of-two ring length met by only a few ring pairs (the single cap rings q = 256, 512, ... below nside) is not
-        // worth a kernel launch of its own: those pairs join the generic list
-        std::vector<int> npairs_q(nside + 1, 0);
-        for (int i = 0; i < g.npairs; ++i) npairs_q[g.nphi[i] / 4] += 1;
-        for (int q = 1; q <= nside; ++q)
-            if ((q & (q - 1)) == 0 && npairs_q[q] < 8) clsA[q] = -1;
-    }
+    // (A power-of-two ring length below nside is met by a single ring pair per hemisphere pair; it still gets the launch of its
+    // direct class: left to the generic kernel those few long rings size its workgroups and LDS for every short polar ring.)
     std::vector<int> listA[kFftClasses], dirA[kFftClasses], splA[kFftClasses], legacyA;
     for (int i = g.npairs - 1; i >= 0; --i) {  // longest rings first
         const int q = g.nphi[i] / 4;
@@ -308,6 +303,8 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
          upload(p, qlist, &qlist_dev) || upload(p, qlistA, &qlistA_dev) ||
          upload(p, MofA, &F.A.Mof) || upload(p, coffA, &F.A.coff) || upload(p, splitA, &F.A.split) || upload(p, legacyA, &F.A.legacy_pairs);
     F.A.legacy_n = (int)legacyA.size();
+    F.A.legacy_qmax = 1;
+    for (int i : legacyA) if (g.nphi[i] / 4 > F.A.legacy_qmax) F.A.legacy_qmax = g.nphi[i] / 4;
     for (int c = 0; c < kFftClasses && !rc; ++c) {
         rc = upload(p, listA[c], &F.A.cls_pairs[c]) || upload(p, dirA[c], &F.A.dir_pairs[c]) || upload(p, splA[c], &F.A.split_pairs[c]);
         F.A.cls_n[c] = (int)listA[c].size();

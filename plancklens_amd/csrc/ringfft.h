@@ -13,6 +13,7 @@ constexpr int kFftClasses = 5;  // register-resident transform sizes N = 256 << 
 struct FftSide {
     const int *legacy_pairs; // generic LDS-resident kernel (short polar rings, aliased rings), longest rings first
     int legacy_n;
+    int legacy_qmax;         // longest quarter-ring of the generic list: sizes its workgroups (threads x points per thread >= qmax)
     const int *cls_pairs[kFftClasses]; // register-resident kernels, transform size N = 256 << c: Bluestein rings (q != N)
     int cls_n[kFftClasses];
     const int *dir_pairs[kFftClasses]; // ... and the rings whose own sub-DFT length is N (q == N, a power of two)

@@ -1087,7 +1087,7 @@ static hipError_t launch_m2p(const DevPlan &P, const DevFFT &F, const int *mlim,
 
 #define PL_FFT_DISPATCH(FN, ...)                                            \
     do {                                                                    \
-        const int ns = P.nside;                                             \
+        const int ns = F.A.legacy_qmax;  /* workgroup threads x points per thread cover the longest quarter-ring of the list */ \
         if (ns <= 256) return FN<256, 1>(__VA_ARGS__);                      \
         if (ns <= 512) return FN<256, 2>(__VA_ARGS__);                      \
         if (ns <= 1024) return FN<256, 4>(__VA_ARGS__);                     \
