@@ -1186,32 +1186,31 @@ static hipError_t launch_stage(const DevPlan &P, const DevFFT &F, const FftStrea
                                const double *in, double *out, hipStream_t st, const NinvProj &W)
 {
     const bool par = fs.ok && !(getenv("PLSHTS_FFT_SERIAL") && atoi(getenv("PLSHTS_FFT_SERIAL")) != 0);
-    // work items w = 3 c + kind of class c (kind 0: direct, 1: Bluestein, 2: split Bluestein); the one with the most work stays
-    // on the caller's stream
-    auto count = [&](int w) { const int c = w / 3, k = w % 3; return k == 0 ? F.A.dir_n[c] : (k == 1 ? F.A.cls_n[c] : F.A.split_n[c]); };
-    int big = -1;
-    { int64_t best = -1;
-      for (int w = 0; w < 3 * kFftClasses; ++w) {
-          const int n = count(w);
-          const int64_t work = (int64_t)n * (256 << (w / 3)) * (w % 3 + 1);
-          if (n > 0 && work > best) { best = work; big = w; }
-      } }
+    // Work items: w = 3 c + kind of class c (kind 0: direct, 1: Bluestein, 2: split Bluestein) and the generic list (w = nw).  Cost
+    // model: ring pairs x transform size x transforms per sub-DFT, plus a fixed latency (the short-ring kernels are latency-bound).
+    // The costliest item stays on the caller's stream; the others go, costliest first, to the side stream with the least work
+    // queued so far (longest-processing-time-first), so that no short kernel waits at the end of a queue and becomes the stage's tail.
+    constexpr int nw = 3 * kFftClasses;
+    auto count = [&](int w) { const int c = w / 3, k = w % 3; return w == nw ? F.A.legacy_n : (k == 0 ? F.A.dir_n[c] : (k == 1 ? F.A.cls_n[c] : F.A.split_n[c])); };
+    int order[nw + 1], nitems = 0;
+    int64_t cost[nw + 1];
+    for (int w = 0; w <= nw; ++w) {
+        cost[w] = 0;
+        if (count(w) == 0) continue;
+        cost[w] = w == nw ? (int64_t)F.A.legacy_n * F.A.legacy_qmax * 8 + (1 << 20)
+                          : (int64_t)count(w) * (256 << (w / 3)) * (w % 3 + 1) + (1 << 19);
+        order[nitems++] = w;
+    }
+    for (int a = 1; a < nitems; ++a)  // insertion sort, costliest first
+        for (int b = a; b > 0 && cost[order[b]] > cost[order[b - 1]]; --b) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
     hipError_t e = hipSuccess;
-    if (par) e = hipEventRecord(fs.fork, st);
-    int used = 0;
+    if (par && nitems > 1) e = hipEventRecord(fs.fork, st);
     bool joined[FftStreams::kN] = {false, false, false, false, false};
-    auto side = [&](int w) -> hipStream_t {
-        if (!par || w == big) return st;
-        const int i = used < FftStreams::kN ? used++ : (used++ % FftStreams::kN);  // more items than streams: share round-robin
-        if (!joined[i] && hipStreamWaitEvent(fs.s[i], fs.fork, 0) != hipSuccess) return st;
-        joined[i] = true;
-        return fs.s[i];
-    };
+    int64_t load[FftStreams::kN] = {0, 0, 0, 0, 0};
     const double *wgt = synth ? W.n_inv : nullptr;
-    auto run = [&](int w) -> hipError_t {
-        if (count(w) == 0) return hipSuccess;
-        hipStream_t s = side(w);
+    auto run = [&](int w, hipStream_t s) -> hipError_t {
         switch (w) {
+        case nw: return synth ? launch_phase2map_legacy(P, F, mlim, ncomp, in, out, s, W) : launch_map2phase_legacy(P, F, mlim, ncomp, in, out, s, W);
         case 14: return launch_split_class<4096>(P, F, 4, synth, mlim, ncomp, in, out, s, wgt);
         case 13: return launch_fast_class<4096, true>(P, F, 4, synth, mlim, ncomp, in, out, s, wgt);
         case 12: return launch_fast_class<4096, false>(P, F, 4, synth, mlim, ncomp, in, out, s, wgt);
@@ -1229,10 +1228,19 @@ static hipError_t launch_stage(const DevPlan &P, const DevFFT &F, const FftStrea
         default: return launch_fast_class<256, false>(P, F, 0, synth, mlim, ncomp, in, out, s, wgt);
         }
     };
-    for (int w = 3 * kFftClasses - 1; w >= 0 && e == hipSuccess; --w) e = run(w);  // longest transforms first
-    if (e == hipSuccess && F.A.legacy_n > 0) {
-        hipStream_t s = big < 0 ? st : side(-1);
-        e = synth ? launch_phase2map_legacy(P, F, mlim, ncomp, in, out, s, W) : launch_map2phase_legacy(P, F, mlim, ncomp, in, out, s, W);
+    for (int a = 0; a < nitems && e == hipSuccess; ++a) {
+        const int w = order[a];
+        hipStream_t s = st;
+        if (par && a > 0) {
+            int best = 0;
+            for (int i = 1; i < FftStreams::kN; ++i) if (load[i] < load[best]) best = i;
+            if (joined[best] || hipStreamWaitEvent(fs.s[best], fs.fork, 0) == hipSuccess) {
+                joined[best] = true;
+                load[best] += cost[w];
+                s = fs.s[best];
+            }
+        }
+        e = run(w, s);
     }
     for (int i = 0; i < FftStreams::kN; ++i) {
         if (!joined[i]) continue;
