@@ -6,10 +6,15 @@
 //   * Register-resident kernels (k_phase2map_fast / k_map2phase_fast, second half of this file) serve every ring without
 //     aliasing whose transform size N is 256 ... 4096: Stockham autosort radix-8 passes in registers, one swizzled N-point
 //     LDS exchange buffer; q a power of two runs directly (N = q), any other q as a band-limited Bluestein convolution of
-//     size N >= q + 2 K + 1 (K = in-band sub-DFT bins) with per-q filter spectra precomputed at plan creation.
+//     size N >= q + 2 K + 1 (K = in-band sub-DFT bins) with per-q filter spectra precomputed at plan creation; a ring that
+//     would need twice the class size runs as two half-size convolutions sharing one transform (SPLIT: 3 transforms of size
+//     N for 2 of size 2 N).  The synthesis kernels can multiply the pixels by a weight map on the way out (WGT: the
+//     inverse-noise weighting of the CG operators).
 //   * The generic kernel (k_phase2map / k_map2phase, first half) keeps a whole sub-DFT in LDS (radix-8/4/2 DIF forward /
 //     DIT inverse, Bluestein size M >= 2 q - 1 with digit-reversed filter spectrum): short polar rings, aliased rings
-//     (lmax >= 2 nside, coarse multigrid levels), and the reference route the register kernels are tested against.
+//     (lmax >= 2 nside, coarse multigrid levels), and the reference route the register kernels are tested against.  Its
+//     workgroups are sized by the longest ring of its list; when the LDS allows, the four sub-DFTs of a ring are transformed
+//     side by side (B4).  It also carries the CG's pixel-space operator with template marginalisation (NinvProj).
 // Synthesis gathers the spectrum bins straight from the phase array and finishes with the radix-4 butterfly while
 // writing pixels; analysis is the exact transpose.
 //
