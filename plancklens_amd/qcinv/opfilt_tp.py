@@ -259,10 +259,43 @@ class alm_filter_ninv(object):
         alm.elm.copy_(ret.elm)
         alm.blm.copy_(ret.blm)
 
+    def _proj_matrices(self):
+        """All T template modes as one device matrix P (nmodes x npix) and R = (P^t N^-1 P)^-1 P^t N^-1: the projection is
+        c = P^t (N^-1 t), t -= R^t c on the device (nothing comes back to the host inside a CG iteration)."""
+        if len(self.templates_t) == 0:
+            return None, None
+        if getattr(self, '_pmat', None) is None:
+            rows = []
+            for t in self.templates_t:
+                for i in range(t.nmodes):
+                    row = torch.ones_like(self.n_inv[0])
+                    t.apply_mode(row, i)
+                    rows.append(row)
+            self._pmat = torch.stack(rows).contiguous()
+            pinv = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64)
+            self._rmat = torch.mm(pinv, self._pmat * self.n_inv[0].unsqueeze(0)).contiguous()
+        return self._pmat, self._rmat
+
+    def one_call_ok(self, alm):
+        """pl_cg_fwd_tt + pl_cg_fwd_pp apply: device vectors, (TT, QQ = UU) noise, one polarization beam, the module's transforms"""
+        same_b = self.b_transf_b is self.b_transf_e or np.array_equal(self.b_transf_e, self.b_transf_b)
+        nmodes = sum(t.nmodes for t in self.templates_t)
+        return (isinstance(alm.tlm, torch.Tensor) and alm.tlm.is_cuda and len(self.n_inv) == 2 and same_b and nmodes <= dev.TEMPLATE_MAX_MODES
+                and alm2map is shts.alm2map and map2alm is shts.map2alm and alm2map_spin is shts.alm2map_spin
+                and map2alm_spin is shts.map2alm_spin and not shts.lane_active())
+
     def apply_alm_new(self, alm):
         """B^t Y^t N^-1 Y B alm as a new teblm (the input is left alone); the beams are fused into the transforms."""
         lmax = alm.lmax
         assert alm.lmaxt == alm.lmaxe == alm.lmaxb == lmax
+        if self.one_call_ok(alm):  # the temperature and polarization blocks as the one-call operators of opfilt_tt / opfilt_pp
+            fac = self.npix / (4. * np.pi)
+            pmat, rmat = self._proj_matrices()
+            ttlm = shts.cg_fwd_tt(alm.tlm, self.nside, lmax, self.n_inv[0], fl_in=self.b_transf_t, fl_out=self.b_transf_t * fac,
+                                  pmat=pmat, rmat=rmat, scratch=dev.tproj_scratch() if pmat is not None else None)
+            telm, tblm = shts.cg_fwd_pp(alm.elm, alm.blm, self.nside, lmax, self.n_inv[1], fl_in=self.b_transf_e,
+                                        fl_out=self.b_transf_e * fac)
+            return teblm([ttlm, telm, tblm])
         same_b = self.b_transf_b is self.b_transf_e or np.array_equal(self.b_transf_e, self.b_transf_b)
         tmap = alm2map(alm.tlm, self.nside, lmax=lmax, fl=self.b_transf_t)
         if same_b:
@@ -283,19 +316,7 @@ class alm_filter_ninv(object):
     def apply_map(self, amap):
         """(T, Q, U) <- N^-1 (T, Q, U) with the T templates projected out (in place)."""
         tmap, qmap, umap = amap
-        if len(self.templates_t) != 0 and getattr(self, '_pmat', None) is None:
-            # all template modes as one device matrix P (nmodes x npix): coefficients, the small solve and the projected
-            # map are device operations, nothing comes back to the host inside a CG iteration
-            rows = []
-            for t in self.templates_t:
-                for i in range(t.nmodes):
-                    row = torch.ones_like(tmap)
-                    t.apply_mode(row, i)
-                    rows.append(row)
-            self._pmat = torch.stack(rows)
-            pinv = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64)
-            # N^-1 P (P^t N^-1 P)^-1 as one matrix: the projection is c = P^t t and t -= R^t c
-            self._rmat = torch.mm(pinv, self._pmat * self.n_inv[0].unsqueeze(0))
+        self._proj_matrices()
         # temperature: N^-1 weighting and template projection in two launches (pl_template_project), as in opfilt_tt
         fused_t = len(self.templates_t) != 0 and self._pmat.shape[0] <= dev.TEMPLATE_MAX_MODES and tmap.is_contiguous()
         if fused_t:
