@@ -1,0 +1,84 @@
+"""cd_solve on the host with plain numpy vectors (the solver is generic over vector types; plancklens/qcinv/cd_solve.py:35-107):
+a small symmetric positive-definite system, the three code paths of the solver (host scalars; device-style `dev` scalars; fused
+`parts` / `axpy`, and the merged `step` / `ortho` form), the private right-hand side of the nested solves, the residual refresh."""
+import numpy as np
+import pytest
+
+from plancklens_amd.qcinv import cd_solve
+
+
+def _system(n=40, seed=0):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((n, n))
+    amat = a @ a.T + n * np.eye(n)
+    return amat, rng.standard_normal(n)
+
+
+class _dot_host(object):
+    def __call__(self, a, b):
+        return float(np.dot(a, b))
+
+
+class _dot_parts(_dot_host):
+    """the interface of the device scalar products: `parts` returns an opaque object, `axpy` consumes two of them"""
+    calls = 0
+
+    def dev(self, a, b):
+        return np.dot(a, b)
+
+    def parts(self, a, b):
+        return np.array([np.dot(a, b)])
+
+    @staticmethod
+    def axpy(y, x, num, den, sign):
+        y += sign * num[0] / den[0] * x
+
+
+class _dot_merged(_dot_parts):
+    def step(self, x, d, r, q, update_r=True, one_launch=False):
+        _dot_merged.calls += 1
+        dtad, delta = self.parts(d, q), self.parts(d, r)
+        x += delta[0] / dtad[0] * d
+        if update_r:
+            r -= delta[0] / dtad[0] * q
+        return dtad, delta
+
+    def ortho(self, s, pq, pd, prev_dtad, one_launch=False):
+        s -= np.dot(s, pq) / prev_dtad[0] * pd
+
+
+class _stop_after(object):
+    def __init__(self, n):
+        self.n = n
+
+    def __call__(self, it, x, residual):
+        return it >= self.n
+
+
+@pytest.mark.parametrize('dot', [_dot_host, _dot_parts, _dot_merged])
+@pytest.mark.parametrize('tr', [cd_solve.tr_cg, cd_solve.tr_cd])
+def test_solves_and_all_paths_agree(dot, tr):
+    amat, b = _system()
+    fwd = lambda v: amat @ v
+    pre = lambda v: v / np.diag(amat)
+    x = np.zeros_like(b)
+    its = cd_solve.cd_solve(x, b, fwd, [pre], dot(), _stop_after(60), tr, roundoff=25)
+    assert its == 60
+    assert np.allclose(x, np.linalg.solve(amat, b), rtol=1e-10, atol=1e-12)
+    if dot is _dot_merged:
+        assert _dot_merged.calls > 0
+
+
+def test_private_right_hand_side_and_refresh_guard():
+    amat, b = _system(seed=1)
+    fwd = lambda v: amat @ v
+    pre = lambda v: v / np.diag(amat)
+    ref = np.zeros_like(b)
+    cd_solve.cd_solve(ref, b.copy(), fwd, [pre], _dot_merged(), _stop_after(5), cd_solve.tr_cg, x_is_zero=True)
+    x, rhs = np.zeros_like(b), b.copy()
+    cd_solve.cd_solve(x, rhs, fwd, [pre], _dot_merged(), _stop_after(5), cd_solve.tr_cg, x_is_zero=True, b_scratch=True)
+    assert np.array_equal(x, ref)                 # same arithmetic, one copy less
+    assert not np.array_equal(rhs, b)             # the right-hand side was used as the residual
+    with pytest.raises(AssertionError):           # a solve that reaches the residual refresh needs its right-hand side
+        cd_solve.cd_solve(np.zeros_like(b), b.copy(), fwd, [pre], _dot_merged(), _stop_after(30), cd_solve.tr_cg, x_is_zero=True,
+                          b_scratch=True)
