@@ -436,6 +436,20 @@ __global__ __launch_bounds__(256) void k_gemv(int nrows, int ncols, int64_t lda,
         const double2 *__restrict__ x2 = reinterpret_cast<const double2 *>(x);
         const int n2 = ncols >> 1;
         int c = lane;
+        for (; c + 448 < n2; c += 512) {  // eight 16-byte loads of the row in flight per lane: the matrix streams from the Infinity Cache
+            const double2 u0 = a2[c], u1 = a2[c + 64], u2 = a2[c + 128], u3 = a2[c + 192];
+            const double2 u4 = a2[c + 256], u5 = a2[c + 320], u6 = a2[c + 384], u7 = a2[c + 448];
+            const double2 v0 = x2[c], v1 = x2[c + 64], v2 = x2[c + 128], v3 = x2[c + 192];
+            const double2 v4 = x2[c + 256], v5 = x2[c + 320], v6 = x2[c + 384], v7 = x2[c + 448];
+            s0 = fma(u0.x, v0.x, s0); s0 = fma(u0.y, v0.y, s0);
+            s1 = fma(u1.x, v1.x, s1); s1 = fma(u1.y, v1.y, s1);
+            s2 = fma(u2.x, v2.x, s2); s2 = fma(u2.y, v2.y, s2);
+            s3 = fma(u3.x, v3.x, s3); s3 = fma(u3.y, v3.y, s3);
+            s0 = fma(u4.x, v4.x, s0); s0 = fma(u4.y, v4.y, s0);
+            s1 = fma(u5.x, v5.x, s1); s1 = fma(u5.y, v5.y, s1);
+            s2 = fma(u6.x, v6.x, s2); s2 = fma(u6.y, v6.y, s2);
+            s3 = fma(u7.x, v7.x, s3); s3 = fma(u7.y, v7.y, s3);
+        }
         for (; c + 192 < n2; c += 256) {
             const double2 u0 = a2[c], u1 = a2[c + 64], u2 = a2[c + 128], u3 = a2[c + 192];
             const double2 v0 = x2[c], v1 = x2[c + 64], v2 = x2[c + 128], v3 = x2[c + 192];
