@@ -240,3 +240,77 @@ def test_full_transform_equals_its_stages_at_4096(env):
     rhs = float((w * ((g.conj() * bg).real + (c.conj() * bc).real)).sum()) * npix / (4 * np.pi)
     assert abs(lhs / rhs - 1) < 1e-10, (lhs, rhs)
     shts.clear_plans()
+
+
+def test_mv_estimator_end_to_end_at_baseline_size(tmp_path):
+    """BASELINE.json's headline configuration end to end against the oracle: T, Q, U maps at nside 2048 -> isotropic filter -> MV 'p'
+    quadratic estimator at lmax = lmax_qlm = 2048, gradient and curl, through the product's own classes (filt_simple / qest.library_sepTP)
+    on the GPU and through oracle/qe_oracle.py on the host (its transforms routed to the threaded C stages of the oracle: Legendre
+    stage and ring FFTs, every ring pair).  north_star asks for qlm rms agreement < 1e-8; observed ~1e-13."""
+    import sys
+    import time
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from oracle import sht_oracle as so, qe_oracle as qo
+    from plancklens_amd import qest
+    from plancklens_amd.filt import filt_simple
+    nside = lmax = 2048
+    nt = bench.usable_cpus()
+    c, s, pair, slots = so._pair_geometry(nside, True)
+
+    def synth(alms, spin):
+        ph = so.legendre(0, 1, spin, lmax, lmax, c, s, pair, alm=np.stack(alms), nthreads=nt)
+        return [so.ring_fft_c(0, nside, lmax, slots, phase=ph[i], nthreads=nt) for i in range(len(alms))]
+
+    def anal(maps, spin, lmax_out):
+        assert lmax_out == lmax
+        ph = np.stack([so.ring_fft_c(1, nside, lmax, slots, m=m, nthreads=nt) for m in maps])
+        return so.legendre(1, 1, spin, lmax, lmax, c, s, pair, phase=ph, nthreads=nt)
+    fast = {'alm2map': lambda alm, ns, lmax=None, **kw: synth([alm], 0)[0],
+            'map2alm': lambda m, lmax=None, **kw: anal([m], 0, lmax)[0],
+            'alm2map_spin': lambda gclm, ns, spin, lm, **kw: synth(list(gclm), spin),
+            'map2alm_spin': lambda maps, spin, lm=None, **kw: anal(list(maps), spin, lm)}
+    rng = np.random.default_rng(11)
+    ell = np.arange(lmax + 1.)
+    cls = {'tt': 1e3 / (ell + 10.) ** 2.5, 'ee': 3e1 / (ell + 10.) ** 2.5, 'bb': 3. / (ell + 10.) ** 2.5}
+    cls['te'] = 0.4 * np.sqrt(cls['tt'] * cls['ee'])
+    transf = np.exp(-0.5 * ell * (ell + 1.) * np.radians(5. / 60.) ** 2 / (8. * np.log(2.)))
+    fl = 1. / (cls['tt'] + 1e-3 / transf ** 2)
+    fl[:2] = 0.
+    fel = 1. / (cls['ee'] + 2e-3 / transf ** 2)
+    fel[:2] = 0.
+    fbl = 1. / (cls['bb'] + 2e-3 / transf ** 2)
+    fbl[:2] = 0.
+    maps = rng.standard_normal((3, 12 * nside ** 2))
+    saved = {k: getattr(so, k) for k in fast}
+    t0 = time.time()
+    try:
+        for k, f in fast.items():
+            setattr(so, k, f)
+        t, e, b = qo.filter_maps(maps[0], maps[1], maps[2], lmax, fl, fel, fbl, transf)
+        Go, Co = qo.qe_sepTP('p', (t, e, b), (t, e, b), cls, nside, lmax)
+    finally:
+        for k, f in saved.items():
+            setattr(so, k, f)
+    t_oracle = time.time() - t0
+
+    class sims(object):
+        def hashdict(self):
+            return {'fullsize': 11}
+
+        def get_sim_tmap(self, idx):
+            return maps[0]
+
+        def get_sim_pmap(self, idx):
+            return maps[1], maps[2]
+    ivfs = filt_simple.library_fullsky_sepTP(str(tmp_path / 'ivfs'), sims(), nside, transf, cls, fl, fel, fbl, cache=False)
+    ql = qest.library_sepTP(str(tmp_path / 'ql'), ivfs, ivfs, cls['te'], nside, lmax_qlm=lmax, cache=False)
+    G = ql.get_sim_qlm('p', 0)
+    C = ql.get_sim_qlm('x', 0)
+    torch.cuda.synchronize()
+    eg, ec = relrms(G, Go), relrms(C, Co)
+    _note("MV 'p' end to end at nside = lmax = lmax_qlm = 2048 vs oracle: gradient rel rms %.2e, curl %.2e (oracle: %.0f s on %d threads)"
+          % (eg, ec, t_oracle, nt))
+    assert eg < 1e-8 and ec < 1e-8, (eg, ec)
+    assert eg < 1e-11 and ec < 1e-11, (eg, ec)  # what the arithmetic delivers; the line above is north_star's bar
