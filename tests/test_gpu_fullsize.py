@@ -242,6 +242,90 @@ def test_full_transform_equals_its_stages_at_4096(env):
     shts.clear_plans()
 
 
+def _oracle_transforms(nside, lmax, nt):
+    """complete transforms of the oracle on its threaded C stages (Legendre stage + ring FFTs, every ring pair)"""
+    from oracle import sht_oracle as so
+    c, s, pair, slots = so._pair_geometry(nside, True)
+
+    def synth(alms, spin):
+        ph = so.legendre(0, 1, spin, lmax, lmax, c, s, pair, alm=np.stack(alms), nthreads=nt)
+        return [so.ring_fft_c(0, nside, lmax, slots, phase=ph[i], nthreads=nt) for i in range(len(alms))]
+
+    def anal(maps, spin, lmax_out):
+        assert lmax_out == lmax
+        ph = np.stack([so.ring_fft_c(1, nside, lmax, slots, m=m, nthreads=nt) for m in maps])
+        return so.legendre(1, 1, spin, lmax, lmax, c, s, pair, phase=ph, nthreads=nt)
+    return synth, anal
+
+
+def test_cg_operators_at_baseline_size():
+    """The conjugate-gradient operators of BASELINE config 4 at its size (nside = lmax = 2048, masked inhomogeneous noise,
+    monopole + dipole marginalised): x -> S^-1 x + B^t Y^t N^-1 Y B x of opfilt_tt and opfilt_pp (the one-call entry points
+    pl_cg_fwd_tt / pl_cg_fwd_pp on the fine grid) and the right-hand sides calc_prep, against the same operators assembled from
+    the oracle's transforms and numpy (opfilt_tt.py:30-73,184-205; opfilt_pp.py:37-55,190-215,306-317)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from plancklens_amd import dev, hp
+    from plancklens_amd.qcinv import opfilt_pp, opfilt_tt
+    from plancklens_amd.qcinv.util_alm import eblm
+    nside = lmax = 2048
+    npix = 12 * nside ** 2
+    nt = bench.usable_cpus()
+    synth, anal = _oracle_transforms(nside, lmax, nt)
+    rng = np.random.default_rng(21)
+    ell = np.arange(lmax + 1.)
+    bl = np.exp(-0.5 * ell * (ell + 1.) * np.radians(5. / 60.) ** 2 / (8. * np.log(2.)))
+    x, y, z = hp.pix2vec(nside, np.arange(npix))
+    ninv = (1. + 0.3 * x) * (np.abs(z) > 0.35) / 1e-3       # a galactic-cut mask (fsky 0.65) times a smooth noise modulation
+    cl = {'tt': 1e3 / (ell + 10.) ** 2.5, 'ee': 3e1 / (ell + 10.) ** 2.5, 'bb': 3. / (ell + 10.) ** 2.5}
+    for k in cl:
+        cl[k][:2] = 0.
+
+    def ralm():
+        a = rng.standard_normal(hp.Alm.getsize(lmax)) + 1j * rng.standard_normal(hp.Alm.getsize(lmax))
+        a[:lmax + 1] = a[:lmax + 1].real
+        return a
+
+    def almxfl(a, f):
+        return hp.almxfl(a, f)
+
+    def cli(c):
+        r = np.zeros_like(c)
+        r[c > 0] = 1. / c[c > 0]
+        return r
+    # ---- temperature
+    nf = opfilt_tt.alm_filter_ninv(ninv, bl, marge_monopole=True, marge_dipole=True)
+    xt = ralm()
+    got = dev.to_host(opfilt_tt.fwd_op(cl, nf)(dev.to_dev(xt)))
+    tmap = synth([almxfl(xt, bl)], 0)[0] * ninv
+    pm = np.stack([np.ones(npix), x, y, z])                 # template_monopole, template_dipole (template_removal.py:112-158)
+    coeffs = np.linalg.solve((pm * ninv) @ pm.T, pm @ tmap)
+    tmap -= ninv * (coeffs @ pm)
+    ref = almxfl(anal([tmap], 0, lmax)[0], bl * npix / (4. * np.pi)) + almxfl(xt, cli(cl['tt']))
+    et = relrms(got, ref)
+    dmap = rng.standard_normal(npix)
+    gotb = dev.to_host(opfilt_tt.calc_prep(dmap, cl, nf))
+    w = dmap * ninv
+    w -= ninv * (np.linalg.solve((pm * ninv) @ pm.T, pm @ w) @ pm)
+    eb = relrms(gotb, almxfl(anal([w], 0, lmax)[0], bl * npix / (4. * np.pi)))
+    del tmap, pm, w, dmap
+    # ---- polarization
+    nfp = opfilt_pp.alm_filter_ninv([ninv], bl)
+    xe, xb = ralm(), ralm()
+    xe[hp.Alm.getlm(lmax)[0] < 2] = 0.
+    xb[hp.Alm.getlm(lmax)[0] < 2] = 0.
+    gp = opfilt_pp.fwd_op(cl, nfp)(eblm([dev.to_dev(xe), dev.to_dev(xb)]))
+    q, u = synth([almxfl(xe, bl), almxfl(xb, bl)], 2)
+    te, tb = anal([q * ninv, u * ninv], 2, lmax)
+    re = almxfl(te, bl * npix / (4. * np.pi)) + almxfl(xe, cli(cl['ee']))
+    rb = almxfl(tb, bl * npix / (4. * np.pi)) + almxfl(xb, cli(cl['bb']))
+    ee, ebb = relrms(dev.to_host(gp.elm), re), relrms(dev.to_host(gp.blm), rb)
+    _note('CG operators at nside = lmax = 2048 (fsky 0.65, monopole + dipole) vs oracle: T fwd_op %.2e, T calc_prep %.2e, P fwd_op E %.2e B %.2e'
+          % (et, eb, ee, ebb))
+    assert max(et, eb, ee, ebb) < 1e-11, (et, eb, ee, ebb)
+
+
 def test_mv_estimator_end_to_end_at_baseline_size(tmp_path):
     """BASELINE.json's headline configuration end to end against the oracle: T, Q, U maps at nside 2048 -> isotropic filter -> MV 'p'
     quadratic estimator at lmax = lmax_qlm = 2048, gradient and curl, through the product's own classes (filt_simple / qest.library_sepTP)
@@ -257,16 +341,7 @@ def test_mv_estimator_end_to_end_at_baseline_size(tmp_path):
     from plancklens_amd.filt import filt_simple
     nside = lmax = 2048
     nt = bench.usable_cpus()
-    c, s, pair, slots = so._pair_geometry(nside, True)
-
-    def synth(alms, spin):
-        ph = so.legendre(0, 1, spin, lmax, lmax, c, s, pair, alm=np.stack(alms), nthreads=nt)
-        return [so.ring_fft_c(0, nside, lmax, slots, phase=ph[i], nthreads=nt) for i in range(len(alms))]
-
-    def anal(maps, spin, lmax_out):
-        assert lmax_out == lmax
-        ph = np.stack([so.ring_fft_c(1, nside, lmax, slots, m=m, nthreads=nt) for m in maps])
-        return so.legendre(1, 1, spin, lmax, lmax, c, s, pair, phase=ph, nthreads=nt)
+    synth, anal = _oracle_transforms(nside, lmax, nt)
     fast = {'alm2map': lambda alm, ns, lmax=None, **kw: synth([alm], 0)[0],
             'map2alm': lambda m, lmax=None, **kw: anal([m], 0, lmax)[0],
             'alm2map_spin': lambda gclm, ns, spin, lm, **kw: synth(list(gclm), spin),
