@@ -1278,7 +1278,8 @@ static int pick_r(const char *env, int dflt, int rmax, const DevPlan &P)
 }
 static int r0_synth(const DevPlan &P) { return pick_r("PLSHTS_R0", 3, 6, P); }
 static int rs_synth(const DevPlan &P) { return pick_r("PLSHTS_RS", 2, 4, P); }
-static int r0_anal(const DevPlan &P) { return pick_r("PLSHTS_R0A", 6, 6, P); }
+// (spin-0 analysis: 8 rings per lane at nside >= 4096 -- 8.31 against 8.99 ms at nside = lmax = 4096; at 2048 6 and 8 are equal, 7 is slower)
+static int r0_anal(const DevPlan &P) { return pick_r("PLSHTS_R0A", P.nside >= 4096 ? 8 : 6, 8, P); }
 static int rs_anal(const DevPlan &P) { return pick_r("PLSHTS_RSA", 4, 4, P); }
 
 int rings_per_group(int spin, const DevPlan &P) { return 64 * (spin == 0 ? r0_anal(P) : rs_anal(P)); }
@@ -1404,6 +1405,8 @@ void launch_anal0(const DevPlan &P, const double *phase, double *partial, const 
     case 3: launch_anal0_r<3>(P, phase, partial, fl, alm, st, add, fl_add); break;
     case 5: launch_anal0_r<5>(P, phase, partial, fl, alm, st, add, fl_add); break;
     case 6: launch_anal0_r<6>(P, phase, partial, fl, alm, st, add, fl_add); break;
+    case 7: launch_anal0_r<7>(P, phase, partial, fl, alm, st, add, fl_add); break;
+    case 8: launch_anal0_r<8>(P, phase, partial, fl, alm, st, add, fl_add); break;
     default: launch_anal0_r<4>(P, phase, partial, fl, alm, st, add, fl_add); break;
     }
 }
