@@ -12,12 +12,12 @@ import csv, collections, glob
 fn = glob.glob('gpurun_out/pmc_fft/**/*counter_collection.csv', recursive=True)
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(fn[0])):
-    k = r['Kernel_Name'].split('(')[0].replace('void plshts::', '')[:34]
+    k = r['Kernel_Name'].split('(')[0].replace('void plshts::', '')[:48]
     if 'phase' in k:
         acc[k][r['Counter_Name']] += float(r['Counter_Value'])
         n[(k, r['Counter_Name'])] += 1
 for k, v in sorted(acc.items()):
-    print('%-34s' % k, ' '.join('%s=%.3g' % (a.replace('SQ_', ''), b / n[(k, a)]) for a, b in v.items()))
+    print('%-48s' % k, ' '.join('%s=%.3g' % (a.replace('SQ_', ''), b / n[(k, a)]) for a, b in v.items()))
 PY
 done
 rm -rf gpurun_out/pmc_fft
