@@ -664,20 +664,20 @@ int pl_cg_fwd_tt(pl_plan *p, const double *alm_in, const double *fl_in, const do
     const DevPlan &P = p->P;
     if (grow(p, &p->phase, &p->phase_cap, pl_plan_phase_doubles(p, 0)) || grow(p, &p->wmap, &p->wmap_cap, P.npix)) return 1;
     if (legendre_synth_impl(p, 0, alm_in, fl_in, p->phase, stream, false)) return 1;
+    // the weighting always rides in the synthesis-side FFT kernels; the projection too where every ring runs in the generic kernel
     const bool fused = nmodes == 0 || (fft_all_generic(P, p->F) && nmodes <= kFuseModes);
     NinvProj W;
-    if (fused) {
-        if (nmodes > 0 && grow(p, &p->tparts, &p->tparts_cap, (int64_t)nmodes * P.npairs)) return 1;
-        W.n_inv = n_inv; W.nmodes = nmodes; W.nparts = P.npairs; W.parts = p->tparts;
-        if (nmodes > 0) { W.pm = pmat; W.rm = rmat; }
+    W.n_inv = n_inv;
+    if (fused && nmodes > 0) {
+        if (grow(p, &p->tparts, &p->tparts_cap, (int64_t)nmodes * P.npairs)) return 1;
+        W.nmodes = nmodes; W.nparts = P.npairs; W.parts = p->tparts; W.pm = pmat; W.rm = rmat;
     }
     {
         ProfScope ps(p, PK_FFT_SYNTH, st);
-        HIPCHK(launch_phase2map(P, p->F, p->fs, mlim_of(p, 0), 1, p->phase, p->wmap, st, fused ? &W : nullptr));
+        HIPCHK(launch_phase2map(P, p->F, p->fs, mlim_of(p, 0), 1, p->phase, p->wmap, st, &W));
     }
-    if (!fused) {
-        if (nmodes > 0) launch_template_project(P.npix, nmodes, p->wmap, n_inv, pmat, rmat, scratch, st);
-        else launch_map_mul(P.npix, p->wmap, n_inv, p->wmap, st);
+    if (!fused) {  // the map arrives weighted: coefficients and projection only (n_inv null)
+        launch_template_project(P.npix, nmodes, p->wmap, nullptr, pmat, rmat, scratch, st);
         HIPCHK(hipGetLastError());
     }
     {

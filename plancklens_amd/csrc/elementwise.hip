@@ -372,8 +372,8 @@ __global__ __launch_bounds__(NT) void k_tproj_coeffs(int64_t n, int nmodes, doub
 #pragma unroll
     for (int k = 0; k < kProjMaxModes; ++k) acc[k] = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
-        const double u = t[i] * n_inv[i];
-        t[i] = u;
+        double u = t[i];
+        if (n_inv) { u *= n_inv[i]; t[i] = u; }  // n_inv null: t arrives weighted (the ring-FFT kernels did it), nothing to store
 #pragma unroll
         for (int k = 0; k < kProjMaxModes; ++k)
             if (k < nmodes) acc[k] = fma(pm[(int64_t)k * n + i], u, acc[k]);
