@@ -1233,17 +1233,32 @@ static hipError_t launch_stage(const DevPlan &P, const DevFFT &F, const FftStrea
         default: return launch_fast_class<256, false>(P, F, 0, synth, mlim, ncomp, in, out, s, wgt);
         }
     };
+    // items of a handful of ring pairs (the single power-of-two cap rings) are pure latency: they go first, one after the other, on
+    // the last side stream, which takes nothing else -- at the end of a queue they were the tail of every stage (45-50 us)
+    static const int nside_streams = [] { const char *v = getenv("PLSHTS_FFT_STREAMS"); const int n = v ? atoi(v) : 3; return n < 2 ? 2 : (n > FftStreams::kN ? FftStreams::kN : n); }();
+    // PLSHTS_FFT_STREAMS: side streams in use, 2 ... 5.  Every one costs a join on the caller's stream (the idle gap at the end of a stage
+    // grows by ~10 us per joined stream); measured 26.54 ms per reconstruction with 3, 26.64 with 5, 26.89 with 2
+    const int kTinyStream = nside_streams - 1;
+    auto tiny = [&](int w) { return w != nw && count(w) < 8; };
+    auto on_side = [&](int i, int w) -> hipStream_t {
+        if (joined[i] || hipStreamWaitEvent(fs.s[i], fs.fork, 0) == hipSuccess) {
+            joined[i] = true;
+            load[i] += cost[w];
+            return fs.s[i];
+        }
+        return st;
+    };
+    if (par && nitems > 1)
+        for (int a = 1; a < nitems && e == hipSuccess; ++a)
+            if (tiny(order[a])) e = run(order[a], on_side(kTinyStream, order[a]));
     for (int a = 0; a < nitems && e == hipSuccess; ++a) {
         const int w = order[a];
         hipStream_t s = st;
         if (par && a > 0) {
+            if (tiny(w)) continue;  // launched above
             int best = 0;
-            for (int i = 1; i < FftStreams::kN; ++i) if (load[i] < load[best]) best = i;
-            if (joined[best] || hipStreamWaitEvent(fs.s[best], fs.fork, 0) == hipSuccess) {
-                joined[best] = true;
-                load[best] += cost[w];
-                s = fs.s[best];
-            }
+            for (int i = 1; i < kTinyStream; ++i) if (load[i] < load[best]) best = i;
+            s = on_side(best, w);
         }
         e = run(w, s);
     }
