@@ -103,7 +103,7 @@ def parse(argv=None):
     ap.add_argument('--qe-only', action='store_true',
                     help='time the estimator from filtered alms that are already resident (the cost of a further key in the reference, qest.py:184-185)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=45.0, help='budget of the CPU baseline (warm-up and all repetitions together)')
+    ap.add_argument('--cpu-seconds', type=float, default=75.0, help='budget of the CPU baseline (warm-up and all repetitions together)')
     ap.add_argument('--no-cg', action='store_true', help='skip the CG block (BASELINE config 4)')
     ap.add_argument('--cg-iters', type=int, default=100)
     return ap.parse_args(argv)
@@ -322,7 +322,7 @@ def run_rank(args):
     from plancklens_amd.helpers import mpi
     mpi.rank, mpi.size = rank, world
 
-    from plancklens_amd import hp, parallel, qest, shts, utils
+    from plancklens_amd import dev, hp, parallel, qest, shts, utils
     from plancklens_amd.filt import filt_simple
 
     nside, lmax, key = args.nside, args.lmax, args.key
@@ -373,9 +373,11 @@ def run_rank(args):
     plan.profile_read()
     t0 = time.perf_counter()
     # K reconstructions on this rank (jobs[rank::size] of world x K simulations), device-resident sum, RCCL all-reduce
-    mf = qlms.get_sim_qlm_mf(key, np.arange(world * K))
+    mf = qlms.get_sim_qlm_mf(key, np.arange(world * K), collective=True)
     assert qlms._last_dev is not None, 'the estimator library kept no device result for key %s' % key
     gathered = parallel.allgather(qlms._last_dev[0])  # output qlm all-gather over xGMI
+    for f_ in list(dev.host_future._in_flight):  # every gradient / curl alm of the timed reconstructions is in host memory (numpy) at dt
+        f_.result()
     sync_all()
     dt = time.perf_counter() - t0
     prof = plan.profile_read()

@@ -70,15 +70,16 @@ def main():
                 qlib.get_sim_qlm(k, idx)
     mpi.barrier()
 
-    # --- mean-fields: every rank takes part in every mean field -- the simulations of one mean field are sharded over the
-    # ranks inside get_sim_qlm_mf and summed with one all-reduce (the reference shards the (key, half) jobs instead,
-    # run_qlms.py:92-95, each rank looping over all simulations of its job)
+    # --- mean-fields: every rank takes part in every mean field -- get_sim_qlm_mf(..., collective=True) shards the simulations of
+    # one mean field over the ranks and sums with one all-reduce (the reference shards the (key, half) jobs instead,
+    # run_qlms.py:92-95, each rank looping over all simulations of its job).  The call is collective: all ranks make it, in the
+    # same order, before the rank-sharded spectra loop below, which then finds the cached mean fields.
     if args.mfdd:
         keys = list(np.unique(np.concatenate([args.kA, args.kB])))
         jobs = [(k, 0) for k in keys] + [(k, 1) for k in keys]
         for i, (k, id0) in enumerate(jobs):
             print("rank %s doing its share of %s QE MF %s" % (mpi.rank, k, id0))
-            par.qlms_dd.get_sim_qlm_mf(k, par.qcls_dd.mc_sims_mf[id0::2])
+            par.qlms_dd.get_sim_qlm_mf(k, par.qcls_dd.mc_sims_mf[id0::2], collective=True)
     mpi.barrier()
 
     # --- unnormalized QE power spectra

@@ -260,10 +260,16 @@ def cg_barrier():
     return _CG_BARRIER[d]
 
 
-def cg_barrier_timed_out():
-    """True if a grid barrier of pl_cg_dot_axpy gave up on this device (results after that are invalid); synchronises."""
+def cg_barrier_timed_out(reset=False):
+    """True if a grid barrier of pl_cg_dot_axpy gave up on this device (results after that are invalid); synchronises.
+    reset: the barrier words are zeroed afterwards (a barrier that gave up leaves its arrival counter non-zero)."""
     d = torch.cuda.current_device()
-    return d in _CG_BARRIER and int(_CG_BARRIER[d][2]) != 0
+    if d not in _CG_BARRIER or torch.cuda.is_current_stream_capturing():
+        return False
+    out = int(_CG_BARRIER[d][2]) != 0
+    if reset and out:
+        _CG_BARRIER[d].zero_()
+    return out
 
 
 def _ptr_array(tensors):

@@ -33,7 +33,11 @@ def init(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if torch.cuda.is_available():
-            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)) % max(1, torch.cuda.device_count()))
+            local, ndev = int(os.environ.get('LOCAL_RANK', 0)), max(1, torch.cuda.device_count())
+            if backend == 'nccl' and local >= ndev:  # RCCL needs one GPU per rank: two ranks on one device hang at the first collective
+                raise RuntimeError('LOCAL_RANK %d but only %d GPU(s) visible: the nccl (RCCL) backend needs one GPU per rank '
+                                   '(PLENS_DIST_BACKEND=gloo lets ranks share a GPU)' % (local, ndev))
+            torch.cuda.set_device(local % ndev)
         dist.init_process_group(backend=backend)
         _initialised_here = True
     rank, size = dist.get_rank(), dist.get_world_size()

@@ -68,13 +68,15 @@ def allgather(x):
     return [torch.view_as_complex(o) if x.is_complex() else o for o in out]
 
 
-def mean_field(get_qlm, idxs, like, get_pair=None):
-    """Mean of get_qlm(idx) over ALL idxs, each rank evaluating only its shard: sum locally, all-reduce, divide.
+def mean_field(get_qlm, idxs, like, get_pair=None, collective=True):
+    """Mean of get_qlm(idx) over ALL idxs.  collective (a COLLECTIVE call: every rank of the job must make it, with the same
+    idxs): each rank evaluates only its shard, sums locally, one all-reduce, divide.  collective=False: the calling rank evaluates
+    every simulation by itself and no other rank is involved (the reference's loop, qest.py:238-244).
     `like` is a zero tensor giving shape / dtype / device of the accumulator.  get_pair(idx0, idx1) -> (q0, q1), when given, serves
     the shard two simulations at a time (their transforms share Legendre recursions); the terms are added in index order either way."""
     idxs = list(np.unique(np.asarray(idxs)))
     acc = torch.zeros_like(like)
-    mine = shard(idxs)
+    mine = shard(idxs) if collective else idxs
 
     def add(q):
         acc.add_(q if isinstance(q, torch.Tensor) else torch.as_tensor(q).to(acc.device))
@@ -85,7 +87,8 @@ def mean_field(get_qlm, idxs, like, get_pair=None):
         add(q1)
     for idx in mine[n2:]:
         add(get_qlm(idx))
-    allreduce_sum(acc)
+    if collective:
+        allreduce_sum(acc)
     if len(idxs) > 0:
         acc /= len(idxs)
     return acc

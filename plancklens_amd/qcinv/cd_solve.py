@@ -63,14 +63,35 @@ def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=
     on_dev = n_pre == 1 and hasattr(dot_op, 'dev')
     fused = on_dev and hasattr(dot_op, 'axpy') and hasattr(dot_op, 'parts')
     merged = fused and hasattr(dot_op, 'step') and hasattr(dot_op, 'ortho') and os.environ.get('PLENS_CG_MERGED', '1') != '0'
-    one_launch = os.environ.get('PLENS_CG_ONE_LAUNCH', '0') == '1'
+    one_launch = merged and os.environ.get('PLENS_CG_ONE_LAUNCH', '0') == '1'
+    if one_launch:  # opt-in experiment: the grid barrier needs every workgroup co-resident; a barrier that gave up invalidates the solve
+        try:
+            return _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_is_zero, b_scratch, True)
+        finally:
+            from .. import dev
+            if dev.cg_barrier_timed_out(reset=True):
+                raise RuntimeError('PLENS_CG_ONE_LAUNCH: a grid barrier of pl_cg_dot_axpy timed out (workgroups not co-resident: '
+                                   'another kernel or process shares the GPU); the solve is invalid -- unset PLENS_CG_ONE_LAUNCH')
+    return _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_is_zero, b_scratch, False)
+
+
+def _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_is_zero, b_scratch, one_launch):
+    n_pre = len(pre_ops)
+    on_dev = n_pre == 1 and hasattr(dot_op, 'dev')
+    fused = on_dev and hasattr(dot_op, 'axpy') and hasattr(dot_op, 'parts')
+    merged = fused and hasattr(dot_op, 'step') and hasattr(dot_op, 'ortho') and os.environ.get('PLENS_CG_MERGED', '1') != '0'
     if x_is_zero and b_scratch:
         residual, b = b, None
     else:
         residual = b * 1.0 if x_is_zero else b - fwd_op(x)
-    searchdirs = [op(residual) for op in pre_ops]
     it = 0
-    while not criterion(it, x, residual):
+    # The criterion is asked before the preconditioners run: the search directions of an iteration that is not going to
+    # happen are never formed (the reference forms and drops them, cd_solve.py:59,93 -- with nested multigrid stages of three
+    # iterations that is a quarter of all coarse work).  Same calls of criterion with the same arguments, same iterates.
+    if criterion(it, x, residual):
+        return it
+    searchdirs = [op(residual) for op in pre_ops]
+    while True:
         searchfwds = [fwd_op(d) for d in searchdirs]
         if fused:
             fresh_residual = np.mod(it + 1, roundoff) == 0
@@ -87,6 +108,9 @@ def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=
             if fresh_residual:
                 assert b is not None, 'b_scratch: the solve ran into a residual refresh'
                 residual = b - fwd_op(x)
+            if criterion(it, x, residual):
+                cache.trim(range(tr(it + 1), it))
+                return it
             searchdirs = [op(residual) for op in pre_ops]
             for titer in range(tr(it), it):
                 prev_dTAd, prev_dirs, prev_fwds = cache.restore(titer)
@@ -117,6 +141,9 @@ def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=
         else:
             for q, alpha in zip(searchfwds, alphas):
                 residual -= q * alpha
+        if criterion(it, x, residual):
+            cache.trim(range(tr(it + 1), it))
+            return it
         searchdirs = [op(residual) for op in pre_ops]
         for titer in range(tr(it), it):
             prev_dTAd_inv, prev_dirs, prev_fwds = cache.restore(titer)
@@ -129,4 +156,3 @@ def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=
                     for beta, pd in zip(betas, prev_dirs):
                         d -= pd * beta
         cache.trim(range(tr(it + 1), it))
-    return it

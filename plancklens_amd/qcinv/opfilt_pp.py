@@ -239,7 +239,7 @@ class alm_filter_ninv(object):
         same_b = self.b_transf_b is self.b_transf_e or np.array_equal(self.b_transf_e, self.b_transf_b)
         return (isinstance(alm.elm, torch.Tensor) and alm.elm.is_cuda and len(self.n_inv) == 1 and not self.wmarg and same_b
                 and alm2map_spin is shts.alm2map_spin and map2alm_spin is shts.map2alm_spin and not shts.lane_active()
-                and self.n_inv[0].is_contiguous())
+                and self.n_inv[0].is_contiguous() and self.n_inv[0].dtype == torch.float64)
 
     def apply_alm_new(self, alm, add=None, fl_add_e=None, fl_add_b=None):
         """B^t Y^t N^-1 Y B (E, B) (+ (fl_add_e E', fl_add_b B') for add = (E', B')) as a new eblm (the input is left alone)."""

@@ -282,7 +282,8 @@ class alm_filter_ninv(object):
         nmodes = sum(t.nmodes for t in self.templates_t)
         return (isinstance(alm.tlm, torch.Tensor) and alm.tlm.is_cuda and len(self.n_inv) == 2 and same_b and nmodes <= dev.TEMPLATE_MAX_MODES
                 and alm2map is shts.alm2map and map2alm is shts.map2alm and alm2map_spin is shts.alm2map_spin
-                and map2alm_spin is shts.map2alm_spin and not shts.lane_active())
+                and map2alm_spin is shts.map2alm_spin and not shts.lane_active()
+                and all(isinstance(n, torch.Tensor) and n.is_contiguous() and n.dtype == torch.float64 for n in self.n_inv))
 
     def apply_alm_new(self, alm):
         """B^t Y^t N^-1 Y B alm as a new teblm (the input is left alone); the beams are fused into the transforms."""

@@ -195,7 +195,7 @@ class alm_filter_ninv(object):
         """pl_cg_fwd_tt applies: device input, the module's transforms not replaced, few enough template modes."""
         nmodes = sum(t.nmodes for t in self.templates)
         return (isinstance(alm, torch.Tensor) and alm.is_cuda and alm2map is shts.alm2map and map2alm is shts.map2alm and not shts.lane_active()
-                and nmodes <= dev.TEMPLATE_MAX_MODES)
+                and nmodes <= dev.TEMPLATE_MAX_MODES and self.n_inv.is_contiguous() and self.n_inv.dtype == torch.float64)
 
     def apply_alm_new(self, alm, alm_add=None, fl_add=None):
         """B^t Y^t N^-1 Y B alm (+ fl_add alm_add) as a new array (the input is left alone)."""

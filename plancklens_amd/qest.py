@@ -227,22 +227,28 @@ class library(object):
         wL = self.resplib.get_response(kQE, ksource) * ut.cli(self.resplib.get_response(ksource + kQE[1:], ksource))
         return kQE, wL
 
-    def get_sim_qlm_mf(self, k, mc_sims, lmax=None):
-        """Mean field: average of the estimates over mc_sims, cached (qest.py:206-246)."""
+    def get_sim_qlm_mf(self, k, mc_sims, lmax=None, collective=False):
+        """Mean field: average of the estimates over mc_sims, cached (qest.py:206-246).
+
+        A local computation by default, as in the reference: the calling rank loops over all of mc_sims, so the call is safe
+        inside rank-sharded loops (qecl.get_sim_qcl under jobs[rank::size]).  collective=True is a COLLECTIVE call -- every rank
+        of the job must make it with the same arguments: the simulations are sharded jobs[rank::size], the running sum stays on the
+        device, one all-reduce (RCCL over xGMI) completes it and rank 0 writes the cache file.  The driver
+        (examples/run_qlms.py -mfdd) and bench.py use that form before any sharded loop needs the mean field."""
         k = self.keys_remaps.get(k, k)
         if lmax is None:
             lmax = self.get_lmax_qlm(k)
         assert lmax <= self.get_lmax_qlm(k)
         if k in ['p_tp', 'x_tp']:
-            return self.get_sim_qlm_mf('%stt' % k[0], mc_sims, lmax=lmax) + self.get_sim_qlm_mf('%s_p' % k[0], mc_sims, lmax=lmax)
+            return self.get_sim_qlm_mf('%stt' % k[0], mc_sims, lmax=lmax, collective=collective) + self.get_sim_qlm_mf('%s_p' % k[0], mc_sims, lmax=lmax, collective=collective)
         if k in ['p_te', 'p_tb', 'p_eb', 'x_te', 'x_tb', 'x_eb']:
-            return self.get_sim_qlm_mf(k[0] + k[2] + k[3], mc_sims, lmax=lmax) \
-                   + self.get_sim_qlm_mf(k[0] + k[3] + k[2], mc_sims, lmax=lmax)
+            return self.get_sim_qlm_mf(k[0] + k[2] + k[3], mc_sims, lmax=lmax, collective=collective) \
+                   + self.get_sim_qlm_mf(k[0] + k[3] + k[2], mc_sims, lmax=lmax, collective=collective)
         if '_bh_' in k:
             kQE, wL = self._bh_weights(k)
             lmax = self.get_lmax_qlm(kQE)
             ksrc = k.split('_bh_')[1] + kQE[1:]
-            return self.get_sim_qlm_mf(kQE, mc_sims, lmax=lmax) - hp.almxfl(self.get_sim_qlm_mf(ksrc, mc_sims, lmax=lmax), wL)
+            return self.get_sim_qlm_mf(kQE, mc_sims, lmax=lmax, collective=collective) - hp.almxfl(self.get_sim_qlm_mf(ksrc, mc_sims, lmax=lmax, collective=collective), wL)
         assert k in self.keys_fund, (k, self.keys_fund)
         fname = os.path.join(self.lib_dir, 'simMF_k1%s_%s.fits' % (k, ut.mchash(mc_sims)))
         if (not self.cache and ('mf', fname) in self._mem):
@@ -251,18 +257,16 @@ class library(object):
             this_mcs = np.unique(mc_sims)
             if len(this_mcs) == 0:
                 return np.zeros(hp.Alm.getsize(lmax), dtype=complex)
-            # The simulations are independent: every rank evaluates its share jobs[rank::size] of them, the running sum
-            # stays on the device, one all-reduce (RCCL over xGMI) completes it.  With one rank this is
-            # the reference's loop (qest.py:238-244).  The cache file is written by rank 0 only.
             from . import parallel
             like = torch.zeros(hp.Alm.getsize(lmax), dtype=torch.complex128, device='cuda')
             MF = dev.to_host(parallel.mean_field(lambda idx: self._get_sim_qlm_dev(k, idx, lmax), this_mcs, like,
-                                                 get_pair=self._pair_getter(k, lmax)))
+                                                 get_pair=self._pair_getter(k, lmax), collective=collective))
             if self.cache:
-                if mpi.rank == 0:
+                if mpi.rank == 0 or not collective:
                     _write_alm(fname, MF)
                     print("Cached ", fname)
-                mpi.barrier()
+                if collective:
+                    mpi.barrier()
             else:
                 self._mem[('mf', fname)] = MF
             return ut.alm_copy(MF, lmax=lmax)

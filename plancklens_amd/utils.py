@@ -41,7 +41,8 @@ def enumerate_progress(lst, label=''):
 
 def clhash(cl, dtype=np.float16):
     """SHA-1 of the array cast to low precision (machine-independent cache keys, utils.py:115-124)."""
-    return hashlib.sha1(np.copy(np.asarray(cl).astype(dtype), order='C')).hexdigest()
+    with np.errstate(over='ignore'):  # values beyond the float16 range hash as inf, as in the reference; no warning per hash
+        return hashlib.sha1(np.copy(np.asarray(cl).astype(dtype), order='C')).hexdigest()
 
 
 def mchash(cl):
