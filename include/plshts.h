@@ -165,6 +165,41 @@ int pl_cg_fwd_pp(pl_plan *plan, const double *elm_in, const double *blm_in, cons
                  const double *blm_add, const double *fl_add_e, const double *fl_add_b, double *elm_out, double *blm_out,
                  const double *fl_out, void *stream);
 
+/* ---- Batched forms: nb right-hand sides through every launch (block vectors of the conjugate-gradient filter) -------------------
+ * The reference filters its Monte-Carlo simulations one at a time (examples/run_qlms.py:57-62 -> filt_cinv.py:196-203,275-289 ->
+ * multigrid.py:56-75 -> cd_solve.py:35-107).  On the GPU the coarse multigrid levels of a solve are chains of dependent launches of a
+ * few microseconds each; nb simulations that share the noise model are therefore solved together: every launch of the solve carries
+ * all of them, each with its own scalar products and step lengths.  Convention: every alm / map argument holds nb arrays back to
+ * back ([nb][nalm] complex, [nb][npix]); l-filters, inverse-noise maps and template matrices are shared by the batch; partial sums of
+ * scalar products are [nb][PL_DOT_PARTS]; scratch_dev of the template projection is nb x PL_TEMPLATE_MAX_MODES x 256 doubles.
+ * Every entry of a batch is computed with exactly the arithmetic of the un-batched call (bit-identical results). */
+#define PL_MAX_BATCH 64
+int pl_almxfl_b(int lmax, int nb, const double *alm_in, const double *fl, int nfl, double *alm_out, void *stream);
+int pl_alm_copy_b(int lmax_in, int nb, const double *alm_in, int lmax_out, double *alm_out, void *stream);
+/* fl_hi may be NULL (pl_alm_splice) or lmax_hi + 1 entries (pl_alm_splice_fl) */
+int pl_alm_splice_b(int lmax_lo, int nb, const double *alm_lo, int lmax_hi, const double *alm_hi, const double *fl_hi, int lsplit, double *out,
+                    void *stream);
+int pl_almxfl_add_b(int lmax, int nb, const double *a, const double *b, const double *fl, int nfl, double *out, void *stream);
+int pl_alm_dot_b(int lmax, int lmin, int nb, const double *a, const double *b, int accumulate, double *parts_dev, void *stream);
+int pl_axpy_dev_b(int64_t n, int nb, const double *num_parts_dev, const double *den_parts_dev, double sign, const double *x, double *y, void *stream);
+/* pl_cg_dot_axpy for nb entries (the host pointer arrays give the first entry of each field; always the two-launch form).
+ * active_dev (may be NULL): nb doubles, 1 or 0 -- the step length of entry b is multiplied by active_dev[b], so that an entry whose
+ * solve has met its stopping criterion keeps its vectors while the others go on (cd_monitors.py:28-41 applied per simulation). */
+int pl_cg_dot_axpy_b(int nb, int nf, const int *lmax, int lmin, const double *const *a, const double *const *b1, const double *const *b2,
+                     double *parts1_dev, double *parts2_dev, const double *den_parts_dev, double *const *y1, const double *const *x1,
+                     double sign1, double *const *y2, const double *const *x2, double sign2, const double *active_dev, void *stream);
+int pl_template_project_b(int64_t npix, int nmodes, int nb, double *tmap, const double *n_inv, const double *pmat, const double *rmat,
+                          double *scratch_dev, void *stream);
+int pl_cg_fwd_tt_b(pl_plan *plan, int nb, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *pmat,
+                   const double *rmat, double *scratch_dev, const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out,
+                   void *stream);
+int pl_cg_fwd_pp_b(pl_plan *plan, int nb, const double *elm_in, const double *blm_in, const double *fl_in, const double *n_inv,
+                   const double *elm_add, const double *blm_add, const double *fl_add_e, const double *fl_add_b, double *elm_out,
+                   double *blm_out, const double *fl_out, void *stream);
+/* Y[b] = A X[b], b < nb: x [nb][ncols], y [nb][nrows] -- the dense preconditioner applied to a block vector (dense.py:118-119); the
+ * matrix is read once for the whole batch. */
+int pl_gemv_b(int nrows, int ncols, int64_t lda, const double *A, int nb, const double *x, double *y, void *stream);
+
 /* y = A x, A row-major nrows x ncols with leading dimension lda, all device arrays (x and y must not overlap): the dense
  * low-l preconditioner of the CG chains applied as one mat-vec (dense.py:118-119,201-202,284-285), and the template
  * coefficient products of the joint filter.  One wavefront per row, fixed summation tree (bit-reproducible). */
@@ -179,6 +214,9 @@ int pl_copy_slim(const double *src_dev, double *dst, int64_t ndoubles, int nbloc
 /* Pixel-space helpers (qest.py:256-257,276-278; opfilt_tt.py:195, opfilt_pp.py:276-299). */
 /* out = a * b (element-wise, n doubles) */
 int pl_map_mul(int64_t n, const double *a, const double *b, double *out, void *stream);
+/* (Q, U) <- (nqq Q + nqu U, nqu Q + nuu U) in place: the polarization inverse-noise weighting with a QU cross term
+ * (alm_filter_ninv.apply_map, opfilt_pp.py:295-300, opfilt_tp.py:321-326) in one pass over the pixels */
+int pl_map_qu_weight(int64_t n, double *qmap, double *umap, const double *nqq, const double *nqu, const double *nuu, void *stream);
 /* complex product of spin maps: (or + i oi) (+)= sign * (ar + s1 i ai)(br + s2 i bi); accumulate != 0 adds into out */
 int pl_map_cmul(int64_t n, const double *ar, const double *ai, double s1, const double *br, const double *bi, double s2,
                 double sign, double *outr, double *outi, int accumulate, void *stream);

@@ -37,7 +37,9 @@ cl_weight['bb'] *= 0.
 # PLENS_DEVICE_SIMS=1: phases, sky alms, maps and noise are generated on the GPU (torch Philox streams instead of numpy's:
 # other realisations, same statistics, still a pure function of (seed, field, index)) and never pass through host memory
 DEVICE_SIMS = os.environ.get('PLENS_DEVICE_SIMS', '0') == '1'
-_pix, _sky = (phas.pix_lib_phas_dev, phas.lib_phas_dev) if DEVICE_SIMS else (phas.pix_lib_phas, phas.lib_phas)
+# (host phases: the counter-seeded libraries -- every rank of a sharded run draws the same simulation for the same index without a
+# shared generator-state database; phas.pix_lib_phas / phas.lib_phas are the reference's state-recording ones)
+_pix, _sky = (phas.pix_lib_phas_dev, phas.lib_phas_dev) if DEVICE_SIMS else (phas.pix_lib_phas_seeded, phas.lib_phas_seeded)
 pix_phas = _pix(os.path.join(TEMP, 'pix_phas_nside%s%s' % (nside, '_dev' * DEVICE_SIMS)), 3, (hp.nside2npix(nside),), seed=11)
 sky_phas = _sky(os.path.join(TEMP, 'sky_phas_lmax%s%s' % (lmax_ivf, '_dev' * DEVICE_SIMS)), 3, lmax_ivf, seed=12)
 skies = cmbs.sims_cmb_unl({k: cl_len[k] for k in ['tt', 'ee', 'bb', 'te']}, sky_phas)

@@ -14,36 +14,40 @@
 
 namespace plshts {
 int rings_per_group(int spin, const DevPlan &P);
-void launch_prep0(const DevPlan &P, const double *alm, const double *fl, double *prep, hipStream_t st);
+void launch_prep0(const DevPlan &P, const double *alm, const double *fl, double *prep, hipStream_t st, int nb = 1);
 void launch_preps(const DevPlan &P, const DevSpinTab &S, int spin, const double *alm, const double *fl, double *prep, hipStream_t st, bool gonly);
-void launch_synth0(const DevPlan &P, const double *prep, double *phase, hipStream_t st);
-void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st, bool gonly);
+void launch_synth0(const DevPlan &P, const double *prep, double *phase, hipStream_t st, int nb = 1);
+void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st, bool gonly, int nb = 1);
 void launch_synths_pair(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st);
 void launch_synths_batch2(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st);
 void launch_anal0(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st,
-                  const double *add = nullptr, const double *fl_add = nullptr);
+                  const double *add = nullptr, const double *fl_add = nullptr, int nb = 1);
 void launch_anals(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
                   const double *fl, double *alm, hipStream_t st);
 void launch_anals_gc(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial, const double *fl,
-                     double *almG, double *almC, hipStream_t st, const double *addG, const double *addC, const double *flG, const double *flC);
+                     double *almG, double *almC, hipStream_t st, const double *addG, const double *addC, const double *flG, const double *flC,
+                     int nb = 1);
 void launch_preps_gc(const DevPlan &P, const DevSpinTab &S, int spin, const double *almG, const double *almC, const double *fl, double *prep,
-                     hipStream_t st);
-void launch_almxfl(int lmax, const double *in, const double *fl, int nfl, double *out, hipStream_t st);
-void launch_alm_copy(int lmax_in, const double *in, int lmax_out, double *out, hipStream_t st);
+                     hipStream_t st, int nb = 1);
+void launch_almxfl(int lmax, const double *in, const double *fl, int nfl, double *out, hipStream_t st, int nb = 1);
+void launch_alm_copy(int lmax_in, const double *in, int lmax_out, double *out, hipStream_t st, int nb = 1);
 void launch_alm2cl(int lmax, const double *a, const double *b, double *cl, hipStream_t st);
 void launch_axpy(int64_t n, double a, const double *x, const double *y, double *out, hipStream_t st);
-void launch_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *parts, hipStream_t st);
-void launch_axpy_dev(int64_t n, const double *num, const double *den, double sign, const double *x, double *y, hipStream_t st);
+void launch_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *parts, hipStream_t st, int nb = 1);
+void launch_axpy_dev(int64_t n, const double *num, const double *den, double sign, const double *x, double *y, hipStream_t st, int nb = 1);
 void launch_cg_fused(int nf, const int *lmax, int lmin, const double *const *a, const double *const *b1, const double *const *b2, double *parts1,
                      double *parts2, const double *den, double *const *y1, const double *const *x1, double sign1, double *const *y2,
-                     const double *const *x2, double sign2, unsigned *bar, hipStream_t st);
+                     const double *const *x2, double sign2, unsigned *bar, hipStream_t st, int nbatch = 1, const double *active = nullptr);
 void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st,
-                       const double *fl_hi = nullptr);
-void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st);
-void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st);
+                       const double *fl_hi = nullptr, int nb = 1);
+void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st,
+                             int nb = 1);
+void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st, int nb = 1);
 void launch_gemv(int nrows, int ncols, int64_t lda, const double *A, const double *x, double *y, hipStream_t st);
+void launch_gemv_nb(int nrows, int ncols, int64_t lda, const double *A, int nb, const double *x, double *y, hipStream_t st);
 void launch_copy_slim(const double *src, double *dst, int64_t ndoubles, int nblocks, hipStream_t st);
 void launch_map_mul(int64_t n, const double *a, const double *b, double *out, hipStream_t st);
+void launch_map_qu_weight(int64_t n, double *q, double *u, const double *nqq, const double *nqu, const double *nuu, hipStream_t st);
 void launch_qe_lens_product(int64_t n, const double *tmap, const double *gt, const double *ct, const double *rep, const double *imp,
                             const double *g3, const double *c3, const double *g1, const double *c1, double *outr, double *outi, hipStream_t st);
 void launch_map_cmul(int64_t n, const double *ar, const double *ai, double s1, const double *br, const double *bi, double s2,
@@ -398,14 +402,14 @@ int64_t pl_plan_phase_doubles(const pl_plan *p, int spin)
     return (int64_t)p->P.npairs * p->P.mstride * 4 * ncomp_of(spin);
 }
 
-static int legendre_synth_impl(pl_plan *p, int spin, const double *alm, const double *fl, double *phase, void *stream, bool gonly)
+static int legendre_synth_impl(pl_plan *p, int spin, const double *alm, const double *fl, double *phase, void *stream, bool gonly, int nb = 1)
 {
     if (!p) return fail("null plan");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (spin == 0) {
-        if (grow(p, &p->prep, &p->prep_cap, p->P.nent0 * 4)) return 1;
-        launch_prep0(p->P, alm, fl, p->prep, st);
-        { ProfScope ps(p, PK_LEG_SYNTH0, st); launch_synth0(p->P, p->prep, phase, st); }
+    if (spin == 0) {  // nb > 1: nb consecutive alm arrays -> phase array of nb components (spin 0 only)
+        if (grow(p, &p->prep, &p->prep_cap, p->P.nent0 * 4 * nb)) return 1;
+        launch_prep0(p->P, alm, fl, p->prep, st, nb);
+        { ProfScope ps(p, PK_LEG_SYNTH0, st); launch_synth0(p->P, p->prep, phase, st, nb); }
     } else {
         if (ensure_spin(p, spin)) return 1;
         if (grow(p, &p->prep, &p->prep_cap, p->nent[spin] * 4)) return 1;
@@ -599,6 +603,83 @@ int pl_alm_copy(int lmax_in, const double *in, int lmax_out, double *out, void *
     return 0;
 }
 
+// ---- batched forms: every alm / map argument holds nb arrays back to back; filters, noise maps and template matrices are shared ----
+#define PL_NB_CHECK(name) if (nb < 1 || nb > PL_MAX_BATCH) return fail(name ": batch count out of range [1, PL_MAX_BATCH]")
+
+int pl_almxfl_b(int lmax, int nb, const double *alm_in, const double *fl, int nfl, double *alm_out, void *stream)
+{
+    PL_NB_CHECK("pl_almxfl_b");
+    launch_almxfl(lmax, alm_in, fl, nfl, alm_out, static_cast<hipStream_t>(stream), nb);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_alm_copy_b(int lmax_in, int nb, const double *in, int lmax_out, double *out, void *stream)
+{
+    PL_NB_CHECK("pl_alm_copy_b");
+    launch_alm_copy(lmax_in, in, lmax_out, out, static_cast<hipStream_t>(stream), nb);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_alm_splice_b(int lmax_lo, int nb, const double *alm_lo, int lmax_hi, const double *alm_hi, const double *fl_hi, int lsplit, double *out, void *stream)
+{
+    PL_NB_CHECK("pl_alm_splice_b");
+    if (lsplit > lmax_lo || lsplit > lmax_hi || lmax_hi < 0) return fail("pl_alm_splice_b: lsplit exceeds a band-limit");
+    launch_alm_splice(lmax_lo, alm_lo, lmax_hi, alm_hi, lsplit, out, static_cast<hipStream_t>(stream), fl_hi, nb);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_almxfl_add_b(int lmax, int nb, const double *a, const double *b, const double *fl, int nfl, double *out, void *stream)
+{
+    PL_NB_CHECK("pl_almxfl_add_b");
+    if (lmax < 0 || !a || !b || !fl || !out) return fail("pl_almxfl_add_b: bad arguments");
+    launch_almxfl_add(lmax, a, b, fl, nfl, out, static_cast<hipStream_t>(stream), nb);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_alm_dot_b(int lmax, int lmin, int nb, const double *a, const double *b, int accumulate, double *parts_dev, void *stream)
+{
+    PL_NB_CHECK("pl_alm_dot_b");
+    if (lmax < 0 || !a || !b || !parts_dev) return fail("pl_alm_dot_b: bad arguments");
+    launch_alm_dot(lmax, lmin < 0 ? 0 : lmin, a, b, accumulate, parts_dev, static_cast<hipStream_t>(stream), nb);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_axpy_dev_b(int64_t n, int nb, const double *num_parts_dev, const double *den_parts_dev, double sign, const double *x, double *y, void *stream)
+{
+    PL_NB_CHECK("pl_axpy_dev_b");
+    if (n < 0 || !num_parts_dev || !x || !y) return fail("pl_axpy_dev_b: bad arguments");
+    if (n == 0) return 0;
+    launch_axpy_dev(n, num_parts_dev, den_parts_dev, sign, x, y, static_cast<hipStream_t>(stream), nb);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_template_project_b(int64_t npix, int nmodes, int nb, double *tmap, const double *n_inv, const double *pmat, const double *rmat, double *scratch,
+                          void *stream)
+{
+    PL_NB_CHECK("pl_template_project_b");
+    if (npix <= 0 || nmodes < 1 || nmodes > PL_TEMPLATE_MAX_MODES || !tmap || !n_inv || !pmat || !rmat || !scratch)
+        return fail("pl_template_project_b: bad arguments (1 <= nmodes <= PL_TEMPLATE_MAX_MODES)");
+    launch_template_project(npix, nmodes, tmap, n_inv, pmat, rmat, scratch, static_cast<hipStream_t>(stream), nb);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_gemv_b(int nrows, int ncols, int64_t lda, const double *A, int nb, const double *x, double *y, void *stream)
+{
+    PL_NB_CHECK("pl_gemv_b");
+    if (nrows < 0 || ncols < 0 || lda < ncols || !A || !x || !y) return fail("pl_gemv_b: bad arguments");
+    if (nrows == 0) return 0;
+    launch_gemv_nb(nrows, ncols, lda, A, nb, x, y, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int pl_axpy(int64_t n, double a, const double *x, const double *y, double *out, void *stream)
 {
     launch_axpy(n, a, x, y, out, static_cast<hipStream_t>(stream));
@@ -623,9 +704,9 @@ int pl_axpy_dev(int64_t n, const double *num_parts_dev, const double *den_parts_
     return 0;
 }
 
-int pl_cg_dot_axpy(int nf, const int *lmax, int lmin, const double *const *a, const double *const *b1, const double *const *b2,
-                   double *parts1_dev, double *parts2_dev, const double *den_parts_dev, double *const *y1, const double *const *x1, double sign1,
-                   double *const *y2, const double *const *x2, double sign2, unsigned *barrier_dev, void *stream)
+static int cg_dot_axpy_impl(int nb, int nf, const int *lmax, int lmin, const double *const *a, const double *const *b1, const double *const *b2,
+                            double *parts1_dev, double *parts2_dev, const double *den_parts_dev, double *const *y1, const double *const *x1, double sign1,
+                            double *const *y2, const double *const *x2, double sign2, unsigned *barrier_dev, const double *active_dev, void *stream)
 {
     if (nf < 1 || nf > 3 || !lmax || !a || !b1 || !parts1_dev || !y1 || !x1) return fail("pl_cg_dot_axpy: bad arguments");
     if (!b2 && !den_parts_dev) return fail("pl_cg_dot_axpy: either a second scalar product (b2) or a denominator (den_parts_dev) is needed");
@@ -635,9 +716,24 @@ int pl_cg_dot_axpy(int nf, const int *lmax, int lmin, const double *const *a, co
     for (int k = 0; k < nf; ++k)
         if (lmax[k] < 0 || !a[k] || !b1[k] || (b2 && !b2[k]) || !y1[k] || !x1[k] || (y2 && (!y2[k] || !x2[k]))) return fail("pl_cg_dot_axpy: null field");
     launch_cg_fused(nf, lmax, lmin < 0 ? 0 : lmin, a, b1, b2, parts1_dev, parts2_dev, den_parts_dev, y1, x1, sign1, y2, x2, sign2, barrier_dev,
-                    static_cast<hipStream_t>(stream));
+                    static_cast<hipStream_t>(stream), nb, active_dev);
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+int pl_cg_dot_axpy(int nf, const int *lmax, int lmin, const double *const *a, const double *const *b1, const double *const *b2,
+                   double *parts1_dev, double *parts2_dev, const double *den_parts_dev, double *const *y1, const double *const *x1, double sign1,
+                   double *const *y2, const double *const *x2, double sign2, unsigned *barrier_dev, void *stream)
+{
+    return cg_dot_axpy_impl(1, nf, lmax, lmin, a, b1, b2, parts1_dev, parts2_dev, den_parts_dev, y1, x1, sign1, y2, x2, sign2, barrier_dev, nullptr, stream);
+}
+
+int pl_cg_dot_axpy_b(int nb, int nf, const int *lmax, int lmin, const double *const *a, const double *const *b1, const double *const *b2,
+                     double *parts1_dev, double *parts2_dev, const double *den_parts_dev, double *const *y1, const double *const *x1, double sign1,
+                     double *const *y2, const double *const *x2, double sign2, const double *active_dev, void *stream)
+{
+    PL_NB_CHECK("pl_cg_dot_axpy_b");
+    return cg_dot_axpy_impl(nb, nf, lmax, lmin, a, b1, b2, parts1_dev, parts2_dev, den_parts_dev, y1, x1, sign1, y2, x2, sign2, nullptr, active_dev, stream);
 }
 
 int pl_template_project(int64_t npix, int nmodes, double *tmap, const double *n_inv, const double *pmat, const double *rmat, double *scratch, void *stream)
@@ -653,8 +749,9 @@ int pl_template_project(int64_t npix, int nmodes, double *tmap, const double *n_
 //   alm_out = fl_out * Y^t [N^-1 - N^-1 P (P^t N^-1 P)^-1 P^t N^-1] Y (fl_in * alm_in)  +  fl_add * alm_add.
 // On grids whose rings all run in the generic ring-FFT kernel (the coarse levels of the multigrid chain) the weighting and the projection
 // ride in the two FFT launches (NinvProj); on the finer grids they are the two pl_template_project launches between the transforms.
-int pl_cg_fwd_tt(pl_plan *p, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *pmat, const double *rmat,
-                 double *scratch, const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out, void *stream)
+static int cg_fwd_tt_impl(pl_plan *p, int nb, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *pmat,
+                          const double *rmat, double *scratch, const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out,
+                          void *stream)
 {
     if (!p) return fail("null plan");
     if (!alm_in || !alm_out || !n_inv) return fail("pl_cg_fwd_tt: null alm / n_inv pointer");
@@ -662,42 +759,55 @@ int pl_cg_fwd_tt(pl_plan *p, const double *alm_in, const double *fl_in, const do
     if ((alm_add == nullptr) != (fl_add == nullptr)) return fail("pl_cg_fwd_tt: alm_add and fl_add come together");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const DevPlan &P = p->P;
-    if (grow(p, &p->phase, &p->phase_cap, pl_plan_phase_doubles(p, 0)) || grow(p, &p->wmap, &p->wmap_cap, P.npix)) return 1;
-    if (legendre_synth_impl(p, 0, alm_in, fl_in, p->phase, stream, false)) return 1;
+    if (grow(p, &p->phase, &p->phase_cap, pl_plan_phase_doubles(p, 0) * nb) || grow(p, &p->wmap, &p->wmap_cap, P.npix * nb)) return 1;
+    if (legendre_synth_impl(p, 0, alm_in, fl_in, p->phase, stream, false, nb)) return 1;
     // the weighting always rides in the synthesis-side FFT kernels; the projection too where every ring runs in the generic kernel
     const bool fused = nmodes == 0 || (fft_all_generic(P, p->F) && nmodes <= kFuseModes);
     NinvProj W;
     W.n_inv = n_inv;
     if (fused && nmodes > 0) {
-        if (grow(p, &p->tparts, &p->tparts_cap, (int64_t)nmodes * P.npairs)) return 1;
+        if (grow(p, &p->tparts, &p->tparts_cap, (int64_t)nmodes * P.npairs * nb)) return 1;
         W.nmodes = nmodes; W.nparts = P.npairs; W.parts = p->tparts; W.pm = pmat; W.rm = rmat;
     }
     {
         ProfScope ps(p, PK_FFT_SYNTH, st);
-        HIPCHK(launch_phase2map(P, p->F, p->fs, mlim_of(p, 0), 1, p->phase, p->wmap, st, &W));
+        HIPCHK(launch_phase2map(P, p->F, p->fs, mlim_of(p, 0), nb, p->phase, p->wmap, st, &W));
     }
     if (!fused) {  // the map arrives weighted: coefficients and projection only (n_inv null)
-        launch_template_project(P.npix, nmodes, p->wmap, nullptr, pmat, rmat, scratch, st);
+        launch_template_project(P.npix, nmodes, p->wmap, nullptr, pmat, rmat, scratch, st, nb);
         HIPCHK(hipGetLastError());
     }
     {
         ProfScope ps(p, PK_FFT_ANAL, st);
-        HIPCHK(launch_map2phase(P, p->F, p->fs, mlim_of(p, 0), 1, p->wmap, p->phase, st, (fused && nmodes > 0) ? &W : nullptr));
+        HIPCHK(launch_map2phase(P, p->F, p->fs, mlim_of(p, 0), nb, p->wmap, p->phase, st, (fused && nmodes > 0) ? &W : nullptr));
     }
     const int RG = rings_per_group(0, P);
     const int ngroups = (P.npairs + RG - 1) / RG;
-    if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * P.nent0 * 4)) return 1;
-    { ProfScope ps(p, PK_LEG_ANAL0, st); launch_anal0(P, p->phase, p->partial, fl_out, alm_out, st, alm_add, fl_add); }
+    if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * P.nent0 * 4 * nb)) return 1;
+    { ProfScope ps(p, PK_LEG_ANAL0, st); launch_anal0(P, p->phase, p->partial, fl_out, alm_out, st, alm_add, fl_add, nb); }
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+int pl_cg_fwd_tt(pl_plan *p, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *pmat, const double *rmat,
+                 double *scratch, const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out, void *stream)
+{
+    return cg_fwd_tt_impl(p, 1, alm_in, fl_in, n_inv, nmodes, pmat, rmat, scratch, alm_add, fl_add, alm_out, fl_out, stream);
+}
+
+int pl_cg_fwd_tt_b(pl_plan *p, int nb, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *pmat, const double *rmat,
+                   double *scratch, const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out, void *stream)
+{
+    PL_NB_CHECK("pl_cg_fwd_tt_b");
+    return cg_fwd_tt_impl(p, nb, alm_in, fl_in, n_inv, nmodes, pmat, rmat, scratch, alm_add, fl_add, alm_out, fl_out, stream);
 }
 
 // The polarization CG operator (fwd_op.calc, plancklens/qcinv/opfilt_pp.py:69-78, apply_alm :190-205 with the single-map apply_map
 // :207-215): (E, B)_out = fl_out * Y2^t [n_inv * Y2 (fl_in * (E, B)_in)] + (fl_add_e E_add, fl_add_b B_add).  E and B are separate arrays.
 // The weighting rides in the synthesis-side ring-FFT launches (every kernel class), the add terms in k_posts.
-int pl_cg_fwd_pp(pl_plan *p, const double *elm_in, const double *blm_in, const double *fl_in, const double *n_inv, const double *elm_add,
-                 const double *blm_add, const double *fl_add_e, const double *fl_add_b, double *elm_out, double *blm_out, const double *fl_out,
-                 void *stream)
+static int cg_fwd_pp_impl(pl_plan *p, int nb, const double *elm_in, const double *blm_in, const double *fl_in, const double *n_inv, const double *elm_add,
+                          const double *blm_add, const double *fl_add_e, const double *fl_add_b, double *elm_out, double *blm_out, const double *fl_out,
+                          void *stream)
 {
     if (!p) return fail("null plan");
     if (!elm_in || !blm_in || !elm_out || !blm_out || !n_inv) return fail("pl_cg_fwd_pp: null alm / n_inv pointer");
@@ -707,32 +817,47 @@ int pl_cg_fwd_pp(pl_plan *p, const double *elm_in, const double *blm_in, const d
     const DevPlan &P = p->P;
     const int spin = 2;
     if (ensure_spin(p, spin)) return 1;
-    if (grow(p, &p->phase, &p->phase_cap, pl_plan_phase_doubles(p, spin)) || grow(p, &p->wmap, &p->wmap_cap, 2 * P.npix) ||
-        grow(p, &p->prep, &p->prep_cap, p->nent[spin] * 4))
+    if (grow(p, &p->phase, &p->phase_cap, pl_plan_phase_doubles(p, spin) * nb) || grow(p, &p->wmap, &p->wmap_cap, 2 * P.npix * nb) ||
+        grow(p, &p->prep, &p->prep_cap, p->nent[spin] * 4 * nb))
         return 1;
-    launch_preps_gc(P, p->S[spin], spin, elm_in, blm_in, fl_in, p->prep, st);
-    { ProfScope ps(p, PK_LEG_SYNTHS, st); launch_synths(P, p->S[spin], spin, p->prep, p->phase, st, false); }
+    launch_preps_gc(P, p->S[spin], spin, elm_in, blm_in, fl_in, p->prep, st, nb);
+    { ProfScope ps(p, PK_LEG_SYNTHS, st); launch_synths(P, p->S[spin], spin, p->prep, p->phase, st, false, nb); }
     HIPCHK(hipGetLastError());
     NinvProj W;
     W.n_inv = n_inv;
     {
         ProfScope ps(p, PK_FFT_SYNTH, st);
-        HIPCHK(launch_phase2map(P, p->F, p->fs, mlim_of(p, spin), 2, p->phase, p->wmap, st, &W));
+        HIPCHK(launch_phase2map(P, p->F, p->fs, mlim_of(p, spin), 2 * nb, p->phase, p->wmap, st, &W));
     }
     {
         ProfScope ps(p, PK_FFT_ANAL, st);
-        HIPCHK(launch_map2phase(P, p->F, p->fs, mlim_of(p, spin), 2, p->wmap, p->phase, st));
+        HIPCHK(launch_map2phase(P, p->F, p->fs, mlim_of(p, spin), 2 * nb, p->wmap, p->phase, st));
     }
     const int RG = rings_per_group(spin, P);
     const int ngroups = (P.npairs + RG - 1) / RG;
-    if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * p->nent[spin] * 4)) return 1;
+    if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * p->nent[spin] * 4 * nb)) return 1;
     {
         ProfScope ps(p, PK_LEG_ANALS, st);
         launch_anals_gc(P, p->S[spin], spin, p->nent[spin], p->phase, p->partial, fl_out, elm_out, blm_out, st, elm_add, blm_add, fl_add_e,
-                        fl_add_b);
+                        fl_add_b, nb);
     }
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+int pl_cg_fwd_pp(pl_plan *p, const double *elm_in, const double *blm_in, const double *fl_in, const double *n_inv, const double *elm_add,
+                 const double *blm_add, const double *fl_add_e, const double *fl_add_b, double *elm_out, double *blm_out, const double *fl_out,
+                 void *stream)
+{
+    return cg_fwd_pp_impl(p, 1, elm_in, blm_in, fl_in, n_inv, elm_add, blm_add, fl_add_e, fl_add_b, elm_out, blm_out, fl_out, stream);
+}
+
+int pl_cg_fwd_pp_b(pl_plan *p, int nb, const double *elm_in, const double *blm_in, const double *fl_in, const double *n_inv, const double *elm_add,
+                   const double *blm_add, const double *fl_add_e, const double *fl_add_b, double *elm_out, double *blm_out, const double *fl_out,
+                   void *stream)
+{
+    PL_NB_CHECK("pl_cg_fwd_pp_b");
+    return cg_fwd_pp_impl(p, nb, elm_in, blm_in, fl_in, n_inv, elm_add, blm_add, fl_add_e, fl_add_b, elm_out, blm_out, fl_out, stream);
 }
 
 int pl_alm_splice(int lmax_lo, const double *alm_lo, int lmax_hi, const double *alm_hi, int lsplit, double *out, void *stream)
@@ -781,6 +906,15 @@ int pl_copy_slim(const double *src_dev, double *dst, int64_t ndoubles, int nbloc
 int pl_map_mul(int64_t n, const double *a, const double *b, double *out, void *stream)
 {
     launch_map_mul(n, a, b, out, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_map_qu_weight(int64_t n, double *qmap, double *umap, const double *nqq, const double *nqu, const double *nuu, void *stream)
+{
+    if (n < 0 || !qmap || !umap || !nqq || !nqu || !nuu) return fail("pl_map_qu_weight: bad arguments");
+    if (n == 0) return 0;
+    launch_map_qu_weight(n, qmap, umap, nqq, nqu, nuu, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -8,9 +8,16 @@
 
 namespace plshts {
 
+// Batches (block vectors of the conjugate-gradient filter: several right-hand sides through every launch): an array argument of a
+// batched launch holds the entries back to back; the kernels take the entry index from blockIdx.z (the (l, m)-grid kernels) or
+// blockIdx.y (the others) and offset their pointers by whole arrays.  A batch of one launches exactly what it always did.
+__device__ __forceinline__ int64_t alm_count(int lmax) { return (int64_t)(lmax + 1) * (lmax + 2) / 2; }
+
 // alm index -> (l, m) without a table: thread per (m, l) on a 2-D grid
-__global__ void k_almxfl(int lmax, const double2 *__restrict__ in, const double *__restrict__ fl, int nfl, double2 *__restrict__ out)
+__global__ void k_almxfl(int lmax, const double2 *__restrict__ in_, const double *__restrict__ fl, int nfl, double2 *__restrict__ out_)
 {
+    const double2 *__restrict__ in = in_ + blockIdx.z * alm_count(lmax);
+    double2 *__restrict__ out = out_ + blockIdx.z * alm_count(lmax);
     const int m = blockIdx.y;
     const int64_t base = (int64_t)m * (2 * lmax + 1 - m) / 2;
     for (int l = m + blockIdx.x * blockDim.x + threadIdx.x; l <= lmax; l += gridDim.x * blockDim.x) {
@@ -20,8 +27,10 @@ __global__ void k_almxfl(int lmax, const double2 *__restrict__ in, const double 
     }
 }
 
-__global__ void k_alm_copy(int lmax_in, const double2 *__restrict__ in, int lmax_out, double2 *__restrict__ out)
+__global__ void k_alm_copy(int lmax_in, const double2 *__restrict__ in_, int lmax_out, double2 *__restrict__ out_)
 {
+    const double2 *__restrict__ in = in_ + blockIdx.z * alm_count(lmax_in);
+    double2 *__restrict__ out = out_ + blockIdx.z * alm_count(lmax_out);
     const int m = blockIdx.y;
     const int64_t bo = (int64_t)m * (2 * lmax_out + 1 - m) / 2;
     const int64_t bi = (int64_t)m * (2 * lmax_in + 1 - m) / 2;
@@ -72,6 +81,19 @@ __global__ void k_map_cmul(int64_t n, const double *__restrict__ ar, const doubl
         double pr = sign * (xr * yr - xi * yi), pi = sign * (xr * yi + xi * yr);
         if (accumulate) { pr += outr[i]; pi += outi[i]; }
         outr[i] = pr; outi[i] = pi;
+    }
+}
+
+// Polarization inverse-noise weighting with a QU cross term, in place (alm_filter_ninv.apply_map, opfilt_pp.py:295-300 and
+// opfilt_tp.py:321-326):  (Q, U) <- (nqq Q + nqu U, nqu Q + nuu U).  One pass: 5 reads + 2 writes per pixel.
+__global__ void k_map_qu_weight(int64_t n, double *__restrict__ q, double *__restrict__ u, const double *__restrict__ nqq,
+                                const double *__restrict__ nqu, const double *__restrict__ nuu)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double a = q[i], b = u[i], x = nqu[i];
+        q[i] = a * nqq[i] + x * b;
+        u[i] = b * nuu[i] + x * a;
     }
 }
 
@@ -218,11 +240,13 @@ __device__ __forceinline__ double alm_dot_partial(int lmax, int lmin, const doub
 // The scalar product is left as kDotParts per-workgroup partial sums; whoever consumes it (k_axpy_dev, the host) adds
 // them in index order.  One launch, no atomics, no cross-XCD fence, bit-reproducible.
 constexpr int kDotParts = 64;
-__global__ __launch_bounds__(kDotThreads) void k_alm_dot_parts(int lmax, int lmin, const double2 *__restrict__ a, const double2 *__restrict__ b,
-                                                               int accumulate, double *__restrict__ parts)
+__global__ __launch_bounds__(kDotThreads) void k_alm_dot_parts(int lmax, int lmin, const double2 *__restrict__ a_, const double2 *__restrict__ b_,
+                                                               int accumulate, double *__restrict__ parts_)
 {
     __shared__ double red[kDotThreads];
     const int64_t nalm = (int64_t)(lmax + 1) * (lmax + 2) / 2;
+    const double2 *__restrict__ a = a_ + blockIdx.y * nalm, *__restrict__ b = b_ + blockIdx.y * nalm;
+    double *__restrict__ parts = parts_ + blockIdx.y * kDotParts;
     const double tot = block_sum_1024(alm_dot_partial(lmax, lmin, a, b, (int64_t)blockIdx.x * kDotThreads + threadIdx.x,
                                                       (int64_t)gridDim.x * kDotThreads, nalm), red);
     if (threadIdx.x == 0) parts[blockIdx.x] = accumulate ? parts[blockIdx.x] + tot : tot;
@@ -235,9 +259,12 @@ __device__ __forceinline__ double dot_parts_sum(const double *__restrict__ parts
     return s;
 }
 // y += sign * num / den * x, num and den given as partial sums in device memory (den may be null: 1)
-__global__ void k_axpy_dev(int64_t n, const double *__restrict__ num, const double *__restrict__ den, double sign,
-                           const double *__restrict__ x, double *__restrict__ y)
+__global__ void k_axpy_dev(int64_t n, const double *__restrict__ num_, const double *__restrict__ den_, double sign,
+                           const double *__restrict__ x_, double *__restrict__ y_)
 {
+    const double *__restrict__ num = num_ + blockIdx.y * kDotParts, *__restrict__ den = den_ ? den_ + blockIdx.y * kDotParts : nullptr;
+    const double *__restrict__ x = x_ + blockIdx.y * n;
+    double *__restrict__ y = y_ + blockIdx.y * n;
     __shared__ double cs;
     if (threadIdx.x == 0) cs = den ? sign * dot_parts_sum(num) * (1.0 / dot_parts_sum(den)) : sign * dot_parts_sum(num);
     __syncthreads();
@@ -298,22 +325,29 @@ __device__ __forceinline__ double dot_parts_sum_coherent(const double *parts)
 }
 // MODE 0: products, barrier, updates; 1: products only; 2: updates only (launched after a MODE 1 launch: no barrier, and the
 // updates of all fields still share one launch)
+// Batch entry blockIdx.y: arrays offset by whole alm arrays, its own partial sums, its own step length (`active`, optional: one
+// double per entry, 1 or 0 -- an entry whose solve has converged keeps its vectors, cd_solve with per-entry stopping).
 template <int MODE>
-__global__ __launch_bounds__(kDotThreads) void k_cg_fused(CgFused f, double *__restrict__ parts1, double *__restrict__ parts2,
-                                                          const double *__restrict__ den, double sign1, double sign2, unsigned *bar)
+__global__ __launch_bounds__(kDotThreads) void k_cg_fused(CgFused f, double *__restrict__ parts1_, double *__restrict__ parts2_,
+                                                          const double *__restrict__ den_, double sign1, double sign2, unsigned *bar,
+                                                          const double *__restrict__ active)
 {
     __shared__ double red[kDotThreads];
     __shared__ double cs;
+    const int bq = blockIdx.y;
+    double *__restrict__ parts1 = parts1_ + bq * kDotParts, *__restrict__ parts2 = parts2_ ? parts2_ + bq * kDotParts : nullptr;
+    const double *__restrict__ den = den_ ? den_ + bq * kDotParts : nullptr;
     if (MODE != 2 && blockIdx.x < kDotParts) {
         double t1 = 0.0, t2 = 0.0;
         for (int k = 0; k < f.nf; ++k) {
             const int64_t nalm = (int64_t)(f.lmax[k] + 1) * (f.lmax[k] + 2) / 2;
             const int64_t first = (int64_t)blockIdx.x * kDotThreads + threadIdx.x, stride = (int64_t)kDotParts * kDotThreads;
-            const double u1 = block_sum_1024(alm_dot_partial(f.lmax[k], f.lmin, f.a[k], f.b1[k], first, stride, nalm), red);
+            const int64_t o = bq * nalm;  // this batch entry's arrays
+            const double u1 = block_sum_1024(alm_dot_partial(f.lmax[k], f.lmin, f.a[k] + o, f.b1[k] + o, first, stride, nalm), red);
             t1 = k == 0 ? u1 : t1 + u1;
             __syncthreads();
             if (f.b2[0]) {
-                const double u2 = block_sum_1024(alm_dot_partial(f.lmax[k], f.lmin, f.a[k], f.b2[k], first, stride, nalm), red);
+                const double u2 = block_sum_1024(alm_dot_partial(f.lmax[k], f.lmin, f.a[k] + o, f.b2[k] + o, first, stride, nalm), red);
                 t2 = k == 0 ? u2 : t2 + u2;
                 __syncthreads();
             }
@@ -335,12 +369,14 @@ __global__ __launch_bounds__(kDotThreads) void k_cg_fused(CgFused f, double *__r
             dn = den ? dot_parts_sum(den) : dot_parts_sum(parts1);
         }
         cs = num * (1.0 / dn);
+        if (active) cs *= active[bq];
     }
     __syncthreads();
     const double c1 = sign1 * cs, c2 = sign2 * cs;  // sign = +-1: same value as k_axpy_dev's sign * num * (1 / den)
     for (int k = 0; k < f.nf; ++k) {
         const int64_t nalm = (int64_t)(f.lmax[k] + 1) * (f.lmax[k] + 2) / 2;
-        for (int64_t i = (int64_t)blockIdx.x * kDotThreads + threadIdx.x; i < nalm; i += (int64_t)gridDim.x * kDotThreads) {
+        const int64_t o = bq * nalm;
+        for (int64_t i = o + (int64_t)blockIdx.x * kDotThreads + threadIdx.x; i < o + nalm; i += (int64_t)gridDim.x * kDotThreads) {
             const double2 u = f.x1[k][i];
             double2 v = f.y1[k][i];
             v.x = fma(c1, u.x, v.x); v.y = fma(c1, u.y, v.y);
@@ -364,9 +400,11 @@ constexpr int kProjParts = 256, kProjMaxModes = 16;
 // coarse multigrid levels, where this pair of kernels runs dozens of times per CG iteration) take fewer, smaller workgroups:
 // the work is a few microseconds and the cost is the launch and the reduction tail.
 template <int NT>
-__global__ __launch_bounds__(NT) void k_tproj_coeffs(int64_t n, int nmodes, double *__restrict__ t, const double *__restrict__ n_inv,
-                                                     const double *__restrict__ pm, double *__restrict__ parts)
+__global__ __launch_bounds__(NT) void k_tproj_coeffs(int64_t n, int nmodes, double *__restrict__ t_, const double *__restrict__ n_inv,
+                                                     const double *__restrict__ pm, double *__restrict__ parts_)
 {
+    double *__restrict__ t = t_ + blockIdx.y * n;  // batch entry blockIdx.y: its own map and partial sums, shared n_inv and modes
+    double *__restrict__ parts = parts_ + blockIdx.y * (kProjMaxModes * kProjParts);
     __shared__ double red[kProjMaxModes][NT / 64];
     double acc[kProjMaxModes];
 #pragma unroll
@@ -397,9 +435,11 @@ __global__ __launch_bounds__(NT) void k_tproj_coeffs(int64_t n, int nmodes, doub
 }
 // c_k = sum of the nparts partial sums of mode k, by one wavefront per mode in a fixed order (lane j takes parts j, j + 64, ...,
 // then a fixed shuffle tree): one barrier instead of a shared-memory tree per mode
-__global__ __launch_bounds__(256) void k_tproj_apply(int64_t n, int nmodes, int nparts, double *__restrict__ t, const double *__restrict__ rm,
-                                                     const double *__restrict__ parts)
+__global__ __launch_bounds__(256) void k_tproj_apply(int64_t n, int nmodes, int nparts, double *__restrict__ t_, const double *__restrict__ rm,
+                                                     const double *__restrict__ parts_)
 {
+    double *__restrict__ t = t_ + blockIdx.y * n;
+    const double *__restrict__ parts = parts_ + blockIdx.y * (kProjMaxModes * kProjParts);
     __shared__ double c[kProjMaxModes];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int k = wave; k < nmodes; k += 4) {
@@ -469,12 +509,74 @@ __global__ __launch_bounds__(256) void k_gemv(int nrows, int ncols, int64_t lda,
     if (lane == 0) y[row] = v;
 }
 
+// The same for NB right-hand sides at once (Y[b] = A X[b], X: [nb][ncols], Y: [nb][nrows]): the block vectors of a batched
+// conjugate-gradient solve.  The matrix is read once for all of them (the 147 MB T block streams from the Infinity Cache at the
+// same rate as for one vector; 2 nb flops per matrix entry is far below the FMA rate: no MFMA needed for nb <= 8).  Every entry's sum
+// is formed exactly as k_gemv<2> forms it (same lane partition, same four chains, same tree): bit-identical to nb separate calls.
+template <int NB>
+__global__ __launch_bounds__(256) void k_gemv_nb(int nrows, int ncols, int64_t lda, const double *__restrict__ A, int nb, const double *__restrict__ X,
+                                                 double *__restrict__ Y)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const double2 *__restrict__ a2 = reinterpret_cast<const double2 *>(A + (int64_t)row * lda);
+    const double2 *__restrict__ x2[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) x2[b] = reinterpret_cast<const double2 *>(X + (int64_t)(b < nb ? b : nb - 1) * ncols);
+    double s[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) s[b][0] = s[b][1] = s[b][2] = s[b][3] = 0.;
+    const int n2 = ncols >> 1;
+    int c = lane;
+    for (; c + 448 < n2; c += 512) {
+        double2 u[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u[j] = a2[c + 64 * j];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double2 v = x2[b][c + 64 * j];
+                s[b][j & 3] = fma(u[j].x, v.x, s[b][j & 3]); s[b][j & 3] = fma(u[j].y, v.y, s[b][j & 3]);
+            }
+        }
+    }
+    for (; c + 192 < n2; c += 256) {
+        double2 u[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = a2[c + 64 * j];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double2 v = x2[b][c + 64 * j];
+                s[b][j] = fma(u[j].x, v.x, s[b][j]); s[b][j] = fma(u[j].y, v.y, s[b][j]);
+            }
+        }
+    }
+    for (; c < n2; c += 64) {
+        const double2 u = a2[c];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { const double2 v = x2[b][c]; s[b][0] = fma(u.x, v.x, s[b][0]); s[b][0] = fma(u.y, v.y, s[b][0]); }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        double v = (s[b][0] + s[b][1]) + (s[b][2] + s[b][3]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0 && b < nb) Y[(int64_t)b * nrows + row] = v;
+    }
+}
+
 // out (band-limit lmax_hi) = alm_lo for l <= lsplit, alm_hi above (util_alm.py:8-24)
 // fl_hi (optional, lmax_hi + 1 entries): the high part is fl_hi[l] * alm_hi -- the diagonal preconditioner of pre_op_split's high
 // multipoles (multigrid.py:163-182 with opfilt_tt.py:76-93) applied on the way
-__global__ void k_alm_splice(int lmax_lo, const double2 *__restrict__ lo, int lmax_hi, const double2 *__restrict__ hi, int lsplit,
-                             double2 *__restrict__ out, const double *__restrict__ fl_hi)
+__global__ void k_alm_splice(int lmax_lo, const double2 *__restrict__ lo_, int lmax_hi, const double2 *__restrict__ hi_, int lsplit,
+                             double2 *__restrict__ out_, const double *__restrict__ fl_hi)
 {
+    const double2 *__restrict__ lo = lo_ + blockIdx.z * alm_count(lmax_lo), *__restrict__ hi = hi_ + blockIdx.z * alm_count(lmax_hi);
+    double2 *__restrict__ out = out_ + blockIdx.z * alm_count(lmax_hi);
     const int m = blockIdx.y;
     const int64_t bh = (int64_t)m * (2 * lmax_hi + 1 - m) / 2;
     const int64_t bl = (int64_t)m * (2 * lmax_lo + 1 - m) / 2;
@@ -490,8 +592,10 @@ __global__ void k_alm_splice(int lmax_lo, const double2 *__restrict__ lo, int lm
 }
 
 // out = a + f_l b (fwd_op: N-part + S^-1 x, opfilt_tt.py:67-73); out may alias a
-__global__ void k_almxfl_add(int lmax, const double2 *a, const double2 *__restrict__ b, const double *__restrict__ fl, int nfl, double2 *out)
+__global__ void k_almxfl_add(int lmax, const double2 *a_, const double2 *__restrict__ b_, const double *__restrict__ fl, int nfl, double2 *out_)
 {
+    const double2 *a = a_ + blockIdx.z * alm_count(lmax), *__restrict__ b = b_ + blockIdx.z * alm_count(lmax);
+    double2 *out = out_ + blockIdx.z * alm_count(lmax);
     const int m = blockIdx.y;
     const int64_t base = (int64_t)m * (2 * lmax + 1 - m) / 2;
     for (int l = m + blockIdx.x * blockDim.x + threadIdx.x; l <= lmax; l += gridDim.x * blockDim.x) {
@@ -503,28 +607,28 @@ __global__ void k_almxfl_add(int lmax, const double2 *a, const double2 *__restri
 
 static inline int nblocks(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
-void launch_almxfl(int lmax, const double *in, const double *fl, int nfl, double *out, hipStream_t st)
+void launch_almxfl(int lmax, const double *in, const double *fl, int nfl, double *out, hipStream_t st, int nb)
 {
-    hipLaunchKernelGGL(k_almxfl, dim3(4, lmax + 1), dim3(256), 0, st, lmax, reinterpret_cast<const double2 *>(in), fl, nfl,
+    hipLaunchKernelGGL(k_almxfl, dim3(4, lmax + 1, nb), dim3(256), 0, st, lmax, reinterpret_cast<const double2 *>(in), fl, nfl,
                        reinterpret_cast<double2 *>(out));
 }
-void launch_alm_copy(int lmax_in, const double *in, int lmax_out, double *out, hipStream_t st)
+void launch_alm_copy(int lmax_in, const double *in, int lmax_out, double *out, hipStream_t st, int nb)
 {
-    hipLaunchKernelGGL(k_alm_copy, dim3(4, lmax_out + 1), dim3(256), 0, st, lmax_in, reinterpret_cast<const double2 *>(in),
+    hipLaunchKernelGGL(k_alm_copy, dim3(4, lmax_out + 1, nb), dim3(256), 0, st, lmax_in, reinterpret_cast<const double2 *>(in),
                        lmax_out, reinterpret_cast<double2 *>(out));
 }
-void launch_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *parts, hipStream_t st)
+void launch_alm_dot(int lmax, int lmin, const double *a, const double *b, int accumulate, double *parts, hipStream_t st, int nb)
 {
-    hipLaunchKernelGGL(k_alm_dot_parts, dim3(kDotParts), dim3(kDotThreads), 0, st, lmax, lmin, reinterpret_cast<const double2 *>(a),
+    hipLaunchKernelGGL(k_alm_dot_parts, dim3(kDotParts, nb), dim3(kDotThreads), 0, st, lmax, lmin, reinterpret_cast<const double2 *>(a),
                        reinterpret_cast<const double2 *>(b), accumulate, parts);
 }
-void launch_axpy_dev(int64_t n, const double *num, const double *den, double sign, const double *x, double *y, hipStream_t st)
+void launch_axpy_dev(int64_t n, const double *num, const double *den, double sign, const double *x, double *y, hipStream_t st, int nb)
 {
-    hipLaunchKernelGGL(k_axpy_dev, dim3(nblocks((n + 1) / 2)), dim3(256), 0, st, n, num, den, sign, x, y);
+    hipLaunchKernelGGL(k_axpy_dev, dim3(nblocks((n + 1) / 2), nb), dim3(256), 0, st, n, num, den, sign, x, y);
 }
 void launch_cg_fused(int nf, const int *lmax, int lmin, const double *const *a, const double *const *b1, const double *const *b2, double *parts1,
                      double *parts2, const double *den, double *const *y1, const double *const *x1, double sign1, double *const *y2,
-                     const double *const *x2, double sign2, unsigned *bar, hipStream_t st)
+                     const double *const *x2, double sign2, unsigned *bar, hipStream_t st, int nbatch, const double *active)
 {
     // bar null: two launches (products, then updates); else one launch with a grid barrier in between
     CgFused f = {};
@@ -547,25 +651,26 @@ void launch_cg_fused(int nf, const int *lmax, int lmin, const double *const *a, 
     if (nb < kDotParts) nb = kDotParts;
     if (nb > kCgBlocks) nb = kCgBlocks;
     if (bar) {
-        hipLaunchKernelGGL(k_cg_fused<0>, dim3(nb), dim3(kDotThreads), 0, st, f, parts1, parts2, den, sign1, sign2, bar);
+        hipLaunchKernelGGL(k_cg_fused<0>, dim3(nb), dim3(kDotThreads), 0, st, f, parts1, parts2, den, sign1, sign2, bar, active);  // (one entry only)
     } else {
-        hipLaunchKernelGGL(k_cg_fused<1>, dim3(kDotParts), dim3(kDotThreads), 0, st, f, parts1, parts2, den, sign1, sign2, bar);
+        hipLaunchKernelGGL(k_cg_fused<1>, dim3(kDotParts, nbatch), dim3(kDotThreads), 0, st, f, parts1, parts2, den, sign1, sign2, bar, active);
         const int nb2 = (int)((nmax + kDotThreads - 1) / kDotThreads);  // updates: one entry per thread up to 1024 workgroups
-        hipLaunchKernelGGL(k_cg_fused<2>, dim3(nb2 < 1 ? 1 : (nb2 > 1024 ? 1024 : nb2)), dim3(kDotThreads), 0, st, f, parts1, parts2, den, sign1,
-                           sign2, bar);
+        hipLaunchKernelGGL(k_cg_fused<2>, dim3(nb2 < 1 ? 1 : (nb2 > 1024 ? 1024 : nb2), nbatch), dim3(kDotThreads), 0, st, f, parts1, parts2, den, sign1,
+                           sign2, bar, active);
     }
 }
-void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st)
+void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st,
+                             int nb)
 {
     if (n >= (int64_t)kProjParts * 4096) {  // fine grids: 256 workgroups of 1024 threads
-        hipLaunchKernelGGL(k_tproj_coeffs<1024>, dim3(kProjParts), dim3(1024), 0, st, n, nmodes, t, n_inv, pm, parts);
-        hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n)), dim3(256), 0, st, n, nmodes, kProjParts, t, rm, parts);
+        hipLaunchKernelGGL(k_tproj_coeffs<1024>, dim3(kProjParts, nb), dim3(1024), 0, st, n, nmodes, t, n_inv, pm, parts);
+        hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n), nb), dim3(256), 0, st, n, nmodes, kProjParts, t, rm, parts);
     } else {  // coarse grids: workgroups of 256 threads, 8 pixels per thread
         int nparts = (int)((n + 2047) / 2048);
         if (nparts < 1) nparts = 1;
         if (nparts > kProjParts) nparts = kProjParts;
-        hipLaunchKernelGGL(k_tproj_coeffs<256>, dim3(nparts), dim3(256), 0, st, n, nmodes, t, n_inv, pm, parts);
-        hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n)), dim3(256), 0, st, n, nmodes, nparts, t, rm, parts);
+        hipLaunchKernelGGL(k_tproj_coeffs<256>, dim3(nparts, nb), dim3(256), 0, st, n, nmodes, t, n_inv, pm, parts);
+        hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n), nb), dim3(256), 0, st, n, nmodes, nparts, t, rm, parts);
     }
 }
 void launch_copy_slim(const double *src, double *dst, int64_t ndoubles, int nblocks, hipStream_t st)
@@ -580,15 +685,32 @@ void launch_gemv(int nrows, int ncols, int64_t lda, const double *A, const doubl
     if (vec) hipLaunchKernelGGL(k_gemv<2>, dim3((nrows + 3) / 4), dim3(256), 0, st, nrows, ncols, lda, A, x, y);
     else hipLaunchKernelGGL(k_gemv<1>, dim3((nrows + 3) / 4), dim3(256), 0, st, nrows, ncols, lda, A, x, y);
 }
-void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st,
-                       const double *fl_hi)
+// nb right-hand sides: x [nb][ncols] -> y [nb][nrows]
+void launch_gemv_nb(int nrows, int ncols, int64_t lda, const double *A, int nb, const double *x, double *y, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_alm_splice, dim3(4, lmax_hi + 1), dim3(256), 0, st, lmax_lo, reinterpret_cast<const double2 *>(lo), lmax_hi,
+    const bool vec = (lda & 1) == 0 && (ncols & 1) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (nb == 1 || !vec) {  // (odd sizes / unaligned: one plain mat-vec per right-hand side)
+        for (int b = 0; b < nb; ++b) launch_gemv(nrows, ncols, lda, A, x + (int64_t)b * ncols, y + (int64_t)b * nrows, st);
+        return;
+    }
+    for (int b0 = 0; b0 < nb; b0 += 8) {
+        const int n = nb - b0 < 8 ? nb - b0 : 8;
+        const double *xb = x + (int64_t)b0 * ncols;
+        double *yb = y + (int64_t)b0 * nrows;
+        if (n <= 2) hipLaunchKernelGGL(k_gemv_nb<2>, dim3((nrows + 3) / 4), dim3(256), 0, st, nrows, ncols, lda, A, n, xb, yb);
+        else if (n <= 4) hipLaunchKernelGGL(k_gemv_nb<4>, dim3((nrows + 3) / 4), dim3(256), 0, st, nrows, ncols, lda, A, n, xb, yb);
+        else hipLaunchKernelGGL(k_gemv_nb<8>, dim3((nrows + 3) / 4), dim3(256), 0, st, nrows, ncols, lda, A, n, xb, yb);
+    }
+}
+void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st,
+                       const double *fl_hi, int nb)
+{
+    hipLaunchKernelGGL(k_alm_splice, dim3(4, lmax_hi + 1, nb), dim3(256), 0, st, lmax_lo, reinterpret_cast<const double2 *>(lo), lmax_hi,
                        reinterpret_cast<const double2 *>(hi), lsplit, reinterpret_cast<double2 *>(out), fl_hi);
 }
-void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st)
+void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st, int nb)
 {
-    hipLaunchKernelGGL(k_almxfl_add, dim3(4, lmax + 1), dim3(256), 0, st, lmax, reinterpret_cast<const double2 *>(a),
+    hipLaunchKernelGGL(k_almxfl_add, dim3(4, lmax + 1, nb), dim3(256), 0, st, lmax, reinterpret_cast<const double2 *>(a),
                        reinterpret_cast<const double2 *>(b), fl, nfl, reinterpret_cast<double2 *>(out));
 }
 void launch_alm2cl(int lmax, const double *a, const double *b, double *cl, hipStream_t st)
@@ -603,6 +725,10 @@ void launch_axpy(int64_t n, double a, const double *x, const double *y, double *
 void launch_map_mul(int64_t n, const double *a, const double *b, double *out, hipStream_t st)
 {
     hipLaunchKernelGGL(k_map_mul, dim3(nblocks(n)), dim3(256), 0, st, n, a, b, out);
+}
+void launch_map_qu_weight(int64_t n, double *q, double *u, const double *nqq, const double *nqu, const double *nuu, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_map_qu_weight, dim3(nblocks(n)), dim3(256), 0, st, n, q, u, nqq, nqu, nuu);
 }
 void launch_map_cmul(int64_t n, const double *ar, const double *ai, double s1, const double *br, const double *bi, double s2,
                      double sign, double *outr, double *outi, int accumulate, hipStream_t st)

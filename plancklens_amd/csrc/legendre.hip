@@ -9,6 +9,12 @@
 // 256-byte (spin s) contiguous pieces.
 //
 // Bound: FP64 FMA issue; no MFMA (a recurrence, not a contraction).
+//
+// Batches (several right-hand sides of the conjugate-gradient filter through one launch, api.hip pl_cg_fwd_*_b): the Legendre
+// kernels take the batch index from blockIdx.y, the prep / post kernels from blockIdx.z.  Entry b reads / writes the b-th
+// consecutive alm, prep and partial-sum array; in the phase array [ring pair][component][m][4] the components of entry b follow
+// those of entry b - 1 (component count = gridDim.y x components of one transform), which is the layout the ring-FFT kernels
+// take for any number of components.  With a batch of one every address is what it was.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -97,8 +103,10 @@ struct StreamPrefetch {
 // alm -> recursion-basis coefficients (fused hp.almxfl)
 // -----------------------------------------------------------------------------------------------------
 // spin 0: prep[e] = {c_re, c_im, d_re, d_im}
-__global__ void k_prep0(DevPlan P, const double2 *__restrict__ alm, const double *__restrict__ fl, double4 *__restrict__ prep)
+__global__ void k_prep0(DevPlan P, const double2 *__restrict__ alm_, const double *__restrict__ fl, double4 *__restrict__ prep_)
 {
+    const double2 *__restrict__ alm = alm_ + (int64_t)blockIdx.z * P.nalm;
+    double4 *__restrict__ prep = prep_ + (int64_t)blockIdx.z * P.nent0;
     const int m = blockIdx.y;
     const int nil = (P.lmax - m) / 2 + 1;
     const int64_t base = P.off0[m];
@@ -125,9 +133,12 @@ __global__ void k_prep0(DevPlan P, const double2 *__restrict__ alm, const double
 }
 
 // spin s: prep[e] = {An_re, An_im, Ap_re, Ap_im}
-__global__ void k_preps(DevPlan P, DevSpinTab S, int spin, const double2 *__restrict__ almG, const double2 *__restrict__ almC,
-                        const double *__restrict__ fl, double4 *__restrict__ prep)
+__global__ void k_preps(DevPlan P, DevSpinTab S, int spin, const double2 *__restrict__ almG_, const double2 *__restrict__ almC_,
+                        const double *__restrict__ fl, double4 *__restrict__ prep_)
 {
+    const double2 *__restrict__ almG = almG_ + (int64_t)blockIdx.z * P.nalm;
+    const double2 *__restrict__ almC = almC_ ? almC_ + (int64_t)blockIdx.z * P.nalm : nullptr;
+    double4 *__restrict__ prep = prep_ + (int64_t)blockIdx.z * S.off[P.mmax + 1];
     const int m = blockIdx.y;
     const int l0 = m > spin ? m : spin;
     const int nl = P.lmax - l0 + 1;
@@ -155,8 +166,9 @@ __global__ void k_preps(DevPlan P, DevSpinTab S, int spin, const double2 *__rest
 // synthesis, spin 0
 // -----------------------------------------------------------------------------------------------------
 template <int R>
-__global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__restrict__ prep, double *__restrict__ phase)
+__global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__restrict__ prep_, double *__restrict__ phase)
 {
+    const double4 *__restrict__ prep = prep_ + (int64_t)blockIdx.y * P.nent0;
     constexpr int RG = 64 * R;
     __shared__ double tile[RG * 16];  // [ring][m_local 4][4]
     const int wave = wave_id();
@@ -313,7 +325,7 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
         const int ip = g * RG + rl;
         if (ip < P.npairs) {
             double2 v = *reinterpret_cast<const double2 *>(tile + rl * 16 + part * 2);
-            *reinterpret_cast<double2 *>(phase + ((int64_t)ip * P.mstride + 4 * mg) * 4 + part * 2) = v;
+            *reinterpret_cast<double2 *>(phase + (((int64_t)ip * gridDim.y + blockIdx.y) * P.mstride + 4 * mg) * 4 + part * 2) = v;
         }
     }
 }
@@ -330,9 +342,11 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
 // per step for two maps instead of 24 (batching independent maps through one recursion).  The sums of each
 // input are formed in the same order as by the single-input kernel: the results are bit-identical.
 template <int R, bool GONLY, int IN2 = 0>
-__global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int spin, const double4 *__restrict__ prep,
-                                                    double *__restrict__ phase, const double4 *__restrict__ prep2 = nullptr)
+__global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int spin, const double4 *__restrict__ prep_,
+                                                    double *__restrict__ phase, const double4 *__restrict__ prep2_ = nullptr)
 {
+    const double4 *__restrict__ prep = prep_ + (int64_t)blockIdx.y * S.off[P.mmax + 1];
+    const double4 *__restrict__ prep2 = prep2_ ? prep2_ + (int64_t)blockIdx.y * S.off[P.mmax + 1] : nullptr;
     static_assert(!(GONLY && IN2 != 0), "a second input rides on a general first one");
     constexpr bool PAIR = IN2 == 1, BATCH = IN2 == 2;
     constexpr int EST = IN2 ? 16 : 8;  // 4 doubles x number of components of the phase array
@@ -618,7 +632,7 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
                 const double2 v = *reinterpret_cast<const double2 *>(tile + rl * 32 + part * 2);
                 // part = 4 m_local + (pair of doubles inside the 8-double block)
                 // phase array [ring pair][component][m][4]: components (off / 4) + 0 (doubles 0-3 of the block) and + 1 (4-7)
-                *reinterpret_cast<double2 *>(phase + ((((int64_t)ip * (EST / 4) + (off >> 2) + ((part >> 1) & 1)) * P.mstride) + 4 * mg + (part >> 2)) * 4 +
+                *reinterpret_cast<double2 *>(phase + (((((int64_t)ip * gridDim.y + blockIdx.y) * (EST / 4) + (off >> 2) + ((part >> 1) & 1)) * P.mstride) + 4 * mg + (part >> 2)) * 4 +
                                              (part & 1) * 2) = v;
             }
         }
@@ -739,7 +753,7 @@ __device__ __forceinline__ int fold4_component(int lane) { const int q = lane >>
 // analysis, spin 0: partial[g][entry] = {C_re, C_im, D_re, D_im} summed over the ring pairs of group g
 // -----------------------------------------------------------------------------------------------------
 template <int R>
-__global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__restrict__ phase, double *__restrict__ partial)
+__global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__restrict__ phase, double *__restrict__ partial_)
 {
     constexpr int RG = 64 * R;
     constexpr int T = 16;
@@ -748,6 +762,7 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
     const int wave = wave_id();
     const int lane = threadIdx.x & 63;
     const int ngroups = (P.npairs + RG - 1) / RG;
+    double *__restrict__ partial = partial_ + (int64_t)blockIdx.y * ngroups * P.nent0 * 4;
     // workgroups are dealt round-robin over the 8 XCDs: rotate the ring group with the m group so that every XCD
     // sees all latitudes (polar groups are light, equatorial ones heavy) -- otherwise the XCDs finish unevenly
     const int mg = blockIdx.x / ngroups, g = (blockIdx.x % ngroups + mg) % ngroups;
@@ -759,7 +774,7 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
         const int rl = c >> 3, part = c & 7;
         const int ip = g * RG + rl;
         double2 v = make_double2(0., 0.);
-        if (ip < P.npairs) v = *reinterpret_cast<const double2 *>(phase + ((int64_t)ip * P.mstride + 4 * mg) * 4 + part * 2);
+        if (ip < P.npairs) v = *reinterpret_cast<const double2 *>(phase + (((int64_t)ip * gridDim.y + blockIdx.y) * P.mstride + 4 * mg) * 4 + part * 2);
         *reinterpret_cast<double2 *>(tile + rl * 16 + part * 2) = v;
     }
     __syncthreads();
@@ -924,14 +939,17 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
 
 // reduce partials over ring groups and convert (C, D) -> a_lm (fused hp.almxfl)
 // add / fl_add (optional): alm = fl * (analysis) + fl_add * add, the S^-1 x term of the CG operator folded in
-__global__ void k_post0(DevPlan P, int RG, const double4 *__restrict__ partial, const double *__restrict__ fl, double2 *__restrict__ alm,
-                        const double2 *__restrict__ add, const double *__restrict__ fl_add)
+__global__ void k_post0(DevPlan P, int RG, const double4 *__restrict__ partial_, const double *__restrict__ fl, double2 *__restrict__ alm_,
+                        const double2 *__restrict__ add_, const double *__restrict__ fl_add)
 {
     const int m = blockIdx.y;
     const int nil = (P.lmax - m) / 2 + 1;
     const int64_t base = P.off0[m];
     const int64_t abase = (int64_t)m * (2 * P.lmax + 1 - m) / 2;
     const int ngroups = (P.npairs + RG - 1) / RG;
+    const double4 *__restrict__ partial = partial_ + (int64_t)blockIdx.z * ngroups * P.nent0;
+    double2 *__restrict__ alm = alm_ + (int64_t)blockIdx.z * P.nalm;
+    const double2 *__restrict__ add = add_ ? add_ + (int64_t)blockIdx.z * P.nalm : nullptr;
     const int mg4 = 4 * (m / 4);
     for (int il = blockIdx.x * blockDim.x + threadIdx.x; il < nil; il += gridDim.x * blockDim.x) {
         const int64_t e = base + il;
@@ -971,7 +989,7 @@ __global__ void k_post0(DevPlan P, int RG, const double4 *__restrict__ partial, 
 // -----------------------------------------------------------------------------------------------------
 template <int R>
 __global__ __launch_bounds__(256) PL_ANALS_ATTR void k_leg_anals(DevPlan P, DevSpinTab S, int spin, const double *__restrict__ phase,
-                                                   double *__restrict__ partial, int64_t nent)
+                                                   double *__restrict__ partial_, int64_t nent)
 {
     constexpr int RG = 64 * R;
     constexpr int T = 16;
@@ -980,6 +998,7 @@ __global__ __launch_bounds__(256) PL_ANALS_ATTR void k_leg_anals(DevPlan P, DevS
     const int wave = wave_id();
     const int lane = threadIdx.x & 63;
     const int ngroups = (P.npairs + RG - 1) / RG;
+    double *__restrict__ partial = partial_ + (int64_t)blockIdx.y * ngroups * nent * 4;
     // workgroups are dealt round-robin over the 8 XCDs: rotate the ring group with the m group so that every XCD
     // sees all latitudes (polar groups are light, equatorial ones heavy) -- otherwise the XCDs finish unevenly
     const int mg = blockIdx.x / ngroups, g = (blockIdx.x % ngroups + mg) % ngroups;
@@ -993,7 +1012,7 @@ __global__ __launch_bounds__(256) PL_ANALS_ATTR void k_leg_anals(DevPlan P, DevS
         const int ip = g * RG + rl;
         double2 v = make_double2(0., 0.);
         if (ip < P.npairs)  // phase array [ring pair][component 2][m][4] -> tile [ring][m_local 4][Q 4 | U 4]
-            v = *reinterpret_cast<const double2 *>(phase + ((((int64_t)ip * 2 + ((part >> 1) & 1)) * P.mstride) + 4 * mg + (part >> 2)) * 4 + (part & 1) * 2);
+            v = *reinterpret_cast<const double2 *>(phase + (((((int64_t)ip * gridDim.y + blockIdx.y) * 2 + ((part >> 1) & 1)) * P.mstride) + 4 * mg + (part >> 2)) * 4 + (part & 1) * 2);
         *reinterpret_cast<double2 *>(tile + rl * 32 + part * 2) = v;
     }
     __syncthreads();
@@ -1207,11 +1226,15 @@ __global__ __launch_bounds__(256) PL_ANALS_ATTR void k_leg_anals(DevPlan P, DevS
 
 // G_l = -1/2 beta_l G'_l,  C_l = i/2 beta_l C'_l
 // addG / addC with flG / flC (optional): almG += flG * addG, almC += flC * addC -- the S^-1 x term of the CG operator folded in
-__global__ void k_posts(DevPlan P, DevSpinTab S, int spin, int RG, int64_t nent, const double4 *__restrict__ partial,
-                        const double *__restrict__ fl, double2 *__restrict__ almG, double2 *__restrict__ almC,
-                        const double2 *__restrict__ addG, const double2 *__restrict__ addC, const double *__restrict__ flG,
+__global__ void k_posts(DevPlan P, DevSpinTab S, int spin, int RG, int64_t nent, const double4 *__restrict__ partial_,
+                        const double *__restrict__ fl, double2 *__restrict__ almG_, double2 *__restrict__ almC_,
+                        const double2 *__restrict__ addG_, const double2 *__restrict__ addC_, const double *__restrict__ flG,
                         const double *__restrict__ flC)
 {
+    const int64_t bz = blockIdx.z;
+    const double4 *__restrict__ partial = partial_ + bz * ((P.npairs + RG - 1) / RG) * nent;
+    double2 *__restrict__ almG = almG_ + bz * P.nalm, *__restrict__ almC = almC_ + bz * P.nalm;
+    const double2 *__restrict__ addG = addG_ ? addG_ + bz * P.nalm : nullptr, *__restrict__ addC = addC_ ? addC_ + bz * P.nalm : nullptr;
     const int m = blockIdx.y;
     const int l0 = m > spin ? m : spin;
     const int64_t abase = (int64_t)m * (2 * P.lmax + 1 - m) / 2;
@@ -1284,56 +1307,56 @@ static int rs_anal(const DevPlan &P) { return pick_r("PLSHTS_RSA", 4, 4, P); }
 
 int rings_per_group(int spin, const DevPlan &P) { return 64 * (spin == 0 ? r0_anal(P) : rs_anal(P)); }
 
-void launch_prep0(const DevPlan &P, const double *alm, const double *fl, double *prep, hipStream_t st)
+void launch_prep0(const DevPlan &P, const double *alm, const double *fl, double *prep, hipStream_t st, int nb)
 {
-    dim3 grid(4, P.mmax + 1);
+    dim3 grid(4, P.mmax + 1, nb);
     hipLaunchKernelGGL(k_prep0, grid, dim3(256), 0, st, P, reinterpret_cast<const double2 *>(alm), fl,
                        reinterpret_cast<double4 *>(prep));
 }
 
 // gradient and curl coefficients as two arrays (almC null: gradient only)
 void launch_preps_gc(const DevPlan &P, const DevSpinTab &S, int spin, const double *almG, const double *almC, const double *fl, double *prep,
-                     hipStream_t st)
+                     hipStream_t st, int nb)
 {
-    dim3 grid(4, P.mmax + 1);
+    dim3 grid(4, P.mmax + 1, nb);
     hipLaunchKernelGGL(k_preps, grid, dim3(256), 0, st, P, S, spin, reinterpret_cast<const double2 *>(almG),
                        reinterpret_cast<const double2 *>(almC), fl, reinterpret_cast<double4 *>(prep));
 }
 
 void launch_preps(const DevPlan &P, const DevSpinTab &S, int spin, const double *alm, const double *fl, double *prep, hipStream_t st, bool gonly)
 {
-    launch_preps_gc(P, S, spin, alm, gonly ? nullptr : alm + 2 * P.nalm, fl, prep, st);
+    launch_preps_gc(P, S, spin, alm, gonly ? nullptr : alm + 2 * P.nalm, fl, prep, st, 1);
 }
 
 template <int R>
-static void launch_synth0_r(const DevPlan &P, const double *prep, double *phase, hipStream_t st)
+static void launch_synth0_r(const DevPlan &P, const double *prep, double *phase, hipStream_t st, int nb)
 {
     constexpr int RG = 64 * R;
     const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
-    hipLaunchKernelGGL(k_leg_synth0<R>, dim3(ngroups * nmg), dim3(256), 0, st, P, reinterpret_cast<const double4 *>(prep), phase);
+    hipLaunchKernelGGL(k_leg_synth0<R>, dim3(ngroups * nmg, nb), dim3(256), 0, st, P, reinterpret_cast<const double4 *>(prep), phase);
 }
 
-void launch_synth0(const DevPlan &P, const double *prep, double *phase, hipStream_t st)
+void launch_synth0(const DevPlan &P, const double *prep, double *phase, hipStream_t st, int nb)
 {
     switch (r0_synth(P)) {
-    case 1: launch_synth0_r<1>(P, prep, phase, st); break;
-    case 2: launch_synth0_r<2>(P, prep, phase, st); break;
-    case 5: launch_synth0_r<5>(P, prep, phase, st); break;
-    case 6: launch_synth0_r<6>(P, prep, phase, st); break;
-    case 4: launch_synth0_r<4>(P, prep, phase, st); break;
-    default: launch_synth0_r<3>(P, prep, phase, st); break;
+    case 1: launch_synth0_r<1>(P, prep, phase, st, nb); break;
+    case 2: launch_synth0_r<2>(P, prep, phase, st, nb); break;
+    case 5: launch_synth0_r<5>(P, prep, phase, st, nb); break;
+    case 6: launch_synth0_r<6>(P, prep, phase, st, nb); break;
+    case 4: launch_synth0_r<4>(P, prep, phase, st, nb); break;
+    default: launch_synth0_r<3>(P, prep, phase, st, nb); break;
     }
 }
 
 template <int R, bool GONLY>
-static void launch_synths_r(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st)
+static void launch_synths_r(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st, int nb)
 {
     constexpr int RG = 64 * R;
     const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
     // PLSHTS_SYNTH_LDS_PAD (bytes, experiments): dynamic LDS nobody touches, to cap the workgroups per CU and leave room for the
     // ring-FFT kernels of another transform running on a second stream
     static const int pad = env_int("PLSHTS_SYNTH_LDS_PAD", 0);
-    hipLaunchKernelGGL((k_leg_synths<R, GONLY, 0>), dim3(ngroups * nmg), dim3(256), pad, st, P, S, spin,
+    hipLaunchKernelGGL((k_leg_synths<R, GONLY, 0>), dim3(ngroups * nmg, nb), dim3(256), pad, st, P, S, spin,
                        reinterpret_cast<const double4 *>(prep), phase);
 }
 
@@ -1364,69 +1387,70 @@ void launch_synths_batch2(const DevPlan &P, const DevSpinTab &S, int spin, const
                            reinterpret_cast<const double4 *>(prep), phase, reinterpret_cast<const double4 *>(prep2));
 }
 
-void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st, bool gonly)
+void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st, bool gonly, int nb)
 {
     const int r = rs_synth(P);
     if (gonly) {
         switch (r) {
-        case 1: launch_synths_r<1, true>(P, S, spin, prep, phase, st); break;
-        case 3: launch_synths_r<3, true>(P, S, spin, prep, phase, st); break;
-        case 4: launch_synths_r<4, true>(P, S, spin, prep, phase, st); break;
-        default: launch_synths_r<2, true>(P, S, spin, prep, phase, st); break;
+        case 1: launch_synths_r<1, true>(P, S, spin, prep, phase, st, nb); break;
+        case 3: launch_synths_r<3, true>(P, S, spin, prep, phase, st, nb); break;
+        case 4: launch_synths_r<4, true>(P, S, spin, prep, phase, st, nb); break;
+        default: launch_synths_r<2, true>(P, S, spin, prep, phase, st, nb); break;
         }
         return;
     }
     switch (r) {
-    case 1: launch_synths_r<1, false>(P, S, spin, prep, phase, st); break;
-    case 3: launch_synths_r<3, false>(P, S, spin, prep, phase, st); break;
-    case 4: launch_synths_r<4, false>(P, S, spin, prep, phase, st); break;
-    default: launch_synths_r<2, false>(P, S, spin, prep, phase, st); break;
+    case 1: launch_synths_r<1, false>(P, S, spin, prep, phase, st, nb); break;
+    case 3: launch_synths_r<3, false>(P, S, spin, prep, phase, st, nb); break;
+    case 4: launch_synths_r<4, false>(P, S, spin, prep, phase, st, nb); break;
+    default: launch_synths_r<2, false>(P, S, spin, prep, phase, st, nb); break;
     }
 }
 
 template <int R>
 static void launch_anal0_r(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st,
-                           const double *add, const double *fl_add)
+                           const double *add, const double *fl_add, int nb)
 {
     constexpr int RG = 64 * R;
     const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
-    hipLaunchKernelGGL(k_leg_anal0<R>, dim3(ngroups * nmg), dim3(256), 0, st, P, phase, partial);
-    dim3 grid(4, P.mmax + 1);
+    hipLaunchKernelGGL(k_leg_anal0<R>, dim3(ngroups * nmg, nb), dim3(256), 0, st, P, phase, partial);
+    dim3 grid(4, P.mmax + 1, nb);
     hipLaunchKernelGGL(k_post0, grid, dim3(256), 0, st, P, RG, reinterpret_cast<const double4 *>(partial), fl,
                        reinterpret_cast<double2 *>(alm), reinterpret_cast<const double2 *>(add), fl_add);
 }
 
 void launch_anal0(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st, const double *add,
-                  const double *fl_add)
+                  const double *fl_add, int nb)
 {
     switch (r0_anal(P)) {
-    case 1: launch_anal0_r<1>(P, phase, partial, fl, alm, st, add, fl_add); break;
-    case 2: launch_anal0_r<2>(P, phase, partial, fl, alm, st, add, fl_add); break;
-    case 3: launch_anal0_r<3>(P, phase, partial, fl, alm, st, add, fl_add); break;
-    case 5: launch_anal0_r<5>(P, phase, partial, fl, alm, st, add, fl_add); break;
-    case 6: launch_anal0_r<6>(P, phase, partial, fl, alm, st, add, fl_add); break;
-    case 7: launch_anal0_r<7>(P, phase, partial, fl, alm, st, add, fl_add); break;
-    case 8: launch_anal0_r<8>(P, phase, partial, fl, alm, st, add, fl_add); break;
-    default: launch_anal0_r<4>(P, phase, partial, fl, alm, st, add, fl_add); break;
+    case 1: launch_anal0_r<1>(P, phase, partial, fl, alm, st, add, fl_add, nb); break;
+    case 2: launch_anal0_r<2>(P, phase, partial, fl, alm, st, add, fl_add, nb); break;
+    case 3: launch_anal0_r<3>(P, phase, partial, fl, alm, st, add, fl_add, nb); break;
+    case 5: launch_anal0_r<5>(P, phase, partial, fl, alm, st, add, fl_add, nb); break;
+    case 6: launch_anal0_r<6>(P, phase, partial, fl, alm, st, add, fl_add, nb); break;
+    case 7: launch_anal0_r<7>(P, phase, partial, fl, alm, st, add, fl_add, nb); break;
+    case 8: launch_anal0_r<8>(P, phase, partial, fl, alm, st, add, fl_add, nb); break;
+    default: launch_anal0_r<4>(P, phase, partial, fl, alm, st, add, fl_add, nb); break;
     }
 }
 
 template <int R>
 static void launch_anals_r(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
                            const double *fl, double *almG, double *almC, hipStream_t st, const double *addG, const double *addC,
-                           const double *flG, const double *flC)
+                           const double *flG, const double *flC, int nb)
 {
     constexpr int RG = 64 * R;
     const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
-    hipLaunchKernelGGL(k_leg_anals<R>, dim3(ngroups * nmg), dim3(256), 0, st, P, S, spin, phase, partial, nent);
-    dim3 grid(4, P.mmax + 1);
+    hipLaunchKernelGGL(k_leg_anals<R>, dim3(ngroups * nmg, nb), dim3(256), 0, st, P, S, spin, phase, partial, nent);
+    dim3 grid(4, P.mmax + 1, nb);
     hipLaunchKernelGGL(k_posts, grid, dim3(256), 0, st, P, S, spin, RG, nent, reinterpret_cast<const double4 *>(partial), fl,
                        reinterpret_cast<double2 *>(almG), reinterpret_cast<double2 *>(almC), reinterpret_cast<const double2 *>(addG),
                        reinterpret_cast<const double2 *>(addC), flG, flC);
 }
 
 void launch_anals_gc(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial, const double *fl,
-                     double *almG, double *almC, hipStream_t st, const double *addG, const double *addC, const double *flG, const double *flC);
+                     double *almG, double *almC, hipStream_t st, const double *addG, const double *addC, const double *flG, const double *flC,
+                     int nb = 1);
 
 void launch_anals(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
                   const double *fl, double *alm, hipStream_t st)
@@ -1436,13 +1460,14 @@ void launch_anals(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent,
 
 // gradient / curl outputs as two arrays, with the optional add terms of k_posts
 void launch_anals_gc(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial, const double *fl,
-                     double *almG, double *almC, hipStream_t st, const double *addG, const double *addC, const double *flG, const double *flC)
+                     double *almG, double *almC, hipStream_t st, const double *addG, const double *addC, const double *flG, const double *flC,
+                     int nb)
 {
     switch (rs_anal(P)) {
-    case 1: launch_anals_r<1>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC); break;
-    case 2: launch_anals_r<2>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC); break;
-    case 4: launch_anals_r<4>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC); break;
-    default: launch_anals_r<3>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC); break;
+    case 1: launch_anals_r<1>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
+    case 2: launch_anals_r<2>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
+    case 4: launch_anals_r<4>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
+    default: launch_anals_r<3>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
     }
 }
 

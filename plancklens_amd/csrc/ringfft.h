@@ -52,7 +52,7 @@ struct NinvProj {
     const double *n_inv = nullptr;  // [npix]; null: plain transform
     const double *pm = nullptr;     // [nmodes][npix]
     const double *rm = nullptr;     // [nmodes][npix]
-    double *parts = nullptr;        // [nmodes][nparts]
+    double *parts = nullptr;        // [ncomp][nmodes][nparts]: one set per component (= per entry of a batch of temperature maps)
     int nmodes = 0, nparts = 0;
 };
 

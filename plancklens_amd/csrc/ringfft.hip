@@ -404,7 +404,7 @@ __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int
         if ((int)threadIdx.x < W.nmodes) {
             double v = 0.0;
             for (int w = 0; w < NT / 64; ++w) v += red[threadIdx.x * (NT / 64) + w];
-            W.parts[threadIdx.x * W.nparts + blockIdx.x] = v;
+            W.parts[((int64_t)comp * W.nmodes + threadIdx.x) * W.nparts + blockIdx.x] = v;  // every component (batch entry) has its own sums
         }
     }
 }
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         for (int k = wave; k < W.nmodes; k += NT / 64) {
             double v = 0.0;
-            for (int j = lane; j < W.nparts; j += 64) v += W.parts[k * W.nparts + j];
+            for (int j = lane; j < W.nparts; j += 64) v += W.parts[((int64_t)blockIdx.y * W.nmodes + k) * W.nparts + j];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if (lane == 0) cproj[k] = v;
@@ -1276,8 +1276,9 @@ bool fft_all_generic(const DevPlan &P, const DevFFT &F) { return F.A.legacy_n ==
 hipError_t launch_phase2map(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *phase,
                             double *map, hipStream_t st, const NinvProj *W)
 {
-    // plain weighting (nmodes = 0) rides in every kernel and for any number of components; the template sums need the generic kernel
-    if (W && W->n_inv && W->nmodes > 0 && !(fft_all_generic(P, F) && ncomp == 1 && W->nmodes <= kFuseModes && W->nparts >= F.A.legacy_n))
+    // plain weighting (nmodes = 0) rides in every kernel and for any number of components; the template sums (one set per component:
+    // W.parts holds ncomp x nmodes x nparts) need the generic kernel
+    if (W && W->n_inv && W->nmodes > 0 && !(fft_all_generic(P, F) && W->nmodes <= kFuseModes && W->nparts >= F.A.legacy_n))
         return hipErrorInvalidValue;
     return launch_stage(P, F, fs, true, mlim, ncomp, phase, map, st, W ? *W : NinvProj());
 }
@@ -1285,7 +1286,7 @@ hipError_t launch_phase2map(const DevPlan &P, const DevFFT &F, const FftStreams 
 hipError_t launch_map2phase(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *map,
                             double *phase, hipStream_t st, const NinvProj *W)
 {
-    if (W && W->rm && !(fft_all_generic(P, F) && ncomp == 1 && W->nmodes <= kFuseModes && W->nparts >= F.A.legacy_n)) return hipErrorInvalidValue;
+    if (W && W->rm && !(fft_all_generic(P, F) && W->nmodes <= kFuseModes && W->nparts >= F.A.legacy_n)) return hipErrorInvalidValue;
     return launch_stage(P, F, fs, false, mlim, ncomp, map, phase, st, W ? *W : NinvProj());
 }
 

@@ -174,51 +174,83 @@ def fl_dev(fl, lmax):
     return t
 
 
+def bshape(a):
+    """(nb, n) of a CG vector: a 1-D tensor is one array of n entries, a 2-D tensor [nb, n] a block of nb arrays (several
+    right-hand sides solved together, the `_b` entry points of include/plshts.h)"""
+    assert a.dim() in (1, 2), a.shape
+    return (1, a.shape[0]) if a.dim() == 1 else (a.shape[0], a.shape[1])
+
+
+def _same_block(*ts):
+    nb = bshape(ts[0])[0]
+    for t in ts:
+        assert t.is_contiguous() and t.dim() == ts[0].dim() and bshape(t)[0] == nb, [tuple(x.shape) for x in ts]
+    return nb
+
+
 def almxfl(alm, fl):
-    """hp.almxfl on a device alm through the C ABI (pl_almxfl); returns a new tensor."""
-    lmax = Alm.getlmax(alm.numel())
+    """hp.almxfl on a device alm (or block of alms) through the C ABI (pl_almxfl / pl_almxfl_b); returns a new tensor."""
+    nb, n = bshape(alm)
+    lmax = Alm.getlmax(n)
     assert lmax >= 0
     f = fl_dev(fl, lmax)
+    alm = alm.contiguous()
     out = torch.empty_like(alm)
-    _lib.check(_lib.lib().pl_almxfl(lmax, alm.data_ptr(), f.data_ptr(), lmax + 1, out.data_ptr(), stream_ptr()))
+    if alm.dim() == 1:
+        _lib.check(_lib.lib().pl_almxfl(lmax, alm.data_ptr(), f.data_ptr(), lmax + 1, out.data_ptr(), stream_ptr()))
+    else:
+        _lib.check(_lib.lib().pl_almxfl_b(lmax, nb, alm.data_ptr(), f.data_ptr(), lmax + 1, out.data_ptr(), stream_ptr()))
     return out
 
 
 def alm_copy(alm, lmax_out):
-    lmax_in = Alm.getlmax(alm.numel())
+    nb, n = bshape(alm)
+    lmax_in = Alm.getlmax(n)
     if lmax_out == lmax_in:
         return alm.clone()
-    out = torch.empty(Alm.getsize(lmax_out), dtype=torch.complex128, device=alm.device)
-    _lib.check(_lib.lib().pl_alm_copy(lmax_in, alm.data_ptr(), lmax_out, out.data_ptr(), stream_ptr()))
+    alm = alm.contiguous()
+    if alm.dim() == 1:
+        out = torch.empty(Alm.getsize(lmax_out), dtype=torch.complex128, device=alm.device)
+        _lib.check(_lib.lib().pl_alm_copy(lmax_in, alm.data_ptr(), lmax_out, out.data_ptr(), stream_ptr()))
+    else:
+        out = torch.empty((nb, Alm.getsize(lmax_out)), dtype=torch.complex128, device=alm.device)
+        _lib.check(_lib.lib().pl_alm_copy_b(lmax_in, nb, alm.data_ptr(), lmax_out, out.data_ptr(), stream_ptr()))
     return out
 
 
 def alm_splice(alm_lo, alm_hi, lsplit):
     """alm_lo for l <= lsplit, alm_hi above; band-limit of alm_hi (pl_alm_splice)."""
-    lmax_lo, lmax_hi = Alm.getlmax(alm_lo.numel()), Alm.getlmax(alm_hi.numel())
-    assert lmax_lo >= lsplit and lmax_hi >= lsplit, (lmax_lo, lmax_hi, lsplit)
-    out = torch.empty_like(alm_hi)
-    _lib.check(_lib.lib().pl_alm_splice(lmax_lo, alm_lo.data_ptr(), lmax_hi, alm_hi.data_ptr(), int(lsplit), out.data_ptr(), stream_ptr()))
-    return out
+    return alm_splice_fl(alm_lo, alm_hi, None, lsplit)
 
 
 def alm_splice_fl(alm_lo, alm_hi, fl_hi, lsplit):
-    """alm_lo for l <= lsplit, fl_hi[l] * alm_hi above; band-limit of alm_hi (pl_alm_splice_fl)."""
-    lmax_lo, lmax_hi = Alm.getlmax(alm_lo.numel()), Alm.getlmax(alm_hi.numel())
+    """alm_lo for l <= lsplit, fl_hi[l] * alm_hi above (fl_hi None: alm_hi); band-limit of alm_hi (pl_alm_splice / _fl / _b)."""
+    nb = _same_block(alm_lo, alm_hi)
+    lmax_lo, lmax_hi = Alm.getlmax(bshape(alm_lo)[1]), Alm.getlmax(bshape(alm_hi)[1])
     assert lmax_lo >= lsplit and lmax_hi >= lsplit, (lmax_lo, lmax_hi, lsplit)
     out = torch.empty_like(alm_hi)
-    _lib.check(_lib.lib().pl_alm_splice_fl(lmax_lo, alm_lo.data_ptr(), lmax_hi, alm_hi.data_ptr(), fl_dev(fl_hi, lmax_hi).data_ptr(),
-                                          int(lsplit), out.data_ptr(), stream_ptr()))
+    f = None if fl_hi is None else fl_dev(fl_hi, lmax_hi).data_ptr()
+    L = _lib.lib()
+    if alm_hi.dim() == 2:
+        _lib.check(L.pl_alm_splice_b(lmax_lo, nb, alm_lo.data_ptr(), lmax_hi, alm_hi.data_ptr(), f, int(lsplit), out.data_ptr(), stream_ptr()))
+    elif f is None:
+        _lib.check(L.pl_alm_splice(lmax_lo, alm_lo.data_ptr(), lmax_hi, alm_hi.data_ptr(), int(lsplit), out.data_ptr(), stream_ptr()))
+    else:
+        _lib.check(L.pl_alm_splice_fl(lmax_lo, alm_lo.data_ptr(), lmax_hi, alm_hi.data_ptr(), f, int(lsplit), out.data_ptr(), stream_ptr()))
     return out
 
 
 def almxfl_add(a, b, fl, out=None):
     """a + f_l b in one pass (pl_almxfl_add); out may be a."""
-    lmax = Alm.getlmax(a.numel())
-    assert b.numel() == a.numel()
+    nb = _same_block(a, b)
+    lmax = Alm.getlmax(bshape(a)[1])
+    assert b.shape == a.shape
     f = fl_dev(fl, lmax)
     out = torch.empty_like(a) if out is None else out
-    _lib.check(_lib.lib().pl_almxfl_add(lmax, a.data_ptr(), b.data_ptr(), f.data_ptr(), lmax + 1, out.data_ptr(), stream_ptr()))
+    if a.dim() == 1:
+        _lib.check(_lib.lib().pl_almxfl_add(lmax, a.data_ptr(), b.data_ptr(), f.data_ptr(), lmax + 1, out.data_ptr(), stream_ptr()))
+    else:
+        _lib.check(_lib.lib().pl_almxfl_add_b(lmax, nb, a.data_ptr(), b.data_ptr(), f.data_ptr(), lmax + 1, out.data_ptr(), stream_ptr()))
     return out
 
 
@@ -228,22 +260,33 @@ DOT_PARTS = 64  # PL_DOT_PARTS of include/plshts.h
 def alm_dot(pairs, lmin=0):
     """sum over the (a, b) pairs of sum_{l >= lmin} (2l + 1) C_l^{ab}, left on the device as DOT_PARTS partial sums (the
     value is their sum in index order: `float(dot.sum())` on the host, or axpy_dev on the device).  One deterministic
-    launch per pair (pl_alm_dot), nothing comes back to the host."""
-    out = torch.empty(DOT_PARTS, dtype=torch.float64, device=device())
+    launch per pair (pl_alm_dot), nothing comes back to the host.  Blocks [nb, nalm]: (nb, DOT_PARTS) partial sums, one scalar
+    product per entry (value: .sum(-1))."""
+    nb = bshape(pairs[0][0])[0]
+    blk = pairs[0][0].dim() == 2
+    out = torch.empty((nb, DOT_PARTS) if blk else DOT_PARTS, dtype=torch.float64, device=device())
     for i, (a, b) in enumerate(pairs):
-        assert a.numel() == b.numel() and a.dtype == torch.complex128 and b.dtype == torch.complex128
-        _lib.check(_lib.lib().pl_alm_dot(Alm.getlmax(a.numel()), int(lmin), a.data_ptr(), b.data_ptr(), int(i > 0), out.data_ptr(),
-                                        stream_ptr()))
+        assert a.shape == b.shape and a.dtype == torch.complex128 and b.dtype == torch.complex128 and _same_block(a, b) == nb
+        lmax = Alm.getlmax(bshape(a)[1])
+        if blk:
+            _lib.check(_lib.lib().pl_alm_dot_b(lmax, int(lmin), nb, a.data_ptr(), b.data_ptr(), int(i > 0), out.data_ptr(), stream_ptr()))
+        else:
+            _lib.check(_lib.lib().pl_alm_dot(lmax, int(lmin), a.data_ptr(), b.data_ptr(), int(i > 0), out.data_ptr(), stream_ptr()))
     return out
 
 
 def axpy_dev(y, x, num, den=None, sign=1.0):
-    """y += sign * num / den * x in place; num, den: scalar products as returned by alm_dot (pl_axpy_dev)."""
-    assert y.numel() == x.numel() and y.dtype == x.dtype and y.is_contiguous() and x.is_contiguous()
-    assert num.numel() == DOT_PARTS and (den is None or den.numel() == DOT_PARTS)
-    n = y.numel() * (2 if y.is_complex() else 1)
-    _lib.check(_lib.lib().pl_axpy_dev(n, num.data_ptr(), None if den is None else den.data_ptr(), float(sign), x.data_ptr(), y.data_ptr(),
-                                     stream_ptr()))
+    """y += sign * num / den * x in place; num, den: scalar products as returned by alm_dot (pl_axpy_dev); blocks: per entry."""
+    assert y.shape == x.shape and y.dtype == x.dtype
+    nb = _same_block(y, x)
+    assert num.numel() == nb * DOT_PARTS and (den is None or den.numel() == nb * DOT_PARTS)
+    n = bshape(y)[1] * (2 if y.is_complex() else 1)
+    if y.dim() == 1:
+        _lib.check(_lib.lib().pl_axpy_dev(n, num.data_ptr(), None if den is None else den.data_ptr(), float(sign), x.data_ptr(), y.data_ptr(),
+                                         stream_ptr()))
+    else:
+        _lib.check(_lib.lib().pl_axpy_dev_b(n, nb, num.data_ptr(), None if den is None else den.data_ptr(), float(sign), x.data_ptr(),
+                                           y.data_ptr(), stream_ptr()))
     return y
 
 
@@ -276,26 +319,36 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-def cg_dot_axpy(a, b1, y1, x1, sign1, b2=None, den=None, y2=None, x2=None, sign2=-1.0, lmin=0, one_launch=False):
+def cg_dot_axpy(a, b1, y1, x1, sign1, b2=None, den=None, y2=None, x2=None, sign2=-1.0, lmin=0, one_launch=False, active=None):
     """Scalar products and the updates they scale (pl_cg_dot_axpy: two launches for all fields, or one with a grid barrier inside
     when `one_launch`) over the fields of the lists a, b1, ...:
     parts1 = <a, b1>, parts2 = <a, b2>; c = parts2 / parts1 (b2 given) or parts1 / den; y1 += sign1 c x1, y2 += sign2 c x2.
-    Returns (parts1, parts2), device tensors of DOT_PARTS partial sums as alm_dot returns them."""
+    Returns (parts1, parts2), device tensors of DOT_PARTS partial sums as alm_dot returns them.
+    Blocks ([nb, nalm] fields, pl_cg_dot_axpy_b): everything per entry -- nb scalar products, nb step lengths; `active` (nb float64
+    zeros / ones on the device, optional) multiplies the step lengths: an entry with 0 keeps its vectors."""
     nf = len(a)
     for group in (b1, y1, x1, b2, y2, x2):
         assert group is None or len(group) == nf
+    nb, blk = bshape(a[0])[0], a[0].dim() == 2
     for k in range(nf):
         for group in (a, b1, y1, x1, b2, y2, x2):
-            assert group is None or (group[k].dtype == torch.complex128 and group[k].is_contiguous() and group[k].numel() == a[k].numel())
-    lmax = (ctypes.c_int * nf)(*[Alm.getlmax(t.numel()) for t in a])
-    parts1 = torch.empty(DOT_PARTS, dtype=torch.float64, device=device())
-    parts2 = torch.empty(DOT_PARTS, dtype=torch.float64, device=device()) if b2 is not None else None
-    assert (b2 is None) != (den is None) and (den is None or den.numel() == DOT_PARTS)
-    _lib.check(_lib.lib().pl_cg_dot_axpy(nf, lmax, int(lmin), _ptr_array(a), _ptr_array(b1), None if b2 is None else _ptr_array(b2),
-                                         parts1.data_ptr(), None if parts2 is None else parts2.data_ptr(),
-                                         None if den is None else den.data_ptr(), _ptr_array(y1), _ptr_array(x1), float(sign1),
-                                         None if y2 is None else _ptr_array(y2), None if x2 is None else _ptr_array(x2), float(sign2),
-                                         cg_barrier().data_ptr() if one_launch else None, stream_ptr()))
+            assert group is None or (group[k].dtype == torch.complex128 and group[k].is_contiguous() and group[k].shape == a[k].shape)
+        assert bshape(a[k])[0] == nb and (a[k].dim() == 2) == blk
+    lmax = (ctypes.c_int * nf)(*[Alm.getlmax(bshape(t)[1]) for t in a])
+    pshape = (nb, DOT_PARTS) if blk else DOT_PARTS
+    parts1 = torch.empty(pshape, dtype=torch.float64, device=device())
+    parts2 = torch.empty(pshape, dtype=torch.float64, device=device()) if b2 is not None else None
+    assert (b2 is None) != (den is None) and (den is None or den.numel() == nb * DOT_PARTS)
+    args = (nf, lmax, int(lmin), _ptr_array(a), _ptr_array(b1), None if b2 is None else _ptr_array(b2),
+            parts1.data_ptr(), None if parts2 is None else parts2.data_ptr(),
+            None if den is None else den.data_ptr(), _ptr_array(y1), _ptr_array(x1), float(sign1),
+            None if y2 is None else _ptr_array(y2), None if x2 is None else _ptr_array(x2), float(sign2))
+    if blk:
+        assert active is None or (active.numel() == nb and active.dtype == torch.float64 and active.is_cuda)
+        _lib.check(_lib.lib().pl_cg_dot_axpy_b(nb, *args, None if active is None else active.data_ptr(), stream_ptr()))
+    else:
+        assert active is None, 'per-entry stopping is a block-vector feature'
+        _lib.check(_lib.lib().pl_cg_dot_axpy(*args, cg_barrier().data_ptr() if one_launch else None, stream_ptr()))
     return parts1, parts2
 
 
@@ -303,33 +356,46 @@ TEMPLATE_MAX_MODES = 16  # PL_TEMPLATE_MAX_MODES of include/plshts.h
 _TPROJ_SCRATCH = {}
 
 
-def tproj_scratch():
-    """the per-device scratch of pl_template_project / pl_cg_fwd_tt"""
+def tproj_scratch(nb=1):
+    """the per-device scratch of pl_template_project / pl_cg_fwd_tt (nb entries of a batch: nb times the size; it only grows, and an
+    outgrown one is kept alive -- a captured HIP graph may hold its address)"""
     d = torch.cuda.current_device()
-    if d not in _TPROJ_SCRATCH:
+    cur = _TPROJ_SCRATCH.get(d)
+    if cur is None or cur[-1].numel() < nb * TEMPLATE_MAX_MODES * 256:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError('template-projection scratch requested while a HIP graph is being captured')
-        _TPROJ_SCRATCH[d] = torch.empty(TEMPLATE_MAX_MODES * 256, dtype=torch.float64, device=device())
-    return _TPROJ_SCRATCH[d]
+        _TPROJ_SCRATCH.setdefault(d, []).append(torch.empty(nb * TEMPLATE_MAX_MODES * 256, dtype=torch.float64, device=device()))
+    return _TPROJ_SCRATCH[d][-1]
 
 
 def template_project(tmap, n_inv, pmat, rmat):
-    """tmap <- n_inv tmap - rmat^t (pmat (n_inv tmap)) in place, two launches (pl_template_project); pmat, rmat: (nmodes, npix)."""
+    """tmap <- n_inv tmap - rmat^t (pmat (n_inv tmap)) in place, two launches (pl_template_project); pmat, rmat: (nmodes, npix);
+    tmap [npix] or a block [nb, npix]."""
     nmodes, npix = pmat.shape
-    assert rmat.shape == pmat.shape and tmap.numel() == npix and n_inv.numel() == npix and pmat.is_contiguous() and rmat.is_contiguous()
-    _lib.check(_lib.lib().pl_template_project(npix, nmodes, tmap.data_ptr(), n_inv.data_ptr(), pmat.data_ptr(), rmat.data_ptr(),
-                                             tproj_scratch().data_ptr(), stream_ptr()))
+    nb, n = bshape(tmap)
+    assert rmat.shape == pmat.shape and n == npix and n_inv.numel() == npix and pmat.is_contiguous() and rmat.is_contiguous() and tmap.is_contiguous()
+    if tmap.dim() == 1:
+        _lib.check(_lib.lib().pl_template_project(npix, nmodes, tmap.data_ptr(), n_inv.data_ptr(), pmat.data_ptr(), rmat.data_ptr(),
+                                                 tproj_scratch().data_ptr(), stream_ptr()))
+    else:
+        _lib.check(_lib.lib().pl_template_project_b(npix, nmodes, nb, tmap.data_ptr(), n_inv.data_ptr(), pmat.data_ptr(), rmat.data_ptr(),
+                                                   tproj_scratch(nb).data_ptr(), stream_ptr()))
     return tmap
 
 
 def gemv(amat, x, out=None):
-    """y = A x on the device (pl_gemv): A a contiguous (nrows, ncols) float64 tensor, x float64 of ncols entries."""
+    """y = A x on the device (pl_gemv): A a contiguous (nrows, ncols) float64 tensor, x float64 of ncols entries -- or a block
+    [nb, ncols] -> [nb, nrows] (pl_gemv_b: the matrix is read once for all right-hand sides)."""
     assert amat.dim() == 2 and amat.is_contiguous() and amat.dtype == torch.float64 and x.dtype == torch.float64
     x = x.contiguous()
-    assert x.numel() == amat.shape[1], (x.shape, amat.shape)
+    nb, n = bshape(x)
+    assert n == amat.shape[1], (x.shape, amat.shape)
     if out is None:
-        out = torch.empty(amat.shape[0], dtype=torch.float64, device=amat.device)
-    _lib.check(_lib.lib().pl_gemv(amat.shape[0], amat.shape[1], amat.shape[1], amat.data_ptr(), x.data_ptr(), out.data_ptr(), stream_ptr()))
+        out = torch.empty(amat.shape[0] if x.dim() == 1 else (nb, amat.shape[0]), dtype=torch.float64, device=amat.device)
+    if x.dim() == 1:
+        _lib.check(_lib.lib().pl_gemv(amat.shape[0], amat.shape[1], amat.shape[1], amat.data_ptr(), x.data_ptr(), out.data_ptr(), stream_ptr()))
+    else:
+        _lib.check(_lib.lib().pl_gemv_b(amat.shape[0], amat.shape[1], amat.shape[1], amat.data_ptr(), nb, x.data_ptr(), out.data_ptr(), stream_ptr()))
     return out
 
 
@@ -344,6 +410,14 @@ def map_mul(a, b, out=None):
     out = torch.empty_like(a) if out is None else out
     _lib.check(_lib.lib().pl_map_mul(a.numel(), a.data_ptr(), b.data_ptr(), out.data_ptr(), stream_ptr()))
     return out
+
+
+def map_qu_weight(qmap, umap, nqq, nqu, nuu):
+    """(Q, U) <- (nqq Q + nqu U, nqu Q + nuu U) in place, one launch (pl_map_qu_weight)"""
+    for t in (qmap, umap, nqq, nqu, nuu):
+        assert t.is_contiguous() and t.dtype == torch.float64 and t.numel() == qmap.numel()
+    _lib.check(_lib.lib().pl_map_qu_weight(qmap.numel(), qmap.data_ptr(), umap.data_ptr(), nqq.data_ptr(), nqu.data_ptr(), nuu.data_ptr(),
+                                          stream_ptr()))
 
 
 def map_cmul(ar, ai, s1, br, bi, s2, sign, outr, outi, accumulate):

@@ -162,6 +162,23 @@ class cinv_t(cinv):
         talm = dev.almxfl(talm, self.rescal_cl)
         return talm if on_dev else dev.to_host(talm)
 
+    def apply_ivf_batch(self, tmaps, soltns=None):
+        """apply_ivf of several maps in ONE block solve: every launch of the multigrid CG carries all of them, each with its own
+        scalar products, step lengths and stopping point (multigrid_chain.solve).  The reference filters its simulations one at a
+        time (filt_cinv.py:196-203 under run_qlms.py:57-62); on the GPU the coarse levels of a solve are chains of dependent
+        microsecond launches that take the extra right-hand sides almost for free.  Returns the list of filtered alms, equal to
+        [apply_ivf(m) for m in tmaps]."""
+        tmaps = list(tmaps)
+        on_dev = isinstance(tmaps[0], torch.Tensor)
+        nb, n = len(tmaps), hp.Alm.getsize(self.lmax)
+        if soltns is None:
+            talm = torch.zeros((nb, n), dtype=torch.complex128, device=dev.device())
+        else:
+            talm = torch.stack([dev.to_dev(s, torch.complex128) for s in soltns]).contiguous()
+        self.chain.solve(talm, tmaps)
+        talm = dev.almxfl(talm, self.rescal_cl)
+        return [talm[i] if on_dev else dev.to_host(talm[i]) for i in range(nb)]
+
 
 class cinv_p(cinv):
     r"""Polarization-only inverse-variance filter (E, B); ninv is a list of 1 (QQ = UU) or 3 (QQ, QU, UU) entries,
@@ -217,6 +234,21 @@ class cinv_p(cinv):
         if on_dev:
             return talm.elm, talm.blm
         return dev.to_host(talm.elm), dev.to_host(talm.blm)
+
+    def apply_ivf_batch(self, pmaps, soltns=None):
+        """apply_ivf of several (Q, U) pairs in ONE block solve (see cinv_t.apply_ivf_batch); returns the list of (elm, blm)."""
+        pmaps = [list(p) for p in pmaps]
+        assert all(len(p) == 2 for p in pmaps)
+        on_dev = isinstance(pmaps[0][0], torch.Tensor)
+        nb, n = len(pmaps), hp.Alm.getsize(self.lmax)
+        if soltns is not None:
+            talm = util_alm.eblm([torch.stack([dev.to_dev(s[k], torch.complex128) for s in soltns]).contiguous() for k in (0, 1)])
+        else:
+            talm = util_alm.eblm([torch.zeros((nb, n), dtype=torch.complex128, device=dev.device()) for _ in (0, 1)])
+        self.chain.solve(talm, pmaps)
+        if on_dev:
+            return [(talm.elm[i], talm.blm[i]) for i in range(nb)]
+        return [(dev.to_host(talm.elm[i]), dev.to_host(talm.blm[i])) for i in range(nb)]
 
     def _calc_febl(self):
         assert 'eb' not in self.chain.s_cls.keys()

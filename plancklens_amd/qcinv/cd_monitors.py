@@ -22,6 +22,10 @@ class monitor_basic(object):
         self.logger = logger
         self.d0 = d0
         self.watch = util.stopwatch()
+        # block vectors (several right-hand sides in one solve): entries that have met the stopping rule, and the 0 / 1 step-length
+        # mask cd_solve hands to dot_op.step (None while every entry is still iterating)
+        self.done = None
+        self.active = None
 
     def criterion(self, iter, soltn, resid):
         if self.quiet and self.eps_min == 0.:
@@ -29,9 +33,35 @@ class monitor_basic(object):
         delta = self.dot_op(resid, resid)
         if iter == 0 and self.d0 is None:
             self.d0 = delta
+        if np.ndim(delta) > 0:
+            return self._criterion_block(iter, soltn, resid, np.asarray(delta, dtype=float))
         if self.logger is not None:
             self.logger(iter, np.sqrt(delta / self.d0), watch=self.watch, soltn=soltn, resid=resid)
         return (iter >= self.iter_max) or (delta <= self.eps_min ** 2 * self.d0)
 
+    def _criterion_block(self, iter, soltn, resid, delta):
+        """The stopping rule applied to every entry of a block vector by itself: an entry that meets it is frozen (its step length
+        is zero from then on, `active`), exactly where its own solve would have returned; the block solve ends when all have."""
+        d0 = np.asarray(self.d0, dtype=float)
+        if self.done is None:
+            self.done = np.zeros(delta.shape, dtype=bool)
+        if self.logger is not None:
+            live = ~self.done if not np.all(self.done) else np.ones_like(self.done)
+            self.logger(iter, float(np.max(np.sqrt(delta[live] / d0[live]))), watch=self.watch, soltn=soltn, resid=resid)
+        newly = (delta <= self.eps_min ** 2 * d0) & ~self.done
+        if np.any(newly):
+            self.done |= newly
+            if not np.all(self.done):
+                import torch
+                self.active = torch.from_numpy((~self.done).astype(np.float64)).to(resid.device if hasattr(resid, 'device') else _first_device(resid))
+        return (iter >= self.iter_max) or bool(np.all(self.done))
+
     def __call__(self, *args):
         return self.criterion(*args)
+
+
+def _first_device(v):
+    for name in ('tlm', 'elm'):
+        if hasattr(v, name):
+            return getattr(v, name).device
+    return v.device

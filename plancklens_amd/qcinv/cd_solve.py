@@ -95,7 +95,13 @@ def _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_i
         searchfwds = [fwd_op(d) for d in searchdirs]
         if fused:
             fresh_residual = np.mod(it + 1, roundoff) == 0
-            if merged:  # both scalar products in one launch, both updates of all fields in another (or all in one)
+            active = getattr(criterion, 'active', None)  # block vectors: 0 / 1 per entry, entries that have converged stand still
+            if active is not None:
+                assert merged, 'per-entry stopping of a block solve needs dot_op.step'
+                # (a residual refresh recomputes the frozen entries' residuals too: harmless, their solutions no longer move and
+                # the monitor's verdict on them is final)
+                dTAd, delta = dot_op.step(x, searchdirs[0], residual, searchfwds[0], update_r=not fresh_residual, active=active)
+            elif merged:  # both scalar products in one launch, both updates of all fields in another (or all in one)
                 dTAd, delta = dot_op.step(x, searchdirs[0], residual, searchfwds[0], update_r=not fresh_residual, one_launch=one_launch)
             else:
                 dTAd = dot_op.parts(searchdirs[0], searchfwds[0])

@@ -190,10 +190,17 @@ class _pre_op_dense(object):
         parts = _parts(talm)
         if getattr(self, '_amat', None) is None:
             self._amat = _flat_matrix(self.minv, self.lmax, len(parts))
-        flat = [torch.view_as_real(p).reshape(-1) for p in parts]
-        out = dev.gemv(self._amat, flat[0] if len(flat) == 1 else torch.cat(flat))  # pl_gemv: one launch
-        n = flat[0].numel()
-        res = [torch.view_as_complex(out[k * n:(k + 1) * n].view(-1, 2)) for k in range(len(parts))]
+        if parts[0].dim() == 2:  # block vectors [nb, nalm]: one mat-mat product, the matrix read once (pl_gemv_b)
+            nb = parts[0].shape[0]
+            flat = [torch.view_as_real(p).reshape(nb, -1) for p in parts]
+            out = dev.gemv(self._amat, flat[0] if len(flat) == 1 else torch.cat(flat, dim=1))
+            n = flat[0].shape[1]
+            res = [torch.view_as_complex(out[:, k * n:(k + 1) * n].contiguous().view(nb, -1, 2)) for k in range(len(parts))]
+        else:
+            flat = [torch.view_as_real(p).reshape(-1) for p in parts]
+            out = dev.gemv(self._amat, flat[0] if len(flat) == 1 else torch.cat(flat))  # pl_gemv: one launch
+            n = flat[0].numel()
+            res = [torch.view_as_complex(out[k * n:(k + 1) * n].view(-1, 2)) for k in range(len(parts))]
         return res[0] if len(res) == 1 else (eblm(res) if len(res) == 2 else teblm(res))
 
 

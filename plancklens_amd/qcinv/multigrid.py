@@ -52,7 +52,12 @@ class multigrid_chain(object):
         self.prev_eps = None
 
     def solve(self, soltn, tpn_map, apply_fini='', dot_op=None):
-        """Solves in place for `soltn` given the data map(s); finishes with opfilt.apply_fini (S^-1 x)."""
+        """Solves in place for `soltn` given the data map(s); finishes with opfilt.apply_fini (S^-1 x).
+
+        Block solves (several simulations filtered together, every launch carrying all of them): `soltn` holds [nb, nalm] device
+        tensors and `tpn_map` is the list of the nb data maps (nb (Q, U) pairs / (T, Q, U) triplets).  Scalar products, step
+        lengths and the stopping rule are per entry (the block solve ends when every entry has met it; an entry that has is frozen
+        where its own solve would have returned): results equal nb separate solves."""
         assert hasattr(self.opfilt, 'apply_fini%s' % apply_fini)
         finifunc = getattr(self.opfilt, 'apply_fini%s' % apply_fini)
         self.watch = util.stopwatch()
@@ -61,7 +66,11 @@ class multigrid_chain(object):
         if dot_op is None:
             dot_op = self.opfilt.dot_op()
         logger = (lambda iter, eps, stage=self.bstage, **kwargs: self.log(stage, iter, eps, **kwargs))
-        tpn_alm = self.opfilt.calc_prep(tpn_map, self.s_cls, self.n_inv_filt)
+        if _is_block(soltn):
+            assert len(tpn_map) == _parts(soltn)[0].shape[0], 'one data map (set) per entry of the block'
+            tpn_alm = self.opfilt.calc_prep_batch(tpn_map, self.s_cls, self.n_inv_filt)
+        else:
+            tpn_alm = self.opfilt.calc_prep(tpn_map, self.s_cls, self.n_inv_filt)
         monitor = cd_monitors.monitor_basic(dot_op, logger=logger, iter_max=self.bstage.iter_max,
                                             eps_min=self.bstage.eps_min, d0=dot_op(tpn_alm, tpn_alm))
         fwd_op = self.opfilt.fwd_op(self.s_cls, self.n_inv_filt)
@@ -186,7 +195,7 @@ class pre_op_multigrid(object):
     def calc(self, talm):
         if not self._capturable(talm):
             return self._calc_eager(talm)
-        key = tuple((p.numel(), p.dtype) for p in _parts(talm))
+        key = tuple((tuple(p.shape), p.dtype) for p in _parts(talm))
         st = self._graphs.setdefault(key, {'calls': 0, 'graph': None})
         if st['graph'] is None:
             st['calls'] += 1
@@ -240,6 +249,12 @@ class pre_op_multigrid(object):
 
 def _lmax_of(v):
     return v.lmax if hasattr(v, 'lmax') else util_alm.Alm.getlmax(util_alm._size(v))
+
+
+def _is_block(v):
+    """True for a block vector: its component tensors are [nb, nalm] (nb right-hand sides solved together)"""
+    p = _parts(v)[0]
+    return isinstance(p, torch.Tensor) and p.dim() == 2
 
 
 def _parts(v):

@@ -24,8 +24,8 @@ class dot_op(object):
         return dev.alm_dot([(alm1.elm, alm2.elm), (alm1.blm, alm2.blm)], lmin=2)
 
     def dev(self, alm1, alm2):
-        """the scalar product as a 0-dim device tensor"""
-        return self.parts(alm1, alm2).sum()
+        """the scalar product as a 0-dim device tensor (block vectors: one value per entry)"""
+        return self.parts(alm1, alm2).sum(-1)
 
     @staticmethod
     def axpy(y, x, num, den, sign):
@@ -34,12 +34,13 @@ class dot_op(object):
         dev.axpy_dev(y.blm, x.blm, num, den, sign)
 
     @staticmethod
-    def step(x, d, r, q, update_r=True, one_launch=False):
+    def step(x, d, r, q, update_r=True, one_launch=False, active=None):
         """one conjugate-directions update, all fields in two launches (or one with a grid barrier): dTAd = <d, q>, delta = <d, r>,
-        x += (delta / dTAd) d and, if update_r, r -= (delta / dTAd) q; returns (dTAd, delta) as `parts` does"""
+        x += (delta / dTAd) d and, if update_r, r -= (delta / dTAd) q; returns (dTAd, delta) as `parts` does.
+        active (block vectors): 0 / 1 per entry, multiplies the step lengths"""
         f = (lambda v: [v.elm, v.blm])
         return dev.cg_dot_axpy(f(d), f(q), f(x), f(d), 1.0, b2=f(r), y2=f(r) if update_r else None, x2=f(q) if update_r else None,
-                               sign2=-1.0, lmin=2, one_launch=one_launch)
+                               sign2=-1.0, lmin=2, one_launch=one_launch, active=active)
 
     @staticmethod
     def ortho(s, pq, pd, prev_dtad, one_launch=False):
@@ -48,7 +49,8 @@ class dot_op(object):
         dev.cg_dot_axpy(f(s), f(pq), f(s), f(pd), -1.0, den=prev_dtad, lmin=2, one_launch=one_launch)
 
     def __call__(self, alm1, alm2):
-        return float(self.parts(alm1, alm2).sum())
+        p = self.parts(alm1, alm2)
+        return float(p.sum()) if p.dim() == 1 else dev.to_host(p.sum(-1))  # block vectors: one value per entry
 
 
 class fwd_op(object):
@@ -64,9 +66,10 @@ class fwd_op(object):
         return self.calc(alm)
 
     def calc(self, alm):
-        f, sl = self.n_inv_filt, self.s_inv_filt.slinv
+        f, sl = util.unjit(self.n_inv_filt), self.s_inv_filt.slinv  # (the filter libraries hand over a lazily built filter)
         if isinstance(f, alm_filter_ninv) and f.one_call_ok(alm) and not np.any(sl[:, 0, 1]) and not np.any(sl[:, 1, 0]):
             return f.apply_alm_new(alm, add=alm, fl_add_e=sl[:, 0, 0], fl_add_b=sl[:, 1, 1])  # the whole operator in pl_cg_fwd_pp
+        assert not (isinstance(alm.elm, torch.Tensor) and alm.elm.dim() == 2), 'block vectors take the one-call operator (pl_cg_fwd_pp_b)'
         nlm = f.apply_alm_new(alm)
         return _apply_2x2(sl, alm, add_to=nlm)
 
@@ -278,28 +281,53 @@ class alm_filter_ninv(object):
         """(Q, U) <- N^-1 (Q, U) in place."""
         self._load_ninv()
         qmap, umap = amap
-        if len(self.n_inv) == 1:
+        if len(self.n_inv) == 1 and self.wmarg:
+            # Templates marginalised: N^-1 - N^-1 P (P^t N^-1 P)^-1 P^t N^-1 on the (Q, U) pair taken as one vector of 2 npix pixels.
+            # The modes (Q-only or U-only maps) and R = (P^t N^-1 P)^-1 (P . N^-1) are device matrices; weighting, coefficients and
+            # projection are the two launches of pl_template_project -- nothing comes back to the host inside a CG iteration
+            # (the reference forms the coefficients with np.dot on the host, opfilt_pp.py:284-294).
+            pmat, rmat, n2 = self._proj_matrices_p()
+            if pmat.shape[0] <= dev.TEMPLATE_MAX_MODES:
+                qu = shts._stack([qmap, umap])  # the halves of one (2, npix) tensor as the transforms return them: no copy
+                shared = qu.data_ptr() == qmap.data_ptr()
+                dev.template_project(qu.view(-1), n2, pmat, rmat)
+                if not shared:
+                    qmap.copy_(qu[0])
+                    umap.copy_(qu[1])
+            else:  # more modes than pl_template_project takes: mat-vecs
+                qu = torch.cat([qmap, umap])
+                qu *= n2
+                qu.addmv_(rmat.t(), dev.gemv(pmat, qu), alpha=-1.0)
+                qmap.copy_(qu[:qmap.numel()])
+                umap.copy_(qu[qmap.numel():])
+        elif len(self.n_inv) == 1:
             qmap *= self.n_inv[0]
             umap *= self.n_inv[0]
-            if self.wmarg:
-                self._build_tniti()
-                coeffs = np.concatenate([t.dot([qmap, umap]) for t in self.templates_p])
-                coeffs = np.dot(self.tniti, coeffs)
-                pmodes = [torch.zeros_like(qmap), torch.zeros_like(umap)]
-                for t, c in zip(self.templates_p, coeffs):
-                    t.accum(pmodes, [c])
-                pmodes[0] *= self.n_inv[0]
-                pmodes[1] *= self.n_inv[0]
-                qmap -= pmodes[0]
-                umap -= pmodes[1]
         elif len(self.n_inv) == 3:
-            qcopy = qmap.clone()
-            qmap *= self.n_inv[0]
-            qmap += self.n_inv[1] * umap
-            umap *= self.n_inv[2]
-            umap += self.n_inv[1] * qcopy
+            if qmap.is_contiguous() and umap.is_contiguous() and all(n.is_contiguous() and n.dtype == torch.float64 for n in self.n_inv):
+                dev.map_qu_weight(qmap, umap, self.n_inv[0], self.n_inv[1], self.n_inv[2])  # one pass (pl_map_qu_weight)
+            else:
+                qcopy = qmap.clone()
+                qmap *= self.n_inv[0]
+                qmap += self.n_inv[1] * umap
+                umap *= self.n_inv[2]
+                umap += self.n_inv[1] * qcopy
         else:
             assert 0
+
+    def _proj_matrices_p(self):
+        """(pmat, rmat, n_inv2): the template modes as rows of a (nmodes, 2 npix) device matrix (a Q template is zero on the U half
+        and vice versa), rmat = (P^t N^-1 P)^-1 (pmat . n_inv2) and n_inv2 = the inverse-noise map repeated for Q and U"""
+        if getattr(self, '_pmat_p', None) is None:
+            self._build_tniti()
+            npix = self.n_inv[0].numel()
+            pm = torch.zeros((len(self.templates_p), 2 * npix), dtype=torch.float64, device=self.n_inv[0].device)
+            for i, t in enumerate(self.templates_p):
+                pm[i, t.comp * npix:(t.comp + 1) * npix] = t.map
+            self._ninv2 = torch.cat([self.n_inv[0], self.n_inv[0]]).contiguous()
+            self._pmat_p = pm.contiguous()
+            self._rmat_p = torch.mm(dev.to_dev(np.ascontiguousarray(self.tniti), torch.float64), pm * self._ninv2.unsqueeze(0)).contiguous()
+        return self._pmat_p, self._rmat_p, self._ninv2
 
 
 class _template_pmap(object):
@@ -326,6 +354,12 @@ def calc_prep(maps, s_cls, n_inv_filt):
     n_inv_filt.apply_map([qmap, umap])
     elm, blm = map2alm_spin([qmap, umap], 2, lmax=lmax)
     return eblm([dev.almxfl(elm, n_inv_filt.b_transf_e * npix / (4. * np.pi)), dev.almxfl(blm, n_inv_filt.b_transf_b * npix / (4. * np.pi))])
+
+
+def calc_prep_batch(maps, s_cls, n_inv_filt):
+    """calc_prep of every (Q, U) pair of the list as one block vector: eblm of [nb, nalm] tensors"""
+    preps = [calc_prep(m, s_cls, n_inv_filt) for m in maps]
+    return eblm([torch.stack([p.elm for p in preps]).contiguous(), torch.stack([p.blm for p in preps]).contiguous()])
 
 
 def apply_fini(alm, s_cls, n_inv_filt):

@@ -327,7 +327,9 @@ class alm_filter_ninv(object):
         if len(self.n_inv) == 2:  # TT, QQ = UU
             qmap *= self.n_inv[1]
             umap *= self.n_inv[1]
-        else:  # TT, QQ, QU, UU
+        elif qmap.is_contiguous() and umap.is_contiguous() and all(n.is_contiguous() for n in self.n_inv[1:]):  # TT, QQ, QU, UU
+            dev.map_qu_weight(qmap, umap, self.n_inv[1], self.n_inv[2], self.n_inv[3])  # one pass (pl_map_qu_weight)
+        else:
             qmap_copy = qmap.clone()
             qmap *= self.n_inv[1]
             qmap += self.n_inv[2] * umap

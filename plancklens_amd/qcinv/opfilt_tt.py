@@ -32,6 +32,11 @@ def calc_prep(m, s_cls, n_inv_filt):
     return map2alm(tmap, lmax=lmax, iter=0, fl=n_inv_filt.b_transf * (tmap.numel() / (4. * np.pi)))
 
 
+def calc_prep_batch(maps, s_cls, n_inv_filt):
+    """calc_prep of every map of the list as one block vector [nb, nalm] (several right-hand sides solved together)"""
+    return torch.stack([calc_prep(m, s_cls, n_inv_filt) for m in maps]).contiguous()
+
+
 def apply_fini(alm, s_cls, n_inv_filt):
     """Wiener-filtered solution -> inverse-variance filtered: x <- S^-1 x (in place)."""
     alm.copy_(dev.almxfl(alm, _cli(s_cls['tt'])))
@@ -43,12 +48,12 @@ class dot_op(object):
     def parts(self, alm1, alm2):
         """the scalar product as dev.DOT_PARTS partial sums in device memory (one launch per field, no host synchronisation);
         its value is their sum, formed by whoever consumes it (axpy below, dev(), __call__)"""
-        assert alm1.numel() == alm2.numel()
+        assert alm1.shape == alm2.shape
         return dev.alm_dot([(alm1, alm2)])
 
     def dev(self, alm1, alm2):
-        """the scalar product as a 0-dim device tensor"""
-        return self.parts(alm1, alm2).sum()
+        """the scalar product as a 0-dim device tensor (block vectors [nb, nalm]: nb values)"""
+        return self.parts(alm1, alm2).sum(-1)
 
     @staticmethod
     def axpy(y, x, num, den, sign):
@@ -56,12 +61,13 @@ class dot_op(object):
         dev.axpy_dev(y, x, num, den, sign)
 
     @staticmethod
-    def step(x, d, r, q, update_r=True, one_launch=False):
+    def step(x, d, r, q, update_r=True, one_launch=False, active=None):
         """one conjugate-directions update, all fields in two launches (or one with a grid barrier): dTAd = <d, q>, delta = <d, r>,
-        x += (delta / dTAd) d and, if update_r, r -= (delta / dTAd) q; returns (dTAd, delta) as `parts` does"""
+        x += (delta / dTAd) d and, if update_r, r -= (delta / dTAd) q; returns (dTAd, delta) as `parts` does.
+        active (block vectors): 0 / 1 per entry, multiplies the step lengths"""
         f = (lambda v: [v])
         return dev.cg_dot_axpy(f(d), f(q), f(x), f(d), 1.0, b2=f(r), y2=f(r) if update_r else None, x2=f(q) if update_r else None,
-                               sign2=-1.0, lmin=0, one_launch=one_launch)
+                               sign2=-1.0, lmin=0, one_launch=one_launch, active=active)
 
     @staticmethod
     def ortho(s, pq, pd, prev_dtad, one_launch=False):
@@ -70,7 +76,8 @@ class dot_op(object):
         dev.cg_dot_axpy(f(s), f(pq), f(s), f(pd), -1.0, den=prev_dtad, lmin=0, one_launch=one_launch)
 
     def __call__(self, alm1, alm2):
-        return float(self.parts(alm1, alm2).sum())
+        p = self.parts(alm1, alm2)
+        return float(p.sum()) if p.dim() == 1 else dev.to_host(p.sum(-1))  # block vectors: one value per entry
 
 
 class fwd_op(object):
@@ -87,9 +94,10 @@ class fwd_op(object):
         return self.calc(talm)
 
     def calc(self, talm):
-        f = self.n_inv_filt
+        f = util.unjit(self.n_inv_filt)  # (the filter libraries hand over a lazily built filter)
         if isinstance(f, alm_filter_ninv) and f.one_call_ok(talm):  # the whole operator in pl_cg_fwd_tt
             return f.apply_alm_new(talm, alm_add=talm, fl_add=self.cltt_inv)
+        assert not (isinstance(talm, torch.Tensor) and talm.dim() == 2), 'block vectors take the one-call operator (pl_cg_fwd_tt_b)'
         alm = f.apply_alm_new(talm)
         return dev.almxfl_add(alm, talm, self.cltt_inv, out=alm)
 
@@ -199,12 +207,13 @@ class alm_filter_ninv(object):
 
     def apply_alm_new(self, alm, alm_add=None, fl_add=None):
         """B^t Y^t N^-1 Y B alm (+ fl_add alm_add) as a new array (the input is left alone)."""
-        lmax = hp.Alm.getlmax(alm.numel())
+        lmax = hp.Alm.getlmax(alm.shape[-1] if isinstance(alm, torch.Tensor) else alm.size)
         fl_out = self.b_transf * (self.npix / (4. * np.pi))
         if self.one_call_ok(alm):
             pmat, rmat = self._proj_matrices()
+            nb = alm.shape[0] if alm.dim() == 2 else 1
             return shts.cg_fwd_tt(alm, self.nside, lmax, self.n_inv, fl_in=self.b_transf, fl_out=fl_out, pmat=pmat, rmat=rmat,
-                                  scratch=dev.tproj_scratch() if pmat is not None else None, alm_add=alm_add, fl_add=fl_add)
+                                  scratch=dev.tproj_scratch(nb) if pmat is not None else None, alm_add=alm_add, fl_add=fl_add)
         tmap = alm2map(alm, self.nside, lmax=lmax, fl=self.b_transf)
         self.apply_map(tmap)
         ret = map2alm(tmap, lmax=lmax, iter=0, fl=fl_out)

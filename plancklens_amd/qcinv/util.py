@@ -68,6 +68,11 @@ class jit(object):
         setattr(self.instantiate(), name, value)
 
 
+def unjit(obj):
+    """the object behind a `jit` stand-in (built now if it was not yet); anything else is returned as it is"""
+    return obj.instantiate() if isinstance(obj, jit) else obj
+
+
 def read_map(m):
     """The map behind `m`: an array is returned as is, a callable is called, 'file.fits' and 'file.fits,3' are read with
     hp.read_map (field 3 in the second form), a list stands for the product of its members."""

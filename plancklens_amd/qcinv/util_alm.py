@@ -18,7 +18,8 @@ def _is_dev(a):
 
 
 def _size(a):
-    return a.numel() if _is_dev(a) else len(a)
+    """entries of one alm array; a 2-D device tensor [nb, nalm] is a block of nb arrays (several right-hand sides of one solve)"""
+    return a.shape[-1] if _is_dev(a) else len(a)
 
 
 def _low_index_maps(lmax_a, lmax_b, lcut):
@@ -69,6 +70,7 @@ def alm_copy(alm, lmax=None):
         return dev.alm_copy(alm, lmax)  # one kernel (pl_alm_copy)
     iin, iout = _maps_for(alm, lmox, lmax, lmax)
     if _is_dev(alm):
+        assert alm.dim() == 1, 'blocks of alm arrays live on the GPU as complex128'
         ret = torch.zeros(Alm.getsize(lmax), dtype=alm.dtype, device=alm.device)
     else:
         ret = np.zeros(Alm.getsize(lmax), dtype=complex)

@@ -246,18 +246,24 @@ def cg_fwd_tt(alm, nside, lmax, n_inv, fl_in=None, fl_out=None, pmat=None, rmat=
     fwd_op.calc of plancklens/qcinv/opfilt_tt.py:67-73.  pmat, rmat: (nmodes, npix) device matrices or None."""
     plan = get_plan(nside, lmax)
     a = alm.to(torch.complex128).contiguous()
-    assert a.numel() == plan.nalm and n_inv.numel() == plan.npix and n_inv.is_contiguous(), (a.shape, plan.nalm)
+    nb = a.shape[0] if a.dim() == 2 else 1  # a block [nb, nalm]: nb right-hand sides through every launch (pl_cg_fwd_tt_b)
+    assert a.shape[-1] == plan.nalm and a.numel() == nb * plan.nalm and n_inv.numel() == plan.npix and n_inv.is_contiguous(), (a.shape, plan.nalm)
     nmodes = 0 if pmat is None else pmat.shape[0]
     if nmodes:
         assert pmat.shape == (nmodes, plan.npix) and rmat.shape == pmat.shape and pmat.is_contiguous() and rmat.is_contiguous()
-    out = torch.empty(plan.nalm, dtype=torch.complex128, device=a.device)
+        assert scratch is not None and scratch.numel() >= nb * 16 * 256
+    out = torch.empty_like(a)
     fi, fo = _fl_arg(fl_in, lmax, True), _fl_arg(fl_out, lmax, True)
     fa = _fl_arg(fl_add, lmax, True) if alm_add is not None else None
     if alm_add is not None:
         alm_add = alm_add.contiguous()
-        assert alm_add.numel() == plan.nalm and alm_add.dtype == torch.complex128
-    _lib.check(_lib.lib().pl_cg_fwd_tt(plan.h, _ptr(a), _ptr(fi), _ptr(n_inv), nmodes, _ptr(pmat), _ptr(rmat), _ptr(scratch), _ptr(alm_add),
-                                       _ptr(fa), _ptr(out), _ptr(fo), _stream()))
+        assert alm_add.shape == a.shape and alm_add.dtype == torch.complex128
+    if a.dim() == 2:
+        _lib.check(_lib.lib().pl_cg_fwd_tt_b(plan.h, nb, _ptr(a), _ptr(fi), _ptr(n_inv), nmodes, _ptr(pmat), _ptr(rmat), _ptr(scratch),
+                                             _ptr(alm_add), _ptr(fa), _ptr(out), _ptr(fo), _stream()))
+    else:
+        _lib.check(_lib.lib().pl_cg_fwd_tt(plan.h, _ptr(a), _ptr(fi), _ptr(n_inv), nmodes, _ptr(pmat), _ptr(rmat), _ptr(scratch), _ptr(alm_add),
+                                           _ptr(fa), _ptr(out), _ptr(fo), _stream()))
     return out
 
 
@@ -266,17 +272,22 @@ def cg_fwd_pp(elm, blm, nside, lmax, n_inv, fl_in=None, fl_out=None, add=None, f
     plancklens/qcinv/opfilt_pp.py:69-78 for a single inverse-noise map.  Returns (elm, blm), two views of one (2, nalm) tensor."""
     plan = get_plan(nside, lmax)
     e, b = elm.contiguous(), blm.contiguous()
-    assert e.numel() == plan.nalm and b.numel() == plan.nalm and e.dtype == torch.complex128 and b.dtype == torch.complex128
+    nb = e.shape[0] if e.dim() == 2 else 1  # blocks [nb, nalm]: nb right-hand sides through every launch (pl_cg_fwd_pp_b)
+    assert e.shape == b.shape and e.shape[-1] == plan.nalm and e.numel() == nb * plan.nalm and e.dtype == torch.complex128 and b.dtype == torch.complex128
     assert n_inv.numel() == plan.npix and n_inv.is_contiguous() and n_inv.dtype == torch.float64
-    out = torch.empty((2, plan.nalm), dtype=torch.complex128, device=e.device)
+    out = torch.empty((2,) + tuple(e.shape), dtype=torch.complex128, device=e.device)
     fi, fo = _fl_arg(fl_in, lmax, True), _fl_arg(fl_out, lmax, True)
     ae = ab = fe = fb = None
     if add is not None:
         ae, ab = add[0].contiguous(), add[1].contiguous()
-        assert ae.numel() == plan.nalm and ab.numel() == plan.nalm and ae.dtype == torch.complex128 and ab.dtype == torch.complex128
+        assert ae.shape == e.shape and ab.shape == e.shape and ae.dtype == torch.complex128 and ab.dtype == torch.complex128
         fe, fb = _fl_arg(fl_add_e, lmax, True), _fl_arg(fl_add_b, lmax, True)
-    _lib.check(_lib.lib().pl_cg_fwd_pp(plan.h, _ptr(e), _ptr(b), _ptr(fi), _ptr(n_inv), _ptr(ae), _ptr(ab), _ptr(fe), _ptr(fb),
-                                       _ptr(out[0]), _ptr(out[1]), _ptr(fo), _stream()))
+    if e.dim() == 2:
+        _lib.check(_lib.lib().pl_cg_fwd_pp_b(plan.h, nb, _ptr(e), _ptr(b), _ptr(fi), _ptr(n_inv), _ptr(ae), _ptr(ab), _ptr(fe), _ptr(fb),
+                                             _ptr(out[0]), _ptr(out[1]), _ptr(fo), _stream()))
+    else:
+        _lib.check(_lib.lib().pl_cg_fwd_pp(plan.h, _ptr(e), _ptr(b), _ptr(fi), _ptr(n_inv), _ptr(ae), _ptr(ab), _ptr(fe), _ptr(fb),
+                                           _ptr(out[0]), _ptr(out[1]), _ptr(fo), _stream()))
     return out[0], out[1]
 
 

@@ -1,4 +1,4 @@
-"""Gaussian CMB sky libraries, API of plancklens/sims/cmbs.py (`sims_cmb_unl` :25-101)."""
+"""Gaussian CMB sky libraries, API of plancklens/sims/cmbs.py (`sims_cmb_unl` :25-101, `sims_cmb_unl_fixed_phi` :236-261)."""
 import numpy as np
 
 from .. import hp, utils
@@ -60,6 +60,9 @@ class sims_cmb_unl(object):
     def get_sim_plm(self, idx):
         return self.get_sim_alm(idx, 'p')
 
+    def get_sim_olm(self, idx):
+        return self.get_sim_alm(idx, 'o')
+
     def get_sim_tlm(self, idx):
         return self.get_sim_alm(idx, 't')
 
@@ -68,3 +71,17 @@ class sims_cmb_unl(object):
 
     def get_sim_blm(self, idx):
         return self.get_sim_alm(idx, 'b')
+
+
+class sims_cmb_unl_fixed_phi(sims_cmb_unl):
+    """sims_cmb_unl whose lensing potential is the same for every index: `plm` if given, that of simulation 0 otherwise
+    (cmbs.py:236-261)."""
+
+    def __init__(self, cls_unl, lib_pha, plm=None):
+        super(sims_cmb_unl_fixed_phi, self).__init__(cls_unl, lib_pha)
+        self.fixed_plm = sims_cmb_unl._get_sim_alm(self, 0, self.fields.index('p')) if plm is None else plm
+
+    def _get_sim_alm(self, idx, idf):
+        if idf == self.fields.index('p'):
+            return self.fixed_plm
+        return sims_cmb_unl._get_sim_alm(self, idx, idf)

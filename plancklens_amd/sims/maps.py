@@ -1,5 +1,5 @@
-"""CMB map simulation libraries, API of plancklens/sims/maps.py (`cmb_maps` :13-77, `cmb_maps_nlev` :100-173):
-sky alm x transfer function -> alm2map / alm2map_spin (GPU) + white pixel noise."""
+"""CMB map simulation libraries, API of plancklens/sims/maps.py (`cmb_maps` :13-77, `cmb_maps_noisefree` :88-99, `cmb_maps_nlev`
+:100-173, `cmb_maps_harmonicspace` :177-275): sky alm x transfer function -> alm2map / alm2map_spin (GPU) + noise."""
 import os
 import pickle as pk
 
@@ -59,6 +59,19 @@ class cmb_maps(object):
         assert 0, 'subclass this'
 
 
+class cmb_maps_noisefree(cmb_maps):
+    """Sky maps without noise (maps.py:88-99)."""
+
+    def __init__(self, sims_cmb_len, cl_transf, nside=2048, cl_transf_P=None, device_maps=False):
+        super(cmb_maps_noisefree, self).__init__(sims_cmb_len, cl_transf, nside=nside, cl_transf_P=cl_transf_P, device_maps=device_maps)
+
+    def get_sim_tnoise(self, idx):
+        return np.zeros(hp.nside2npix(self.nside))
+
+    get_sim_qnoise = get_sim_tnoise
+    get_sim_unoise = get_sim_tnoise
+
+
 class cmb_maps_nlev(cmb_maps):
     """Homogeneous white noise of nlev_t / nlev_p muK-arcmin on top of the sky maps (maps.py:100-173)."""
 
@@ -91,3 +104,59 @@ class cmb_maps_nlev(cmb_maps):
 
     def get_sim_unoise(self, idx):
         return self.nlev_p / self._vamin() * self.pix_lib_phas.get_sim(idx, idf=2)
+
+
+class cmb_maps_harmonicspace(object):
+    """Sky alm x per-field transfer function + isotropic (possibly coloured) noise drawn in harmonic space from a `lib_phas` with at
+    least three fields (maps.py:177-275).  Returns alms -- what filt_simple.library_fullsky_alms_sepTP filters -- or, with nside,
+    maps synthesised on the GPU."""
+
+    def __init__(self, sims_cmb_len, cls_transf, cls_noise, noise_phas, lib_dir=None, nside=None):
+        assert noise_phas.nfields >= 3, noise_phas.nfields
+        self.sims_cmb_len = sims_cmb_len
+        self.cls_transf = cls_transf
+        self.cls_noise = cls_noise
+        self.phas = noise_phas
+        self.nside = nside
+        if hasattr(sims_cmb_len, 'lmax'):
+            assert sims_cmb_len.lmax == noise_phas.lmax, 'band-limits of the sky (%s) and of the noise phases (%s) differ' % (sims_cmb_len.lmax, noise_phas.lmax)
+        if lib_dir is not None:
+            fn_hash = os.path.join(lib_dir, 'sim_hash.pk')
+            if mpi.rank == 0 and not os.path.exists(fn_hash):
+                if not os.path.exists(lib_dir):
+                    os.makedirs(lib_dir)
+                pk.dump(self.hashdict(), open(fn_hash, 'wb'), protocol=2)
+            mpi.barrier()
+            hash_check(self.hashdict(), pk.load(open(fn_hash, 'rb')), fn=fn_hash)
+
+    def hashdict(self):
+        ret = {'sims_cmb_len': self.sims_cmb_len.hashdict(), 'phas': self.phas.hashdict()}
+        ret.update({'noise' + k: clhash(v) for k, v in self.cls_noise.items()})
+        ret.update({'transf' + k: clhash(v) for k, v in self.cls_transf.items()})
+        return ret
+
+    def _noise(self, idx, field, idf):
+        assert field in self.cls_noise, field
+        return hp.almxfl(self.phas.get_sim(idx, idf), np.sqrt(self.cls_noise[field]))
+
+    def get_sim_tnoise(self, idx):
+        return self._noise(idx, 't', 0)
+
+    def get_sim_enoise(self, idx):
+        return self._noise(idx, 'e', 1)
+
+    def get_sim_bnoise(self, idx):
+        return self._noise(idx, 'b', 2)
+
+    def get_sim_tmap(self, idx):
+        assert 't' in self.cls_transf
+        tlm = hp.almxfl(self.sims_cmb_len.get_sim_tlm(idx), self.cls_transf['t']) + self.get_sim_tnoise(idx)
+        return tlm if not self.nside else shts.alm2map(tlm, self.nside)
+
+    def get_sim_pmap(self, idx):
+        assert 'e' in self.cls_transf and 'b' in self.cls_transf
+        elm = hp.almxfl(self.sims_cmb_len.get_sim_elm(idx), self.cls_transf['e']) + self.get_sim_enoise(idx)
+        blm = hp.almxfl(self.sims_cmb_len.get_sim_blm(idx), self.cls_transf['b']) + self.get_sim_bnoise(idx)
+        if self.nside is not None:
+            return shts.alm2map_spin([elm, blm], self.nside, 2, hp.Alm.getlmax(elm.size))
+        return elm, blm

@@ -1,24 +1,196 @@
-"""Random-phase libraries, API of plancklens/sims/phas.py (`lib_phas` :178-195, `pix_lib_phas` :137-155).
+"""Random-phase libraries, API of plancklens/sims/phas.py (`rng_db` :13-62, `sim_lib` :65-123, `pix_lib_phas` :126-155,
+`lib_phas` :157-195).
 
-The reference stores numpy RNG states in sqlite so that a simulation can be regenerated; here the same
-guarantee (get_sim(idx, idf) is a pure function of (library seed, idf, idx)) comes from counter-based seeding
-of numpy's Philox-free default generator: default_rng([seed, idf, idx]).  The seed is part of hashdict().
+Reference semantics (the default classes `lib_phas`, `pix_lib_phas`): a simulation is *the state of numpy's global legacy generator
+at the moment the simulation was first asked for*, kept per index in an sqlite table (`rngdb.db`, one directory per field:
+`pha_%04d`, `pix_pha_%04d`) beside a `sim_hash.pk`; asking again restores that state and redraws.  An existing `$PLENS` tree
+therefore yields here the phases it yields in the reference, and a fresh library driven by the same `np.random.seed` produces the
+same sequence (the draw advances the global generator exactly as the reference's does).  Table layout, file names and the draw
+order (real parts, then imaginary parts, / sqrt 2, m = 0 column made real with unit variance) are that contract.
 
-`pix_lib_phas_dev` / `lib_phas_dev` are device-side variants: the same interface and the same
-pure-function guarantee, with the numbers drawn on the GPU by torch's counter-based Philox generator seeded from
-(library seed, idf, idx) and returned as device tensors -- at GPU reconstruction speeds the host draw of 3 npix normals
-and their upload would be the bottleneck of a Monte-Carlo run.  The streams differ from the numpy ones (and so the
-realisations), which the hash records ('rng' entry).
+Extensions: `lib_phas_seeded` / `pix_lib_phas_seeded` make get_sim(idx, idf) a pure function of (library seed, idf, idx)
+(`default_rng([seed, idf, idx])`, no database, order-independent, what a sharded run wants), and `lib_phas_dev` /
+`pix_lib_phas_dev` draw on the GPU with torch's counter-based Philox generator seeded the same way and
+return device tensors -- at GPU reconstruction speeds the host draw of 3 npix normals and their upload would be the bottleneck
+of a Monte-Carlo run.  Their streams differ from numpy's (and so the realisations), which the hash records.
 """
 import os
 import pickle as pk
+import sqlite3
 
 import numpy as np
 
 from .. import hp, utils
 from ..helpers import mpi
 
+_RNG_COLUMNS = ('type', 'pos', 'has_gauss', 'cached_gaussian', 'keys')  # np.random.get_state(): (name, keys[624], pos, has_gauss, cached)
 
+
+class rng_db(object):
+    """Generator states of numpy's legacy RandomState in an sqlite file: table rngdb(id, type, pos, has_gauss, cached_gaussian,
+    keys), the 624 key words stored as one '_'-joined string (phas.py:13-62)."""
+
+    def __init__(self, fname, idtype="INTEGER"):
+        if mpi.rank == 0 and not os.path.exists(fname):
+            con = sqlite3.connect(fname, detect_types=sqlite3.PARSE_DECLTYPES, timeout=3600)
+            con.execute("create table rngdb (id %s PRIMARY KEY, type STRING, pos INTEGER, has_gauss INTEGER,cached_gaussian REAL, keys STRING)" % idtype)
+            con.commit()
+            con.close()
+        mpi.barrier()
+        self.con = sqlite3.connect(fname, timeout=3600., detect_types=sqlite3.PARSE_DECLTYPES)
+
+    def get(self, idx):
+        row = self.con.execute("SELECT %s FROM rngdb WHERE id=?" % ', '.join(_RNG_COLUMNS), (int(idx),)).fetchone()
+        if row is None:
+            return None
+        typ, pos, has_gauss, cached, keys = row
+        return [typ, np.array(keys.split('_'), dtype=np.uint64).astype(np.uint32), pos, has_gauss, cached]
+
+    def add(self, idx, state):
+        """stores the state under idx unless idx is taken (reported, not raised, like the reference)"""
+        try:
+            assert self.get(idx) is None
+            name, keys, pos, has_gauss, cached = state
+            self.con.execute("INSERT INTO rngdb (id, %s) VALUES (?,?,?,?,?,?)" % ', '.join(_RNG_COLUMNS),
+                             (int(idx), name, int(pos), int(has_gauss), float(cached), '_'.join(str(int(k)) for k in keys)))
+            self.con.commit()
+        except Exception:
+            print("rng_db::rngdb add failed!")
+
+    def delete(self, idx):
+        try:
+            if self.get(idx) is not None:
+                self.con.execute("DELETE FROM rngdb WHERE id=?", (int(idx),))
+                self.con.commit()
+        except Exception:
+            print("rng_db::rngdb delete %s failed!" % idx)
+
+
+class sim_lib(object):
+    """Simulations defined by stored generator states (phas.py:65-123): subclasses give hashdict() and
+    _build_sim_from_rng(state, **kwargs)."""
+
+    def __init__(self, lib_dir, get_state_func=np.random.get_state, nsims_max=None):
+        if mpi.rank == 0 and not os.path.exists(lib_dir):
+            os.makedirs(lib_dir)
+        self.nmax = nsims_max
+        fn_hash = os.path.join(lib_dir, 'sim_hash.pk')
+        if mpi.rank == 0 and not os.path.exists(fn_hash):
+            pk.dump(self.hashdict(), open(fn_hash, 'wb'), protocol=2)
+        mpi.barrier()
+        utils.hash_check(pk.load(open(fn_hash, 'rb')), self.hashdict(), ignore=['lib_dir'], fn=fn_hash)
+        self._rng_db = rng_db(os.path.join(lib_dir, 'rngdb.db'), idtype='INTEGER')
+        self._get_rng_state = get_state_func
+
+    def get_sim(self, idx, **kwargs):
+        """Simulation idx; the first request records the generator's current state under idx."""
+        assert self.nmax is None or idx < self.nmax
+        if not self.is_stored(idx):
+            self._rng_db.add(idx, self._get_rng_state())
+        return self._build_sim_from_rng(self._rng_db.get(idx), **kwargs)
+
+    def has_nmax(self):
+        return self.nmax is not None
+
+    def is_stored(self, idx):
+        return self._rng_db.get(idx) is not None
+
+    def is_full(self):
+        return self.has_nmax() and all(self.is_stored(i) for i in range(self.nmax))
+
+    def is_empty(self):
+        assert self.nmax is not None
+        return not any(self.is_stored(i) for i in range(self.nmax))
+
+    def hashdict(self):
+        assert 0, 'override this'
+
+    def _build_sim_from_rng(self, rng_state, **kwargs):
+        assert 0, 'override this'
+
+
+def _restore(state):
+    """numpy's global legacy generator put into `state` (as the reference does: the draw that follows advances the global stream)"""
+    np.random.set_state((state[0], np.asarray(state[1], dtype=np.uint32), int(state[2]), int(state[3]), float(state[4])))
+    return np.random
+
+
+class _pix_lib_phas(sim_lib):
+    def __init__(self, lib_dir, shape, **kwargs):
+        self.shape = shape
+        super(_pix_lib_phas, self).__init__(lib_dir, **kwargs)
+
+    def _build_sim_from_rng(self, rng_state, phas_only=False):
+        return _restore(rng_state).standard_normal(self.shape)
+
+    def hashdict(self):
+        return {'shape': self.shape}
+
+
+class _lib_phas(sim_lib):
+    def __init__(self, lib_dir, lmax, **kwargs):
+        self.lmax = lmax
+        super(_lib_phas, self).__init__(lib_dir, **kwargs)
+
+    def _build_sim_from_rng(self, rng_state, phas_only=False):
+        rng = _restore(rng_state)
+        n = hp.Alm.getsize(self.lmax)
+        re = rng.standard_normal(n)
+        alm = (re + 1j * rng.standard_normal(n)) / np.sqrt(2.)
+        if phas_only:
+            return None
+        alm[:self.lmax + 1] = np.sqrt(2.) * alm[:self.lmax + 1].real  # the m = 0 entries open the array
+        return alm
+
+    def hashdict(self):
+        return {'lmax': self.lmax}
+
+
+class _fields(object):
+    """nfields independent single-field libraries in sub-directories `<prefix>_%04d` of lib_dir"""
+
+    def __init__(self, lib_dir, nfields, make, prefix):
+        self.nfields = nfields
+        self._libs = {i: make(os.path.join(lib_dir, '%s_%04d' % (prefix, i))) for i in range(nfields)}
+
+    def __getitem__(self, i):
+        return self._libs[i]
+
+    def is_full(self):
+        return bool(np.all([lib.is_full() for lib in self._libs.values()]))
+
+    def get_sim(self, idx, idf=None, phas_only=False):
+        if idf is not None:
+            assert idf < self.nfields, (idf, self.nfields)
+            return self._libs[idf].get_sim(idx, phas_only=phas_only)
+        return np.array([self._libs[i].get_sim(idx, phas_only=phas_only) for i in range(self.nfields)])
+
+
+class pix_lib_phas(_fields):
+    """Unit-variance white pixel maps, nfields of them per simulation (phas.py:137-155)."""
+
+    def __init__(self, lib_dir, nfields, shape, **kwargs):
+        self.shape = shape
+        super(pix_lib_phas, self).__init__(lib_dir, nfields, lambda d: _pix_lib_phas(d, shape, **kwargs), 'pix_pha')
+        self.lib_pix = self._libs
+
+    def hashdict(self):
+        return {'nfields': self.nfields, 'shape': self.shape}
+
+
+class lib_phas(_fields):
+    """Unit-variance harmonic phases: complex normal alm with real m = 0 column (phas.py:157-195)."""
+
+    def __init__(self, lib_dir, nfields, lmax, **kwargs):
+        self.lmax = lmax
+        super(lib_phas, self).__init__(lib_dir, nfields, lambda d: _lib_phas(d, lmax, **kwargs), 'pha')
+        self.lib_phas = self._libs
+
+    def hashdict(self):
+        return {'nfields': self.nfields, 'lmax': self.lmax}
+
+
+# ---- counter-seeded variants (extension): no database, get_sim a pure function of (seed, idf, idx) ------------------------------
 class _seeded_lib(object):
     def __init__(self, lib_dir, seed=None, nsims_max=None):
         self.lib_dir = lib_dir
@@ -43,14 +215,17 @@ class _seeded_lib(object):
             assert idx < self.nmax
         return np.random.default_rng([self.seed, int(idf), int(idx)])
 
+    def is_full(self):
+        return True
 
-class pix_lib_phas(_seeded_lib):
-    """Unit-variance white pixel maps (phas.py:137-155)."""
+
+class pix_lib_phas_seeded(_seeded_lib):
+    """pix_lib_phas without stored states."""
 
     def __init__(self, lib_dir, nfields, shape, seed=None, **kwargs):
         self.nfields = nfields
         self.shape = shape
-        super(pix_lib_phas, self).__init__(lib_dir, seed=seed, **kwargs)
+        super(pix_lib_phas_seeded, self).__init__(lib_dir, seed=seed, **kwargs)
 
     def get_sim(self, idx, idf=None, phas_only=False):
         if idf is not None:
@@ -62,13 +237,13 @@ class pix_lib_phas(_seeded_lib):
         return {'nfields': self.nfields, 'shape': self.shape, 'seed': self.seed}
 
 
-class lib_phas(_seeded_lib):
-    """Unit-variance harmonic phases: complex normal alm with real m = 0 column (phas.py:157-195)."""
+class lib_phas_seeded(_seeded_lib):
+    """lib_phas without stored states."""
 
     def __init__(self, lib_dir, nfields, lmax, seed=None, **kwargs):
         self.nfields = nfields
         self.lmax = lmax
-        super(lib_phas, self).__init__(lib_dir, seed=seed, **kwargs)
+        super(lib_phas_seeded, self).__init__(lib_dir, seed=seed, **kwargs)
 
     def get_sim(self, idx, idf=None, phas_only=False):
         if idf is not None:
@@ -96,7 +271,7 @@ def _dev_generator(seed, idf, idx):
     return g
 
 
-class pix_lib_phas_dev(pix_lib_phas):
+class pix_lib_phas_dev(pix_lib_phas_seeded):
     """pix_lib_phas drawn on the device: get_sim returns float64 CUDA tensors."""
 
     def get_sim(self, idx, idf=None, phas_only=False):
@@ -114,7 +289,7 @@ class pix_lib_phas_dev(pix_lib_phas):
         return {'nfields': self.nfields, 'shape': self.shape, 'seed': self.seed, 'rng': 'torch-philox-cuda'}
 
 
-class lib_phas_dev(lib_phas):
+class lib_phas_dev(lib_phas_seeded):
     """lib_phas drawn on the device: get_sim returns complex128 CUDA tensors (unit variance, real m = 0 column)."""
 
     def get_sim(self, idx, idf=None, phas_only=False):

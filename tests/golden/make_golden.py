@@ -414,6 +414,187 @@ def make_lib_golden():
     print('wrote lib_golden.npz with %d arrays' % len(out))
 
 
+def make_sims_golden():
+    """Simulation inputs and the small wrapper classes, from the reference's own classes:
+    phas.lib_phas / pix_lib_phas (numpy generator states in sqlite: the rngdb.db files themselves are stored, so that the test can
+    hand an *existing* library to the new code), cmbs.sims_cmb_unl / sims_cmb_unl_fixed_phi, maps.cmb_maps_nlev /
+    cmb_maps_noisefree / cmb_maps_harmonicspace, filt_util.library_fml, and the cross-filtered estimator keys of qest
+    (_build_sim_xfiltMVgclm, qest.py:372-402)."""
+    from plancklens import qest, utils
+    from plancklens.sims import phas, cmbs, maps
+    from plancklens.filt import filt_simple, filt_util
+    nside, lmax = 8, 20
+    npix = 12 * nside ** 2
+    out = {'nside': nside, 'lmax': lmax}
+    tmp = tempfile.mkdtemp(prefix='plgolden_sims_')
+    try:
+        np.random.seed(4242)
+        lp = phas.lib_phas(os.path.join(tmp, 'pha'), 4, lmax)
+        pp = phas.pix_lib_phas(os.path.join(tmp, 'pix'), 3, (npix,))
+        for idx in (0, 1):   # request order matters: every first request records the global generator's state
+            out['pha_%d' % idx] = lp.get_sim(idx)
+            out['pix_%d' % idx] = pp.get_sim(idx)
+        assert np.array_equal(lp.get_sim(0, idf=2), out['pha_0'][2])
+        ell = np.arange(lmax + 1.)
+        cls = {'tt': 1e3 / (ell + 5.) ** 2, 'ee': 30. / (ell + 5.) ** 2, 'bb': 2. / (ell + 5.) ** 2, 'pp': 1e-2 / (ell + 5.) ** 4}
+        cls['te'] = 0.5 * np.sqrt(cls['tt'] * cls['ee'])
+        cls['tp'] = 0.2 * np.sqrt(cls['tt'] * cls['pp'])
+        for k, v in cls.items():
+            out['cls_' + k] = v
+        sky = cmbs.sims_cmb_unl(cls, lp)
+        out['sky_fields'] = np.array(sky.fields)
+        for f in 'pteb':
+            out['sky_%slm_1' % f] = sky.get_sim_alm(1, f)
+        fixed = cmbs.sims_cmb_unl_fixed_phi(cls, lp)
+        out['fixed_plm_1'], out['fixed_tlm_1'] = fixed.get_sim_plm(1), fixed.get_sim_tlm(1)
+        transf = myhp.gauss_beam(8. / 180. * np.pi, lmax=lmax)
+        out['transf'] = transf
+        nl = maps.cmb_maps_nlev(sky, transf, 50., 70., nside, pix_lib_phas=pp)
+        out['nlev_tmap_0'] = nl.get_sim_tmap(0)
+        out['nlev_qmap_0'], out['nlev_umap_0'] = nl.get_sim_pmap(0)
+        nf = maps.cmb_maps_noisefree(sky, transf, nside=nside, cl_transf_P=transf ** 2)
+        out['nf_tmap_1'] = nf.get_sim_tmap(1)
+        out['nf_qmap_1'], out['nf_umap_1'] = nf.get_sim_pmap(1)
+        cls_noise = {'t': 1. / (1. + ell), 'e': 0.5 * np.ones(lmax + 1), 'b': 0.25 * np.ones(lmax + 1)}
+        cls_transf = {'t': transf, 'e': transf ** 2, 'b': transf ** 3}
+        for k in 'teb':
+            out['hs_noise_' + k], out['hs_transf_' + k] = cls_noise[k], cls_transf[k]
+        hs = maps.cmb_maps_harmonicspace(sky, cls_transf, cls_noise, lp)
+        out['hs_tlm_0'] = hs.get_sim_tmap(0)
+        out['hs_elm_0'], out['hs_blm_0'] = hs.get_sim_pmap(0)
+        hsm = maps.cmb_maps_harmonicspace(sky, cls_transf, cls_noise, lp, nside=nside)
+        out['hs_tmap_0'] = hsm.get_sim_tmap(0)
+        out['hs_qmap_0'], out['hs_umap_0'] = hsm.get_sim_pmap(0)
+        # the library files as data: an existing $PLENS tree the new code must read
+        for name, lib, nf_ in (('pha', 'pha', 4), ('pix', 'pix_pha', 3)):
+            for i in range(nf_):
+                d = os.path.join(tmp, name, '%s_%04d' % (lib, i))
+                lp_, pp_ = None, None
+                out['file_%s_%d_rngdb' % (name, i)] = np.frombuffer(open(os.path.join(d, 'rngdb.db'), 'rb').read(), dtype=np.uint8)
+                out['file_%s_%d_hash' % (name, i)] = np.frombuffer(open(os.path.join(d, 'sim_hash.pk'), 'rb').read(), dtype=np.uint8)
+
+        # ---- library_fml over a stub filtering library of seeded random alms
+        lmax_i, lmax_f = 24, 17
+
+        class stub_ivfs(object):
+            lib_dir = tmp
+
+            def hashdict(self):
+                return {'stub': 1}
+
+            def _a(self, idx, k):
+                rng = np.random.default_rng(100 * idx + k)
+                a = rng.standard_normal(so.alm_size(lmax_i)) + 1j * rng.standard_normal(so.alm_size(lmax_i))
+                a[:lmax_i + 1] = a[:lmax_i + 1].real
+                return a
+
+            def get_fmask(self):
+                return np.ones(48)
+
+            def get_tal(self, a):
+                return np.ones(lmax_i + 1)
+
+            def get_ftl(self):
+                return 1. / (1. + np.arange(lmax_i + 1.))
+
+            def get_fel(self):
+                return 2. / (2. + np.arange(lmax_i + 1.))
+
+            def get_fbl(self):
+                return 3. / (3. + np.arange(lmax_i + 1.))
+        for k, name in enumerate(['tlm', 'elm', 'blm', 'tmliklm', 'emliklm', 'bmliklm']):
+            setattr(stub_ivfs, 'get_sim_' + name, (lambda self, idx, k=k: self._a(idx, k)))
+        mt, me, mb = 1. / (1. + 0.1 * np.arange(lmax_i + 1.)), np.cos(0.2 * np.arange(lmax_i + 1.)) ** 2, 0.5 + 0.5 * (np.arange(lmax_i + 1) % 2)
+        out['fml_lmax_in'], out['fml_lmax'], out['fml_mt'], out['fml_me'], out['fml_mb'] = lmax_i, lmax_f, mt, me, mb
+        fml = filt_util.library_fml(stub_ivfs(), lmax_f, mt, me, mb)
+        for name in ['tlm', 'elm', 'blm', 'tmliklm', 'emliklm', 'bmliklm']:
+            out['fml_%s_3' % name] = getattr(fml, 'get_sim_' + name)(3)
+        out['fml_ftl'], out['fml_fel'], out['fml_fbl'] = fml.get_ftl(), fml.get_fel(), fml.get_fbl()
+
+        # ---- cross-filtered estimator keys on the tiny estimator configuration of main()
+        nside_q, lmax_ivf, lmax_qlm, lmin_ivf = 16, 40, 47, 4
+        cls_path = os.path.join(ROOT, 'plancklens_amd', 'data', 'cls', 'FFP10_wdipole_lensedCls.dat')
+        cl_len = utils.camb_clfile(cls_path, lmax=lmax_ivf)
+        nlev_t, nlev_p = 1200., 35.
+        transf_q = myhp.gauss_beam(4. / 180. * np.pi, lmax=lmax_ivf)
+        sims = tiny_sims(nside_q, lmax_ivf, cl_len, transf_q, nlev_t, nlev_p)
+        arcmin = np.pi / 180. / 60.
+        ftl = utils.cli(cl_len['tt'][:lmax_ivf + 1] + (nlev_t * arcmin) ** 2 * utils.cli(transf_q ** 2))
+        fel = utils.cli(cl_len['ee'][:lmax_ivf + 1] + (nlev_p * arcmin) ** 2 * utils.cli(transf_q ** 2))
+        fbl = utils.cli(cl_len['bb'][:lmax_ivf + 1] + (nlev_p * arcmin) ** 2 * utils.cli(transf_q ** 2))
+        ftl[:lmin_ivf] = 0; fel[:lmin_ivf] = 0; fbl[:lmin_ivf] = 0
+        out.update({'q_nside': nside_q, 'q_lmax_ivf': lmax_ivf, 'q_lmax_qlm': lmax_qlm, 'q_nlev_t': nlev_t, 'q_nlev_p': nlev_p,
+                    'q_transf': transf_q, 'q_ftl': ftl, 'q_fel': fel, 'q_fbl': fbl})
+        for k in ['tt', 'ee', 'bb', 'te']:
+            out['q_cl_' + k] = cl_len[k]
+        ivfs = filt_simple.library_fullsky_sepTP(os.path.join(tmp, 'ivfs'), sims, nside_q, transf_q, cl_len, ftl, fel, fbl, cache=False)
+        ivfs_s = filt_util.library_shuffle(ivfs, {0: 1, 1: 0})
+        qdd = qest.library_sepTP(os.path.join(tmp, 'qdd'), ivfs, ivfs, cl_len['te'], nside_q, lmax_qlm=lmax_qlm)
+        qds = qest.library_sepTP(os.path.join(tmp, 'qds'), ivfs, ivfs_s, cl_len['te'], nside_q, lmax_qlm=lmax_qlm)
+        for k in ['pte', 'pet', 'pee', 'peb', 'pbe', 'ptb', 'xeb', 'xte']:
+            out['xf_dd_%s_0' % k] = qdd.get_sim_qlm(k, 0)
+        for k in ['pte', 'peb', 'xbe']:
+            out['xf_ds_%s_0' % k] = qds.get_sim_qlm(k, 0)
+        out['xf_dd_p_eb_0'] = qdd.get_sim_qlm('p_eb', 0)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    np.savez_compressed(os.path.join(HERE, 'sims_golden.npz'), **out)
+    print('wrote sims_golden.npz with %d arrays' % len(out))
+
+
+def make_cg2_golden():
+    """Operator fixtures of the noise models the first CG set did not reach: opfilt_pp.alm_filter_ninv with three maps (QQ, QU, UU)
+    and with marginalised Q / U template maps (apply_map, opfilt_pp.py:272-303), opfilt_tp.alm_filter_ninv with four maps
+    (TT, QQ, QU, UU; opfilt_tp.py:306-327), each through fwd_op and calc_prep."""
+    from plancklens.qcinv import opfilt_pp, opfilt_tp, util_alm
+    nside, lmax = 16, 32
+    npix = 12 * nside ** 2
+    rng = np.random.default_rng(78)
+    ell = np.arange(lmax + 1.)
+    cl = {'tt': np.where(ell >= 2, 3e3 / np.maximum(ell, 1.) ** 2.2, 0.), 'ee': np.where(ell >= 2, 60. / np.maximum(ell, 1.) ** 1.8, 0.),
+          'bb': np.where(ell >= 2, 2. / np.maximum(ell, 1.) ** 1.5, 0.)}
+    cl['te'] = 0.6 * np.sqrt(cl['tt'] * cl['ee'])
+    transf = myhp.gauss_beam(6. / 180. * np.pi, lmax=lmax)
+    th, ph = myhp.pix2ang(nside)
+    mask = (np.abs(np.cos(th)) > 0.25).astype(float)
+    sc = (npix / (4 * np.pi)) * 1e-4
+    nqq = mask * (0.6 + 0.3 * np.cos(2 * ph)) / 10. ** 2 * sc
+    nuu = mask * (0.7 + 0.2 * np.sin(ph)) / 10. ** 2 * sc
+    nqu = mask * 0.15 * np.sin(2 * ph) * np.sin(th) / 10. ** 2 * sc
+    ntt = mask * (0.5 + 0.4 * np.sin(3 * ph) * np.sin(th)) / 40. ** 2 * sc
+    qmap, umap, tmap = rng.standard_normal(npix) * 10., rng.standard_normal(npix) * 10., rng.standard_normal(npix) * 40.
+    tq = [np.cos(th) * mask, np.sin(th) * np.cos(ph) * mask]   # two Q templates
+    tu = [np.sin(2 * th) * np.sin(ph) * mask]                   # one U template
+    out = {'nside': nside, 'lmax': lmax, 'transf': transf, 'nqq': nqq, 'nqu': nqu, 'nuu': nuu, 'ntt': ntt, 'qmap': qmap, 'umap': umap,
+           'tmap': tmap, 'tq0': tq[0], 'tq1': tq[1], 'tu0': tu[0]}
+    for k in cl:
+        out['cl_' + k] = cl[k]
+    x = util_alm.eblm([myhp.synalm(cl['ee'], lmax, rng), myhp.synalm(cl['bb'], lmax, rng)])
+    out['xe'], out['xb'] = x.elm, x.blm
+    # (QQ, QU, UU)
+    f3 = opfilt_pp.alm_filter_ninv([nqq, nqu, nuu], transf)
+    r = opfilt_pp.fwd_op(cl, f3)(x)
+    out['pp3_fwd_e'], out['pp3_fwd_b'] = r.elm, r.blm
+    pr = opfilt_pp.calc_prep([qmap, umap], cl, f3)
+    out['pp3_prep_e'], out['pp3_prep_b'] = pr.elm, pr.blm
+    # one map + marginalised templates
+    fm = opfilt_pp.alm_filter_ninv([nqq], transf, marge_qmaps=tq, marge_umaps=tu)
+    r = opfilt_pp.fwd_op(cl, fm)(x)
+    out['ppm_fwd_e'], out['ppm_fwd_b'] = r.elm, r.blm
+    pr = opfilt_pp.calc_prep([qmap, umap], cl, fm)
+    out['ppm_prep_e'], out['ppm_prep_b'] = pr.elm, pr.blm
+    # joint filter, four maps
+    f4 = opfilt_tp.alm_filter_ninv([ntt, nqq, nqu, nuu], transf, marge_monopole=True, marge_dipole=True)
+    xt = util_alm.teblm([myhp.synalm(cl['tt'], lmax, rng), myhp.synalm(cl['ee'], lmax, rng), myhp.synalm(cl['bb'], lmax, rng)])
+    out['tp4_xt'], out['tp4_xe'], out['tp4_xb'] = xt.tlm, xt.elm, xt.blm
+    r = opfilt_tp.fwd_op(cl, f4)(xt)
+    out['tp4_fwd_t'], out['tp4_fwd_e'], out['tp4_fwd_b'] = r.tlm, r.elm, r.blm
+    pr = opfilt_tp.calc_prep([tmap, qmap, umap], cl, f4)
+    out['tp4_prep_t'], out['tp4_prep_e'], out['tp4_prep_b'] = pr.tlm, pr.elm, pr.blm
+    np.savez_compressed(os.path.join(HERE, 'cg2_golden.npz'), **out)
+    print('wrote cg2_golden.npz with %d arrays' % len(out))
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'resp':   # only the response / N0 fixtures
         assert os.path.isdir(REF), 'the reference is only present in the build container'
@@ -425,6 +606,11 @@ if __name__ == '__main__':
         install_healpy_standin()
         sys.path.insert(0, REF)
         make_lib_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] in ('sims', 'cg2'):   # simulation inputs / small wrapper classes; further noise models of the CG
+        assert os.path.isdir(REF), 'the reference is only present in the build container'
+        install_healpy_standin()
+        sys.path.insert(0, REF)
+        {'sims': make_sims_golden, 'cg2': make_cg2_golden}[sys.argv[1]]()
     elif len(sys.argv) > 1 and sys.argv[1] == 'cg':   # only the CG fixtures
         assert os.path.isdir(REF), 'the reference is only present in the build container'
         install_healpy_standin()

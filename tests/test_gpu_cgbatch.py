@@ -1,0 +1,237 @@
+"""Block solves of the qcinv conjugate-gradient filter: several right-hand sides (simulations) through every launch
+(`_b` entry points of include/plshts.h, multigrid_chain.solve on [nb, nalm] vectors, filt_cinv.cinv_*.apply_ivf_batch).
+
+The reference filters one simulation at a time (examples/run_qlms.py:57-62 -> filt_cinv.py:196-203,275-289); a block solve
+must give what nb separate solves give.  Every batched kernel forms each entry's result with the arithmetic of the un-batched
+launch, so the comparisons below are bit-for-bit wherever both sides go through the same route."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import relrms
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cg_golden.npz')
+
+
+def _ralm(rng, lmax, nb):
+    import torch
+    from plancklens_amd import hp
+    n = hp.Alm.getsize(lmax)
+    a = rng.standard_normal((nb, n)) + 1j * rng.standard_normal((nb, n))
+    a[:, :lmax + 1] = a[:, :lmax + 1].real
+    return torch.from_numpy(a).cuda()
+
+
+def test_block_vector_helpers_equal_their_loops():
+    """almxfl, alm_copy, alm_splice(_fl), almxfl_add, alm_dot, axpy_dev, cg_dot_axpy (with and without `active`), gemv and
+    template_project on blocks against the same call entry by entry: bit-identical."""
+    import torch
+    from plancklens_amd import dev
+    rng = np.random.default_rng(0)
+    nb, lmax, llo = 3, 37, 12
+    a, b, c, d = (_ralm(rng, lmax, nb) for _ in range(4))
+    lo = _ralm(rng, llo, nb)
+    fl = rng.standard_normal(lmax + 1)
+    eq = lambda x, y: bool((x == y).all())
+    assert eq(dev.almxfl(a, fl), torch.stack([dev.almxfl(a[i], fl) for i in range(nb)]))
+    assert eq(dev.alm_copy(a, llo), torch.stack([dev.alm_copy(a[i], llo) for i in range(nb)]))
+    assert eq(dev.alm_copy(lo, lmax), torch.stack([dev.alm_copy(lo[i], lmax) for i in range(nb)]))
+    assert eq(dev.alm_splice(lo, a, 9), torch.stack([dev.alm_splice(lo[i], a[i], 9) for i in range(nb)]))
+    assert eq(dev.alm_splice_fl(lo, a, fl, 9), torch.stack([dev.alm_splice_fl(lo[i], a[i], fl, 9) for i in range(nb)]))
+    assert eq(dev.almxfl_add(a, b, fl), torch.stack([dev.almxfl_add(a[i], b[i], fl) for i in range(nb)]))
+    for lmin in (0, 2):
+        assert eq(dev.alm_dot([(a, b), (c, d)], lmin=lmin), torch.stack([dev.alm_dot([(a[i], b[i]), (c[i], d[i])], lmin=lmin) for i in range(nb)]))
+    num, den = dev.alm_dot([(a, b)]), dev.alm_dot([(c, c)])
+    y1, y2 = a.clone(), a.clone()
+    dev.axpy_dev(y1, d, num, den, -1.0)
+    for i in range(nb):
+        dev.axpy_dev(y2[i], d[i], num[i], den[i], -1.0)
+    assert eq(y1, y2)
+    # one conjugate-directions update over two fields, blocks against loops; then with one entry frozen
+    for active in (None, torch.tensor([1., 0., 1.], dtype=torch.float64, device='cuda')):
+        xs = [[t.clone() for t in (a, b)] for _ in range(2)]   # x (two fields)
+        rs = [[t.clone() for t in (c, d)] for _ in range(2)]   # r
+        dd, qq = [c + a, d - b], [a * 2. + d, b - c * .5]
+        p1, p2 = dev.cg_dot_axpy(dd, qq, xs[0], dd, 1.0, b2=rs[0], y2=rs[0], x2=qq, sign2=-1.0, lmin=2, active=active)
+        for i in range(nb):
+            if active is not None and float(active[i]) == 0.:
+                continue
+            q1, q2 = dev.cg_dot_axpy([t[i] for t in dd], [t[i] for t in qq], [t[i] for t in xs[1]], [t[i] for t in dd], 1.0, b2=[t[i] for t in rs[1]],
+                                     y2=[t[i] for t in rs[1]], x2=[t[i] for t in qq], sign2=-1.0, lmin=2)
+            assert eq(p1[i], q1) and eq(p2[i], q2)
+        for k in range(2):
+            assert eq(xs[0][k], xs[1][k]) and eq(rs[0][k], rs[1][k])
+        if active is not None:
+            assert eq(xs[0][0][1], a[1]) and eq(rs[0][1][1], d[1])  # the frozen entry did not move
+    # dense preconditioner product
+    for nrhs in (2, 3, 5, 8, 11):
+        n = 2 * 46  # even, as the (re, im) views of alm arrays are
+        A = torch.from_numpy(rng.standard_normal((n + 5, n))).cuda()
+        X = torch.from_numpy(rng.standard_normal((nrhs, n))).cuda()
+        assert eq(dev.gemv(A, X), torch.stack([dev.gemv(A, X[i]) for i in range(nrhs)]))
+    A = torch.from_numpy(rng.standard_normal((3000, 4290))).cuda()  # the row length of the temperature block at lmax 64
+    X = torch.from_numpy(rng.standard_normal((4, 4290))).cuda()
+    assert eq(dev.gemv(A, X), torch.stack([dev.gemv(A, X[i]) for i in range(4)]))
+    assert relrms(dev.to_host(dev.gemv(A, X)), dev.to_host(X) @ dev.to_host(A).T) < 1e-13
+    # template projection, coarse- and fine-grid variants of the kernels
+    for npix in (12 * 16 ** 2, 12 * 512 ** 2):
+        t = torch.from_numpy(rng.standard_normal((nb, npix))).cuda()
+        ninv = torch.from_numpy(rng.random(npix)).cuda()
+        pm = torch.from_numpy(rng.standard_normal((4, npix))).cuda()
+        rm = torch.from_numpy(rng.standard_normal((4, npix)) * 1e-3).cuda()
+        t1, t2 = t.clone(), t.clone()
+        dev.template_project(t1, ninv, pm, rm)
+        for i in range(nb):
+            dev.template_project(t2[i], ninv, pm, rm)
+        assert eq(t1, t2)
+
+
+@pytest.mark.parametrize('nside,lmax,marge', [(8, 16, True), (32, 64, True), (512, 600, True), (512, 600, False), (1024, 1100, True)])
+def test_block_operators_equal_their_loops(nside, lmax, marge):
+    """pl_cg_fwd_tt_b / pl_cg_fwd_pp_b against entry-by-entry pl_cg_fwd_tt / pl_cg_fwd_pp (fwd_op.calc of opfilt_tt / opfilt_pp) on
+    grids of every route: all rings in the generic FFT kernel with the projection folded in (8, 32), register FFT classes with
+    the separate projection kernels (512, 1024).  Bit-identical."""
+    import torch
+    from plancklens_amd import dev, hp
+    from plancklens_amd.qcinv import opfilt_pp, opfilt_tt
+    from plancklens_amd.qcinv.util_alm import eblm
+    rng = np.random.default_rng(nside)
+    nb = 3
+    npix = 12 * nside ** 2
+    ell = np.arange(lmax + 1.)
+    bl = np.exp(-ell * (ell + 1.) * 1e-6)
+    x, y, z = hp.pix2vec(nside, np.arange(npix))
+    ninv = (1. + 0.3 * x) * (np.abs(z) > 0.3)
+    cl = {'tt': 1. / (ell + 3.) ** 2, 'ee': .1 / (ell + 3.) ** 2, 'bb': .01 / (ell + 3.) ** 2}
+    nf = opfilt_tt.alm_filter_ninv(ninv, bl, marge_monopole=marge, marge_dipole=marge)
+    op = opfilt_tt.fwd_op(cl, nf)
+    xt = _ralm(rng, lmax, nb)
+    x0 = xt.clone()
+    got = op(xt)
+    assert got.shape == xt.shape and bool((xt == x0).all())
+    for i in range(nb):
+        assert bool((got[i] == op(xt[i].contiguous())).all()), (nside, i)
+    assert bool((opfilt_tt.pre_op_diag(cl, nf)(xt) == torch.stack([opfilt_tt.pre_op_diag(cl, nf)(xt[i]) for i in range(nb)])).all())
+    nfp = opfilt_pp.alm_filter_ninv([ninv], bl)
+    opp = opfilt_pp.fwd_op(cl, nfp)
+    xe, xb = _ralm(rng, lmax, nb), _ralm(rng, lmax, nb)
+    gp = opp(eblm([xe, xb]))
+    for i in range(nb):
+        one = opp(eblm([xe[i].contiguous(), xb[i].contiguous()]))
+        assert bool((gp.elm[i] == one.elm).all()) and bool((gp.blm[i] == one.blm).all()), (nside, i)
+    d = opfilt_pp.dot_op()
+    vals = d(eblm([xe, xb]), gp)
+    assert vals.shape == (nb,)
+    for i in range(nb):
+        one = d(eblm([xe[i].contiguous(), xb[i].contiguous()]), eblm([gp.elm[i].contiguous(), gp.blm[i].contiguous()]))
+        assert abs(vals[i] - one) <= 1e-14 * abs(one)  # (the 64 partial sums are equal bit for bit; torch adds them in its own order)
+
+
+def _chain_descr(lmax, nside, niter, dense_lmax, eps=0.0):
+    from plancklens_amd.qcinv import cd_solve
+    return [[1, ["split(dense(), %d, diag_cl)" % dense_lmax], 16, 8, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
+            [0, ["split(stage(1), 16, diag_cl)"], lmax, nside, niter, eps, cd_solve.tr_cg, cd_solve.cache_mem()]]
+
+
+def test_reference_chains_reproduce_inside_a_block():
+    """The reference's stored multigrid solutions (tests/golden/cg_golden.npz: multigrid_chain + opfilt_tt / opfilt_pp + dense +
+    template_removal run by the reference itself) come out of a block solve of two right-hand sides -- the golden one and a
+    different one -- and the block equals two separate solves."""
+    import torch
+    from plancklens_amd import dev
+    from plancklens_amd.qcinv import multigrid, opfilt_pp, opfilt_tt
+    from plancklens_amd.qcinv.util_alm import eblm
+    g = np.load(GOLD)
+    rng = np.random.default_rng(5)
+    lmax, nside = int(g['lmax']), int(g['nside'])
+    cl = {'tt': g['cl_tt'], 'ee': g['cl_ee'], 'bb': g['cl_bb']}
+    n = g['cg_tlm'].size
+    other = g['tmap'][::-1].copy() * 0.7 + 0.1 * rng.standard_normal(g['tmap'].size)
+    nf = opfilt_tt.alm_filter_ninv(g['ninv_t'], g['transf'], marge_monopole=True, marge_dipole=True)
+    mk = lambda: multigrid.multigrid_chain(opfilt_tt, _chain_descr(lmax, nside, 6, 6), cl, nf)
+    blk = torch.zeros((2, n), dtype=torch.complex128, device='cuda')
+    mk().solve(blk, [g['tmap'], other])
+    assert relrms(dev.to_host(blk[0]), g['cg_tlm']) < 1e-8
+    for i, m in enumerate((g['tmap'], other)):
+        one = torch.zeros(n, dtype=torch.complex128, device='cuda')
+        mk().solve(one, m)
+        assert relrms(dev.to_host(blk[i]), dev.to_host(one)) < 1e-12, i
+    # polarization
+    nfp = opfilt_pp.alm_filter_ninv([g['ninv_p']], g['transf'])
+    mkp = lambda: multigrid.multigrid_chain(opfilt_pp, _chain_descr(lmax, nside, 5, 5), cl, nfp)
+    q2, u2 = g['umap'] * 0.5 + 0.2 * g['qmap'], g['qmap'][::-1].copy()
+    pblk = eblm([torch.zeros((2, n), dtype=torch.complex128, device='cuda'), torch.zeros((2, n), dtype=torch.complex128, device='cuda')])
+    mkp().solve(pblk, [[g['qmap'], g['umap']], [q2, u2]])
+    assert relrms(dev.to_host(pblk.elm[0]), g['cg_elm']) < 1e-8 and relrms(dev.to_host(pblk.blm[0]), g['cg_blm']) < 1e-7
+    for i, m in enumerate(([g['qmap'], g['umap']], [q2, u2])):
+        one = eblm([torch.zeros(n, dtype=torch.complex128, device='cuda'), torch.zeros(n, dtype=torch.complex128, device='cuda')])
+        mkp().solve(one, m)
+        assert relrms(dev.to_host(pblk.elm[i]), dev.to_host(one.elm)) < 1e-12 and relrms(dev.to_host(pblk.blm[i]), dev.to_host(one.blm)) < 1e-12, i
+
+
+def test_block_entries_stop_where_their_own_solves_stop():
+    """eps_min > 0: the entries of a block converge after different numbers of iterations; each is frozen at the iterate its own
+    solve returns (cd_monitors stopping rule per entry), while the others go on."""
+    import torch
+    from plancklens_amd import dev
+    from plancklens_amd.qcinv import multigrid, opfilt_tt
+    g = np.load(GOLD)
+    rng = np.random.default_rng(9)
+    lmax, nside = int(g['lmax']), int(g['nside'])
+    cl = {'tt': g['cl_tt']}
+    n = g['cg_tlm'].size
+    nf = opfilt_tt.alm_filter_ninv(g['ninv_t'], g['transf'], marge_monopole=True, marge_dipole=True)
+    maps = [g['tmap'], rng.standard_normal(g['tmap'].size) * g['tmap'].std(), g['tmap'] * np.linspace(0., 2., g['tmap'].size)]
+    differed = False
+    for eps in (1e-4, 1e-6, 1e-8, 1e-10):
+        mk = lambda: multigrid.multigrid_chain(opfilt_tt, _chain_descr(lmax, nside, np.inf, 6, eps=eps), cl, nf)
+        iters = []
+        for m in maps:
+            c = mk()
+            one = torch.zeros(n, dtype=torch.complex128, device='cuda')
+            c.solve(one, m)
+            iters.append((c.last_iters, dev.to_host(one)))
+        cb = mk()
+        blk = torch.zeros((len(maps), n), dtype=torch.complex128, device='cuda')
+        cb.solve(blk, maps)
+        assert cb.last_iters == max(i for i, _ in iters), (eps, cb.last_iters, [i for i, _ in iters])
+        differed = differed or len(set(i for i, _ in iters)) > 1
+        for i, (_, ref) in enumerate(iters):
+            assert relrms(dev.to_host(blk[i]), ref) < 1e-12, (eps, i, [k for k, _ in iters])
+    assert differed, 'the right-hand sides were meant to converge at different iterations for at least one tolerance'
+
+
+def test_cinv_block_filtering_at_survey_size(tmp_path):
+    """filt_cinv.cinv_t / cinv_p.apply_ivf_batch with the reference's default chains (4 and 3 stages, eps 1e-5, dense coarse level)
+    on a masked sky at nside 512, lmax 1024: three simulations in one block solve equal three separate apply_ivf calls (which
+    replay captured HIP graphs of the nested stages; the block solve captures its own)."""
+    from plancklens_amd import hp, shts
+    from plancklens_amd.filt import filt_cinv
+    rng = np.random.default_rng(4)
+    nside, lmax = 512, 1024
+    npix = 12 * nside ** 2
+    ell = np.arange(lmax + 1.)
+    cl = {'tt': np.where(ell >= 2, 1e4 / np.maximum(ell, 1) ** 2.5, 0.), 'ee': np.where(ell >= 2, 50. / np.maximum(ell, 1) ** 2, 0.),
+          'bb': np.where(ell >= 2, 1. / np.maximum(ell, 1) ** 2, 0.)}
+    transf = hp.gauss_beam(10. / 60 / 180 * np.pi, lmax=lmax)
+    x, y, z = hp.pix2vec(nside, np.arange(npix))
+    mask = (np.abs(z) > 0.25).astype(float)
+    vamin = np.sqrt(hp.nside2pixarea(nside, degrees=True)) * 60
+    nb = 3
+    tmaps, pmaps = [], []
+    for i in range(nb):
+        tmaps.append(shts.alm2map(hp.almxfl(hp.synalm(cl['tt'], lmax, rng), transf), nside) + 30. / vamin * rng.standard_normal(npix))
+        q, u = shts.alm2map_spin([hp.almxfl(hp.synalm(cl['ee'], lmax, rng), transf), hp.almxfl(hp.synalm(cl['bb'], lmax, rng), transf)], nside, 2, lmax)
+        pmaps.append([q + 40. / vamin * rng.standard_normal(npix), u + 40. / vamin * rng.standard_normal(npix)])
+    cinv_t = filt_cinv.cinv_t(str(tmp_path / 'cinv_t'), lmax, nside, cl, transf, [mask * (vamin / 30.) ** 2])
+    ones = [cinv_t.apply_ivf(m) for m in tmaps]
+    blk = cinv_t.apply_ivf_batch(tmaps)
+    for i in range(nb):
+        assert relrms(blk[i], ones[i]) < 1e-12, i
+    cinv_p = filt_cinv.cinv_p(str(tmp_path / 'cinv_p'), lmax, nside, cl, transf, [[mask * (vamin / 40.) ** 2]])
+    onesp = [cinv_p.apply_ivf(m) for m in pmaps]
+    blkp = cinv_p.apply_ivf_batch(pmaps)
+    for i in range(nb):
+        assert relrms(blkp[i][0], onesp[i][0]) < 1e-12 and relrms(blkp[i][1], onesp[i][1]) < 1e-12, i

@@ -327,11 +327,11 @@ def test_cg_operators_at_baseline_size():
     assert max(et, eb, ee, ebb) < 1e-11, (et, eb, ee, ebb)
 
 
-def test_mv_estimator_end_to_end_at_baseline_size(tmp_path):
-    """BASELINE.json's headline configuration end to end against the oracle: T, Q, U maps at nside 2048 -> isotropic filter -> MV 'p'
-    quadratic estimator at lmax = lmax_qlm = 2048, gradient and curl, through the product's own classes (filt_simple / qest.library_sepTP)
-    on the GPU and through oracle/qe_oracle.py on the host (its transforms routed to the threaded C stages of the oracle: Legendre
-    stage and ring FFTs, every ring pair).  north_star asks for qlm rms agreement < 1e-8; observed ~1e-13."""
+def _estimators_vs_oracle(tmp_path, nside, keys, seed=11):
+    """T, Q, U maps at `nside` -> isotropic filter -> the quadratic estimators `keys` at lmax = lmax_qlm = nside, gradient and curl,
+    through the product's own classes (filt_simple / qest.library_sepTP) on the GPU and through oracle/qe_oracle.py on the host
+    (its transforms routed to the threaded C stages of the oracle: Legendre stage and ring FFTs, every ring pair).
+    Returns {key: (gradient rel rms, curl rel rms)}."""
     import sys
     import time
     import torch
@@ -340,14 +340,14 @@ def test_mv_estimator_end_to_end_at_baseline_size(tmp_path):
     from oracle import sht_oracle as so, qe_oracle as qo
     from plancklens_amd import qest
     from plancklens_amd.filt import filt_simple
-    nside = lmax = 2048
+    lmax = nside
     nt = bench.usable_cpus()
     synth, anal = _oracle_transforms(nside, lmax, nt)
     fast = {'alm2map': lambda alm, ns, lmax=None, **kw: synth([alm], 0)[0],
             'map2alm': lambda m, lmax=None, **kw: anal([m], 0, lmax)[0],
             'alm2map_spin': lambda gclm, ns, spin, lm, **kw: synth(list(gclm), spin),
             'map2alm_spin': lambda maps, spin, lm=None, **kw: anal(list(maps), spin, lm)}
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(seed)
     ell = np.arange(lmax + 1.)
     cls = {'tt': 1e3 / (ell + 10.) ** 2.5, 'ee': 3e1 / (ell + 10.) ** 2.5, 'bb': 3. / (ell + 10.) ** 2.5}
     cls['te'] = 0.4 * np.sqrt(cls['tt'] * cls['ee'])
@@ -361,11 +361,13 @@ def test_mv_estimator_end_to_end_at_baseline_size(tmp_path):
     maps = rng.standard_normal((3, 12 * nside ** 2))
     saved = {k: getattr(so, k) for k in fast}
     t0 = time.time()
+    ref = {}
     try:
         for k, f in fast.items():
             setattr(so, k, f)
         t, e, b = qo.filter_maps(maps[0], maps[1], maps[2], lmax, fl, fel, fbl, transf)
-        Go, Co = qo.qe_sepTP('p', (t, e, b), (t, e, b), cls, nside, lmax)
+        for key in keys:
+            ref[key] = qo.qe_sepTP(key, (t, e, b), (t, e, b), cls, nside, lmax)
     finally:
         for k, f in saved.items():
             setattr(so, k, f)
@@ -373,7 +375,7 @@ def test_mv_estimator_end_to_end_at_baseline_size(tmp_path):
 
     class sims(object):
         def hashdict(self):
-            return {'fullsize': 11}
+            return {'fullsize': seed}
 
         def get_sim_tmap(self, idx):
             return maps[0]
@@ -382,11 +384,30 @@ def test_mv_estimator_end_to_end_at_baseline_size(tmp_path):
             return maps[1], maps[2]
     ivfs = filt_simple.library_fullsky_sepTP(str(tmp_path / 'ivfs'), sims(), nside, transf, cls, fl, fel, fbl, cache=False)
     ql = qest.library_sepTP(str(tmp_path / 'ql'), ivfs, ivfs, cls['te'], nside, lmax_qlm=lmax, cache=False)
-    G = ql.get_sim_qlm('p', 0)
-    C = ql.get_sim_qlm('x', 0)
-    torch.cuda.synchronize()
-    eg, ec = relrms(G, Go), relrms(C, Co)
-    _note("MV 'p' end to end at nside = lmax = lmax_qlm = 2048 vs oracle: gradient rel rms %.2e, curl %.2e (oracle: %.0f s on %d threads)"
-          % (eg, ec, t_oracle, nt))
+    out = {}
+    for key in keys:
+        G = ql.get_sim_qlm(key, 0)
+        C = ql.get_sim_qlm('x' + key[1:], 0)
+        torch.cuda.synchronize()
+        out[key] = (relrms(G, ref[key][0]), relrms(C, ref[key][1]))
+        _note("'%s' end to end at nside = lmax = lmax_qlm = %d vs oracle: gradient rel rms %.2e, curl %.2e" % ((key, nside) + out[key]))
+    _note("   (oracle: filter + %s in %.0f s on %d threads)" % (', '.join(keys), t_oracle, nt))
+    return out
+
+
+def test_estimators_end_to_end_at_baseline_size(tmp_path):
+    """BASELINE.json's configurations 2, 3 and the headline one by name, end to end against the oracle at nside = lmax = lmax_qlm =
+    2048: 'ptt' (the gradient-only spin-1 synthesis k_leg_synths<R, true>), 'p_p' (spin-2 / spin-3 legs) and the MV 'p' (paired
+    spin-1 synthesis, the nine-map product).  north_star asks for qlm rms agreement < 1e-8; observed ~1e-13."""
+    out = _estimators_vs_oracle(tmp_path, 2048, ['p', 'ptt', 'p_p'])
+    for key, (eg, ec) in out.items():
+        assert eg < 1e-8 and ec < 1e-8, (key, eg, ec)
+        assert eg < 1e-11 and ec < 1e-11, (key, eg, ec)  # what the arithmetic delivers; the line above is north_star's bar
+
+
+def test_mv_estimator_end_to_end_at_4096(tmp_path):
+    """BASELINE config 5's per-GPU unit of work -- the MV 'p' reconstruction at nside = lmax = lmax_qlm = 4096 -- against the oracle
+    (k_leg_anal0<8>, the split-Bluestein 4096 class, the four-component phase buffers and the nine-map product at npix = 2e8)."""
+    (eg, ec), = _estimators_vs_oracle(tmp_path, 4096, ['p'], seed=12).values()
     assert eg < 1e-8 and ec < 1e-8, (eg, ec)
-    assert eg < 1e-11 and ec < 1e-11, (eg, ec)  # what the arithmetic delivers; the line above is north_star's bar
+    assert eg < 1e-11 and ec < 1e-11, (eg, ec)

@@ -120,3 +120,44 @@ def test_fits_reader_on_a_file_written_elsewhere():
     assert np.array_equal(cols['a'], ref['f0']) and np.allclose(cols['a'], [5.1, 5.2, 5.3])
     assert np.array_equal(cols['b'], ref['f1']) and list(cols['b']) == [61, 62, 63]
     assert [c.decode().strip() for c in cols['c']] == ['abcde', 'fghij', 'kl']
+
+
+def test_alm_files_have_healpy_s_table_layout(tmp_path):
+    """healpy.write_alm / read_alm (plancklens/qest.py:17,201; filt/filt_simple.py:97-99): the fixture is that table for a small
+    alm, assembled byte by byte from the documented format by tests/golden/make_healpy_alm_fixture.py (independent of fitsio.py).
+    read_alm must decode it; write_alm must produce the same rows -- index = l^2 + l + m + 1 as 32-bit, real and imag as 64-bit
+    big-endian, m-major -- and the structural keywords a reader relies on."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import make_healpy_alm_fixture as mk
+    from plancklens_amd import hp
+    fix = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'healpy_alm_lmax3.fits')
+    raw = open(fix, 'rb').read()
+    assert raw == mk.build(), 'the committed fixture is what its script builds'
+    rows = mk.alm_values()
+    expect = np.array([re + 1j * im for _, re, im in rows])
+    alm, mmax = hp.read_alm(fix, return_mmax=True)
+    assert mmax == mk.LMAX and np.array_equal(alm, expect)
+    out = str(tmp_path / 'ours.fits')
+    hp.write_alm(out, expect)
+    ours = open(out, 'rb').read()
+    assert len(ours) == len(raw) and len(ours) % 2880 == 0
+    assert ours[-2880:] == raw[-2880:], 'table rows differ from the healpy layout'
+
+    def cards(b):
+        hdr = b[2880:5760].decode('ascii')
+        kv = {}
+        for i in range(0, 2880, 80):
+            c = hdr[i:i + 80]
+            if c[8:10] == '= ':
+                kv[c[:8].strip()] = c[10:].split(' /')[0].strip().strip("'").strip()
+        return kv
+    a, b = cards(ours), cards(raw)
+    for k in ['XTENSION', 'BITPIX', 'NAXIS', 'NAXIS1', 'NAXIS2', 'PCOUNT', 'GCOUNT', 'TFIELDS', 'TTYPE1', 'TTYPE2', 'TTYPE3']:
+        assert a[k] == b[k], (k, a[k], b[k])
+    for k in ['TFORM1', 'TFORM2', 'TFORM3']:
+        assert a[k].lstrip('1') == b[k], (k, a[k], b[k])  # '1J' and 'J' are the same format
+    assert ours[:2880] == raw[:2880] or ours[:80].startswith(b'SIMPLE  =                    T')
+    # a truncated write keeps healpy's semantics: rows with l <= lmax only
+    hp.write_alm(out, expect, lmax=2, overwrite=True)
+    assert np.array_equal(hp.read_alm(out), expect[[0, 1, 2, 4, 5, 7]])

@@ -1,0 +1,132 @@
+"""Simulation-input classes against outputs of the reference's own classes (tests/golden/sims_golden.npz, written by
+tests/golden/make_golden.py sims from /root/reference): phase libraries with the reference's generator-state database, Gaussian
+skies, harmonic-space map library, m-dependent rescaling of a filtering library.  Host logic only (no GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import relrms
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'sims_golden.npz')
+
+
+@pytest.fixture(scope='module')
+def g():
+    return np.load(GOLD)
+
+
+def _plant(g, root, name, sub, nfields):
+    """an existing library on disk: the reference's own rngdb.db / sim_hash.pk files, byte for byte"""
+    for i in range(nfields):
+        d = os.path.join(root, '%s_%04d' % (sub, i))
+        os.makedirs(d)
+        open(os.path.join(d, 'rngdb.db'), 'wb').write(g['file_%s_%d_rngdb' % (name, i)].tobytes())
+        open(os.path.join(d, 'sim_hash.pk'), 'wb').write(g['file_%s_%d_hash' % (name, i)].tobytes())
+
+
+def _libs(g, tmp_path):
+    from plancklens_amd.sims import phas
+    _plant(g, str(tmp_path / 'pha'), 'pha', 'pha', 4)
+    _plant(g, str(tmp_path / 'pix'), 'pix', 'pix_pha', 3)
+    lmax, nside = int(g['lmax']), int(g['nside'])
+    return phas.lib_phas(str(tmp_path / 'pha'), 4, lmax), phas.pix_lib_phas(str(tmp_path / 'pix'), 3, (12 * nside ** 2,))
+
+
+def test_existing_phase_libraries_yield_the_reference_phases(g, tmp_path):
+    """plancklens/sims/phas.py:13-195: the stored numpy generator states of an existing library reproduce its simulations --
+    whatever the state of the global generator now, and in any request order."""
+    np.random.seed(1)
+    lp, pp = _libs(g, tmp_path)
+    assert lp.is_full() is False and lp[1].is_stored(0) and not lp[1].is_stored(2)
+    for idx in (1, 0):
+        assert np.array_equal(lp.get_sim(idx), g['pha_%d' % idx])
+        assert np.array_equal(pp.get_sim(idx), g['pix_%d' % idx])
+    assert np.array_equal(lp.get_sim(0, idf=3), g['pha_0'][3]) and np.array_equal(pp.get_sim(1, idf=2), g['pix_1'][2])
+    assert lp.get_sim(0, idf=1, phas_only=True) is None
+    assert lp.hashdict() == {'nfields': 4, 'lmax': int(g['lmax'])}
+
+
+def test_fresh_phase_libraries_follow_the_global_generator_like_the_reference(g, tmp_path):
+    """a new library driven by the same np.random.seed and the same request order records the same states"""
+    from plancklens_amd.sims import phas
+    lmax, nside = int(g['lmax']), int(g['nside'])
+    np.random.seed(4242)
+    lp = phas.lib_phas(str(tmp_path / 'pha'), 4, lmax)
+    pp = phas.pix_lib_phas(str(tmp_path / 'pix'), 3, (12 * nside ** 2,))
+    for idx in (0, 1):
+        assert np.array_equal(lp.get_sim(idx), g['pha_%d' % idx])
+        assert np.array_equal(pp.get_sim(idx), g['pix_%d' % idx])
+    st = lp[2]._rng_db.get(1)
+    assert st[0] == 'MT19937' and st[1].dtype == np.uint32 and st[1].size == 624
+    lp[2]._rng_db.delete(1)
+    assert not lp[2].is_stored(1)
+    lim = phas.pix_lib_phas(str(tmp_path / 'lim'), 1, (4,), nsims_max=2)
+    lim.get_sim(0), lim.get_sim(1)
+    assert lim.is_full()
+    with pytest.raises(AssertionError):
+        lim.get_sim(2)
+
+
+def test_gaussian_skies_and_harmonic_space_maps(g, tmp_path):
+    """cmbs.sims_cmb_unl / sims_cmb_unl_fixed_phi (cmbs.py:25-101,236-261) and maps.cmb_maps_harmonicspace in alm mode
+    (maps.py:177-275) on the reference's phases"""
+    from plancklens_amd.sims import cmbs, maps
+    lp, _ = _libs(g, tmp_path)
+    cls = {k[4:]: g[k] for k in g.files if k.startswith('cls_')}
+    sky = cmbs.sims_cmb_unl(cls, lp)
+    assert list(sky.fields) == [str(f) for f in g['sky_fields']]
+    for f in 'pteb':
+        assert relrms(sky.get_sim_alm(1, f), g['sky_%slm_1' % f]) < 1e-13
+    fixed = cmbs.sims_cmb_unl_fixed_phi(cls, lp)
+    assert relrms(fixed.get_sim_plm(1), g['fixed_plm_1']) < 1e-13 and relrms(fixed.get_sim_tlm(1), g['fixed_tlm_1']) < 1e-13
+    assert np.array_equal(fixed.get_sim_plm(1), fixed.get_sim_plm(0))
+    hs = maps.cmb_maps_harmonicspace(sky, {k: g['hs_transf_' + k] for k in 'teb'}, {k: g['hs_noise_' + k] for k in 'teb'}, lp,
+                                     lib_dir=str(tmp_path / 'hs'))
+    assert relrms(hs.get_sim_tmap(0), g['hs_tlm_0']) < 1e-13
+    e, b = hs.get_sim_pmap(0)
+    assert relrms(e, g['hs_elm_0']) < 1e-13 and relrms(b, g['hs_blm_0']) < 1e-13
+    assert relrms(sky.get_sim_tlm(0), sky.get_sim_tlm(0)) == 0.  # the getters do not modify the library's alms
+
+
+def test_library_fml_vs_reference(g):
+    """filt_util.library_fml (filt_util.py:106-182), including its use of the temperature weights for the filtered E and B alms"""
+    from plancklens_amd import hp
+    from plancklens_amd.filt import filt_util
+    lmax_i, lmax_f = int(g['fml_lmax_in']), int(g['fml_lmax'])
+
+    class stub_ivfs(object):
+        lib_dir = None
+
+        def hashdict(self):
+            return {'stub': 1}
+
+        def _a(self, idx, k):
+            rng = np.random.default_rng(100 * idx + k)
+            a = rng.standard_normal(hp.Alm.getsize(lmax_i)) + 1j * rng.standard_normal(hp.Alm.getsize(lmax_i))
+            a[:lmax_i + 1] = a[:lmax_i + 1].real
+            return a
+
+        def get_fmask(self):
+            return np.ones(48)
+
+        def get_tal(self, a):
+            return np.ones(lmax_i + 1)
+
+        def get_ftl(self):
+            return 1. / (1. + np.arange(lmax_i + 1.))
+
+        def get_fel(self):
+            return 2. / (2. + np.arange(lmax_i + 1.))
+
+        def get_fbl(self):
+            return 3. / (3. + np.arange(lmax_i + 1.))
+    names = ['tlm', 'elm', 'blm', 'tmliklm', 'emliklm', 'bmliklm']
+    for k, name in enumerate(names):
+        setattr(stub_ivfs, 'get_sim_' + name, (lambda self, idx, k=k: self._a(idx, k)))
+    fml = filt_util.library_fml(stub_ivfs(), lmax_f, g['fml_mt'], g['fml_me'], g['fml_mb'])
+    for name in names:
+        assert relrms(getattr(fml, 'get_sim_' + name)(3), g['fml_%s_3' % name]) < 1e-14, name
+    for name in ['ftl', 'fel', 'fbl']:
+        assert np.allclose(getattr(fml, 'get_' + name)(), g['fml_' + name], rtol=1e-14, atol=0)
+    assert set(fml.hashdict().keys()) == {'ivfs', 'filt_t', 'filt_e', 'filt_b'}

@@ -46,21 +46,23 @@ def chain(kind, n, lmax, nside, pcf):
             [0, ["split(stage(1), 1024, diag_cl)"], lmax, nside, n, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()]]
 
 
-def run(nside=2048, lmax=2048, iters=100, kinds=('t', 'p'), joint=False, verbose=False, peak_tflops=78.6):
+def run(nside=2048, lmax=2048, iters=100, kinds=('t', 'p'), joint=False, verbose=False, peak_tflops=78.6, batches=()):
     """verbose=False: nothing reaches stdout (the filter classes print their set-up like the reference does; bench.py must
     print exactly one JSON line)."""
     if not verbose:
         stdout = sys.stdout
         sys.stdout = open(os.devnull, 'w')
         try:
-            return _run(nside, lmax, iters, kinds, joint, False, peak_tflops)
+            return _run(nside, lmax, iters, kinds, joint, False, peak_tflops, batches)
         finally:
             sys.stdout.close()
             sys.stdout = stdout
-    return _run(nside, lmax, iters, kinds, joint, True, peak_tflops)
+    return _run(nside, lmax, iters, kinds, joint, True, peak_tflops, batches)
 
 
-def _run(nside, lmax, iters, kinds, joint, verbose, peak_tflops):
+def _run(nside, lmax, iters, kinds, joint, verbose, peak_tflops, batches=()):
+    """batches: block sizes B > 1 to time as well -- B simulations (different data maps, same noise model) filtered in ONE block
+    solve (cinv_*.apply_ivf_batch); reported per simulation: iterations/s of one solve x B."""
     import torch
     from plancklens_amd import dev, hp, shts, utils
     from plancklens_amd.filt import filt_cinv
@@ -118,6 +120,30 @@ def _run(nside, lmax, iters, kinds, joint, verbose, peak_tflops):
             res[kind]['frac_of_fp64_floor'] = FLOP_PER_ITER_2048[kind] / peak_tflops / 1e12 / (dt / iters)
         if verbose:
             print(kind, json.dumps(res[kind]), flush=True)
+        for B in batches:
+            if B <= 1:
+                continue
+            # B different data maps: the resident map scaled and point-reflected copies of it with other noise draws would do as well;
+            # what matters to the timing is that every entry is a full right-hand side of its own
+            gen = torch.Generator(device='cuda')
+            gen.manual_seed(100 + B)
+            if kind == 't':
+                dmaps = [dmap] + [dmap + torch.randn(dmap.shape, generator=gen, dtype=torch.float64, device='cuda') * (nlev_t / vamin) for _ in range(B - 1)]
+            else:
+                dmaps = [dmap] + [[c + torch.randn(c.shape, generator=gen, dtype=torch.float64, device='cuda') * (nlev_p / vamin) for c in dmap] for _ in range(B - 1)]
+            f.apply_ivf_batch(dmaps)  # warm-up: graph capture of the nested stages for this block size
+            torch.cuda.synchronize()
+            t0 = time.time()
+            out = f.apply_ivf_batch(dmaps)
+            torch.cuda.synchronize()
+            dtb = time.time() - t0
+            first = out[0] if kind == 't' else out[0][0]
+            res.setdefault('batched', {}).setdefault(kind, {})[str(B)] = {
+                'seconds': dtb, 'ms_per_block_iter': 1e3 * dtb / iters, 'iters_per_s_per_sim': B * iters / dtb,
+                'speedup_per_sim_vs_B1': (B * iters / dtb) / (iters / dt)}
+            del out, dmaps, first
+            if verbose:
+                print(kind, 'B =', B, json.dumps(res['batched'][kind][str(B)]), flush=True)
     if joint:
         pcf = os.path.join(tmp, 'dense_tp.pk')
         cl_tp = {k: cl[k] for k in ['tt', 'ee', 'bb', 'te']}
@@ -135,6 +161,14 @@ def _run(nside, lmax, iters, kinds, joint, verbose, peak_tflops):
             floor_ms = 1e3 * (FLOP_PER_ITER_2048['t'] + FLOP_PER_ITER_2048['p']) / peak_tflops / 1e12
             res['tp']['fp64_floor_ms_per_iter'] = floor_ms
             res['tp']['frac_of_fp64_floor'] = floor_ms / res['tp']['ms_per_iter']
+        for B in batches:
+            bt, bp = res.get('batched', {}).get('t', {}).get(str(B)), res.get('batched', {}).get('p', {}).get(str(B))
+            if bt and bp:
+                tot_b = bt['seconds'] + bp['seconds']
+                e = {'iters_per_s_per_sim': B * iters / tot_b, 'speedup_per_sim_vs_B1': (B * iters / tot_b) / (iters / tot)}
+                if nside == 2048 and lmax == 2048:
+                    e['frac_of_fp64_floor'] = floor_ms / (1e3 * tot_b / iters / B)
+                res['batched'].setdefault('tp', {})[str(B)] = e
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
     return res
@@ -145,8 +179,10 @@ if __name__ == '__main__':
     lmax = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 100
     only = os.environ.get('CG_BENCH_ONLY', 'tp')
-    r = run(nside, lmax, iters, kinds=[k for k in ('t', 'p') if k in only], joint=os.environ.get('CG_BENCH_JOINT', '0') == '1', verbose=True)
+    batches = [int(b) for b in os.environ.get('CG_BENCH_BATCHES', '2,4,8').split(',') if b.strip()]
+    r = run(nside, lmax, iters, kinds=[k for k in ('t', 'p') if k in only], joint=os.environ.get('CG_BENCH_JOINT', '0') == '1', verbose=True,
+            batches=batches)
     print(json.dumps({'metric': 'CG-iter/sec (cinv_t + cinv_p, nside=%d lmax=%d, masked fsky=%.2f, %d iterations)' % (nside, lmax, r['fsky'], iters),
                       'T_iters_per_s': r.get('t', {}).get('iters_per_s'), 'P_iters_per_s': r.get('p', {}).get('iters_per_s'),
                       'TP_iters_per_s': r.get('tp', {}).get('iters_per_s'), 'TP_frac_of_fp64_floor': r.get('tp', {}).get('frac_of_fp64_floor'),
-                      'TP_joint_iters_per_s': r.get('tp_joint', {}).get('iters_per_s')}))
+                      'TP_joint_iters_per_s': r.get('tp_joint', {}).get('iters_per_s'), 'batched': r.get('batched')}))
