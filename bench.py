@@ -106,6 +106,7 @@ def parse(argv=None):
     ap.add_argument('--cpu-seconds', type=float, default=75.0, help='budget of the CPU baseline (warm-up and all repetitions together)')
     ap.add_argument('--no-cg', action='store_true', help='skip the CG block (BASELINE config 4)')
     ap.add_argument('--cg-iters', type=int, default=100)
+    ap.add_argument('--cg-batches', type=str, default='2,4,8', help='block sizes B > 1 of the CG block (simulations filtered together); empty: none')
     return ap.parse_args(argv)
 
 
@@ -480,7 +481,8 @@ def run_rank(args):
             try:
                 sys.path.insert(0, os.path.join(ROOT, 'tools'))
                 import cg_bench
-                cg = cg_bench.run(nside, lmax, args.cg_iters, kinds=('t', 'p'), peak_tflops=FP64_PEAK_TFLOPS)
+                cg = cg_bench.run(nside, lmax, args.cg_iters, kinds=('t', 'p'), peak_tflops=FP64_PEAK_TFLOPS,
+                                  batches=[int(b) for b in args.cg_batches.split(',') if b.strip()])
                 res['cg'] = {'metric': 'CG-iter/sec: qcinv multigrid Wiener filter, cinv_t + cinv_p, nside=%d lmax=%d, masked sky fsky=%.2f, '
                                        '%d top-level iterations each (eps_min=0), default chains, dense preconditioner cached outside the timed region'
                                        % (nside, lmax, cg['fsky'], args.cg_iters),
@@ -489,7 +491,11 @@ def run_rank(args):
                              'fp64_floor_ms_per_iter': cg['tp'].get('fp64_floor_ms_per_iter'),
                              'frac_of_fp64_floor': cg['tp'].get('frac_of_fp64_floor'),
                              'dense_setup_s': {'t': cg['t']['first_call_incl_dense_setup_s'], 'p': cg['p']['first_call_incl_dense_setup_s']},
-                             'residual_first_last': {'t': cg['t']['eps_first_last'], 'p': cg['p']['eps_first_last']}}
+                             'residual_first_last': {'t': cg['t']['eps_first_last'], 'p': cg['p']['eps_first_last']},
+                             # B simulations filtered in ONE block solve (cinv_*.apply_ivf_batch): every launch carries all B, each with
+                             # its own step lengths; iterations/s per simulation = B x iterations/s of the block solve
+                             'block_solves': {'note': 'B right-hand sides (simulations sharing the noise model) per solve; per-simulation rates; '
+                                                      'B = 1 is the figures above', 'per_B': cg.get('batched')}}
             except Exception as e:  # a report, never a reason to lose the QE number
                 res['cg'] = {'error': repr(e)}
         if not args.no_cpu_baseline:

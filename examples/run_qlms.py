@@ -44,7 +44,15 @@ def main():
             jobs += [(idx, lab) for idx in range(args.imin, args.imax + 1)]
             if args.ds and args.imin >= 0:
                 jobs += [(-1, lab)]
-    for i, (idx, lab) in enumerate(jobs[mpi.rank::mpi.size]):
+    mine = jobs[mpi.rank::mpi.size]
+    if hasattr(par.ivfs, 'filter_sims'):  # conjugate-gradient filters: this rank's simulations in block solves (several per solve)
+        for lab in ('t', 'p'):
+            idxs = [idx for idx, l in mine if l == lab]
+            if idxs:
+                print('rank %s filtering sims %s %s in block solves' % (mpi.rank, idxs, lab))
+                par.ivfs.filter_sims(idxs, fields=lab)
+        mine = []
+    for i, (idx, lab) in enumerate(mine):
         print('rank %s filtering sim %s %s, job %s in %s' % (mpi.rank, idx, lab, i, len(jobs[mpi.rank::mpi.size])))
         if lab == 't':
             par.ivfs.get_sim_tlm(idx)

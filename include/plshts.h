@@ -52,6 +52,24 @@ int64_t pl_plan_npix(const pl_plan *plan);
 int64_t pl_plan_nalm(const pl_plan *plan);
 int64_t pl_plan_bytes(const pl_plan *plan); /* device bytes held by the plan */
 
+/* One transform over several GPUs ("m-blocks shard across the GPUs", BASELINE.json north_star; the reference's only parallelism
+ * inside a transform is the third-party library's threads, shts.py:10).  Shard `rank` of `nranks`:
+ *   - the Legendre-stage calls on this plan (pl_legendre_synth / _anal and the transforms built on them) cover the m-groups
+ *     rank, rank + nranks, ... -- an m-group is 4 consecutive orders m, the unit of one workgroup;
+ *   - its ring-FFT calls (pl_phase2map / pl_map2phase) cover the ring pairs rank, rank + nranks, ... (interleaved: every ring-length
+ *     class stays balanced), i.e. read / write only the pixels of those rings;
+ *   - between the stages the ranks exchange phase slices: pl_phase_pack gathers the sub-grid (ring pairs pair0 + j pair_stride,
+ *     m-groups mg0 + k mg_stride) of a phase array into the contiguous buffer [j][component][k][4 orders][4 doubles] that one rank
+ *     sends another, pl_phase_unpack scatters a received buffer (one all-to-all per transform: plancklens_amd/parallel.py);
+ *   - pl_alm_keep_mgroups zeroes the alm entries outside a rank's m-groups, so that the analysis results of the ranks add up
+ *     exactly (every entry is non-zero on one rank only).
+ * Results equal the single-plan transform up to the order of the ring-group partial sums of the analysis (1e-15 relative). */
+int pl_plan_create_shard(int nside, int lmax, int rank, int nranks, pl_plan **plan);
+int pl_phase_pack(pl_plan *plan, int ncomp, const double *phase, double *buf, int pair0, int pair_stride, int mg0, int mg_stride, void *stream);
+int pl_phase_unpack(pl_plan *plan, int ncomp, double *phase, const double *buf, int pair0, int pair_stride, int mg0, int mg_stride, void *stream);
+int64_t pl_phase_pack_doubles(const pl_plan *plan, int ncomp, int pair0, int pair_stride, int mg0, int mg_stride);
+int pl_alm_keep_mgroups(int lmax, int nb, double *alm, int mg0, int mg_stride, void *stream);
+
 /* shts.alm2map (shts.py:12-15) / shts.alm2map_spin (shts.py:22-24).  spin = 0: alm -> map;
  * spin = 1,2,3: [G|C] -> [Q|U].  If fl != NULL (length lmax + 1) the alm are multiplied by fl_l on the
  * fly (hp.almxfl fused; qest.py:463,502-503,592).  Inputs are not modified. */

@@ -53,6 +53,8 @@ void launch_qe_lens_product(int64_t n, const double *tmap, const double *gt, con
 void launch_map_cmul(int64_t n, const double *ar, const double *ai, double s1, const double *br, const double *bi, double s2,
                      double sign, double *outr, double *outi, int accumulate, hipStream_t st);
 void launch_fma_peak(int mode, int iters, double *out, int nblk, hipStream_t st);
+void launch_phase_pack(const DevPlan &P, int ncomp, double *phase, double *buf, int pair0, int pstride, int mg0, int mgstride, bool unpack, hipStream_t st);
+void launch_alm_keep_mgroups(int lmax, double *alm, int mg0, int mgstride, int nb, hipStream_t st);
 }  // namespace plshts
 
 using namespace plshts;
@@ -189,7 +191,21 @@ int pl_device_count(void)
     return n;
 }
 
-int pl_plan_create(int nside, int lmax, pl_plan **out)
+static int plan_create_impl(int nside, int lmax, int rank, int nranks, pl_plan **out);
+
+int pl_plan_create(int nside, int lmax, pl_plan **out) { return plan_create_impl(nside, lmax, 0, 1, out); }
+
+// A plan for one of `nranks` shards of a single transform (north_star: "m-blocks shard across the GPUs"; SURVEY.md 8(e), secondary):
+// its Legendre launches cover the m-groups rank, rank + nranks, ... (4 consecutive orders each), its ring-FFT launches the ring
+// pairs rank, rank + nranks, ...  Between the two stages the ranks exchange phase slices (pl_phase_pack / pl_phase_unpack around
+// one all-to-all, plancklens_amd/parallel.py); tables and workspaces are those of an ordinary plan.
+int pl_plan_create_shard(int nside, int lmax, int rank, int nranks, pl_plan **out)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("pl_plan_create_shard: rank out of range");
+    return plan_create_impl(nside, lmax, rank, nranks, out);
+}
+
+static int plan_create_impl(int nside, int lmax, int rank, int nranks, pl_plan **out)
 {
     if (!out) return fail("null plan pointer");
     *out = nullptr;
@@ -202,6 +218,7 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
     P.npix = 12LL * nside * nside;
     P.nalm = (int64_t)(lmax + 1) * (lmax + 2) / 2;
     P.mstride = (lmax + 1 + 3) / 4 * 4;
+    P.mg0 = rank; P.mgstride = nranks;
     RingGeom g;
     build_geometry(nside, g);
     P.npairs = g.npairs;
@@ -261,6 +278,7 @@ int pl_plan_create(int nside, int lmax, pl_plan **out)
     // direct class: left to the generic kernel those few long rings size its workgroups and LDS for every short polar ring.)
     std::vector<int> listA[kFftClasses], dirA[kFftClasses], splA[kFftClasses], legacyA;
     for (int i = g.npairs - 1; i >= 0; --i) {  // longest rings first
+        if (i % nranks != rank) continue;  // shard plan: the ring pairs of this rank only (interleaved: every class stays balanced)
         const int q = g.nphi[i] / 4;
         const bool direct = (q & (q - 1)) == 0;
         if (clsA[q] >= 0) (direct ? dirA : (splitA[q] ? splA : listA))[clsA[q]].push_back(i); else legacyA.push_back(i);
@@ -364,6 +382,45 @@ int pl_plan_destroy(pl_plan *p)
     if (p->h_map) (void)hipFree(p->h_map);
     if (p->h_fl) (void)hipFree(p->h_fl);
     delete p;
+    return 0;
+}
+
+// The sub-grid (ring pairs pair0, pair0 + pair_stride, ...; m-groups mg0, mg0 + mg_stride, ...) of a phase array of ncomp components,
+// as one contiguous buffer [pair][component][m-group][4 orders][4 doubles] -- what one rank sends another between the Legendre and
+// ring-FFT stages of a sharded transform -- and back.
+int pl_phase_pack(pl_plan *p, int ncomp, const double *phase, double *buf, int pair0, int pair_stride, int mg0, int mg_stride, void *stream)
+{
+    if (!p || !phase || !buf || ncomp < 1 || pair_stride < 1 || mg_stride < 1 || pair0 < 0 || mg0 < 0) return fail("pl_phase_pack: bad arguments");
+    launch_phase_pack(p->P, ncomp, const_cast<double *>(phase), buf, pair0, pair_stride, mg0, mg_stride, false, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_phase_unpack(pl_plan *p, int ncomp, double *phase, const double *buf, int pair0, int pair_stride, int mg0, int mg_stride, void *stream)
+{
+    if (!p || !phase || !buf || ncomp < 1 || pair_stride < 1 || mg_stride < 1 || pair0 < 0 || mg0 < 0) return fail("pl_phase_unpack: bad arguments");
+    launch_phase_pack(p->P, ncomp, phase, const_cast<double *>(buf), pair0, pair_stride, mg0, mg_stride, true, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// doubles of the pl_phase_pack buffer for that sub-grid
+int64_t pl_phase_pack_doubles(const pl_plan *p, int ncomp, int pair0, int pair_stride, int mg0, int mg_stride)
+{
+    if (!p || pair_stride < 1 || mg_stride < 1) return 0;
+    const int64_t np = p->P.npairs > pair0 ? (p->P.npairs - pair0 + pair_stride - 1) / pair_stride : 0;
+    const int nmg_all = (p->P.mmax + 4) / 4;
+    const int64_t nm = nmg_all > mg0 ? (nmg_all - mg0 + mg_stride - 1) / mg_stride : 0;
+    return np * ncomp * nm * 16;
+}
+
+// alm (nb arrays back to back) with every entry outside the m-groups mg0, mg0 + mg_stride, ... set to zero: the share of one rank of
+// a sharded analysis, ready for a sum over ranks (each entry is non-zero on exactly one rank: the sum is exact)
+int pl_alm_keep_mgroups(int lmax, int nb, double *alm, int mg0, int mg_stride, void *stream)
+{
+    if (lmax < 0 || nb < 1 || !alm || mg0 < 0 || mg_stride < 1) return fail("pl_alm_keep_mgroups: bad arguments");
+    launch_alm_keep_mgroups(lmax, alm, mg0, mg_stride, nb, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

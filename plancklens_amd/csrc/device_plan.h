@@ -29,6 +29,9 @@ struct DevPlan {
     const double *seed0;     // [mmax + 1]
     const int *mlim0;        // [npairs]
     int64_t nent0;           // total spin-0 entries
+    // m-block shard (pl_plan_create_shard): the Legendre launches of this plan cover the m-groups mg0, mg0 + mgstride, ... only
+    // (an m-group = 4 consecutive orders, the unit of a workgroup); 0 / 1 on an ordinary plan
+    int mg0, mgstride;
 };
 
 }  // namespace plshts

@@ -6,6 +6,8 @@
 
 #include <cstdint>
 
+#include "device_plan.h"
+
 namespace plshts {
 
 // Batches (block vectors of the conjugate-gradient filter: several right-hand sides through every launch): an array argument of a
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(kDotThreads) void k_cg_fused(CgFused f, double *__r
             dn = den ? dot_parts_sum(den) : dot_parts_sum(parts1);
         }
         cs = num * (1.0 / dn);
-        if (active) cs *= active[bq];
+        if (active && active[bq] == 0.0) cs = 0.0;  // a frozen entry stands still whatever its products are (0 / 0 for a zero right-hand side)
     }
     __syncthreads();
     const double c1 = sign1 * cs, c2 = sign2 * cs;  // sign = +-1: same value as k_axpy_dev's sign * num * (1 / den)
@@ -396,9 +398,95 @@ __global__ __launch_bounds__(kDotThreads) void k_cg_fused(CgFused f, double *__r
 //   pass 1: t <- n_inv t and the per-workgroup partial sums of c_k = sum_i P_ki t_i;  pass 2: t_i -= sum_k R_ki c_k.
 // The partial sums are added in index order by every workgroup of pass 2: bit-reproducible, no atomics.
 constexpr int kProjParts = 256, kProjMaxModes = 16;
+constexpr int kFuseModesB = 4;  // block-vector kernels below: monopole + dipole (more modes: one launch set per map)
 // NT threads per workgroup, gridDim.x = nparts <= kProjParts workgroups: one partial sum per workgroup and mode.  Small maps (the
 // coarse multigrid levels, where this pair of kernels runs dozens of times per CG iteration) take fewer, smaller workgroups:
 // the work is a few microseconds and the cost is the launch and the reduction tail.
+// Block vectors: up to kProjChunk maps per workgroup pass -- the template rows (shared by the batch) are read once for all of them.
+// Every map's sums are formed exactly as the one-map kernel forms them (same pixels per thread, same order): bit-identical.
+constexpr int kProjChunk = 4;
+template <int NT>
+__global__ __launch_bounds__(NT) void k_tproj_coeffs_b(int64_t n, int nmodes, int nb, double *__restrict__ t_, const double *__restrict__ n_inv,
+                                                       const double *__restrict__ pm, double *__restrict__ parts_)
+{
+    __shared__ double red[kProjChunk][kFuseModesB][NT / 64];
+    const int b0 = blockIdx.y * kProjChunk, nbc = min(kProjChunk, nb - b0);
+    double acc[kProjChunk][kFuseModesB];
+#pragma unroll
+    for (int b = 0; b < kProjChunk; ++b)
+#pragma unroll
+        for (int k = 0; k < kFuseModesB; ++k) acc[b][k] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        double p[kFuseModesB];
+#pragma unroll
+        for (int k = 0; k < kFuseModesB; ++k) p[k] = k < nmodes ? pm[(int64_t)k * n + i] : 0.0;
+        const double w = n_inv ? n_inv[i] : 1.0;
+#pragma unroll
+        for (int b = 0; b < kProjChunk; ++b) {
+            if (b < nbc) {
+                double *tb = t_ + (int64_t)(b0 + b) * n;
+                double u = tb[i];
+                if (n_inv) { u *= w; tb[i] = u; }
+#pragma unroll
+                for (int k = 0; k < kFuseModesB; ++k)
+                    if (k < nmodes) acc[b][k] = fma(p[k], u, acc[b][k]);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int b = 0; b < kProjChunk; ++b)
+#pragma unroll
+        for (int k = 0; k < kFuseModesB; ++k) {
+            if (b < nbc && k < nmodes) {  // wave-uniform
+                double v = acc[b][k];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                if (lane == 0) red[b][k][wave] = v;
+            }
+        }
+    __syncthreads();
+    if ((int)threadIdx.x < nmodes * nbc) {
+        const int b = threadIdx.x / nmodes, k = threadIdx.x % nmodes;
+        double v = 0.0;
+        for (int w = 0; w < NT / 64; ++w) v += red[b][k][w];
+        parts_[(int64_t)(b0 + b) * (kProjMaxModes * kProjParts) + k * kProjParts + blockIdx.x] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_tproj_apply_b(int64_t n, int nmodes, int nparts, int nb, double *__restrict__ t_, const double *__restrict__ rm,
+                                                       const double *__restrict__ parts_)
+{
+    __shared__ double c[kProjChunk][kFuseModesB];
+    const int b0 = blockIdx.y * kProjChunk, nbc = min(kProjChunk, nb - b0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int q = wave; q < nmodes * nbc; q += 4) {
+        const int b = q / nmodes, k = q % nmodes;
+        const double *parts = parts_ + (int64_t)(b0 + b) * (kProjMaxModes * kProjParts);
+        double v = 0.0;
+        for (int j = lane; j < nparts; j += 64) v += parts[k * kProjParts + j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) c[b][k] = v;
+    }
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double r[kFuseModesB];
+#pragma unroll
+        for (int k = 0; k < kFuseModesB; ++k) r[k] = k < nmodes ? rm[(int64_t)k * n + i] : 0.0;
+#pragma unroll
+        for (int b = 0; b < kProjChunk; ++b) {
+            if (b < nbc) {
+                double *tb = t_ + (int64_t)(b0 + b) * n;
+                double v = tb[i];
+#pragma unroll
+                for (int k = 0; k < kFuseModesB; ++k)
+                    if (k < nmodes) v = fma(-r[k], c[b][k], v);
+                tb[i] = v;
+            }
+        }
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void k_tproj_coeffs(int64_t n, int nmodes, double *__restrict__ t_, const double *__restrict__ n_inv,
                                                      const double *__restrict__ pm, double *__restrict__ parts_)
@@ -605,8 +693,51 @@ __global__ void k_almxfl_add(int lmax, const double2 *a_, const double2 *__restr
     }
 }
 
+// ---- m-block sharding of one transform: phase slices between the Legendre stage (sharded by m-group) and the ring FFTs (by ring pair) ----
+// buf [j][component][k][16 doubles] <-> phase [pair0 + j pstride][component][4 (mg0 + k mgstride) ... + 3][4]; one 128-byte piece per
+// (pair, component, m-group), 8 lanes of 16 bytes each
+__global__ void k_phase_pack(DevPlan P, int ncomp, double *__restrict__ phase, double *__restrict__ buf, int pair0, int pstride, int mg0, int mgstride,
+                             int nsel, int nmsel, int unpack)
+{
+    const int64_t npieces = (int64_t)nsel * ncomp * nmsel;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npieces * 8; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t piece = t >> 3;
+        const int part = (int)(t & 7);
+        const int k = (int)(piece % nmsel);
+        const int c = (int)((piece / nmsel) % ncomp);
+        const int j = (int)(piece / ((int64_t)nmsel * ncomp));
+        const int ip = pair0 + j * pstride, mg = mg0 + k * mgstride;
+        double2 *g = reinterpret_cast<double2 *>(phase + (((int64_t)ip * ncomp + c) * P.mstride + 4 * mg) * 4) + part;
+        double2 *b = reinterpret_cast<double2 *>(buf + piece * 16) + part;
+        if (unpack) *g = *b; else *b = *g;
+    }
+}
+
+__global__ void k_alm_keep_mgroups(int lmax, double2 *__restrict__ alm_, int mg0, int mgstride)
+{
+    double2 *__restrict__ alm = alm_ + blockIdx.z * alm_count(lmax);
+    const int m = blockIdx.y;
+    const int mg = m >> 2;
+    if (mg >= mg0 && (mg - mg0) % mgstride == 0) return;
+    const int64_t base = (int64_t)m * (2 * lmax + 1 - m) / 2;
+    for (int l = m + blockIdx.x * blockDim.x + threadIdx.x; l <= lmax; l += gridDim.x * blockDim.x) alm[base + l] = make_double2(0., 0.);
+}
+
 static inline int nblocks(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
+void launch_phase_pack(const DevPlan &P, int ncomp, double *phase, double *buf, int pair0, int pstride, int mg0, int mgstride, bool unpack, hipStream_t st)
+{
+    const int nsel = P.npairs > pair0 ? (P.npairs - pair0 + pstride - 1) / pstride : 0;
+    const int nmg_all = (P.mmax + 4) / 4;
+    const int nmsel = nmg_all > mg0 ? (nmg_all - mg0 + mgstride - 1) / mgstride : 0;
+    const int64_t n = (int64_t)nsel * ncomp * nmsel * 8;
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_phase_pack, dim3(nblocks(n)), dim3(256), 0, st, P, ncomp, phase, buf, pair0, pstride, mg0, mgstride, nsel, nmsel, unpack ? 1 : 0);
+}
+void launch_alm_keep_mgroups(int lmax, double *alm, int mg0, int mgstride, int nb, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_alm_keep_mgroups, dim3(4, lmax + 1, nb), dim3(256), 0, st, lmax, reinterpret_cast<double2 *>(alm), mg0, mgstride);
+}
 void launch_almxfl(int lmax, const double *in, const double *fl, int nfl, double *out, hipStream_t st, int nb)
 {
     hipLaunchKernelGGL(k_almxfl, dim3(4, lmax + 1, nb), dim3(256), 0, st, lmax, reinterpret_cast<const double2 *>(in), fl, nfl,
@@ -662,6 +793,20 @@ void launch_cg_fused(int nf, const int *lmax, int lmin, const double *const *a, 
 void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st,
                              int nb)
 {
+    if (nb > 1 && nmodes <= kFuseModesB) {  // block vectors: the template rows read once per chunk of kProjChunk maps
+        const int nchunk = (nb + kProjChunk - 1) / kProjChunk;
+        if (n >= (int64_t)kProjParts * 4096) {
+            hipLaunchKernelGGL(k_tproj_coeffs_b<1024>, dim3(kProjParts, nchunk), dim3(1024), 0, st, n, nmodes, nb, t, n_inv, pm, parts);
+            hipLaunchKernelGGL(k_tproj_apply_b, dim3(nblocks(n), nchunk), dim3(256), 0, st, n, nmodes, kProjParts, nb, t, rm, parts);
+        } else {
+            int nparts = (int)((n + 2047) / 2048);
+            if (nparts < 1) nparts = 1;
+            if (nparts > kProjParts) nparts = kProjParts;
+            hipLaunchKernelGGL(k_tproj_coeffs_b<256>, dim3(nparts, nchunk), dim3(256), 0, st, n, nmodes, nb, t, n_inv, pm, parts);
+            hipLaunchKernelGGL(k_tproj_apply_b, dim3(nblocks(n), nchunk), dim3(256), 0, st, n, nmodes, nparts, nb, t, rm, parts);
+        }
+        return;
+    }
     if (n >= (int64_t)kProjParts * 4096) {  // fine grids: 256 workgroups of 1024 threads
         hipLaunchKernelGGL(k_tproj_coeffs<1024>, dim3(kProjParts, nb), dim3(1024), 0, st, n, nmodes, t, n_inv, pm, parts);
         hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n), nb), dim3(256), 0, st, n, nmodes, kProjParts, t, rm, parts);

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
     const int ngroups = (P.npairs + RG - 1) / RG;
     // workgroups are dealt round-robin over the 8 XCDs: rotate the ring group with the m group so that every XCD
     // sees all latitudes (polar groups are light, equatorial ones heavy) -- otherwise the XCDs finish unevenly
-    const int mg = blockIdx.x / ngroups, g = (blockIdx.x % ngroups + mg) % ngroups;
+    const int mg = P.mg0 + P.mgstride * (blockIdx.x / ngroups), g = (blockIdx.x % ngroups + mg) % ngroups;  // (m-group shard of the plan: device_plan.h)
     const int last = min(P.npairs - 1, g * RG + RG - 1);
     if (P.mlim0[last] < 4 * mg) return;  // every ring of the group is pruned for every m of the group
     const int m = 4 * mg + wave;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
     const int ngroups = (P.npairs + RG - 1) / RG;
     // workgroups are dealt round-robin over the 8 XCDs: rotate the ring group with the m group so that every XCD
     // sees all latitudes (polar groups are light, equatorial ones heavy) -- otherwise the XCDs finish unevenly
-    const int mg = blockIdx.x / ngroups, g = (blockIdx.x % ngroups + mg) % ngroups;
+    const int mg = P.mg0 + P.mgstride * (blockIdx.x / ngroups), g = (blockIdx.x % ngroups + mg) % ngroups;  // (m-group shard of the plan: device_plan.h)
     const int last = min(P.npairs - 1, g * RG + RG - 1);
     if (S.mlim[last] < 4 * mg) return;
     const int m = 4 * mg + wave;
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
     double *__restrict__ partial = partial_ + (int64_t)blockIdx.y * ngroups * P.nent0 * 4;
     // workgroups are dealt round-robin over the 8 XCDs: rotate the ring group with the m group so that every XCD
     // sees all latitudes (polar groups are light, equatorial ones heavy) -- otherwise the XCDs finish unevenly
-    const int mg = blockIdx.x / ngroups, g = (blockIdx.x % ngroups + mg) % ngroups;
+    const int mg = P.mg0 + P.mgstride * (blockIdx.x / ngroups), g = (blockIdx.x % ngroups + mg) % ngroups;  // (m-group shard of the plan: device_plan.h)
     const int last = min(P.npairs - 1, g * RG + RG - 1);
     if (P.mlim0[last] < 4 * mg) return;
     const int m = 4 * mg + wave;
@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(256) PL_ANALS_ATTR void k_leg_anals(DevPlan P, DevS
     double *__restrict__ partial = partial_ + (int64_t)blockIdx.y * ngroups * nent * 4;
     // workgroups are dealt round-robin over the 8 XCDs: rotate the ring group with the m group so that every XCD
     // sees all latitudes (polar groups are light, equatorial ones heavy) -- otherwise the XCDs finish unevenly
-    const int mg = blockIdx.x / ngroups, g = (blockIdx.x % ngroups + mg) % ngroups;
+    const int mg = P.mg0 + P.mgstride * (blockIdx.x / ngroups), g = (blockIdx.x % ngroups + mg) % ngroups;  // (m-group shard of the plan: device_plan.h)
     const int last = min(P.npairs - 1, g * RG + RG - 1);
     if (S.mlim[last] < 4 * mg) return;
     const int m = 4 * mg + wave;
@@ -1290,12 +1290,18 @@ static int env_int(const char *name, int dflt)
 // Ring pairs per lane (R): more rings per lane amortise the per-l overhead (coefficient fetch, cross-lane reduce) but
 // coarsen the polar pruning and shrink the grid.  The defaults are the measured optima at nside = lmax = 2048; smaller
 // transforms step R down until the grid has at least ~4 workgroups per CU.  PLSHTS_R0 / RS / R0A / RSA override.
+// m-groups (4 consecutive orders) this plan's Legendre launches cover: all of them, or every mgstride-th from mg0 on a shard plan
+static int own_mgroups(const DevPlan &P)
+{
+    const int all = (P.mmax + 4) / 4;
+    return P.mg0 >= all ? 0 : (all - P.mg0 + P.mgstride - 1) / P.mgstride;
+}
 static int pick_r(const char *env, int dflt, int rmax, const DevPlan &P)
 {
     const int e = env_int(env, 0);
     if (e >= 1 && e <= rmax) return e;
     int r = dflt;
-    const int nmg = (P.mmax + 4) / 4;
+    const int nmg = own_mgroups(P);
     while (r > 1 && (int64_t)((P.npairs + 64 * r - 1) / (64 * r)) * nmg < 1024) --r;
     return r;
 }
@@ -1303,7 +1309,7 @@ static int r0_synth(const DevPlan &P) { return pick_r("PLSHTS_R0", 3, 6, P); }
 static int rs_synth(const DevPlan &P) { return pick_r("PLSHTS_RS", 2, 4, P); }
 // (spin-0 analysis: 8 rings per lane at nside >= 4096 -- 8.31 against 8.99 ms at nside = lmax = 4096; at 2048 6 and 8 are equal, 7 is slower)
 static int r0_anal(const DevPlan &P) { return pick_r("PLSHTS_R0A", P.nside >= 4096 ? 8 : 6, 8, P); }
-static int rs_anal(const DevPlan &P) { return pick_r("PLSHTS_RSA", 4, 4, P); }
+static int rs_anal(const DevPlan &P) { return pick_r("PLSHTS_RSA", 4, 8, P); }  // (5, 6, 8: experiments, one wave per SIMD)
 
 int rings_per_group(int spin, const DevPlan &P) { return 64 * (spin == 0 ? r0_anal(P) : rs_anal(P)); }
 
@@ -1332,7 +1338,8 @@ template <int R>
 static void launch_synth0_r(const DevPlan &P, const double *prep, double *phase, hipStream_t st, int nb)
 {
     constexpr int RG = 64 * R;
-    const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
+    const int ngroups = (P.npairs + RG - 1) / RG, nmg = own_mgroups(P);
+    if (nmg == 0) return;
     hipLaunchKernelGGL(k_leg_synth0<R>, dim3(ngroups * nmg, nb), dim3(256), 0, st, P, reinterpret_cast<const double4 *>(prep), phase);
 }
 
@@ -1352,10 +1359,11 @@ template <int R, bool GONLY>
 static void launch_synths_r(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st, int nb)
 {
     constexpr int RG = 64 * R;
-    const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
+    const int ngroups = (P.npairs + RG - 1) / RG, nmg = own_mgroups(P);
     // PLSHTS_SYNTH_LDS_PAD (bytes, experiments): dynamic LDS nobody touches, to cap the workgroups per CU and leave room for the
     // ring-FFT kernels of another transform running on a second stream
     static const int pad = env_int("PLSHTS_SYNTH_LDS_PAD", 0);
+    if (nmg == 0) return;
     hipLaunchKernelGGL((k_leg_synths<R, GONLY, 0>), dim3(ngroups * nmg, nb), dim3(256), pad, st, P, S, spin,
                        reinterpret_cast<const double4 *>(prep), phase);
 }
@@ -1363,7 +1371,7 @@ static void launch_synths_r(const DevPlan &P, const DevSpinTab &S, int spin, con
 // general input (prep) + gradient-only input (prep2) on one recursion; phase entries of 16 doubles (four components)
 void launch_synths_pair(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st)
 {
-    const int ngroups1 = (P.npairs + 63) / 64, ngroups2 = (P.npairs + 127) / 128, nmg = (P.mmax + 4) / 4;
+    const int ngroups1 = (P.npairs + 63) / 64, ngroups2 = (P.npairs + 127) / 128, nmg = own_mgroups(P);
     if (rs_synth(P) == 1)
         hipLaunchKernelGGL((k_leg_synths<1, false, 1>), dim3(ngroups1 * nmg), dim3(256), 0, st, P, S, spin,
                            reinterpret_cast<const double4 *>(prep), phase, reinterpret_cast<const double4 *>(prep2));
@@ -1376,7 +1384,7 @@ void launch_synths_pair(const DevPlan &P, const DevSpinTab &S, int spin, const d
 // PLSHTS_RSB overrides the rings per lane (1 or 2)
 void launch_synths_batch2(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st)
 {
-    const int ngroups1 = (P.npairs + 63) / 64, ngroups2 = (P.npairs + 127) / 128, nmg = (P.mmax + 4) / 4;
+    const int ngroups1 = (P.npairs + 63) / 64, ngroups2 = (P.npairs + 127) / 128, nmg = own_mgroups(P);
     int r = env_int("PLSHTS_RSB", 0);
     if (r != 1 && r != 2) r = rs_synth(P) == 1 ? 1 : 2;
     if (r == 1)
@@ -1412,8 +1420,8 @@ static void launch_anal0_r(const DevPlan &P, const double *phase, double *partia
                            const double *add, const double *fl_add, int nb)
 {
     constexpr int RG = 64 * R;
-    const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
-    hipLaunchKernelGGL(k_leg_anal0<R>, dim3(ngroups * nmg, nb), dim3(256), 0, st, P, phase, partial);
+    const int ngroups = (P.npairs + RG - 1) / RG, nmg = own_mgroups(P);
+    if (nmg > 0) hipLaunchKernelGGL(k_leg_anal0<R>, dim3(ngroups * nmg, nb), dim3(256), 0, st, P, phase, partial);
     dim3 grid(4, P.mmax + 1, nb);
     hipLaunchKernelGGL(k_post0, grid, dim3(256), 0, st, P, RG, reinterpret_cast<const double4 *>(partial), fl,
                        reinterpret_cast<double2 *>(alm), reinterpret_cast<const double2 *>(add), fl_add);
@@ -1440,8 +1448,8 @@ static void launch_anals_r(const DevPlan &P, const DevSpinTab &S, int spin, int6
                            const double *flG, const double *flC, int nb)
 {
     constexpr int RG = 64 * R;
-    const int ngroups = (P.npairs + RG - 1) / RG, nmg = (P.mmax + 4) / 4;
-    hipLaunchKernelGGL(k_leg_anals<R>, dim3(ngroups * nmg, nb), dim3(256), 0, st, P, S, spin, phase, partial, nent);
+    const int ngroups = (P.npairs + RG - 1) / RG, nmg = own_mgroups(P);
+    if (nmg > 0) hipLaunchKernelGGL(k_leg_anals<R>, dim3(ngroups * nmg, nb), dim3(256), 0, st, P, S, spin, phase, partial, nent);
     dim3 grid(4, P.mmax + 1, nb);
     hipLaunchKernelGGL(k_posts, grid, dim3(256), 0, st, P, S, spin, RG, nent, reinterpret_cast<const double4 *>(partial), fl,
                        reinterpret_cast<double2 *>(almG), reinterpret_cast<double2 *>(almC), reinterpret_cast<const double2 *>(addG),
@@ -1467,6 +1475,9 @@ void launch_anals_gc(const DevPlan &P, const DevSpinTab &S, int spin, int64_t ne
     case 1: launch_anals_r<1>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
     case 2: launch_anals_r<2>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
     case 4: launch_anals_r<4>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
+    case 5: launch_anals_r<5>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
+    case 6: launch_anals_r<6>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
+    case 8: launch_anals_r<8>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
     default: launch_anals_r<3>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
     }
 }

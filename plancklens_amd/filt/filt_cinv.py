@@ -448,6 +448,37 @@ class library_cinv_sepTP(filt_simple.library_sepTP):
     def _apply_ivf_p(self, pmap, soltn=None):
         return self.cinv_p.apply_ivf(pmap, soltn=soltn)
 
+    def filter_sims(self, idxs, fields='tp', batch=None):
+        """Filters (and caches) the simulations `idxs` that are not cached yet, `batch` at a time in block solves of the CG
+        (cinv_t / cinv_p.apply_ivf_batch: every launch of a solve carries the whole block) -- what the driver's filtering phase
+        calls instead of looping over get_sim_tlm / get_sim_elm one simulation at a time (run_qlms.py:57-62).  Same cache files, same
+        alms.  batch: block size (default $PLENS_CG_BATCH or 4; 1 = one solve per simulation)."""
+        if batch is None:
+            batch = int(os.environ.get('PLENS_CG_BATCH', '4'))
+        for a in fields:
+            assert a in 'tp', a
+            names = ['t'] if a == 't' else ['e', 'b']
+            todo = [i for i in idxs if not (self.cache and all(os.path.exists(self._fn(n, i)) for n in names))
+                    and not all(n in self._dev_cache.get(i, {}) for n in names)]
+            for k in range(0, len(todo), max(1, batch)):
+                blk = todo[k:k + max(1, batch)]
+                if len(blk) == 1 or self.soltn_lib is not None:  # (starting points come one by one)
+                    for i in blk:
+                        self.get_sim_alm_dev(names[0] + 'lm', i)
+                    continue
+                if a == 't':
+                    maps = [dev.to_dev(self.sim_lib.get_sim_tmap(i), torch.float64) for i in blk]
+                    outs = [(x,) for x in self.cinv_t.apply_ivf_batch(maps)]
+                else:
+                    maps = [[dev.to_dev(m, torch.float64) for m in self.sim_lib.get_sim_pmap(i)] for i in blk]
+                    outs = self.cinv_p.apply_ivf_batch(maps)
+                for i, out in zip(blk, outs):
+                    ent = self._dev_entry(i)
+                    for n, x in zip(names, out):
+                        ent[n] = x.clone()  # (rows of the block solution: own storage, so that the block can be released)
+                        if self.cache:
+                            hp.write_alm(self._fn(n, i), dev.to_host(ent[n]), overwrite=True)
+
     def get_tmliklm(self, idx):
         return hp.almxfl(self.get_sim_tlm(idx), self.cinv_t.cl['tt'])
 

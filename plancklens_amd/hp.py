@@ -187,6 +187,13 @@ def pix2ang(nside, ipix=None):
     return th[ipix], ph[ipix]
 
 
+def pix2ring(nside, ipix=None):
+    """ring number 1 ... 4 nside - 1 (north to south) of RING pixels (all of them if ipix is None)"""
+    nphi = ring_info(nside)[2]
+    ring = np.repeat(np.arange(1, nphi.size + 1), nphi)
+    return ring if ipix is None else ring[ipix]
+
+
 def pix2vec(nside, ipix=None):
     cth, sth, nphi, phi0, ofs = ring_info(nside)
     npix = nside2npix(nside)

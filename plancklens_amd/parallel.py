@@ -92,3 +92,110 @@ def mean_field(get_qlm, idxs, like, get_pair=None, collective=True):
     if len(idxs) > 0:
         acc /= len(idxs)
     return acc
+
+
+# ---- one transform over several GPUs: Legendre stage sharded by m-group, ring FFTs by ring pair ("m-blocks") ------------
+def _all_to_all(send):
+    """send: (nranks, n) float64 tensor, row s for rank s; returns the (nranks, n) tensor of rows received (row s from rank s).
+    RCCL on device tensors; a CPU backend (gloo in the tests) is staged through the host."""
+    dist = _dist()
+    if dist is None:
+        return send
+    staged = send.is_cuda and dist.get_backend() != 'nccl'
+    src = send.cpu() if staged else send
+    out = torch.empty_like(src)
+    dist.all_to_all_single(out, src) if dist.get_backend() == 'nccl' else _all_to_all_gloo(dist, out, src)
+    return out.to(send.device) if staged else out
+
+
+def _all_to_all_gloo(dist, out, src):
+    """gloo has no all_to_all: one scatter per root (test backend only)"""
+    rank, size = dist.get_rank(), dist.get_world_size()
+    for root in range(size):
+        dist.scatter(out[root], [src[s].contiguous() for s in range(size)] if rank == root else None, src=root)
+
+
+class sharded_sht(object):
+    """alm2map / map2alm of ONE map over the ranks of the job: every rank runs the Legendre stage for its m-groups (4 orders each,
+    interleaved) and the ring FFTs for its ring pairs (interleaved), with one all-to-all of phase slices between them -- per rank
+    and transform (1 - 1 / R) of 32 B x npairs x (mmax + 1) x ncomp / R (30 MB at nside = lmax = 2048, spin 2, R = 8), against
+    8 npix x ncomp for an all-reduce of partial maps.  alm inputs are full arrays on every rank; map2alm returns the full alm on
+    every rank (sum over ranks of shares that are zero outside the rank's m-groups: exact); alm2map returns the rank's own rings
+    (`gather=False`: the other pixels are left as they are -- pixel-local products need no more) or the full map on every rank.
+    Collective calls: every rank of the job makes them in the same order.  rank / size default to the job's (helpers.mpi)."""
+
+    def __init__(self, nside, lmax, rank=None, size=None):
+        from . import shts
+        self.rank = mpi.rank if rank is None else rank
+        self.size = mpi.size if size is None else size
+        self.nside, self.lmax = nside, lmax
+        self.plan = shts.get_shard_plan(nside, lmax, self.rank, self.size)
+        self._mask = None
+
+    def _exchange(self, phase, ncomp, synth):
+        """synthesis: my m-groups of everybody's ring pairs go out, everybody's m-groups of my ring pairs come in; analysis: the reverse"""
+        from . import _lib, dev
+        L, h, R, r = _lib.lib(), self.plan.h, self.size, self.rank
+        sel_out = (lambda s: (s, R, r, R)) if synth else (lambda s: (r, R, s, R))   # (pair0, pair_stride, mg0, mg_stride) sent to rank s
+        sel_in = (lambda s: (r, R, s, R)) if synth else (lambda s: (s, R, r, R))    # ... received from rank s
+        n = max(int(L.pl_phase_pack_doubles(h, ncomp, *sel(s))) for s in range(R) for sel in (sel_out, sel_in))
+        n_all = allreduce_max(n)  # equal splits: the largest slice of any pair of ranks
+        send = torch.zeros((R, n_all), dtype=torch.float64, device=phase.device)
+        for s in range(R):
+            _lib.check(L.pl_phase_pack(h, ncomp, phase.data_ptr(), send[s].data_ptr(), *sel_out(s), dev.stream_ptr()))
+        recv = _all_to_all(send)
+        for s in range(R):
+            _lib.check(L.pl_phase_unpack(h, ncomp, phase.data_ptr(), recv[s].data_ptr(), *sel_in(s), dev.stream_ptr()))
+
+    def own_pixels(self):
+        """bool device tensor: the pixels of this rank's ring pairs"""
+        if self._mask is None:
+            from . import hp
+            ring = hp.pix2ring(self.nside)  # 1 ... 4 nside - 1
+            pair = np.minimum(ring, 4 * self.nside - ring) - 1
+            self._mask = torch.from_numpy(pair % self.size == self.rank).cuda()
+        return self._mask
+
+    def alm2map(self, alm, spin=0, fl=None, gather=True):
+        """alm: device tensor [nalm] (spin 0) or [2, nalm] (spin s, gradient and curl)"""
+        from . import _lib, dev, shts
+        L, h = _lib.lib(), self.plan.h
+        ncomp = 1 if spin == 0 else 2
+        a = alm.to(torch.complex128).contiguous()
+        assert a.numel() == ncomp * self.plan.nalm
+        f = shts._fl_arg(fl, self.lmax, True)
+        phase = torch.empty(self.plan.phase_doubles(spin), dtype=torch.float64, device=a.device)
+        _lib.check(L.pl_legendre_synth(h, int(spin), a.data_ptr(), shts._ptr(f), phase.data_ptr(), dev.stream_ptr()))
+        self._exchange(phase, ncomp, synth=True)
+        m = torch.zeros((ncomp, self.plan.npix) if ncomp == 2 else self.plan.npix, dtype=torch.float64, device=a.device)
+        _lib.check(L.pl_phase2map(h, int(spin), phase.data_ptr(), m.data_ptr(), dev.stream_ptr()))
+        if gather:
+            allreduce_sum(m)  # every pixel is non-zero on one rank only
+        return m
+
+    def map2alm(self, m, spin=0, fl=None):
+        """m: device tensor [npix] or [2, npix]; only the pixels of this rank's rings are read"""
+        from . import _lib, dev, shts
+        L, h = _lib.lib(), self.plan.h
+        ncomp = 1 if spin == 0 else 2
+        mm = m.to(torch.float64).contiguous()
+        assert mm.numel() == ncomp * self.plan.npix
+        f = shts._fl_arg(fl, self.lmax, True)
+        phase = torch.empty(self.plan.phase_doubles(spin), dtype=torch.float64, device=mm.device)
+        _lib.check(L.pl_map2phase(h, int(spin), mm.data_ptr(), phase.data_ptr(), dev.stream_ptr()))
+        self._exchange(phase, ncomp, synth=False)
+        alm = torch.empty((ncomp, self.plan.nalm) if ncomp == 2 else self.plan.nalm, dtype=torch.complex128, device=mm.device)
+        _lib.check(L.pl_legendre_anal(h, int(spin), phase.data_ptr(), alm.data_ptr(), shts._ptr(f), dev.stream_ptr()))
+        _lib.check(L.pl_alm_keep_mgroups(self.lmax, ncomp, alm.data_ptr(), self.rank, self.size, dev.stream_ptr()))
+        return allreduce_sum(alm)
+
+
+def allreduce_max(n):
+    dist = _dist()
+    if dist is None:
+        return int(n)
+    t = torch.tensor([int(n)], dtype=torch.int64)
+    if dist.get_backend() == 'nccl':
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())

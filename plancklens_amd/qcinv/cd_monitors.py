@@ -36,7 +36,9 @@ class monitor_basic(object):
         if np.ndim(delta) > 0:
             return self._criterion_block(iter, soltn, resid, np.asarray(delta, dtype=float))
         if self.logger is not None:
-            self.logger(iter, np.sqrt(delta / self.d0), watch=self.watch, soltn=soltn, resid=resid)
+            with np.errstate(invalid='ignore', divide='ignore'):  # (0 / 0 for an all-zero right-hand side: nan in the log, as in the reference)
+                eps = np.sqrt(np.float64(delta) / np.float64(self.d0))
+            self.logger(iter, eps, watch=self.watch, soltn=soltn, resid=resid)
         return (iter >= self.iter_max) or (delta <= self.eps_min ** 2 * self.d0)
 
     def _criterion_block(self, iter, soltn, resid, delta):
@@ -47,7 +49,9 @@ class monitor_basic(object):
             self.done = np.zeros(delta.shape, dtype=bool)
         if self.logger is not None:
             live = ~self.done if not np.all(self.done) else np.ones_like(self.done)
-            self.logger(iter, float(np.max(np.sqrt(delta[live] / d0[live]))), watch=self.watch, soltn=soltn, resid=resid)
+            with np.errstate(invalid='ignore', divide='ignore'):  # (an all-zero right-hand side has d0 = 0)
+                eps = np.sqrt(delta[live] / d0[live])
+            self.logger(iter, float(np.nanmax(eps)) if np.any(np.isfinite(eps)) else 0., watch=self.watch, soltn=soltn, resid=resid)
         newly = (delta <= self.eps_min ** 2 * d0) & ~self.done
         if np.any(newly):
             self.done |= newly

@@ -27,12 +27,17 @@ _PLANS = {}
 class Plan(object):
     """One (nside, lmax) plan of the HIP engine (ring geometry, recursion and FFT tables, workspaces)."""
 
-    def __init__(self, nside, lmax):
+    def __init__(self, nside, lmax, shard=None):
+        """shard = (rank, nranks): the plan of one rank of a transform sharded by m-group / ring pair (pl_plan_create_shard)"""
         L = _lib.lib()
         if _lib.device_count() < 1:
             raise RuntimeError('no HIP device visible: plancklens_amd.shts has no CPU path')
         h = ctypes.c_void_p()
-        _lib.check(L.pl_plan_create(int(nside), int(lmax), ctypes.byref(h)))
+        if shard is None:
+            _lib.check(L.pl_plan_create(int(nside), int(lmax), ctypes.byref(h)))
+        else:
+            _lib.check(L.pl_plan_create_shard(int(nside), int(lmax), int(shard[0]), int(shard[1]), ctypes.byref(h)))
+        self.shard = shard
         self.h = h
         self.nside, self.lmax = int(nside), int(lmax)
         self.npix = int(L.pl_plan_npix(h))
@@ -102,6 +107,13 @@ def get_plan(nside, lmax):
     key = _plan_key(nside, lmax)
     if key not in _PLANS:
         _PLANS[key] = Plan(key[0], key[1])
+    return _PLANS[key]
+
+
+def get_shard_plan(nside, lmax, rank, nranks):
+    key = _plan_key(nside, lmax) + ('shard', int(rank), int(nranks))
+    if key not in _PLANS:
+        _PLANS[key] = Plan(nside, lmax, shard=(int(rank), int(nranks)))
     return _PLANS[key]
 
 
