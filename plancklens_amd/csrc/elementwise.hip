@@ -371,8 +371,10 @@ __global__ __launch_bounds__(kDotThreads) void k_cg_fused(CgFused f, double *__r
             dn = den ? dot_parts_sum(den) : dot_parts_sum(parts1);
         }
         cs = num * (1.0 / dn);
-        if (active && active[bq] == 0.0) cs = 0.0;  // a frozen entry stands still whatever its products are (0 / 0 for a zero right-hand side)
     }
+    // a frozen entry stands still whatever its products and directions are (0 / 0 and NaN directions for an all-zero right-hand
+    // side: 0 x NaN would still be NaN, so its vectors are not touched at all)
+    if (active && active[bq] == 0.0) return;
     __syncthreads();
     const double c1 = sign1 * cs, c2 = sign2 * cs;  // sign = +-1: same value as k_axpy_dev's sign * num * (1 / den)
     for (int k = 0; k < f.nf; ++k) {

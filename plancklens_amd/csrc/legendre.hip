@@ -1309,7 +1309,7 @@ static int r0_synth(const DevPlan &P) { return pick_r("PLSHTS_R0", 3, 6, P); }
 static int rs_synth(const DevPlan &P) { return pick_r("PLSHTS_RS", 2, 4, P); }
 // (spin-0 analysis: 8 rings per lane at nside >= 4096 -- 8.31 against 8.99 ms at nside = lmax = 4096; at 2048 6 and 8 are equal, 7 is slower)
 static int r0_anal(const DevPlan &P) { return pick_r("PLSHTS_R0A", P.nside >= 4096 ? 8 : 6, 8, P); }
-static int rs_anal(const DevPlan &P) { return pick_r("PLSHTS_RSA", 4, 8, P); }  // (5, 6, 8: experiments, one wave per SIMD)
+static int rs_anal(const DevPlan &P) { return pick_r("PLSHTS_RSA", 4, 4, P); }  // (5, 6, 8 rings per lane -- one wave per SIMD -- measured 5.30 / 6.27 / 10.0 ms against 4.53 ms: round 3)
 
 int rings_per_group(int spin, const DevPlan &P) { return 64 * (spin == 0 ? r0_anal(P) : rs_anal(P)); }
 
@@ -1475,9 +1475,6 @@ void launch_anals_gc(const DevPlan &P, const DevSpinTab &S, int spin, int64_t ne
     case 1: launch_anals_r<1>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
     case 2: launch_anals_r<2>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
     case 4: launch_anals_r<4>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
-    case 5: launch_anals_r<5>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
-    case 6: launch_anals_r<6>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
-    case 8: launch_anals_r<8>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
     default: launch_anals_r<3>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
     }
 }

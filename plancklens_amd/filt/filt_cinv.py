@@ -398,6 +398,19 @@ class cinv_tp(object):
         ret = [dev.almxfl(a, self.rescal_cl[f]) for a, f in zip((talm.tlm, talm.elm, talm.blm), 'teb')]
         return tuple(ret) if on_dev else tuple(dev.to_host(a) for a in ret)
 
+    def apply_ivf_batch(self, tqumaps, apply_fini=''):
+        """apply_ivf of several (T, Q, U) triplets in ONE block solve (see cinv_t.apply_ivf_batch); returns the list of (tlm, elm, blm)."""
+        tqumaps = [list(m) for m in tqumaps]
+        assert all(len(m) == 3 for m in tqumaps)
+        on_dev = isinstance(tqumaps[0][0], torch.Tensor)
+        nb, n = len(tqumaps), hp.Alm.getsize(self.lmax)
+        talm = util_alm.teblm([torch.zeros((nb, n), dtype=torch.complex128, device=dev.device()) for _ in range(3)])
+        self.chain.solve(talm, tqumaps, apply_fini=apply_fini)
+        ret = [dev.almxfl(a, self.rescal_cl[f]) for a, f in zip((talm.tlm, talm.elm, talm.blm), 'teb')]
+        if on_dev:
+            return [tuple(a[i] for a in ret) for i in range(nb)]
+        return [tuple(dev.to_host(a[i]) for a in ret) for i in range(nb)]
+
     def _ninv_hash(self):
         def h(c):  # arrays by content, nested lists element-wise, paths and scalars as they are
             if isinstance(c, (list, tuple)):

@@ -31,6 +31,12 @@ def calc_prep(maps, s_cls, n_inv_filt):
     return teblm([tlm, elm, blm])
 
 
+def calc_prep_batch(maps, s_cls, n_inv_filt):
+    """calc_prep of every (T, Q, U) triplet of the list as one block vector: teblm of [nb, nalm] tensors"""
+    preps = [calc_prep(m, s_cls, n_inv_filt) for m in maps]
+    return teblm([torch.stack([getattr(p, a) for p in preps]).contiguous() for a in ('tlm', 'elm', 'blm')])
+
+
 def apply_fini(alm, s_cls, n_inv_filt):
     """Wiener-filtered solution -> inverse-variance filtered: x <- S^-1 x (in place)."""
     lmax = len(n_inv_filt.b_transf) - 1
@@ -56,8 +62,8 @@ class dot_op(object):
         return dev.alm_dot([(alm1.tlm, alm2.tlm), (alm1.elm, alm2.elm), (alm1.blm, alm2.blm)])
 
     def dev(self, alm1, alm2):
-        """the scalar product as a 0-dim device tensor"""
-        return self.parts(alm1, alm2).sum()
+        """the scalar product as a 0-dim device tensor (block vectors: one value per entry)"""
+        return self.parts(alm1, alm2).sum(-1)
 
     @staticmethod
     def axpy(y, x, num, den, sign):
@@ -67,12 +73,13 @@ class dot_op(object):
         dev.axpy_dev(y.blm, x.blm, num, den, sign)
 
     @staticmethod
-    def step(x, d, r, q, update_r=True, one_launch=False):
+    def step(x, d, r, q, update_r=True, one_launch=False, active=None):
         """one conjugate-directions update, all fields in two launches (or one with a grid barrier): dTAd = <d, q>, delta = <d, r>,
-        x += (delta / dTAd) d and, if update_r, r -= (delta / dTAd) q; returns (dTAd, delta) as `parts` does"""
+        x += (delta / dTAd) d and, if update_r, r -= (delta / dTAd) q; returns (dTAd, delta) as `parts` does.
+        active (block vectors): 0 / 1 per entry, an entry with 0 stands still"""
         f = (lambda v: [v.tlm, v.elm, v.blm])
         return dev.cg_dot_axpy(f(d), f(q), f(x), f(d), 1.0, b2=f(r), y2=f(r) if update_r else None, x2=f(q) if update_r else None,
-                               sign2=-1.0, lmin=0, one_launch=one_launch)
+                               sign2=-1.0, lmin=0, one_launch=one_launch, active=active)
 
     @staticmethod
     def ortho(s, pq, pd, prev_dtad, one_launch=False):
@@ -81,7 +88,8 @@ class dot_op(object):
         dev.cg_dot_axpy(f(s), f(pq), f(s), f(pd), -1.0, den=prev_dtad, lmin=0, one_launch=one_launch)
 
     def __call__(self, alm1, alm2):
-        return float(self.parts(alm1, alm2).sum())
+        p = self.parts(alm1, alm2)
+        return float(p.sum()) if p.dim() == 1 else dev.to_host(p.sum(-1))  # block vectors: one value per entry
 
 
 class fwd_op(object):
@@ -292,11 +300,13 @@ class alm_filter_ninv(object):
         if self.one_call_ok(alm):  # the temperature and polarization blocks as the one-call operators of opfilt_tt / opfilt_pp
             fac = self.npix / (4. * np.pi)
             pmat, rmat = self._proj_matrices()
+            nb = alm.tlm.shape[0] if alm.tlm.dim() == 2 else 1
             ttlm = shts.cg_fwd_tt(alm.tlm, self.nside, lmax, self.n_inv[0], fl_in=self.b_transf_t, fl_out=self.b_transf_t * fac,
-                                  pmat=pmat, rmat=rmat, scratch=dev.tproj_scratch() if pmat is not None else None)
+                                  pmat=pmat, rmat=rmat, scratch=dev.tproj_scratch(nb) if pmat is not None else None)
             telm, tblm = shts.cg_fwd_pp(alm.elm, alm.blm, self.nside, lmax, self.n_inv[1], fl_in=self.b_transf_e,
                                         fl_out=self.b_transf_e * fac)
             return teblm([ttlm, telm, tblm])
+        assert not (isinstance(alm.tlm, torch.Tensor) and alm.tlm.dim() == 2), 'block vectors take the one-call operators (pl_cg_fwd_tt_b / _pp_b)'
         same_b = self.b_transf_b is self.b_transf_e or np.array_equal(self.b_transf_e, self.b_transf_b)
         tmap = alm2map(alm.tlm, self.nside, lmax=lmax, fl=self.b_transf_t)
         if same_b:

@@ -171,6 +171,32 @@ def test_reference_chains_reproduce_inside_a_block():
         assert relrms(dev.to_host(pblk.elm[i]), dev.to_host(one.elm)) < 1e-12 and relrms(dev.to_host(pblk.blm[i]), dev.to_host(one.blm)) < 1e-12, i
 
 
+def test_joint_filter_chain_reproduces_inside_a_block():
+    """opfilt_tp (teblm block vectors, the T and P blocks through pl_cg_fwd_tt_b / pl_cg_fwd_pp_b, dense.pre_op_dense_tp on blocks):
+    the reference's stored joint solution comes out of a block of two right-hand sides, equal to separate solves."""
+    import torch
+    from plancklens_amd import dev
+    from plancklens_amd.qcinv import multigrid, opfilt_tp
+    from plancklens_amd.qcinv.util_alm import teblm
+    g = np.load(GOLD)
+    lmax, nside = int(g['lmax']), int(g['nside'])
+    cl = {'tt': g['cl_tt'], 'ee': g['cl_ee'], 'bb': g['cl_bb'], 'te': g['cl_te']}
+    nf = opfilt_tp.alm_filter_ninv([g['ninv_t'], g['ninv_p']], g['transf'], b_transf_e=g['transf_e'], b_transf_b=g['transf_e'],
+                                   marge_monopole=True, marge_dipole=True)
+    mk = lambda: multigrid.multigrid_chain(opfilt_tp, _chain_descr(lmax, nside, 5, 4), cl, nf)
+    n = g['cg_tp_tlm'].size
+    other = [g['tmap'][::-1].copy(), g['umap'] * 0.5, g['qmap'][::-1].copy()]
+    blk = teblm([torch.zeros((2, n), dtype=torch.complex128, device='cuda') for _ in range(3)])
+    mk().solve(blk, [[g['tmap'], g['qmap'], g['umap']], other])
+    assert relrms(dev.to_host(blk.tlm[0]), g['cg_tp_tlm']) < 1e-8
+    assert relrms(dev.to_host(blk.elm[0]), g['cg_tp_elm']) < 1e-8 and relrms(dev.to_host(blk.blm[0]), g['cg_tp_blm']) < 1e-7
+    for i, m in enumerate(([g['tmap'], g['qmap'], g['umap']], other)):
+        one = teblm([torch.zeros(n, dtype=torch.complex128, device='cuda') for _ in range(3)])
+        mk().solve(one, m)
+        for a in ('tlm', 'elm', 'blm'):
+            assert relrms(dev.to_host(getattr(blk, a)[i]), dev.to_host(getattr(one, a))) < 1e-12, (i, a)
+
+
 def test_block_entries_stop_where_their_own_solves_stop():
     """eps_min > 0: the entries of a block converge after different numbers of iterations; each is frozen at the iterate its own
     solve returns (cd_monitors stopping rule per entry), while the others go on."""

@@ -1,6 +1,6 @@
 #!/bin/bash
-# round-2 evidence set (run on the GPU box): the bench line, rocprofv3 kernel stats of the same command, PMC traffic of the SHT stages
-TAG=${1:-round2_a}
+# round evidence set (run on the GPU box): the bench line, rocprofv3 kernel stats of the same command, PMC traffic of the SHT stages
+TAG=${1:-round3_a}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$TAG
@@ -26,7 +26,7 @@ for t, col in (('f', 'FETCH_SIZE'), ('w', 'WRITE_SIZE')):
     for k, (v, n) in acc.items():
         res[k][col] = v / n; res[k]['n'] = n
 with open('gpurun_out/%s/pmc_traffic.csv' % tag, 'w') as f:
-    f.write('# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/kernel_bench.py 2048 2048 2 ls,la,ps,pa 0,2  (tools/prof_round2.sh)\n')
+    f.write('# rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/kernel_bench.py 2048 2048 2 ls,la,ps,pa 0,2  (tools/prof_round.sh)\n')
     f.write('# MI355X, nside = lmax = 2048; rocprofv3 FETCH_SIZE / WRITE_SIZE in KB, mean per launch.  gfx950 (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 1/2 of the bytes of\n')
     f.write('# 16-B-per-lane streaming reads; other widths (scalar table streams, 8-B pixel stores) are uncalibrated; Infinity-Cache hits included.\n')
     f.write('kernel,FETCH_SIZE_KB,WRITE_SIZE_KB,launches\n')
