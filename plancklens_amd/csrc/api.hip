@@ -19,7 +19,8 @@ void launch_preps(const DevPlan &P, const DevSpinTab &S, int spin, const double 
 void launch_synth0(const DevPlan &P, const double *prep, double *phase, hipStream_t st, int nb = 1);
 void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st, bool gonly, int nb = 1);
 void launch_synths_pair(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st);
-void launch_synths_batch2(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st);
+void launch_synths_batch2(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st,
+                          int npairs_b = 1);
 void launch_anal0(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st,
                   const double *add = nullptr, const double *fl_add = nullptr, int nb = 1);
 void launch_anals(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
@@ -878,7 +879,17 @@ static int cg_fwd_pp_impl(pl_plan *p, int nb, const double *elm_in, const double
         grow(p, &p->prep, &p->prep_cap, p->nent[spin] * 4 * nb))
         return 1;
     launch_preps_gc(P, p->S[spin], spin, elm_in, blm_in, fl_in, p->prep, st, nb);
-    { ProfScope ps(p, PK_LEG_SYNTHS, st); launch_synths(P, p->S[spin], spin, p->prep, p->phase, st, false, nb); }
+    // Block vectors on the grids where the kernel is bound by FMA issue: the entries go through the synthesis two at a time on one
+    // recursion (k_leg_synths<R, false, 2>: 20 instead of 24 FMAs per step and pair, bit-identical maps); odd block sizes go unpaired.
+    // On the coarse grids (launch latency, not FMA issue) every entry is a workgroup row of the ordinary kernel.
+    static const int pair_min_nside = getenv("PLSHTS_CG_PAIR_NSIDE") ? atoi(getenv("PLSHTS_CG_PAIR_NSIDE")) : 1024;
+    if (nb >= 2 && (nb & 1) == 0 && P.nside >= pair_min_nside) {  // (odd block sizes take the unpaired route)
+        ProfScope ps(p, PK_LEG_SYNTHS_BATCH2, st);
+        launch_synths_batch2(P, p->S[spin], spin, p->prep, p->prep + p->nent[spin] * 4, p->phase, st, nb / 2);
+    } else {
+        ProfScope ps(p, PK_LEG_SYNTHS, st);
+        launch_synths(P, p->S[spin], spin, p->prep, p->phase, st, false, nb);
+    }
     HIPCHK(hipGetLastError());
     NinvProj W;
     W.n_inv = n_inv;

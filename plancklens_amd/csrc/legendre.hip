@@ -343,10 +343,13 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
 // input are formed in the same order as by the single-input kernel: the results are bit-identical.
 template <int R, bool GONLY, int IN2 = 0>
 __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int spin, const double4 *__restrict__ prep_,
-                                                    double *__restrict__ phase, const double4 *__restrict__ prep2_ = nullptr)
+                                                    double *__restrict__ phase, const double4 *__restrict__ prep2_ = nullptr,
+                                                    int bstride = 1)
 {
-    const double4 *__restrict__ prep = prep_ + (int64_t)blockIdx.y * S.off[P.mmax + 1];
-    const double4 *__restrict__ prep2 = prep2_ ? prep2_ + (int64_t)blockIdx.y * S.off[P.mmax + 1] : nullptr;
+    // batch entry blockIdx.y: prep arrays bstride entries apart (2 when the second input of a paired launch is the next entry of
+    // the same block vector: entries 2 y and 2 y + 1 share the recursion)
+    const double4 *__restrict__ prep = prep_ + (int64_t)blockIdx.y * bstride * S.off[P.mmax + 1];
+    const double4 *__restrict__ prep2 = prep2_ ? prep2_ + (int64_t)blockIdx.y * bstride * S.off[P.mmax + 1] : nullptr;
     static_assert(!(GONLY && IN2 != 0), "a second input rides on a general first one");
     constexpr bool PAIR = IN2 == 1, BATCH = IN2 == 2;
     constexpr int EST = IN2 ? 16 : 8;  // 4 doubles x number of components of the phase array
@@ -1382,17 +1385,22 @@ void launch_synths_pair(const DevPlan &P, const DevSpinTab &S, int spin, const d
 
 // two general inputs (two simulations) on one recursion; phase entries of 16 doubles: components (Q1, U1, Q2, U2).
 // PLSHTS_RSB overrides the rings per lane (1 or 2)
-void launch_synths_batch2(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st)
+// npairs_b > 1: that many pairs of inputs in one launch (blockIdx.y), prep / prep2 of pair y at 2 y prep arrays from the given
+// pointers -- the entries (2 y, 2 y + 1) of a block of prep arrays when prep2 = prep + one array; phase components 4 y ... 4 y + 3
+void launch_synths_batch2(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st,
+                          int npairs_b)
 {
     const int ngroups1 = (P.npairs + 63) / 64, ngroups2 = (P.npairs + 127) / 128, nmg = own_mgroups(P);
+    if (nmg == 0) return;
     int r = env_int("PLSHTS_RSB", 0);
     if (r != 1 && r != 2) r = rs_synth(P) == 1 ? 1 : 2;
+    const int bstride = npairs_b > 1 ? 2 : 1;
     if (r == 1)
-        hipLaunchKernelGGL((k_leg_synths<1, false, 2>), dim3(ngroups1 * nmg), dim3(256), 0, st, P, S, spin,
-                           reinterpret_cast<const double4 *>(prep), phase, reinterpret_cast<const double4 *>(prep2));
+        hipLaunchKernelGGL((k_leg_synths<1, false, 2>), dim3(ngroups1 * nmg, npairs_b), dim3(256), 0, st, P, S, spin,
+                           reinterpret_cast<const double4 *>(prep), phase, reinterpret_cast<const double4 *>(prep2), bstride);
     else
-        hipLaunchKernelGGL((k_leg_synths<2, false, 2>), dim3(ngroups2 * nmg), dim3(256), 0, st, P, S, spin,
-                           reinterpret_cast<const double4 *>(prep), phase, reinterpret_cast<const double4 *>(prep2));
+        hipLaunchKernelGGL((k_leg_synths<2, false, 2>), dim3(ngroups2 * nmg, npairs_b), dim3(256), 0, st, P, S, spin,
+                           reinterpret_cast<const double4 *>(prep), phase, reinterpret_cast<const double4 *>(prep2), bstride);
 }
 
 void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st, bool gonly, int nb)

@@ -88,17 +88,18 @@ def test_block_vector_helpers_equal_their_loops():
         assert eq(t1, t2)
 
 
-@pytest.mark.parametrize('nside,lmax,marge', [(8, 16, True), (32, 64, True), (512, 600, True), (512, 600, False), (1024, 1100, True)])
-def test_block_operators_equal_their_loops(nside, lmax, marge):
+@pytest.mark.parametrize('nside,lmax,marge,nb', [(8, 16, True, 3), (32, 64, True, 3), (512, 600, True, 3), (512, 600, False, 2), (1024, 1100, True, 3),
+                                                 (1024, 1100, False, 4)])
+def test_block_operators_equal_their_loops(nside, lmax, marge, nb):
     """pl_cg_fwd_tt_b / pl_cg_fwd_pp_b against entry-by-entry pl_cg_fwd_tt / pl_cg_fwd_pp (fwd_op.calc of opfilt_tt / opfilt_pp) on
     grids of every route: all rings in the generic FFT kernel with the projection folded in (8, 32), register FFT classes with
-    the separate projection kernels (512, 1024).  Bit-identical."""
+    the separate projection kernels (512, 1024); even blocks at nside >= 1024 send the polarization entries through the synthesis
+    two at a time on one recursion (k_leg_synths<R, false, 2>), odd ones singly.  Bit-identical."""
     import torch
     from plancklens_amd import dev, hp
     from plancklens_amd.qcinv import opfilt_pp, opfilt_tt
     from plancklens_amd.qcinv.util_alm import eblm
     rng = np.random.default_rng(nside)
-    nb = 3
     npix = 12 * nside ** 2
     ell = np.arange(lmax + 1.)
     bl = np.exp(-ell * (ell + 1.) * 1e-6)
