@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel statistics of ONE top-level CG iteration of a block solve of B right-hand sides: difference of two kernel-trace runs with
-# 4 and 12 iterations per solve (3 solves each).   usage: tools/prof_cg_batch.sh B t|p     (run on the GPU box)
+# 4 and 12 iterations per solve (4 solves each: one warm-up + 3).   usage: tools/prof_cg_batch.sh B t|p     (run on the GPU box)
 B=${1:-4}; K=${2:-t}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
@@ -17,7 +17,7 @@ def load(n):
     fn = glob.glob('gpurun_out/prof_cgb%d/**/cg_kernel_stats.csv' % n, recursive=True)[0]
     return {r['Name']: (int(r['Calls']), int(r['TotalDurationNs'])) for r in csv.DictReader(open(fn))}
 a, b = load(4), load(12)
-nit = 3 * (12 - 4)
+nit = 4 * (12 - 4)  # cg_profile_b.py runs 4 solves per trace (1 warm-up + 3 timed)
 rows = []
 for k in b:
     c0, t0 = a.get(k, (0, 0))
