@@ -214,6 +214,11 @@ int pl_cg_fwd_tt_b(pl_plan *plan, int nb, const double *alm_in, const double *fl
 int pl_cg_fwd_pp_b(pl_plan *plan, int nb, const double *elm_in, const double *blm_in, const double *fl_in, const double *n_inv,
                    const double *elm_add, const double *blm_add, const double *fl_add_e, const double *fl_add_b, double *elm_out,
                    double *blm_out, const double *fl_out, void *stream);
+/* pl_cg_fwd_pp_b for a polarization noise model with a QU cross term (three maps QQ, QU, UU; opfilt_pp.py:295-300): the weighting is
+ * one pass of pl_map_qu_weight between the two ring-FFT stages.  nb = 1 for a single right-hand side. */
+int pl_cg_fwd_pp_qu_b(pl_plan *plan, int nb, const double *elm_in, const double *blm_in, const double *fl_in, const double *n_qq,
+                      const double *n_qu, const double *n_uu, const double *elm_add, const double *blm_add, const double *fl_add_e,
+                      const double *fl_add_b, double *elm_out, double *blm_out, const double *fl_out, void *stream);
 /* Y[b] = A X[b], b < nb: x [nb][ncols], y [nb][nrows] -- the dense preconditioner applied to a block vector (dense.py:118-119); the
  * matrix is read once for the whole batch. */
 int pl_gemv_b(int nrows, int ncols, int64_t lda, const double *A, int nb, const double *x, double *y, void *stream);

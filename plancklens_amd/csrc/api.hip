@@ -48,7 +48,8 @@ void launch_gemv(int nrows, int ncols, int64_t lda, const double *A, const doubl
 void launch_gemv_nb(int nrows, int ncols, int64_t lda, const double *A, int nb, const double *x, double *y, hipStream_t st);
 void launch_copy_slim(const double *src, double *dst, int64_t ndoubles, int nblocks, hipStream_t st);
 void launch_map_mul(int64_t n, const double *a, const double *b, double *out, hipStream_t st);
-void launch_map_qu_weight(int64_t n, double *q, double *u, const double *nqq, const double *nqu, const double *nuu, hipStream_t st);
+void launch_map_qu_weight(int64_t n, double *q, double *u, const double *nqq, const double *nqu, const double *nuu, hipStream_t st, int nb = 1,
+                          int64_t bstride = 0);
 void launch_qe_lens_product(int64_t n, const double *tmap, const double *gt, const double *ct, const double *rep, const double *imp,
                             const double *g3, const double *c3, const double *g1, const double *c1, double *outr, double *outi, hipStream_t st);
 void launch_map_cmul(int64_t n, const double *ar, const double *ai, double s1, const double *br, const double *bi, double s2,
@@ -865,8 +866,11 @@ int pl_cg_fwd_tt_b(pl_plan *p, int nb, const double *alm_in, const double *fl_in
 // The weighting rides in the synthesis-side ring-FFT launches (every kernel class), the add terms in k_posts.
 static int cg_fwd_pp_impl(pl_plan *p, int nb, const double *elm_in, const double *blm_in, const double *fl_in, const double *n_inv, const double *elm_add,
                           const double *blm_add, const double *fl_add_e, const double *fl_add_b, double *elm_out, double *blm_out, const double *fl_out,
-                          void *stream)
+                          void *stream, const double *n_qu = nullptr, const double *n_uu = nullptr)
 {
+    // n_qu / n_uu given: n_inv is the QQ map of a (QQ, QU, UU) noise model -- the weighting is then one pass of k_map_qu_weight between
+    // the two ring-FFT stages instead of riding in the synthesis-side kernels
+    if ((n_qu == nullptr) != (n_uu == nullptr)) return fail("pl_cg_fwd_pp: n_qu and n_uu come together");
     if (!p) return fail("null plan");
     if (!elm_in || !blm_in || !elm_out || !blm_out || !n_inv) return fail("pl_cg_fwd_pp: null alm / n_inv pointer");
     if ((elm_add == nullptr) != (blm_add == nullptr) || (elm_add && (!fl_add_e || !fl_add_b)))
@@ -892,10 +896,14 @@ static int cg_fwd_pp_impl(pl_plan *p, int nb, const double *elm_in, const double
     }
     HIPCHK(hipGetLastError());
     NinvProj W;
-    W.n_inv = n_inv;
+    W.n_inv = n_qu ? nullptr : n_inv;
     {
         ProfScope ps(p, PK_FFT_SYNTH, st);
         HIPCHK(launch_phase2map(P, p->F, p->fs, mlim_of(p, spin), 2 * nb, p->phase, p->wmap, st, &W));
+    }
+    if (n_qu) {
+        launch_map_qu_weight(P.npix, p->wmap, p->wmap + P.npix, n_inv, n_qu, n_uu, st, nb, 2 * P.npix);
+        HIPCHK(hipGetLastError());
     }
     {
         ProfScope ps(p, PK_FFT_ANAL, st);
@@ -918,6 +926,15 @@ int pl_cg_fwd_pp(pl_plan *p, const double *elm_in, const double *blm_in, const d
                  void *stream)
 {
     return cg_fwd_pp_impl(p, 1, elm_in, blm_in, fl_in, n_inv, elm_add, blm_add, fl_add_e, fl_add_b, elm_out, blm_out, fl_out, stream);
+}
+
+int pl_cg_fwd_pp_qu_b(pl_plan *p, int nb, const double *elm_in, const double *blm_in, const double *fl_in, const double *n_qq, const double *n_qu,
+                      const double *n_uu, const double *elm_add, const double *blm_add, const double *fl_add_e, const double *fl_add_b, double *elm_out,
+                      double *blm_out, const double *fl_out, void *stream)
+{
+    PL_NB_CHECK("pl_cg_fwd_pp_qu_b");
+    if (!n_qu || !n_uu) return fail("pl_cg_fwd_pp_qu_b: null noise map");
+    return cg_fwd_pp_impl(p, nb, elm_in, blm_in, fl_in, n_qq, elm_add, blm_add, fl_add_e, fl_add_b, elm_out, blm_out, fl_out, stream, n_qu, n_uu);
 }
 
 int pl_cg_fwd_pp_b(pl_plan *p, int nb, const double *elm_in, const double *blm_in, const double *fl_in, const double *n_inv, const double *elm_add,

@@ -88,9 +88,10 @@ __global__ void k_map_cmul(int64_t n, const double *__restrict__ ar, const doubl
 
 // Polarization inverse-noise weighting with a QU cross term, in place (alm_filter_ninv.apply_map, opfilt_pp.py:295-300 and
 // opfilt_tp.py:321-326):  (Q, U) <- (nqq Q + nqu U, nqu Q + nuu U).  One pass: 5 reads + 2 writes per pixel.
-__global__ void k_map_qu_weight(int64_t n, double *__restrict__ q, double *__restrict__ u, const double *__restrict__ nqq,
-                                const double *__restrict__ nqu, const double *__restrict__ nuu)
+__global__ void k_map_qu_weight(int64_t n, double *__restrict__ q_, double *__restrict__ u_, const double *__restrict__ nqq,
+                                const double *__restrict__ nqu, const double *__restrict__ nuu, int64_t bstride)
 {
+    double *__restrict__ q = q_ + blockIdx.y * bstride, *__restrict__ u = u_ + blockIdx.y * bstride;  // batch entry blockIdx.y
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const double a = q[i], b = u[i], x = nqu[i];
@@ -873,9 +874,10 @@ void launch_map_mul(int64_t n, const double *a, const double *b, double *out, hi
 {
     hipLaunchKernelGGL(k_map_mul, dim3(nblocks(n)), dim3(256), 0, st, n, a, b, out);
 }
-void launch_map_qu_weight(int64_t n, double *q, double *u, const double *nqq, const double *nqu, const double *nuu, hipStream_t st)
+void launch_map_qu_weight(int64_t n, double *q, double *u, const double *nqq, const double *nqu, const double *nuu, hipStream_t st, int nb,
+                          int64_t bstride)
 {
-    hipLaunchKernelGGL(k_map_qu_weight, dim3(nblocks(n)), dim3(256), 0, st, n, q, u, nqq, nqu, nuu);
+    hipLaunchKernelGGL(k_map_qu_weight, dim3(nblocks(n), nb), dim3(256), 0, st, n, q, u, nqq, nqu, nuu, bstride);
 }
 void launch_map_cmul(int64_t n, const double *ar, const double *ai, double s1, const double *br, const double *bi, double s2,
                      double sign, double *outr, double *outi, int accumulate, hipStream_t st)

@@ -237,12 +237,13 @@ class alm_filter_ninv(object):
         alm.blm.copy_(ret.blm)
 
     def one_call_ok(self, alm):
-        """pl_cg_fwd_pp applies: device vectors, one inverse-noise map, no templates, one beam, the module's transforms not replaced."""
+        """pl_cg_fwd_pp applies: device vectors, one inverse-noise map or three (QQ, QU, UU), no templates, one beam, the module's
+        transforms not replaced."""
         self._load_ninv()
         same_b = self.b_transf_b is self.b_transf_e or np.array_equal(self.b_transf_e, self.b_transf_b)
-        return (isinstance(alm.elm, torch.Tensor) and alm.elm.is_cuda and len(self.n_inv) == 1 and not self.wmarg and same_b
+        return (isinstance(alm.elm, torch.Tensor) and alm.elm.is_cuda and len(self.n_inv) in (1, 3) and not self.wmarg and same_b
                 and alm2map_spin is shts.alm2map_spin and map2alm_spin is shts.map2alm_spin and not shts.lane_active()
-                and self.n_inv[0].is_contiguous() and self.n_inv[0].dtype == torch.float64)
+                and all(n.is_contiguous() and n.dtype == torch.float64 for n in self.n_inv))
 
     def apply_alm_new(self, alm, add=None, fl_add_e=None, fl_add_b=None):
         """B^t Y^t N^-1 Y B (E, B) (+ (fl_add_e E', fl_add_b B') for add = (E', B')) as a new eblm (the input is left alone)."""
@@ -252,7 +253,8 @@ class alm_filter_ninv(object):
             npix = self.n_inv[0].numel()
             elm, blm = shts.cg_fwd_pp(alm.elm, alm.blm, self.nside, lmax, self.n_inv[0], fl_in=self.b_transf_e,
                                       fl_out=self.b_transf_e * (npix / (4. * np.pi)),
-                                      add=None if add is None else (add.elm, add.blm), fl_add_e=fl_add_e, fl_add_b=fl_add_b)
+                                      add=None if add is None else (add.elm, add.blm), fl_add_e=fl_add_e, fl_add_b=fl_add_b,
+                                      n_qu=self.n_inv[1] if len(self.n_inv) == 3 else None, n_uu=self.n_inv[2] if len(self.n_inv) == 3 else None)
             return eblm([elm, blm])
         ret = self._apply_alm_steps(alm)
         if add is not None:

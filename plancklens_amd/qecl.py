@@ -82,7 +82,10 @@ class library(object):
     def _spectrum(self, k1, k2, idx, lmax):
         """unnormalised (no 1 / fsky) spectrum of the mean-field subtracted estimates"""
         same = k1 == k2 and self.qeA is self.qeB
-        dev_route = hasattr(self.qeA, '_get_sim_qlm_dev') and hasattr(self.qeB, '_get_sim_qlm_dev')
+        # the device route forms the spectrum with pl_alm2cl; a subclass that overrides the reference's hook _alm2clfsky1234
+        # (qecl.py:147-148: e.g. a mask-deconvolved spectrum) gets host arrays through its hook, as in the reference
+        dev_route = (hasattr(self.qeA, '_get_sim_qlm_dev') and hasattr(self.qeB, '_get_sim_qlm_dev')
+                     and type(self)._alm2clfsky1234 is library._alm2clfsky1234)
         if dev_route:
             from . import dev
             import torch

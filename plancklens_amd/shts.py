@@ -279,7 +279,7 @@ def cg_fwd_tt(alm, nside, lmax, n_inv, fl_in=None, fl_out=None, pmat=None, rmat=
     return out
 
 
-def cg_fwd_pp(elm, blm, nside, lmax, n_inv, fl_in=None, fl_out=None, add=None, fl_add_e=None, fl_add_b=None):
+def cg_fwd_pp(elm, blm, nside, lmax, n_inv, fl_in=None, fl_out=None, add=None, fl_add_e=None, fl_add_b=None, n_qu=None, n_uu=None):
     """fl_out Y2^t [n_inv Y2 (fl_in (E, B))] + (fl_add_e E_add, fl_add_b B_add) on the device, one call (pl_cg_fwd_pp): fwd_op.calc of
     plancklens/qcinv/opfilt_pp.py:69-78 for a single inverse-noise map.  Returns (elm, blm), two views of one (2, nalm) tensor."""
     plan = get_plan(nside, lmax)
@@ -287,6 +287,8 @@ def cg_fwd_pp(elm, blm, nside, lmax, n_inv, fl_in=None, fl_out=None, add=None, f
     nb = e.shape[0] if e.dim() == 2 else 1  # blocks [nb, nalm]: nb right-hand sides through every launch (pl_cg_fwd_pp_b)
     assert e.shape == b.shape and e.shape[-1] == plan.nalm and e.numel() == nb * plan.nalm and e.dtype == torch.complex128 and b.dtype == torch.complex128
     assert n_inv.numel() == plan.npix and n_inv.is_contiguous() and n_inv.dtype == torch.float64
+    for n_ in (n_qu, n_uu):  # (QQ, QU, UU) noise: n_inv is the QQ map (pl_cg_fwd_pp_qu_b)
+        assert (n_qu is None) == (n_uu is None) and (n_ is None or (n_.numel() == plan.npix and n_.is_contiguous() and n_.dtype == torch.float64))
     out = torch.empty((2,) + tuple(e.shape), dtype=torch.complex128, device=e.device)
     fi, fo = _fl_arg(fl_in, lmax, True), _fl_arg(fl_out, lmax, True)
     ae = ab = fe = fb = None
@@ -294,7 +296,10 @@ def cg_fwd_pp(elm, blm, nside, lmax, n_inv, fl_in=None, fl_out=None, add=None, f
         ae, ab = add[0].contiguous(), add[1].contiguous()
         assert ae.shape == e.shape and ab.shape == e.shape and ae.dtype == torch.complex128 and ab.dtype == torch.complex128
         fe, fb = _fl_arg(fl_add_e, lmax, True), _fl_arg(fl_add_b, lmax, True)
-    if e.dim() == 2:
+    if n_qu is not None:
+        _lib.check(_lib.lib().pl_cg_fwd_pp_qu_b(plan.h, nb, _ptr(e), _ptr(b), _ptr(fi), _ptr(n_inv), _ptr(n_qu), _ptr(n_uu), _ptr(ae), _ptr(ab),
+                                                _ptr(fe), _ptr(fb), _ptr(out[0]), _ptr(out[1]), _ptr(fo), _stream()))
+    elif e.dim() == 2:
         _lib.check(_lib.lib().pl_cg_fwd_pp_b(plan.h, nb, _ptr(e), _ptr(b), _ptr(fi), _ptr(n_inv), _ptr(ae), _ptr(ab), _ptr(fe), _ptr(fb),
                                              _ptr(out[0]), _ptr(out[1]), _ptr(fo), _stream()))
     else:

@@ -101,6 +101,16 @@ def test_polarization_operators_with_qu_noise_and_templates(g2):
     assert relrms(dev.to_host(r.elm), g['pp3_fwd_e']) < 1e-11 and relrms(dev.to_host(r.blm), g['pp3_fwd_b']) < 1e-11
     pr = opfilt_pp.calc_prep([g['qmap'], g['umap']], cl, f3)
     assert relrms(dev.to_host(pr.elm), g['pp3_prep_e']) < 1e-11 and relrms(dev.to_host(pr.blm), g['pp3_prep_b']) < 1e-11
+    # the same operator on a block of two right-hand sides (pl_cg_fwd_pp_qu_b), and step by step (map_qu_weight in apply_map)
+    xb = eblm([torch.stack([x.elm, x.blm * 0.5]).contiguous(), torch.stack([x.blm, x.elm * 2.]).contiguous()])
+    rb = opfilt_pp.fwd_op(cl, f3)(xb)
+    assert bool((rb.elm[0] == r.elm).all()) and bool((rb.blm[0] == r.blm).all())
+    r1 = opfilt_pp.fwd_op(cl, f3)(eblm([xb.elm[1].contiguous(), xb.blm[1].contiguous()]))
+    assert bool((rb.elm[1] == r1.elm).all()) and bool((rb.blm[1] == r1.blm).all())
+    steps = f3._apply_alm_steps(x)
+    from plancklens_amd.qcinv.opfilt_pp import _apply_2x2
+    steps = _apply_2x2(opfilt_pp.fwd_op(cl, f3).s_inv_filt.slinv, x, add_to=steps)
+    assert relrms(dev.to_host(steps.elm), g['pp3_fwd_e']) < 1e-11 and relrms(dev.to_host(steps.blm), g['pp3_fwd_b']) < 1e-11
     fm = opfilt_pp.alm_filter_ninv([g['nqq']], g['transf'], marge_qmaps=[g['tq0'], g['tq1']], marge_umaps=[g['tu0']])
     r = opfilt_pp.fwd_op(cl, fm)(x)
     assert relrms(dev.to_host(r.elm), g['ppm_fwd_e']) < 1e-11 and relrms(dev.to_host(r.blm), g['ppm_fwd_b']) < 1e-11
