@@ -1190,7 +1190,10 @@ static hipError_t launch_split_class(const DevPlan &P, const DevFFT &F, int cls,
 static hipError_t launch_stage(const DevPlan &P, const DevFFT &F, const FftStreams &fs, bool synth, const int *mlim, int ncomp,
                                const double *in, double *out, hipStream_t st, const NinvProj &W)
 {
-    const bool par = fs.ok && !(getenv("PLSHTS_FFT_SERIAL") && atoi(getenv("PLSHTS_FFT_SERIAL")) != 0);
+    // PLSHTS_FFT_SERIAL=1: every class on the caller's stream; PLSHTS_FFT_SERIAL_NSIDE=n: on grids up to nside n (fork / join of the
+    // side streams costs tens of microseconds per stage, which the small grids of the CG chains may not earn back)
+    static const int serial_nside = getenv("PLSHTS_FFT_SERIAL_NSIDE") ? atoi(getenv("PLSHTS_FFT_SERIAL_NSIDE")) : 0;
+    const bool par = fs.ok && !(getenv("PLSHTS_FFT_SERIAL") && atoi(getenv("PLSHTS_FFT_SERIAL")) != 0) && P.nside > serial_nside;
     // Work items: w = 3 c + kind of class c (kind 0: direct, 1: Bluestein, 2: split Bluestein) and the generic list (w = nw).  Cost
     // model: ring pairs x transform size x transforms per sub-DFT, plus a fixed latency (the short-ring kernels are latency-bound).
     // The costliest item stays on the caller's stream; the others go, costliest first, to the side stream with the least work

@@ -1,6 +1,6 @@
 """Templates marginalised by the pixel-space inverse-noise operator, API of plancklens/qcinv/template_removal.py
-(`template_monopole` :116-129, `template_dipole` :132-150, `template_map` :36-60, `xyz_to_alm` / `alm_to_xyz`
-:153-166).  The reference evaluates the dipole through lmax = 1 SHTs; here the (x, y, z) pixel maps are built
+(`template_monopole` :116-129, `template_dipole` :132-150, `template_map` :36-60, `template_qmap` / `template_umap` :55-108,
+`xyz_to_alm` / `alm_to_xyz` :153-166).  The reference evaluates the dipole through lmax = 1 SHTs; here the (x, y, z) pixel maps are built
 once per nside on the device and the dot products are plain device reductions (same numbers: the lmax = 1
 transform of the reference is sum_p m_p (x, y, z)_p up to the normalisation it divides out again)."""
 import numpy as np
@@ -111,3 +111,44 @@ class template_dipole(template):
     def dot(self, tmap):
         xyz = _xyz_dev(hp.npix2nside(tmap.numel()))
         return list(dev.to_host(xyz @ tmap))
+
+
+class _template_pol(template):
+    """One polarization template living in the Q (comp 0) or U (comp 1) map of a (Q, U) pair
+    (template_removal.py:55-108: template_qmap, template_umap).  opfilt_pp marginalises these through a device matrix
+    (alm_filter_ninv._proj_matrices_p); the methods here are the reference's element-wise interface."""
+    comp = 0
+
+    def __init__(self, m):
+        self.nmodes = 1
+        self.map = m
+
+    def _m(self, like):
+        t = dev.to_dev(read_map(self.map), torch.float64)
+        return t if isinstance(like, torch.Tensor) else dev.to_host(t)
+
+    def apply(self, pmap, coeffs):
+        assert len(coeffs) == self.nmodes
+        if len(pmap) == 2:  # (Q, U): the template's component times the template, the other component zero
+            pmap[self.comp] *= self._m(pmap[self.comp]) * float(coeffs[0])
+            pmap[1 - self.comp] *= 0.
+        else:  # the template's component alone
+            assert len(pmap) == 1
+            pmap[0] *= self._m(pmap[0]) * float(coeffs[0])
+
+    def accum(self, pmap, coeffs):
+        assert len(pmap) == 2 and len(coeffs) == self.nmodes
+        pmap[self.comp] += self._m(pmap[self.comp]) * float(coeffs[0])
+
+    def dot(self, pmap):
+        m = pmap[self.comp if len(pmap) == 2 else 0]
+        return [float((self._m(m) * m).sum())]
+
+
+class template_qmap(_template_pol):
+    comp = 0
+
+
+class template_umap(_template_pol):
+    comp = 1
+

@@ -170,3 +170,18 @@ class average(object):
 
     def get_dat_qcl(self, k1, k2=None, lmax=None):
         return self.get_sim_qcl(k1, -1, k2=k2, lmax=lmax)
+
+    def get_sim_stats_qcl(self, k1, mc_sims, k2=None, recache=False, lmax=None):
+        """utils.stats of the averaged spectra over mc_sims, pickled in lib_dir (qecl.py:205-222)"""
+        k2 = k1 if k2 is None else k2
+        lmax = self.get_lmaxqcl(k1, k2) if lmax is None else lmax
+        assert lmax <= self.get_lmaxqcl(k1, k2)
+        fn = os.path.join(self.lib_dir, 'sim_qcl_stats_%s_%s_%s_%s.pk' % (k1, k2, lmax, utils.mchash(mc_sims)))
+        if recache or not os.path.exists(fn):
+            st = utils.stats(lmax + 1, docov=False)
+            for _, idx in utils.enumerate_progress(mc_sims, label='sim_stats qcl (k1,k2)=' + str((k1, k2))):
+                st.add(self.get_sim_qcl(k1, idx, k2=k2, lmax=lmax))
+            with open(fn, 'wb') as f:
+                pk.dump(st, f, protocol=2)
+        with open(fn, 'rb') as f:
+            return pk.load(f)

@@ -144,6 +144,43 @@ class stats(object):
         assert self.N > 0
         return self.sigmas() / np.sqrt(self.N)
 
+    def corrcoeffs(self):
+        sig = self.sigmas()
+        return self.cov() / np.outer(sig, sig)
+
+    def inverse(self, bias_p=None):
+        """inverse covariance, de-biased for the finite number of samples ((N - size - 2) / (N - 1) unless bias_p is given)"""
+        assert self.N > self.size, "Non invertible cov.matrix"
+        if bias_p is None:
+            bias_p = (self.N - self.size - 2.) / (self.N - 1)
+        return bias_p * np.linalg.inv(self.cov())
+
+    def get_chisq(self, data):
+        """(data - mean)^t C^-1 (data - mean)"""
+        assert data.size == self.size, (data.size, self.size)
+        dx = data - self.mean()
+        return float(dx @ self.inverse() @ dx)
+
+    def get_chisq_pte(self, data):
+        from scipy.stats import chi2
+        return chi2.sf(self.get_chisq(data), self.N - 1)
+
+    def rebin_that_nooverlap(self, orig_coord, lmins, lmaxs, weights=None):
+        """stats of the weighted bin averages over the non-overlapping bins [lmins[k], lmaxs[k]] of the coordinate orig_coord"""
+        lmins, lmaxs = np.asarray(lmins), np.asarray(lmaxs)
+        assert orig_coord.size == self.size and lmins.size == lmaxs.size, "Incompatible input"
+        assert np.all(np.diff(lmins) > 0.) and np.all(np.diff(lmaxs) > 0.), "This only for non overlapping bins."
+        w = np.ones(self.size) if weights is None else np.asarray(weights)
+        assert w.size == self.size and self.size > lmins.size, "incompatible input"
+        tmat = np.zeros((lmins.size, self.size))
+        for k, (lo, hi) in enumerate(zip(lmins, lmaxs)):
+            sel = (orig_coord >= lo) & (orig_coord <= hi)
+            if np.any(sel):
+                tmat[k, sel] = w[sel] / np.sum(w[sel])
+        ret = stats(lmins.size, xcoord=0.5 * (lmins[:-1] + lmaxs[1:]))
+        ret.sum, ret.mom, ret.N = tmat @ self.sum, tmat @ self.mom @ tmat.T, self.N
+        return ret
+
 
 def cl_inverse(cls):
     """Per-multipole pseudo-inverse of the symmetric T, E, B spectral matrix given as a dictionary ('tt', 'ee', 'bb',
@@ -164,3 +201,46 @@ def cl_inverse(cls):
         if np.any(inv[:, i, j]):
             ret[k] = inv[:, i, j].copy()
     return ret
+
+
+def extcl(lmax, cl):
+    """cl zero-padded or truncated to lmax + 1 entries (utils.py:367-373)"""
+    cl = np.asarray(cl)
+    if len(cl) > lmax:
+        return cl[:lmax + 1]
+    out = np.zeros(lmax + 1)
+    out[:len(cl)] = cl
+    return out
+
+
+def _cldict2arr(cls_dict):
+    """(3, 3, lmax + 1) array of a T, E, B spectra dictionary (symmetric; missing spectra zero)"""
+    n = max(len(cl) for cl in cls_dict.values())
+    return np.array([[extcl(n - 1, cls_dict.get(a + b, cls_dict.get(b + a, np.zeros(1)))) for b in 'teb'] for a in 'teb'], dtype=float)
+
+
+def cls_dot(cls_list, ret_dict=False):
+    """Per-multipole product of T, E, B spectral matrices, each a dictionary or a (3, 3, lmax + 1) array (utils.py:383-416);
+    ret_dict: the non-zero entries of the upper triangle as a dictionary."""
+    mats = [_cldict2arr(c) if isinstance(c, dict) else np.asarray(c) for c in cls_list]
+    ret = mats[-1]
+    for m in mats[-2::-1]:
+        ret = np.einsum('ikl,kjl->ijl', m, ret)
+    if not ret_dict:
+        return ret
+    out = {}
+    for k, (i, j) in zip(['tt', 'ee', 'bb', 'te', 'tb', 'eb'], [(0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)]):
+        if np.any(ret[i, j]):
+            out[k] = ret[i, j].copy()
+    return out
+
+
+def alm2rlm(alm):
+    """complex alm -> real harmonic coefficients (utils.py:37-52; the dense preconditioners' layout, qcinv.dense.alm2rlm)"""
+    from .qcinv import dense
+    return dense.alm2rlm(np.asarray(alm))
+
+
+def rlm2alm(rlm):
+    from .qcinv import dense
+    return dense.rlm2alm(np.asarray(rlm))

@@ -161,3 +161,34 @@ def test_alm_files_have_healpy_s_table_layout(tmp_path):
     # a truncated write keeps healpy's semantics: rows with l <= lmax only
     hp.write_alm(out, expect, lmax=2, overwrite=True)
     assert np.array_equal(hp.read_alm(out), expect[[0, 1, 2, 4, 5, 7]])
+
+
+def test_spectral_matrix_and_statistics_helpers():
+    """utils.cls_dot / extcl (utils.py:367-416) and the utils.stats methods behind the spectra statistics (utils.py:181-260)
+    against explicit numpy evaluations of their definitions"""
+    from plancklens_amd import utils
+    rng = np.random.default_rng(1)
+    a = {'tt': rng.random(6), 'ee': rng.random(4), 'te': rng.random(6), 'bb': rng.random(5)}
+    b = {'tt': rng.random(3), 'eb': rng.random(6), 'bb': rng.random(6)}
+    A, B = utils._cldict2arr(a), utils._cldict2arr(b)
+    assert A.shape == (3, 3, 6) and np.array_equal(A[0, 1], A[1, 0]) and np.array_equal(A[1, 1, :4], a['ee']) and not A[1, 1, 4:].any()
+    ref = np.stack([[sum(A[i, k] * sum(B[k, m] * A[m, j] for m in range(3)) for k in range(3)) for j in range(3)] for i in range(3)])
+    assert np.allclose(utils.cls_dot([a, b, a]), ref, rtol=1e-14, atol=0)
+    d = utils.cls_dot([a, b], ret_dict=True)
+    assert np.allclose(d['tt'], A[0, 0] * B[0, 0]) and np.allclose(d['eb'], (A[1, 1] * B[1, 2] + A[1, 0] * B[0, 2]))
+    assert np.array_equal(utils.extcl(7, np.arange(3.)), [0, 1, 2, 0, 0, 0, 0, 0]) and np.array_equal(utils.extcl(1, np.arange(3.)), [0, 1])
+    x = rng.standard_normal((40, 5)) @ rng.standard_normal((5, 5))
+    st = utils.stats(5)
+    for v in x:
+        st.add(v)
+    cov = np.cov(x.T)
+    assert np.allclose(st.cov(), cov) and np.allclose(st.avg(), x.mean(0)) and np.allclose(st.corrcoeffs(), np.corrcoef(x.T))
+    assert np.allclose(st.inverse(), (40 - 5 - 2.) / 39. * np.linalg.inv(cov))
+    dx = np.ones(5) - x.mean(0)
+    assert np.isclose(st.get_chisq(np.ones(5)), dx @ st.inverse() @ dx) and 0. <= st.get_chisq_pte(np.ones(5)) <= 1.
+    rb = st.rebin_that_nooverlap(np.arange(5.), np.array([0., 2.]), np.array([1., 4.]), weights=np.array([1., 3., 1., 1., 2.]))
+    xb = np.stack([(x[:, 0] + 3 * x[:, 1]) / 4., (x[:, 2] + x[:, 3] + 2 * x[:, 4]) / 4.], axis=1)
+    assert np.allclose(rb.mean(), xb.mean(0)) and np.allclose(rb.cov(), np.cov(xb.T))
+    alm = rng.standard_normal(10) + 1j * rng.standard_normal(10)
+    alm[:4] = alm[:4].real
+    assert np.allclose(utils.rlm2alm(utils.alm2rlm(alm)), alm) and utils.alm2rlm(alm).size == 16
