@@ -1,25 +1,33 @@
 """Wrappers around filtering libraries, API of plancklens/filt/filt_util.py (`library_ftl` :39-103, `library_fml` :106-182,
-`library_shuffle` :186-236).  Pure index / l- and m-weight bookkeeping; device-resident alms are passed through."""
+`library_shuffle` :186-236): the same `ivfs` protocol (get_sim_tlm / elm / blm, get_sim_tmliklm / emliklm / bmliklm, get_ftl / fel /
+fbl, get_tal, get_fmask, hashdict) seen through a re-weighting of the alms or a re-mapping of the simulation index.
+
+One base class forwards the protocol; a wrapper only says what it does to an alm of a given field (`_alm`), to the isotropic
+filter of a field (`_fl`) and to a simulation index (`_idx`).  Pure index / l- and m-weight bookkeeping on host arrays;
+device-resident alms are passed through where the wrapped library offers them."""
 import numpy as np
 
-from .. import dev, hp
+from .. import hp, utils
+
+_ALMS = ('tlm', 'elm', 'blm', 'tmliklm', 'emliklm', 'bmliklm')
 
 
-class library_ftl(object):
-    """Rescales the filtered alms of `ivfs` by isotropic functions of l (filt_util.py:39-103)."""
-
-    def __init__(self, ivfs, lmax, lfilt_t, lfilt_e, lfilt_b):
-        assert len(lfilt_t) > lmax and len(lfilt_e) > lmax and len(lfilt_b) > lmax
+class _ivfs_view(object):
+    def __init__(self, ivfs):
         self.ivfs = ivfs
-        self.lmax = lmax
-        self.lfilt_t, self.lfilt_e, self.lfilt_b = lfilt_t, lfilt_e, lfilt_b
-        self.lib_dir = ivfs.lib_dir
+        self.lib_dir = getattr(ivfs, 'lib_dir', None)
 
-    def hashdict(self):
-        from .. import utils
-        return {'ivfs': self.ivfs.hashdict(), 'filt_t': utils.clhash(self.lfilt_t[:self.lmax + 1]),
-                'filt_e': utils.clhash(self.lfilt_e[:self.lmax + 1]), 'filt_b': utils.clhash(self.lfilt_b[:self.lmax + 1])}
+    # what a wrapper changes
+    def _idx(self, idx):
+        return idx
 
+    def _alm(self, name, alm):
+        return alm
+
+    def _fl(self, field, fl):
+        return fl
+
+    # the protocol, forwarded
     def get_fmask(self):
         return self.ivfs.get_fmask()
 
@@ -27,146 +35,96 @@ class library_ftl(object):
         return self.ivfs.get_tal(a)
 
     def get_ftl(self):
-        return self.ivfs.get_ftl()[:self.lmax + 1] * self.lfilt_t[:self.lmax + 1]
+        return self._fl('t', self.ivfs.get_ftl())
 
     def get_fel(self):
-        return self.ivfs.get_fel()[:self.lmax + 1] * self.lfilt_e[:self.lmax + 1]
+        return self._fl('e', self.ivfs.get_fel())
 
     def get_fbl(self):
-        return self.ivfs.get_fbl()[:self.lmax + 1] * self.lfilt_b[:self.lmax + 1]
-
-    def _resc(self, alm, fl):
-        from ..utils import alm_copy
-        return hp.almxfl(alm_copy(alm, lmax=self.lmax), fl[:self.lmax + 1], inplace=True)
-
-    def get_sim_tlm(self, idx):
-        return self._resc(self.ivfs.get_sim_tlm(idx), self.lfilt_t)
-
-    def get_sim_elm(self, idx):
-        return self._resc(self.ivfs.get_sim_elm(idx), self.lfilt_e)
-
-    def get_sim_blm(self, idx):
-        return self._resc(self.ivfs.get_sim_blm(idx), self.lfilt_b)
-
-    def get_sim_tmliklm(self, idx):
-        return self._resc(self.ivfs.get_sim_tmliklm(idx), self.lfilt_t)
-
-    def get_sim_emliklm(self, idx):
-        return self._resc(self.ivfs.get_sim_emliklm(idx), self.lfilt_e)
-
-    def get_sim_bmliklm(self, idx):
-        return self._resc(self.ivfs.get_sim_bmliklm(idx), self.lfilt_b)
+        return self._fl('b', self.ivfs.get_fbl())
 
 
-class library_fml(object):
-    """Rescales the filtered alms of `ivfs` by functions of the azimuthal order: a_lm -> f_m a_lm (filt_util.py:106-182).
-    As in the reference, the inverse-variance filtered E and B alms take the *temperature* weights mfilt_t (filt_util.py:169-173;
-    the Wiener-filtered ones take their own) -- results parity first."""
+def _forward(name):
+    def get(self, idx):
+        return self._alm(name, getattr(self.ivfs, 'get_sim_' + name)(self._idx(idx)))
+    get.__name__ = 'get_sim_' + name
+    get.__doc__ = "the wrapped library's get_sim_%s through this wrapper" % name
+    return get
 
-    def __init__(self, ivfs, lmax, mfilt_t, mfilt_e, mfilt_b):
-        assert len(mfilt_t) > lmax and len(mfilt_e) > lmax and len(mfilt_b) > lmax
-        self.ivfs = ivfs
+
+for _n in _ALMS:
+    setattr(_ivfs_view, 'get_sim_' + _n, _forward(_n))
+
+
+class _reweighted(_ivfs_view):
+    """alms cut to a new band-limit and multiplied by per-field weight arrays"""
+
+    def __init__(self, ivfs, lmax, wt, we, wb):
+        assert min(len(wt), len(we), len(wb)) > lmax
+        super(_reweighted, self).__init__(ivfs)
         self.lmax = lmax
-        self.mfilt_t, self.mfilt_e, self.mfilt_b = mfilt_t, mfilt_e, mfilt_b
-        self.lib_dir = ivfs.lib_dir
+        self._w = {'t': wt, 'e': we, 'b': wb}
 
     def hashdict(self):
-        from .. import utils
-        return {'ivfs': self.ivfs.hashdict(), 'filt_t': utils.clhash(self.mfilt_t[:self.lmax + 1]),
-                'filt_e': utils.clhash(self.mfilt_e[:self.lmax + 1]), 'filt_b': utils.clhash(self.mfilt_b[:self.lmax + 1])}
+        ret = {'ivfs': self.ivfs.hashdict()}
+        ret.update({'filt_' + f: utils.clhash(self._w[f][:self.lmax + 1]) for f in 'teb'})
+        return ret
 
-    def get_fmask(self):
-        return self.ivfs.get_fmask()
 
-    def get_tal(self, a):
-        return self.ivfs.get_tal(a)
+class library_ftl(_reweighted):
+    """Rescales the filtered alms of `ivfs` by isotropic functions of l: a_lm -> f_l a_lm (filt_util.py:39-103)."""
+
+    def __init__(self, ivfs, lmax, lfilt_t, lfilt_e, lfilt_b):
+        super(library_ftl, self).__init__(ivfs, lmax, lfilt_t, lfilt_e, lfilt_b)
+        self.lfilt_t, self.lfilt_e, self.lfilt_b = lfilt_t, lfilt_e, lfilt_b
+
+    def _alm(self, name, alm):
+        return hp.almxfl(utils.alm_copy(alm, lmax=self.lmax), self._w[name[0]][:self.lmax + 1], inplace=True)
+
+    def _fl(self, field, fl):
+        return fl[:self.lmax + 1] * self._w[field][:self.lmax + 1]
+
+
+class library_fml(_reweighted):
+    """Rescales the filtered alms of `ivfs` by functions of the azimuthal order: a_lm -> f_m a_lm (filt_util.py:106-182).
+    As in the reference, the inverse-variance filtered E and B alms take the *temperature* weights (filt_util.py:169-173; the
+    Wiener-filtered ones take their own) -- results parity first."""
+    _WEIGHT_OF = {'tlm': 't', 'elm': 't', 'blm': 't', 'tmliklm': 't', 'emliklm': 'e', 'bmliklm': 'b'}
+
+    def __init__(self, ivfs, lmax, mfilt_t, mfilt_e, mfilt_b):
+        super(library_fml, self).__init__(ivfs, lmax, mfilt_t, mfilt_e, mfilt_b)
+        self.mfilt_t, self.mfilt_e, self.mfilt_b = mfilt_t, mfilt_e, mfilt_b
 
     @staticmethod
     def almxfm(alm, fm, lmax):
         """copy of alm at band-limit lmax with every entry multiplied by fm[m]"""
-        from ..utils import alm_copy
-        ret = alm_copy(alm, lmax=lmax)
+        ret = utils.alm_copy(alm, lmax=lmax)
         ret *= np.asarray(fm)[hp.Alm.getlm(lmax)[1]]
         return ret
 
-    def _isotropic_equivalent(self, fl, fm):
+    def _alm(self, name, alm):
+        return self.almxfm(alm, self._w[self._WEIGHT_OF[name]], self.lmax)
+
+    def _fl(self, field, fl):
         """f_l sqrt(<f_m>_l), <f_m>_l the mean of f_|m| over the 2l + 1 orders of l (the root: applies at the spectrum level)"""
-        f = np.asarray(fm[:self.lmax + 1], dtype=float)
-        mean = (2. * np.cumsum(f) - f[0]) / (2. * np.arange(self.lmax + 1) + 1.)
-        return fl[:self.lmax + 1] * np.sqrt(mean)
-
-    def get_ftl(self):
-        return self._isotropic_equivalent(self.ivfs.get_ftl(), self.mfilt_t)
-
-    def get_fel(self):
-        return self._isotropic_equivalent(self.ivfs.get_fel(), self.mfilt_e)
-
-    def get_fbl(self):
-        return self._isotropic_equivalent(self.ivfs.get_fbl(), self.mfilt_b)
-
-    def get_sim_tlm(self, idx):
-        return self.almxfm(self.ivfs.get_sim_tlm(idx), self.mfilt_t, self.lmax)
-
-    def get_sim_elm(self, idx):
-        return self.almxfm(self.ivfs.get_sim_elm(idx), self.mfilt_t, self.lmax)
-
-    def get_sim_blm(self, idx):
-        return self.almxfm(self.ivfs.get_sim_blm(idx), self.mfilt_t, self.lmax)
-
-    def get_sim_tmliklm(self, idx):
-        return self.almxfm(self.ivfs.get_sim_tmliklm(idx), self.mfilt_t, self.lmax)
-
-    def get_sim_emliklm(self, idx):
-        return self.almxfm(self.ivfs.get_sim_emliklm(idx), self.mfilt_e, self.lmax)
-
-    def get_sim_bmliklm(self, idx):
-        return self.almxfm(self.ivfs.get_sim_bmliklm(idx), self.mfilt_b, self.lmax)
+        f = np.asarray(self._w[field][:self.lmax + 1], dtype=float)
+        return fl[:self.lmax + 1] * np.sqrt((2. * np.cumsum(f) - f[0]) / (2. * np.arange(self.lmax + 1) + 1.))
 
 
-class library_shuffle(object):
+class library_shuffle(_ivfs_view):
     """Filtering library with remapped simulation indices: idx -> idxs[idx] (filt_util.py:186-236).
     This is what makes ivfs1 != ivfs2 in the ds / ss estimator pairs (qest.py:327-332)."""
 
     def __init__(self, ivfs, idxs):
-        self.ivfs = ivfs
+        super(library_shuffle, self).__init__(ivfs)
         self.idxs = idxs
 
     def hashdict(self):
         return {'ivfs': self.ivfs.hashdict(), 'idxs': self.idxs}
 
-    def get_fmask(self):
-        return self.ivfs.get_fmask()
-
-    def get_tal(self, a):
-        return self.ivfs.get_tal(a)
-
-    def get_ftl(self):
-        return self.ivfs.get_ftl()
-
-    def get_fel(self):
-        return self.ivfs.get_fel()
-
-    def get_fbl(self):
-        return self.ivfs.get_fbl()
+    def _idx(self, idx):
+        return self.idxs[idx]
 
     def get_sim_alm_dev(self, name, idx):
         getter = getattr(self.ivfs, 'get_sim_alm_dev', None)
         return None if getter is None else getter(name, self.idxs[idx])
-
-    def get_sim_tlm(self, idx):
-        return self.ivfs.get_sim_tlm(self.idxs[idx])
-
-    def get_sim_elm(self, idx):
-        return self.ivfs.get_sim_elm(self.idxs[idx])
-
-    def get_sim_blm(self, idx):
-        return self.ivfs.get_sim_blm(self.idxs[idx])
-
-    def get_sim_tmliklm(self, idx):
-        return self.ivfs.get_sim_tmliklm(self.idxs[idx])
-
-    def get_sim_emliklm(self, idx):
-        return self.ivfs.get_sim_emliklm(self.idxs[idx])
-
-    def get_sim_bmliklm(self, idx):
-        return self.ivfs.get_sim_bmliklm(self.idxs[idx])
