@@ -89,7 +89,7 @@ def test_block_vector_helpers_equal_their_loops():
 
 
 @pytest.mark.parametrize('nside,lmax,marge,nb', [(8, 16, True, 3), (32, 64, True, 3), (512, 600, True, 3), (512, 600, False, 2), (1024, 1100, True, 3),
-                                                 (1024, 1100, False, 4)])
+                                                 (1024, 1100, False, 4), (2048, 2048, True, 2)])
 def test_block_operators_equal_their_loops(nside, lmax, marge, nb):
     """pl_cg_fwd_tt_b / pl_cg_fwd_pp_b against entry-by-entry pl_cg_fwd_tt / pl_cg_fwd_pp (fwd_op.calc of opfilt_tt / opfilt_pp) on
     grids of every route: all rings in the generic FFT kernel with the projection folded in (8, 32), register FFT classes with
