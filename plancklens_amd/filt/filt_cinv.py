@@ -18,6 +18,30 @@ from ..qcinv import cd_solve, multigrid, opfilt_pp, opfilt_tp, opfilt_tt, util, 
 from . import filt_simple
 
 
+# The reference's default multigrid chains as data (filt_cinv.py:112-116 temperature, :236-239 polarization, :398-407 joint): per
+# stage (band-limit, nside, dense band-limit or None); every coarse stage runs three unmonitored iterations, the stage it
+# preconditions splits at its band-limit; the top stage (the filter's own lmax and nside) iterates to |residual| <= 1e-5 |rhs|.
+_COARSE_STAGES = {'t': [(256, 128, 64), (512, 256, None), (1024, 512, None)],
+                  'p': [(512, 256, 32), (1024, 512, None)],
+                  'tp': [(256, 128, 64), (512, 256, None), (1024, 512, None)]}
+
+
+def default_chain_descr(kind, lmax, nside, pcf):
+    """chain descriptor in the reference's mini-language for cinv_t ('t'), cinv_p ('p') or cinv_tp ('tp'); pcf: cache file of the
+    dense coarse preconditioner ('' / None: none)"""
+    coarse = _COARSE_STAGES[kind]
+    chain, below = [], None
+    for depth, (st_lmax, st_nside, dense_lmax) in zip(range(len(coarse), 0, -1), coarse):
+        if dense_lmax is not None:
+            descr = "split(dense(%s), %d, diag_cl)" % (pcf, dense_lmax)
+        else:
+            descr = "split(stage(%d),  %d, diag_cl)" % (depth + 1, below)
+        chain.append([depth, [descr], st_lmax, st_nside, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()])
+        below = st_lmax
+    chain.append([0, ["split(stage(1), %d, diag_cl)" % below], lmax, nside, np.inf, 1.0e-5, cd_solve.tr_cg, cd_solve.cache_mem()])
+    return chain
+
+
 class cinv(object):
     def __init__(self, lib_dir, lmax):
         self.lib_dir = lib_dir
@@ -103,11 +127,7 @@ class cinv_t(cinv):
         self.marge_maps = marge_maps
         pcf = os.path.join(lib_dir, "dense.pk") if pcf == 'default' else ''
         if chain_descr is None:
-            chain_descr = \
-                [[3, ["split(dense(" + pcf + "), 64, diag_cl)"], 256, 128, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
-                 [2, ["split(stage(3),  256, diag_cl)"], 512, 256, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
-                 [1, ["split(stage(2),  512, diag_cl)"], 1024, 512, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
-                 [0, ["split(stage(1), 1024, diag_cl)"], lmax, nside, np.inf, 1.0e-5, cd_solve.tr_cg, cd_solve.cache_mem()]]
+            chain_descr = default_chain_descr('t', lmax, nside, pcf)
         n_inv_filt = util.jit(opfilt_tt.alm_filter_ninv, ninv, transf_dl, marge_monopole=marge_monopole,
                               marge_dipole=marge_dipole, marge_maps=marge_maps)
         self.chain_descr = chain_descr
@@ -196,10 +216,7 @@ class cinv_p(cinv):
         self.ninv = ninv
         pcf = os.path.join(lib_dir, "dense.pk") if pcf == 'default' else None
         if chain_descr is None:
-            chain_descr = \
-                [[2, ["split(dense(%s), 32, diag_cl)" % pcf], 512, 256, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
-                 [1, ["split(stage(2),  512, diag_cl)"], 1024, 512, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
-                 [0, ["split(stage(1), 1024, diag_cl)"], lmax, nside, np.inf, 1.0e-5, cd_solve.tr_cg, cd_solve.cache_mem()]]
+            chain_descr = default_chain_descr('p', lmax, nside, pcf)
         n_inv_filt = util.jit(opfilt_pp.alm_filter_ninv, ninv, transf[0:lmax + 1], b_transf_b=transf_blm,
                               marge_umaps=marge_umaps, marge_qmaps=marge_qmaps)
         self.chain_descr = chain_descr
@@ -317,11 +334,7 @@ class cinv_tp(object):
         self.rescal_cl = rescal_cl
         if chain_descr is None:
             pcf = os.path.join(lib_dir, "dense_tp.pk") if pcf == 'default' else None
-            chain_descr = \
-                [[3, ["split(dense(%s), 64, diag_cl)" % pcf], 256, 128, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
-                 [2, ["split(stage(3),  256, diag_cl)"], 512, 256, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
-                 [1, ["split(stage(2),  512, diag_cl)"], 1024, 512, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
-                 [0, ["split(stage(1), 1024, diag_cl)"], lmax, nside, np.inf, 1.0e-5, cd_solve.tr_cg, cd_solve.cache_mem()]]
+            chain_descr = default_chain_descr('tp', lmax, nside, pcf)
         n_inv_filt = util.jit(opfilt_tp.alm_filter_ninv, ninv, transf_dls['t'], b_transf_e=transf_dls['e'], b_transf_b=transf_dls['b'],
                               marge_maps_t=marge_maps_t, marge_monopole=marge_monopole, marge_dipole=marge_dipole)
         self.chain_descr = chain_descr
