@@ -243,7 +243,10 @@ static int plan_create_impl(int nside, int lmax, int rank, int nranks, pl_plan *
     // Bluestein tables) or, for the short polar rings, aliased rings and anything unusual, by the LDS-resident generic
     // kernel.  PLSHTS_FFT_LEGACY=1 sends every pair to the generic kernel.
     DevFFT &F = p->F;
-    const bool all_legacy = getenv("PLSHTS_FFT_LEGACY") && atoi(getenv("PLSHTS_FFT_LEGACY")) != 0;
+    // (PLSHTS_FFT_LEGACY_NSIDE=n: every ring of the grids up to nside n in the generic kernel -- one launch per stage instead of one per
+    // ring-length class, and the template projection of the CG operator folded into it)
+    const bool all_legacy = (getenv("PLSHTS_FFT_LEGACY") && atoi(getenv("PLSHTS_FFT_LEGACY")) != 0) ||
+                            (getenv("PLSHTS_FFT_LEGACY_NSIDE") && nside <= atoi(getenv("PLSHTS_FFT_LEGACY_NSIDE")));
     std::vector<int> K2of(nside + 1, 0), MofA(nside + 1, 0), clsA(nside + 1, -1), splitA(nside + 1, 0);
     // smallest half-size for which a Bluestein ring is split into two half-size convolutions (PLSHTS_FFT_SPLIT: 0 = never)
     const int split_min = getenv("PLSHTS_FFT_SPLIT") ? atoi(getenv("PLSHTS_FFT_SPLIT")) : 512;
