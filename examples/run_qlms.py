@@ -48,10 +48,9 @@ def main():
     if hasattr(par.ivfs, 'filter_sims'):  # conjugate-gradient filters: this rank's simulations in block solves (several per solve)
         for lab in ('t', 'p'):
             idxs = [idx for idx, l in mine if l == lab]
-            if idxs:
-                print('rank %s filtering sims %s %s in block solves' % (mpi.rank, idxs, lab))
-                par.ivfs.filter_sims(idxs, fields=lab)
-        mine = []
+            if idxs and par.ivfs.filter_sims(idxs, fields=lab):
+                print('rank %s filtered sims %s %s in block solves' % (mpi.rank, idxs, lab))
+                mine = [(idx, l) for idx, l in mine if l != lab]
     for i, (idx, lab) in enumerate(mine):
         print('rank %s filtering sim %s %s, job %s in %s' % (mpi.rank, idx, lab, i, len(jobs[mpi.rank::mpi.size])))
         if lab == 't':

@@ -478,7 +478,8 @@ class library_cinv_sepTP(filt_simple.library_sepTP):
         """Filters (and caches) the simulations `idxs` that are not cached yet, `batch` at a time in block solves of the CG
         (cinv_t / cinv_p.apply_ivf_batch: every launch of a solve carries the whole block) -- what the driver's filtering phase
         calls instead of looping over get_sim_tlm / get_sim_elm one simulation at a time (run_qlms.py:57-62).  Same cache files, same
-        alms.  batch: block size (default $PLENS_CG_BATCH or 4; 1 = one solve per simulation)."""
+        alms.  batch: block size (default $PLENS_CG_BATCH or 4; 1 = one solve per simulation).  Returns True (the wrappers of
+        filt_util forward the call and report whether the library underneath took it)."""
         if batch is None:
             batch = int(os.environ.get('PLENS_CG_BATCH', '4'))
         for a in fields:
@@ -504,6 +505,7 @@ class library_cinv_sepTP(filt_simple.library_sepTP):
                         ent[n] = x.clone()  # (rows of the block solution: own storage, so that the block can be released)
                         if self.cache:
                             hp.write_alm(self._fn(n, i), dev.to_host(ent[n]), overwrite=True)
+        return True
 
     def get_tmliklm(self, idx):
         return hp.almxfl(self.get_sim_tlm(idx), self.cinv_t.cl['tt'])

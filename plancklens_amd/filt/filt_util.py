@@ -27,6 +27,11 @@ class _ivfs_view(object):
     def _fl(self, field, fl):
         return fl
 
+    def filter_sims(self, idxs, **kwargs):
+        """block filtering of the wrapped library where it offers it (filt_cinv.library_cinv_sepTP.filter_sims); True if done"""
+        inner = getattr(self.ivfs, 'filter_sims', None)
+        return bool(inner is not None and inner([self._idx(i) for i in idxs], **kwargs))
+
     # the protocol, forwarded
     def get_fmask(self):
         return self.ivfs.get_fmask()

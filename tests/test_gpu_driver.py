@@ -120,3 +120,38 @@ def test_run_qlms_with_device_side_sims(tmp_path):
     from plancklens_amd import hp
     qlm = hp.read_alm(os.path.join(temp, 'qlms_dd', 'sim_p_0001.fits'))
     assert np.all(np.isfinite(qlm.real)) and np.abs(qlm).max() > 0
+
+
+def test_run_qlms_masked_sky_cg_filters(tmp_path):
+    """The driver over params/anisofilt_example.py (the structure of the reference's params/anisofilt_example.py: masked sky,
+    cinv_t + cinv_p with the default multigrid chains and dense coarse preconditioners, library_ftl on top) at nside 512, lmax 1024:
+    the filtering phase runs in block solves (library_cinv_sepTP.filter_sims through the library_ftl wrapper), the estimators are
+    built from the cached filtered alms, and a one-by-one filtering of the same simulation gives the same alm."""
+    env = dict(os.environ, PLENS=str(tmp_path), PLENS_NSIDE='512', PLENS_LMAX='1024', PLENS_NSIMS='10', PLENS_CG_BATCH='3')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'examples', 'run_qlms.py'), os.path.join(ROOT, 'params', 'anisofilt_example.py'),
+           '-imin', '0', '-imax', '2', '-k', 'p', '-ivt', '-ivp', '-dd']
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    log = out.stdout.decode()
+    assert out.returncode == 0, log[-3000:]
+    assert 'filtered sims [0, 1, 2] t in block solves' in log and 'filtered sims [0, 1, 2] p in block solves' in log, log[-3000:]
+    temp = os.path.join(str(tmp_path), 'temp', 'anisofilt_example')
+    for f in ['ivfs/sim_0000_tlm.fits', 'ivfs/sim_0002_elm.fits', 'ivfs/sim_0001_blm.fits', 'cinv_t/dense.pk', 'cinv_p/dense.pk', 'cinv_t/ftl.dat',
+              'qlms_dd/sim_p_0002.fits', 'qlms_dd/sim_x_0000.fits']:
+        assert os.path.exists(os.path.join(temp, f)), f
+    # the same simulation filtered by itself (fresh libraries over the same caches of masks and dense preconditioners)
+    sys.path.insert(0, ROOT)
+    os.environ.update({k: env[k] for k in ('PLENS', 'PLENS_NSIDE', 'PLENS_LMAX', 'PLENS_NSIMS')})
+    try:
+        from importlib.machinery import SourceFileLoader
+        from plancklens_amd import dev, hp
+        par = SourceFileLoader('aniso_par', os.path.join(ROOT, 'params', 'anisofilt_example.py')).load_module()
+        blk = hp.read_alm(os.path.join(temp, 'ivfs', 'sim_0001_tlm.fits'))
+        one = par.cinv_t.apply_ivf(par.sims.get_sim_tmap(1))
+        assert np.abs(blk).max() > 0 and np.abs(np.asarray(one) - blk).max() < 1e-10 * np.abs(blk).max()
+        qlm = hp.read_alm(os.path.join(temp, 'qlms_dd', 'sim_p_0001.fits'))
+        assert hp.Alm.getlmax(qlm.size) == 2048 and np.all(np.isfinite(qlm.real)) and np.abs(qlm).max() > 0
+    finally:
+        for k in ('PLENS', 'PLENS_NSIDE', 'PLENS_LMAX', 'PLENS_NSIMS'):
+            os.environ.pop(k, None)
