@@ -214,6 +214,17 @@ int pl_cg_fwd_tt_b(pl_plan *plan, int nb, const double *alm_in, const double *fl
 int pl_cg_fwd_pp_b(pl_plan *plan, int nb, const double *elm_in, const double *blm_in, const double *fl_in, const double *n_inv,
                    const double *elm_add, const double *blm_add, const double *fl_add_e, const double *fl_add_b, double *elm_out,
                    double *blm_out, const double *fl_out, void *stream);
+/* Monopole + dipole marginalisation with the templates (1, x, y, z of the pixel centres: template_removal.py:116-150) evaluated from
+ * the ring geometry of the plan instead of read as stored maps -- 4 passes over the map instead of 11, three launches:
+ *   tmap <- n_inv tmap - n_inv (d_0 + d_1 x + d_2 y + d_3 z),  d = pinv c,  c_k = sum_i (1, x, y, z)_k,i n_inv_i tmap_i,
+ * for nb maps back to back; pinv_dev = (P^t N^-1 P)^-1 (4 x 4, row-major, device memory); scratch_dev:
+ * pl_template_md_scratch_doubles(plan, nb) doubles.  pl_cg_fwd_tt_md_b is pl_cg_fwd_tt_b with this projection (on every grid: the
+ * stored-map form folded into the ring-FFT launches is what the all-generic coarse grids use, pl_plan_fft_all_generic). */
+int pl_template_project_md_b(pl_plan *plan, int nb, double *tmap, const double *n_inv, const double *pinv_dev, double *scratch_dev, void *stream);
+int64_t pl_template_md_scratch_doubles(const pl_plan *plan, int nb);
+int pl_plan_fft_all_generic(const pl_plan *plan);
+int pl_cg_fwd_tt_md_b(pl_plan *plan, int nb, const double *alm_in, const double *fl_in, const double *n_inv, const double *pinv_dev,
+                      double *scratch_dev, const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out, void *stream);
 /* pl_cg_fwd_pp_b for a polarization noise model with a QU cross term (three maps QQ, QU, UU; opfilt_pp.py:295-300): the weighting is
  * one pass of pl_map_qu_weight between the two ring-FFT stages.  nb = 1 for a single right-hand side. */
 int pl_cg_fwd_pp_qu_b(pl_plan *plan, int nb, const double *elm_in, const double *blm_in, const double *fl_in, const double *n_qq,

@@ -55,6 +55,8 @@ void launch_qe_lens_product(int64_t n, const double *tmap, const double *gt, con
 void launch_map_cmul(int64_t n, const double *ar, const double *ai, double s1, const double *br, const double *bi, double s2,
                      double sign, double *outr, double *outi, int accumulate, hipStream_t st);
 void launch_fma_peak(int mode, int iters, double *out, int nblk, hipStream_t st);
+void launch_template_project_md(const DevPlan &P, int nb, double *t, const double *n_inv, int weighted, const double *pinv, double *scratch,
+                                hipStream_t st);
 void launch_phase_pack(const DevPlan &P, int ncomp, double *phase, double *buf, int pair0, int pstride, int mg0, int mgstride, bool unpack, hipStream_t st);
 void launch_alm_keep_mgroups(int lmax, double *alm, int mg0, int mgstride, int nb, hipStream_t st);
 }  // namespace plshts
@@ -813,18 +815,20 @@ int pl_template_project(int64_t npix, int nmodes, double *tmap, const double *n_
 // ride in the two FFT launches (NinvProj); on the finer grids they are the two pl_template_project launches between the transforms.
 static int cg_fwd_tt_impl(pl_plan *p, int nb, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *pmat,
                           const double *rmat, double *scratch, const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out,
-                          void *stream)
+                          void *stream, const double *pinv_md = nullptr)
 {
     if (!p) return fail("null plan");
     if (!alm_in || !alm_out || !n_inv) return fail("pl_cg_fwd_tt: null alm / n_inv pointer");
-    if (nmodes < 0 || nmodes > PL_TEMPLATE_MAX_MODES || (nmodes > 0 && (!pmat || !rmat || !scratch))) return fail("pl_cg_fwd_tt: bad template arguments");
+    // pinv_md: the templates are exactly (monopole, dipole) and evaluated from the ring geometry (k_tproj_md_*): nmodes = 4, no matrices
+    if (pinv_md && (nmodes != 4 || !scratch)) return fail("pl_cg_fwd_tt_md: nmodes = 4 and a scratch buffer are required");
+    if (nmodes < 0 || nmodes > PL_TEMPLATE_MAX_MODES || (nmodes > 0 && !pinv_md && (!pmat || !rmat || !scratch))) return fail("pl_cg_fwd_tt: bad template arguments");
     if ((alm_add == nullptr) != (fl_add == nullptr)) return fail("pl_cg_fwd_tt: alm_add and fl_add come together");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const DevPlan &P = p->P;
     if (grow(p, &p->phase, &p->phase_cap, pl_plan_phase_doubles(p, 0) * nb) || grow(p, &p->wmap, &p->wmap_cap, P.npix * nb)) return 1;
     if (legendre_synth_impl(p, 0, alm_in, fl_in, p->phase, stream, false, nb)) return 1;
     // the weighting always rides in the synthesis-side FFT kernels; the projection too where every ring runs in the generic kernel
-    const bool fused = nmodes == 0 || (fft_all_generic(P, p->F) && nmodes <= kFuseModes);
+    const bool fused = nmodes == 0 || (!pinv_md && fft_all_generic(P, p->F) && nmodes <= kFuseModes);
     NinvProj W;
     W.n_inv = n_inv;
     if (fused && nmodes > 0) {
@@ -835,8 +839,9 @@ static int cg_fwd_tt_impl(pl_plan *p, int nb, const double *alm_in, const double
         ProfScope ps(p, PK_FFT_SYNTH, st);
         HIPCHK(launch_phase2map(P, p->F, p->fs, mlim_of(p, 0), nb, p->phase, p->wmap, st, &W));
     }
-    if (!fused) {  // the map arrives weighted: coefficients and projection only (n_inv null)
-        launch_template_project(P.npix, nmodes, p->wmap, nullptr, pmat, rmat, scratch, st, nb);
+    if (!fused) {  // the map arrives weighted: coefficients and projection only
+        if (pinv_md) launch_template_project_md(P, nb, p->wmap, n_inv, 1, pinv_md, scratch, st);
+        else launch_template_project(P.npix, nmodes, p->wmap, nullptr, pmat, rmat, scratch, st, nb);
         HIPCHK(hipGetLastError());
     }
     {
@@ -855,6 +860,27 @@ int pl_cg_fwd_tt(pl_plan *p, const double *alm_in, const double *fl_in, const do
                  double *scratch, const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out, void *stream)
 {
     return cg_fwd_tt_impl(p, 1, alm_in, fl_in, n_inv, nmodes, pmat, rmat, scratch, alm_add, fl_add, alm_out, fl_out, stream);
+}
+
+int pl_plan_fft_all_generic(const pl_plan *p) { return p ? (fft_all_generic(p->P, p->F) ? 1 : 0) : 0; }
+
+int64_t pl_template_md_scratch_doubles(const pl_plan *p, int nb) { return p ? (int64_t)nb * 4 * (p->P.npairs + 1) : 0; }
+
+int pl_template_project_md_b(pl_plan *p, int nb, double *tmap, const double *n_inv, const double *pinv_dev, double *scratch, void *stream)
+{
+    if (!p || !tmap || !n_inv || !pinv_dev || !scratch) return fail("pl_template_project_md_b: null pointer");
+    PL_NB_CHECK("pl_template_project_md_b");
+    launch_template_project_md(p->P, nb, tmap, n_inv, 0, pinv_dev, scratch, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_cg_fwd_tt_md_b(pl_plan *p, int nb, const double *alm_in, const double *fl_in, const double *n_inv, const double *pinv_dev, double *scratch,
+                      const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out, void *stream)
+{
+    PL_NB_CHECK("pl_cg_fwd_tt_md_b");
+    if (!pinv_dev) return fail("pl_cg_fwd_tt_md_b: null pinv");
+    return cg_fwd_tt_impl(p, nb, alm_in, fl_in, n_inv, 4, nullptr, nullptr, scratch, alm_add, fl_add, alm_out, fl_out, stream, pinv_dev);
 }
 
 int pl_cg_fwd_tt_b(pl_plan *p, int nb, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *pmat, const double *rmat,

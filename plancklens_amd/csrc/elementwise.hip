@@ -548,6 +548,109 @@ __global__ __launch_bounds__(256) void k_tproj_apply(int64_t n, int nmodes, int 
     }
 }
 
+// ---- monopole + dipole marginalisation with the templates evaluated from the ring geometry ---------------------------------------
+// The templates of template_removal.py:116-150 are (1, x, y, z) of the pixel centres.  Read as stored maps (k_tproj_*) they cost 4
+// template rows in the coefficient pass and 4 rows of R in the projection pass: 11 passes over a map for the two launches.  Here a
+// workgroup owns a ring pair (z = +- cos theta, sin theta, phi_j = phi0 + 2 pi j / n known from the plan) and evaluates x, y per pixel
+// with one sincospi: 4 passes (map in; map in, n_inv in, map out), at the price of a third tiny launch that adds the ring sums.
+//   coeffs:  parts[b][k][pair] = sum over the pair's pixels of (1, x, y, z)_k u_i,  u = n_inv t (stored back) or t itself (weighted = 1)
+//   reduce:  c_k = sum_pairs parts (fixed order), d = Pinv c  (Pinv = (P^t N^-1 P)^-1, symmetric 4 x 4)
+//   apply:   t_i -= n_inv_i (d_0 + d_1 x_i + d_2 y_i + d_3 z_i)
+// Up to kProjChunk maps of a block share the geometry per pass.  Deterministic (fixed trees), batch entries bit-identical to single calls.
+__global__ __launch_bounds__(256) void k_tproj_md_coeffs(DevPlan P, int nb, double *__restrict__ t_, const double *__restrict__ n_inv, int weighted,
+                                                         double *__restrict__ parts)
+{
+    __shared__ double red[kProjChunk][4][4];
+    const int ip = blockIdx.x, b0 = blockIdx.y * kProjChunk, nbc = min(kProjChunk, nb - b0);
+    const int n = P.nphi[ip];
+    const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
+    const double z = P.cth[ip], s = P.sth[ip], ph0 = P.phi0[ip] * 0.31830988618379067154, inv_n2 = 2.0 / n;
+    double acc[kProjChunk][4];
+#pragma unroll
+    for (int b = 0; b < kProjChunk; ++b) acc[b][0] = acc[b][1] = acc[b][2] = acc[b][3] = 0.0;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        double sn, cs;
+        sincospi(ph0 + j * inv_n2, &sn, &cs);
+        const double x = s * cs, y = s * sn;
+        const double wn = (weighted || !n_inv) ? 1.0 : n_inv[on + j], ws = (weighted || !n_inv || os < 0) ? 1.0 : n_inv[os + j];
+#pragma unroll
+        for (int b = 0; b < kProjChunk; ++b) {
+            if (b < nbc) {
+                double *tb = t_ + (int64_t)(b0 + b) * P.npix;
+                double un = tb[on + j], us = os >= 0 ? tb[os + j] : 0.0;
+                if (!weighted && n_inv) {
+                    un *= wn; tb[on + j] = un;
+                    if (os >= 0) { us *= ws; tb[os + j] = us; }
+                }
+                const double sum = un + us;
+                acc[b][0] += sum;
+                acc[b][1] = fma(x, sum, acc[b][1]);
+                acc[b][2] = fma(y, sum, acc[b][2]);
+                acc[b][3] = fma(z, un - us, acc[b][3]);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int b = 0; b < kProjChunk; ++b)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double v = acc[b][k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) red[b][k][wave] = v;
+        }
+    __syncthreads();
+    if ((int)threadIdx.x < 4 * nbc) {
+        const int b = threadIdx.x >> 2, k = threadIdx.x & 3;
+        parts[((int64_t)(b0 + b) * 4 + k) * P.npairs + ip] = (red[b][k][0] + red[b][k][1]) + (red[b][k][2] + red[b][k][3]);
+    }
+}
+__global__ __launch_bounds__(256) void k_tproj_md_reduce(int npairs, const double *__restrict__ parts, const double *__restrict__ pinv,
+                                                         double *__restrict__ d)
+{
+    __shared__ double c[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, k = threadIdx.x >> 6;  // one wavefront per mode
+    double v = 0.0;
+    for (int j = lane; j < npairs; j += 64) v += parts[((int64_t)b * 4 + k) * npairs + j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) c[k] = v;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int r = threadIdx.x;
+        d[b * 4 + r] = ((pinv[4 * r] * c[0] + pinv[4 * r + 1] * c[1]) + pinv[4 * r + 2] * c[2]) + pinv[4 * r + 3] * c[3];
+    }
+}
+__global__ __launch_bounds__(256) void k_tproj_md_apply(DevPlan P, int nb, double *__restrict__ t_, const double *__restrict__ n_inv,
+                                                        const double *__restrict__ d_)
+{
+    const int ip = blockIdx.x, b0 = blockIdx.y * kProjChunk, nbc = min(kProjChunk, nb - b0);
+    const int n = P.nphi[ip];
+    const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
+    const double z = P.cth[ip], s = P.sth[ip], ph0 = P.phi0[ip] * 0.31830988618379067154, inv_n2 = 2.0 / n;
+    double d[kProjChunk][4];
+#pragma unroll
+    for (int b = 0; b < kProjChunk; ++b)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[b][k] = b < nbc ? d_[(b0 + b) * 4 + k] : 0.0;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        double sn, cs;
+        sincospi(ph0 + j * inv_n2, &sn, &cs);
+        const double x = s * cs, y = s * sn;
+        const double wn = n_inv[on + j], ws = os >= 0 ? n_inv[os + j] : 0.0;
+#pragma unroll
+        for (int b = 0; b < kProjChunk; ++b) {
+            if (b < nbc) {
+                double *tb = t_ + (int64_t)(b0 + b) * P.npix;
+                const double h = fma(d[b][2], y, fma(d[b][1], x, d[b][0]));  // d0 + d1 x + d2 y
+                tb[on + j] = fma(-wn, fma(d[b][3], z, h), tb[on + j]);
+                if (os >= 0) tb[os + j] = fma(-ws, fma(-d[b][3], z, h), tb[os + j]);
+            }
+        }
+    }
+}
+
 // ---- dense mat-vec y = A x (the dense coarse preconditioner, dense.py:118-119,201-202,284-285) -------------------------
 // A row-major (nrows x ncols, leading dimension lda).  One wavefront per row: every trip the wave reads 1 KiB of the row
 // with 16-byte loads per lane (VEC = 2), four trips in flight; x comes from L2 / L1 (34 KiB at the 4290-column T block).
@@ -820,6 +923,16 @@ void launch_template_project(int64_t n, int nmodes, double *t, const double *n_i
         hipLaunchKernelGGL(k_tproj_coeffs<256>, dim3(nparts, nb), dim3(256), 0, st, n, nmodes, t, n_inv, pm, parts);
         hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n), nb), dim3(256), 0, st, n, nmodes, nparts, t, rm, parts);
     }
+}
+// scratch: nb x 4 x npairs partial sums followed by nb x 4 coefficients
+void launch_template_project_md(const DevPlan &P, int nb, double *t, const double *n_inv, int weighted, const double *pinv, double *scratch,
+                                hipStream_t st)
+{
+    const int nchunk = (nb + kProjChunk - 1) / kProjChunk;
+    double *d = scratch + (int64_t)nb * 4 * P.npairs;
+    hipLaunchKernelGGL(k_tproj_md_coeffs, dim3(P.npairs, nchunk), dim3(256), 0, st, P, nb, t, n_inv, weighted, scratch);
+    hipLaunchKernelGGL(k_tproj_md_reduce, dim3(nb), dim3(256), 0, st, P.npairs, scratch, pinv, d);
+    hipLaunchKernelGGL(k_tproj_md_apply, dim3(P.npairs, nchunk), dim3(256), 0, st, P, nb, t, n_inv, d);
 }
 void launch_copy_slim(const double *src, double *dst, int64_t ndoubles, int nblocks, hipStream_t st)
 {

@@ -383,6 +383,33 @@ def template_project(tmap, n_inv, pmat, rmat):
     return tmap
 
 
+_TPROJ_MD_SCRATCH = {}
+
+
+def tproj_md_scratch(ndoubles):
+    """the per-device scratch of pl_template_project_md_b / pl_cg_fwd_tt_md_b (grows; outgrown buffers stay alive for captured graphs)"""
+    d = torch.cuda.current_device()
+    cur = _TPROJ_MD_SCRATCH.get(d)
+    if cur is None or cur[-1].numel() < ndoubles:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('template-projection scratch requested while a HIP graph is being captured')
+        _TPROJ_MD_SCRATCH.setdefault(d, []).append(torch.empty(int(ndoubles), dtype=torch.float64, device=device()))
+    return _TPROJ_MD_SCRATCH[d][-1]
+
+
+def template_project_md(tmap, n_inv, nside, lmax, pinv):
+    """tmap <- n_inv tmap with monopole and dipole projected out, the templates evaluated from the ring geometry (pl_template_project_md_b);
+    tmap [npix] or a block [nb, npix]; pinv: (P^t N^-1 P)^-1 as a (4, 4) device tensor.  Any plan of this nside serves (geometry only)."""
+    from . import shts
+    plan = shts.get_plan(nside, lmax)
+    nb, n = bshape(tmap)
+    assert n == plan.npix and n_inv.numel() == n and tmap.is_contiguous() and n_inv.is_contiguous() and pinv.numel() == 16 and pinv.is_contiguous()
+    L = _lib.lib()
+    scratch = tproj_md_scratch(L.pl_template_md_scratch_doubles(plan.h, nb))
+    _lib.check(L.pl_template_project_md_b(plan.h, nb, tmap.data_ptr(), n_inv.data_ptr(), pinv.data_ptr(), scratch.data_ptr(), stream_ptr()))
+    return tmap
+
+
 def gemv(amat, x, out=None):
     """y = A x on the device (pl_gemv): A a contiguous (nrows, ncols) float64 tensor, x float64 of ncols entries -- or a block
     [nb, ncols] -> [nb, nrows] (pl_gemv_b: the matrix is read once for all right-hand sides)."""

@@ -6,6 +6,8 @@ Y = (alm2map, alm2map_spin 2) and Y^t = npix / 4 pi (map2alm, map2alm_spin 2) ru
 the transforms; the inverse-noise maps, the T template projector and every CG vector live in HBM."""
 from __future__ import print_function
 
+import os
+
 import numpy as np
 import torch
 
@@ -299,10 +301,19 @@ class alm_filter_ninv(object):
         assert alm.lmaxt == alm.lmaxe == alm.lmaxb == lmax
         if self.one_call_ok(alm):  # the temperature and polarization blocks as the one-call operators of opfilt_tt / opfilt_pp
             fac = self.npix / (4. * np.pi)
-            pmat, rmat = self._proj_matrices()
             nb = alm.tlm.shape[0] if alm.tlm.dim() == 2 else 1
-            ttlm = shts.cg_fwd_tt(alm.tlm, self.nside, lmax, self.n_inv[0], fl_in=self.b_transf_t, fl_out=self.b_transf_t * fac,
-                                  pmat=pmat, rmat=rmat, scratch=dev.tproj_scratch(nb) if pmat is not None else None)
+            md = (len(self.templates_t) == 2 and isinstance(self.templates_t[0], template_removal.template_monopole)
+                  and isinstance(self.templates_t[1], template_removal.template_dipole) and os.environ.get('PLENS_TPROJ_MD', '1') != '0'
+                  and not shts.plan_all_generic(self.nside, lmax))
+            if md:  # monopole + dipole evaluated from the ring geometry (pl_cg_fwd_tt_md_b), as in opfilt_tt
+                if getattr(self, '_pinv_md_dev', None) is None:
+                    self._pinv_md_dev = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64).contiguous()
+                ttlm = shts.cg_fwd_tt(alm.tlm, self.nside, lmax, self.n_inv[0], fl_in=self.b_transf_t, fl_out=self.b_transf_t * fac,
+                                      pinv_md=self._pinv_md_dev)
+            else:
+                pmat, rmat = self._proj_matrices()
+                ttlm = shts.cg_fwd_tt(alm.tlm, self.nside, lmax, self.n_inv[0], fl_in=self.b_transf_t, fl_out=self.b_transf_t * fac,
+                                      pmat=pmat, rmat=rmat, scratch=dev.tproj_scratch(nb) if pmat is not None else None)
             telm, tblm = shts.cg_fwd_pp(alm.elm, alm.blm, self.nside, lmax, self.n_inv[1], fl_in=self.b_transf_e,
                                         fl_out=self.b_transf_e * fac)
             return teblm([ttlm, telm, tblm])

@@ -7,6 +7,7 @@ transforms; the inverse-noise map, the template projector and every CG vector li
 from __future__ import print_function
 
 import hashlib
+import os
 
 import numpy as np
 import torch
@@ -210,6 +211,10 @@ class alm_filter_ninv(object):
         lmax = hp.Alm.getlmax(alm.shape[-1] if isinstance(alm, torch.Tensor) else alm.size)
         fl_out = self.b_transf * (self.npix / (4. * np.pi))
         if self.one_call_ok(alm):
+            if self._md_only() and not shts.plan_all_generic(self.nside, lmax):
+                # monopole + dipole on a grid with register FFT classes: the templates come from the ring geometry, no stored maps
+                return shts.cg_fwd_tt(alm, self.nside, lmax, self.n_inv, fl_in=self.b_transf, fl_out=fl_out, pinv_md=self._pinv_md(),
+                                      alm_add=alm_add, fl_add=fl_add)
             pmat, rmat = self._proj_matrices()
             nb = alm.shape[0] if alm.dim() == 2 else 1
             return shts.cg_fwd_tt(alm, self.nside, lmax, self.n_inv, fl_in=self.b_transf, fl_out=fl_out, pmat=pmat, rmat=rmat,
@@ -218,6 +223,17 @@ class alm_filter_ninv(object):
         self.apply_map(tmap)
         ret = map2alm(tmap, lmax=lmax, iter=0, fl=fl_out)
         return ret if alm_add is None else dev.almxfl_add(ret, alm_add, fl_add, out=ret)
+
+    def _md_only(self):
+        """the templates are exactly (monopole, dipole): (1, x, y, z) of the pixel centres, which the kernels can evaluate themselves"""
+        if os.environ.get('PLENS_TPROJ_MD', '1') == '0' or len(self.templates) != 2:
+            return False
+        return isinstance(self.templates[0], template_removal.template_monopole) and isinstance(self.templates[1], template_removal.template_dipole)
+
+    def _pinv_md(self):
+        if getattr(self, '_pinv_md_dev', None) is None:
+            self._pinv_md_dev = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64).contiguous()
+        return self._pinv_md_dev
 
     def _proj_matrices(self):
         """All template modes as one device matrix P (nmodes x npix) and R = (P^t N^-1 P)^-1 P^t N^-1: the projection is two
@@ -239,6 +255,9 @@ class alm_filter_ninv(object):
 
     def apply_map(self, tmap):
         """tmap <- N^-1 tmap with the templates projected out (in place)."""
+        if self._md_only() and tmap.is_contiguous() and tmap.is_cuda and tmap.dtype == torch.float64:
+            dev.template_project_md(tmap, self.n_inv, self.nside, len(self.b_transf) - 1, self._pinv_md())
+            return
         pmat, rmat = self._proj_matrices()
         if pmat is None:
             tmap *= self.n_inv

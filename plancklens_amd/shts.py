@@ -253,7 +253,13 @@ def lane_active():
     return _lane_active()
 
 
-def cg_fwd_tt(alm, nside, lmax, n_inv, fl_in=None, fl_out=None, pmat=None, rmat=None, scratch=None, alm_add=None, fl_add=None):
+def plan_all_generic(nside, lmax):
+    """True when every ring of this grid runs in the generic ring-FFT kernel (the coarse levels of the CG chains): the CG operator
+    then folds the stored-map template projection into its two FFT launches"""
+    return bool(_lib.lib().pl_plan_fft_all_generic(get_plan(nside, lmax).h))
+
+
+def cg_fwd_tt(alm, nside, lmax, n_inv, fl_in=None, fl_out=None, pmat=None, rmat=None, scratch=None, alm_add=None, fl_add=None, pinv_md=None):
     """fl_out Y^t [N^-1 - N^-1 P (P^t N^-1 P)^-1 P^t N^-1] Y (fl_in alm) + fl_add alm_add on the device, one call (pl_cg_fwd_tt):
     fwd_op.calc of plancklens/qcinv/opfilt_tt.py:67-73.  pmat, rmat: (nmodes, npix) device matrices or None."""
     plan = get_plan(nside, lmax)
@@ -264,13 +270,20 @@ def cg_fwd_tt(alm, nside, lmax, n_inv, fl_in=None, fl_out=None, pmat=None, rmat=
     if nmodes:
         assert pmat.shape == (nmodes, plan.npix) and rmat.shape == pmat.shape and pmat.is_contiguous() and rmat.is_contiguous()
         assert scratch is not None and scratch.numel() >= nb * 16 * 256
+    if pinv_md is not None:  # monopole + dipole from the ring geometry (pl_cg_fwd_tt_md_b): no template matrices
+        assert pmat is None and pinv_md.numel() == 16 and pinv_md.is_contiguous() and pinv_md.dtype == torch.float64
+        from . import dev as _dev
+        scratch = _dev.tproj_md_scratch(_lib.lib().pl_template_md_scratch_doubles(plan.h, nb))
     out = torch.empty_like(a)
     fi, fo = _fl_arg(fl_in, lmax, True), _fl_arg(fl_out, lmax, True)
     fa = _fl_arg(fl_add, lmax, True) if alm_add is not None else None
     if alm_add is not None:
         alm_add = alm_add.contiguous()
         assert alm_add.shape == a.shape and alm_add.dtype == torch.complex128
-    if a.dim() == 2:
+    if pinv_md is not None:
+        _lib.check(_lib.lib().pl_cg_fwd_tt_md_b(plan.h, nb, _ptr(a), _ptr(fi), _ptr(n_inv), _ptr(pinv_md), _ptr(scratch), _ptr(alm_add), _ptr(fa),
+                                                _ptr(out), _ptr(fo), _stream()))
+    elif a.dim() == 2:
         _lib.check(_lib.lib().pl_cg_fwd_tt_b(plan.h, nb, _ptr(a), _ptr(fi), _ptr(n_inv), nmodes, _ptr(pmat), _ptr(rmat), _ptr(scratch),
                                              _ptr(alm_add), _ptr(fa), _ptr(out), _ptr(fo), _stream()))
     else:

@@ -172,3 +172,30 @@ def test_cg_dot_axpy_one_launch(lmaxs, lmin):
     for _ in range(200):  # the barrier words are reusable back to back
         dev.cg_dot_axpy(s1, q, s1, d, -1.0, den=dtad, lmin=lmin, one_launch=True)
     assert not dev.cg_barrier_timed_out()
+
+
+@pytest.mark.parametrize('nside', [1, 2, 16, 64, 512])
+def test_monopole_dipole_projection_from_the_ring_geometry(nside):
+    """pl_template_project_md_b (templates (1, x, y, z) evaluated per pixel from the plan's ring geometry) against pl_template_project
+    on the stored template maps of template_removal.template_monopole / template_dipole (template_removal.py:116-150), single maps and
+    a block of five (one full chunk of four and a remainder)."""
+    import torch
+    from plancklens_amd import dev, hp
+    rng = np.random.default_rng(nside)
+    npix = 12 * nside ** 2
+    x, y, z = hp.pix2vec(nside, np.arange(npix))
+    pm = np.stack([np.ones(npix), x, y, z])
+    ninv = (rng.random(npix) + 0.5) * (np.abs(z) > 0.2 if nside > 2 else 1.)
+    pinv = np.linalg.inv((pm * ninv) @ pm.T)
+    rm = pinv @ (pm * ninv)
+    t = rng.standard_normal((5, npix))
+    ref = t * ninv
+    ref = ref - (ref @ pm.T) @ rm
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    got = dev.template_project_md(d(t), d(ninv), nside, 2 * nside, d(pinv))
+    assert relrms(dev.to_host(got), ref) < 1e-13
+    one = dev.template_project_md(d(t[3]), d(ninv), nside, 2 * nside, d(pinv))
+    assert bool((one == got[3]).all())
+    if nside >= 16:
+        mat = dev.template_project(d(t[3]), d(ninv), d(pm), d(rm))
+        assert relrms(dev.to_host(one), dev.to_host(mat)) < 1e-13
