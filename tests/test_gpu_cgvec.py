@@ -4,6 +4,8 @@ single-matrix dense preconditioner against the alm -> rlm -> mat-vec -> alm rout
 import numpy as np
 import pytest
 
+from helpers import relrms
+
 pytestmark = pytest.mark.gpu
 
 
