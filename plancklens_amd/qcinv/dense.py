@@ -51,16 +51,16 @@ def _rlm_maps_dev(lmax, d):
 def alm2rlm(alm):
     """Complex alm -> real harmonic coefficients (m = 0 real part; sqrt(2) Re, sqrt(2) Im for m > 0)."""
     is_dev = isinstance(alm, torch.Tensor)
-    n = alm.numel() if is_dev else alm.size
+    n = alm.shape[-1] if is_dev else alm.size
     lmax = Alm.getlmax(n)
     ra, rr, ia, ir = _rlm_maps(lmax)
     rt2 = np.sqrt(2.)
-    if is_dev:
+    if is_dev:  # (a leading block dimension [nb, nalm] is carried along)
         d = alm.device
         dra, drr, dia, dir_, w2, _ = _rlm_maps_dev(lmax, d)
-        rlm = torch.zeros((lmax + 1) ** 2, dtype=torch.float64, device=d)
-        rlm[drr] = alm.real[dra] * w2
-        rlm[dir_] = alm.imag[dia] * rt2
+        rlm = torch.zeros(tuple(alm.shape[:-1]) + ((lmax + 1) ** 2,), dtype=torch.float64, device=d)
+        rlm[..., drr] = alm.real[..., dra] * w2
+        rlm[..., dir_] = alm.imag[..., dia] * rt2
         return rlm
     rlm = np.zeros((lmax + 1) ** 2)
     w = np.full(ra.size, rt2)
@@ -73,19 +73,19 @@ def alm2rlm(alm):
 def rlm2alm(rlm):
     """Inverse of alm2rlm."""
     is_dev = isinstance(rlm, torch.Tensor)
-    n = rlm.numel() if is_dev else len(rlm)
+    n = rlm.shape[-1] if is_dev else len(rlm)
     lmax = int(np.sqrt(n) - 1)
     assert (lmax + 1) ** 2 == n
     ra, rr, ia, ir = _rlm_maps(lmax)
     ir2 = 1.0 / np.sqrt(2.)
-    if is_dev:
+    if is_dev:  # (a leading block dimension is carried along)
         d = rlm.device
         dra, drr, dia, dir_, _, wi = _rlm_maps_dev(lmax, d)
-        re = torch.zeros(Alm.getsize(lmax), dtype=torch.float64, device=d)
+        re = torch.zeros(tuple(rlm.shape[:-1]) + (Alm.getsize(lmax),), dtype=torch.float64, device=d)
         im = torch.zeros_like(re)
-        re[dra] = rlm[drr] * wi
-        im[dia] = rlm[dir_] * ir2
-        return torch.complex(re, im)
+        re[..., dra] = rlm[..., drr] * wi
+        im[..., dia] = rlm[..., dir_] * ir2
+        return torch.complex(re, im).contiguous()
     alm = np.zeros(Alm.getsize(lmax), dtype=complex)
     w = np.full(ra.size, ir2)
     w[:lmax + 1] = 1.
@@ -158,11 +158,24 @@ class _pre_op_dense(object):
         ntmpl = self._ntmpl(fwd_op)
         print("computing dense preconditioner: lmax = %d, ntmpl = %d, size %d" % (lmax, ntmpl, nrlm))
         tmat = torch.zeros((nrlm, nrlm), dtype=torch.float64, device=dev.device())
-        trlm = torch.zeros(nrlm, dtype=torch.float64, device=dev.device())
-        for i in range(nrlm):
-            trlm[i] = 1.0
-            tmat[:, i] = self._to_rlm(fwd_op(self._to_alm(trlm)))
-            trlm[i] = 0.0
+        # The columns are fwd_op of the unit vectors (dense.py:77-84 applies it to one vector at a time: thousands of launch-bound
+        # coarse operators).  Here nbk unit vectors go through the operator as one block vector -- every launch carries all of them,
+        # each column bit-identical to the one-at-a-time result; an operator that does not take blocks gets them one by one.
+        nbk = max(1, min(int(os.environ.get('PLENS_DENSE_BLOCK', '32')), 64))
+        i0 = 0
+        while i0 < nrlm:
+            n_ = min(nbk, nrlm - i0)
+            blk = torch.zeros((n_, nrlm), dtype=torch.float64, device=dev.device())
+            blk[torch.arange(n_), i0 + torch.arange(n_)] = 1.0
+            try:
+                cols = self._to_rlm(fwd_op(self._to_alm(blk))) if n_ > 1 else None
+            except AssertionError:
+                cols, nbk = None, 1
+            if cols is None:
+                n_ = 1
+                cols = self._to_rlm(fwd_op(self._to_alm(blk[0].contiguous()))).unsqueeze(0)
+            tmat[:, i0:i0 + n_] = cols.t()
+            i0 += n_
         eigv, eigw = np.linalg.eigh(dev.to_host(tmat))
         assert np.all(eigv[ntmpl:] > 0.)
         eigv_inv = np.zeros_like(eigv)
@@ -232,11 +245,11 @@ class pre_op_dense_pp(_pre_op_dense):
         return 2 * (lmax + 1) ** 2
 
     def _to_rlm(self, alm):
-        return torch.cat([alm2rlm(alm.elm), alm2rlm(alm.blm)])
+        return torch.cat([alm2rlm(alm.elm), alm2rlm(alm.blm)], dim=-1)
 
     def _to_alm(self, rlm):
-        n = rlm.numel() // 2
-        return eblm([rlm2alm(rlm[:n]), rlm2alm(rlm[n:])])
+        n = rlm.shape[-1] // 2
+        return eblm([rlm2alm(rlm[..., :n]), rlm2alm(rlm[..., n:])])
 
 
 class pre_op_dense_tp(_pre_op_dense):
@@ -254,8 +267,8 @@ class pre_op_dense_tp(_pre_op_dense):
         return 3 * (lmax + 1) ** 2
 
     def _to_rlm(self, alm):
-        return torch.cat([alm2rlm(alm.tlm), alm2rlm(alm.elm), alm2rlm(alm.blm)])
+        return torch.cat([alm2rlm(alm.tlm), alm2rlm(alm.elm), alm2rlm(alm.blm)], dim=-1)
 
     def _to_alm(self, rlm):
-        n = rlm.numel() // 3
-        return teblm([rlm2alm(rlm[:n]), rlm2alm(rlm[n:2 * n]), rlm2alm(rlm[2 * n:])])
+        n = rlm.shape[-1] // 3
+        return teblm([rlm2alm(rlm[..., :n]), rlm2alm(rlm[..., n:2 * n]), rlm2alm(rlm[..., 2 * n:])])

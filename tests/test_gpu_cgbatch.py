@@ -283,3 +283,24 @@ def test_cinv_block_filtering_at_survey_size(tmp_path):
         assert relrms(lib.get_sim_tlm(i), ones[i]) < 1e-12
         assert relrms(lib.get_sim_elm(i), onesp[i][0]) < 1e-12 and relrms(lib.get_sim_blm(i), onesp[i][1]) < 1e-12
 
+
+
+def test_dense_preconditioner_built_through_block_vectors(monkeypatch):
+    """dense.pre_op_dense_tt / _pp / _tp.compute_minv (dense.py:57-285: fwd_op applied to every unit vector) with the unit vectors sent
+    through the operator 32 at a time as block vectors: the matrix equals the one-vector-at-a-time build bit for bit."""
+    from plancklens_amd import hp
+    from plancklens_amd.qcinv import dense, opfilt_pp, opfilt_tp, opfilt_tt
+    g = np.load(GOLD)
+    nside = 8
+    cl = {'tt': g['cl_tt'], 'ee': g['cl_ee'], 'bb': g['cl_bb'], 'te': g['cl_te']}
+    nt = hp.ud_grade(g['ninv_t'], nside, power=-2)
+    npol = hp.ud_grade(g['ninv_p'], nside, power=-2)
+    ops = [(dense.pre_op_dense_tt, opfilt_tt.fwd_op(cl, opfilt_tt.alm_filter_ninv(nt, g['transf'][:17], marge_monopole=True, marge_dipole=True)), 6),
+           (dense.pre_op_dense_pp, opfilt_pp.fwd_op(cl, opfilt_pp.alm_filter_ninv([npol], g['transf'][:17])), 5),
+           (dense.pre_op_dense_tp, opfilt_tp.fwd_op(cl, opfilt_tp.alm_filter_ninv([nt, npol], g['transf'][:17], marge_monopole=True, marge_dipole=True)), 4)]
+    for cls_, op, lmax in ops:
+        monkeypatch.setenv('PLENS_DENSE_BLOCK', '1')
+        one = cls_(lmax, op).minv
+        monkeypatch.setenv('PLENS_DENSE_BLOCK', '32')
+        blk = cls_(lmax, op).minv
+        assert bool((one == blk).all()), cls_.__name__
