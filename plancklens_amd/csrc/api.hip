@@ -266,8 +266,14 @@ static int plan_create_impl(int nside, int lmax, int rank, int nranks, pl_plan *
         for (int q = 1; q <= nside; ++q) {
             const int K = (mlmax[q] + 3) / 4 + 1;  // sub-DFT bins c = k1 or k1 - q with 4 |c| <= mlim + 3
             K2of[q] = K;
-            if (all_legacy || 2 * K + 1 >= q) continue;                 // aliased ring (mlim >= n / 2 - 5): generic kernel
-            if ((q & (q - 1)) == 0) { clsA[q] = cls_of(q); continue; }  // the ring's own sub-DFT length
+            if (all_legacy) continue;
+            // the ring's own sub-DFT length: no band limit needed, only one order per bin (mlim <= n / 2; the kernels know the bin n / 2 --
+            // the belt of a grid with lmax = 2 nside, which every coarse level of the CG chains is)
+            // (PLSHTS_FFT_NYQ = shortest sub-DFT routed this way, 0 = never: measured 17 % / 7 % faster stages (synthesis / analysis) at
+            // q = 2048, even at q <= 512, a slower analysis at q = 1024 -- the generic kernel runs those belts as well)
+            const int nyq_min = getenv("PLSHTS_FFT_NYQ") ? atoi(getenv("PLSHTS_FFT_NYQ")) : 2048;
+            if ((q & (q - 1)) == 0) { if ((nyq_min > 0 && q >= nyq_min) ? mlmax[q] <= 2 * q : 2 * K + 1 < q) clsA[q] = cls_of(q); continue; }
+            if (2 * K + 1 >= q) continue;                               // aliased ring (mlim >= n / 2 - 5): generic kernel
             int Na = 256;
             while (Na < q + 2 * K + 1) Na <<= 1;       // only the 2 K + 1 in-band bins are non-zero (synthesis) / needed (analysis)
             // Two half-size convolutions instead (ringfft.hip, SPLIT): output / input halves [0, Nh / 2) and [Nh / 2, q) with

@@ -673,8 +673,9 @@ __device__ __forceinline__ void fft8(double2 (&x)[8], double2 *lds, int tl_in, c
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// The register classes are only used for rings without aliasing (mlim < n / 2 - 5, see pl_plan_create), so every
-// spectrum bin k = 4 k1 + k2 holds at most one term: frequency +k when k <= mlim, else -(n - k) when n - k <= mlim.
+// The register classes are only used for rings without aliasing (Bluestein classes: mlim < n / 2 - 5; direct classes: mlim <= n / 2,
+// see pl_plan_create), so every spectrum bin k = 4 k1 + k2 holds at most one term: frequency +k when k <= mlim, else -(n - k) when
+// n - k <= mlim -- except the bin n / 2 of a direct ring with mlim = n / 2, which the kernels treat on its own.
 // Slot idx = tl + G j of a thread is sub-DFT bin k1 = idx (direct, or Bluestein input c = idx >= 0) or, in the
 // Bluestein classes, c = idx - N < 0, i.e. k1 = q + c.  sgn: +1 positive-frequency side, -1 negative side, 0 out of band.
 struct FastBin { int k1, cabs, sgn; };
@@ -753,6 +754,13 @@ __global__ __launch_bounds__(N / 8, 2) void k_phase2map_fast(DevPlan P, DevFFT F
                 double2 z;
                 z.x = have ? (b.sgn > 0 ? fn.x - fs.y : fn.x + fs.y) : 0.0;
                 z.y = have ? (b.sgn > 0 ? fn.y + fs.x : -fn.y + fs.x) : 0.0;
+                if (!blue && k2 == 0 && j == 4) {
+                    // direct rings with mlim = n / 2 (lmax = 2 nside on the belt): bin n / 2 = slot q / 2 of sub-DFT 0 (tl = 0, j = 4)
+                    // holds the order n / 2 from both sides, (f_N + i f_S) + (conj f_N + i conj f_S) = 2 Re f_N + 2 i Re f_S
+                    const bool nyq = have && tl == 0;
+                    z.x = nyq ? 2.0 * fn.x : z.x;
+                    z.y = nyq ? 2.0 * fs.x : z.y;
+                }
                 d[k2][j] = cmul(z, cw);
             }
             pj = cmul(pj, pstep);
@@ -878,7 +886,9 @@ __global__ __launch_bounds__(N / 8, 2) void k_map2phase_fast(DevPlan P, DevFFT F
         for (int j = 0; j < 8; ++j) {
             const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
             const int m = 4 * b.k1 + k2;
-            if (b.sgn > 0 && m <= ml) {
+            // (direct rings with mlim = n / 2: the order n / 2 sits in the first - side slot, q / 2 of sub-DFT 0, and mirrors into itself)
+            const bool nyq = !blue && k2 == 0 && j == 4 && tl == 0;
+            if ((b.sgn > 0 || nyq) && m <= ml) {
                 const int k1m = k2 == 0 ? (b.k1 == 0 ? 0 : q - b.k1) : q - 1 - b.k1;
                 const double2 a = cconj(own[j]);
                 const double2 vm = lds[swz(k1m)];
