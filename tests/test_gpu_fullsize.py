@@ -44,7 +44,7 @@ def _note(line):
             f.write(line + '\n')
 
 
-SIZES = [(2048, 2048), (4096, 4096), (2048, 4096)]  # the last: lmax_qlm = 4096 of the parameter file on nside 2048 (the belt carries the order n / 2: direct FFT classes with that bin treated on its own; every cap ring aliased: generic FFT kernel)
+SIZES = [(2048, 2048), (4096, 4096), (2048, 4096)]  # the last: lmax_qlm = 4096 of the parameter file on nside 2048 (the belt carries the order n / 2: direct FFT classes with that bin treated on its own)
 
 
 def mlim_rings(lmax, spin, cth, sth):
