@@ -208,6 +208,12 @@ int pl_cg_dot_axpy_b(int nb, int nf, const int *lmax, int lmin, const double *co
                      double sign1, double *const *y2, const double *const *x2, double sign2, const double *active_dev, void *stream);
 int pl_template_project_b(int64_t npix, int nmodes, int nb, double *tmap, const double *n_inv, const double *pmat, const double *rmat,
                           double *scratch_dev, void *stream);
+/* y_b -= rmat^t (pmat x_b), b < nb, vectors of n doubles, pmat / rmat (nmodes, n): the template projection of the CG operators applied
+ * in harmonic space -- B^t Y^t [N^-1 - N^-1 T (T^t N^-1 T)^-1 T^t N^-1] Y B x = B^t Y^t N^-1 Y B x - V (T^t N^-1 T)^-1 V^t x with
+ * V = B^t Y^t N^-1 T (reference: the bracket in pixel space, plancklens/qcinv/opfilt_tt.py:196-205, opfilt_pp.py:272-303).  x is only
+ * read.  scratch_dev as in pl_template_project_b.  Bit-reproducible; every entry equals the nb = 1 call. */
+int pl_lowrank_update_b(int64_t n, int nmodes, int nb, const double *x, double *y, const double *pmat, const double *rmat, double *scratch_dev,
+                        void *stream);
 int pl_cg_fwd_tt_b(pl_plan *plan, int nb, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *pmat,
                    const double *rmat, double *scratch_dev, const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out,
                    void *stream);

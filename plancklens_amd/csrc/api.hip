@@ -42,7 +42,7 @@ void launch_cg_fused(int nf, const int *lmax, int lmin, const double *const *a, 
 void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st,
                        const double *fl_hi = nullptr, int nb = 1);
 void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st,
-                             int nb = 1);
+                             int nb = 1, double *t_apply = nullptr);
 void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st, int nb = 1);
 void launch_gemv(int nrows, int ncols, int64_t lda, const double *A, const double *x, double *y, hipStream_t st);
 void launch_gemv_nb(int nrows, int ncols, int64_t lda, const double *A, int nb, const double *x, double *y, hipStream_t st);
@@ -736,6 +736,21 @@ int pl_template_project_b(int64_t npix, int nmodes, int nb, double *tmap, const 
     if (npix <= 0 || nmodes < 1 || nmodes > PL_TEMPLATE_MAX_MODES || !tmap || !n_inv || !pmat || !rmat || !scratch)
         return fail("pl_template_project_b: bad arguments (1 <= nmodes <= PL_TEMPLATE_MAX_MODES)");
     launch_template_project(npix, nmodes, tmap, n_inv, pmat, rmat, scratch, static_cast<hipStream_t>(stream), nb);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// y_b -= rmat^t (pmat x_b) for nb vectors of n doubles: a rank-nmodes update with the coefficient pass on one vector and the subtraction on
+// another.  It is how the CG operators project templates out in harmonic space: with V = B^t Y^t N^-1 T (one alm per template mode),
+//   B^t Y^t [N^-1 - N^-1 T (T^t N^-1 T)^-1 T^t N^-1] Y B x  =  B^t Y^t N^-1 Y B x  -  V (T^t N^-1 T)^-1 V^t x
+// (plancklens/qcinv/opfilt_tt.py:196-205 applies the bracket in pixel space), pmat = V with the weights of the real scalar product folded in,
+// rmat = (T^t N^-1 T)^-1 V, both as real (nmodes, 2 nalm) matrices.  The kernels are those of pl_template_project (fixed reduction trees).
+int pl_lowrank_update_b(int64_t n, int nmodes, int nb, const double *x, double *y, const double *pmat, const double *rmat, double *scratch, void *stream)
+{
+    PL_NB_CHECK("pl_lowrank_update_b");
+    if (n <= 0 || nmodes < 1 || nmodes > PL_TEMPLATE_MAX_MODES || !x || !y || !pmat || !rmat || !scratch)
+        return fail("pl_lowrank_update_b: bad arguments (1 <= nmodes <= PL_TEMPLATE_MAX_MODES)");
+    launch_template_project(n, nmodes, const_cast<double *>(x), nullptr, pmat, rmat, scratch, static_cast<hipStream_t>(stream), nb, y);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -896,32 +896,35 @@ void launch_cg_fused(int nf, const int *lmax, int lmin, const double *const *a, 
                            sign2, bar, active);
     }
 }
+// t_apply (optional): the projection is subtracted from this vector instead of t, which is then only read (n_inv null) -- the
+// rank-nmodes update y -= rm^t (pm x) of launch_lowrank_update
 void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st,
-                             int nb)
+                             int nb, double *t_apply)
 {
+    double *ta = t_apply ? t_apply : t;
     if (nb > 1 && nmodes <= kFuseModesB) {  // block vectors: the template rows read once per chunk of kProjChunk maps
         const int nchunk = (nb + kProjChunk - 1) / kProjChunk;
         if (n >= (int64_t)kProjParts * 4096) {
             hipLaunchKernelGGL(k_tproj_coeffs_b<1024>, dim3(kProjParts, nchunk), dim3(1024), 0, st, n, nmodes, nb, t, n_inv, pm, parts);
-            hipLaunchKernelGGL(k_tproj_apply_b, dim3(nblocks(n), nchunk), dim3(256), 0, st, n, nmodes, kProjParts, nb, t, rm, parts);
+            hipLaunchKernelGGL(k_tproj_apply_b, dim3(nblocks(n), nchunk), dim3(256), 0, st, n, nmodes, kProjParts, nb, ta, rm, parts);
         } else {
             int nparts = (int)((n + 2047) / 2048);
             if (nparts < 1) nparts = 1;
             if (nparts > kProjParts) nparts = kProjParts;
             hipLaunchKernelGGL(k_tproj_coeffs_b<256>, dim3(nparts, nchunk), dim3(256), 0, st, n, nmodes, nb, t, n_inv, pm, parts);
-            hipLaunchKernelGGL(k_tproj_apply_b, dim3(nblocks(n), nchunk), dim3(256), 0, st, n, nmodes, nparts, nb, t, rm, parts);
+            hipLaunchKernelGGL(k_tproj_apply_b, dim3(nblocks(n), nchunk), dim3(256), 0, st, n, nmodes, nparts, nb, ta, rm, parts);
         }
         return;
     }
     if (n >= (int64_t)kProjParts * 4096) {  // fine grids: 256 workgroups of 1024 threads
         hipLaunchKernelGGL(k_tproj_coeffs<1024>, dim3(kProjParts, nb), dim3(1024), 0, st, n, nmodes, t, n_inv, pm, parts);
-        hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n), nb), dim3(256), 0, st, n, nmodes, kProjParts, t, rm, parts);
+        hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n), nb), dim3(256), 0, st, n, nmodes, kProjParts, ta, rm, parts);
     } else {  // coarse grids: workgroups of 256 threads, 8 pixels per thread
         int nparts = (int)((n + 2047) / 2048);
         if (nparts < 1) nparts = 1;
         if (nparts > kProjParts) nparts = kProjParts;
         hipLaunchKernelGGL(k_tproj_coeffs<256>, dim3(nparts, nb), dim3(256), 0, st, n, nmodes, t, n_inv, pm, parts);
-        hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n), nb), dim3(256), 0, st, n, nmodes, nparts, t, rm, parts);
+        hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n), nb), dim3(256), 0, st, n, nmodes, nparts, ta, rm, parts);
     }
 }
 // scratch: nb x 4 x npairs partial sums followed by nb x 4 coefficients

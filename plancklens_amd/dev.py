@@ -383,6 +383,20 @@ def template_project(tmap, n_inv, pmat, rmat):
     return tmap
 
 
+def lowrank_update(y, x, pmat, rmat):
+    """y <- y - rmat^t (pmat x) in place (pl_lowrank_update_b): x, y alm (complex128) or real vectors, or blocks [nb, .] of them, read as
+    real vectors of n doubles; pmat, rmat: real (nmodes, n) device matrices.  The harmonic-space form of the template projection."""
+    nmodes, n = pmat.shape
+    nb, nx = bshape(x)
+    if x.is_complex():
+        nx *= 2
+    assert rmat.shape == pmat.shape and nx == n and y.shape == x.shape and y.dtype == x.dtype and x.is_contiguous() and y.is_contiguous()
+    assert pmat.is_contiguous() and rmat.is_contiguous() and pmat.dtype == torch.float64 and 1 <= nmodes <= TEMPLATE_MAX_MODES
+    _lib.check(_lib.lib().pl_lowrank_update_b(n, nmodes, nb, x.data_ptr(), y.data_ptr(), pmat.data_ptr(), rmat.data_ptr(),
+                                             tproj_scratch(nb).data_ptr(), stream_ptr()))
+    return y
+
+
 _TPROJ_MD_SCRATCH = {}
 
 

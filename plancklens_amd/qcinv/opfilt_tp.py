@@ -286,6 +286,25 @@ class alm_filter_ninv(object):
             self._rmat = torch.mm(pinv, self._pmat * self.n_inv[0].unsqueeze(0)).contiguous()
         return self._pmat, self._rmat
 
+    def _harm_matrices(self, lmax):
+        """the temperature templates in harmonic space, V_k = B_t^t Y^t N_T^-1 T_k (opfilt_tt.alm_filter_ninv._harm_matrices)"""
+        cache = self.__dict__.setdefault('_harm', {})
+        if lmax not in cache:
+            fl_out = self.b_transf_t * (self.npix / (4. * np.pi))
+            rows = []
+            for t in self.templates_t:
+                for i in range(t.nmodes):
+                    tmap = self.n_inv[0].clone()
+                    t.apply_mode(tmap, i)
+                    vlm = dev.to_dev(map2alm(tmap, lmax=lmax, iter=0, fl=fl_out), torch.complex128).contiguous()
+                    rows.append(torch.view_as_real(vlm).reshape(-1))
+            v = torch.stack(rows).contiguous()
+            w = torch.full((v.shape[1] // 2,), 2., dtype=torch.float64, device=v.device)
+            w[:lmax + 1] = 1.
+            pinv = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64)
+            cache[lmax] = ((v * w.repeat_interleave(2).unsqueeze(0)).contiguous(), torch.mm(pinv, v).contiguous())
+        return cache[lmax]
+
     def one_call_ok(self, alm):
         """pl_cg_fwd_tt + pl_cg_fwd_pp apply: device vectors, (TT, QQ = UU) noise, one polarization beam, the module's transforms"""
         same_b = self.b_transf_b is self.b_transf_e or np.array_equal(self.b_transf_e, self.b_transf_b)
@@ -305,7 +324,12 @@ class alm_filter_ninv(object):
             md = (len(self.templates_t) == 2 and isinstance(self.templates_t[0], template_removal.template_monopole)
                   and isinstance(self.templates_t[1], template_removal.template_dipole) and os.environ.get('PLENS_TPROJ_MD', '1') != '0'
                   and not shts.plan_all_generic(self.nside, lmax))
-            if md:  # monopole + dipole evaluated from the ring geometry (pl_cg_fwd_tt_md_b), as in opfilt_tt
+            if len(self.templates_t) != 0 and os.environ.get('PLENS_TPROJ_HARM', '1') != '0':
+                # the temperature templates as a rank-nmodes update in harmonic space, as in opfilt_tt (pl_lowrank_update_b)
+                hpm, hrm = self._harm_matrices(lmax)
+                ttlm = shts.cg_fwd_tt(alm.tlm, self.nside, lmax, self.n_inv[0], fl_in=self.b_transf_t, fl_out=self.b_transf_t * fac)
+                dev.lowrank_update(ttlm, alm.tlm.to(torch.complex128).contiguous(), hpm, hrm)
+            elif md:  # monopole + dipole evaluated from the ring geometry (pl_cg_fwd_tt_md_b), as in opfilt_tt
                 if getattr(self, '_pinv_md_dev', None) is None:
                     self._pinv_md_dev = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64).contiguous()
                 ttlm = shts.cg_fwd_tt(alm.tlm, self.nside, lmax, self.n_inv[0], fl_in=self.b_transf_t, fl_out=self.b_transf_t * fac,

@@ -304,3 +304,39 @@ def test_dense_preconditioner_built_through_block_vectors(monkeypatch):
         monkeypatch.setenv('PLENS_DENSE_BLOCK', '32')
         blk = cls_(lmax, op).minv
         assert bool((one == blk).all()), cls_.__name__
+
+
+@pytest.mark.parametrize('nside,lmax,nb', [(16, 32, 1), (32, 64, 3), (256, 512, 1), (512, 600, 2), (1024, 1100, 1)])
+def test_template_projection_in_harmonic_space_equals_the_pixel_space_one(nside, lmax, nb, monkeypatch):
+    """B^t Y^t [N^-1 - N^-1 T (T^t N^-1 T)^-1 T^t N^-1] Y B x (opfilt_tt.py:196-205: the bracket applied to the map) against
+    B^t Y^t N^-1 Y B x - V (T^t N^-1 T)^-1 V^t x with V = B^t Y^t N^-1 T (pl_lowrank_update_b, the default): the same operator up to
+    rounding, for monopole + dipole and for stored template maps, single vectors and blocks; the projected modes are annihilated."""
+    import torch
+    from plancklens_amd import dev, hp, shts
+    from plancklens_amd.qcinv import opfilt_tt
+    rng = np.random.default_rng(3 * nside + nb)
+    npix = 12 * nside ** 2
+    ell = np.arange(lmax + 1.)
+    bl = np.exp(-ell * (ell + 1.) * 1e-6)
+    x, y, z = hp.pix2vec(nside, np.arange(npix))
+    ninv = (1. + 0.3 * x) * (np.abs(z) > 0.3) * (1. + 0.2 * rng.random(npix))
+    cl = {'tt': 1. / (ell + 3.) ** 2}
+    marge_maps = [np.cos(3. * np.arctan2(y, x)) * (1. - z ** 2), rng.standard_normal(npix)] if nside <= 256 else []
+    nf = opfilt_tt.alm_filter_ninv(ninv, bl, marge_monopole=True, marge_dipole=True, marge_maps=marge_maps)
+    op = opfilt_tt.fwd_op(cl, nf)
+    xt = _ralm(rng, lmax, nb) if nb > 1 else _ralm(rng, lmax, 2)[0].contiguous()
+    monkeypatch.setenv('PLENS_TPROJ_HARM', '0')
+    ref = op(xt)
+    monkeypatch.setenv('PLENS_TPROJ_HARM', '1')
+    got = op(xt)
+    assert got.shape == ref.shape
+    assert relrms(dev.to_host(got), dev.to_host(ref)) < 1e-12
+    if nb > 1:  # block entries equal single calls bit for bit
+        for i in range(nb):
+            assert bool((got[i] == op(xt[i].contiguous())).all())
+    # a vector made of the templates alone, Y^t-side: N^-1-weighted operator part vanishes (S^-1 x remains)
+    tmap = dev.to_dev(1. + 2. * x - y + .5 * z + (3. * marge_maps[0] if marge_maps else 0.), torch.float64)
+    nf2 = opfilt_tt.alm_filter_ninv(ninv, bl, marge_monopole=True, marge_dipole=True, marge_maps=marge_maps)
+    t1, t2 = tmap.clone(), tmap.clone()
+    nf2.apply_map(t1)
+    assert float(t1.abs().max()) < 1e-9 * float((dev.to_dev(ninv, torch.float64) * t2).abs().max())
