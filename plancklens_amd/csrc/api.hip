@@ -834,6 +834,12 @@ int pl_template_project(int64_t npix, int nmodes, double *tmap, const double *n_
 //   alm_out = fl_out * Y^t [N^-1 - N^-1 P (P^t N^-1 P)^-1 P^t N^-1] Y (fl_in * alm_in)  +  fl_add * alm_add.
 // On grids whose rings all run in the generic ring-FFT kernel (the coarse levels of the multigrid chain) the weighting and the projection
 // ride in the two FFT launches (NinvProj); on the finer grids they are the two pl_template_project launches between the transforms.
+static bool cg_roundtrip_enabled()
+{
+    static const bool on = !(getenv("PLSHTS_CG_ROUNDTRIP") && atoi(getenv("PLSHTS_CG_ROUNDTRIP")) == 0);
+    return on;
+}
+
 static int cg_fwd_tt_impl(pl_plan *p, int nb, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *pmat,
                           const double *rmat, double *scratch, const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out,
                           void *stream, const double *pinv_md = nullptr)
@@ -856,7 +862,13 @@ static int cg_fwd_tt_impl(pl_plan *p, int nb, const double *alm_in, const double
         if (grow(p, &p->tparts, &p->tparts_cap, (int64_t)nmodes * P.npairs * nb)) return 1;
         W.nmodes = nmodes; W.nparts = P.npairs; W.parts = p->tparts; W.pm = pmat; W.rm = rmat;
     }
-    {
+    // no projection in pixel space and every ring in the generic kernel (the coarse levels of the chains): the ring transforms both ways
+    // and the weighting in one launch, no map written (PLSHTS_CG_ROUNDTRIP=0: the two launches)
+    const bool roundtrip = nmodes == 0 && cg_roundtrip_enabled() && fft_all_generic(P, p->F);
+    if (roundtrip) {
+        ProfScope ps(p, PK_FFT_SYNTH, st);
+        HIPCHK(launch_ring_roundtrip(P, p->F, mlim_of(p, 0), nb, p->phase, n_inv, st));
+    } else {
         ProfScope ps(p, PK_FFT_SYNTH, st);
         HIPCHK(launch_phase2map(P, p->F, p->fs, mlim_of(p, 0), nb, p->phase, p->wmap, st, &W));
     }
@@ -865,7 +877,7 @@ static int cg_fwd_tt_impl(pl_plan *p, int nb, const double *alm_in, const double
         else launch_template_project(P.npix, nmodes, p->wmap, nullptr, pmat, rmat, scratch, st, nb);
         HIPCHK(hipGetLastError());
     }
-    {
+    if (!roundtrip) {
         ProfScope ps(p, PK_FFT_ANAL, st);
         HIPCHK(launch_map2phase(P, p->F, p->fs, mlim_of(p, 0), nb, p->wmap, p->phase, st, (fused && nmodes > 0) ? &W : nullptr));
     }
@@ -947,7 +959,11 @@ static int cg_fwd_pp_impl(pl_plan *p, int nb, const double *elm_in, const double
     HIPCHK(hipGetLastError());
     NinvProj W;
     W.n_inv = n_qu ? nullptr : n_inv;
-    {
+    const bool roundtrip = !n_qu && cg_roundtrip_enabled() && fft_all_generic(P, p->F);  // as in cg_fwd_tt_impl: Q and U weighted alike
+    if (roundtrip) {
+        ProfScope ps(p, PK_FFT_SYNTH, st);
+        HIPCHK(launch_ring_roundtrip(P, p->F, mlim_of(p, spin), 2 * nb, p->phase, n_inv, st));
+    } else {
         ProfScope ps(p, PK_FFT_SYNTH, st);
         HIPCHK(launch_phase2map(P, p->F, p->fs, mlim_of(p, spin), 2 * nb, p->phase, p->wmap, st, &W));
     }
@@ -955,7 +971,7 @@ static int cg_fwd_pp_impl(pl_plan *p, int nb, const double *elm_in, const double
         launch_map_qu_weight(P.npix, p->wmap, p->wmap + P.npix, n_inv, n_qu, n_uu, st, nb, 2 * P.npix);
         HIPCHK(hipGetLastError());
     }
-    {
+    if (!roundtrip) {
         ProfScope ps(p, PK_FFT_ANAL, st);
         HIPCHK(launch_map2phase(P, p->F, p->fs, mlim_of(p, spin), 2 * nb, p->wmap, p->phase, st));
     }

@@ -908,7 +908,7 @@ void launch_template_project(int64_t n, int nmodes, double *t, const double *n_i
             hipLaunchKernelGGL(k_tproj_coeffs_b<1024>, dim3(kProjParts, nchunk), dim3(1024), 0, st, n, nmodes, nb, t, n_inv, pm, parts);
             hipLaunchKernelGGL(k_tproj_apply_b, dim3(nblocks(n), nchunk), dim3(256), 0, st, n, nmodes, kProjParts, nb, ta, rm, parts);
         } else {
-            int nparts = (int)((n + 2047) / 2048);
+            int nparts = (int)((n + 511) / 512);  // two entries per thread: the coefficient pass of a coarse grid is a latency chain of its loads
             if (nparts < 1) nparts = 1;
             if (nparts > kProjParts) nparts = kProjParts;
             hipLaunchKernelGGL(k_tproj_coeffs_b<256>, dim3(nparts, nchunk), dim3(256), 0, st, n, nmodes, nb, t, n_inv, pm, parts);
@@ -919,8 +919,8 @@ void launch_template_project(int64_t n, int nmodes, double *t, const double *n_i
     if (n >= (int64_t)kProjParts * 4096) {  // fine grids: 256 workgroups of 1024 threads
         hipLaunchKernelGGL(k_tproj_coeffs<1024>, dim3(kProjParts, nb), dim3(1024), 0, st, n, nmodes, t, n_inv, pm, parts);
         hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n), nb), dim3(256), 0, st, n, nmodes, kProjParts, ta, rm, parts);
-    } else {  // coarse grids: workgroups of 256 threads, 8 pixels per thread
-        int nparts = (int)((n + 2047) / 2048);
+    } else {  // coarse grids: workgroups of 256 threads
+        int nparts = (int)((n + 511) / 512);  // two entries per thread: the coefficient pass of a coarse grid is a latency chain of its loads
         if (nparts < 1) nparts = 1;
         if (nparts > kProjParts) nparts = kProjParts;
         hipLaunchKernelGGL(k_tproj_coeffs<256>, dim3(nparts, nb), dim3(256), 0, st, n, nmodes, t, n_inv, pm, parts);

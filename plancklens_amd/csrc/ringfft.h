@@ -71,6 +71,8 @@ hipError_t launch_phase2map(const DevPlan &P, const DevFFT &F, const FftStreams 
                             const NinvProj *W = nullptr);
 hipError_t launch_map2phase(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *map, double *phase, hipStream_t st,
                             const NinvProj *W = nullptr);
+// phase -> pixels -> n_inv x pixels -> phase in one launch and in place (k_ring_roundtrip): plans with fft_all_generic only
+hipError_t launch_ring_roundtrip(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, double *phase, const double *n_inv, hipStream_t st);
 bool fft_all_generic(const DevPlan &P, const DevFFT &F);  // every ring pair runs in the generic kernel: NinvProj can be fused
 hipError_t launch_twiddles(double *tw, int Mtw, hipStream_t st);
 hipError_t launch_bluestein_setup(const DevFFT &F, const int *qlist_dev, int nq, double *chirp, double *filt, hipStream_t st);

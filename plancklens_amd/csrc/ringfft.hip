@@ -263,36 +263,48 @@ __global__ void k_twiddles(double2 *tw, int Mtw)
 }
 
 // -----------------------------------------------------------------------------------------------------
-// synthesis: phase -> pixels
+// generic kernels: one workgroup per ring pair and component, transforms in LDS
 // -----------------------------------------------------------------------------------------------------
+// Thread t of NT owns the pixels j = j1 + q j2 with j1 = t + NT qq (qq < QMAX, j2 < 4) of both rings of the pair -- in the synthesis
+// as well as in the analysis, which is what lets k_ring_roundtrip hand them over in registers.
+struct RingCtx {
+    int n, q, M, ml;
+    bool shifted;
+    double inv_n;
+    const double2 *chirp, *filt;
+    double2 *twl;
+};
+
+template <int NT, bool B4>
+__device__ __forceinline__ RingCtx ring_ctx(const DevPlan &P, const DevFFT &F, int ip, const int *__restrict__ mlim, double2 *ws)
+{
+    RingCtx c;
+    c.n = P.nphi[ip]; c.q = c.n >> 2;
+    c.M = F.Mof[c.q];
+    c.chirp = F.chirp + F.woff[c.q];
+    c.filt = F.filt + F.coff[c.q];
+    c.ml = min(mlim[ip], P.mmax);
+    c.shifted = P.phi0[ip] != 0.0;
+    c.inv_n = 1.0 / c.n;
+    c.twl = F.twl_cap ? ws + (B4 ? 4 : 1) * F.Lmax : nullptr;
+    if (c.twl) fft_build_twl<NT>(c.twl, c.M ? c.M : c.q, F.tw, F.Mtw);
+    return c;
+}
+
+// synthesis: phase rows ph[m][N re, N im, S re, S im] -> acc[j2][qq] = (north, south) values of the thread's pixels
 // B4: the four sub-DFTs of the ring are transformed side by side (LDS for 4 F.Lmax points) -- the coarse grids of the CG
 // multigrid, where one short transform leaves most of the workgroup idle and the chain of barriers is the cost.
 template <int NT, int QMAX, bool B4>
-__global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim, int ncomp,
-                                                  const double *__restrict__ phase, double *__restrict__ map, int dbg, NinvProj W)
+__device__ __forceinline__ void ring_synth(const RingCtx &c, const DevFFT &F, const double *__restrict__ ph, double2 *ws, double2 (&acc)[4][QMAX],
+                                           const double2 (&e1)[QMAX], int dbg)
 {
-    extern __shared__ double2 ws[];
-    const int ip = pairs[blockIdx.x];  // largest rings first
-    const int comp = blockIdx.y;
-    const int n = P.nphi[ip], q = n >> 2;
-    const int M = F.Mof[q];
-    const double2 *__restrict__ chirp = F.chirp + F.woff[q];
-    const double2 *__restrict__ filt = F.filt + F.coff[q];
-    const int ml = min(mlim[ip], P.mmax);
-    const bool shifted = P.phi0[ip] != 0.0;
-    const double inv_n = 1.0 / n;
-    constexpr int estride = 4;  // phase array [ring pair][component][m][N re, N im, S re, S im]: a component's orders are contiguous
-    const double *__restrict__ ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * estride;
-    double2 *twl = F.twl_cap ? ws + (B4 ? 4 : 1) * F.Lmax : nullptr;
-    if (twl) fft_build_twl<NT>(twl, M ? M : q, F.tw, F.Mtw);
-
-    double2 acc[4][QMAX], e1[QMAX];
+    constexpr int estride = 4;
+    const int n = c.n, q = c.q, M = c.M, ml = c.ml;
+    const bool shifted = c.shifted;
+    const double inv_n = c.inv_n;
+    const double2 *__restrict__ chirp = c.chirp;
 #pragma unroll
-    for (int qq = 0; qq < QMAX; ++qq) {
-        acc[0][qq] = acc[1][qq] = acc[2][qq] = acc[3][qq] = make_double2(0., 0.);
-        const int j1 = threadIdx.x + NT * qq;
-        e1[qq] = cispi(2.0 * j1 * inv_n);  // e^{2 pi i j1 / n}
-    }
+    for (int qq = 0; qq < QMAX; ++qq) acc[0][qq] = acc[1][qq] = acc[2][qq] = acc[3][qq] = make_double2(0., 0.);
     // input bin k = 4 k1 + k2 of the ring transform: all orders aliased onto it
     auto fold = [&](int k1, int k2) -> double2 {
         const int k = 4 * k1 + k2;
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int
             if (M) ws[idx] = cmul(z, chirp[k1]);
             else ws[k2 * S + digit_reverse(k1, q)] = z;
         }
-        if (!(dbg & 2)) sub_dft_inverse<NT>(ws, q, M, filt, F, twl, 4, S);
+        if (!(dbg & 2)) sub_dft_inverse<NT>(ws, q, M, c.filt, F, c.twl, 4, S);
         else __syncthreads();
 #pragma unroll
         for (int k2 = 0; k2 < 4; ++k2) scatter(k2, ws + k2 * S);
@@ -354,12 +366,137 @@ __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int
                 if (M) ws[k1] = cmul(z, chirp[k1]);
                 else ws[digit_reverse(k1, q)] = z;
             }
-            if (!(dbg & 2)) sub_dft_inverse<NT>(ws, q, M, filt, F, twl);
+            if (!(dbg & 2)) sub_dft_inverse<NT>(ws, q, M, c.filt, F, c.twl);
             else __syncthreads();
             scatter(k2, ws);
             __syncthreads();
         }
     }
+}
+
+// analysis: zc[j2][qq] = (north, -south) values of the thread's pixels (conj(z_j), j = j1 + q j2) -> phase rows, uniform quadrature
+// weights 4 pi / npix (wgt includes the 1/2 of the N/S split)
+template <int NT, int QMAX, bool B4>
+__device__ __forceinline__ void ring_anal(const RingCtx &c, const DevFFT &F, double *__restrict__ ph, double2 *ws, const double2 (&zc)[4][QMAX],
+                                          const double2 (&e1)[QMAX], bool has_s, double wgt)
+{
+    constexpr int estride = 4;
+    const int n = c.n, q = c.q, M = c.M, ml = c.ml;
+    const bool shifted = c.shifted;
+    const double inv_n = c.inv_n;
+    const double2 *__restrict__ chirp = c.chirp;
+    double2 hold[QMAX];
+#pragma unroll
+    for (int qq = 0; qq < QMAX; ++qq) hold[qq] = make_double2(0., 0.);
+
+    // store F_N, F_S of order m given V_k = conj(Z_k) and V_{n-k}
+    auto emit = [&](int m, double2 vk, double2 vm) {
+        // F_N = (conj(V_k) + V_{n-k}) / 2,  F_S = (conj(V_k) - V_{n-k}) / (2i)
+        const double2 a = cconj(vk);
+        double2 fn = cadd(a, vm);
+        const double2 d = csub(a, vm);
+        double2 fs = make_double2(d.y, -d.x);  // d / i
+        const double2 p = shifted ? cispi(-m * inv_n) : make_double2(1., 0.);
+        fn = cmul(fn, p); fs = cmul(fs, p);
+        double4 o;
+        o.x = fn.x * wgt; o.y = fn.y * wgt;
+        o.z = has_s ? fs.x * wgt : 0.0; o.w = has_s ? fs.y * wgt : 0.0;
+        *reinterpret_cast<double4 *>(ph + (int64_t)m * estride) = o;
+    };
+
+    // input of sub-DFT k2 into w[0 .. S): radix-4 butterfly over the quarter rings, twiddle, (chirp), zero padding
+    auto gather = [&](int k2, double2 *w) {
+        if (M) for (int t = q + threadIdx.x; t < M; t += NT) w[t] = make_double2(0., 0.);
+#pragma unroll
+        for (int qq = 0; qq < QMAX; ++qq) {
+            const int j1 = threadIdx.x + NT * qq;
+            if (j1 < q) {
+                double2 x = make_double2(0., 0.);
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) x = cadd(x, crot(zc[j2][qq], j2 * k2));
+                double2 tw = make_double2(1., 0.);
+                if (k2 >= 1) tw = e1[qq];
+                if (k2 >= 2) tw = cmul(tw, e1[qq]);
+                if (k2 >= 3) tw = cmul(tw, e1[qq]);
+                x = cmul(x, tw);
+                if (M) w[j1] = cmul(x, chirp[j1]);
+                else w[digit_reverse(j1, q)] = x;
+            }
+        }
+    };
+    if constexpr (B4) {  // the four sub-DFTs side by side: V_{4 k1 + k2} = ws[k2 S + k1] (* chirp[k1])
+        const int S = M ? M : q;
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) gather(k2, ws + k2 * S);
+        sub_dft_inverse<NT>(ws, q, M, c.filt, F, c.twl, 4, S);
+        auto val = [&](int k) {  // V_k, 0 <= k < n
+            double2 v = ws[(k & 3) * S + (k >> 2)];
+            if (M) v = cmul(v, chirp[k >> 2]);
+            return v;
+        };
+        for (int m = threadIdx.x; m <= ml; m += NT) {
+            const int k = m % n;
+            emit(m, val(k), val((n - k) % n));
+        }
+        return;
+    }
+    for (int kk = 0; kk < 4; ++kk) {
+        const int k2 = (kk == 0) ? 0 : (kk == 1) ? 2 : (kk == 2) ? 1 : 3;
+        gather(k2, ws);
+        sub_dft_inverse<NT>(ws, q, M, c.filt, F, c.twl);
+        // now V_{4 k1 + k2} = ws[k1] (* chirp[k1])
+        if (k2 == 0 || k2 == 2) {
+            for (int m = k2 + 4 * threadIdx.x; m <= ml; m += 4 * NT) {
+                const int k = m % n;
+                const int km = (n - k) % n;
+                double2 vk = ws[k >> 2], vm = ws[km >> 2];
+                if (M) { vk = cmul(vk, chirp[k >> 2]); vm = cmul(vm, chirp[km >> 2]); }
+                emit(m, vk, vm);
+            }
+        } else if (k2 == 1) {
+#pragma unroll
+            for (int qq = 0; qq < QMAX; ++qq) {
+                const int k1 = threadIdx.x + NT * qq;
+                if (k1 < q) {
+                    double2 v = ws[k1];
+                    if (M) v = cmul(v, chirp[k1]);
+                    hold[qq] = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int qq = 0; qq < QMAX; ++qq) {
+                const int k1 = threadIdx.x + NT * qq;
+                if (k1 < q) {
+                    const int k1p = q - 1 - k1;
+                    const double2 a = hold[qq];      // V_{4 k1 + 1}
+                    double2 b = ws[k1p];             // V_{4 k1p + 3} = V_{n - (4 k1 + 1)}
+                    if (M) b = cmul(b, chirp[k1p]);
+                    for (int m = 4 * k1 + 1; m <= ml; m += n) emit(m, a, b);
+                    for (int m = 4 * k1p + 3; m <= ml; m += n) emit(m, b, a);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// synthesis: phase -> pixels
+template <int NT, int QMAX, bool B4>
+__global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim, int ncomp,
+                                                  const double *__restrict__ phase, double *__restrict__ map, int dbg, NinvProj W)
+{
+    extern __shared__ double2 ws[];
+    const int ip = pairs[blockIdx.x];  // largest rings first
+    const int comp = blockIdx.y;
+    const RingCtx c = ring_ctx<NT, B4>(P, F, ip, mlim, ws);
+    const int q = c.q;
+    // phase array [ring pair][component][m][N re, N im, S re, S im]: a component's orders are contiguous
+    const double *__restrict__ ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * 4;
+    double2 acc[4][QMAX], e1[QMAX];
+#pragma unroll
+    for (int qq = 0; qq < QMAX; ++qq) e1[qq] = cispi(2.0 * (threadIdx.x + NT * qq) * c.inv_n);  // e^{2 pi i j1 / n}
+    ring_synth<NT, QMAX, B4>(c, F, ph, ws, acc, e1, dbg);
     double *__restrict__ mp = map + (int64_t)comp * P.npix;
     const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
     double cw[kFuseModes] = {0., 0., 0., 0.};  // NinvProj: this thread's share of the template coefficients
@@ -409,9 +546,7 @@ __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int
     }
 }
 
-// -----------------------------------------------------------------------------------------------------
-// analysis: pixels -> phase (uniform quadrature weights 4 pi / npix)
-// -----------------------------------------------------------------------------------------------------
+// analysis: pixels -> phase
 template <int NT, int QMAX, bool B4>
 __global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim, int ncomp,
                                                   const double *__restrict__ map, double *__restrict__ phase, NinvProj W)
@@ -431,29 +566,20 @@ __global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int
     }
     const int ip = pairs[blockIdx.x];
     const int comp = blockIdx.y;
-    const int n = P.nphi[ip], q = n >> 2;
-    const int M = F.Mof[q];
-    const double2 *__restrict__ chirp = F.chirp + F.woff[q];
-    const double2 *__restrict__ filt = F.filt + F.coff[q];
-    const int ml = min(mlim[ip], P.mmax);
-    const bool shifted = P.phi0[ip] != 0.0;
-    const double inv_n = 1.0 / n;
-    constexpr int estride = 4;  // phase array [ring pair][component][m][N re, N im, S re, S im]
-    double *__restrict__ ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * estride;
-    double2 *twl = F.twl_cap ? ws + (B4 ? 4 : 1) * F.Lmax : nullptr;
-    if (twl) fft_build_twl<NT>(twl, M ? M : q, F.tw, F.Mtw);
+    const RingCtx c = ring_ctx<NT, B4>(P, F, ip, mlim, ws);
+    const int q = c.q;
+    double *__restrict__ ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * 4;
     const double wgt = 0.5 * 4.0 * 3.14159265358979323846 / (double)P.npix;  // includes the 1/2 of the N/S split
     const double *__restrict__ mp = map + (int64_t)comp * P.npix;
     const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
     const bool has_s = os >= 0;
 
     // conj(z_j) = north - i south, j = j1 + q j2
-    double2 zc[4][QMAX], e1[QMAX], hold[QMAX];
+    double2 zc[4][QMAX], e1[QMAX];
 #pragma unroll
     for (int qq = 0; qq < QMAX; ++qq) {
         const int j1 = threadIdx.x + NT * qq;
-        e1[qq] = cispi(2.0 * j1 * inv_n);
-        hold[qq] = make_double2(0., 0.);
+        e1[qq] = cispi(2.0 * j1 * c.inv_n);
 #pragma unroll
         for (int j2 = 0; j2 < 4; ++j2) {
             double2 v = make_double2(0., 0.);
@@ -472,97 +598,46 @@ __global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int
             zc[j2][qq] = v;
         }
     }
+    ring_anal<NT, QMAX, B4>(c, F, ph, ws, zc, e1, has_s, wgt);
+}
 
-    // store F_N, F_S of order m given V_k = conj(Z_k) and V_{n-k}
-    auto emit = [&](int m, double2 vk, double2 vm) {
-        // F_N = (conj(V_k) + V_{n-k}) / 2,  F_S = (conj(V_k) - V_{n-k}) / (2i)
-        const double2 a = cconj(vk);
-        double2 fn = cadd(a, vm);
-        const double2 d = csub(a, vm);
-        double2 fs = make_double2(d.y, -d.x);  // d / i
-        const double2 p = shifted ? cispi(-m * inv_n) : make_double2(1., 0.);
-        fn = cmul(fn, p); fs = cmul(fs, p);
-        double4 o;
-        o.x = fn.x * wgt; o.y = fn.y * wgt;
-        o.z = has_s ? fs.x * wgt : 0.0; o.w = has_s ? fs.y * wgt : 0.0;
-        *reinterpret_cast<double4 *>(ph + (int64_t)m * estride) = o;
-    };
-
-    // input of sub-DFT k2 into w[0 .. S): radix-4 butterfly over the quarter rings, twiddle, (chirp), zero padding
-    auto gather = [&](int k2, double2 *w) {
-        if (M) for (int t = q + threadIdx.x; t < M; t += NT) w[t] = make_double2(0., 0.);
+// The pixel-space part of a CG operator whose inverse noise is diagonal, phase -> pixels -> n_inv x pixels -> phase, for the rings
+// of the generic kernel in ONE launch (the coarse levels of the multigrid chains, where every ring is one): the pixel values
+// stay in the registers of the threads that own them, no map is written.  In place on the phase array (a workgroup reads its
+// rows before it writes them).  Same arithmetic as k_phase2map (weighted) followed by k_map2phase: results identical.
+template <int NT, int QMAX, bool B4>
+__global__ __launch_bounds__(NT) void k_ring_roundtrip(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim, int ncomp,
+                                                       double *phase, const double *__restrict__ n_inv)
+{
+    extern __shared__ double2 ws[];
+    const int ip = pairs[blockIdx.x];
+    const int comp = blockIdx.y;
+    const RingCtx c = ring_ctx<NT, B4>(P, F, ip, mlim, ws);
+    const int q = c.q;
+    double *ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * 4;
+    const double wgt = 0.5 * 4.0 * 3.14159265358979323846 / (double)P.npix;
+    const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
+    const bool has_s = os >= 0;
+    double2 px[4][QMAX], e1[QMAX];
+#pragma unroll
+    for (int qq = 0; qq < QMAX; ++qq) e1[qq] = cispi(2.0 * (threadIdx.x + NT * qq) * c.inv_n);
+    ring_synth<NT, QMAX, B4>(c, F, ph, ws, px, e1, 0);
+#pragma unroll
+    for (int j2 = 0; j2 < 4; ++j2) {
 #pragma unroll
         for (int qq = 0; qq < QMAX; ++qq) {
             const int j1 = threadIdx.x + NT * qq;
+            double2 v = make_double2(0., 0.);
             if (j1 < q) {
-                double2 x = make_double2(0., 0.);
-#pragma unroll
-                for (int j2 = 0; j2 < 4; ++j2) x = cadd(x, crot(zc[j2][qq], j2 * k2));
-                double2 tw = make_double2(1., 0.);
-                if (k2 >= 1) tw = e1[qq];
-                if (k2 >= 2) tw = cmul(tw, e1[qq]);
-                if (k2 >= 3) tw = cmul(tw, e1[qq]);
-                x = cmul(x, tw);
-                if (M) w[j1] = cmul(x, chirp[j1]);
-                else w[digit_reverse(j1, q)] = x;
+                const int j = j1 + q * j2;
+                v.x = px[j2][qq].x * n_inv[on + j];
+                v.y = -(has_s ? px[j2][qq].y * n_inv[os + j] : 0.0);  // (the sign of the zero as k_map2phase forms it)
             }
+            px[j2][qq] = v;
         }
-    };
-    if constexpr (B4) {  // the four sub-DFTs side by side: V_{4 k1 + k2} = ws[k2 S + k1] (* chirp[k1])
-        const int S = M ? M : q;
-#pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2) gather(k2, ws + k2 * S);
-        sub_dft_inverse<NT>(ws, q, M, filt, F, twl, 4, S);
-        auto val = [&](int k) {  // V_k, 0 <= k < n
-            double2 v = ws[(k & 3) * S + (k >> 2)];
-            if (M) v = cmul(v, chirp[k >> 2]);
-            return v;
-        };
-        for (int m = threadIdx.x; m <= ml; m += NT) {
-            const int k = m % n;
-            emit(m, val(k), val((n - k) % n));
-        }
-        return;
     }
-    for (int kk = 0; kk < 4; ++kk) {
-        const int k2 = (kk == 0) ? 0 : (kk == 1) ? 2 : (kk == 2) ? 1 : 3;
-        gather(k2, ws);
-        sub_dft_inverse<NT>(ws, q, M, filt, F, twl);
-        // now V_{4 k1 + k2} = ws[k1] (* chirp[k1])
-        if (k2 == 0 || k2 == 2) {
-            for (int m = k2 + 4 * threadIdx.x; m <= ml; m += 4 * NT) {
-                const int k = m % n;
-                const int km = (n - k) % n;
-                double2 vk = ws[k >> 2], vm = ws[km >> 2];
-                if (M) { vk = cmul(vk, chirp[k >> 2]); vm = cmul(vm, chirp[km >> 2]); }
-                emit(m, vk, vm);
-            }
-        } else if (k2 == 1) {
-#pragma unroll
-            for (int qq = 0; qq < QMAX; ++qq) {
-                const int k1 = threadIdx.x + NT * qq;
-                if (k1 < q) {
-                    double2 v = ws[k1];
-                    if (M) v = cmul(v, chirp[k1]);
-                    hold[qq] = v;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int qq = 0; qq < QMAX; ++qq) {
-                const int k1 = threadIdx.x + NT * qq;
-                if (k1 < q) {
-                    const int k1p = q - 1 - k1;
-                    const double2 a = hold[qq];      // V_{4 k1 + 1}
-                    double2 b = ws[k1p];             // V_{4 k1p + 3} = V_{n - (4 k1 + 1)}
-                    if (M) b = cmul(b, chirp[k1p]);
-                    for (int m = 4 * k1 + 1; m <= ml; m += n) emit(m, a, b);
-                    for (int m = 4 * k1p + 3; m <= ml; m += n) emit(m, b, a);
-                }
-            }
-        }
-        __syncthreads();
-    }
+    __syncthreads();  // the transforms of the synthesis have been read out: the workspace takes the analysis side
+    ring_anal<NT, QMAX, B4>(c, F, ph, ws, px, e1, has_s, wgt);
 }
 
 // =====================================================================================================
@@ -1111,6 +1186,45 @@ static hipError_t launch_m2p(const DevPlan &P, const DevFFT &F, const int *mlim,
         if (ns <= 8192) return FN<1024, 8>(__VA_ARGS__);                    \
         return hipErrorInvalidValue;                                        \
     } while (0)
+
+template <int NT, int QMAX>
+static hipError_t launch_rt(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, double *phase, hipStream_t st, const double *n_inv)
+{
+    if (F.A.legacy_n == 0) return hipSuccess;
+    static const bool no_b4 = getenv("PLSHTS_FFT_NOB4") && atoi(getenv("PLSHTS_FFT_NOB4")) != 0;
+    const size_t lds4 = (size_t)(4 * F.Lmax + F.twl_cap) * sizeof(double2);
+    if (!no_b4 && lds4 <= kB4MaxLds) {
+        static bool attr4_done[kMaxDevices] = {};
+        const int dv4 = current_device();
+        if (!attr4_done[dv4] && lds4 > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ring_roundtrip<NT, QMAX, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kGenericMaxLds);
+            if (e != hipSuccess) return e;
+            attr4_done[dv4] = true;
+        }
+        hipLaunchKernelGGL((k_ring_roundtrip<NT, QMAX, true>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds4, st, P, F, F.A.legacy_pairs, mlim, ncomp,
+                           phase, n_inv);
+        return hipGetLastError();
+    }
+    const size_t lds = fft_lds_bytes(F);
+    static bool attr_done[kMaxDevices] = {};
+    const int dv = current_device();
+    if (!attr_done[dv] && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ring_roundtrip<NT, QMAX, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kGenericMaxLds);
+        if (e != hipSuccess) return e;
+        attr_done[dv] = true;
+    }
+    hipLaunchKernelGGL((k_ring_roundtrip<NT, QMAX, false>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds, st, P, F, F.A.legacy_pairs, mlim, ncomp,
+                       phase, n_inv);
+    return hipGetLastError();
+}
+
+// phase -> pixels -> n_inv x pixels -> phase in one launch, in place; only for plans whose rings all run in the generic kernel
+hipError_t launch_ring_roundtrip(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, double *phase, const double *n_inv, hipStream_t st)
+{
+    PL_FFT_DISPATCH(launch_rt, P, F, mlim, ncomp, phase, st, n_inv);
+}
 
 static hipError_t launch_phase2map_legacy(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, const double *phase, double *map,
                                           hipStream_t st, const NinvProj &W)
