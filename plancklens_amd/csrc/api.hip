@@ -287,6 +287,15 @@ static int plan_create_impl(int nside, int lmax, int rank, int nranks, pl_plan *
             if (clsA[q] >= 0) MofA[q] = Na;
         }
     }
+    {   // A plan whose register classes would hold only a few ring pairs (nside 256 at lmax = 2 nside: 25 of 512) runs every ring in the
+        // generic kernel: the stage is then one launch without a fork / join of side streams, and the CG operators can take the whole
+        // pixel-space part in one (k_ring_roundtrip).  PLSHTS_FFT_MIN_FAST = d: below 1 / d of the pairs (default 8; 0: never).
+        const int min_fast = getenv("PLSHTS_FFT_MIN_FAST") ? atoi(getenv("PLSHTS_FFT_MIN_FAST")) : 8;
+        int64_t nfast = 0;
+        for (int i = 0; i < g.npairs; ++i) nfast += clsA[g.nphi[i] / 4] >= 0;
+        if (min_fast > 0 && nfast > 0 && nfast * min_fast < g.npairs)
+            for (int q = 1; q <= nside; ++q) { clsA[q] = -1; MofA[q] = 0; splitA[q] = 0; }
+    }
     // (A power-of-two ring length below nside is met by a single ring pair per hemisphere pair; it still gets the launch of its
     // direct class: left to the generic kernel those few long rings size its workgroups and LDS for every short polar ring.)
     std::vector<int> listA[kFftClasses], dirA[kFftClasses], splA[kFftClasses], legacyA;
