@@ -3,6 +3,8 @@
 `calc_prep` :306-317, `apply_fini` :320-324).  Vectors are util_alm.eblm pairs of device tensors."""
 from __future__ import print_function
 
+import os
+
 import numpy as np
 import torch
 
@@ -241,7 +243,10 @@ class alm_filter_ninv(object):
         transforms not replaced."""
         self._load_ninv()
         same_b = self.b_transf_b is self.b_transf_e or np.array_equal(self.b_transf_e, self.b_transf_b)
-        return (isinstance(alm.elm, torch.Tensor) and alm.elm.is_cuda and len(self.n_inv) in (1, 3) and not self.wmarg and same_b
+        # (templates: as a rank-nmodes update in harmonic space, single vectors only -- the (E, B) pair of a block entry is not contiguous)
+        harm = (self.wmarg and os.environ.get('PLENS_TPROJ_HARM', '1') != '0' and isinstance(alm.elm, torch.Tensor) and alm.elm.dim() == 1
+                and len(self.n_inv) == 1 and len(self.marge_qmaps) + len(self.marge_umaps) <= dev.TEMPLATE_MAX_MODES)
+        return (isinstance(alm.elm, torch.Tensor) and alm.elm.is_cuda and len(self.n_inv) in (1, 3) and (not self.wmarg or harm) and same_b
                 and alm2map_spin is shts.alm2map_spin and map2alm_spin is shts.map2alm_spin and not shts.lane_active()
                 and all(n.is_contiguous() and n.dtype == torch.float64 for n in self.n_inv))
 
@@ -255,6 +260,11 @@ class alm_filter_ninv(object):
                                       fl_out=self.b_transf_e * (npix / (4. * np.pi)),
                                       add=None if add is None else (add.elm, add.blm), fl_add_e=fl_add_e, fl_add_b=fl_add_b,
                                       n_qu=self.n_inv[1] if len(self.n_inv) == 3 else None, n_uu=self.n_inv[2] if len(self.n_inv) == 3 else None)
+            if self.wmarg:  # the Q / U templates: y -= V (T^t N^-1 T)^-1 V^t x on the stacked (E, B) vectors (pl_lowrank_update_b)
+                hpm, hrm = self._harm_matrices(lmax)
+                y = torch.stack([elm, blm])
+                dev.lowrank_update(y.view(-1), torch.stack([alm.elm, alm.blm]).to(torch.complex128).view(-1), hpm, hrm)
+                elm, blm = y[0], y[1]
             return eblm([elm, blm])
         ret = self._apply_alm_steps(alm)
         if add is not None:
@@ -316,6 +326,31 @@ class alm_filter_ninv(object):
                 umap += self.n_inv[1] * qcopy
         else:
             assert 0
+
+    def _harm_matrices(self, lmax):
+        """The Q / U templates in harmonic space, V_k = B^t Y2^t N^-1 T_k as an (E, B) pair per mode (see
+        template_removal.harmonic_matrices for the scalar case): real (nmodes, 4 nalm) device matrices for dev.lowrank_update on
+        stacked (E, B) vectors -- V with the weights of the real scalar product folded in, and (T^t N^-1 T)^-1 V."""
+        cache = self.__dict__.setdefault('_harm', {})
+        if lmax not in cache:
+            self._build_tniti()
+            npix = self.n_inv[0].numel()
+            fl_out = self.b_transf_e * (npix / (4. * np.pi))
+            rows = []
+            for t in self.templates_p:
+                qu = torch.zeros((2, npix), dtype=torch.float64, device=self.n_inv[0].device)
+                qu[t.comp] = self.n_inv[0] * t.map
+                e, b = map2alm_spin([qu[0], qu[1]], 2, lmax=lmax, fl=fl_out)
+                vlm = torch.stack([dev.to_dev(e, torch.complex128), dev.to_dev(b, torch.complex128)]).contiguous()
+                rows.append(torch.view_as_real(vlm).reshape(-1))
+            v = torch.stack(rows).contiguous()
+            nalm = v.shape[1] // 4
+            w = torch.full((nalm,), 2., dtype=torch.float64, device=v.device)
+            w[:lmax + 1] = 1.
+            w4 = w.repeat_interleave(2).repeat(2)
+            pinv = dev.to_dev(np.ascontiguousarray(self.tniti), torch.float64)
+            cache[lmax] = ((v * w4.unsqueeze(0)).contiguous(), torch.mm(pinv, v).contiguous())
+        return cache[lmax]
 
     def _proj_matrices_p(self):
         """(pmat, rmat, n_inv2): the template modes as rows of a (nmodes, 2 npix) device matrix (a Q template is zero on the U half

@@ -287,22 +287,11 @@ class alm_filter_ninv(object):
         return self._pmat, self._rmat
 
     def _harm_matrices(self, lmax):
-        """the temperature templates in harmonic space, V_k = B_t^t Y^t N_T^-1 T_k (opfilt_tt.alm_filter_ninv._harm_matrices)"""
+        """the temperature templates in harmonic space (template_removal.harmonic_matrices), once per band-limit"""
         cache = self.__dict__.setdefault('_harm', {})
         if lmax not in cache:
-            fl_out = self.b_transf_t * (self.npix / (4. * np.pi))
-            rows = []
-            for t in self.templates_t:
-                for i in range(t.nmodes):
-                    tmap = self.n_inv[0].clone()
-                    t.apply_mode(tmap, i)
-                    vlm = dev.to_dev(map2alm(tmap, lmax=lmax, iter=0, fl=fl_out), torch.complex128).contiguous()
-                    rows.append(torch.view_as_real(vlm).reshape(-1))
-            v = torch.stack(rows).contiguous()
-            w = torch.full((v.shape[1] // 2,), 2., dtype=torch.float64, device=v.device)
-            w[:lmax + 1] = 1.
-            pinv = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64)
-            cache[lmax] = ((v * w.repeat_interleave(2).unsqueeze(0)).contiguous(), torch.mm(pinv, v).contiguous())
+            cache[lmax] = template_removal.harmonic_matrices(self.templates_t, self.n_inv[0], map2alm, lmax,
+                                                             self.b_transf_t * (self.npix / (4. * np.pi)), self.Pt_Nn1_P_inv)
         return cache[lmax]
 
     def one_call_ok(self, alm):

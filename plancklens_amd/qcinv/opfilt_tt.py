@@ -231,26 +231,11 @@ class alm_filter_ninv(object):
         return ret if alm_add is None else dev.almxfl_add(ret, alm_add, fl_add, out=ret)
 
     def _harm_matrices(self, lmax):
-        """The template modes in harmonic space: V_k = B^t Y^t N^-1 T_k, one alm per mode, so that
-            B^t Y^t [N^-1 - N^-1 T (T^t N^-1 T)^-1 T^t N^-1] Y B x = B^t Y^t N^-1 Y B x - V (T^t N^-1 T)^-1 V^t x
-        (the bracket is what opfilt_tt.py:196-205 applies to the map).  Returned as real (nmodes, 2 nalm) device matrices for
-        dev.lowrank_update: V with the weights of the real scalar product of alm vectors folded in (1 for m = 0, 2 above), and
-        (T^t N^-1 T)^-1 V.  nmodes analysis transforms, once per band-limit."""
+        """the template modes in harmonic space (template_removal.harmonic_matrices), once per band-limit"""
         cache = self.__dict__.setdefault('_harm', {})
         if lmax not in cache:
-            fl_out = self.b_transf * (self.npix / (4. * np.pi))
-            rows = []
-            for t in self.templates:
-                for i in range(t.nmodes):
-                    tmap = self.n_inv.clone()
-                    t.apply_mode(tmap, i)
-                    vlm = dev.to_dev(map2alm(tmap, lmax=lmax, iter=0, fl=fl_out), torch.complex128).contiguous()
-                    rows.append(torch.view_as_real(vlm).reshape(-1))
-            v = torch.stack(rows).contiguous()
-            w = torch.full((v.shape[1] // 2,), 2., dtype=torch.float64, device=v.device)
-            w[:lmax + 1] = 1.
-            pinv = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64)
-            cache[lmax] = ((v * w.repeat_interleave(2).unsqueeze(0)).contiguous(), torch.mm(pinv, v).contiguous())
+            cache[lmax] = template_removal.harmonic_matrices(self.templates, self.n_inv, map2alm, lmax, self.b_transf * (self.npix / (4. * np.pi)),
+                                                             self.Pt_Nn1_P_inv)
         return cache[lmax]
 
     def _md_only(self):

@@ -152,3 +152,23 @@ class template_qmap(_template_pol):
 class template_umap(_template_pol):
     comp = 1
 
+
+
+def harmonic_matrices(templates, n_inv, map2alm, lmax, fl_out, pt_nn1_p_inv):
+    """Scalar templates in harmonic space, for the rank-nmodes form of the projection inside a CG operator:
+        B^t Y^t [N^-1 - N^-1 T (T^t N^-1 T)^-1 T^t N^-1] Y B x = B^t Y^t N^-1 Y B x - V (T^t N^-1 T)^-1 V^t x,   V = B^t Y^t N^-1 T
+    (the bracket is what opfilt_tt.py:196-205 applies to the map; Y^t the adjoint of the synthesis, (npix / 4 pi) map2alm, both factors in
+    fl_out).  Returns two real (nmodes, 2 nalm) device matrices for dev.lowrank_update: V with the weights of the real scalar product of
+    alm vectors folded in (1 for m = 0, 2 above), and (T^t N^-1 T)^-1 V.  One analysis transform per mode."""
+    rows = []
+    for t in templates:
+        for i in range(t.nmodes):
+            tmap = n_inv.clone()
+            t.apply_mode(tmap, i)
+            vlm = dev.to_dev(map2alm(tmap, lmax=lmax, iter=0, fl=fl_out), torch.complex128).contiguous()
+            rows.append(torch.view_as_real(vlm).reshape(-1))
+    v = torch.stack(rows).contiguous()
+    w = torch.full((v.shape[1] // 2,), 2., dtype=torch.float64, device=v.device)
+    w[:lmax + 1] = 1.
+    pinv = dev.to_dev(np.ascontiguousarray(pt_nn1_p_inv), torch.float64)
+    return (v * w.repeat_interleave(2).unsqueeze(0)).contiguous(), torch.mm(pinv, v).contiguous()

@@ -114,6 +114,17 @@ def test_polarization_operators_with_qu_noise_and_templates(g2):
     fm = opfilt_pp.alm_filter_ninv([g['nqq']], g['transf'], marge_qmaps=[g['tq0'], g['tq1']], marge_umaps=[g['tu0']])
     r = opfilt_pp.fwd_op(cl, fm)(x)
     assert relrms(dev.to_host(r.elm), g['ppm_fwd_e']) < 1e-11 and relrms(dev.to_host(r.blm), g['ppm_fwd_b']) < 1e-11
+    # (that was the projection as a rank-3 update in harmonic space, pl_lowrank_update_b on the stacked (E, B) vectors; the pixel-space form:)
+    import os
+    os.environ['PLENS_TPROJ_HARM'] = '0'
+    try:
+        assert not fm.one_call_ok(x)
+        r0 = opfilt_pp.fwd_op(cl, fm)(x)
+    finally:
+        del os.environ['PLENS_TPROJ_HARM']
+    assert fm.one_call_ok(x)
+    assert relrms(dev.to_host(r0.elm), g['ppm_fwd_e']) < 1e-11 and relrms(dev.to_host(r0.blm), g['ppm_fwd_b']) < 1e-11
+    assert relrms(dev.to_host(r.elm), dev.to_host(r0.elm)) < 1e-12 and relrms(dev.to_host(r.blm), dev.to_host(r0.blm)) < 1e-12
     pr = opfilt_pp.calc_prep([g['qmap'], g['umap']], cl, fm)
     assert relrms(dev.to_host(pr.elm), g['ppm_prep_e']) < 1e-11 and relrms(dev.to_host(pr.blm), g['ppm_prep_b']) < 1e-11
     assert bool((x.elm == x0[0]).all()) and bool((x.blm == x0[1]).all())
