@@ -340,3 +340,21 @@ def test_template_projection_in_harmonic_space_equals_the_pixel_space_one(nside,
     t1, t2 = tmap.clone(), tmap.clone()
     nf2.apply_map(t1)
     assert float(t1.abs().max()) < 1e-9 * float((dev.to_dev(ninv, torch.float64) * t2).abs().max())
+
+
+def test_ring_roundtrip_kernel_is_bit_identical_to_the_two_launches():
+    """k_ring_roundtrip (synthesis FFT, N^-1 weighting and analysis FFT of an all-generic grid in one launch, the pixel values kept in
+    registers) against k_phase2map + k_map2phase: the switch is read once per process, so two child processes print a checksum of the
+    temperature and polarization operators (with and without templates, single vectors and blocks, nside 8 ... 256) and must agree."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sums = []
+    for v in ('0', '1'):
+        env = dict(os.environ, PLSHTS_CG_ROUNDTRIP=v)
+        out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'probes', 'roundtrip_check.py')], cwd=root, env=env,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        sums.append(out.stdout.strip().splitlines()[-1])
+    assert len(sums[0]) == 64 and sums[0] == sums[1]
