@@ -353,7 +353,7 @@ def test_ring_roundtrip_kernel_is_bit_identical_to_the_two_launches():
     sums = []
     for v in ('0', '1'):
         env = dict(os.environ, PLSHTS_CG_ROUNDTRIP=v)
-        out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'probes', 'roundtrip_check.py')], cwd=root, env=env,
+        out = subprocess.run([sys.executable, os.path.join(root, 'tests', 'workers', 'roundtrip_check.py')], cwd=root, env=env,
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         sums.append(out.stdout.strip().splitlines()[-1])
