@@ -484,12 +484,14 @@ def run_rank(args):
                 cg = cg_bench.run(nside, lmax, args.cg_iters, kinds=('t', 'p'), peak_tflops=FP64_PEAK_TFLOPS,
                                   batches=[int(b) for b in args.cg_batches.split(',') if b.strip()])
                 res['cg'] = {'metric': 'CG-iter/sec: qcinv multigrid Wiener filter, cinv_t + cinv_p, nside=%d lmax=%d, masked sky fsky=%.2f, '
-                                       '%d top-level iterations each (eps_min=0), default chains, dense preconditioner cached outside the timed region'
-                                       % (nside, lmax, cg['fsky'], args.cg_iters),
+                                       '%d top-level iterations each (eps_min=0), default chains, dense preconditioner cached outside the timed region; '
+                                       'median of %d solves per filter'
+                                       % (nside, lmax, cg['fsky'], args.cg_iters, len(cg['t']['seconds_each_solve'])),
                              'T_iters_per_s': cg['t']['iters_per_s'], 'P_iters_per_s': cg['p']['iters_per_s'],
                              'TP_iters_per_s': cg['tp']['iters_per_s'], 'TP_ms_per_iter': cg['tp']['ms_per_iter'],
                              'fp64_floor_ms_per_iter': cg['tp'].get('fp64_floor_ms_per_iter'),
                              'frac_of_fp64_floor': cg['tp'].get('frac_of_fp64_floor'),
+                             'seconds_each_solve': {'t': cg['t']['seconds_each_solve'], 'p': cg['p']['seconds_each_solve']},
                              'dense_setup_s': {'t': cg['t']['first_call_incl_dense_setup_s'], 'p': cg['p']['first_call_incl_dense_setup_s']},
                              'residual_first_last': {'t': cg['t']['eps_first_last'], 'p': cg['p']['eps_first_last']},
                              # B simulations filtered in ONE block solve (cinv_*.apply_ivf_batch): every launch carries all B, each with

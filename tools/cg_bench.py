@@ -20,6 +20,7 @@ if ROOT not in sys.path:
 # FP64 floor of one top-level iteration of the default chains at nside = lmax = 2048 (78.6 TFLOP/s):
 # T 1.83e11 flop, P 5.68e11 flop, T + P 7.51e11 flop = 9.6 ms
 FLOP_PER_ITER_2048 = {'t': 1.83e11, 'p': 5.68e11}
+REPS = int(os.environ.get('CG_BENCH_REPS', '3'))  # timed solves per filter at B = 1 (median reported)
 
 
 def make_mask(nside, rng):
@@ -98,11 +99,17 @@ def _run(nside, lmax, iters, kinds, joint, verbose, peak_tflops, batches=()):
                 open(os.path.join(bdir, 'ready_%d' % os.getpid()), 'w').close()
                 while len([x for x in os.listdir(bdir) if x.startswith('ready_')]) < int(os.environ.get('CG_BENCH_BARRIER_N', '2')):
                     time.sleep(0.001)
-            t0 = time.time()
-            f.apply_ivf(dmap)
-            torch.cuda.synchronize()
-            dt = time.time() - t0
-        return dt, setup, trace
+            dts = []
+            for rep in range(REPS):  # REPS solves of `iters` iterations each, timed one by one: the median is reported (solves differ by +-3 %)
+                t0 = time.time()
+                f.apply_ivf(dmap)
+                torch.cuda.synchronize()
+                dts.append(time.time() - t0)
+                if rep == 0:
+                    trace = trace[:]  # the residual trace of the first timed solve
+                    f.chain.log = log0
+            dt = float(np.median(dts))
+        return dt, setup, trace, dts
 
     for kind in kinds:
         pcf = os.path.join(tmp, 'dense_%s.pk' % kind)
@@ -118,8 +125,9 @@ def _run(nside, lmax, iters, kinds, joint, verbose, peak_tflops, batches=()):
         torch.cuda.synchronize()
         t_chain = time.time() - t0
         f.chain.plogdepth = -1
-        dt, setup, trace = timed(f, dmap)
-        res[kind] = {'seconds': dt, 'iters_per_s': iters / dt, 'ms_per_iter': 1e3 * dt / iters, 'first_call_incl_dense_setup_s': setup + t_chain,
+        dt, setup, trace, dts = timed(f, dmap)
+        res[kind] = {'seconds': dt, 'seconds_each_solve': dts, 'iters_per_s': iters / dt, 'ms_per_iter': 1e3 * dt / iters,
+                     'first_call_incl_dense_setup_s': setup + t_chain,
                      'chain_setup_s': t_chain,
                      'eps_first_last': [trace[0], trace[-1]] if trace else None}
         if nside == 2048 and lmax == 2048:
@@ -156,7 +164,7 @@ def _run(nside, lmax, iters, kinds, joint, verbose, peak_tflops, batches=()):
         f = filt_cinv.cinv_tp(os.path.join(tmp, 'cinv_tp'), lmax, nside, cl_tp, transf, [ninv_t[0], ninv_p[0][0]], marge_monopole=True,
                               marge_dipole=True, chain_descr=chain('tp', iters, lmax, nside, pcf))
         f.chain.plogdepth = -1
-        dt, setup, _ = timed(f, [dev.to_dev(tmap), dev.to_dev(q), dev.to_dev(u)])
+        dt, setup, _, _ = timed(f, [dev.to_dev(tmap), dev.to_dev(q), dev.to_dev(u)])
         res['tp_joint'] = {'seconds': dt, 'iters_per_s': iters / dt, 'first_call_incl_dense_setup_s': setup}
         if verbose:
             print('tp_joint', json.dumps(res['tp_joint']), flush=True)
