@@ -50,12 +50,12 @@ HBM_ACHIEVABLE_GBS = 6300.0  # MI355X_MICROARCH.md chip table: measured streamin
 # (profiles/*_pmc_traffic.csv; refreshed whenever a kernel changes materially).  FETCH_SIZE on gfx950 counts half of the
 # bytes of 16-B-per-lane streaming reads and is uncalibrated for the scalar table streams of these kernels.
 PMC_TRAFFIC_BYTES = {
-    'leg_anals': (476752 + 887048) * 1024,   # profiles/round3_c_pmc_traffic.csv (k_leg_anals<4>; unchanged since round 1 to 0.2 %)
-    'leg_synths': (430978 + 373984) * 1024,
-    'leg_anal0': (222360 + 311186) * 1024,
-    'leg_synth0': (204853 + 188760) * 1024,
+    'leg_anals': (476783 + 887049) * 1024,   # profiles/round3_d_pmc_traffic.csv (k_leg_anals<4>; unchanged since round 1 to 0.2 %)
+    'leg_synths': (431696 + 373984) * 1024,
+    'leg_anal0': (222168 + 311194) * 1024,
+    'leg_synth0': (205126 + 188760) * 1024,
 }
-PMC_TRAFFIC_SOURCE = 'profiles/round3_c_pmc_traffic.csv'
+PMC_TRAFFIC_SOURCE = 'profiles/round3_d_pmc_traffic.csv'
 KERNEL_NAMES = {'leg_synth0': 'k_leg_synth0 (scalar Legendre synthesis)', 'leg_synths': 'k_leg_synths (spin-weighted Legendre synthesis)',
                 'leg_anal0': 'k_leg_anal0 (scalar Legendre analysis)', 'leg_anals': 'k_leg_anals (spin-weighted Legendre analysis)',
                 'leg_synths_grad': 'k_leg_synths<GONLY> (gradient-only spin synthesis)',
