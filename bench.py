@@ -494,6 +494,9 @@ def run_rank(args):
                              'seconds_each_solve': {'t': cg['t']['seconds_each_solve'], 'p': cg['p']['seconds_each_solve']},
                              'dense_setup_s': {'t': cg['t']['first_call_incl_dense_setup_s'], 'p': cg['p']['first_call_incl_dense_setup_s']},
                              'residual_first_last': {'t': cg['t']['eps_first_last'], 'p': cg['p']['eps_first_last']},
+                             # cinv_t and cinv_p of one simulation at the same time on two streams of this process (filt_cinv.apply_ivf_tp,
+                             # what library_cinv_sepTP.filter_sims runs); the T / P / TP figures above are one solve after the other
+                             'TP_concurrent': cg.get('tp_concurrent'),
                              # B simulations filtered in ONE block solve (cinv_*.apply_ivf_batch): every launch carries all B, each with
                              # its own step lengths; iterations/s per simulation = B x iterations/s of the block solve
                              'block_solves': {'note': 'B right-hand sides (simulations sharing the noise model) per solve; per-simulation rates; '

@@ -293,9 +293,16 @@ def axpy_dev(y, x, num, den=None, sign=1.0):
 _CG_BARRIER = {}
 
 
+def _ctx_key():
+    """(device, plan context of the calling thread): scratch buffers are per solver context (shts.plan_context), so that two solvers
+    running at the same time on different streams never share one"""
+    from . import shts
+    return (torch.cuda.current_device(), shts.context())
+
+
 def cg_barrier():
-    """the per-device grid-barrier words of pl_cg_dot_axpy (every solver of this process launches on one stream at a time)"""
-    d = torch.cuda.current_device()
+    """the per-device, per-context grid-barrier words of pl_cg_dot_axpy (a solver launches on one stream at a time)"""
+    d = _ctx_key()
     if d not in _CG_BARRIER:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError('CG barrier words requested while a HIP graph is being captured')
@@ -306,7 +313,7 @@ def cg_barrier():
 def cg_barrier_timed_out(reset=False):
     """True if a grid barrier of pl_cg_dot_axpy gave up on this device (results after that are invalid); synchronises.
     reset: the barrier words are zeroed afterwards (a barrier that gave up leaves its arrival counter non-zero)."""
-    d = torch.cuda.current_device()
+    d = _ctx_key()
     if d not in _CG_BARRIER or torch.cuda.is_current_stream_capturing():
         return False
     out = int(_CG_BARRIER[d][2]) != 0
@@ -359,7 +366,7 @@ _TPROJ_SCRATCH = {}
 def tproj_scratch(nb=1):
     """the per-device scratch of pl_template_project / pl_cg_fwd_tt (nb entries of a batch: nb times the size; it only grows, and an
     outgrown one is kept alive -- a captured HIP graph may hold its address)"""
-    d = torch.cuda.current_device()
+    d = _ctx_key()
     cur = _TPROJ_SCRATCH.get(d)
     if cur is None or cur[-1].numel() < nb * TEMPLATE_MAX_MODES * 256:
         if torch.cuda.is_current_stream_capturing():
@@ -402,7 +409,7 @@ _TPROJ_MD_SCRATCH = {}
 
 def tproj_md_scratch(ndoubles):
     """the per-device scratch of pl_template_project_md_b / pl_cg_fwd_tt_md_b (grows; outgrown buffers stay alive for captured graphs)"""
-    d = torch.cuda.current_device()
+    d = _ctx_key()
     cur = _TPROJ_MD_SCRATCH.get(d)
     if cur is None or cur[-1].numel() < ndoubles:
         if torch.cuda.is_current_stream_capturing():

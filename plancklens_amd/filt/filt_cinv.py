@@ -42,6 +42,102 @@ def default_chain_descr(kind, lmax, nside, pcf):
     return chain
 
 
+# ---- cinv_t and cinv_p of a simulation at the same time -------------------------------------------------------------------
+P_CONTEXT = 1  # the plan context (shts.plan_context) polarization solves run in when they may overlap a temperature solve
+_TP_SIDE_STREAMS = {}
+
+
+def _tp_side_stream():
+    """the stream of the polarization solve, one per device"""
+    d = torch.cuda.current_device()
+    if d not in _TP_SIDE_STREAMS:
+        _TP_SIDE_STREAMS[d] = torch.cuda.Stream()
+    return _TP_SIDE_STREAMS[d]
+
+
+def _p_context():
+    """the plan context of this library's polarization solves: P_CONTEXT unless $PLENS_TP_CONCURRENT = 0"""
+    from .. import shts
+    return shts.plan_context(P_CONTEXT if os.environ.get('PLENS_TP_CONCURRENT', '1') != '0' else 0)
+
+
+def run_tp(job_t, job_p, warm=True):
+    """(job_t(), job_p()) with the two jobs -- a temperature and a polarization solve, independent in the reference
+    (filt_cinv.py:515-580 `_apply_ivf_t` / `_apply_ivf_p`, called one after the other from run_qlms.py:57-62) -- running at the same
+    time in this process: job_t on the calling thread and torch's current stream, job_p on a helper thread and a side stream, inside
+    plan context P_CONTEXT (own plan workspaces, scratch buffers and captured graphs; shts.plan_context).  Most of an iteration of
+    either solve is the latency-bound chain of small kernels of its coarse multigrid levels, which leaves the other solve room on
+    the chip.  The GIL is released inside every library call and every wait on the device, so the two launch threads interleave.
+    warm=False: the same two jobs in the same contexts, one after the other on the calling thread -- used for the first solve of a
+    shape, which allocates workspaces and captures the nested stages into HIP graphs.  Results are identical either way."""
+    from .. import shts
+    if not warm or os.environ.get('PLENS_TP_CONCURRENT', '1') == '0':
+        rt = job_t()
+        with _p_context():
+            rp = job_p()
+        return rt, rp
+    import threading
+    main = torch.cuda.current_stream()
+    side = _tp_side_stream()
+    side.wait_stream(main)  # inputs made on the caller's stream
+    devid = torch.cuda.current_device()
+    box = {}
+
+    def work():
+        try:
+            torch.cuda.set_device(devid)  # (a new thread starts on device 0)
+            with torch.cuda.stream(side), shts.plan_context(P_CONTEXT):
+                box['r'] = job_p()
+        except BaseException as e:  # re-raised on the calling thread
+            box['e'] = e
+    th = threading.Thread(target=work, name='plens_cinv_p')
+    th.start()
+    try:
+        rt = job_t()
+    finally:
+        th.join()
+        main.wait_stream(side)
+    if 'e' in box:
+        raise box['e']
+    return rt, box['r']
+
+
+def _dev_tensors(x):
+    if isinstance(x, torch.Tensor):
+        return [x]
+    if isinstance(x, (list, tuple)):
+        return [t for y in x for t in _dev_tensors(y)]
+    return []
+
+
+def apply_ivf_tp(cinv_t, tmap, cinv_p, pmap, soltn_t=None, soltn_p=None):
+    """(cinv_t.apply_ivf(tmap), cinv_p.apply_ivf(pmap)) with the two solves overlapped on two streams of this process (run_tp).
+    tmap / pmap may be lists of maps / of (Q, U) pairs: block solves (apply_ivf_batch).  The first call of a shape runs the solves one
+    after the other (set-up, graph capture)."""
+    blk_t = isinstance(tmap, (list, tuple))
+    blk_p = isinstance(pmap[0], (list, tuple))
+    key = ('tp', len(tmap) if blk_t else 0, len(pmap) if blk_p else 0)
+    warm_t, warm_p = cinv_t.__dict__.setdefault('_tp_warm', set()), cinv_p.__dict__.setdefault('_tp_warm', set())
+    job_t = (lambda: cinv_t.apply_ivf_batch(tmap, soltns=soltn_t)) if blk_t else (lambda: cinv_t.apply_ivf(tmap, soltn=soltn_t))
+    job_p = (lambda: cinv_p.apply_ivf_batch(pmap, soltns=soltn_p)) if blk_p else (lambda: cinv_p.apply_ivf(pmap, soltn=soltn_p))
+    warm = key in warm_t and key in warm_p
+    paced = warm and os.environ.get('PLENS_TP_CONCURRENT', '1') != '0' and os.environ.get('PLENS_TP_PACE', '1') != '0'
+    if paced:  # the two solves meet before every top-level preconditioner call (multigrid.pace)
+        pc = multigrid.pace(2)
+        util.unjit(cinv_t.chain).pace = util.unjit(cinv_p.chain).pace = pc
+    try:
+        rt, rp = run_tp(job_t, job_p, warm=warm)
+    finally:
+        if paced:
+            util.unjit(cinv_t.chain).pace = util.unjit(cinv_p.chain).pace = None
+    if warm:  # results made on the side stream are handed to the caller's stream (their memory returns to the side stream's pool)
+        for t in _dev_tensors(rp):
+            t.record_stream(torch.cuda.current_stream())
+    warm_t.add(key)
+    warm_p.add(key)
+    return rt, rp
+
+
 class cinv(object):
     def __init__(self, lib_dir, lmax):
         self.lib_dir = lib_dir
@@ -472,39 +568,99 @@ class library_cinv_sepTP(filt_simple.library_sepTP):
         return self.cinv_t.apply_ivf(tmap, soltn=soltn)
 
     def _apply_ivf_p(self, pmap, soltn=None):
-        return self.cinv_p.apply_ivf(pmap, soltn=soltn)
+        with _p_context():  # (the context the polarization solves of filter_sims run in: one set of workspaces and graphs)
+            return self.cinv_p.apply_ivf(pmap, soltn=soltn)
 
-    def filter_sims(self, idxs, fields='tp', batch=None):
+    def supports_block(self, a):
+        """True when the 't' / 'p' filter takes block vectors (several simulations per solve): the one-call operators only -- Q / U
+        templates, more than dev.TEMPLATE_MAX_MODES temperature modes, an EB spectrum or replaced transforms rule it out"""
+        f = self.cinv_t if a == 't' else self.cinv_p
+        ok = util.unjit(f.chain.n_inv_filt).supports_block()
+        if a == 'p':
+            ok = ok and 'eb' not in f.cl
+        return bool(ok)
+
+    def filter_sims(self, idxs, fields='tp', batch=None, concurrent=None):
         """Filters (and caches) the simulations `idxs` that are not cached yet, `batch` at a time in block solves of the CG
         (cinv_t / cinv_p.apply_ivf_batch: every launch of a solve carries the whole block) -- what the driver's filtering phase
         calls instead of looping over get_sim_tlm / get_sim_elm one simulation at a time (run_qlms.py:57-62).  Same cache files, same
-        alms.  batch: block size (default $PLENS_CG_BATCH or 4; 1 = one solve per simulation).  Returns True (the wrappers of
-        filt_util forward the call and report whether the library underneath took it)."""
+        alms.  batch: block size (default $PLENS_CG_BATCH or 4; 1 = one solve per simulation); a filter that cannot take block
+        vectors (supports_block) is served one simulation at a time.  concurrent (default $PLENS_TP_CONCURRENT != 0): when both 't'
+        and 'p' are asked for, the temperature and polarization solves of a block run at the same time on two streams of this
+        process (apply_ivf_tp) instead of one after the other.  With cache=False the results only live in the device cache of
+        _dev_slots simulations, which grows to the block size; more indices than that per call are solved again when asked for.
+        Returns True (the wrappers of filt_util forward the call and report whether the library underneath took it)."""
         if batch is None:
             batch = int(os.environ.get('PLENS_CG_BATCH', '4'))
+        batch = max(1, batch)
+        if concurrent is None:
+            concurrent = os.environ.get('PLENS_TP_CONCURRENT', '1') != '0'
         for a in fields:
             assert a in 'tp', a
-            names = ['t'] if a == 't' else ['e', 'b']
-            todo = [i for i in idxs if not (self.cache and all(os.path.exists(self._fn(n, i)) for n in names))
-                    and not all(n in self._dev_cache.get(i, {}) for n in names)]
-            for k in range(0, len(todo), max(1, batch)):
-                blk = todo[k:k + max(1, batch)]
-                if len(blk) == 1 or self.soltn_lib is not None:  # (starting points come one by one)
-                    for i in blk:
-                        self.get_sim_alm_dev(names[0] + 'lm', i)
-                    continue
-                if a == 't':
-                    maps = [dev.to_dev(self.sim_lib.get_sim_tmap(i), torch.float64) for i in blk]
-                    outs = [(x,) for x in self.cinv_t.apply_ivf_batch(maps)]
+        fields = [a for a in 'tp' if a in fields]
+        names = {'t': ['t'], 'p': ['e', 'b']}
+
+        def missing(a, i):
+            return not (self.cache and all(os.path.exists(self._fn(n, i)) for n in names[a])) \
+                and not all(n in self._dev_cache.get(i, {}) for n in names[a])
+        todo = {a: [i for i in idxs if missing(a, i)] for a in fields}
+        bsz = {a: (batch if (self.supports_block(a) and self.soltn_lib is None) else 1) for a in fields}  # (starting points come one by one)
+        if not self.cache:
+            n_all = len(set(i for a in fields for i in todo[a]))
+            if n_all > self._dev_slots:
+                self._dev_slots = min(n_all, max(self._dev_slots, batch))  # (instance attribute: this library only)
+            if n_all > self._dev_slots:
+                print('filter_sims: cache=False and %d simulations asked for: only the last %d stay resident' % (n_all, self._dev_slots))
+
+        def data(a, i):
+            if a == 't':
+                return dev.to_dev(self.sim_lib.get_sim_tmap(i), torch.float64)
+            return [dev.to_dev(m, torch.float64) for m in self.sim_lib.get_sim_pmap(i)]
+
+        def store(a, blk, outs):
+            for i, out in zip(blk, outs):
+                ent = self._dev_entry(i)
+                for n, x in zip(names[a], out):
+                    ent[n] = dev.to_dev(x).clone()  # (rows of the block solution: own storage, so that the block can be released)
+                    if self.cache:
+                        hp.write_alm(self._fn(n, i), dev.to_host(ent[n]), overwrite=True)
+
+        def solve(a, blk):
+            f = self.cinv_t if a == 't' else self.cinv_p
+            if len(blk) == 1:
+                soltn = None if self.soltn_lib is None else (self._soltn_t(blk[0]) if a == 't' else self._soltn_p(blk[0]))
+                out = f.apply_ivf(data(a, blk[0]), soltn=soltn)
+                return [(out,)] if a == 't' else [tuple(out)]
+            outs = f.apply_ivf_batch([data(a, i) for i in blk])
+            return [(x,) for x in outs] if a == 't' else [tuple(x) for x in outs]
+
+        if concurrent and len(fields) == 2:
+            # blocks of simulations that need both filters: T block and P block at the same time
+            both = [i for i in todo['t'] if i in set(todo['p'])]
+            step = min(bsz['t'], bsz['p'])
+            for k in range(0, len(both), step):
+                blk = both[k:k + step]
+                if len(blk) == 1:
+                    st = None if self.soltn_lib is None else self._soltn_t(blk[0])
+                    sp = None if self.soltn_lib is None else self._soltn_p(blk[0])
+                    rt, rp = apply_ivf_tp(self.cinv_t, data('t', blk[0]), self.cinv_p, data('p', blk[0]), soltn_t=st, soltn_p=sp)
+                    rt, rp = [(rt,)], [tuple(rp)]
                 else:
-                    maps = [[dev.to_dev(m, torch.float64) for m in self.sim_lib.get_sim_pmap(i)] for i in blk]
-                    outs = self.cinv_p.apply_ivf_batch(maps)
-                for i, out in zip(blk, outs):
-                    ent = self._dev_entry(i)
-                    for n, x in zip(names, out):
-                        ent[n] = x.clone()  # (rows of the block solution: own storage, so that the block can be released)
-                        if self.cache:
-                            hp.write_alm(self._fn(n, i), dev.to_host(ent[n]), overwrite=True)
+                    rt, rp = apply_ivf_tp(self.cinv_t, [data('t', i) for i in blk], self.cinv_p, [data('p', i) for i in blk])
+                    rt, rp = [(x,) for x in rt], [tuple(x) for x in rp]
+                store('t', blk, rt)
+                store('p', blk, rp)
+            done = set(both)
+            todo = {a: [i for i in todo[a] if i not in done] for a in fields}
+        for a in fields:
+            for k in range(0, len(todo[a]), bsz[a]):
+                blk = todo[a][k:k + bsz[a]]
+                if a == 'p':  # (polarization solves always in their own plan context, see run_tp)
+                    with _p_context():
+                        outs = solve(a, blk)
+                else:
+                    outs = solve(a, blk)
+                store(a, blk, outs)
         return True
 
     def get_tmliklm(self, idx):

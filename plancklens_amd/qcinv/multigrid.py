@@ -74,8 +74,18 @@ class multigrid_chain(object):
         monitor = cd_monitors.monitor_basic(dot_op, logger=logger, iter_max=self.bstage.iter_max,
                                             eps_min=self.bstage.eps_min, d0=dot_op(tpn_alm, tpn_alm))
         fwd_op = self.opfilt.fwd_op(self.s_cls, self.n_inv_filt)
-        self.last_iters = cd_solve.cd_solve(soltn, tpn_alm, fwd_op, self.bstage.pre_ops, dot_op, monitor,
-                                            tr=self.bstage.tr, cache=self.bstage.cache)
+        pre_ops, pace = self.bstage.pre_ops, getattr(self, 'pace', None)
+        if pace is not None:
+            # two solves of this process running at the same time (filt_cinv.run_tp): each waits for the other before it launches
+            # its preconditioner.  The stopping criterion just before has drained this solve's stream, so the two chains of small
+            # coarse-level kernels start together and overlap each other instead of hiding behind the other solve's chip-filling
+            # fine-level transforms.
+            pre_ops = [_paced(op, pace) for op in pre_ops]
+        try:
+            self.last_iters = cd_solve.cd_solve(soltn, tpn_alm, fwd_op, pre_ops, dot_op, monitor, tr=self.bstage.tr, cache=self.bstage.cache)
+        finally:
+            if pace is not None:
+                pace.leave()
         finifunc(soltn, self.s_cls, self.n_inv_filt)
 
     def log(self, stage, iter, eps, **kwargs):
@@ -95,6 +105,47 @@ class multigrid_chain(object):
                         dev.to_host(s) if not hasattr(s, 'elm') else np.array([dev.to_host(s.elm), dev.to_host(s.blm)]))
             with open(self.debug_log_prefix + 'stage_%d.dat' % stage.depth, 'a') as f:
                 f.write('%05d %05d %10.6e %05d %s\n' % (self.iter_tot, int(elapsed), eps, iter, str(elapsed)))
+
+
+class pace(object):
+    """Rendezvous of the top-level iterations of solves that run at the same time on different streams (one thread each): `wait`
+    returns once every party still in the game has arrived (or after `timeout` seconds: pacing is an optimisation, never a
+    condition for progress); a solve that ends calls `leave`."""
+
+    def __init__(self, parties, timeout=0.25):
+        import threading
+        self.cond = threading.Condition()
+        self.parties, self.timeout = parties, timeout
+        self.waiting, self.generation = 0, 0
+
+    def wait(self):
+        with self.cond:
+            if self.parties <= 1:
+                return
+            self.waiting += 1
+            if self.waiting >= self.parties:
+                self.waiting = 0
+                self.generation += 1
+                self.cond.notify_all()
+                return
+            gen = self.generation
+            if not self.cond.wait_for(lambda: self.generation != gen, timeout=self.timeout):
+                self.waiting = max(0, self.waiting - 1)  # gave up: go on alone
+
+    def leave(self):
+        with self.cond:
+            self.parties -= 1
+            if self.waiting >= self.parties > 0:
+                self.waiting = 0
+                self.generation += 1
+            self.cond.notify_all()
+
+
+def _paced(op, pc):
+    def call(v):
+        pc.wait()
+        return op(v)
+    return call
 
 
 def parse_pre_op_descr(pre_op_descr, **kwargs):
@@ -195,7 +246,9 @@ class pre_op_multigrid(object):
     def calc(self, talm):
         if not self._capturable(talm):
             return self._calc_eager(talm)
-        key = tuple((tuple(p.shape), p.dtype) for p in _parts(talm))
+        from .. import shts
+        # (a graph holds the workspace addresses of the plan context it was recorded in: one graph per context)
+        key = tuple((tuple(p.shape), p.dtype) for p in _parts(talm)) + (shts.context(),)
         st = self._graphs.setdefault(key, {'calls': 0, 'graph': None})
         if st['graph'] is None:
             st['calls'] += 1
@@ -213,7 +266,8 @@ class pre_op_multigrid(object):
                 gc_was_on = gc.isenabled()
                 gc.disable()
                 try:
-                    with torch.cuda.graph(g):
+                    # thread_local: another solver of this process may be launching (and allocating) on its own stream meanwhile
+                    with torch.cuda.graph(g, capture_error_mode='thread_local'):
                         out = self._calc_eager(_like(talm, st['in']))
                 finally:
                     if gc_was_on:

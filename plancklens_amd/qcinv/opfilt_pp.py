@@ -250,6 +250,13 @@ class alm_filter_ninv(object):
                 and alm2map_spin is shts.alm2map_spin and map2alm_spin is shts.map2alm_spin and not shts.lane_active()
                 and all(n.is_contiguous() and n.dtype == torch.float64 for n in self.n_inv))
 
+    def supports_block(self):
+        """True when block vectors (eblm of [nb, nalm] tensors) can go through this filter: they take the one-call operator only
+        (fwd_op.calc), which marginalised Q / U templates, two different beams or replaced transforms rule out"""
+        self._load_ninv()
+        z = torch.empty((1, 1), dtype=torch.complex128, device=self.n_inv[0].device)
+        return self.one_call_ok(eblm([z, z]))
+
     def apply_alm_new(self, alm, add=None, fl_add_e=None, fl_add_b=None):
         """B^t Y^t N^-1 Y B (E, B) (+ (fl_add_e E', fl_add_b B') for add = (E', B')) as a new eblm (the input is left alone)."""
         self._load_ninv()

@@ -206,6 +206,10 @@ class alm_filter_ninv(object):
         return (isinstance(alm, torch.Tensor) and alm.is_cuda and alm2map is shts.alm2map and map2alm is shts.map2alm and not shts.lane_active()
                 and nmodes <= dev.TEMPLATE_MAX_MODES and self.n_inv.is_contiguous() and self.n_inv.dtype == torch.float64)
 
+    def supports_block(self):
+        """True when block vectors [nb, nalm] can go through this filter (they take the one-call operator only: fwd_op.calc)"""
+        return self.one_call_ok(torch.empty((1, 1), dtype=torch.complex128, device=self.n_inv.device))
+
     def apply_alm_new(self, alm, alm_add=None, fl_add=None):
         """B^t Y^t N^-1 Y B alm (+ fl_add alm_add) as a new array (the input is left alone)."""
         lmax = hp.Alm.getlmax(alm.shape[-1] if isinstance(alm, torch.Tensor) else alm.size)

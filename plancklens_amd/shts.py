@@ -10,6 +10,7 @@ modified).  torch CUDA tensors in -> torch CUDA tensors out (device pointers, as
 stream): used by the device-resident QE / CG layers.
 """
 import ctypes
+import threading
 
 import numpy as np
 
@@ -48,12 +49,15 @@ class Plan(object):
         different forks and streams may overlap.  Fork 0 is the plan itself."""
         if i == 0:
             return self
+        if getattr(self, '_parent', None) is not None:  # a fork of a fork is another fork of the original plan
+            return self._parent.fork((getattr(self, '_fork_key', None), i))
         forks = self.__dict__.setdefault('_forks', {})
         if i not in forks:
             h = ctypes.c_void_p()
             _lib.check(_lib.lib().pl_plan_fork(self.h, ctypes.byref(h)))
             f = Plan.__new__(Plan)
             f.h, f.nside, f.lmax, f.npix, f.nalm, f._parent = h, self.nside, self.lmax, self.npix, self.nalm, self
+            f.shard, f._fork_key = self.shard, i
             if getattr(self, '_profiling', False):
                 f.profile(True)
             forks[i] = f
@@ -103,11 +107,44 @@ def _plan_key(nside, lmax):
     return (int(nside), int(lmax), dev_id)
 
 
+# ---- plan contexts: independent solvers of one process on different streams ---------------------------------------------
+_CTX = threading.local()
+_PLANS_LOCK = threading.RLock()
+
+
+def context():
+    """The plan context of the calling thread (0 unless inside `plan_context`)."""
+    return getattr(_CTX, 'i', 0)
+
+
+class plan_context(object):
+    """`with shts.plan_context(i):` -- every plan handed out inside (get_plan, and with it every transform and one-call CG operator)
+    is fork i of the shared plan: same geometry / recursion / FFT tables, own workspaces, phase buffer and ring-FFT side streams.
+    Two solvers that run at the same time on different streams of one process -- cinv_t and cinv_p of a simulation
+    (filt_cinv.library_cinv_sepTP.filter_sims) -- each work inside a context of their own, so that neither the eager launches nor
+    the HIP graphs captured there (which hold workspace addresses) share a buffer.  The context is a property of the thread;
+    the per-device scratch buffers of plancklens_amd.dev are keyed by it as well.  Context 0 is the plain plan."""
+
+    def __init__(self, i):
+        self.i = int(i)
+
+    def __enter__(self):
+        self.prev = context()
+        _CTX.i = self.i
+        return self
+
+    def __exit__(self, *exc):
+        _CTX.i = self.prev
+        return False
+
+
 def get_plan(nside, lmax):
     key = _plan_key(nside, lmax)
-    if key not in _PLANS:
-        _PLANS[key] = Plan(key[0], key[1])
-    return _PLANS[key]
+    with _PLANS_LOCK:
+        if key not in _PLANS:
+            _PLANS[key] = Plan(key[0], key[1])
+        c = context()
+        return _PLANS[key] if c == 0 else _PLANS[key].fork(('ctx', c))
 
 
 def get_shard_plan(nside, lmax, rank, nranks):

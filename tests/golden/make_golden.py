@@ -595,6 +595,62 @@ def make_cg2_golden():
     print('wrote cg2_golden.npz with %d arrays' % len(out))
 
 
+def make_cinv_golden():
+    """The reference's own filt_cinv.cinv_t and cinv_p (filt_cinv.py:56-338) at the smallest size their constructors accept
+    (nside 512, lmax 1024; :77, :225), default 4-stage / 3-stage chains with the dense(64) / dense(32) levels and the D_l rescaling,
+    eps = 1e-5 stopping rule, on a masked sky with inhomogeneous noise, monopole + dipole marginalised, over the oracle SHTs.
+    Inputs are the recipe tests/helpers.py::cinv_golden_inputs (checksums stored); outputs: side files, the top-level residual
+    trace, C_l of the solutions, every entry with l <= 64 and a seeded 10 000-entry subset of the rest."""
+    import time
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import cinv_golden_inputs
+    from plancklens.filt import filt_cinv
+    d = cinv_golden_inputs(so.alm2map, so.alm2map_spin)
+    nside, lmax, cl, transf = d['nside'], d['lmax'], d['cl'], d['transf']
+    out = {'nside': nside, 'lmax': lmax, 'transf': transf}
+    for k in ['ninv_t', 'ninv_p', 'tmap', 'qmap', 'umap']:
+        out['chk_' + k] = np.array([d[k].sum(), (d[k] ** 2).sum(), d[k][::9973].sum()])
+    for k in cl:
+        out['cl_' + k] = cl[k]
+    l_of = np.concatenate([np.arange(m, lmax + 1) for m in range(lmax + 1)])
+    sub = np.sort(np.random.default_rng(99).choice(l_of.size, 10000, replace=False))
+    out['subset'] = sub
+    out['low'] = np.nonzero(l_of <= 64)[0]
+    tmp = tempfile.mkdtemp(prefix='plgolden_cinv_')
+    try:
+        for kind in ('t', 'p'):
+            trace = []
+            t0 = time.time()
+            if kind == 't':
+                filt = filt_cinv.cinv_t(os.path.join(tmp, 'cinv_t'), lmax, nside, cl, transf, [d['ninv_t']])
+            else:
+                filt = filt_cinv.cinv_p(os.path.join(tmp, 'cinv_p'), lmax, nside, cl, transf, [[d['ninv_p']]])
+            log0 = filt.chain.log
+            filt.chain.log = lambda stage, it, eps, **kw: (trace.append((stage.depth, it, eps)), log0(stage, it, eps, **kw))
+            if kind == 't':
+                sol = [filt.apply_ivf(d['tmap'])]
+                out['ftl'] = np.loadtxt(os.path.join(tmp, 'cinv_t', 'ftl.dat'))
+                out['tal_t'] = np.loadtxt(os.path.join(tmp, 'cinv_t', 'tal.dat'))
+                out['fmask_t_sum'] = myhp.read_map(os.path.join(tmp, 'cinv_t', 'fmask.fits.gz')).sum()
+                names = ['tlm']
+            else:
+                sol = list(filt.apply_ivf([d['qmap'], d['umap']]))
+                out['fel'] = np.loadtxt(os.path.join(tmp, 'cinv_p', 'fel.dat'))
+                out['fbl'] = np.loadtxt(os.path.join(tmp, 'cinv_p', 'fbl.dat'))
+                names = ['elm', 'blm']
+            out['trace_' + kind] = np.array([t[2] for t in trace if t[0] == 0])
+            for nm, a in zip(names, sol):
+                out[nm + '_cl'] = myhp.alm2cl(a)
+                out[nm + '_sub'] = a[sub]
+                out[nm + '_low'] = a[out['low']]
+            print('cinv_%s: %d top-level iterations in %.0f s, last eps %.3e' % (kind, len(out['trace_' + kind]), time.time() - t0,
+                                                                               out['trace_' + kind][-1]), flush=True)
+            np.savez_compressed(os.path.join(HERE, 'cinv_golden.npz'), **out)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    print('wrote cinv_golden.npz with %d arrays' % len(out))
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'resp':   # only the response / N0 fixtures
         assert os.path.isdir(REF), 'the reference is only present in the build container'
@@ -606,11 +662,11 @@ if __name__ == '__main__':
         install_healpy_standin()
         sys.path.insert(0, REF)
         make_lib_golden()
-    elif len(sys.argv) > 1 and sys.argv[1] in ('sims', 'cg2'):   # simulation inputs / small wrapper classes; further noise models of the CG
+    elif len(sys.argv) > 1 and sys.argv[1] in ('sims', 'cg2', 'cinv'):   # simulation inputs / small wrapper classes; further noise models of the CG
         assert os.path.isdir(REF), 'the reference is only present in the build container'
         install_healpy_standin()
         sys.path.insert(0, REF)
-        {'sims': make_sims_golden, 'cg2': make_cg2_golden}[sys.argv[1]]()
+        {'sims': make_sims_golden, 'cg2': make_cg2_golden, 'cinv': make_cinv_golden}[sys.argv[1]]()
     elif len(sys.argv) > 1 and sys.argv[1] == 'cg':   # only the CG fixtures
         assert os.path.isdir(REF), 'the reference is only present in the build container'
         install_healpy_standin()

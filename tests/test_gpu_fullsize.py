@@ -405,6 +405,16 @@ def test_estimators_end_to_end_at_baseline_size(tmp_path):
         assert eg < 1e-11 and ec < 1e-11, (key, eg, ec)  # what the arithmetic delivers; the line above is north_star's bar
 
 
+def test_ptt_end_to_end_at_config1_size(tmp_path):
+    """BASELINE config 1's exact workload -- the temperature-only 'ptt' estimator at nside = lmax = lmax_qlm = 512 (the reference's own
+    CPU-runnable case, idealized_example.py on a small grid) -- end to end against the oracle: the 512 plan picks other rings-per-lane
+    and ring-FFT classes than the 2048 one.  The polarization and MV keys ride along (the oracle does this size in seconds)."""
+    out = _estimators_vs_oracle(tmp_path, 512, ['ptt', 'p_p', 'p'], seed=13)
+    for key, (eg, ec) in out.items():
+        assert eg < 1e-8 and ec < 1e-8, (key, eg, ec)
+        assert eg < 1e-11 and ec < 1e-11, (key, eg, ec)
+
+
 def test_mv_estimator_end_to_end_at_4096(tmp_path):
     """BASELINE config 5's per-GPU unit of work -- the MV 'p' reconstruction at nside = lmax = lmax_qlm = 4096 -- against the oracle
     (k_leg_anal0<8>, the split-Bluestein 4096 class, the four-component phase buffers and the nine-map product at npix = 2e8)."""

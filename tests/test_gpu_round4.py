@@ -1,0 +1,165 @@
+"""Round-4 GPU tests: cinv_t and cinv_p of a simulation at the same time on two streams (filt_cinv.apply_ivf_tp / run_tp,
+shts.plan_context), filter_sims on filters that cannot take block vectors, and the reference's own filt_cinv.cinv_t / cinv_p
+classes at the smallest size they accept (tests/golden/cinv_golden.npz, made by tests/golden/make_golden.py cinv)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import relrms
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _survey_setup(nb, seed=4):
+    from plancklens_amd import hp, shts
+    rng = np.random.default_rng(seed)
+    nside, lmax = 512, 1024
+    npix = 12 * nside ** 2
+    ell = np.arange(lmax + 1.)
+    cl = {'tt': np.where(ell >= 2, 1e4 / np.maximum(ell, 1) ** 2.5, 0.), 'ee': np.where(ell >= 2, 50. / np.maximum(ell, 1) ** 2, 0.),
+          'bb': np.where(ell >= 2, 1. / np.maximum(ell, 1) ** 2, 0.)}
+    transf = hp.gauss_beam(10. / 60 / 180 * np.pi, lmax=lmax)
+    x, y, z = hp.pix2vec(nside, np.arange(npix))
+    mask = (np.abs(z) > 0.25).astype(float)
+    vamin = np.sqrt(hp.nside2pixarea(nside, degrees=True)) * 60
+    tmaps, pmaps = [], []
+    for i in range(nb):
+        tmaps.append(shts.alm2map(hp.almxfl(hp.synalm(cl['tt'], lmax, rng), transf), nside) + 30. / vamin * rng.standard_normal(npix))
+        q, u = shts.alm2map_spin([hp.almxfl(hp.synalm(cl['ee'], lmax, rng), transf), hp.almxfl(hp.synalm(cl['bb'], lmax, rng), transf)], nside, 2, lmax)
+        pmaps.append([q + 40. / vamin * rng.standard_normal(npix), u + 40. / vamin * rng.standard_normal(npix)])
+    return nside, lmax, cl, transf, mask, vamin, tmaps, pmaps
+
+
+def test_cinv_t_and_cinv_p_at_the_same_time(tmp_path):
+    """apply_ivf_tp: the temperature solve on the calling thread / current stream and the polarization solve on a helper thread / side
+    stream inside its own plan context give exactly what the two solves give one after the other (same kernels, same order within
+    each solve; only workspaces, scratch buffers and captured graphs are per context) -- single solves, block solves, and through
+    library_cinv_sepTP.filter_sims."""
+    import torch
+    from plancklens_amd import dev, shts
+    from plancklens_amd.filt import filt_cinv
+    nside, lmax, cl, transf, mask, vamin, tmaps, pmaps = _survey_setup(4)
+    cinv_t = filt_cinv.cinv_t(str(tmp_path / 'cinv_t'), lmax, nside, cl, transf, [mask * (vamin / 30.) ** 2])
+    cinv_p = filt_cinv.cinv_p(str(tmp_path / 'cinv_p'), lmax, nside, cl, transf, [[mask * (vamin / 40.) ** 2]])
+    ones_t = [cinv_t.apply_ivf(m) for m in tmaps]
+    ones_p = [cinv_p.apply_ivf(m) for m in pmaps]
+    assert shts.context() == 0
+    for rep in range(3):  # first call: one after the other in the two contexts (set-up, graph capture); then overlapped
+        i = rep % 2
+        t, (e, b) = filt_cinv.apply_ivf_tp(cinv_t, tmaps[i], cinv_p, pmaps[i])
+        assert np.array_equal(t, ones_t[i]), (rep, relrms(t, ones_t[i]))
+        assert np.array_equal(e, ones_p[i][0]) and np.array_equal(b, ones_p[i][1]), (rep, relrms(e, ones_p[i][0]))
+    assert shts.context() == 0
+    # device maps in, device alms out, usable on the caller's stream
+    td, pd = dev.to_dev(tmaps[2]), [dev.to_dev(m) for m in pmaps[2]]
+    t, (e, b) = filt_cinv.apply_ivf_tp(cinv_t, td, cinv_p, pd)
+    assert isinstance(e, torch.Tensor) and np.array_equal(dev.to_host(t), ones_t[2]) and np.array_equal(dev.to_host(b), ones_p[2][1])
+    # block solves of two simulations each
+    for rep in range(2):
+        ts, ps = filt_cinv.apply_ivf_tp(cinv_t, tmaps[:2], cinv_p, pmaps[:2])
+        for i in range(2):
+            assert relrms(ts[i], ones_t[i]) < 1e-12 and relrms(ps[i][0], ones_p[i][0]) < 1e-12 and relrms(ps[i][1], ones_p[i][1]) < 1e-12
+
+    class sims(object):
+        def hashdict(self):
+            return {'tp': 4}
+
+        def get_sim_tmap(self, idx):
+            return tmaps[idx]
+
+        def get_sim_pmap(self, idx):
+            return pmaps[idx]
+    lib = filt_cinv.library_cinv_sepTP(str(tmp_path / 'ivfs'), sims(), cinv_t, cinv_p, cl)
+    lib.filter_sims([0, 1, 2, 3], fields='tp', batch=2)  # the second block runs overlapped
+    for i in range(4):
+        assert relrms(lib.get_sim_tlm(i), ones_t[i]) < 1e-12
+        assert relrms(lib.get_sim_elm(i), ones_p[i][0]) < 1e-12 and relrms(lib.get_sim_blm(i), ones_p[i][1]) < 1e-12
+    # one by one through the library: the polarization solve in its own context as well
+    lib2 = filt_cinv.library_cinv_sepTP(str(tmp_path / 'ivfs2'), sims(), cinv_t, cinv_p, cl, )
+    assert relrms(lib2.get_sim_elm(3), ones_p[3][0]) < 1e-12 and relrms(lib2.get_sim_tlm(3), ones_t[3]) < 1e-12
+
+
+def test_filter_sims_falls_back_when_a_filter_takes_no_block_vectors(tmp_path):
+    """A cinv_p with marginalised Q / U templates has no block operator (opfilt_pp.one_call_ok needs single vectors for the
+    harmonic-space projection): filter_sims must serve it one simulation at a time instead of failing in fwd_op, with the
+    temperature filter still going through block solves; cache=False keeps every result of the call resident."""
+    from plancklens_amd import hp
+    from plancklens_amd.filt import filt_cinv
+    nside, lmax, cl, transf, mask, vamin, tmaps, pmaps = _survey_setup(3, seed=5)
+    npix = 12 * nside ** 2
+    th, ph = hp.pix2ang(nside, np.arange(npix))
+    tq = [np.cos(th) * mask, np.sin(th) * np.cos(ph) * mask]
+    tu = [np.sin(2 * th) * np.sin(ph) * mask]
+    cinv_t = filt_cinv.cinv_t(str(tmp_path / 'cinv_t'), lmax, nside, cl, transf, [mask * (vamin / 30.) ** 2])
+    cinv_p = filt_cinv.cinv_p(str(tmp_path / 'cinv_p'), lmax, nside, cl, transf, [[mask * (vamin / 40.) ** 2]], marge_qmaps=tq, marge_umaps=tu)
+
+    class sims(object):
+        def hashdict(self):
+            return {'tmpl': 3}
+
+        def get_sim_tmap(self, idx):
+            return tmaps[idx]
+
+        def get_sim_pmap(self, idx):
+            return pmaps[idx]
+    lib = filt_cinv.library_cinv_sepTP(str(tmp_path / 'ivfs'), sims(), cinv_t, cinv_p, cl)
+    lib.cache = False
+    assert lib.supports_block('t') and not lib.supports_block('p')
+    lib.filter_sims([0, 1, 2], fields='tp', batch=3)
+    assert all(set(lib._dev_cache.get(i, {})) == {'t', 'e', 'b'} for i in range(3)), 'every simulation of the call stays resident'
+    for i in range(3):
+        e, b = cinv_p.apply_ivf(pmaps[i])
+        assert relrms(lib.get_sim_elm(i), e) < 1e-12 and relrms(lib.get_sim_blm(i), b) < 1e-12
+        assert relrms(lib.get_sim_tlm(i), cinv_t.apply_ivf(tmaps[i])) < 1e-12
+
+
+def test_cinv_t_and_cinv_p_vs_the_reference_classes(tmp_path, oracle):
+    """filt_cinv.cinv_t / cinv_p against the reference's own classes (filt_cinv.py:56-338) at the smallest size their constructors
+    accept (nside 512, lmax 1024): default 4-stage / 3-stage chains with the dense(64) / dense(32) levels, D_l rescaling, eps = 1e-5
+    stopping rule, galactic-cut + point-source mask, inhomogeneous noise, monopole + dipole marginalised.  The reference ran over
+    the oracle's transforms (tests/golden/make_golden.py cinv -> cinv_golden.npz); inputs are re-made here from the shared recipe
+    (tests/helpers.py::cinv_golden_inputs, checksums stored).  Compared: the side files, the number of top-level iterations, the
+    residual trace, C_l of the solutions, every entry with l <= 64 and a seeded 10 000-entry subset."""
+    from helpers import cinv_golden_inputs
+    from plancklens_amd import hp
+    from plancklens_amd.filt import filt_cinv
+    g = np.load(os.path.join(HERE, 'golden', 'cinv_golden.npz'))
+    d = cinv_golden_inputs(oracle.alm2map, oracle.alm2map_spin)
+    nside, lmax, cl, transf = d['nside'], d['lmax'], d['cl'], d['transf']
+    assert nside == int(g['nside']) and lmax == int(g['lmax']) and np.array_equal(transf, g['transf'])
+    for k in ['ninv_t', 'ninv_p', 'tmap', 'qmap', 'umap']:  # the same inputs as the generator's (their transforms may round differently)
+        chk = np.array([d[k].sum(), (d[k] ** 2).sum(), d[k][::9973].sum()])
+        assert np.allclose(chk, g['chk_' + k], rtol=1e-9, atol=1e-9 * np.sqrt(chk[1])), (k, chk, g['chk_' + k])
+    sub, low = g['subset'], g['low']
+    report = []
+    for kind in ('t', 'p'):
+        trace = []
+        if kind == 't':
+            filt = filt_cinv.cinv_t(str(tmp_path / 'cinv_t'), lmax, nside, cl, transf, [d['ninv_t']])
+        else:
+            filt = filt_cinv.cinv_p(str(tmp_path / 'cinv_p'), lmax, nside, cl, transf, [[d['ninv_p']]])
+        log0 = filt.chain.log
+        filt.chain.log = lambda stage, it, eps, **kw: (trace.append((stage.depth, it, eps)), log0(stage, it, eps, **kw))
+        if kind == 't':
+            sols = {'tlm': filt.apply_ivf(d['tmap'])}
+            assert np.allclose(filt.get_ftl(), g['ftl'], rtol=1e-12, atol=0) and np.allclose(filt.get_tal('t'), g['tal_t'], rtol=1e-12)
+            assert filt.get_fmask().sum() == float(g['fmask_t_sum'])
+        else:
+            e, b = filt.apply_ivf([d['qmap'], d['umap']])
+            sols = {'elm': e, 'blm': b}
+            assert np.allclose(filt.get_fel(), g['fel'], rtol=1e-12, atol=0) and np.allclose(filt.get_fbl(), g['fbl'], rtol=1e-12, atol=0)
+        tr = np.array([t[2] for t in trace if t[0] == 0])
+        ref = g['trace_' + kind]
+        assert len(tr) == len(ref), (kind, len(tr), len(ref), tr[-3:], ref[-3:])  # same number of top-level iterations
+        assert np.allclose(tr, ref, rtol=1e-6), (kind, np.max(np.abs(tr / ref - 1)))
+        for nm, a in sols.items():
+            e_sub, e_low = relrms(a[sub], g[nm + '_sub']), relrms(a[low], g[nm + '_low'])
+            e_cl = float(np.max(np.abs(hp.alm2cl(a)[2:] / g[nm + '_cl'][2:] - 1)))
+            report.append('%s: %d iterations, subset %.1e, l <= 64 %.1e, C_l %.1e, trace %.1e' % (nm, len(tr) - 1, e_sub, e_low, e_cl,
+                                                                                              np.max(np.abs(tr / ref - 1))))
+            assert e_sub < 1e-8 and e_low < 1e-8 and e_cl < 1e-8, report[-1]
+    with open(os.path.join(os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(HERE)), 'gpurun_out', 'cinv_reference_parity.txt'), 'w') as f:
+        f.write('\n'.join(report) + '\n')
+    print('\n'.join(report))

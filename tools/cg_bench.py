@@ -111,6 +111,7 @@ def _run(nside, lmax, iters, kinds, joint, verbose, peak_tflops, batches=()):
             dt = float(np.median(dts))
         return dt, setup, trace, dts
 
+    filters, dmaps_of = {}, {}
     for kind in kinds:
         pcf = os.path.join(tmp, 'dense_%s.pk' % kind)
         if kind == 't':
@@ -119,6 +120,7 @@ def _run(nside, lmax, iters, kinds, joint, verbose, peak_tflops, batches=()):
         else:
             f = filt_cinv.cinv_p(os.path.join(tmp, 'cinv_p'), lmax, nside, cl, transf, ninv_p, chain_descr=chain('p', iters, lmax, nside, pcf))
             dmap = [dev.to_dev(q), dev.to_dev(u)]
+        filters[kind], dmaps_of[kind] = f, dmap
         torch.cuda.synchronize()
         t0 = time.time()
         f.chain.instantiate()  # parses the chain: builds (or loads) the dense coarse preconditioner
@@ -168,6 +170,28 @@ def _run(nside, lmax, iters, kinds, joint, verbose, peak_tflops, batches=()):
         res['tp_joint'] = {'seconds': dt, 'iters_per_s': iters / dt, 'first_call_incl_dense_setup_s': setup}
         if verbose:
             print('tp_joint', json.dumps(res['tp_joint']), flush=True)
+    if 't' in res and 'p' in res and os.environ.get('CG_BENCH_CONCURRENT', '1') != '0':
+        # cinv_t and cinv_p of the simulation at the same time on two streams of this process (filt_cinv.apply_ivf_tp): the form
+        # library_cinv_sepTP.filter_sims runs.  One "T + P iteration" = one top-level iteration of each solve.
+        try:
+            ft, fp = filters['t'], filters['p']
+            filt_cinv.apply_ivf_tp(ft, dmaps_of['t'], fp, dmaps_of['p'])  # first call: one after the other, in the contexts of the concurrent form
+            torch.cuda.synchronize()
+            dts = []
+            for rep in range(REPS):
+                t0 = time.time()
+                filt_cinv.apply_ivf_tp(ft, dmaps_of['t'], fp, dmaps_of['p'])
+                torch.cuda.synchronize()
+                dts.append(time.time() - t0)
+            dtc = float(np.median(dts))
+            res['tp_concurrent'] = {'seconds': dtc, 'seconds_each_solve': dts, 'iters_per_s': iters / dtc, 'ms_per_iter': 1e3 * dtc / iters,
+                                    'speedup_vs_one_after_the_other': (res['t']['seconds'] + res['p']['seconds']) / dtc}
+            if nside == 2048 and lmax == 2048:
+                res['tp_concurrent']['frac_of_fp64_floor'] = (FLOP_PER_ITER_2048['t'] + FLOP_PER_ITER_2048['p']) / peak_tflops / 1e12 / (dtc / iters)
+        except Exception as e:  # the sequential figures stand on their own
+            res['tp_concurrent'] = {'error': repr(e)}
+        if verbose:
+            print('tp_concurrent', json.dumps(res['tp_concurrent']), flush=True)
     if 't' in res and 'p' in res:
         tot = res['t']['seconds'] + res['p']['seconds']
         res['tp'] = {'iters_per_s': iters / tot, 'ms_per_iter': 1e3 * tot / iters}
@@ -199,4 +223,5 @@ if __name__ == '__main__':
     print(json.dumps({'metric': 'CG-iter/sec (cinv_t + cinv_p, nside=%d lmax=%d, masked fsky=%.2f, %d iterations)' % (nside, lmax, r['fsky'], iters),
                       'T_iters_per_s': r.get('t', {}).get('iters_per_s'), 'P_iters_per_s': r.get('p', {}).get('iters_per_s'),
                       'TP_iters_per_s': r.get('tp', {}).get('iters_per_s'), 'TP_frac_of_fp64_floor': r.get('tp', {}).get('frac_of_fp64_floor'),
+                      'TP_concurrent': r.get('tp_concurrent'),
                       'TP_joint_iters_per_s': r.get('tp_joint', {}).get('iters_per_s'), 'batched': r.get('batched')}))
