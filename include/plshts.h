@@ -273,8 +273,7 @@ int pl_qe_lens_product(int64_t n, const double *tmap, const double *gt, const do
 /* FP64 FMA-rate microbenchmarks (16 independent chains per lane, no memory traffic): achieved TFLOP/s.
  * pl_fma64_rate_tflops: mode 0 = one vector + one scalar source besides the accumulator, 1 = two scalar (wave-uniform)
  * sources -- the operand mix of the synthesis kernels --, 2 = three vector sources -- the analysis kernels.
- * Probes of the matrix pipe (no transform uses it): 3 = four v_mfma_f64_16x16x4 chains, 4 = those plus as many cycles of v_fma_f64
- * (combined flop rate: tells whether the matrix pipe runs beside the vector pipe).
+ * (The probes of the FP64 matrix pipe live outside the library: tools/probes/mfma64_probe.hip.)
  * pl_fma64_peak_tflops = mode 1, the highest of the vector modes. */
 double pl_fma64_rate_tflops(int mode, int iters, void *stream);
 double pl_fma64_peak_tflops(int iters, void *stream);

@@ -245,10 +245,7 @@ static int plan_create_impl(int nside, int lmax, int rank, int nranks, pl_plan *
     // Bluestein tables) or, for the short polar rings, aliased rings and anything unusual, by the LDS-resident generic
     // kernel.  PLSHTS_FFT_LEGACY=1 sends every pair to the generic kernel.
     DevFFT &F = p->F;
-    // (PLSHTS_FFT_LEGACY_NSIDE=n: every ring of the grids up to nside n in the generic kernel -- one launch per stage instead of one per
-    // ring-length class, and the template projection of the CG operator folded into it)
-    const bool all_legacy = (getenv("PLSHTS_FFT_LEGACY") && atoi(getenv("PLSHTS_FFT_LEGACY")) != 0) ||
-                            (getenv("PLSHTS_FFT_LEGACY_NSIDE") && nside <= atoi(getenv("PLSHTS_FFT_LEGACY_NSIDE")));
+    const bool all_legacy = getenv("PLSHTS_FFT_LEGACY") && atoi(getenv("PLSHTS_FFT_LEGACY")) != 0;
     std::vector<int> K2of(nside + 1, 0), MofA(nside + 1, 0), clsA(nside + 1, -1), splitA(nside + 1, 0);
     // smallest half-size for which a Bluestein ring is split into two half-size convolutions (PLSHTS_FFT_SPLIT: 0 = never)
     const int split_min = getenv("PLSHTS_FFT_SPLIT") ? atoi(getenv("PLSHTS_FFT_SPLIT")) : 512;
@@ -1102,7 +1099,7 @@ double pl_fma64_rate_tflops(int mode, int iters, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
     double *out = nullptr;
-    if (mode < 0 || mode > 4) return -1.0;
+    if (mode < 0 || mode > 2) return -1.0;
     if (hipMalloc(reinterpret_cast<void **>(&out), 8) != hipSuccess) return -1.0;
     const int nblk = 256 * 8;
     hipEvent_t e0, e1;
@@ -1116,8 +1113,7 @@ double pl_fma64_rate_tflops(int mode, int iters, void *stream)
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(out);
     if (!ok || ms <= 0.f) return -1.0;
-    // per trip and wave: modes 0-2 16 v_fma_f64 (128 flop each); mode 3 four 16x16x4 MFMAs (2048 flop each); mode 4 both (4 x 16 FMAs)
-    const double per_wave = mode <= 2 ? 16.0 * 128.0 : (4.0 * 2048.0 + (mode == 4 ? 64.0 * 128.0 : 0.0));
+    const double per_wave = 16.0 * 128.0;  // per trip and wave: 16 v_fma_f64 of 128 flop each
     const double flops = per_wave * (double)iters * 4.0 * nblk;
     return flops / (ms * 1e-3) / 1e12;
 }

@@ -153,49 +153,6 @@ __global__ __launch_bounds__(256) void k_copy_slim(const double2 *__restrict__ s
     if (blockIdx.x == 0 && (int)threadIdx.x < ntail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }
 
-// Probe (not used by any transform): does the FP64 matrix pipe run beside the FP64 vector pipe?  MODE 3: four independent
-// v_mfma_f64_16x16x4 accumulation chains only; MODE 4: the same plus 64 independent-chain v_fma_f64 per trip (equal pipe time
-// if one MFMA occupies 64 cycles and one FMA 4).  The combined rate tells whether work moved to MFMA would add throughput.
-typedef double v4d_t __attribute__((ext_vector_type(4)));
-template <int MODE>
-__global__ __launch_bounds__(256) void k_mfma_mix(int iters, double xs, double ys, double *out)
-{
-    double a[16];
-    const double xv = 1.0 + 1e-9 * threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = i * 0.125;
-    v4d_t c0 = {0., 0., 0., 0.}, c1 = c0, c2 = c0, c3 = c0;
-    const double ma = 1e-3 * (threadIdx.x & 15), mb = 1.0 + 1e-6 * threadIdx.x;
-    for (int it = 0; it < iters; ++it) {
-        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ma, mb, c0, 0, 0, 0);
-        if constexpr (MODE == 4) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) a[i] = fma(a[i], xv, ys);
-        }
-        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ma, mb, c1, 0, 0, 0);
-        if constexpr (MODE == 4) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) a[i] = fma(a[i], xv, ys);
-        }
-        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ma, mb, c2, 0, 0, 0);
-        if constexpr (MODE == 4) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) a[i] = fma(a[i], xv, ys);
-        }
-        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(ma, mb, c3, 0, 0, 0);
-        if constexpr (MODE == 4) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) a[i] = fma(a[i], xv, ys);
-        }
-    }
-    double s = xs * 0.;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s += a[i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
-    if (s == 12345.678) out[0] = s;
-}
-
 // ---- CG vector primitives (cd_solve.py:53-107): one launch each, scalars stay on the device -----------------------
 // dot = sum_{l >= lmin} sum_m w_m Re(a_lm conj(b_lm)), w_0 = 1, w_{m>0} = 2  (= sum_l (2l + 1) C_l^{ab}; opfilt_tt.py:43-51).
 // One workgroup walks the m-major array with a fixed thread stride and reduces in a fixed tree: deterministic.
@@ -1008,9 +965,7 @@ void launch_qe_lens_product(int64_t n, const double *tmap, const double *gt, con
 void launch_fma_peak(int mode, int iters, double *out, int nblk, hipStream_t st)
 {
     const double xs = 1.0 + 1e-9, ys = 1e-12;
-    if (mode == 3) hipLaunchKernelGGL(k_mfma_mix<3>, dim3(nblk), dim3(256), 0, st, iters, xs, ys, out);
-    else if (mode == 4) hipLaunchKernelGGL(k_mfma_mix<4>, dim3(nblk), dim3(256), 0, st, iters, xs, ys, out);
-    else if (mode == 1) hipLaunchKernelGGL(k_fma_peak<1>, dim3(nblk), dim3(256), 0, st, iters, xs, ys, out);
+    if (mode == 1) hipLaunchKernelGGL(k_fma_peak<1>, dim3(nblk), dim3(256), 0, st, iters, xs, ys, out);
     else if (mode == 2) hipLaunchKernelGGL(k_fma_peak<2>, dim3(nblk), dim3(256), 0, st, iters, xs, ys, out);
     else hipLaunchKernelGGL(k_fma_peak<0>, dim3(nblk), dim3(256), 0, st, iters, xs, ys, out);
 }

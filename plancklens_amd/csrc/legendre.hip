@@ -23,12 +23,6 @@
 #include "device_plan.h"
 #include "legendre_math.h"
 
-#ifndef PL_ANALS_ATTR
-#define PL_ANALS_ATTR
-#endif
-#ifndef PL_EXP_ANALS
-#define PL_EXP_ANALS 0  // timing experiments on k_leg_anals (wrong results): 1 no cross-lane reduce, 2 every tile on the all-active path, 4 wave-uniform data operand
-#endif
 
 namespace plshts {
 
@@ -400,11 +394,7 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
         const int nl = P.lmax - l0 + 1;
         const int64_t base = S.off[m];
         const double2 *__restrict__ ab = reinterpret_cast<const double2 *>(S.ab) + base;
-#if defined(PL_EXP_SAMEALM)  // timing experiment only (wrong results): every wave reads the alm stream of m = 0
-        const double4 *__restrict__ aa = prep;
-#else
         const double4 *__restrict__ aa = prep + base;
-#endif
         const d2v_t *__restrict__ abv = reinterpret_cast<const d2v_t *>(ab);
         const d4v_t *__restrict__ aav = reinterpret_cast<const d4v_t *>(aa);
         const double4 *__restrict__ aa2 = IN2 ? prep2 + base : nullptr;  // pair: gradient-only prep {sg Ap2, Ap2}, only Ap2 is read; batch: {An2, Ap2}
@@ -991,7 +981,7 @@ __global__ void k_post0(DevPlan P, int RG, const double4 *__restrict__ partial_,
 // analysis, spin s: partial[g][entry] = {G'_re, G'_im, C'_re, C'_im}
 // -----------------------------------------------------------------------------------------------------
 template <int R>
-__global__ __launch_bounds__(256) PL_ANALS_ATTR void k_leg_anals(DevPlan P, DevSpinTab S, int spin, const double *__restrict__ phase,
+__global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int spin, const double *__restrict__ phase,
                                                    double *__restrict__ partial_, int64_t nent)
 {
     constexpr int RG = 64 * R;
@@ -1071,21 +1061,11 @@ __global__ __launch_bounds__(256) PL_ANALS_ATTR void k_leg_anals(DevPlan P, DevS
     auto accum = [&](int t, int k, double vn, double vp, double &a0, double &a1, double &a2, double &a3) {
         const double *pa0 = (t & 1) == 0 ? aer : aor, *pa1 = (t & 1) == 0 ? aei : aoi, *pa2 = (t & 1) == 0 ? aor : aer, *pa3 = (t & 1) == 0 ? aoi : aei;
         const double *pb0 = (t & 1) == 0 ? ber : bor, *pb1 = (t & 1) == 0 ? bei : boi, *pb2 = (t & 1) == 0 ? bor : ber, *pb3 = (t & 1) == 0 ? boi : bei;
-        if constexpr ((PL_EXP_ANALS & 4) != 0) {  // experiment: the data operand is wave-uniform (an SGPR pair), as in the synthesis kernels
-            const double u = QA[k & 7];
-            if (k == 0) { a0 = vn * u; a1 = vn * u; a2 = vn * u; a3 = vn * u; }
-            else { a0 = fma(vn, u, a0); a1 = fma(vn, u, a1); a2 = fma(vn, u, a2); a3 = fma(vn, u, a3); }
-            a0 = fma(vp, u, a0); a1 = fma(vp, u, a1); a2 = fma(-vp, u, a2); a3 = fma(-vp, u, a3);
-            return;
-        }
         if (k == 0) { a0 = vn * pa0[0]; a1 = vn * pa1[0]; a2 = vn * pa2[0]; a3 = vn * pa3[0]; }
         else { a0 = fma(vn, pa0[k], a0); a1 = fma(vn, pa1[k], a1); a2 = fma(vn, pa2[k], a2); a3 = fma(vn, pa3[k], a3); }
         a0 = fma(vp, pb0[k], a0); a1 = fma(vp, pb1[k], a1); a2 = fma(-vp, pb2[k], a2); a3 = fma(-vp, pb3[k], a3);
     };
-    auto fold = [&](double a0, double a1, double a2, double a3) -> double {
-        if constexpr ((PL_EXP_ANALS & 1) != 0) return (a0 + a1) + (a2 + a3);
-        else return fold4(a0, a1, a2, a3);
-    };
+    auto fold = [&](double a0, double a1, double a2, double a3) -> double { return fold4(a0, a1, a2, a3); };
     // one quarter tile: 4 consecutive l with the coefficient set c = 4 (a, b) pairs
     auto quarter = [&](auto qc, const d8v_t &c, int ib) {
         constexpr int h = decltype(qc)::value;
@@ -1213,17 +1193,10 @@ __global__ __launch_bounds__(256) PL_ANALS_ATTR void k_leg_anals(DevPlan P, DevS
 #pragma unroll
             for (int k = 0; k < R; ++k)
                 done = done && (r[k].scn == 0 || r[k].scn == kNeverActive) && (r[k].scp == 0 || r[k].scp == kNeverActive);
-            all_active = wave_all(done) || (PL_EXP_ANALS & 2) != 0;
+            all_active = wave_all(done);
         }
-        if constexpr ((PL_EXP_ANALS & 1) != 0) {
-            double tsum = 0.;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) tsum += acc[t];
-            if (tsum == 1.2345e300) out[lane] = tsum;
-        } else {
-            const double tot = reduce16_lds(acc, lane, scratch);
-            if (i0 + (lane & 15) < nl) out[(int64_t)(i0 + (lane & 15)) * 4 + fold4_component(lane)] = tot;
-        }
+        const double tot = reduce16_lds(acc, lane, scratch);
+        if (i0 + (lane & 15) < nl) out[(int64_t)(i0 + (lane & 15)) * 4 + fold4_component(lane)] = tot;
     }
 }
 
@@ -1363,11 +1336,8 @@ static void launch_synths_r(const DevPlan &P, const DevSpinTab &S, int spin, con
 {
     constexpr int RG = 64 * R;
     const int ngroups = (P.npairs + RG - 1) / RG, nmg = own_mgroups(P);
-    // PLSHTS_SYNTH_LDS_PAD (bytes, experiments): dynamic LDS nobody touches, to cap the workgroups per CU and leave room for the
-    // ring-FFT kernels of another transform running on a second stream
-    static const int pad = env_int("PLSHTS_SYNTH_LDS_PAD", 0);
     if (nmg == 0) return;
-    hipLaunchKernelGGL((k_leg_synths<R, GONLY, 0>), dim3(ngroups * nmg, nb), dim3(256), pad, st, P, S, spin,
+    hipLaunchKernelGGL((k_leg_synths<R, GONLY, 0>), dim3(ngroups * nmg, nb), dim3(256), 0, st, P, S, spin,
                        reinterpret_cast<const double4 *>(prep), phase);
 }
 

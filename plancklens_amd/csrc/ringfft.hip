@@ -296,7 +296,7 @@ __device__ __forceinline__ RingCtx ring_ctx(const DevPlan &P, const DevFFT &F, i
 // multigrid, where one short transform leaves most of the workgroup idle and the chain of barriers is the cost.
 template <int NT, int QMAX, bool B4>
 __device__ __forceinline__ void ring_synth(const RingCtx &c, const DevFFT &F, const double *__restrict__ ph, double2 *ws, double2 (&acc)[4][QMAX],
-                                           const double2 (&e1)[QMAX], int dbg)
+                                           const double2 (&e1)[QMAX])
 {
     constexpr int estride = 4;
     const int n = c.n, q = c.q, M = c.M, ml = c.ml;
@@ -309,10 +309,9 @@ __device__ __forceinline__ void ring_synth(const RingCtx &c, const DevFFT &F, co
     auto fold = [&](int k1, int k2) -> double2 {
         const int k = 4 * k1 + k2;
         double zr = 0., zi = 0.;
-        if (dbg & 4) return make_double2(1., 0.);
         for (int m = k; m <= ml; m += n) {  // positive frequencies aliased onto bin k
             const double4 f = *reinterpret_cast<const double4 *>(ph + (int64_t)m * estride);
-            double2 p = (shifted && !(dbg & 1)) ? cispi(m * inv_n) : make_double2(1., 0.);
+            double2 p = shifted ? cispi(m * inv_n) : make_double2(1., 0.);
             const double2 fn = cmul(make_double2(f.x, f.y), p), fs = cmul(make_double2(f.z, f.w), p);
             zr += fn.x - fs.y; zi += fn.y + fs.x;  // f_N + i f_S
         }
@@ -354,8 +353,7 @@ __device__ __forceinline__ void ring_synth(const RingCtx &c, const DevFFT &F, co
             if (M) ws[idx] = cmul(z, chirp[k1]);
             else ws[k2 * S + digit_reverse(k1, q)] = z;
         }
-        if (!(dbg & 2)) sub_dft_inverse<NT>(ws, q, M, c.filt, F, c.twl, 4, S);
-        else __syncthreads();
+        sub_dft_inverse<NT>(ws, q, M, c.filt, F, c.twl, 4, S);
 #pragma unroll
         for (int k2 = 0; k2 < 4; ++k2) scatter(k2, ws + k2 * S);
     } else {
@@ -366,8 +364,7 @@ __device__ __forceinline__ void ring_synth(const RingCtx &c, const DevFFT &F, co
                 if (M) ws[k1] = cmul(z, chirp[k1]);
                 else ws[digit_reverse(k1, q)] = z;
             }
-            if (!(dbg & 2)) sub_dft_inverse<NT>(ws, q, M, c.filt, F, c.twl);
-            else __syncthreads();
+            sub_dft_inverse<NT>(ws, q, M, c.filt, F, c.twl);
             scatter(k2, ws);
             __syncthreads();
         }
@@ -484,7 +481,7 @@ __device__ __forceinline__ void ring_anal(const RingCtx &c, const DevFFT &F, dou
 // synthesis: phase -> pixels
 template <int NT, int QMAX, bool B4>
 __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim, int ncomp,
-                                                  const double *__restrict__ phase, double *__restrict__ map, int dbg, NinvProj W)
+                                                  const double *__restrict__ phase, double *__restrict__ map, NinvProj W)
 {
     extern __shared__ double2 ws[];
     const int ip = pairs[blockIdx.x];  // largest rings first
@@ -496,7 +493,7 @@ __global__ __launch_bounds__(NT) void k_phase2map(DevPlan P, DevFFT F, const int
     double2 acc[4][QMAX], e1[QMAX];
 #pragma unroll
     for (int qq = 0; qq < QMAX; ++qq) e1[qq] = cispi(2.0 * (threadIdx.x + NT * qq) * c.inv_n);  // e^{2 pi i j1 / n}
-    ring_synth<NT, QMAX, B4>(c, F, ph, ws, acc, e1, dbg);
+    ring_synth<NT, QMAX, B4>(c, F, ph, ws, acc, e1);
     double *__restrict__ mp = map + (int64_t)comp * P.npix;
     const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
     double cw[kFuseModes] = {0., 0., 0., 0.};  // NinvProj: this thread's share of the template coefficients
@@ -621,7 +618,7 @@ __global__ __launch_bounds__(NT) void k_ring_roundtrip(DevPlan P, DevFFT F, cons
     double2 px[4][QMAX], e1[QMAX];
 #pragma unroll
     for (int qq = 0; qq < QMAX; ++qq) e1[qq] = cispi(2.0 * (threadIdx.x + NT * qq) * c.inv_n);
-    ring_synth<NT, QMAX, B4>(c, F, ph, ws, px, e1, 0);
+    ring_synth<NT, QMAX, B4>(c, F, ph, ws, px, e1);
 #pragma unroll
     for (int j2 = 0; j2 < 4; ++j2) {
 #pragma unroll
@@ -651,9 +648,6 @@ __global__ __launch_bounds__(NT) void k_ring_roundtrip(DevPlan P, DevFFT F, cons
 // unit-stride loads (ds_read_b128: 16-lane groups, 64 banks) are conflict-free.
 // Bluestein here uses the band limit of the ring: only the bins |m| <= mlim are non-zero, i.e. sub-DFT inputs
 // c in [-K, K] (K = F.K2of[q]), so a convolution of size N >= q + 2 K + 1 is enough (instead of 2 q - 1).
-#ifndef PL_FFT_ABL
-#define PL_FFT_ABL 0   // timing ablations of the register-resident kernels (development only, results wrong): 1 no FFT, 2 no gather, 4 no stores
-#endif
 __device__ __forceinline__ int swz(int i) { return i ^ ((i >> 3) & 7); }
 // Launders a table index: the kernels below are fully unrolled and hipcc would otherwise load every table entry once
 // at the top -- or hoist the loads of a later phase above the barriers of the current one -- and park the values in
@@ -696,7 +690,6 @@ template <int N, bool FWD>
 __device__ __forceinline__ void fft8(double2 (&x)[8], double2 *lds, int tl_in, const Tw8<N> &tw_in)
 {
     constexpr int G = N / 8, P8 = Tw8<N>::P8, T = Tw8<N>::T;
-    if (PL_FFT_ABL & 1) return;
     // A kernel calls this 4 to 8 times with the same twiddles and thread index.  Left alone, hipcc computes the twiddle
     // powers and LDS addresses of all passes once and keeps them live across every call (CSE): +130 VGPRs.  Laundering the
     // inputs makes each call recompute them (a few dozen multiplies) and keeps the kernel at 2-3 waves per SIMD.
@@ -819,7 +812,7 @@ __global__ __launch_bounds__(N / 8, 2) void k_phase2map_fast(DevPlan P, DevFFT F
                 const int mm = b.sgn > 0 ? k : n - k;
                 const bool have = b.sgn != 0 && mm <= ml;
                 const int m = have ? mm : 0;
-                const double4 f = (PL_FFT_ABL & 2) ? make_double4(1., 2., 3., m) : *reinterpret_cast<const double4 *>(ph + (int64_t)m * estride);
+                const double4 f = *reinterpret_cast<const double4 *>(ph + (int64_t)m * estride);
                 double2 fn = make_double2(f.x, f.y), fs = make_double2(f.z, f.w);
                 if (shifted) {
                     const double2 pk = cmul(pj, k2 == 0 ? make_double2(1., 0.) : k2 == 1 ? s1 : k2 == 2 ? s2 : s3);
@@ -896,7 +889,6 @@ __global__ __launch_bounds__(N / 8, 2) void k_phase2map_fast(DevPlan P, DevFFT F
             dft_small<4, false>(y);  // y[j2] = sum_k2 i^(j2 k2) y_k2
 #pragma unroll
             for (int j2 = 0; j2 < 4; ++j2) {
-                if ((PL_FFT_ABL & 4) && y[j2].x != 1.2345) continue;
                 if constexpr (WGT) {
                     mp[on + j1 + q * j2] = y[j2].x * wgt[on + j1 + q * j2];
                     if (os >= 0) mp[os + j1 + q * j2] = y[j2].y * wgt[os + j1 + q * j2];
@@ -974,7 +966,7 @@ __global__ __launch_bounds__(N / 8, 2) void k_map2phase_fast(DevPlan P, DevFFT F
                 double4 o;
                 o.x = fn.x * wgt; o.y = fn.y * wgt;
                 o.z = has_s ? fs.x * wgt : 0.0; o.w = has_s ? fs.y * wgt : 0.0;
-                if (!(PL_FFT_ABL & 4) || o.x == 1.2345) *reinterpret_cast<double4 *>(ph + (int64_t)m * estride) = o;
+                *reinterpret_cast<double4 *>(ph + (int64_t)m * estride) = o;
             }
             pjj = cmul(pjj, pstep);
             if ((j & 1) == 1) phase_fence();  // at most two j (8 loads) in flight
@@ -997,7 +989,7 @@ __global__ __launch_bounds__(N / 8, 2) void k_map2phase_fast(DevPlan P, DevFFT F
             const double *mps = has_s ? mp + os : mp + on;
 #pragma unroll
             for (int j2 = 0; j2 < 4; ++j2) {
-                const double vn = (PL_FFT_ABL & 2) ? 1.0 + j1c : mp[on + j1c + q * j2], vs = (PL_FFT_ABL & 2) ? 2.0 : mps[j1c + q * j2];
+                const double vn = mp[on + j1c + q * j2], vs = mps[j1c + q * j2];
                 y[j2].x = j1 < q ? vn : 0.0;
                 y[j2].y = (j1 < q && has_s) ? -vs : 0.0;
             }
@@ -1111,7 +1103,6 @@ static hipError_t launch_p2m(const DevPlan &P, const DevFFT &F, const int *mlim,
                              hipStream_t st, const NinvProj &W)
 {
     if (F.A.legacy_n == 0) return hipSuccess;
-    static int dbg = getenv("PLSHTS_FFTDBG") ? atoi(getenv("PLSHTS_FFTDBG")) : 0;
     static const bool no_b4 = getenv("PLSHTS_FFT_NOB4") && atoi(getenv("PLSHTS_FFT_NOB4")) != 0;
     const size_t lds4 = (size_t)(4 * F.Lmax + F.twl_cap) * sizeof(double2);
     if (!no_b4 && lds4 <= kB4MaxLds) {  // short transforms (coarse grids, short cap rings): the four sub-DFTs side by side
@@ -1124,7 +1115,7 @@ static hipError_t launch_p2m(const DevPlan &P, const DevFFT &F, const int *mlim,
             attr4_done[dv4] = true;
         }
         hipLaunchKernelGGL((k_phase2map<NT, QMAX, true>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds4, st, P, F, F.A.legacy_pairs, mlim, ncomp,
-                           phase, map, dbg, W);
+                           phase, map, W);
         return hipGetLastError();
     }
     const size_t lds = fft_lds_bytes(F);
@@ -1137,7 +1128,7 @@ static hipError_t launch_p2m(const DevPlan &P, const DevFFT &F, const int *mlim,
         attr_done[dv] = true;
     }
     hipLaunchKernelGGL((k_phase2map<NT, QMAX, false>), dim3(F.A.legacy_n, ncomp), dim3(NT), lds, st, P, F, F.A.legacy_pairs, mlim, ncomp, phase,
-                       map, dbg, W);
+                       map, W);
     return hipGetLastError();
 }
 
@@ -1314,10 +1305,8 @@ static hipError_t launch_split_class(const DevPlan &P, const DevFFT &F, int cls,
 static hipError_t launch_stage(const DevPlan &P, const DevFFT &F, const FftStreams &fs, bool synth, const int *mlim, int ncomp,
                                const double *in, double *out, hipStream_t st, const NinvProj &W)
 {
-    // PLSHTS_FFT_SERIAL=1: every class on the caller's stream; PLSHTS_FFT_SERIAL_NSIDE=n: on grids up to nside n (fork / join of the
-    // side streams costs tens of microseconds per stage, which the small grids of the CG chains may not earn back)
-    static const int serial_nside = getenv("PLSHTS_FFT_SERIAL_NSIDE") ? atoi(getenv("PLSHTS_FFT_SERIAL_NSIDE")) : 0;
-    const bool par = fs.ok && !(getenv("PLSHTS_FFT_SERIAL") && atoi(getenv("PLSHTS_FFT_SERIAL")) != 0) && P.nside > serial_nside;
+    // PLSHTS_FFT_SERIAL=1: every class on the caller's stream (profiling with PMC counters: one kernel at a time)
+    const bool par = fs.ok && !(getenv("PLSHTS_FFT_SERIAL") && atoi(getenv("PLSHTS_FFT_SERIAL")) != 0);
     // Work items: w = 3 c + kind of class c (kind 0: direct, 1: Bluestein, 2: split Bluestein) and the generic list (w = nw).  Cost
     // model: ring pairs x transform size x transforms per sub-DFT, plus a fixed latency (the short-ring kernels are latency-bound).
     // The costliest item stays on the caller's stream; the others go, costliest first, to the side stream with the least work

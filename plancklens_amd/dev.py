@@ -422,7 +422,7 @@ def template_project_md(tmap, n_inv, nside, lmax, pinv):
     """tmap <- n_inv tmap with monopole and dipole projected out, the templates evaluated from the ring geometry (pl_template_project_md_b);
     tmap [npix] or a block [nb, npix]; pinv: (P^t N^-1 P)^-1 as a (4, 4) device tensor.  Any plan of this nside serves (geometry only)."""
     from . import shts
-    plan = shts.get_plan(nside, lmax)
+    plan = shts.geometry_plan(nside, lmax)
     nb, n = bshape(tmap)
     assert n == plan.npix and n_inv.numel() == n and tmap.is_contiguous() and n_inv.is_contiguous() and pinv.numel() == 16 and pinv.is_contiguous()
     L = _lib.lib()

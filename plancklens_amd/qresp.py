@@ -209,6 +209,60 @@ def get_dresponse_dlncl(qe_key, l, cl_key, lmax_ivf, source, cls_weight, cls_cmb
     return _get_response(get_qes(qe_key, lmax_ivf, cls_weight, lmax2=lmax_ivf2), source, dcls, fal_leg1, lmax_out, fal_leg2=fal_leg2)
 
 
+
+def get_mf_resp(qe_key, cls_cmb, cls_ivfs, lmax_qe, lmax_out, retterms=False):
+    """Deflection-induced mean-field response (plancklens/qresp.py:421-500; 'ptt' and 'p_p').
+
+    With xi the CMB spectra, K the filter spectra and (xi K xi, xi K) their products, the gradient / curl responses are sums over the
+    spin pairs (s1, s2) of the fields and the two spin-raising / lowering routes a = -+1 of Wigner products
+    h = 2 (-1)^(s1 + s2) W(cl1, cl2), collected as  G += -a h, C += -h  for the "K (xi - xi K xi)" part and subtracted for the
+    "(xi K)(xi K)" part; the curl response at L = 1 (pure rotation: no mean field) fixes the constant, and L (L + 1) / 4 converts
+    to the potential normalisation.  retterms: also the three pieces of the gradient response, as the reference returns them."""
+    assert qe_key in ['p_p', 'ptt'], qe_key
+    fields = {'ptt': ['tt'], 'p_p': ['ee', 'bb']}[qe_key]
+    spins = {'ptt': [0], 'p_p': [-2, 2]}[qe_key]
+    lmax_cmb = min(len(cls_cmb[k]) - 1 for k in fields)
+    assert lmax_qe <= lmax_cmb
+    xKx = {k: cls_cmb[k][:lmax_qe + 1] ** 2 * cls_ivfs[k][:lmax_qe + 1] for k in fields}
+    xK = {k: cls_cmb[k][:lmax_qe + 1] * cls_ivfs[k][:lmax_qe + 1] for k in fields}
+    half = lambda s: 0.5 if s != 0 else 1.   # the 1/2 of each map from spin fields to (T, E, B)
+    ladder = lambda a, s, lmax: uspin.get_spin_lower(s, lmax) if a == -1 else uspin.get_spin_raise(s, lmax)
+    L = np.arange(lmax_out + 1, dtype=float)
+    G1, C1, G2, C2 = (np.zeros(lmax_out + 1) for _ in range(4))
+    for s1 in spins:
+        for s2 in spins:
+            sgn = 2. * (-1) ** (s1 + s2)
+            # K (xi - xi K xi): the difference is formed before the Wigner product (the two terms alone are unstable)
+            k_cl = uspin.spin_cls(s1, s2, cls_ivfs)[:lmax_qe + 1] * (half(s1) * half(s2))
+            x_cl = np.copy(uspin.spin_cls(s2, s1, cls_cmb)[:lmax_cmb + 1])
+            x_cl[:lmax_qe + 1] -= uspin.spin_cls(s2, s1, xKx)[:lmax_qe + 1]
+            if np.any(k_cl) and np.any(x_cl):
+                lower_m_s1 = uspin.get_spin_lower(-s1, lmax_cmb)
+                for a in (-1, 1):
+                    h = sgn * uspin.wignerc(k_cl, x_cl * ladder(a, s2, lmax_cmb) * lower_m_s1, s2, s1, -s2 - a, -s1 - 1, lmax_out=lmax_out)
+                    G1 -= a * h
+                    C1 -= h
+            # (xi K) (xi K)
+            c1 = uspin.spin_cls(s2, s1, xK)[:lmax_qe + 1] * half(s1)
+            c2 = uspin.spin_cls(s1, s2, xK)[:lmax_qe + 1] * half(s2)
+            if np.any(c1) and np.any(c2):
+                lower_s1 = uspin.get_spin_lower(s1, lmax_qe)
+                for a in (-1, 1):
+                    h = sgn * uspin.wignerc(c1 * ladder(a, s2, lmax_qe), c2 * lower_s1, -s2 - a, -s1, s2, s1 - 1, lmax_out=lmax_out)
+                    G2 -= a * h
+                    C2 -= h
+    GL, CL = G1 - G2, C1 - C2
+    c0 = CL[1]
+    print("CL[1] ", c0)
+    print("GL[1] (before subtraction) ", GL[1])
+    print("GL[1] (after subtraction) ", GL[1] - c0)
+    norm = 0.25 * L * (L + 1.)
+    ret = ((GL - c0) * norm, (CL - c0) * norm)
+    if not retterms:
+        return ret
+    return ret + ({'GK': G1 * norm, 'GxiK': -G2 * norm, 'Gcons': -np.ones(lmax_out + 1) * c0 * norm},)
+
+
 class resp_lib_simple(object):
     """Caches get_response outputs in an sqlite npdb under lib_dir (qresp.py:183-267)."""
 

@@ -147,6 +147,19 @@ def get_plan(nside, lmax):
         return _PLANS[key] if c == 0 else _PLANS[key].fork(('ctx', c))
 
 
+def geometry_plan(nside, lmax):
+    """A plan of this nside for a caller that only needs the ring geometry (pl_template_project_md_b): an existing plan of any
+    band-limit serves -- the one with the largest lmax already built in this context is returned, so that a geometry-only need never
+    builds (or, inside a captured region, allocates) a second set of recursion tables and workspaces; (nside, lmax) is created only
+    when the grid has no plan yet."""
+    dev_id = _plan_key(nside, lmax)[2]
+    with _PLANS_LOCK:
+        have = [k for k in _PLANS if len(k) == 3 and k[0] == int(nside) and k[2] == dev_id]
+    if have:
+        return get_plan(nside, max(k[1] for k in have))
+    return get_plan(nside, lmax)
+
+
 def get_shard_plan(nside, lmax, rank, nranks):
     key = _plan_key(nside, lmax) + ('shard', int(rank), int(nranks))
     if key not in _PLANS:

@@ -651,6 +651,35 @@ def make_cinv_golden():
     print('wrote cinv_golden.npz with %d arrays' % len(out))
 
 
+def make_mfresp_golden():
+    """Reference qresp.get_mf_resp (qresp.py:421-500; its Python on its own Fortran Wigner module) for 'ptt' and 'p_p' on the tiny
+    configuration of the response fixtures, with the three pieces of the gradient response (retterms)."""
+    install_fortran_wigners()
+    from plancklens import qresp, utils
+    lmax_qe, lmax_out, lmin = 40, 47, 4
+    cls_path = os.path.join(ROOT, 'plancklens_amd', 'data', 'cls', 'FFP10_wdipole_lensedCls.dat')
+    cl_len = utils.camb_clfile(cls_path, lmax=lmax_qe + 20)   # the CMB spectra reach beyond the filtered range, as in an analysis
+    transf = myhp.gauss_beam(4. / 180. * np.pi, lmax=lmax_qe)
+    arcmin = np.pi / 180. / 60.
+    ivf = {'tt': utils.cli(cl_len['tt'][:lmax_qe + 1] + (1200. * arcmin) ** 2 * utils.cli(transf ** 2)),
+           'ee': utils.cli(cl_len['ee'][:lmax_qe + 1] + (35. * arcmin) ** 2 * utils.cli(transf ** 2)),
+           'bb': utils.cli(cl_len['bb'][:lmax_qe + 1] + (35. * arcmin) ** 2 * utils.cli(transf ** 2))}
+    for f in ivf.values():
+        f[:lmin] = 0
+    out = {'lmax_qe': lmax_qe, 'lmax_out': lmax_out}
+    for k in ['tt', 'ee', 'bb', 'te']:
+        out['cl_' + k] = cl_len[k]
+    for k in ivf:
+        out['ivf_' + k] = ivf[k]
+    for key in ['ptt', 'p_p']:
+        GL, CL, terms = qresp.get_mf_resp(key, cl_len, ivf, lmax_qe, lmax_out, retterms=True)
+        out['G_' + key], out['C_' + key] = GL, CL
+        for t in terms:
+            out['%s_%s' % (t, key)] = terms[t]
+    np.savez_compressed(os.path.join(HERE, 'mfresp_golden.npz'), **out)
+    print('wrote mfresp_golden.npz with %d arrays' % len(out))
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'resp':   # only the response / N0 fixtures
         assert os.path.isdir(REF), 'the reference is only present in the build container'
@@ -662,11 +691,11 @@ if __name__ == '__main__':
         install_healpy_standin()
         sys.path.insert(0, REF)
         make_lib_golden()
-    elif len(sys.argv) > 1 and sys.argv[1] in ('sims', 'cg2', 'cinv'):   # simulation inputs / small wrapper classes; further noise models of the CG
+    elif len(sys.argv) > 1 and sys.argv[1] in ('sims', 'cg2', 'cinv', 'mfresp'):   # simulation inputs / small wrapper classes; further noise models of the CG
         assert os.path.isdir(REF), 'the reference is only present in the build container'
         install_healpy_standin()
         sys.path.insert(0, REF)
-        {'sims': make_sims_golden, 'cg2': make_cg2_golden, 'cinv': make_cinv_golden}[sys.argv[1]]()
+        {'sims': make_sims_golden, 'cg2': make_cg2_golden, 'cinv': make_cinv_golden, 'mfresp': make_mfresp_golden}[sys.argv[1]]()
     elif len(sys.argv) > 1 and sys.argv[1] == 'cg':   # only the CG fixtures
         assert os.path.isdir(REF), 'the reference is only present in the build container'
         install_healpy_standin()

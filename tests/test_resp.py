@@ -94,3 +94,24 @@ def test_n0_equals_response_for_optimal_filtering():
         RG, RC, RGC, RCG = qresp.get_response(src, lmax_ivf, src, cls_weight, cls_len, fal_jt, lmax_qlm=lmax_qlm)
         assert np.allclose(NG[1:], RG[1:], rtol=1e-6) and np.allclose(NC[2:], RC[2:], rtol=1e-6), src
         assert np.all(NCG == 0.) and np.all(NGC == 0.) and np.all(RCG == 0.) and np.all(RGC == 0.)
+
+
+def test_mean_field_response_vs_reference():
+    """qresp.get_mf_resp (qresp.py:421-500) against the reference's own Python on its Fortran Wigner module
+    (tests/golden/mfresp_golden.npz, made by tests/golden/make_golden.py mfresp): 'ptt' and 'p_p', gradient and curl parts and the
+    three pieces of the gradient response.  The responses are differences of large terms (C_L=1 ~ 8e4 against G - C ~ 2e2): the
+    tolerance is relative to the largest piece."""
+    from plancklens_amd import qresp
+    g = np.load(os.path.join(HERE, 'golden', 'mfresp_golden.npz'))
+    cls = {k: g['cl_' + k] for k in ['tt', 'te', 'ee', 'bb']}
+    ivf = {k: g['ivf_' + k] for k in ['tt', 'ee', 'bb']}
+    lmax_qe, lmax_out = int(g['lmax_qe']), int(g['lmax_out'])
+    for key in ['ptt', 'p_p']:
+        GL, CL, terms = qresp.get_mf_resp(key, cls, ivf, lmax_qe, lmax_out, retterms=True)
+        scale = np.abs(g['GK_' + key]).max()
+        assert np.abs(GL - g['G_' + key]).max() < 1e-11 * scale and np.abs(CL - g['C_' + key]).max() < 1e-11 * scale, key
+        assert set(terms) == {'GK', 'GxiK', 'Gcons'}
+        for t in terms:
+            assert np.abs(terms[t] - g['%s_%s' % (t, key)]).max() < 1e-11 * scale, (key, t)
+        G2, C2 = qresp.get_mf_resp(key, cls, ivf, lmax_qe, lmax_out)
+        assert np.array_equal(G2, GL) and np.array_equal(C2, CL) and CL[1] == 0.

@@ -130,3 +130,51 @@ def test_library_fml_vs_reference(g):
     for name in ['ftl', 'fel', 'fbl']:
         assert np.allclose(getattr(fml, 'get_' + name)(), g['fml_' + name], rtol=1e-14, atol=0)
     assert set(fml.hashdict().keys()) == {'ivfs', 'filt_t', 'filt_e', 'filt_b'}
+
+
+class _fake_lib(object):
+    def __init__(self, tag, npix=48):
+        self.tag, self.npix = tag, npix
+
+    def hashdict(self):
+        return {'fake': self.tag}
+
+    def get_sim_tmap(self, idx):
+        return np.random.default_rng(100 * self.tag + idx + 7).standard_normal(self.npix)
+
+    def get_sim_pmap(self, idx):
+        r = np.random.default_rng(1000 * self.tag + idx + 7)
+        return r.standard_normal(self.npix), r.standard_normal(self.npix)
+
+
+def test_sim_lib_add_sim_and_add_dat():
+    """sims.utils.sim_lib_add_sim / sim_lib_add_dat (sims/utils.py:20-95): weighted sums of libraries for simulation (idx >= 0) resp.
+    data (idx < 0) indices only, the first library alone otherwise; hash dictionaries with the reference's keys; nested as the
+    reference's smicadx12 parameter file nests them -- and, where the reference is present, equal to its classes."""
+    from plancklens_amd.sims import utils as su
+    libs, w = [_fake_lib(1), _fake_lib(2), _fake_lib(3)], np.array([1., -0.5, 2.])
+    a, d = su.sim_lib_add_sim(libs, weights=w), su.sim_lib_add_dat(libs, weights=w)
+    for idx in (-1, 0, 3):
+        full_t = sum(l.get_sim_tmap(idx) * x for l, x in zip(libs, w))
+        full_q = sum(l.get_sim_pmap(idx)[0] * x for l, x in zip(libs, w))
+        first_t, first_u = libs[0].get_sim_tmap(idx) * w[0], libs[0].get_sim_pmap(idx)[1] * w[0]
+        assert np.allclose(a.get_sim_tmap(idx), full_t if idx >= 0 else first_t, rtol=1e-15, atol=1e-15)
+        assert np.allclose(d.get_sim_tmap(idx), full_t if idx < 0 else first_t, rtol=1e-15, atol=1e-15)
+        assert np.allclose(a.get_sim_pmap(idx)[0], full_q if idx >= 0 else libs[0].get_sim_pmap(idx)[0] * w[0], rtol=1e-15, atol=1e-15)
+        assert np.allclose(d.get_sim_pmap(idx)[1], first_u if idx >= 0 else sum(l.get_sim_pmap(idx)[1] * x for l, x in zip(libs, w)), rtol=1e-15, atol=1e-15)
+    assert a.hashdict() == {'lib': 'add_sim', 'sim_lib 0': {'fake': 1}, 'w 0': 1., 'sim_lib 1': {'fake': 2}, 'w 1': -0.5, 'sim_lib 2': {'fake': 3}, 'w 2': 2.}
+    assert su.sim_lib_add_dat(libs[:2]).hashdict() == {'lib': 'add_dat', 'sim_lib 0': {'fake': 1}, 'w 0': 1., 'sim_lib 1': {'fake': 2}, 'w 1': 1.}
+    nested = su.sim_lib_add_dat([su.sim_lib_add_sim(libs[:2]), su.sim_lib_shuffle(libs[2], {-1: 5})])
+    assert np.allclose(nested.get_sim_tmap(-1), libs[0].get_sim_tmap(-1) + libs[2].get_sim_tmap(5))
+    assert np.allclose(nested.get_sim_tmap(2), libs[0].get_sim_tmap(2) + libs[1].get_sim_tmap(2))
+    assert su.sim_lib_shuffle(libs[2], {-1: 5}).hashdict() == {'sim_lib': {'fake': 3}, 'shuffle': {-1: 5}}
+    if os.path.exists('/root/reference/plancklens/sims/utils.py'):  # the reference's own classes on the same libraries
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('ref_sims_utils', '/root/reference/plancklens/sims/utils.py')
+        ru = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ru)
+        for ours, theirs in ((a, ru.sim_lib_add_sim(libs, weights=w)), (d, ru.sim_lib_add_dat(libs, weights=w))):
+            assert ours.hashdict() == theirs.hashdict()
+            for idx in (-1, 0, 2):
+                assert np.allclose(ours.get_sim_tmap(idx), theirs.get_sim_tmap(idx), rtol=1e-15, atol=1e-15)
+                assert all(np.allclose(x, y, rtol=1e-15, atol=1e-15) for x, y in zip(ours.get_sim_pmap(idx), theirs.get_sim_pmap(idx)))
