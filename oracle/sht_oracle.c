@@ -308,6 +308,91 @@ static inline void anal_one(int spin, int lmax, int m, int l0, const double *fp,
     }
 }
 
+
+/* ---- mode 1 accumulation, NV rings at a time (the vector direction of rec_fill's tables) ----------------------------------
+ * Same sums as synth_one / anal_one, formed for the NV rings of a block together: the Legendre values of one l are one vector
+ * (fp[l * NV + v]), the alm coefficients are broadcast scalars (synthesis) or the targets of horizontal sums (analysis).  The l loop
+ * runs in steps of two so that the parity roles (which of the even / odd accumulators a term goes to) are fixed inside the body.
+ * This is what makes the "port" baseline a vectorised code (AVX2 / AVX-512 through -march=native and omp simd); the scalar
+ * per-ring routines above remain the long-double route and the reference the block routines are tested against. */
+typedef struct { double qe[2][NV], qo[2][NV], ue[2][NV], uo[2][NV]; } blkacc;
+
+static inline void synth_blk_step(int spin, const double *p, const double *q, const double *g, const double *c,
+                                  double (*ep)[NV], double (*om)[NV], double (*uep)[NV], double (*uom)[NV])
+{
+    /* a term with Legendre value p goes to (ep, uep), one with q to (om, uom): Q += G p + i C q, U += C p - i G q */
+    const double gr = g[0], gi = g[1];
+    if (spin == 0) {
+#pragma omp simd
+        for (int v = 0; v < NV; ++v) { ep[0][v] += gr * p[v]; ep[1][v] += gi * p[v]; }
+        return;
+    }
+    const double cr = c[0], ci = c[1];
+#pragma omp simd
+    for (int v = 0; v < NV; ++v) {
+        const double pv = p[v], qv = q[v];
+        ep[0][v] += gr * pv; ep[1][v] += gi * pv;
+        om[0][v] -= ci * qv; om[1][v] += cr * qv;
+        uep[0][v] += cr * pv; uep[1][v] += ci * pv;
+        uom[0][v] += gi * qv; uom[1][v] -= gr * qv;
+    }
+}
+
+static void synth_blk(int spin, int lmax, int m, int first, const double *fp, const double *fm, const double *almG, const double *almC, blkacc *A)
+{
+    memset(A, 0, sizeof(*A));
+    int l = first;
+    if (l <= lmax && ((l + m + spin) & 1)) {  /* odd parity: Fp terms to the odd sums, Fm terms to the even ones */
+        synth_blk_step(spin, fp + (size_t)l * NV, fm + (size_t)l * NV, almG + 2 * l, almC ? almC + 2 * l : NULL, A->qo, A->qe, A->uo, A->ue);
+        ++l;
+    }
+    for (; l + 1 <= lmax; l += 2) {
+        synth_blk_step(spin, fp + (size_t)l * NV, fm + (size_t)l * NV, almG + 2 * l, almC ? almC + 2 * l : NULL, A->qe, A->qo, A->ue, A->uo);
+        synth_blk_step(spin, fp + (size_t)(l + 1) * NV, fm + (size_t)(l + 1) * NV, almG + 2 * (l + 1), almC ? almC + 2 * (l + 1) : NULL,
+                       A->qo, A->qe, A->uo, A->ue);
+    }
+    if (l <= lmax)
+        synth_blk_step(spin, fp + (size_t)l * NV, fm + (size_t)l * NV, almG + 2 * l, almC ? almC + 2 * l : NULL, A->qe, A->qo, A->ue, A->uo);
+}
+
+static inline void anal_blk_step(int spin, const double *p, const double *q, double *g, double *c,
+                                 double (*qp)[NV], double (*qm)[NV], double (*up)[NV], double (*um)[NV])
+{
+    /* G += Q p + i U q ; C += U p - i Q q, with (qp, up) the parity class that meets Fp at this l and (qm, um) the one that meets Fm */
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (spin == 0) {
+#pragma omp simd reduction(+ : s0, s1)
+        for (int v = 0; v < NV; ++v) { s0 += qp[0][v] * p[v]; s1 += qp[1][v] * p[v]; }
+        g[0] += s0; g[1] += s1;
+        return;
+    }
+#pragma omp simd reduction(+ : s0, s1, s2, s3)
+    for (int v = 0; v < NV; ++v) {
+        const double pv = p[v], qv = q[v];
+        s0 += qp[0][v] * pv - um[1][v] * qv;
+        s1 += qp[1][v] * pv + um[0][v] * qv;
+        s2 += up[0][v] * pv + qm[1][v] * qv;
+        s3 += up[1][v] * pv - qm[0][v] * qv;
+    }
+    g[0] += s0; g[1] += s1; c[0] += s2; c[1] += s3;
+}
+
+static void anal_blk(int spin, int lmax, int m, int first, const double *fp, const double *fm, double *almG, double *almC, blkacc *A)
+{
+    int l = first;
+    if (l <= lmax && ((l + m + spin) & 1)) {
+        anal_blk_step(spin, fp + (size_t)l * NV, fm + (size_t)l * NV, almG + 2 * l, almC ? almC + 2 * l : NULL, A->qo, A->qe, A->uo, A->ue);
+        ++l;
+    }
+    for (; l + 1 <= lmax; l += 2) {
+        anal_blk_step(spin, fp + (size_t)l * NV, fm + (size_t)l * NV, almG + 2 * l, almC ? almC + 2 * l : NULL, A->qe, A->qo, A->ue, A->uo);
+        anal_blk_step(spin, fp + (size_t)(l + 1) * NV, fm + (size_t)(l + 1) * NV, almG + 2 * (l + 1), almC ? almC + 2 * (l + 1) : NULL,
+                      A->qo, A->qe, A->uo, A->ue);
+    }
+    if (l <= lmax)
+        anal_blk_step(spin, fp + (size_t)l * NV, fm + (size_t)l * NV, almG + 2 * l, almC ? almC + 2 * l : NULL, A->qe, A->qo, A->ue, A->uo);
+}
+
 /* direction: 0 = synthesis (alm -> phase), 1 = analysis (phase -> alm, accumulating into zeroed alm).
  * mode: 0 long double, 1 scaled double.  Returns 0. */
 int orc_legendre(int direction, int mode, int spin, int lmax, int mmax, int nring,
@@ -377,14 +462,45 @@ int orc_legendre(int direction, int mode, int spin, int lmax, int mmax, int nrin
                     }
                     if (first > lmax) continue;
                 }
+                if (mode == 1) {  /* the NV rings of the block together (synth_blk / anal_blk) */
+                    blkacc A;
+                    const int64_t cs = 2 * nslot * mstride;  /* component stride of the phase array, in doubles */
+                    if (direction == 1) {
+                        memset(&A, 0, sizeof(A));
+                        for (int v = 0; v < nv; ++v) {
+                            int r = r0 + v;
+                            if (m > mlim[r]) continue;
+                            const double *pn = phase + 2 * ((2 * (int64_t)r) * mstride + m);
+                            const double *ps = pair[r] ? phase + 2 * ((2 * (int64_t)r + 1) * mstride + m) : NULL;
+                            for (int k = 0; k < 2; ++k) {
+                                double qn = pn[k], qs = ps ? ps[k] : 0.0;
+                                A.qe[k][v] = qn + qs; A.qo[k][v] = qn - qs;
+                                if (ncomp == 2) { double un = pn[cs + k], us = ps ? ps[cs + k] : 0.0; A.ue[k][v] = un + us; A.uo[k][v] = un - us; }
+                            }
+                        }
+                        anal_blk(spin, lmax, m, first, fp, fm, aG, aC, &A);
+                    } else {
+                        synth_blk(spin, lmax, m, first, fp, fm, aG, aC, &A);
+                        for (int v = 0; v < nv; ++v) {
+                            int r = r0 + v;
+                            if (m > mlim[r]) continue;
+                            double *pn = phase + 2 * ((2 * (int64_t)r) * mstride + m);
+                            double *ps = pair[r] ? phase + 2 * ((2 * (int64_t)r + 1) * mstride + m) : NULL;
+                            for (int k = 0; k < 2; ++k) {
+                                pn[k] = A.qe[k][v] + A.qo[k][v];
+                                if (ps) ps[k] = A.qe[k][v] - A.qo[k][v];
+                                if (ncomp == 2) { pn[cs + k] = A.ue[k][v] + A.uo[k][v]; if (ps) ps[cs + k] = A.ue[k][v] - A.uo[k][v]; }
+                            }
+                        }
+                    }
+                    continue;
+                }
                 for (int v = 0; v < nv; ++v) {
                     int r = r0 + v;
-                    if (mode == 1 && m > mlim[r]) continue;
                     double *pq_n = phase + 2 * ((2 * (int64_t)r) * mstride + m);
                     double *pq_s = pair[r] ? phase + 2 * ((2 * (int64_t)r + 1) * mstride + m) : NULL;
                     double *pu_n = ncomp == 2 ? pq_n + 2 * nslot * mstride : NULL;
                     double *pu_s = (ncomp == 2 && pq_s) ? pq_s + 2 * nslot * mstride : NULL;
-                    double dum[2];
                     if (direction == 0) {
                         double du[2], dus[2];
                         synth_one(spin, lmax, m, first, fp + v, spin ? fm + v : NULL, stride, aG, aC,
@@ -393,7 +509,6 @@ int orc_legendre(int direction, int mode, int spin, int lmax, int mmax, int nrin
                         anal_one(spin, lmax, m, first, fp + v, spin ? fm + v : NULL, stride, aG, aC,
                                  pq_n, pu_n, pq_s, pu_s);
                     }
-                    (void)dum;
                 }
             }
         }
@@ -407,28 +522,53 @@ int orc_legendre(int direction, int mode, int spin, int lmax, int mmax, int nrin
 /* Fourier stage in C (the numpy route of sht_oracle.py stays the default of the tests; this one   */
 /* is threaded over rings for bench.py's cpu_baseline and is checked against the numpy route)      */
 /* ------------------------------------------------------------------------------------------- */
-/* In-place complex FFT of power-of-two length n (iterative radix 2); sign = -1 forward, +1 inverse (unnormalised). */
-static void fft_pow2(double *re, double *im, int n, int sign, const double *twr, const double *twi /* e^{-2 pi i k / n}, k < n/2 */)
+/* In-place complex FFT of power-of-two length n (iterative radix 2); sign = -1 forward, +1 inverse (unnormalised).
+ * tw: per-stage twiddles, stage of butterfly span `half` at tw[half + k] = e^{-2 pi i k / (2 half)}, k < half (contiguous in k, so
+ * the butterfly loop vectorises). */
+typedef struct { int n; double *r, *i; } twtab;
+
+static void twtab_make(twtab *t, int n)
+{
+    t->n = n;
+    t->r = malloc(sizeof(double) * 2 * (size_t)(n > 1 ? n : 2)); t->i = t->r + (n > 1 ? n : 2);
+    for (int half = 1; half < n; half <<= 1)
+        for (int k = 0; k < half; ++k) { double a = -(double)ORC_PI * k / half; t->r[half + k] = cos(a); t->i[half + k] = sin(a); }
+}
+
+static void fft_pow2(double *re, double *im, int n, int sign, const twtab *t)
 {
     for (int i = 1, j = 0; i < n; ++i) {
         int bit = n >> 1;
         for (; j & bit; bit >>= 1) j ^= bit;
         j ^= bit;
-        if (i < j) { double t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
+        if (i < j) { double x = re[i]; re[i] = re[j]; re[j] = x; x = im[i]; im[i] = im[j]; im[j] = x; }
     }
-    for (int len = 2; len <= n; len <<= 1) {
-        int half = len >> 1, step = n / len;
-        for (int i = 0; i < n; i += len)
+    const double sg = sign < 0 ? 1.0 : -1.0;
+    for (int half = 1; half < n; half <<= 1) {
+        const double *wr = t->r + half, *wi = t->i + half;
+        for (int i = 0; i < n; i += 2 * half) {
+            double *ar = re + i, *ai = im + i, *br = re + i + half, *bi = im + i + half;
+#pragma omp simd
             for (int k = 0; k < half; ++k) {
-                double wr = twr[k * step], wi = sign < 0 ? twi[k * step] : -twi[k * step];
-                double xr = re[i + k + half] * wr - im[i + k + half] * wi, xi = re[i + k + half] * wi + im[i + k + half] * wr;
-                re[i + k + half] = re[i + k] - xr; im[i + k + half] = im[i + k] - xi;
-                re[i + k] += xr; im[i + k] += xi;
+                const double c = wr[k], d = sg * wi[k];
+                const double xr = br[k] * c - bi[k] * d, xi = br[k] * d + bi[k] * c;
+                br[k] = ar[k] - xr; bi[k] = ai[k] - xi;
+                ar[k] += xr; ai[k] += xi;
             }
+        }
     }
 }
 
-typedef struct { int n, M; double *twr, *twi, *cr, *ci, *fr, *fi, *ar, *ai; } ringfft_plan;
+/* per-thread tables: twiddles by transform size (a handful of powers of two), Bluestein chirp and filter spectrum of the current n */
+typedef struct { int n, M; twtab tw[32]; double *cr, *ci, *fr, *fi, *ar, *ai; int cap; } ringfft_plan;
+
+static const twtab *plan_tw(ringfft_plan *p, int M)
+{
+    int lg = 0;
+    while ((1 << lg) < M) ++lg;
+    if (p->tw[lg].r == NULL) twtab_make(&p->tw[lg], M);
+    return &p->tw[lg];
+}
 
 /* plan for length n: direct when n is a power of two, otherwise Bluestein (chirp e^{-i pi k^2 / n}, convolution size M >= 2n - 1) */
 static void ringfft_make(ringfft_plan *p, int n)
@@ -437,10 +577,12 @@ static void ringfft_make(ringfft_plan *p, int n)
     int M = 1;
     if ((n & (n - 1)) == 0) M = n; else { while (M < 2 * n - 1) M <<= 1; }
     p->M = M;
-    p->twr = malloc(sizeof(double) * 8 * (size_t)M); p->twi = p->twr + M;
-    p->cr = p->twi + M; p->ci = p->cr + M; p->fr = p->ci + M; p->fi = p->fr + M; p->ar = p->fi + M; p->ai = p->ar + M;
-    for (int k = 0; k < M / 2; ++k) { double a = -2.0 * (double)ORC_PI * k / M; p->twr[k] = cos(a); p->twi[k] = sin(a); }
     if (M == n) return;
+    if (M > p->cap) {
+        free(p->cr);
+        p->cr = malloc(sizeof(double) * 6 * (size_t)M); p->cap = M;
+    }
+    p->ci = p->cr + p->cap; p->fr = p->ci + p->cap; p->fi = p->fr + p->cap; p->ar = p->fi + p->cap; p->ai = p->ar + p->cap;
     for (int k = 0; k < n; ++k) {
         long long k2 = ((long long)k * k) % (2LL * n);
         double a = (double)ORC_PI * (double)k2 / n;
@@ -451,22 +593,27 @@ static void ringfft_make(ringfft_plan *p, int n)
         p->fr[k] = p->cr[k]; p->fi[k] = -p->ci[k];
         if (k) { p->fr[M - k] = p->cr[k]; p->fi[M - k] = -p->ci[k]; }
     }
-    fft_pow2(p->fr, p->fi, M, -1, p->twr, p->twi);
+    fft_pow2(p->fr, p->fi, M, -1, plan_tw(p, M));
 }
 
-static void ringfft_free(ringfft_plan *p) { free(p->twr); p->twr = NULL; }
+static void ringfft_free(ringfft_plan *p)
+{
+    free(p->cr); p->cr = NULL; p->cap = 0;
+    for (int i = 0; i < 32; ++i) { free(p->tw[i].r); p->tw[i].r = NULL; }
+}
 
 /* X_k = sum_j x_j e^{sign 2 pi i jk/n}, in place on (re, im) of length n; sign = -1 forward, +1 inverse (unnormalised) */
 static void ringfft_run(ringfft_plan *p, double *re, double *im, int sign)
 {
     const int n = p->n, M = p->M;
-    if (M == n) { fft_pow2(re, im, n, sign, p->twr, p->twi); return; }
+    if (M == n) { fft_pow2(re, im, n, sign, plan_tw(p, n)); return; }
+    const twtab *t = plan_tw(p, M);
     if (sign > 0) for (int k = 0; k < n; ++k) im[k] = -im[k];   /* inverse = conj(forward(conj(x))) */
     for (int k = 0; k < n; ++k) { p->ar[k] = re[k] * p->cr[k] - im[k] * p->ci[k]; p->ai[k] = re[k] * p->ci[k] + im[k] * p->cr[k]; }
     for (int k = n; k < M; ++k) { p->ar[k] = 0; p->ai[k] = 0; }
-    fft_pow2(p->ar, p->ai, M, -1, p->twr, p->twi);
+    fft_pow2(p->ar, p->ai, M, -1, t);
     for (int k = 0; k < M; ++k) { double r = p->ar[k] * p->fr[k] - p->ai[k] * p->fi[k]; p->ai[k] = p->ar[k] * p->fi[k] + p->ai[k] * p->fr[k]; p->ar[k] = r; }
-    fft_pow2(p->ar, p->ai, M, +1, p->twr, p->twi);
+    fft_pow2(p->ar, p->ai, M, +1, t);
     const double inv = 1.0 / M;
     for (int k = 0; k < n; ++k) {
         double r = p->ar[k] * inv, i = p->ai[k] * inv;
@@ -477,7 +624,9 @@ static void ringfft_run(ringfft_plan *p, double *re, double *im, int sign)
 
 /* direction 0: phase[slot][m] -> ring pixels (x_j = sum_m w_m Re(F_m e^{i m phi_j}), aliasing folded explicitly);
  * direction 1: ring pixels -> phase[slot][m] = (4 pi / npix) sum_j x_j e^{-i m phi_j}.
- * ring[slot] = ring index (0 .. 4 nside - 2) or -1; nphi / phi0 / ofs per ring index as sht_oracle.ring_geometry. */
+ * ring[slot] = ring index (0 .. 4 nside - 2) or -1; nphi / phi0 / ofs per ring index as sht_oracle.ring_geometry.
+ * Slots 2 i and 2 i + 1 that hold two rings of the same length and offset angle (a ring and its mirror) go through ONE complex
+ * transform, z = x_a + i x_b: both are real, so the two spectra separate by Hermitian symmetry. */
 int orc_ring_fft(int direction, int64_t npix, int mmax, int nslot, const int64_t *ring, const int64_t *nphi, const double *phi0,
                  const int64_t *ofs, double *phase, double *map, int nthreads)
 {
@@ -485,41 +634,65 @@ int orc_ring_fft(int direction, int64_t npix, int mmax, int nslot, const int64_t
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
     const double w = 4.0 * (double)ORC_PI / (double)npix;
+    const int npairs = (nslot + 1) / 2;
 #pragma omp parallel
     {
-        ringfft_plan pl; pl.twr = NULL; pl.n = 0;
-        double *re = NULL, *im = NULL; int cap = 0;
-#pragma omp for schedule(dynamic, 4)
-        for (int s = 0; s < nslot; ++s) {
-            const int64_t r = ring[s];
-            if (r < 0) continue;
-            const int n = (int)nphi[r];
-            if (pl.twr == NULL || pl.n != n) { if (pl.twr) ringfft_free(&pl); ringfft_make(&pl, n); }
-            if (n > cap) { free(re); free(im); re = malloc(sizeof(double) * n); im = malloc(sizeof(double) * n); cap = n; }
-            double *ph = phase + 2 * (int64_t)s * (mmax + 1);
-            double *px = map + ofs[r];
-            if (direction == 0) {
-                for (int k = 0; k < n; ++k) { re[k] = 0; im[k] = 0; }
-                for (int m = 0; m <= mmax; ++m) {
-                    double a = phi0[r] * m, c = cos(a), sn = sin(a);
-                    double fr = ph[2 * m] * c - ph[2 * m + 1] * sn, fi = ph[2 * m] * sn + ph[2 * m + 1] * c;
-                    re[m % n] += fr; im[m % n] += fi;
-                    if (m) { int k = (n - m % n) % n; re[k] += fr; im[k] -= fi; }
-                }
-                ringfft_run(&pl, re, im, +1);
-                for (int j = 0; j < n; ++j) px[j] = re[j];
-            } else {
-                for (int j = 0; j < n; ++j) { re[j] = px[j]; im[j] = 0; }
-                ringfft_run(&pl, re, im, -1);
-                for (int m = 0; m <= mmax; ++m) {
-                    double a = -phi0[r] * m, c = cos(a), sn = sin(a);
-                    double zr = re[m % n], zi = im[m % n];
-                    ph[2 * m] = (zr * c - zi * sn) * w; ph[2 * m + 1] = (zr * sn + zi * c) * w;
+        ringfft_plan pl; memset(&pl, 0, sizeof(pl));
+        double *re = NULL, *im = NULL, *pc = malloc(sizeof(double) * 2 * (size_t)(mmax + 1)), *ps = pc + mmax + 1; int cap = 0;
+#pragma omp for schedule(dynamic, 2)
+        for (int ip = 0; ip < npairs; ++ip) {
+            int sa = 2 * ip, sb = 2 * ip + 1;
+            int64_t ra = ring[sa], rb = sb < nslot ? ring[sb] : -1;
+            if (ra < 0 && rb < 0) continue;
+            if (ra < 0) { ra = rb; sa = sb; rb = -1; }
+            const int two = rb >= 0 && nphi[rb] == nphi[ra] && phi0[rb] == phi0[ra];
+            for (int pass = 0; pass < (two || rb < 0 ? 1 : 2); ++pass) {  /* (rings that do not match go one by one) */
+                const int64_t r = pass == 0 ? ra : rb, r2 = two ? rb : -1;
+                const int s1 = pass == 0 ? sa : sb;
+                const int n = (int)nphi[r];
+                if (pl.n != n) ringfft_make(&pl, n);
+                if (n > cap) { free(re); re = malloc(sizeof(double) * 2 * (size_t)n); im = re + n; cap = n; } else im = re + cap;
+                double *ph = phase + 2 * (int64_t)s1 * (mmax + 1), *ph2 = two ? phase + 2 * (int64_t)sb * (mmax + 1) : NULL;
+                double *px = map + ofs[r], *px2 = two ? map + ofs[r2] : NULL;
+                const int shifted = phi0[r] != 0.0;
+                if (shifted) for (int m = 0; m <= mmax; ++m) { double a = phi0[r] * m; pc[m] = cos(a); ps[m] = sin(a); }
+                if (direction == 0) {
+                    for (int k = 0; k < n; ++k) { re[k] = 0; im[k] = 0; }
+                    for (int m = 0; m <= mmax; ++m) {
+                        const double c = shifted ? pc[m] : 1.0, sn = shifted ? ps[m] : 0.0;
+                        double fr = ph[2 * m] * c - ph[2 * m + 1] * sn, fi = ph[2 * m] * sn + ph[2 * m + 1] * c;
+                        const int k = m % n, kn = (n - k) % n;
+                        re[k] += fr; im[k] += fi;
+                        if (m) { re[kn] += fr; im[kn] -= fi; }
+                        if (two) {  /* + i (spectrum of the second ring) */
+                            double gr = ph2[2 * m] * c - ph2[2 * m + 1] * sn, gi = ph2[2 * m] * sn + ph2[2 * m + 1] * c;
+                            re[k] -= gi; im[k] += gr;
+                            if (m) { re[kn] += gi; im[kn] += gr; }
+                        }
+                    }
+                    ringfft_run(&pl, re, im, +1);
+                    for (int j = 0; j < n; ++j) px[j] = re[j];
+                    if (two) for (int j = 0; j < n; ++j) px2[j] = im[j];
+                } else {
+                    for (int j = 0; j < n; ++j) { re[j] = px[j]; im[j] = two ? px2[j] : 0.0; }
+                    ringfft_run(&pl, re, im, -1);
+                    for (int m = 0; m <= mmax; ++m) {
+                        const double c = shifted ? pc[m] : 1.0, sn = shifted ? -ps[m] : 0.0;
+                        const int k = m % n, kn = (n - k) % n;
+                        double zr = re[k], zi = im[k];
+                        if (two) {  /* X_a = (Z_k + conj Z_{n-k}) / 2, X_b = (Z_k - conj Z_{n-k}) / (2 i) */
+                            const double yr = re[kn], yi = im[kn];
+                            const double ar = 0.5 * (zr + yr), ai = 0.5 * (zi - yi), br = 0.5 * (zi + yi), bi = 0.5 * (yr - zr);
+                            ph2[2 * m] = (br * c - bi * sn) * w; ph2[2 * m + 1] = (br * sn + bi * c) * w;
+                            zr = ar; zi = ai;
+                        }
+                        ph[2 * m] = (zr * c - zi * sn) * w; ph[2 * m + 1] = (zr * sn + zi * c) * w;
+                    }
                 }
             }
         }
-        if (pl.twr) ringfft_free(&pl);
-        free(re); free(im);
+        ringfft_free(&pl);
+        free(re); free(pc);
     }
     return 0;
 }

@@ -110,7 +110,9 @@ def lambda_lm(spin, m, lmax, cth, sth):
     return fp, fm
 
 
-def legendre(direction, mode, spin, lmax, mmax, cth, sth, pair, alm=None, phase=None, nthreads=0):
+def legendre(direction, mode, spin, lmax, mmax, cth, sth, pair, alm=None, phase=None, nthreads=0, out=None):
+    """out: a preallocated result array (direction 0: complex128 (ncomp, 2 nring, mmax + 1); direction 1: complex128 (ncomp, nalm)),
+    overwritten -- the C stage zeroes it first.  Saves the page faults of a fresh 100 MB+ array per call (bench.py's cpu_baseline)."""
     ncomp = 1 if spin == 0 else 2
     nring = len(cth)
     nalm = alm_size(lmax) if mmax == lmax else mmax * (2 * lmax + 1 - mmax) // 2 + lmax + 1
@@ -119,10 +121,12 @@ def legendre(direction, mode, spin, lmax, mmax, cth, sth, pair, alm=None, phase=
     pair = np.ascontiguousarray(pair, dtype=np.int32)
     if direction == 0:
         alm = np.ascontiguousarray(alm, dtype=np.complex128).reshape(ncomp, nalm)
-        phase = np.zeros((ncomp, 2 * nring, mmax + 1), dtype=np.complex128)
+        phase = np.zeros((ncomp, 2 * nring, mmax + 1), dtype=np.complex128) if out is None else out
+        assert phase.shape == (ncomp, 2 * nring, mmax + 1) and phase.dtype == np.complex128 and phase.flags.c_contiguous
     else:
         phase = np.ascontiguousarray(phase, dtype=np.complex128).reshape(ncomp, 2 * nring, mmax + 1)
-        alm = np.zeros((ncomp, nalm), dtype=np.complex128)
+        alm = np.zeros((ncomp, nalm), dtype=np.complex128) if out is None else out
+        assert alm.shape == (ncomp, nalm) and alm.dtype == np.complex128 and alm.flags.c_contiguous
     _lib().orc_legendre(direction, mode, spin, lmax, mmax, nring, _dp(cth), _dp(sth),
                         pair.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
                         _dp(alm.view(np.float64)), _dp(phase.view(np.float64)), nthreads)
@@ -207,8 +211,8 @@ def _map2phase(m, nside, mmax, slots):
 
 def ring_fft_c(direction, nside, mmax, slots, phase=None, m=None, out=None, nthreads=0):
     """The Fourier stage in C, threaded over rings (oracle/sht_oracle.c orc_ring_fft: radix-2 / Bluestein FFTs written out
-    in full): same contract as _phase2map (direction 0; returns / fills the map) and _map2phase (direction 1; returns
-    phase[slot, m]).  bench.py's cpu_baseline uses it; tests/test_oracle.py checks it against the numpy route."""
+    in full): same contract as _phase2map (direction 0; returns / fills the map `out`) and _map2phase (direction 1; returns
+    phase[slot, m], written into `out` when given).  bench.py's cpu_baseline uses it; tests/test_oracle.py checks it against the numpy route."""
     cth, sth, nphi, phi0, ofs = ring_geometry(nside)
     npix = 12 * nside ** 2
     slots = np.ascontiguousarray(slots, dtype=np.int64)
@@ -226,7 +230,9 @@ def ring_fft_c(direction, nside, mmax, slots, phase=None, m=None, out=None, nthr
     else:
         mp = np.ascontiguousarray(m, dtype=np.float64)
         assert mp.size == npix
-        ph = np.zeros((slots.size, mmax + 1), dtype=np.complex128)
+        # out (direction 1): a preallocated phase array; the rows of unused slots (ring -1) are not written -- the caller zeroed them once
+        ph = np.zeros((slots.size, mmax + 1), dtype=np.complex128) if out is None else out
+        assert ph.shape == (slots.size, mmax + 1) and ph.dtype == np.complex128 and ph.flags.c_contiguous
     _lib().orc_ring_fft(direction, npix, mmax, slots.size, slots.ctypes.data_as(lp), nphi.ctypes.data_as(lp), _dp(phi0),
                         ofs.ctypes.data_as(lp), _dp(ph.view(np.float64)), _dp(mp), nthreads)
     return mp if direction == 0 else ph
