@@ -273,18 +273,22 @@ class library(object):
         return ut.alm_copy(hp.read_alm(fname), lmax=lmax)
 
     def _pair_getter(self, k, lmax):
-        """(idx0, idx1) -> the two device estimates, evaluated together (pl_alm2map_batch2 for the leg syntheses), or None when this
-        key / library does not pair: minimum-variance keys of a same-legs library at its full band-limit.  PLENS_BATCH2=0 disables."""
+        """(idx0, idx1) -> the two device estimates, evaluated together (the leg syntheses of the two simulations share their Legendre
+        recursions, pl_alm2map_batch2), or None when this key / library does not pair: 'p' / 'x' (minimum variance), 'p_p' / 'x_p'
+        (polarization) and 'ptt' / 'xtt' (temperature: the filter stage only) of a same-legs library at its full band-limit.
+        PLENS_BATCH2=0 disables."""
         k = self.keys_remaps.get(k, k)
-        if (k not in ('p', 'x') or k not in self.keys_fund or lmax != self.get_lmax_qlm(k) or not self._same_legs()
+        fam = self._GC_FAMILY.get(k)
+        if (fam is None or k not in self.keys_fund or lmax != self.get_lmax_qlm(k) or not self._same_legs()
                 or os.environ.get('PLENS_BATCH2', '1') == '0'):
             return None
-        which = 0 if k == 'p' else 1
+        build = {'p': self._build_sim_MVgclm_pair, 'p_p': self._build_sim_Pgclm_pair, 'ptt': self._build_sim_Tgclm_pair}[fam[0]]
+        which = fam[1]
 
         def get_pair(idx0, idx1):
             if self._has(k, idx0) or self._has(k, idx1):
                 return self._get_sim_qlm_dev(k, idx0, lmax), self._get_sim_qlm_dev(k, idx1, lmax)
-            (r0, r1) = self._build_sim_MVgclm_pair(idx0, idx1)
+            (r0, r1) = build(idx0, idx1)
             return r0[which], r1[which]
         return get_pair
 
@@ -319,20 +323,16 @@ class library(object):
         xf1, xf2 = (xfilt2, xfilt1) if swapped else (xfilt1, xfilt2)
         tmap = f2map1.get_irestmap(idx, xfilt=xf1)
         G, C = f2map2.get_gtmap(idx, k=k, xfilt=xf2)
-        return dev.map_mul(G, tmap, out=G), dev.map_mul(C, tmap, out=C)
+        return dev.qe_lens_product((tmap, G, C), None)  # both components in one pass over the three maps
 
     def _p_product(self, idx, k, swapped=False, xfilt1=None, xfilt2=None):
         """(Qb - iUb)(3G + i 3C) - (Qb + iUb)(1G - i 1C): the real-space product of the P estimator (qest.py:273-278)."""
         f2map1, f2map2 = self._legs(swapped)
         xf1, xf2 = (xfilt2, xfilt1) if swapped else (xfilt1, xfilt2)
         repmap, impmap = f2map1.get_irespmap(idx, xfilt=xf1)
-        Gs, Cs = f2map2.get_gpmap(idx, 3, k=k, xfilt=xf2)
-        d = torch.empty((2, repmap.numel()), dtype=torch.float64, device=repmap.device)
-        dre, dim = d[0], d[1]
-        dev.map_cmul(repmap, impmap, -1., Gs, Cs, +1., +1., dre, dim, False)
-        Gs, Cs = f2map2.get_gpmap(idx, 1, k=k, xfilt=xf2)
-        dev.map_cmul(repmap, impmap, +1., Gs, Cs, -1., -1., dre, dim, True)
-        return dre, dim
+        g3, c3 = f2map2.get_gpmap(idx, 3, k=k, xfilt=xf2)
+        g1, c1 = f2map2.get_gpmap(idx, 1, k=k, xfilt=xf2)
+        return dev.qe_lens_product(None, (repmap, impmap, g3, c3, g1, c1))  # both terms in one pass over the six leg maps
 
     def _get_sim_Tgclm_dev(self, idx, k, swapped=False, xfilt1=None, xfilt2=None):
         G, C = self._t_product(idx, k, swapped=swapped, xfilt1=xfilt1, xfilt2=xfilt2)
@@ -416,6 +416,42 @@ class library(object):
         self._last_dev, self._last_dev_key = (out[1][2], out[1][3]), ('p', idx1, False)
         return out
 
+    def _get_sim_Pgclm_pair(self, idx0, idx1, defer=False):
+        """_get_sim_Pgclm of two simulations: the spin-2, spin-3 and spin-1 leg syntheses each serve both on one Legendre recursion
+        (lib_filt2map.get_irespmap_batch2 / get_gpmap_batch2; same legs on both sides only); maps bit-identical to the one-by-one
+        evaluation.  Returns, per simulation, (G host, C host, G device, C device) like _get_sim_MVgclm_pair."""
+        f2map1, f2map2 = self._legs(False)
+        resp = f2map1.get_irespmap_batch2(idx0, idx1)
+        gp3 = f2map2.get_gpmap_batch2(idx0, idx1, 3, k='p_p')
+        gp1 = f2map2.get_gpmap_batch2(idx0, idx1, 1, k='p_p')
+        out = []
+        for j in (0, 1):
+            dre, dim = dev.qe_lens_product(None, (resp[j][0], resp[j][1], gp3[j][0], gp3[j][1], gp1[j][0], gp1[j][1]))
+            G, C = self._gc_from_product(dre, dim, 'P')
+            if defer and G.numel() >= self._DEFER_MIN_ENTRIES:
+                out.append((dev.host_future(G), dev.host_future(C), G, C))
+            else:
+                out.append((dev.to_host(G), dev.to_host(C), G, C))
+        self._last_dev, self._last_dev_key = (out[1][2], out[1][3]), ('p_p', idx1, False)
+        return out
+
+    def _get_sim_Tgclm_pair(self, idx0, idx1, defer=False):
+        """_get_sim_Tgclm of two simulations back to back.  The temperature estimator has no general spin-weighted leg to share a
+        recursion on (its gradient leg is the gradient-only synthesis, 8 of 12 FMAs per step already); what the pair buys is the
+        filter stage of both simulations issued before either estimator, so that no host work sits between the two."""
+        f2map1, _ = self._legs(False)
+        for i in (idx0, idx1):
+            f2map1._alm('tlm', i)
+        out = []
+        for idx in (idx0, idx1):
+            G, C = self._get_sim_Tgclm_dev(idx, 'ptt')
+            if defer and G.numel() >= self._DEFER_MIN_ENTRIES:
+                out.append((dev.host_future(G), dev.host_future(C), G, C))
+            else:
+                out.append((dev.to_host(G), dev.to_host(C), G, C))
+        self._last_dev, self._last_dev_key = (out[1][2], out[1][3]), ('ptt', idx1, False)
+        return out
+
     def _scalar_from_product(self, prod, fac, lmax_key):
         lmax = self.get_lmax_qlm(lmax_key)
         return dev.to_host(shts.map2alm(prod, lmax=lmax, iter=0)) * fac
@@ -496,6 +532,22 @@ class library(object):
         for idx, (G, C, _, _) in zip((idx0, idx1), res):
             self._store('p', idx, G)
             self._store('x', idx, C)
+        return [(r[2], r[3]) for r in res]
+
+    def _build_sim_Pgclm_pair(self, idx0, idx1):
+        """both simulations' ('p_p', 'x_p') entries from one paired evaluation; returns their device (G, C)"""
+        res = self._get_sim_Pgclm_pair(idx0, idx1, defer=self._defer_ok())
+        for idx, (G, C, _, _) in zip((idx0, idx1), res):
+            self._store('p_p', idx, G)
+            self._store('x_p', idx, C)
+        return [(r[2], r[3]) for r in res]
+
+    def _build_sim_Tgclm_pair(self, idx0, idx1):
+        """both simulations' ('ptt', 'xtt') entries; returns their device (G, C)"""
+        res = self._get_sim_Tgclm_pair(idx0, idx1, defer=self._defer_ok())
+        for idx, (G, C, _, _) in zip((idx0, idx1), res):
+            self._store('ptt', idx, G)
+            self._store('xtt', idx, C)
         return [(r[2], r[3]) for r in res]
 
     def _build_sim_f(self, idx):

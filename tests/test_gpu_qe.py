@@ -227,8 +227,12 @@ def test_paired_simulations_equal_single_evaluations(setup, tmp_path):
             q = qest.library_sepTP(str(tmp_path / ('q_' + tag)), ivfs, ivfs, cl['te'], nside, lmax_qlm=lmax_qlm, cache=False)
             mf = q.get_sim_qlm_mf('p', np.array([0, 1]))
             res[tag] = (mf, q.get_sim_qlm('p', 0), q.get_sim_qlm('p', 1), q.get_sim_qlm('x', 1))
+            # round 4: the polarization-only and temperature-only keys pair as well ('p_p': all three leg syntheses on shared recursions)
+            for k, kx in (('p_p', 'x_p'), ('ptt', 'xtt')):
+                res[tag] += (q.get_sim_qlm_mf(k, np.array([0, 1])), q.get_sim_qlm(k, 0), q.get_sim_qlm(k, 1), q.get_sim_qlm(kx, 0))
         finally:
             del os.environ['PLENS_BATCH2']
     for a, b in zip(res['pair'], res['single']):
         assert np.array_equal(a, b)
     assert relrms(res['pair'][0], g['dd_mf_p']) < TOL and relrms(res['pair'][2], g['dd_p_1']) < TOL
+    assert relrms(res['pair'][5], g['dd_p_p_0']) < TOL and relrms(res['pair'][9], g['dd_ptt_0']) < TOL and relrms(res['pair'][11], g['dd_xtt_0']) < TOL
