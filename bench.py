@@ -103,6 +103,7 @@ def parse(argv=None):
     ap.add_argument('--qe-only', action='store_true',
                     help='time the estimator from filtered alms that are already resident (the cost of a further key in the reference, qest.py:184-185)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-from-sims', action='store_true', help="skip the `from_sims` leg (reconstructions timed including the device-side generation of their input maps)")
     ap.add_argument('--cpu-seconds', type=float, default=75.0, help='budget of the CPU baseline (warm-up and all repetitions together)')
     ap.add_argument('--no-cg', action='store_true', help='skip the CG block (BASELINE config 4)')
     ap.add_argument('--cg-iters', type=int, default=100)
@@ -395,6 +396,8 @@ def run_rank(args):
     gathered = parallel.allgather(qlms._last_dev[0])  # output qlm all-gather over xGMI
     for f_ in list(dev.host_future._in_flight):  # every gradient / curl alm of the timed reconstructions is in host memory (numpy) at dt
         f_.result()
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0  # this rank's own work (collectives included), before the closing barrier
     sync_all()
     dt = time.perf_counter() - t0
     prof = plan.profile_read()
@@ -403,13 +406,65 @@ def run_rank(args):
     nrec = sum(1 for (k_, i_) in qlms._mem if k_ == key and isinstance(i_, (int, np.integer)))
     assert nrec == K, 'timed region ran %d reconstructions on rank %d, expected %d' % (nrec, rank, K)
     ranks_seen = world
+    dt_ranks = [dt]
     if use_dist:
+        # per-rank times of the timed region (before the closing barrier a slow rank shows up as a long time of its own, after it as
+        # everybody's): gathered so that imbalance between GPUs is visible in the line; `value` uses the maximum
+        mine = torch.zeros(world, dtype=torch.float64, device='cuda')
+        mine[rank] = dt_local
+        dist.all_reduce(mine)
+        dt_ranks = [float(x) for x in mine.tolist()]
         tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         one = torch.ones(1, device='cuda')
         dist.all_reduce(one)
         ranks_seen = int(one.item())
+
+    # ---- the same reconstructions INCLUDING the device-side generation of their inputs (simulation synthesis must not
+    # be what limits an 8-GPU run): phases drawn on the GPU (Philox), sky alms coloured, T / Q / U maps synthesised, white noise added
+    # (sims.maps.cmb_maps_nlev on sims.phas.*_dev, as params/idealized_example.py does with PLENS_DEVICE_SIMS=1) -> filter -> QE.
+    from_sims = None
+    if not args.no_from_sims and not args.qe_only:
+        try:
+            from plancklens_amd.sims import cmbs, maps as sim_maps, phas
+            pix_ph = phas.pix_lib_phas_dev(os.path.join(tmp, 'pix_phas'), 3, (hp.nside2npix(nside),), seed=11 + rank)
+            sky_ph = phas.lib_phas_dev(os.path.join(tmp, 'sky_phas'), 3, lmax, seed=12 + rank)
+            skies = cmbs.sims_cmb_unl({k: cl_len[k] for k in ['tt', 'ee', 'bb', 'te']}, sky_ph)
+            gsims = sim_maps.cmb_maps_nlev(skies, transf, nlev_t, nlev_p, nside, pix_lib_phas=pix_ph, device_maps=True)
+            mpi.rank, mpi.size = 0, 1
+            ivfs_g = filt_simple.library_fullsky_sepTP(os.path.join(tmp, 'ivfs_g'), gsims, nside, transf, cl_len, ftl, fel, fbl, cache=False)
+            qlms_g = qest.library_sepTP(os.path.join(tmp, 'qlms_g'), ivfs_g, ivfs_g, cl_len['te'], nside, lmax_qlm=lmax_qlm, cache=False)
+            mpi.rank, mpi.size = rank, world
+            qlms_g.get_sim_qlms(key, [10 ** 6 + world * w + rank for w in range(min(args.warmup, 2))])
+            qlms_g._mem.clear()
+            sync_all()
+            t0 = time.perf_counter()
+            qlms_g.get_sim_qlm_mf(key, np.arange(world * K), collective=True)
+            for f_ in list(dev.host_future._in_flight):
+                f_.result()
+            sync_all()
+            dtg = time.perf_counter() - t0
+            # generation alone (maps of K further simulations made and dropped)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for idx in range(K):
+                gsims.get_sim_tmap(2 * 10 ** 6 + idx)
+                gsims.get_sim_pmap(2 * 10 ** 6 + idx)
+            torch.cuda.synchronize()
+            dgen = time.perf_counter() - t0
+            if use_dist:
+                tt = torch.tensor([dtg, dgen], dtype=torch.float64, device='cuda')
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dtg, dgen = float(tt[0]), float(tt[1])
+            from_sims = {'value': world * K / dtg, 'unit': 'reconstructions/s', 'ms_per_step': 1e3 * dtg / K,
+                         'generation_ms_per_simulation': 1e3 * dgen / K, 'generation_share_of_step': dgen / dtg,
+                         'note': "same estimator, inputs NOT resident: every simulation's T, Q, U maps are generated on the device inside the "
+                                 "timed region (Philox phases -> coloured alms -> alm2map + alm2map_spin + white noise: sims.maps.cmb_maps_nlev, "
+                                 "maps.py:46-77,136-173 of the reference); `value` of the line stays the resident-input rate"}
+            del gsims, ivfs_g, qlms_g, skies
+        except Exception as e:  # a report, never a reason to lose the headline number
+            from_sims = {'error': repr(e)}
 
     if rank == 0:
         nalm = hp.Alm.getsize(lmax)
@@ -422,6 +477,7 @@ def run_rank(args):
             'value': world * K / dt, 'unit': 'reconstructions/s', 'n_gpus': world, 'steps': K,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / K, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic', 'ranks_seen': ranks_seen,
+            'ms_per_step_by_rank': [1e3 * x / K for x in dt_ranks],
             'config': {'workload': "'%s' MV quadratic estimator from T,Q,U maps: isotropic filter + qest.library_sepTP, "
                                    "nside=%d lmax_ivf=%d lmax_qlm=%d, 9 SHTs (2 scalar + 7 spin pairs) per reconstruction (BASELINE.json headline config); "
                                    "timed region = qest.library.get_sim_qlm_mf over %d simulations (%d per GPU) + all-gather of the last qlm"
@@ -490,6 +546,8 @@ def run_rank(args):
                       'achieved_GBs': bytes_rec / 1e9 / (dt / K), 'peak_GBs': HBM_PEAK_GBS,
                       'frac': bytes_rec / 1e9 / (dt / K) / HBM_PEAK_GBS,
                       'note': 'path is FP64-FMA bound (arithmetic intensity ~190 flop/B): a low HBM fraction is a property of the algorithm'}
+    if rank == 0 and from_sims is not None:
+        res['from_sims'] = from_sims
     # release the QE working set before the CG block
     del sims, ivfs, qlms, gathered
     if world == 1 and rank == 0:

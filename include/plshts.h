@@ -69,6 +69,12 @@ int pl_phase_pack(pl_plan *plan, int ncomp, const double *phase, double *buf, in
 int pl_phase_unpack(pl_plan *plan, int ncomp, double *phase, const double *buf, int pair0, int pair_stride, int mg0, int mg_stride, void *stream);
 int64_t pl_phase_pack_doubles(const pl_plan *plan, int ncomp, int pair0, int pair_stride, int mg0, int mg_stride);
 int pl_alm_keep_mgroups(int lmax, int nb, double *alm, int mg0, int mg_stride, void *stream);
+/* The pixels of the ring pairs pair0, pair0 + pair_stride, ... of an ncomp-component map (components npix apart) packed as
+ * [component][pair: north ring, south ring], pl_map_pack_doubles doubles per component, and back: a rank's own rings for the all-gather
+ * that completes a sharded synthesis (1 / R of the map instead of an all-reduce of zero-padded maps; plancklens_amd/parallel.py). */
+int64_t pl_map_pack_doubles(const pl_plan *plan, int pair0, int pair_stride);
+int pl_map_pack_rings(pl_plan *plan, int ncomp, const double *map, double *buf, int pair0, int pair_stride, void *stream);
+int pl_map_unpack_rings(pl_plan *plan, int ncomp, double *map, const double *buf, int pair0, int pair_stride, void *stream);
 
 /* shts.alm2map (shts.py:12-15) / shts.alm2map_spin (shts.py:22-24).  spin = 0: alm -> map;
  * spin = 1,2,3: [G|C] -> [Q|U].  If fl != NULL (length lmax + 1) the alm are multiplied by fl_l on the

@@ -174,10 +174,16 @@ static void rectab_build(rectab *t, int m, int n, int lmax)
 }
 
 /* Fill lam[l*NV + v] (l = l0..lmax) with the IEEE-range values of the function (0 while still below 2^-256),
- * for NV rings.  Returns the first l with a non-zero entry (lmax + 1 if none). */
-static int rec_fill(const rectab *t, int lmax, const double *x, const double *st, const double *ch, const double *sh, int nv, double *lam)
+ * for NV rings.  Returns the first l with a non-zero entry (lmax + 1 if none).
+ * Two parts: rec_scaled seeds the recursion and runs it while at least one ring is still below the IEEE window (per-lane scale
+ * bookkeeping); rec_ieee continues with the plain three-term step.  rec_fill2 runs the two functions of a spin-weighted transform
+ * (n = -s and n = +s) through the IEEE part together: one recursion is a chain of dependent FMAs, two interleaved ones fill the pipe. */
+typedef struct { double v1[NV], v2[NV]; int l, first; } recstate;
+
+static void rec_scaled(const rectab *t, int lmax, const double *x, const double *st, const double *ch, const double *sh, int nv, double *lam,
+                       recstate *S)
 {
-    double v1[NV], v2[NV]; int sc[NV];
+    double *v1 = S->v1, *v2 = S->v2; int sc[NV];
     int l0 = t->l0;
     for (int v = 0; v < NV; ++v) { v1[v] = 0; v2[v] = 0; sc[v] = 0; }
     for (int v = 0; v < nv; ++v) {
@@ -209,10 +215,18 @@ static int rec_fill(const rectab *t, int lmax, const double *x, const double *st
         }
     }
     if (l <= lmax && first > lmax) first = l;
-    /* IEEE phase */
-    for (; l <= lmax; ++l) {
+    S->l = l; S->first = first;
+}
+
+/* IEEE phase from S->l up to (and including) lend <= lmax: stores lam[l] and steps; on return S->l = lend + 1 (state = value at lend + 1
+ * unless lend = lmax) */
+static void rec_ieee(const rectab *t, int lmax, const double *x, double *lam, recstate *S, int lend)
+{
+    double *v1 = S->v1, *v2 = S->v2;
+    int l = S->l;
+    for (; l <= lend; ++l) {
         for (int v = 0; v < NV; ++v) lam[(size_t)l * NV + v] = v2[v];
-        if (l == lmax) break;
+        if (l == lmax) { ++l; break; }
         double a = t->a[l], b = t->b[l], c = t->c[l];
 #pragma omp simd
         for (int v = 0; v < NV; ++v) {
@@ -220,7 +234,46 @@ static int rec_fill(const rectab *t, int lmax, const double *x, const double *st
             v1[v] = v2[v]; v2[v] = nw;
         }
     }
-    return first;
+    S->l = l;
+}
+
+static int rec_fill(const rectab *t, int lmax, const double *x, const double *st, const double *ch, const double *sh, int nv, double *lam)
+{
+    recstate S;
+    rec_scaled(t, lmax, x, st, ch, sh, nv, lam, &S);
+    rec_ieee(t, lmax, x, lam, &S, lmax);
+    return S.first;
+}
+
+typedef struct { double x[NV], st[NV], ch[NV], sh[NV]; int nv; } blkgeom;
+
+/* two recursions side by side: functions ta, tb on ring blocks ga, gb (the same block for the two functions of a spin-weighted
+ * transform, two different blocks of one function for spin 0) */
+static void rec_fill2(const rectab *ta, const rectab *tb, int lmax, const blkgeom *ga, const blkgeom *gb,
+                      double *lama, double *lamb, int *firsta, int *firstb)
+{
+    recstate A, B;
+    const double *x = ga->x, *xb = gb->x;
+    rec_scaled(ta, lmax, ga->x, ga->st, ga->ch, ga->sh, ga->nv, lama, &A);
+    rec_scaled(tb, lmax, gb->x, gb->st, gb->ch, gb->sh, gb->nv, lamb, &B);
+    *firsta = A.first; *firstb = B.first;
+    /* the one that reached the IEEE window first goes on alone until the other has */
+    if (A.l < B.l) rec_ieee(ta, lmax, x, lama, &A, B.l - 1 < lmax ? B.l - 1 : lmax);
+    else if (B.l < A.l) rec_ieee(tb, lmax, xb, lamb, &B, A.l - 1 < lmax ? A.l - 1 : lmax);
+    /* the joint loop on local copies (no aliasing with the state structs: the loop vectorises with both chains in registers) */
+    double xa_[NV], xb_[NV], p1[NV], p2[NV], q1[NV], q2[NV];
+    for (int v = 0; v < NV; ++v) { xa_[v] = x[v]; xb_[v] = xb[v]; p1[v] = A.v1[v]; p2[v] = A.v2[v]; q1[v] = B.v1[v]; q2[v] = B.v2[v]; }
+    for (int l = A.l; l <= lmax; ++l) {
+        double *restrict oa = lama + (size_t)l * NV, *restrict ob = lamb + (size_t)l * NV;
+        for (int v = 0; v < NV; ++v) { oa[v] = p2[v]; ob[v] = q2[v]; }
+        if (l == lmax) break;
+        const double a1 = ta->a[l], b1 = ta->b[l], c1 = ta->c[l], a2 = tb->a[l], b2 = tb->b[l], c2 = tb->c[l];
+#pragma omp simd
+        for (int v = 0; v < NV; ++v) {
+            const double n1 = (xa_[v] * a1 - b1) * p2[v] - c1 * p1[v], n2 = (xb_[v] * a2 - b2) * q2[v] - c2 * q1[v];
+            p1[v] = p2[v]; p2[v] = n1; q1[v] = q2[v]; q2[v] = n2;
+        }
+    }
 }
 
 /* libsharp's polar-optimisation bound: orders m above this contribute < ~1e-30 on the ring */
@@ -393,6 +446,64 @@ static void anal_blk(int spin, int lmax, int m, int first, const double *fp, con
         anal_blk_step(spin, fp + (size_t)l * NV, fm + (size_t)l * NV, almG + 2 * l, almC ? almC + 2 * l : NULL, A->qe, A->qo, A->ue, A->uo);
 }
 
+
+/* ---- spin s > 0 without the Fp / Fm tables --------------------------------------------------------------------------------
+ * With D- = sqrt((2l+1)/4pi) d^l_{m,-s}, D+ = ... d^l_{m,+s} (the two tables of rec_fill2), sg = (-1)^s:
+ *   Fp = -(sg D- + D+) / 2, Fm = -(sg D- - D+) / 2,   and under theta -> pi - theta:  sg D- -> sigma D+, D+ -> sigma sg D-,
+ *   sigma = (-1)^(l+m+s).  Substituting into Q = sum G Fp + i C Fm, U = sum C Fp - i G Fm:
+ *   north:  X = sum_l A_l D-,  Y = sum_l B_l D+,   A = -sg (G + iC) / 2,  B = -(G - iC) / 2,   Q = X + Y,  U = i (Y - X)
+ *   south:  X_S = sg sum_l sigma A_l D+,  Y_S = sg sum_l sigma B_l D-,  same combinations.
+ * The analysis is the adjoint: T- = sum_rings [D- P_N + sigma sg D+ P_S], T+ = sum_rings [D+ M_N + sigma sg D- M_S] with P = Q + iU,
+ * M = Q - iU, and G = -(sg T- + T+) / 2, C = -i (T+ - sg T-) / 2.  Same FMA count as the Fp / Fm form, no pass that builds Fp, Fm. */
+typedef struct { double x[2][NV], y[2][NV], xe[2][NV], xo[2][NV], ye[2][NV], yo[2][NV]; } blkacc2;
+
+static inline void synth2_step(const double *dm, const double *dp, const double *A, const double *B,
+                               double (*X)[NV], double (*Y)[NV], double (*XS)[NV], double (*YS)[NV])
+{
+    const double ar = A[0], ai = A[1], br = B[0], bi = B[1];
+#pragma omp simd
+    for (int v = 0; v < NV; ++v) {
+        const double m_ = dm[v], p_ = dp[v];
+        X[0][v] += ar * m_; X[1][v] += ai * m_; Y[0][v] += br * p_; Y[1][v] += bi * p_;
+        XS[0][v] += ar * p_; XS[1][v] += ai * p_; YS[0][v] += br * m_; YS[1][v] += bi * m_;
+    }
+}
+
+static void synth_blk2(int spin, int lmax, int m, int first, const double *Dm, const double *Dp, const double *A, const double *B, blkacc2 *S)
+{
+    memset(S, 0, sizeof(*S));
+    int l = first;
+    if (l <= lmax && ((l + m + spin) & 1)) { synth2_step(Dm + (size_t)l * NV, Dp + (size_t)l * NV, A + 2 * l, B + 2 * l, S->x, S->y, S->xo, S->yo); ++l; }
+    for (; l + 1 <= lmax; l += 2) {
+        synth2_step(Dm + (size_t)l * NV, Dp + (size_t)l * NV, A + 2 * l, B + 2 * l, S->x, S->y, S->xe, S->ye);
+        synth2_step(Dm + (size_t)(l + 1) * NV, Dp + (size_t)(l + 1) * NV, A + 2 * (l + 1), B + 2 * (l + 1), S->x, S->y, S->xo, S->yo);
+    }
+    if (l <= lmax) synth2_step(Dm + (size_t)l * NV, Dp + (size_t)l * NV, A + 2 * l, B + 2 * l, S->x, S->y, S->xe, S->ye);
+}
+
+/* inputs: pn = P_N, mn = M_N, ps = sg P_S, ms = sg M_S per ring ([re / im][ring]); sigma = +1 or -1 for this l */
+static inline void anal2_step(const double *dm, const double *dp, double sigma, double (*pn)[NV], double (*mn)[NV], double (*ps)[NV], double (*ms)[NV],
+                              double *Tm, double *Tp)
+{
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma omp simd reduction(+ : s0, s1, s2, s3)
+    for (int v = 0; v < NV; ++v) {
+        const double m_ = dm[v], p_ = sigma * dp[v], q_ = dp[v], r_ = sigma * dm[v];
+        s0 += m_ * pn[0][v] + p_ * ps[0][v];
+        s1 += m_ * pn[1][v] + p_ * ps[1][v];
+        s2 += q_ * mn[0][v] + r_ * ms[0][v];
+        s3 += q_ * mn[1][v] + r_ * ms[1][v];
+    }
+    Tm[0] += s0; Tm[1] += s1; Tp[0] += s2; Tp[1] += s3;
+}
+
+static void anal_blk2(int spin, int lmax, int m, int first, const double *Dm, const double *Dp, double (*pn)[NV], double (*mn)[NV], double (*ps)[NV],
+                      double (*ms)[NV], double *Tm, double *Tp)
+{
+    for (int l = first; l <= lmax; ++l)
+        anal2_step(Dm + (size_t)l * NV, Dp + (size_t)l * NV, ((l + m + spin) & 1) ? -1.0 : 1.0, pn, mn, ps, ms, Tm + 2 * l, Tp + 2 * l);
+}
+
 /* direction: 0 = synthesis (alm -> phase), 1 = analysis (phase -> alm, accumulating into zeroed alm).
  * mode: 0 long double, 1 scaled double.  Returns 0. */
 int orc_legendre(int direction, int mode, int spin, int lmax, int mmax, int nring,
@@ -412,9 +523,13 @@ int orc_legendre(int direction, int mode, int spin, int lmax, int mmax, int nrin
 
 #pragma omp parallel
     {
-        double *fp = malloc(sizeof(double) * (size_t)(lmax + 1) * NV);
-        double *fm = malloc(sizeof(double) * (size_t)(lmax + 1) * NV);
-        double *tm = malloc(sizeof(double) * (size_t)(lmax + 1) * NV);
+        /* (64-byte aligned: a row of NV doubles is one cache line / one vector) */
+        /* one block, the three tables 64-byte aligned and staggered by a few cache lines: equal offsets modulo 4 KB would make the two
+         * table rows written per l (and the rows read back) alias in the store buffers */
+        const size_t tabn = ((size_t)(lmax + 1) * NV + 7) & ~(size_t)7;
+        double *tabs = aligned_alloc(64, sizeof(double) * (3 * tabn + 64 * 3));
+        double *fp = tabs, *fm = tabs + tabn + 24, *tm = tabs + 2 * tabn + 88;
+        double *Aa = malloc(sizeof(double) * 8 * (size_t)(lmax + 1)), *Ab = Aa + 2 * (lmax + 1), *Tm = Ab + 2 * (lmax + 1), *Tp = Tm + 2 * (lmax + 1);
         long double *scr = malloc(sizeof(long double) * 3 * (size_t)(lmax + 1));
         rectab tp, tn;
         tp.a = malloc(sizeof(double) * 3 * (size_t)(lmax + 2)); tp.b = tp.a + lmax + 2; tp.c = tp.b + lmax + 2;
@@ -427,9 +542,23 @@ int orc_legendre(int direction, int mode, int spin, int lmax, int mmax, int nrin
             if (mode == 1) {
                 rectab_build(&tp, m, -spin, lmax);
                 if (spin) rectab_build(&tn, m, spin, lmax);
+                if (spin && direction == 0) {
+                    const double sg = (spin & 1) ? -1.0 : 1.0;
+                    for (int l = l0; l <= lmax; ++l) {  /* A = -sg (G + iC) / 2, B = -(G - iC) / 2 */
+                        const double gr = aG[2 * l], gi = aG[2 * l + 1], cr = aC[2 * l], ci = aC[2 * l + 1];
+                        Aa[2 * l] = -0.5 * sg * (gr - ci); Aa[2 * l + 1] = -0.5 * sg * (gi + cr);
+                        Ab[2 * l] = -0.5 * (gr + ci); Ab[2 * l + 1] = -0.5 * (gi - cr);
+                    }
+                } else if (spin) {
+                    memset(Tm, 0, sizeof(double) * 2 * (size_t)(lmax + 1)); memset(Tp, 0, sizeof(double) * 2 * (size_t)(lmax + 1));
+                }
             }
+            /* mode 1, spin 0: ring blocks go through the recursion two at a time (rec_fill2 on two blocks; the second one's values
+             * wait in `tm`); `held` = the block whose values are in tm, to be accumulated next */
+            int held = -1, held_first = 0;
             for (int r0 = 0; r0 < nring; r0 += (mode == 1 ? NV : 1)) {
                 int nv = 1, first = l0, stride = 1;
+                double *lamtab = fp;
                 if (mode == 0) {
                     get_lam_ld(spin, m, lmax, cth[r0], sth[r0], fp, fm, scr);
                 } else {
@@ -437,32 +566,75 @@ int orc_legendre(int direction, int mode, int spin, int lmax, int mmax, int nrin
                     int anyact = 0;
                     for (int v = 0; v < nv; ++v) anyact |= (m <= mlim[r0 + v]);
                     if (!anyact) continue;
-                    double x[NV], st[NV], ch[NV], sh[NV];
-                    for (int v = 0; v < NV; ++v) {
-                        int r = r0 + (v < nv ? v : 0);
-                        x[v] = cth[r]; st[v] = sth[r];
-                        /* half-angle functions without cancellation: cos(th/2)^2 = (1+x)/2, sin(th/2) = sin(th) / (2 cos(th/2)) */
-                        if (cth[r] >= 0) { ch[v] = sqrt(0.5 * (1.0 + cth[r])); sh[v] = 0.5 * sth[r] / ch[v]; }
-                        else { sh[v] = sqrt(0.5 * (1.0 - cth[r])); ch[v] = 0.5 * sth[r] / sh[v]; }
-                    }
                     stride = NV;
-                    int f1 = rec_fill(&tp, lmax, x, st, ch, sh, nv, fp);
-                    first = f1;
-                    if (spin) {
-                        int f2 = rec_fill(&tn, lmax, x, st, ch, sh, nv, tm);
-                        first = f1 < f2 ? f1 : f2;
-                        double sg = (spin & 1) ? -1.0 : 1.0;
-                        for (int l = first; l <= lmax; ++l)
+                    if (held == r0) {  /* spin 0: this block was filled together with the previous one */
+                        lamtab = tm; first = held_first; held = -1;
+                    } else {
+                        blkgeom g[2];
+                        int nblk = 1;
+                        if (spin == 0 && r0 + NV < nring) {  /* a second active block to ride along? */
+                            int act2 = 0, nv2 = nring - (r0 + NV) < NV ? nring - (r0 + NV) : NV;
+                            for (int v = 0; v < nv2; ++v) act2 |= (m <= mlim[r0 + NV + v]);
+                            if (act2) nblk = 2;
+                        }
+                        for (int b = 0; b < nblk; ++b) {
+                            const int rb = r0 + b * NV, nvb = nring - rb < NV ? nring - rb : NV;
+                            g[b].nv = nvb;
                             for (int v = 0; v < NV; ++v) {
-                                double lp = sg * fp[(size_t)l * NV + v], lm_ = sg * tm[(size_t)l * NV + v];
-                                if (l < f1) lp = 0; if (l < f2) lm_ = 0;
-                                fp[(size_t)l * NV + v] = -0.5 * (lp + sg * lm_);
-                                fm[(size_t)l * NV + v] = -0.5 * (lp - sg * lm_);
+                                int r = rb + (v < nvb ? v : 0);
+                                g[b].x[v] = cth[r]; g[b].st[v] = sth[r];
+                                /* half-angle functions without cancellation: cos(th/2)^2 = (1+x)/2, sin(th/2) = sin(th) / (2 cos(th/2)) */
+                                if (cth[r] >= 0) { g[b].ch[v] = sqrt(0.5 * (1.0 + cth[r])); g[b].sh[v] = 0.5 * sth[r] / g[b].ch[v]; }
+                                else { g[b].sh[v] = sqrt(0.5 * (1.0 - cth[r])); g[b].ch[v] = 0.5 * sth[r] / g[b].sh[v]; }
                             }
+                        }
+                        int f1, f2 = lmax + 1;
+                        if (spin) rec_fill2(&tp, &tn, lmax, &g[0], &g[0], fp, tm, &f1, &f2);   /* fp = D-, tm = D+ */
+                        else if (nblk == 2) { rec_fill2(&tp, &tp, lmax, &g[0], &g[1], fp, tm, &f1, &held_first); held = r0 + NV; }
+                        else f1 = rec_fill(&tp, lmax, g[0].x, g[0].st, g[0].ch, g[0].sh, nv, fp);
+                        first = spin ? (f1 < f2 ? f1 : f2) : f1;
                     }
                     if (first > lmax) continue;
                 }
-                if (mode == 1) {  /* the NV rings of the block together (synth_blk / anal_blk) */
+                if (mode == 1 && spin > 0) {  /* the NV rings of the block together, on D- and D+ directly (synth_blk2 / anal_blk2) */
+                    const int64_t cs = 2 * nslot * mstride;  /* component stride of the phase array, in doubles */
+                    const double sg = (spin & 1) ? -1.0 : 1.0;
+                    if (direction == 1) {
+                        double pn[2][NV], mn[2][NV], ps[2][NV], ms[2][NV];
+                        memset(pn, 0, sizeof(pn)); memset(mn, 0, sizeof(mn)); memset(ps, 0, sizeof(ps)); memset(ms, 0, sizeof(ms));
+                        for (int v = 0; v < nv; ++v) {
+                            int r = r0 + v;
+                            if (m > mlim[r]) continue;
+                            const double *qn = phase + 2 * ((2 * (int64_t)r) * mstride + m), *un = qn + cs;
+                            pn[0][v] = qn[0] - un[1]; pn[1][v] = qn[1] + un[0];   /* P = Q + i U */
+                            mn[0][v] = qn[0] + un[1]; mn[1][v] = qn[1] - un[0];   /* M = Q - i U */
+                            if (pair[r]) {
+                                const double *qs = phase + 2 * ((2 * (int64_t)r + 1) * mstride + m), *us = qs + cs;
+                                ps[0][v] = sg * (qs[0] - us[1]); ps[1][v] = sg * (qs[1] + us[0]);
+                                ms[0][v] = sg * (qs[0] + us[1]); ms[1][v] = sg * (qs[1] - us[0]);
+                            }
+                        }
+                        anal_blk2(spin, lmax, m, first, fp, tm, pn, mn, ps, ms, Tm, Tp);
+                    } else {
+                        blkacc2 S;
+                        synth_blk2(spin, lmax, m, first, fp, tm, Aa, Ab, &S);
+                        for (int v = 0; v < nv; ++v) {
+                            int r = r0 + v;
+                            if (m > mlim[r]) continue;
+                            double *qn = phase + 2 * ((2 * (int64_t)r) * mstride + m), *un = qn + cs;
+                            qn[0] = S.x[0][v] + S.y[0][v]; qn[1] = S.x[1][v] + S.y[1][v];                 /* Q = X + Y */
+                            un[0] = -(S.y[1][v] - S.x[1][v]); un[1] = S.y[0][v] - S.x[0][v];              /* U = i (Y - X) */
+                            if (pair[r]) {
+                                double *qs = phase + 2 * ((2 * (int64_t)r + 1) * mstride + m), *us = qs + cs;
+                                const double xr = sg * (S.xe[0][v] - S.xo[0][v]), xi = sg * (S.xe[1][v] - S.xo[1][v]);
+                                const double yr = sg * (S.ye[0][v] - S.yo[0][v]), yi = sg * (S.ye[1][v] - S.yo[1][v]);
+                                qs[0] = xr + yr; qs[1] = xi + yi; us[0] = -(yi - xi); us[1] = yr - xr;
+                            }
+                        }
+                    }
+                    continue;
+                }
+                if (mode == 1) {  /* spin 0: the NV rings of the block together (synth_blk / anal_blk) */
                     blkacc A;
                     const int64_t cs = 2 * nslot * mstride;  /* component stride of the phase array, in doubles */
                     if (direction == 1) {
@@ -478,9 +650,9 @@ int orc_legendre(int direction, int mode, int spin, int lmax, int mmax, int nrin
                                 if (ncomp == 2) { double un = pn[cs + k], us = ps ? ps[cs + k] : 0.0; A.ue[k][v] = un + us; A.uo[k][v] = un - us; }
                             }
                         }
-                        anal_blk(spin, lmax, m, first, fp, fm, aG, aC, &A);
+                        anal_blk(spin, lmax, m, first, lamtab, fm, aG, aC, &A);
                     } else {
-                        synth_blk(spin, lmax, m, first, fp, fm, aG, aC, &A);
+                        synth_blk(spin, lmax, m, first, lamtab, fm, aG, aC, &A);
                         for (int v = 0; v < nv; ++v) {
                             int r = r0 + v;
                             if (m > mlim[r]) continue;
@@ -511,8 +683,16 @@ int orc_legendre(int direction, int mode, int spin, int lmax, int mmax, int nrin
                     }
                 }
             }
+            if (mode == 1 && spin && direction == 1) {  /* G = -(sg T- + T+) / 2, C = -i (T+ - sg T-) / 2 */
+                const double sg = (spin & 1) ? -1.0 : 1.0;
+                for (int l = l0; l <= lmax; ++l) {
+                    const double tmr = sg * Tm[2 * l], tmi = sg * Tm[2 * l + 1], tpr = Tp[2 * l], tpi = Tp[2 * l + 1];
+                    aG[2 * l] = -0.5 * (tmr + tpr); aG[2 * l + 1] = -0.5 * (tmi + tpi);
+                    aC[2 * l] = 0.5 * (tpi - tmi); aC[2 * l + 1] = -0.5 * (tpr - tmr);
+                }
+            }
         }
-        free(fp); free(fm); free(tm); free(scr); free(tp.a); free(tn.a);
+        free(tabs); free(scr); free(tp.a); free(tn.a); free(Aa);
     }
     free(mlim);
     return 0;

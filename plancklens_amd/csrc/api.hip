@@ -59,6 +59,8 @@ void launch_template_project_md(const DevPlan &P, int nb, double *t, const doubl
                                 hipStream_t st);
 void launch_phase_pack(const DevPlan &P, int ncomp, double *phase, double *buf, int pair0, int pstride, int mg0, int mgstride, bool unpack, hipStream_t st);
 void launch_alm_keep_mgroups(int lmax, double *alm, int mg0, int mgstride, int nb, hipStream_t st);
+int64_t map_pack_doubles(const DevPlan &P, int pair0, int pstride);
+void launch_map_pack_rings(const DevPlan &P, int ncomp, double *map, double *buf, int pair0, int pstride, bool unpack, hipStream_t st);
 }  // namespace plshts
 
 using namespace plshts;
@@ -419,6 +421,28 @@ int pl_phase_unpack(pl_plan *p, int ncomp, double *phase, const double *buf, int
 {
     if (!p || !phase || !buf || ncomp < 1 || pair_stride < 1 || mg_stride < 1 || pair0 < 0 || mg0 < 0) return fail("pl_phase_unpack: bad arguments");
     launch_phase_pack(p->P, ncomp, phase, const_cast<double *>(buf), pair0, pair_stride, mg0, mg_stride, true, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// The pixels of ring pairs pair0, pair0 + pair_stride, ... of an ncomp-component map as one buffer [component][pair: north ring, south
+// ring] (pl_map_pack_doubles per component) and back: what a rank contributes to the all-gather that completes a sharded synthesis.
+int64_t pl_map_pack_doubles(const pl_plan *p, int pair0, int pair_stride)
+{
+    if (!p || pair_stride < 1 || pair0 < 0) return 0;
+    return map_pack_doubles(p->P, pair0, pair_stride);
+}
+int pl_map_pack_rings(pl_plan *p, int ncomp, const double *map, double *buf, int pair0, int pair_stride, void *stream)
+{
+    if (!p || !map || !buf || ncomp < 1 || pair_stride < 1 || pair0 < 0) return fail("pl_map_pack_rings: bad arguments");
+    launch_map_pack_rings(p->P, ncomp, const_cast<double *>(map), buf, pair0, pair_stride, false, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int pl_map_unpack_rings(pl_plan *p, int ncomp, double *map, const double *buf, int pair0, int pair_stride, void *stream)
+{
+    if (!p || !map || !buf || ncomp < 1 || pair_stride < 1 || pair0 < 0) return fail("pl_map_unpack_rings: bad arguments");
+    launch_map_pack_rings(p->P, ncomp, map, const_cast<double *>(buf), pair0, pair_stride, true, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -776,6 +776,31 @@ __global__ void k_phase_pack(DevPlan P, int ncomp, double *__restrict__ phase, d
     }
 }
 
+// The pixels of the ring pairs pair0, pair0 + pstride, ... of a map (a rank's rings of a sharded transform) as one packed buffer
+// [component][pair j: north ring, south ring] and back.  Doubles in front of selected pair j: ring lengths are 4 (ip + 1) in the cap
+// (ip <= nside - 2) and 4 nside in the belt; the equator (last pair) has no partner.
+__host__ __device__ inline int64_t ring_pack_offset(int nside, int pair0, int pstride, int j)
+{
+    int64_t k = 0;
+    if (pair0 <= nside - 2) { k = (nside - 2 - pair0) / pstride + 1; if (k > j) k = j; }
+    return 2 * (4 * (k * (int64_t)(pair0 + 1) + (int64_t)pstride * k * (k - 1) / 2) + 4 * (int64_t)nside * (j - k));
+}
+__global__ __launch_bounds__(256) void k_map_pack_rings(DevPlan P, double *__restrict__ map, double *__restrict__ buf, int pair0, int pstride,
+                                                        int64_t per_comp, int unpack)
+{
+    const int j = blockIdx.x, c = blockIdx.y;
+    const int ip = pair0 + j * pstride;
+    const int n = P.nphi[ip];
+    const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
+    double2 *b = reinterpret_cast<double2 *>(buf + (int64_t)c * per_comp + ring_pack_offset(P.nside, pair0, pstride, j));
+    double2 *mn = reinterpret_cast<double2 *>(map + (int64_t)c * P.npix + on);
+    double2 *ms = os >= 0 ? reinterpret_cast<double2 *>(map + (int64_t)c * P.npix + os) : nullptr;
+    for (int t = threadIdx.x; t < n / 2; t += 256) {  // (ring lengths and offsets are multiples of 4 doubles)
+        if (unpack) { mn[t] = b[t]; if (ms) ms[t] = b[n / 2 + t]; }
+        else { b[t] = mn[t]; if (ms) b[n / 2 + t] = ms[t]; }
+    }
+}
+
 __global__ void k_alm_keep_mgroups(int lmax, double2 *__restrict__ alm_, int mg0, int mgstride)
 {
     double2 *__restrict__ alm = alm_ + blockIdx.z * alm_count(lmax);
@@ -796,6 +821,20 @@ void launch_phase_pack(const DevPlan &P, int ncomp, double *phase, double *buf, 
     const int64_t n = (int64_t)nsel * ncomp * nmsel * 8;
     if (n == 0) return;
     hipLaunchKernelGGL(k_phase_pack, dim3(nblocks(n)), dim3(256), 0, st, P, ncomp, phase, buf, pair0, pstride, mg0, mgstride, nsel, nmsel, unpack ? 1 : 0);
+}
+int64_t map_pack_doubles(const DevPlan &P, int pair0, int pstride)
+{
+    const int nsel = P.npairs > pair0 ? (P.npairs - pair0 + pstride - 1) / pstride : 0;
+    if (nsel == 0) return 0;
+    int64_t n = ring_pack_offset(P.nside, pair0, pstride, nsel);
+    if (pair0 + (nsel - 1) * pstride == P.npairs - 1) n -= 4 * (int64_t)P.nside;  // the equator has no mirror ring
+    return n;
+}
+void launch_map_pack_rings(const DevPlan &P, int ncomp, double *map, double *buf, int pair0, int pstride, bool unpack, hipStream_t st)
+{
+    const int nsel = P.npairs > pair0 ? (P.npairs - pair0 + pstride - 1) / pstride : 0;
+    if (nsel == 0) return;
+    hipLaunchKernelGGL(k_map_pack_rings, dim3(nsel, ncomp), dim3(256), 0, st, P, map, buf, pair0, pstride, map_pack_doubles(P, pair0, pstride), unpack ? 1 : 0);
 }
 void launch_alm_keep_mgroups(int lmax, double *alm, int mg0, int mgstride, int nb, hipStream_t st)
 {

@@ -108,6 +108,23 @@ def _all_to_all(send):
     return out.to(send.device) if staged else out
 
 
+def _all_gather(send, out):
+    """send: (n,) float64 tensor; out: (nranks, n), row s = rank s's send.  RCCL all_gather_into_tensor on device tensors; a CPU backend
+    (gloo in the tests) is staged through the host."""
+    dist = _dist()
+    if dist is None:
+        out[0].copy_(send)
+        return out
+    if send.is_cuda and dist.get_backend() != 'nccl':
+        rows = [torch.empty(send.shape, dtype=send.dtype) for _ in range(dist.get_world_size())]
+        dist.all_gather(rows, send.cpu())
+        for s, row in enumerate(rows):
+            out[s].copy_(row)
+        return out
+    dist.all_gather_into_tensor(out, send)
+    return out
+
+
 def _all_to_all_gloo(dist, out, src):
     """gloo has no all_to_all: one scatter per root (test backend only)"""
     rank, size = dist.get_rank(), dist.get_world_size()
@@ -128,9 +145,19 @@ class sharded_sht(object):
         from . import shts
         self.rank = mpi.rank if rank is None else rank
         self.size = mpi.size if size is None else size
+        # (without a process group _all_to_all / _all_gather would hand back the rank's own buffers: wrong maps, silently)
+        assert self.size == 1 or _dist() is not None, 'sharded_sht over %d ranks needs torch.distributed to be initialised' % self.size
         self.nside, self.lmax = nside, lmax
         self.plan = shts.get_shard_plan(nside, lmax, self.rank, self.size)
         self._mask = None
+        self._bufs = {}
+
+    def _buf(self, name, shape, device):
+        """exchange buffers, kept per shape (sizes depend on geometry, R and the number of components only)"""
+        b = self._bufs.get(name)
+        if b is None or tuple(b.shape) != tuple(shape) or b.device != device:
+            b = self._bufs[name] = torch.empty(shape, dtype=torch.float64, device=device)
+        return b
 
     def _exchange(self, phase, ncomp, synth):
         """synthesis: my m-groups of everybody's ring pairs go out, everybody's m-groups of my ring pairs come in; analysis: the reverse"""
@@ -138,14 +165,32 @@ class sharded_sht(object):
         L, h, R, r = _lib.lib(), self.plan.h, self.size, self.rank
         sel_out = (lambda s: (s, R, r, R)) if synth else (lambda s: (r, R, s, R))   # (pair0, pair_stride, mg0, mg_stride) sent to rank s
         sel_in = (lambda s: (r, R, s, R)) if synth else (lambda s: (s, R, r, R))    # ... received from rank s
-        n = max(int(L.pl_phase_pack_doubles(h, ncomp, *sel(s))) for s in range(R) for sel in (sel_out, sel_in))
-        n_all = allreduce_max(n)  # equal splits: the largest slice of any pair of ranks
-        send = torch.zeros((R, n_all), dtype=torch.float64, device=phase.device)
+        # equal splits: the largest slice of any pair of ranks is the one of ring pairs 0, R, ... and m-groups 0, R, ... (the counts
+        # ceil((n - start) / R) do not grow with the start) -- the same number on every rank, no collective needed to agree on it
+        n_all = int(L.pl_phase_pack_doubles(h, ncomp, 0, R, 0, R))
+        send = self._buf('send%d' % ncomp, (R, n_all), phase.device)  # (the tails past a slice are never read by the receiver)
         for s in range(R):
             _lib.check(L.pl_phase_pack(h, ncomp, phase.data_ptr(), send[s].data_ptr(), *sel_out(s), dev.stream_ptr()))
         recv = _all_to_all(send)
         for s in range(R):
             _lib.check(L.pl_phase_unpack(h, ncomp, phase.data_ptr(), recv[s].data_ptr(), *sel_in(s), dev.stream_ptr()))
+
+    def _gather_rings(self, m, ncomp):
+        """every rank's own ring pairs into every rank's map: one all-gather of 1 / R of the map per rank (pl_map_pack_rings), instead
+        of an all-reduce of R zero-padded maps (8 npix ncomp bytes per rank: 3.2 GB at nside 4096, spin 2)"""
+        from . import _lib, dev
+        L, h, R, r = _lib.lib(), self.plan.h, self.size, self.rank
+        if R == 1:
+            return m
+        per = [int(L.pl_map_pack_doubles(h, s, R)) for s in range(R)]
+        n_all = ncomp * max(per)
+        send = self._buf('gsend%d' % ncomp, (n_all,), m.device)
+        _lib.check(L.pl_map_pack_rings(h, ncomp, m.data_ptr(), send.data_ptr(), r, R, dev.stream_ptr()))
+        recv = _all_gather(send, self._buf('grecv%d' % ncomp, (R, n_all), m.device))
+        for s in range(R):
+            if s != r:
+                _lib.check(L.pl_map_unpack_rings(h, ncomp, m.data_ptr(), recv[s].data_ptr(), s, R, dev.stream_ptr()))
+        return m
 
     def own_pixels(self):
         """bool device tensor: the pixels of this rank's ring pairs"""
@@ -167,10 +212,12 @@ class sharded_sht(object):
         phase = torch.empty(self.plan.phase_doubles(spin), dtype=torch.float64, device=a.device)
         _lib.check(L.pl_legendre_synth(h, int(spin), a.data_ptr(), shts._ptr(f), phase.data_ptr(), dev.stream_ptr()))
         self._exchange(phase, ncomp, synth=True)
-        m = torch.zeros((ncomp, self.plan.npix) if ncomp == 2 else self.plan.npix, dtype=torch.float64, device=a.device)
+        shape = (ncomp, self.plan.npix) if ncomp == 2 else (self.plan.npix,)
+        # gather: every pixel is written, by this rank's ring FFTs or by the unpack of another rank's rings; else the others stay zero
+        m = (torch.empty if gather else torch.zeros)(shape, dtype=torch.float64, device=a.device)
         _lib.check(L.pl_phase2map(h, int(spin), phase.data_ptr(), m.data_ptr(), dev.stream_ptr()))
         if gather:
-            allreduce_sum(m)  # every pixel is non-zero on one rank only
+            self._gather_rings(m, ncomp)
         return m
 
     def map2alm(self, m, spin=0, fl=None):

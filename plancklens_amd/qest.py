@@ -213,7 +213,7 @@ class library(object):
         if pair is not None:
             todo = [i for i in idxs if not self._has(k_, i)]
             for a, b in zip(todo[0::2], todo[1::2]):
-                self._build_sim_MVgclm_pair(a, b)
+                pair(a, b)  # (evaluates and stores both simulations' gradient and curl entries)
         return [self.get_sim_qlm(k, i, lmax=lmax) for i in idxs]
 
     def get_dat_qlm(self, k, **kwargs):

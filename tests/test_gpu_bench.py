@@ -33,6 +33,10 @@ def test_bench_line_contract():
         assert k in c, k
     assert c['kind'] in ('reference', 'port') and c['value'] > 0 and c['cores'] >= 1
     assert d['ranks_seen'] == 1 and 'kernels' in d and 'leg_anals' in d['kernels']
+    assert len(d['ms_per_step_by_rank']) == 1 and 0 < d['ms_per_step_by_rank'][0] <= d['ms_per_step'] * 1.0001
+    f = d['from_sims']  # the same reconstructions with their inputs generated on the device inside the timed region
+    assert 'error' not in f, f
+    assert f['value'] > 0 and f['generation_ms_per_simulation'] > 0 and 0 < f['generation_share_of_step'] < 1
 
 
 def test_bench_under_launcher_with_rccl_collectives():
@@ -47,4 +51,4 @@ def test_bench_under_launcher_with_rccl_collectives():
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, PLENS_DIST_FORCE='1'))
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
-    assert d['n_gpus'] == 1 and d['ranks_seen'] == 1 and d['value'] > 0
+    assert d['n_gpus'] == 1 and d['ranks_seen'] == 1 and d['value'] > 0 and len(d['ms_per_step_by_rank']) == 1 and 'error' not in d['from_sims']

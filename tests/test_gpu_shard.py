@@ -107,3 +107,34 @@ def test_two_ranks_share_one_transform(tmp_path):
         assert int(got['rank']) == r and int(got['size']) == 2 and bool(got['own_ok'])
         for k, v in ref.items():
             assert relrms(got[k], v) < TOL, (r, k)
+
+
+@pytest.mark.parametrize('nside,R', [(1, 2), (4, 3), (16, 2), (64, 5), (512, 8)])
+def test_ring_pack_covers_the_map_once(nside, R):
+    """pl_map_pack_rings / pl_map_unpack_rings (the all-gather that completes a sharded synthesis): the packed buffers of the R ranks
+    have the announced sizes, together hold every pixel exactly once, and unpacking them rebuilds the map bit for bit (two components)."""
+    import torch
+    from plancklens_amd import _lib, dev, hp, shts
+    L = _lib.lib()
+    st = dev.stream_ptr()
+    lmax = 2 * nside
+    plan = shts.get_plan(nside, lmax)
+    npix = 12 * nside ** 2
+    rng = np.random.default_rng(nside + R)
+    ref = torch.from_numpy(rng.standard_normal((2, npix))).cuda()
+    out = torch.full((2, npix), float('nan'), dtype=torch.float64, device='cuda')
+    pair = np.minimum(hp.pix2ring(nside), 4 * nside - hp.pix2ring(nside)) - 1
+    total = 0
+    for r in range(R):
+        n = int(L.pl_map_pack_doubles(plan.h, r, R))
+        assert n == int((pair % R == r).sum()), (r, n)
+        total += n
+        buf = torch.full((2, max(n, 1)), float('nan'), dtype=torch.float64, device='cuda')
+        _lib.check(L.pl_map_pack_rings(plan.h, 2, ref.data_ptr(), buf.data_ptr(), r, R, st))
+        assert n == 0 or bool(torch.isfinite(buf[:, :n]).all())
+        # the packed values are this rank's pixels in ring order
+        own = torch.from_numpy(pair % R == r).cuda()
+        assert sorted(dev.to_host(buf[0, :n]).tolist()) == sorted(dev.to_host(ref[0][own]).tolist())
+        _lib.check(L.pl_map_unpack_rings(plan.h, 2, out.data_ptr(), buf.data_ptr(), r, R, st))
+    assert total == npix
+    assert bool((out == ref).all())
