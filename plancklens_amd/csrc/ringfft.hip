@@ -1045,6 +1045,287 @@ __global__ __launch_bounds__(N / 8, 2) void k_map2phase_fast(DevPlan P, DevFFT F
     }
 }
 
+// =====================================================================================================
+// "Quad" variants of the register-resident kernels: one workgroup of 4 G = N / 2 threads per ring pair and component, thread group
+// k2 = threadIdx / G owning sub-DFT k2 -- 8 points per thread instead of 4 x 8.  The four sub-DFTs of a ring then go through their
+// LDS exchanges at the same time (4 exchange buffers, 6 instead of 24 barrier pairs per ring), every gather or store round is
+// one set of 8 accesses per thread with four times as many threads in flight, and at ~100 registers a CU holds 16 waves instead of 8.
+// The radix-4 step on the pixel side (which needs all four sub-DFTs of a pixel) goes through the exchange buffers once more.
+// Same arithmetic per sub-DFT as k_phase2map_fast / k_map2phase_fast (fft8, fast_bin, the chirp / filter tables): N <= 2048
+// (N = 4096 would need 2048 threads and 256 KB of LDS).
+template <int N, bool BLUE, bool WGT = false, bool SPLIT = false>
+__global__ __launch_bounds__(N / 2) void k_phase2map_quad(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim,
+                                                          int ncomp, const double *__restrict__ phase, double *__restrict__ map,
+                                                          const double *__restrict__ wgt)
+{
+    extern __shared__ double2 lds_all[];
+    constexpr int G = N / 8;
+    const int k2 = threadIdx.x / G, tl0 = threadIdx.x % G;
+    double2 *lds = lds_all + k2 * N;
+    const int ip = pairs[blockIdx.x], comp = blockIdx.y;
+    const int n = P.nphi[ip], q = n >> 2;
+    constexpr bool blue = BLUE;
+    const int K = F.K2of[q];
+    const double2 *__restrict__ chirp = F.chirp + F.woff[q];
+    const double2 *__restrict__ filt = F.A.filt + F.A.coff[q];
+    const int ml = min(mlim[ip], P.mmax);
+    const bool shifted = P.phi0[ip] != 0.0;
+    const double inv_n = 1.0 / n;
+    constexpr int estride = 4;
+    const double *__restrict__ ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * estride;
+    Tw8<N> tw;
+    tw8_load<N>(tw, tl0, F.tw, F.Mtw);
+    double2 d[8];
+    {   // gather (see k_phase2map_fast): bins 4 k1 + k2 of this group's sub-DFT.  All eight loads of a thread are issued before the first
+        // one is used (one round trip to memory per ring instead of eight)
+        const int tl = fresh(tl0);
+        double4 f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
+            const int k = 4 * b.k1 + k2;
+            const int mm = b.sgn > 0 ? k : n - k;
+            const bool have = b.sgn != 0 && mm <= ml;
+            f[j] = *reinterpret_cast<const double4 *>(ph + (int64_t)(have ? mm : 0) * estride);  // out-of-band bins: entry 0, zeroed below
+        }
+        double2 pj = make_double2(1., 0.), pstep = pj, uneg = pj;
+        if (shifted) {
+            pj = cispi((4.0 * tl + k2) * inv_n); pstep = cispi(4.0 * G * inv_n);
+            uneg = cispi(4.0 * N * inv_n);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
+            double2 cw = make_double2(1., 0.);
+            if (blue) cw = chirp[b.cabs];
+            const int k = 4 * b.k1 + k2;
+            const int mm = b.sgn > 0 ? k : n - k;
+            const bool have = b.sgn != 0 && mm <= ml;
+            double2 fn = make_double2(f[j].x, f[j].y), fs = make_double2(f[j].z, f[j].w);
+            if (shifted) {
+                const double2 pm = b.sgn > 0 ? pj : cmulc(uneg, pj);
+                fn = cmul(fn, pm); fs = cmul(fs, pm);
+            }
+            double2 z;
+            z.x = have ? (b.sgn > 0 ? fn.x - fs.y : fn.x + fs.y) : 0.0;
+            z.y = have ? (b.sgn > 0 ? fn.y + fs.x : -fn.y + fs.x) : 0.0;
+            if (!blue && j == 4) {  // order n / 2 of a direct ring with mlim = n / 2 (see k_phase2map_fast)
+                const bool nyq = have && tl == 0 && k2 == 0;
+                z.x = nyq ? 2.0 * fn.x : z.x;
+                z.y = nyq ? 2.0 * fs.x : z.y;
+            }
+            d[j] = cmul(z, cw);
+            pj = cmul(pj, pstep);
+        }
+    }
+    if constexpr (SPLIT) {
+        fft8<N, true>(d, lds, tl0, tw);
+        double2 spec[8], half[4];
+        {
+            const int tl = fresh(tl0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { spec[j] = d[j]; d[j] = cmul(d[j], filt[tl + G * j]); }
+        }
+        fft8<N, false>(d, lds, tl0, tw);
+        {
+            const int tl = fresh(tl0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) half[j] = d[j];  // pixels j1 < N / 2
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = cmul(spec[j], filt[N + tl + G * j]);
+        }
+        fft8<N, false>(d, lds, tl0, tw);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { d[j + 4] = d[j]; d[j] = half[j]; }
+    } else if (blue) {
+        fft8<N, true>(d, lds, tl0, tw);
+        const int tl = fresh(tl0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = cmul(d[j], filt[tl + G * j]);
+        fft8<N, false>(d, lds, tl0, tw);
+    } else {
+        fft8<N, false>(d, lds, tl0, tw);
+    }
+    // pixel side: y_k2(j1) = d(j1) chirp e^{2 pi i j1 k2 / n} into the exchange buffers, then thread group g combines the four sub-DFTs
+    // for the pixels j1 = tl + G j, j = 2 g, 2 g + 1
+    const int tl = fresh(tl0);
+    {
+        double2 ek = cispi(2.0 * k2 * tl * inv_n);
+        const double2 estep = cispi(2.0 * k2 * G * inv_n);
+        __syncthreads();  // every group is done with its exchange buffer
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int j1 = tl + G * j;
+            double2 cw = ek;
+            if (blue) cw = cmul(ek, chirp[min(j1, q - 1)]);
+            lds_all[k2 * N + j1] = cmul(d[j], cw);
+            ek = cmul(ek, estep);
+        }
+        __syncthreads();
+    }
+    double *__restrict__ mp = map + (int64_t)comp * P.npix;
+    const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j1 = tl + G * (2 * k2 + u);
+        if (j1 < q) {
+            double2 y[4] = {lds_all[j1], lds_all[N + j1], lds_all[2 * N + j1], lds_all[3 * N + j1]};
+            dft_small<4, false>(y);  // y[j2] = sum_k2 i^(j2 k2) y_k2
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                if constexpr (WGT) {
+                    mp[on + j1 + q * j2] = y[j2].x * wgt[on + j1 + q * j2];
+                    if (os >= 0) mp[os + j1 + q * j2] = y[j2].y * wgt[os + j1 + q * j2];
+                } else {
+                    mp[on + j1 + q * j2] = y[j2].x;
+                    if (os >= 0) mp[os + j1 + q * j2] = y[j2].y;
+                }
+            }
+        }
+    }
+}
+
+template <int N, bool BLUE, bool SPLIT = false>
+__global__ __launch_bounds__(N / 2) void k_map2phase_quad(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim,
+                                                          int ncomp, const double *map, double *phase)
+{
+    extern __shared__ double2 lds_all[];
+    constexpr int G = N / 8;
+    const int k2 = threadIdx.x / G, tl0 = threadIdx.x % G;
+    double2 *lds = lds_all + k2 * N;
+    const int ip = pairs[blockIdx.x], comp = blockIdx.y;
+    const int n = P.nphi[ip], q = n >> 2;
+    constexpr bool blue = BLUE;
+    const int K = F.K2of[q];
+    const double2 *__restrict__ chirp = F.chirp + F.woff[q];
+    const double2 *__restrict__ filt = F.A.filt + F.A.coff[q];
+    const int ml = min(mlim[ip], P.mmax);
+    const bool shifted = P.phi0[ip] != 0.0;
+    const double inv_n = 1.0 / n;
+    constexpr int estride = 4;
+    double *ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * estride;
+    const double wgt = 0.5 * 4.0 * 3.14159265358979323846 / (double)P.npix;  // includes the 1/2 of the N/S split
+    const double *mp = map + (int64_t)comp * P.npix;
+    const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
+    const bool has_s = os >= 0;
+    Tw8<N> tw;
+    tw8_load<N>(tw, tl0, F.tw, F.Mtw);
+    {   // pixels in: thread group g loads the pixels j1 = tl + G j, j = 2 g, 2 g + 1 (all four j2, both rings), does the radix-4 step and
+        // hands y_k2(j1) e^{2 pi i j1 k2 / n} chirp to sub-DFT k2's buffer; slots beyond the ring are zero
+        const int tl = fresh(tl0);
+        const double *mps = has_s ? mp + os : mp + on;
+        double vn[2][4], vs[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {   // all sixteen loads first
+            const int j1c = min(tl + G * (2 * k2 + u), q - 1);
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) { vn[u][j2] = mp[on + j1c + q * j2]; vs[u][j2] = mps[j1c + q * j2]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j1 = tl + G * (2 * k2 + u);
+            const int j1c = min(j1, q - 1);
+            double2 y[4];
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                y[j2].x = j1 < q ? vn[u][j2] : 0.0;
+                y[j2].y = (j1 < q && has_s) ? -vs[u][j2] : 0.0;
+            }
+            dft_small<4, false>(y);  // y[k2] = sum_j2 i^(j2 k2) conj(z)_(j1 + q j2)
+            double2 cw = make_double2(1., 0.);
+            if (blue) cw = chirp[j1c];
+            const double2 e1 = cispi(2.0 * j1 * inv_n), e2 = cmul(e1, e1), e3 = cmul(e2, e1);
+            lds_all[j1] = cmul(y[0], cw);
+            lds_all[N + j1] = cmul(y[1], cmul(cw, e1));
+            lds_all[2 * N + j1] = cmul(y[2], cmul(cw, e2));
+            lds_all[3 * N + j1] = cmul(y[3], cmul(cw, e3));
+        }
+        __syncthreads();
+    }
+    double2 d[8];
+    {
+        const int tl = fresh(tl0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = lds[tl + G * j];
+    }
+    if constexpr (SPLIT) {
+        double2 hi[8] = {d[4], d[5], d[6], d[7], make_double2(0., 0.), make_double2(0., 0.), make_double2(0., 0.), make_double2(0., 0.)};
+#pragma unroll
+        for (int j = 4; j < 8; ++j) d[j] = make_double2(0., 0.);
+        fft8<N, true>(d, lds, tl0, tw);
+        phase_fence();
+        {
+            const int tl = fresh(tl0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = cmul(d[j], filt[(N - (tl + G * j)) & (N - 1)]);
+        }
+        fft8<N, true>(hi, lds, tl0, tw);
+        phase_fence();
+        {
+            const int tl = fresh(tl0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = cadd(d[j], cmul(hi[j], filt[N + ((N - (tl + G * j)) & (N - 1))]));
+        }
+        fft8<N, false>(d, lds, tl0, tw);
+        phase_fence();
+        {
+            const int tl = fresh(tl0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = cmul(d[j], chirp[fast_bin(blue, tl + G * j, N, q, K).cabs]);
+        }
+    } else if (blue) {
+        fft8<N, true>(d, lds, tl0, tw);
+        phase_fence();
+        {
+            const int tl = fresh(tl0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = cmul(d[j], filt[(N - (tl + G * j)) & (N - 1)]);  // spectrum of the mirrored filter
+        }
+        fft8<N, false>(d, lds, tl0, tw);
+        phase_fence();
+        {
+            const int tl = fresh(tl0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = cmul(d[j], chirp[fast_bin(blue, tl + G * j, N, q, K).cabs]);
+        }
+    } else {
+        fft8<N, false>(d, lds, tl0, tw);
+    }
+    // F_N, F_S of order m = 4 k1 + k2 need V_m (own) and V_(n - m), which lives in sub-DFT (4 - k2) mod 4: every group publishes its
+    // - side values (and bin 0) in its own buffer, indexed by k1, and reads its partner's
+    const int tl = fresh(tl0);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
+        if (b.sgn < 0 || (b.sgn > 0 && b.k1 == 0)) lds[swz(b.k1)] = d[j];
+    }
+    __syncthreads();
+    const double2 *other = lds_all + ((4 - k2) & 3) * N;
+    double2 pjj = make_double2(1., 0.), pstep = pjj;
+    if (shifted) { pjj = cispi((4.0 * tl + k2) * inv_n); pstep = cispi(4.0 * G * inv_n); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
+        const int m = 4 * b.k1 + k2;
+        const bool nyq = !blue && k2 == 0 && j == 4 && tl == 0;
+        if ((b.sgn > 0 || nyq) && m <= ml) {
+            const int k1m = k2 == 0 ? (b.k1 == 0 ? 0 : q - b.k1) : q - 1 - b.k1;
+            const double2 a = cconj(d[j]);
+            const double2 vm = other[swz(k1m)];
+            double2 fn = cadd(a, vm);
+            const double2 dd = csub(a, vm);
+            double2 fs = make_double2(dd.y, -dd.x);   // (conj(V_m) - V_(n-m)) / i
+            if (shifted) { fn = cmulc(fn, pjj); fs = cmulc(fs, pjj); }  // e^{-i pi m / n}
+            double4 o;
+            o.x = fn.x * wgt; o.y = fn.y * wgt;
+            o.z = has_s ? fs.x * wgt : 0.0; o.w = has_s ? fs.y * wgt : 0.0;
+            *reinterpret_cast<double4 *>(ph + (int64_t)m * estride) = o;
+        }
+        pjj = cmul(pjj, pstep);
+    }
+}
+
 // plan-time: natural-order spectrum (times 1/M) of the wrapped conjugate chirp h_d = e^{-i pi d^2 / q}, d in [-K, q-1+K],
 // K = K2of[q] (band-limited sub-DFT bins)
 template <int NT>
@@ -1229,6 +1510,46 @@ static hipError_t launch_map2phase_legacy(const DevPlan &P, const DevFFT &F, con
     PL_FFT_DISPATCH(launch_m2p, P, F, mlim, ncomp, map, phase, st, W);
 }
 
+// Which classes run in the quad kernels (one thread group per sub-DFT).  Measured per kernel at nside = lmax = 2048, two components
+// (tools/fft_kernel_stats.sh, profiles/round4_b_fft_kernel_stats.txt): N = 512 classes 2.0x faster, N = 1024 1.2-1.8x, N = 2048 analysis
+// of the direct rings 1.07x; the N = 2048 syntheses and Bluestein analyses are equal or slower (one 1024-thread workgroup per CU:
+// no second workgroup to overlap its memory phases with, and the per-thread phase-factor set-up is paid by four times the threads).
+// PLSHTS_FFT_QUAD: 0 = never, 2 = every class N <= 2048 (development).
+// In a synthesis stage of a grid that has N = 2048 classes the quad kernels of the small classes (512- and 1024-thread workgroups with
+// 64-128 KB of LDS) get in the way of the dominant one-group kernel running beside them (stage 0.66 -> 0.70 ms): syntheses use them
+// on grids up to nside 1024 only (the coarse and middle levels of the CG chains), analyses everywhere.
+template <int N, bool BLUE, bool SPLIT>
+static bool fft_quad_enabled(bool synth, int nside)
+{
+    static const int mode = getenv("PLSHTS_FFT_QUAD") ? atoi(getenv("PLSHTS_FFT_QUAD")) : 1;
+    if (mode == 0 || N < 512 || N > 2048) return false;
+    if (mode == 2) return true;
+    if (synth) return nside <= 1024 && N <= 1024;
+    return N <= 1024 || !BLUE;  // N = 2048: the analysis of the direct (equatorial) rings only
+}
+
+template <int N, bool BLUE, bool SPLIT>
+static hipError_t launch_quad_class(const DevPlan &P, const DevFFT &F, int n, const int *pairs, bool synth, const int *mlim, int ncomp, const double *in,
+                                    double *out, hipStream_t st, const double *wgt)
+{
+    constexpr int lds = 4 * N * (int)sizeof(double2);
+    if (lds > 48 * 1024) {
+        static bool attr_done[kMaxDevices] = {};
+        const int dv = current_device();
+        if (!attr_done[dv]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map_quad<N, BLUE, false, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map_quad<N, BLUE, true, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_map2phase_quad<N, BLUE, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return e;
+            attr_done[dv] = true;
+        }
+    }
+    if (synth && wgt) hipLaunchKernelGGL((k_phase2map_quad<N, BLUE, true, SPLIT>), dim3(n, ncomp), dim3(N / 2), lds, st, P, F, pairs, mlim, ncomp, in, out, wgt);
+    else if (synth) hipLaunchKernelGGL((k_phase2map_quad<N, BLUE, false, SPLIT>), dim3(n, ncomp), dim3(N / 2), lds, st, P, F, pairs, mlim, ncomp, in, out, wgt);
+    else hipLaunchKernelGGL((k_map2phase_quad<N, BLUE, SPLIT>), dim3(n, ncomp), dim3(N / 2), lds, st, P, F, pairs, mlim, ncomp, in, out);
+    return hipGetLastError();
+}
+
 template <int N, bool BLUE>
 static hipError_t launch_fast_class(const DevPlan &P, const DevFFT &F, int cls, bool synth, const int *mlim, int ncomp, const double *in,
                                     double *out, hipStream_t st, const double *wgt)
@@ -1237,6 +1558,9 @@ static hipError_t launch_fast_class(const DevPlan &P, const DevFFT &F, int cls, 
     const int n = BLUE ? sd.cls_n[cls] : sd.dir_n[cls];
     const int *pairs = BLUE ? sd.cls_pairs[cls] : sd.dir_pairs[cls];
     if (n == 0) return hipSuccess;
+    if constexpr (N <= 2048 && N >= 512) {
+        if (fft_quad_enabled<N, BLUE, false>(synth, P.nside)) return launch_quad_class<N, BLUE, false>(P, F, n, pairs, synth, mlim, ncomp, in, out, st, wgt);
+    }
     const size_t lds = (size_t)N * sizeof(double2);
     if (lds > 48 * 1024) {
         static bool attr_done[kMaxDevices] = {};
@@ -1285,6 +1609,9 @@ static hipError_t launch_split_class(const DevPlan &P, const DevFFT &F, int cls,
 {
     const int n = F.A.split_n[cls];
     if (n == 0) return hipSuccess;
+    if constexpr (N <= 2048 && N >= 512) {
+        if (fft_quad_enabled<N, true, true>(synth, P.nside)) return launch_quad_class<N, true, true>(P, F, n, F.A.split_pairs[cls], synth, mlim, ncomp, in, out, st, wgt);
+    }
     const size_t lds = (size_t)N * sizeof(double2) * (synth ? 2 : 1);  // synthesis: exchange buffer + the parked forward spectrum
     static bool attr_done[kMaxDevices] = {};
     const int dv = current_device();

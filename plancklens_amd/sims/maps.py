@@ -38,16 +38,25 @@ class cmb_maps(object):
     def _out(self, t):
         return t if self.device_maps else dev.to_host(t)
 
+    def _add_noise(self, m, noise):
+        """m + noise; a (scale, unit-variance device tensor) pair is added in place in one pass (device noise, see cmb_maps_nlev)"""
+        if isinstance(noise, tuple):
+            return m.add_(noise[1], alpha=float(noise[0]))
+        return m + dev.to_dev(noise)
+
     def get_sim_tmap(self, idx):
         tlm = dev.to_dev(self.sims_cmb_len.get_sim_tlm(idx))
         tmap = shts.alm2map(tlm, self.nside, fl=self.cl_transf_T)
-        return self._out(tmap + dev.to_dev(self.get_sim_tnoise(idx)))
+        return self._out(self._add_noise(tmap, self._noise_term(idx, 0)))
 
     def get_sim_pmap(self, idx):
         elm = dev.to_dev(self.sims_cmb_len.get_sim_elm(idx))
         blm = dev.to_dev(self.sims_cmb_len.get_sim_blm(idx))
         Q, U = shts.alm2map_spin([elm, blm], self.nside, 2, hp.Alm.getlmax(elm.numel()), fl=self.cl_transf_P)
-        return self._out(Q + dev.to_dev(self.get_sim_qnoise(idx))), self._out(U + dev.to_dev(self.get_sim_unoise(idx)))
+        return self._out(self._add_noise(Q, self._noise_term(idx, 1))), self._out(self._add_noise(U, self._noise_term(idx, 2)))
+
+    def _noise_term(self, idx, idf):
+        return (self.get_sim_tnoise, self.get_sim_qnoise, self.get_sim_unoise)[idf](idx)
 
     def get_sim_tnoise(self, idx):
         assert 0, 'subclass this'
@@ -95,6 +104,15 @@ class cmb_maps_nlev(cmb_maps):
 
     def _vamin(self):
         return np.sqrt(hp.nside2pixarea(self.nside, degrees=True)) * 60
+
+    def _noise_term(self, idx, idf):
+        """device phases: (scale, unit-variance tensor) for an in-place scaled add -- two passes over a map less than scaling the
+        noise and adding it out of place; host phases: the noise map"""
+        pha = self.pix_lib_phas.get_sim(idx, idf=idf)
+        scale = (self.nlev_t if idf == 0 else self.nlev_p) / self._vamin()
+        if isinstance(pha, np.ndarray):
+            return scale * pha
+        return (scale, pha)
 
     def get_sim_tnoise(self, idx):
         return self.nlev_t / self._vamin() * self.pix_lib_phas.get_sim(idx, idf=0)
