@@ -223,6 +223,12 @@ int pl_lowrank_update_b(int64_t n, int nmodes, int nb, const double *x, double *
 int pl_cg_fwd_tt_b(pl_plan *plan, int nb, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *pmat,
                    const double *rmat, double *scratch_dev, const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out,
                    void *stream);
+/* pl_cg_fwd_tt_b with plain weighting followed by the harmonic-space template projection alm_out -= hrm^t (hpm alm_in) (hpm, hrm:
+ * (nmodes, 2 nalm) real device matrices, pl_lowrank_update_b): one call, the coefficient pass on a side stream of the plan beside the
+ * transforms.  alm_out must not alias alm_in. */
+int pl_cg_fwd_tt_lr_b(pl_plan *plan, int nb, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *hpm,
+                      const double *hrm, double *scratch_dev, const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out,
+                      void *stream);
 int pl_cg_fwd_pp_b(pl_plan *plan, int nb, const double *elm_in, const double *blm_in, const double *fl_in, const double *n_inv,
                    const double *elm_add, const double *blm_add, const double *fl_add_e, const double *fl_add_b, double *elm_out,
                    double *blm_out, const double *fl_out, void *stream);

@@ -42,7 +42,7 @@ void launch_cg_fused(int nf, const int *lmax, int lmin, const double *const *a, 
 void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st,
                        const double *fl_hi = nullptr, int nb = 1);
 void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st,
-                             int nb = 1, double *t_apply = nullptr);
+                             int nb = 1, double *t_apply = nullptr, int phase = 0);
 void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st, int nb = 1);
 void launch_gemv(int nrows, int ncols, int64_t lda, const double *A, const double *x, double *y, hipStream_t st);
 void launch_gemv_nb(int nrows, int ncols, int64_t lda, const double *A, int nb, const double *x, double *y, hipStream_t st);
@@ -870,9 +870,11 @@ static bool cg_roundtrip_enabled()
     return on;
 }
 
+struct LowRank { int nmodes = 0; const double *pm = nullptr, *rm = nullptr; double *scratch = nullptr; };
+
 static int cg_fwd_tt_impl(pl_plan *p, int nb, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *pmat,
                           const double *rmat, double *scratch, const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out,
-                          void *stream, const double *pinv_md = nullptr)
+                          void *stream, const double *pinv_md = nullptr, const LowRank *lr = nullptr)
 {
     if (!p) return fail("null plan");
     if (!alm_in || !alm_out || !n_inv) return fail("pl_cg_fwd_tt: null alm / n_inv pointer");
@@ -883,6 +885,20 @@ static int cg_fwd_tt_impl(pl_plan *p, int nb, const double *alm_in, const double
     hipStream_t st = static_cast<hipStream_t>(stream);
     const DevPlan &P = p->P;
     if (grow(p, &p->phase, &p->phase_cap, pl_plan_phase_doubles(p, 0) * nb) || grow(p, &p->wmap, &p->wmap_cap, P.npix * nb)) return 1;
+    // low-rank template update of the result (lr): its coefficient pass c = pm x reads the input only, so it runs beside the transforms
+    // on a side stream of the plan (a parallel branch when the solve is replayed as a HIP graph) and leaves the critical path
+    bool lr_forked = false;
+    if (lr && lr->nmodes > 0) {
+        hipStream_t side = p->fs.ok ? p->fs.s[FftStreams::kN - 1] : nullptr;
+        if (side && hipEventRecord(p->fs.fork, st) == hipSuccess && hipStreamWaitEvent(side, p->fs.fork, 0) == hipSuccess) {
+            launch_template_project(2 * P.nalm, lr->nmodes, const_cast<double *>(alm_in), nullptr, lr->pm, lr->rm, lr->scratch, side, nb, alm_out, 1);
+            lr_forked = hipEventRecord(p->fs.join[FftStreams::kN - 1], side) == hipSuccess;
+            if (!lr_forked) return fail("pl_cg_fwd_tt_lr: event record on the side stream failed");
+        } else {
+            launch_template_project(2 * P.nalm, lr->nmodes, const_cast<double *>(alm_in), nullptr, lr->pm, lr->rm, lr->scratch, st, nb, alm_out, 1);
+        }
+        HIPCHK(hipGetLastError());
+    }
     if (legendre_synth_impl(p, 0, alm_in, fl_in, p->phase, stream, false, nb)) return 1;
     // the weighting always rides in the synthesis-side FFT kernels; the projection too where every ring runs in the generic kernel
     const bool fused = nmodes == 0 || (!pinv_md && fft_all_generic(P, p->F) && nmodes <= kFuseModes);
@@ -916,7 +932,25 @@ static int cg_fwd_tt_impl(pl_plan *p, int nb, const double *alm_in, const double
     if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * P.nent0 * 4 * nb)) return 1;
     { ProfScope ps(p, PK_LEG_ANAL0, st); launch_anal0(P, p->phase, p->partial, fl_out, alm_out, st, alm_add, fl_add, nb); }
     HIPCHK(hipGetLastError());
+    if (lr && lr->nmodes > 0) {  // alm_out -= rm^t c
+        if (lr_forked) HIPCHK(hipStreamWaitEvent(st, p->fs.join[FftStreams::kN - 1], 0));
+        launch_template_project(2 * P.nalm, lr->nmodes, const_cast<double *>(alm_in), nullptr, lr->pm, lr->rm, lr->scratch, st, nb, alm_out, 2);
+        HIPCHK(hipGetLastError());
+    }
     return 0;
+}
+
+// pl_cg_fwd_tt_b with plain N^-1 weighting, followed by the low-rank update alm_out -= hrm^t (hpm alm_in) (the template projection in
+// harmonic space, pl_lowrank_update_b) whose coefficient pass overlaps the transforms.  Same results as the two separate calls.
+int pl_cg_fwd_tt_lr_b(pl_plan *p, int nb, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *hpm, const double *hrm,
+                      double *scratch, const double *alm_add, const double *fl_add, double *alm_out, const double *fl_out, void *stream)
+{
+    PL_NB_CHECK("pl_cg_fwd_tt_lr_b");
+    if (nmodes < 1 || nmodes > PL_TEMPLATE_MAX_MODES || !hpm || !hrm || !scratch) return fail("pl_cg_fwd_tt_lr_b: bad low-rank arguments");
+    if (alm_out == alm_in) return fail("pl_cg_fwd_tt_lr_b: alm_out must not alias alm_in");
+    LowRank lr;
+    lr.nmodes = nmodes; lr.pm = hpm; lr.rm = hrm; lr.scratch = scratch;
+    return cg_fwd_tt_impl(p, nb, alm_in, fl_in, n_inv, 0, nullptr, nullptr, nullptr, alm_add, fl_add, alm_out, fl_out, stream, nullptr, &lr);
 }
 
 int pl_cg_fwd_tt(pl_plan *p, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *pmat, const double *rmat,

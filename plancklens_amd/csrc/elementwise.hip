@@ -894,33 +894,36 @@ void launch_cg_fused(int nf, const int *lmax, int lmin, const double *const *a, 
 }
 // t_apply (optional): the projection is subtracted from this vector instead of t, which is then only read (n_inv null) -- the
 // rank-nmodes update y -= rm^t (pm x) of launch_lowrank_update
+// phase: 0 both launches on st; 1 the coefficient pass only; 2 the subtraction only (the two halves of a low-rank update whose
+// coefficient pass runs beside the transforms on another stream, pl_cg_fwd_tt_lr_b)
 void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st,
-                             int nb, double *t_apply)
+                             int nb, double *t_apply, int phase)
 {
     double *ta = t_apply ? t_apply : t;
+    const bool do_c = phase != 2, do_a = phase != 1;
     if (nb > 1 && nmodes <= kFuseModesB) {  // block vectors: the template rows read once per chunk of kProjChunk maps
         const int nchunk = (nb + kProjChunk - 1) / kProjChunk;
         if (n >= (int64_t)kProjParts * 4096) {
-            hipLaunchKernelGGL(k_tproj_coeffs_b<1024>, dim3(kProjParts, nchunk), dim3(1024), 0, st, n, nmodes, nb, t, n_inv, pm, parts);
-            hipLaunchKernelGGL(k_tproj_apply_b, dim3(nblocks(n), nchunk), dim3(256), 0, st, n, nmodes, kProjParts, nb, ta, rm, parts);
+            if (do_c) hipLaunchKernelGGL(k_tproj_coeffs_b<1024>, dim3(kProjParts, nchunk), dim3(1024), 0, st, n, nmodes, nb, t, n_inv, pm, parts);
+            if (do_a) hipLaunchKernelGGL(k_tproj_apply_b, dim3(nblocks(n), nchunk), dim3(256), 0, st, n, nmodes, kProjParts, nb, ta, rm, parts);
         } else {
             int nparts = (int)((n + 511) / 512);  // two entries per thread: the coefficient pass of a coarse grid is a latency chain of its loads
             if (nparts < 1) nparts = 1;
             if (nparts > kProjParts) nparts = kProjParts;
-            hipLaunchKernelGGL(k_tproj_coeffs_b<256>, dim3(nparts, nchunk), dim3(256), 0, st, n, nmodes, nb, t, n_inv, pm, parts);
-            hipLaunchKernelGGL(k_tproj_apply_b, dim3(nblocks(n), nchunk), dim3(256), 0, st, n, nmodes, nparts, nb, ta, rm, parts);
+            if (do_c) hipLaunchKernelGGL(k_tproj_coeffs_b<256>, dim3(nparts, nchunk), dim3(256), 0, st, n, nmodes, nb, t, n_inv, pm, parts);
+            if (do_a) hipLaunchKernelGGL(k_tproj_apply_b, dim3(nblocks(n), nchunk), dim3(256), 0, st, n, nmodes, nparts, nb, ta, rm, parts);
         }
         return;
     }
     if (n >= (int64_t)kProjParts * 4096) {  // fine grids: 256 workgroups of 1024 threads
-        hipLaunchKernelGGL(k_tproj_coeffs<1024>, dim3(kProjParts, nb), dim3(1024), 0, st, n, nmodes, t, n_inv, pm, parts);
-        hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n), nb), dim3(256), 0, st, n, nmodes, kProjParts, ta, rm, parts);
+        if (do_c) hipLaunchKernelGGL(k_tproj_coeffs<1024>, dim3(kProjParts, nb), dim3(1024), 0, st, n, nmodes, t, n_inv, pm, parts);
+        if (do_a) hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n), nb), dim3(256), 0, st, n, nmodes, kProjParts, ta, rm, parts);
     } else {  // coarse grids: workgroups of 256 threads
         int nparts = (int)((n + 511) / 512);  // two entries per thread: the coefficient pass of a coarse grid is a latency chain of its loads
         if (nparts < 1) nparts = 1;
         if (nparts > kProjParts) nparts = kProjParts;
-        hipLaunchKernelGGL(k_tproj_coeffs<256>, dim3(nparts, nb), dim3(256), 0, st, n, nmodes, t, n_inv, pm, parts);
-        hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n), nb), dim3(256), 0, st, n, nmodes, nparts, ta, rm, parts);
+        if (do_c) hipLaunchKernelGGL(k_tproj_coeffs<256>, dim3(nparts, nb), dim3(256), 0, st, n, nmodes, t, n_inv, pm, parts);
+        if (do_a) hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n), nb), dim3(256), 0, st, n, nmodes, nparts, ta, rm, parts);
     }
 }
 // scratch: nb x 4 x npairs partial sums followed by nb x 4 coefficients

@@ -316,8 +316,7 @@ class alm_filter_ninv(object):
             if len(self.templates_t) != 0 and os.environ.get('PLENS_TPROJ_HARM', '1') != '0':
                 # the temperature templates as a rank-nmodes update in harmonic space, as in opfilt_tt (pl_lowrank_update_b)
                 hpm, hrm = self._harm_matrices(lmax)
-                ttlm = shts.cg_fwd_tt(alm.tlm, self.nside, lmax, self.n_inv[0], fl_in=self.b_transf_t, fl_out=self.b_transf_t * fac)
-                dev.lowrank_update(ttlm, alm.tlm.to(torch.complex128).contiguous(), hpm, hrm)
+                ttlm = shts.cg_fwd_tt(alm.tlm, self.nside, lmax, self.n_inv[0], fl_in=self.b_transf_t, fl_out=self.b_transf_t * fac, lowrank=(hpm, hrm))
             elif md:  # monopole + dipole evaluated from the ring geometry (pl_cg_fwd_tt_md_b), as in opfilt_tt
                 if getattr(self, '_pinv_md_dev', None) is None:
                     self._pinv_md_dev = dev.to_dev(np.ascontiguousarray(self.Pt_Nn1_P_inv), torch.float64).contiguous()

@@ -219,6 +219,9 @@ class alm_filter_ninv(object):
                 # the projection in harmonic space: the transforms carry the plain N^-1 weighting (inside the ring-FFT launches),
                 # the templates are a rank-nmodes update of the result (pl_lowrank_update_b)
                 hpm, hrm = self._harm_matrices(lmax)
+                if hpm.shape[0] <= dev.TEMPLATE_MAX_MODES:  # one call: the coefficient pass of the update runs beside the transforms
+                    return shts.cg_fwd_tt(alm, self.nside, lmax, self.n_inv, fl_in=self.b_transf, fl_out=fl_out, alm_add=alm_add, fl_add=fl_add,
+                                          lowrank=(hpm, hrm))
                 ret = shts.cg_fwd_tt(alm, self.nside, lmax, self.n_inv, fl_in=self.b_transf, fl_out=fl_out, alm_add=alm_add, fl_add=fl_add)
                 return dev.lowrank_update(ret, alm.to(torch.complex128).contiguous(), hpm, hrm)
             if self._md_only() and not shts.plan_all_generic(self.nside, lmax):

@@ -309,9 +309,11 @@ def plan_all_generic(nside, lmax):
     return bool(_lib.lib().pl_plan_fft_all_generic(get_plan(nside, lmax).h))
 
 
-def cg_fwd_tt(alm, nside, lmax, n_inv, fl_in=None, fl_out=None, pmat=None, rmat=None, scratch=None, alm_add=None, fl_add=None, pinv_md=None):
+def cg_fwd_tt(alm, nside, lmax, n_inv, fl_in=None, fl_out=None, pmat=None, rmat=None, scratch=None, alm_add=None, fl_add=None, pinv_md=None, lowrank=None):
     """fl_out Y^t [N^-1 - N^-1 P (P^t N^-1 P)^-1 P^t N^-1] Y (fl_in alm) + fl_add alm_add on the device, one call (pl_cg_fwd_tt):
-    fwd_op.calc of plancklens/qcinv/opfilt_tt.py:67-73.  pmat, rmat: (nmodes, npix) device matrices or None."""
+    fwd_op.calc of plancklens/qcinv/opfilt_tt.py:67-73.  pmat, rmat: (nmodes, npix) device matrices or None.
+    lowrank = (hpm, hrm): plain weighting in pixel space and the template projection as the rank-nmodes update result -= hrm^t (hpm alm)
+    in the same call (pl_cg_fwd_tt_lr_b; hpm, hrm: (nmodes, 2 nalm) real device matrices)."""
     plan = get_plan(nside, lmax)
     a = alm.to(torch.complex128).contiguous()
     nb = a.shape[0] if a.dim() == 2 else 1  # a block [nb, nalm]: nb right-hand sides through every launch (pl_cg_fwd_tt_b)
@@ -330,7 +332,14 @@ def cg_fwd_tt(alm, nside, lmax, n_inv, fl_in=None, fl_out=None, pmat=None, rmat=
     if alm_add is not None:
         alm_add = alm_add.contiguous()
         assert alm_add.shape == a.shape and alm_add.dtype == torch.complex128
-    if pinv_md is not None:
+    if lowrank is not None:
+        hpm, hrm = lowrank
+        assert pmat is None and pinv_md is None and hpm.shape == hrm.shape and hpm.shape[1] == 2 * plan.nalm and hpm.is_contiguous() and hrm.is_contiguous()
+        assert hpm.dtype == torch.float64 and hrm.dtype == torch.float64
+        from . import dev as _dev
+        _lib.check(_lib.lib().pl_cg_fwd_tt_lr_b(plan.h, nb, _ptr(a), _ptr(fi), _ptr(n_inv), int(hpm.shape[0]), _ptr(hpm), _ptr(hrm), _ptr(_dev.tproj_scratch(nb)),
+                                                _ptr(alm_add), _ptr(fa), _ptr(out), _ptr(fo), _stream()))
+    elif pinv_md is not None:
         _lib.check(_lib.lib().pl_cg_fwd_tt_md_b(plan.h, nb, _ptr(a), _ptr(fi), _ptr(n_inv), _ptr(pinv_md), _ptr(scratch), _ptr(alm_add), _ptr(fa),
                                                 _ptr(out), _ptr(fo), _stream()))
     elif a.dim() == 2:

@@ -188,8 +188,29 @@ def _run(nside, lmax, iters, kinds, joint, verbose, peak_tflops, batches=()):
                                     'speedup_vs_one_after_the_other': (res['t']['seconds'] + res['p']['seconds']) / dtc}
             if nside == 2048 and lmax == 2048:
                 res['tp_concurrent']['frac_of_fp64_floor'] = (FLOP_PER_ITER_2048['t'] + FLOP_PER_ITER_2048['p']) / peak_tflops / 1e12 / (dtc / iters)
+            # block solves of B simulations, T block and P block at the same time (what filter_sims runs with its default batch)
+            for B in batches:
+                if B <= 1:
+                    continue
+                gen = torch.Generator(device='cuda')
+                gen.manual_seed(200 + B)
+                tm = [dmaps_of['t']] + [dmaps_of['t'] + torch.randn(dmaps_of['t'].shape, generator=gen, dtype=torch.float64, device='cuda') * (nlev_t / vamin)
+                                        for _ in range(B - 1)]
+                pm = [dmaps_of['p']] + [[c + torch.randn(c.shape, generator=gen, dtype=torch.float64, device='cuda') * (nlev_p / vamin) for c in dmaps_of['p']]
+                                        for _ in range(B - 1)]
+                filt_cinv.apply_ivf_tp(ft, tm, fp, pm)  # contexts / graphs of this block shape
+                torch.cuda.synchronize()
+                t0 = time.time()
+                filt_cinv.apply_ivf_tp(ft, tm, fp, pm)
+                torch.cuda.synchronize()
+                dtb = time.time() - t0
+                e = {'seconds': dtb, 'iters_per_s_per_sim': B * iters / dtb}
+                if nside == 2048 and lmax == 2048:
+                    e['frac_of_fp64_floor'] = (FLOP_PER_ITER_2048['t'] + FLOP_PER_ITER_2048['p']) / peak_tflops / 1e12 / (dtb / iters / B)
+                res['tp_concurrent'].setdefault('block_solves', {})[str(B)] = e
+                del tm, pm
         except Exception as e:  # the sequential figures stand on their own
-            res['tp_concurrent'] = {'error': repr(e)}
+            res['tp_concurrent'] = dict(res.get('tp_concurrent', {}), error=repr(e))
         if verbose:
             print('tp_concurrent', json.dumps(res['tp_concurrent']), flush=True)
     if 't' in res and 'p' in res:
