@@ -44,7 +44,17 @@ def main():
             jobs += [(idx, lab) for idx in range(args.imin, args.imax + 1)]
             if args.ds and args.imin >= 0:
                 jobs += [(-1, lab)]
-    mine = jobs[mpi.rank::mpi.size]
+    if args.ivt and args.ivp and hasattr(par.ivfs, 'filter_sims'):
+        # both filters of a simulation on the same rank (the reference shards the (simulation, field) jobs, run_qlms.py:57): the
+        # conjugate-gradient library then runs the temperature and polarization solves of a block at the same time on two streams
+        sims_all = sorted(set(idx for idx, _ in jobs))
+        mine = [(idx, lab) for idx in sims_all[mpi.rank::mpi.size] for lab in ('t', 'p')]
+        idxs = sims_all[mpi.rank::mpi.size]
+        if idxs and par.ivfs.filter_sims(idxs, fields='tp'):
+            print('rank %s filtered sims %s (t and p) in overlapped block solves' % (mpi.rank, idxs))
+            mine = []
+    else:
+        mine = jobs[mpi.rank::mpi.size]
     if hasattr(par.ivfs, 'filter_sims'):  # conjugate-gradient filters: this rank's simulations in block solves (several per solve)
         for lab in ('t', 'p'):
             idxs = [idx for idx, l in mine if l == lab]
