@@ -135,7 +135,7 @@ def test_run_qlms_masked_sky_cg_filters(tmp_path):
     out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     log = out.stdout.decode()
     assert out.returncode == 0, log[-3000:]
-    assert 'filtered sims [0, 1, 2] t in block solves' in log and 'filtered sims [0, 1, 2] p in block solves' in log, log[-3000:]
+    assert 'filtered sims [0, 1, 2] (t and p) in overlapped block solves' in log, log[-3000:]  # both fields of a simulation on one rank
     temp = os.path.join(str(tmp_path), 'temp', 'anisofilt_example')
     for f in ['ivfs/sim_0000_tlm.fits', 'ivfs/sim_0002_elm.fits', 'ivfs/sim_0001_blm.fits', 'cinv_t/dense.pk', 'cinv_p/dense.pk', 'cinv_t/ftl.dat',
               'qlms_dd/sim_p_0002.fits', 'qlms_dd/sim_x_0000.fits']:
@@ -150,6 +150,9 @@ def test_run_qlms_masked_sky_cg_filters(tmp_path):
         blk = hp.read_alm(os.path.join(temp, 'ivfs', 'sim_0001_tlm.fits'))
         one = par.cinv_t.apply_ivf(par.sims.get_sim_tmap(1))
         assert np.abs(blk).max() > 0 and np.abs(np.asarray(one) - blk).max() < 1e-10 * np.abs(blk).max()
+        eblk = hp.read_alm(os.path.join(temp, 'ivfs', 'sim_0002_elm.fits'))
+        eone, _ = par.cinv_p.apply_ivf(par.sims.get_sim_pmap(2))
+        assert np.abs(eblk).max() > 0 and np.abs(np.asarray(eone) - eblk).max() < 1e-10 * np.abs(eblk).max()
         qlm = hp.read_alm(os.path.join(temp, 'qlms_dd', 'sim_p_0001.fits'))
         assert hp.Alm.getlmax(qlm.size) == 2048 and np.all(np.isfinite(qlm.real)) and np.abs(qlm).max() > 0
     finally:
