@@ -288,6 +288,9 @@ class library(object):
         def get_pair(idx0, idx1):
             if self._has(k, idx0) or self._has(k, idx1):
                 return self._get_sim_qlm_dev(k, idx0, lmax), self._get_sim_qlm_dev(k, idx1, lmax)
+            sim_lib = getattr(self.f2map1.ivfs, 'sim_lib', None)
+            if fam[0] != 'ptt' and hasattr(sim_lib, 'hint_pair'):
+                sim_lib.hint_pair(idx0, idx1)  # simulation libraries that make their maps on the device pair the sky syntheses too
             (r0, r1) = build(idx0, idx1)
             return r0[which], r1[which]
         return get_pair

@@ -50,10 +50,30 @@ class cmb_maps(object):
         return self._out(self._add_noise(tmap, self._noise_term(idx, 0)))
 
     def get_sim_pmap(self, idx):
-        elm = dev.to_dev(self.sims_cmb_len.get_sim_elm(idx))
-        blm = dev.to_dev(self.sims_cmb_len.get_sim_blm(idx))
-        Q, U = shts.alm2map_spin([elm, blm], self.nside, 2, hp.Alm.getlmax(elm.numel()), fl=self.cl_transf_P)
+        held = self.__dict__.get('_pair_held')
+        if held is not None and held[0] == idx:  # made together with the previous simulation (hint_pair)
+            self._pair_held = None
+            Q, U = held[1]
+        else:
+            elm = dev.to_dev(self.sims_cmb_len.get_sim_elm(idx))
+            blm = dev.to_dev(self.sims_cmb_len.get_sim_blm(idx))
+            lmax = hp.Alm.getlmax(elm.numel())
+            nxt = self.__dict__.get('_pair_next')
+            self._pair_next = None
+            if nxt is not None and nxt[0] == idx and self.device_maps:
+                # the sky of the announced next simulation on the same Legendre recursion (pl_alm2map_batch2: bit-identical maps)
+                e2, b2 = dev.to_dev(self.sims_cmb_len.get_sim_elm(nxt[1])), dev.to_dev(self.sims_cmb_len.get_sim_blm(nxt[1]))
+                (Q, U), (Q2, U2) = shts.alm2map_spin_batch2([elm, blm], [e2, b2], self.nside, 2, lmax, fl=self.cl_transf_P)
+                self._pair_held = (nxt[1], (Q2, U2))
+            else:
+                Q, U = shts.alm2map_spin([elm, blm], self.nside, 2, lmax, fl=self.cl_transf_P)
         return self._out(self._add_noise(Q, self._noise_term(idx, 1))), self._out(self._add_noise(U, self._noise_term(idx, 2)))
+
+    def hint_pair(self, idx0, idx1):
+        """The caller is about to ask for the polarization maps of idx0 and then idx1 (a mean-field loop serving simulations in
+        pairs): with device maps the two sky syntheses then share one Legendre recursion.  A hint only: any other order of calls
+        gives the same maps one by one."""
+        self._pair_next = (idx0, idx1)
 
     def _noise_term(self, idx, idf):
         return (self.get_sim_tnoise, self.get_sim_qnoise, self.get_sim_unoise)[idf](idx)

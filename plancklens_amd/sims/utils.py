@@ -20,6 +20,11 @@ class sim_lib_shuffle(object):
     def get_sim_pmap(self, idx):
         return self.sim_lib.get_sim_pmap(int(self._shuffle[idx]))
 
+    def hint_pair(self, idx0, idx1):
+        """forwarded (see sims.maps.cmb_maps.hint_pair)"""
+        if hasattr(self.sim_lib, 'hint_pair'):
+            self.sim_lib.hint_pair(int(self._shuffle[idx0]), int(self._shuffle[idx1]))
+
 
 class _sim_lib_add(object):
     """Weighted sum of the maps of several libraries for the indices `self._adds(idx)` selects; the first library alone

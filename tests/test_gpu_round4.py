@@ -163,3 +163,35 @@ def test_cinv_t_and_cinv_p_vs_the_reference_classes(tmp_path, oracle):
     with open(os.path.join(os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(HERE)), 'gpurun_out', 'cinv_reference_parity.txt'), 'w') as f:
         f.write('\n'.join(report) + '\n')
     print('\n'.join(report))
+
+
+def test_paired_sky_synthesis_of_device_simulations(tmp_path):
+    """sims.maps.cmb_maps.hint_pair: the polarization maps of two announced simulations come out of one batched synthesis
+    (pl_alm2map_batch2) and equal the maps made one by one bit for bit; the hint is forwarded through sim_lib_shuffle, and a request
+    in any other order still gives the right maps."""
+    import torch
+    from plancklens_amd import hp, utils
+    from plancklens_amd.sims import cmbs, maps, phas, utils as sutils
+    nside, lmax = 64, 128
+    cl = utils.camb_clfile(os.path.join(os.path.dirname(HERE), 'plancklens_amd', 'data', 'cls', 'FFP10_wdipole_lensedCls.dat'), lmax=lmax)
+    transf = hp.gauss_beam(20. / 60. / 180. * np.pi, lmax=lmax)
+
+    def lib(tag):
+        pix = phas.pix_lib_phas_dev(str(tmp_path / ('pix' + tag)), 3, (hp.nside2npix(nside),), seed=3)
+        sky = phas.lib_phas_dev(str(tmp_path / ('sky' + tag)), 3, lmax, seed=4)
+        skies = cmbs.sims_cmb_unl({k: cl[k] for k in ['tt', 'ee', 'bb', 'te']}, sky)
+        return maps.cmb_maps_nlev(skies, transf, 30., 40., nside, pix_lib_phas=pix, device_maps=True)
+    ref, a = lib('a'), lib('b')
+    sh = sutils.sim_lib_shuffle(a, {0: 0, 1: 1, 2: 2, 3: 3})
+    sh.hint_pair(0, 1)
+    q0, u0 = sh.get_sim_pmap(0)
+    assert a.__dict__.get('_pair_held') is not None and a._pair_held[0] == 1
+    q1, u1 = sh.get_sim_pmap(1)
+    assert a._pair_held is None
+    for i, (q, u) in enumerate(((q0, u0), (q1, u1))):
+        rq, ru = ref.get_sim_pmap(i)
+        assert isinstance(q, torch.Tensor) and bool((q == rq).all()) and bool((u == ru).all()), i
+    sh.hint_pair(2, 3)      # the hint is not followed: 3 first
+    q3, u3 = sh.get_sim_pmap(3)
+    q2, u2 = sh.get_sim_pmap(2)
+    assert bool((q3 == ref.get_sim_pmap(3)[0]).all()) and bool((u2 == ref.get_sim_pmap(2)[1]).all())
