@@ -256,6 +256,12 @@ int pl_gemv_b(int nrows, int ncols, int64_t lda, const double *A, int nb, const 
  * low-l preconditioner of the CG chains applied as one mat-vec (dense.py:118-119,201-202,284-285), and the template
  * coefficient products of the joint filter.  One wavefront per row, fixed summation tree (bit-reproducible). */
 int pl_gemv(int nrows, int ncols, int64_t lda, const double *A, const double *x, double *y, void *stream);
+/* pre_op_split (multigrid.py:163-182) with the dense block below lmax_lo and a diagonal preconditioner above it, one launch, for nf = 1
+ * (temperature) or 2 (E, B) fields given as arrays of nf pointers: alm_out[f] (band-limit lmax_hi) = [rows of field f of A x, x = the entries
+ * l <= lmax_lo of [alm_hi[0] | alm_hi[1]] | fl_hi[f][l] alm_hi[f] above]; A: pre_op_dense's matrix on the interleaved (re, im) view of the lmax_lo
+ * layout(s), map_dev: nalm(lmax_lo) int32 positions of those entries in the lmax_hi layout.  Bit-identical to pl_alm_copy + pl_gemv + pl_alm_splice_fl. */
+int pl_gemv_split(int nf, int lmax_lo, int lmax_hi, int64_t lda, const double *A, const double *const *alm_hi, const int *map_dev,
+                  const double *const *fl_hi, double *const *alm_out, void *stream);
 
 /* Copy of ndoubles doubles from device memory to `dst` -- device memory or pinned (device-mapped) host memory -- by a kernel of
  * `nblocks` workgroups on `stream` (16-byte aligned pointers).  Used for the estimator outputs (the reference writes them

@@ -45,6 +45,8 @@ void launch_template_project(int64_t n, int nmodes, double *t, const double *n_i
                              int nb = 1, double *t_apply = nullptr, int phase = 0);
 void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st, int nb = 1);
 void launch_gemv(int nrows, int ncols, int64_t lda, const double *A, const double *x, double *y, hipStream_t st);
+void launch_gemv_split(int nf, int64_t lda, const double *A, const double *const *hi, const int *map, int lmax_lo, int lmax_hi, const double *const *fl_hi,
+                       double *const *out, hipStream_t st);
 void launch_gemv_nb(int nrows, int ncols, int64_t lda, const double *A, int nb, const double *x, double *y, hipStream_t st);
 void launch_copy_slim(const double *src, double *dst, int64_t ndoubles, int nblocks, hipStream_t st);
 void launch_map_mul(int64_t n, const double *a, const double *b, double *out, hipStream_t st);
@@ -1104,6 +1106,25 @@ int pl_gemv(int nrows, int ncols, int64_t lda, const double *A, const double *x,
     if (nrows < 0 || ncols < 0 || lda < ncols || !A || !x || !y) return fail("pl_gemv: bad arguments");
     if (nrows == 0) return 0;
     launch_gemv(nrows, ncols, lda, A, x, y, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// pre_op_split with a dense low block and a diagonal high part as one launch (k_gemv_split), nf = 1 (temperature) or 2 (E, B) fields:
+// alm_out[f] (lmax_hi) = [rows of field f of A ([alm_hi[0] | alm_hi[1]] truncated to lmax_lo) | fl_hi[f] alm_hi[f] above lmax_lo].  A: the
+// (nf 2 nalm_lo)^2 flat matrix of pre_op_dense (row stride lda, 16-byte aligned); map_dev: nalm_lo int32 indices of the lmax_lo entries in the
+// lmax_hi layout.  No alm_out may alias an alm_hi.
+int pl_gemv_split(int nf, int lmax_lo, int lmax_hi, int64_t lda, const double *A, const double *const *alm_hi, const int *map_dev, const double *const *fl_hi,
+                  double *const *alm_out, void *stream)
+{
+    if (nf < 1 || nf > 2 || lmax_lo < 0 || lmax_hi <= lmax_lo || !A || !alm_hi || !map_dev || !fl_hi || !alm_out) return fail("pl_gemv_split: bad arguments");
+    for (int f = 0; f < nf; ++f) {
+        if (!alm_hi[f] || !fl_hi[f] || !alm_out[f]) return fail("pl_gemv_split: null field pointer");
+        for (int g = 0; g < nf; ++g) if (alm_out[f] == alm_hi[g]) return fail("pl_gemv_split: output aliases an input");
+    }
+    const int nrows = nf * (lmax_lo + 1) * (lmax_lo + 2);
+    if (lda < nrows || (lda & 1) || (reinterpret_cast<uintptr_t>(A) & 15)) return fail("pl_gemv_split: the matrix must be 16-byte aligned with an even row stride");
+    launch_gemv_split(nf, lda, A, alm_hi, map_dev, lmax_lo, lmax_hi, fl_hi, alm_out, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -660,6 +660,76 @@ __global__ __launch_bounds__(256) void k_gemv(int nrows, int ncols, int64_t lda,
     if (lane == 0) y[row] = v;
 }
 
+// pre_op_split around the dense block in ONE launch (multigrid.py:163-182 with dense.py:118-119): out (band-limit lmax_hi) =
+//   [l <= lmax_lo:  A x_lo,  x_lo = the entries l <= lmax_lo of hi (the truncating alm_copy, read in place through `map`)]
+//   [l  > lmax_lo:  fl_hi[l] hi]                                                  (the diagonal preconditioner, the splice)
+// A acts on the interleaved (re, im) view of the lmax_lo alm layout (pre_op_dense's flat matrix); map[e] = index in the lmax_hi layout
+// of entry e of the lmax_lo layout.  Workgroups [0, ngemv) are those of k_gemv<2> -- same lane partition, chains and tree, so the low
+// part is bit-identical to alm_copy + k_gemv<2> + k_alm_splice -- the others write the high part.
+struct SplitFields { const double2 *hi[2]; double2 *out[2]; const double *fl[2]; };
+template <int NF>
+__global__ __launch_bounds__(256) void k_gemv_split(int nrows, int64_t lda, const double *__restrict__ A, SplitFields F, const int *__restrict__ map,
+                                                    int lmax_lo, int lmax_hi, int ngemv)
+{
+    const int lane = threadIdx.x & 63;
+    const int nlo = (lmax_lo + 1) * (lmax_lo + 2) / 2;  // complex entries of one field at lmax_lo
+    if ((int)blockIdx.x >= ngemv) {  // high multipoles: 4 workgroups per (field, m), as k_alm_splice
+        const int b = blockIdx.x - ngemv, f = NF == 1 ? 0 : b / (4 * (lmax_hi + 1)), bb = b - f * 4 * (lmax_hi + 1), m = bb >> 2;
+        const int64_t bh = (int64_t)m * (2 * lmax_hi + 1 - m) / 2;
+        const int lstart = m > lmax_lo + 1 ? m : lmax_lo + 1;
+        const double2 *__restrict__ hi = F.hi[f];
+        const double *__restrict__ fl = F.fl[f];
+        double2 *__restrict__ out = F.out[f];
+        for (int l = lstart + (bb & 3) * 256 + threadIdx.x; l <= lmax_hi; l += 4 * 256) {
+            double2 v = hi[bh + l];
+            v.x *= fl[l]; v.y *= fl[l];
+            out[bh + l] = v;
+        }
+        return;
+    }
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const double2 *__restrict__ a2 = reinterpret_cast<const double2 *>(A + (int64_t)row * lda);
+    // entry c of the concatenated low-band-limit vector [field 0 | field 1]: read in place from the field's full array
+    auto x = [&](int c) -> double2 {
+        if constexpr (NF == 1) return F.hi[0][map[c]];
+        else return c < nlo ? F.hi[0][map[c]] : F.hi[1][map[c - nlo]];
+    };
+    double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+    const int n2 = NF * nlo;
+    int c = lane;
+    for (; c + 448 < n2; c += 512) {
+        const double2 u0 = a2[c], u1 = a2[c + 64], u2 = a2[c + 128], u3 = a2[c + 192];
+        const double2 u4 = a2[c + 256], u5 = a2[c + 320], u6 = a2[c + 384], u7 = a2[c + 448];
+        const double2 v0 = x(c), v1 = x(c + 64), v2 = x(c + 128), v3 = x(c + 192);
+        const double2 v4 = x(c + 256), v5 = x(c + 320), v6 = x(c + 384), v7 = x(c + 448);
+        s0 = fma(u0.x, v0.x, s0); s0 = fma(u0.y, v0.y, s0);
+        s1 = fma(u1.x, v1.x, s1); s1 = fma(u1.y, v1.y, s1);
+        s2 = fma(u2.x, v2.x, s2); s2 = fma(u2.y, v2.y, s2);
+        s3 = fma(u3.x, v3.x, s3); s3 = fma(u3.y, v3.y, s3);
+        s0 = fma(u4.x, v4.x, s0); s0 = fma(u4.y, v4.y, s0);
+        s1 = fma(u5.x, v5.x, s1); s1 = fma(u5.y, v5.y, s1);
+        s2 = fma(u6.x, v6.x, s2); s2 = fma(u6.y, v6.y, s2);
+        s3 = fma(u7.x, v7.x, s3); s3 = fma(u7.y, v7.y, s3);
+    }
+    for (; c + 192 < n2; c += 256) {
+        const double2 u0 = a2[c], u1 = a2[c + 64], u2 = a2[c + 128], u3 = a2[c + 192];
+        const double2 v0 = x(c), v1 = x(c + 64), v2 = x(c + 128), v3 = x(c + 192);
+        s0 = fma(u0.x, v0.x, s0); s0 = fma(u0.y, v0.y, s0);
+        s1 = fma(u1.x, v1.x, s1); s1 = fma(u1.y, v1.y, s1);
+        s2 = fma(u2.x, v2.x, s2); s2 = fma(u2.y, v2.y, s2);
+        s3 = fma(u3.x, v3.x, s3); s3 = fma(u3.y, v3.y, s3);
+    }
+    for (; c < n2; c += 64) { const double2 u = a2[c], v = x(c); s0 = fma(u.x, v.x, s0); s0 = fma(u.y, v.y, s0); }
+    double v = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) {
+        const int f = NF == 1 ? 0 : row / (2 * nlo), r = row - f * 2 * nlo;
+        reinterpret_cast<double *>(F.out[f])[2 * (int64_t)map[r >> 1] + (r & 1)] = v;
+    }
+}
+
 // The same for NB right-hand sides at once (Y[b] = A X[b], X: [nb][ncols], Y: [nb][nrows]): the block vectors of a batched
 // conjugate-gradient solve.  The matrix is read once for all of them (the 147 MB T block streams from the Infinity Cache at the
 // same rate as for one vector; 2 nb flops per matrix entry is far below the FMA rate: no MFMA needed for nb <= 8).  Every entry's sum
@@ -947,6 +1017,17 @@ void launch_gemv(int nrows, int ncols, int64_t lda, const double *A, const doubl
     const bool vec = (lda & 1) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     if (vec) hipLaunchKernelGGL(k_gemv<2>, dim3((nrows + 3) / 4), dim3(256), 0, st, nrows, ncols, lda, A, x, y);
     else hipLaunchKernelGGL(k_gemv<1>, dim3((nrows + 3) / 4), dim3(256), 0, st, nrows, ncols, lda, A, x, y);
+}
+void launch_gemv_split(int nf, int64_t lda, const double *A, const double *const *hi, const int *map, int lmax_lo, int lmax_hi, const double *const *fl_hi,
+                       double *const *out, hipStream_t st)
+{
+    const int nrows = nf * (lmax_lo + 1) * (lmax_lo + 2);
+    const int ngemv = (nrows + 3) / 4;
+    SplitFields F = {};
+    for (int f = 0; f < nf; ++f) { F.hi[f] = reinterpret_cast<const double2 *>(hi[f]); F.out[f] = reinterpret_cast<double2 *>(out[f]); F.fl[f] = fl_hi[f]; }
+    const dim3 grid(ngemv + nf * 4 * (lmax_hi + 1));
+    if (nf == 1) hipLaunchKernelGGL(k_gemv_split<1>, grid, dim3(256), 0, st, nrows, lda, A, F, map, lmax_lo, lmax_hi, ngemv);
+    else hipLaunchKernelGGL(k_gemv_split<2>, grid, dim3(256), 0, st, nrows, lda, A, F, map, lmax_lo, lmax_hi, ngemv);
 }
 // nb right-hand sides: x [nb][ncols] -> y [nb][nrows]
 void launch_gemv_nb(int nrows, int ncols, int64_t lda, const double *A, int nb, const double *x, double *y, hipStream_t st)

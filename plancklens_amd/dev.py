@@ -447,6 +447,33 @@ def gemv(amat, x, out=None):
     return out
 
 
+_SPLIT_MAP = {}
+
+
+def gemv_split(amat, alms_hi, lmax_lo, fls_hi):
+    """pre_op_split in one launch (pl_gemv_split) for the fields alms_hi (one tensor, or two: E and B) with their high-l filters fls_hi:
+    per field [rows of amat ([fields] truncated to lmax_lo) for l <= lmax_lo | fl_hi alm_hi above], band-limit of the inputs.
+    amat: pre_op_dense's flat matrix for these fields at lmax_lo.  Returns the list of output tensors."""
+    nf = len(alms_hi)
+    lmax_hi = Alm.getlmax(alms_hi[0].shape[0])
+    n = nf * (lmax_lo + 1) * (lmax_lo + 2)
+    for a in alms_hi:
+        assert a.dim() == 1 and a.is_contiguous() and a.dtype == torch.complex128 and a.shape == alms_hi[0].shape and lmax_hi > lmax_lo
+    assert nf in (1, 2) and len(fls_hi) == nf and amat.shape == (n, n) and amat.is_contiguous() and amat.dtype == torch.float64
+    key = (lmax_lo, lmax_hi, torch.cuda.current_device())
+    if key not in _SPLIT_MAP:  # positions of the lmax_lo entries in the lmax_hi layout
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('index map requested while a HIP graph is being captured')
+        m = np.concatenate([np.full(lmax_lo + 1 - mm, mm) for mm in range(lmax_lo + 1)])
+        l = np.concatenate([np.arange(mm, lmax_lo + 1) for mm in range(lmax_lo + 1)])
+        _SPLIT_MAP[key] = torch.from_numpy((m * (2 * lmax_hi + 1 - m) // 2 + l).astype(np.int32)).to(device())
+    outs = [torch.empty_like(a) for a in alms_hi]
+    fls = [fl_dev(f, lmax_hi) for f in fls_hi]
+    _lib.check(_lib.lib().pl_gemv_split(nf, int(lmax_lo), int(lmax_hi), n, amat.data_ptr(), _ptr_array(alms_hi), _SPLIT_MAP[key].data_ptr(),
+                                        _ptr_array(fls), _ptr_array(outs), stream_ptr()))
+    return outs
+
+
 def alm2cl(a, b=None):
     lmax = Alm.getlmax(a.numel())
     out = torch.empty(lmax + 1, dtype=torch.float64, device=a.device)

@@ -194,6 +194,30 @@ class _pre_op_dense(object):
     def __call__(self, talm):
         return self.calc(talm)
 
+    def split_apply(self, talm, lsplit, pre_op_hgh):
+        """pre_op_split's whole result for a device vector of a higher band-limit -- truncation to lsplit, this dense block, the diagonal
+        preconditioner of pre_op_hgh above lsplit and the splice in one launch (pl_gemv_split) -- or None when that form does not apply
+        (block vectors, host vectors, three fields, a high-l preconditioner that couples fields)"""
+        parts = _parts(talm)
+        if len(parts) == 1 and hasattr(pre_op_hgh, 'filt'):
+            fls = [pre_op_hgh.filt]
+        elif len(parts) == 2 and hasattr(pre_op_hgh, 'flmat') and pre_op_hgh.flmat.shape[1:] == (2, 2) \
+                and not (np.any(pre_op_hgh.flmat[:, 0, 1]) or np.any(pre_op_hgh.flmat[:, 1, 0])):
+            fls = [pre_op_hgh.flmat[:, 0, 0], pre_op_hgh.flmat[:, 1, 1]]
+        else:
+            return None
+        if lsplit != self.lmax or not all(isinstance(p, torch.Tensor) and p.is_cuda and p.dim() == 1 and p.dtype == torch.complex128 and p.is_contiguous()
+                                          and p.shape == parts[0].shape for p in parts):
+            return None
+        if Alm.getlmax(parts[0].shape[0]) <= lsplit or any(len(f) <= lsplit for f in fls):
+            return None
+        if getattr(self, '_amat', None) is None:
+            self._amat = _flat_matrix(self.minv, self.lmax, len(parts))
+        if self._amat.shape[0] != len(parts) * (self.lmax + 1) * (self.lmax + 2):
+            return None
+        res = dev.gemv_split(self._amat, parts, lsplit, fls)
+        return res[0] if len(res) == 1 else eblm(res)
+
     def calc(self, talm):
         if isinstance(talm, np.ndarray):
             return dev.to_host(self.calc(dev.to_dev(talm, torch.complex128)))  # host array in, host array out (temperature block)

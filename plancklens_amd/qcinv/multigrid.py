@@ -197,6 +197,10 @@ class pre_op_split(object):
 
     def calc(self, talm):
         self.iter += 1
+        if hasattr(self.pre_op_low, 'split_apply') and _lmax_of(talm) == self.lmax:
+            ret = self.pre_op_low.split_apply(talm, self.lsplit, self.pre_op_hgh)  # dense block + diagonal + splice in one launch
+            if ret is not None:
+                return ret
         talm_low = self.pre_op_low(util_alm.alm_copy(talm, lmax=self.lsplit))
         if hasattr(self.pre_op_hgh, 'splice_above') and _lmax_of(talm) == self.lmax:
             ret = self.pre_op_hgh.splice_above(talm_low, talm, self.lsplit)  # diagonal high-l part applied inside the splice

@@ -195,3 +195,55 @@ def test_paired_sky_synthesis_of_device_simulations(tmp_path):
     q3, u3 = sh.get_sim_pmap(3)
     q2, u2 = sh.get_sim_pmap(2)
     assert bool((q3 == ref.get_sim_pmap(3)[0]).all()) and bool((u2 == ref.get_sim_pmap(2)[1]).all())
+
+
+@pytest.mark.parametrize('lsplit,lmax', [(6, 16), (32, 64), (64, 256)])
+def test_split_preconditioner_in_one_launch(lsplit, lmax):
+    """pl_gemv_split: pre_op_split with a dense low block and a diagonal high part (multigrid.py:163-182, dense.py:118-119) in one launch
+    equals truncating alm_copy + pl_gemv + pl_alm_splice_fl bit for bit, for one field (temperature) and two (E, B), and pre_op_split
+    takes that route for device vectors."""
+    import torch
+    from plancklens_amd import dev, hp
+    from plancklens_amd.qcinv import dense, multigrid, opfilt_pp, util_alm
+    rng = np.random.default_rng(lsplit)
+
+    def ralm():
+        x = rng.standard_normal(hp.Alm.getsize(lmax)) + 1j * rng.standard_normal(hp.Alm.getsize(lmax))
+        x[:lmax + 1] = x[:lmax + 1].real
+        return dev.to_dev(x)
+    for nf in (1, 2):
+        nr = nf * (lsplit + 1) ** 2
+        a = rng.standard_normal((nr, nr))
+        base = dense.pre_op_dense_tt if nf == 1 else dense.pre_op_dense_pp
+
+        class low(base):  # a dense block with a given (symmetric) matrix
+            def __init__(self):
+                self.lmax = lsplit
+                self.minv = dev.to_dev(a + a.T, torch.float64)
+        if nf == 1:
+            class diag(object):
+                filt = rng.uniform(0.5, 2., lmax + 1)
+
+                def __call__(self, talm):
+                    return dev.almxfl(talm, self.filt)
+
+                def splice_above(self, alm_low, talm, ls):
+                    return dev.alm_splice_fl(alm_low, talm, self.filt, ls)
+            ph, x = diag(), ralm()
+        else:
+            ph = opfilt_pp.pre_op_diag.__new__(opfilt_pp.pre_op_diag)
+            ph.flmat = np.zeros((lmax + 1, 2, 2))
+            ph.flmat[:, 0, 0], ph.flmat[:, 1, 1] = rng.uniform(0.5, 2., lmax + 1), rng.uniform(0.5, 2., lmax + 1)
+            x = util_alm.eblm([ralm(), ralm()])
+        pl = low()
+        ref = ph.splice_above(pl(util_alm.alm_copy(x, lmax=lsplit)), x, lsplit)   # the step-by-step launches
+        one = pl.split_apply(x, lsplit, ph)
+        assert one is not None
+        for r, o in zip(multigrid._parts(ref), multigrid._parts(one)):
+            assert torch.equal(o, r)
+        sp = multigrid.pre_op_split(lsplit, lmax, pl, ph)
+        for r, o in zip(multigrid._parts(ref), multigrid._parts(sp(x))):
+            assert torch.equal(o, r)
+        # block vectors keep the step-by-step route
+        blk = torch.stack([multigrid._parts(x)[0]] * 2)
+        assert pl.split_apply(blk if nf == 1 else util_alm.eblm([blk, blk]), lsplit, ph) is None
