@@ -22,7 +22,9 @@ void launch_synths_pair(const DevPlan &P, const DevSpinTab &S, int spin, const d
 void launch_synths_batch2(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st,
                           int npairs_b = 1);
 void launch_anal0(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st,
-                  const double *add = nullptr, const double *fl_add = nullptr, int nb = 1);
+                  const double *add = nullptr, const double *fl_add = nullptr, int nb = 1, int lr_nmodes = 0, int lr_nparts = 0, int lr_pstride = 0,
+                  const double *lr_rm = nullptr, const double *lr_parts = nullptr);
+void tproj_parts_layout(int64_t n, int *nparts, int *pstride);
 void launch_anals(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
                   const double *fl, double *alm, hipStream_t st);
 void launch_anals_gc(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial, const double *fl,
@@ -932,10 +934,19 @@ static int cg_fwd_tt_impl(pl_plan *p, int nb, const double *alm_in, const double
     const int RG = rings_per_group(0, P);
     const int ngroups = (P.npairs + RG - 1) / RG;
     if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * P.nent0 * 4 * nb)) return 1;
-    { ProfScope ps(p, PK_LEG_ANAL0, st); launch_anal0(P, p->phase, p->partial, fl_out, alm_out, st, alm_add, fl_add, nb); }
+    const bool lr_on = lr && lr->nmodes > 0;
+    if (lr_on && lr_forked) HIPCHK(hipStreamWaitEvent(st, p->fs.join[FftStreams::kN - 1], 0));  // the coefficients are needed from here on
+    if (lr_on && nb == 1) {  // single vector: alm_out -= rm^t c inside the post-processing of the analysis (k_post0)
+        int nparts = 0, pstride = 0;
+        tproj_parts_layout(2 * P.nalm, &nparts, &pstride);
+        ProfScope ps(p, PK_LEG_ANAL0, st);
+        launch_anal0(P, p->phase, p->partial, fl_out, alm_out, st, alm_add, fl_add, nb, lr->nmodes, nparts, pstride, lr->rm, lr->scratch);
+    } else {
+        ProfScope ps(p, PK_LEG_ANAL0, st);
+        launch_anal0(P, p->phase, p->partial, fl_out, alm_out, st, alm_add, fl_add, nb);
+    }
     HIPCHK(hipGetLastError());
-    if (lr && lr->nmodes > 0) {  // alm_out -= rm^t c
-        if (lr_forked) HIPCHK(hipStreamWaitEvent(st, p->fs.join[FftStreams::kN - 1], 0));
+    if (lr_on && nb > 1) {  // block vectors: the subtraction as its own launch
         launch_template_project(2 * P.nalm, lr->nmodes, const_cast<double *>(alm_in), nullptr, lr->pm, lr->rm, lr->scratch, st, nb, alm_out, 2);
         HIPCHK(hipGetLastError());
     }

@@ -996,6 +996,13 @@ void launch_template_project(int64_t n, int nmodes, double *t, const double *n_i
         if (do_a) hipLaunchKernelGGL(k_tproj_apply, dim3(nblocks(n), nb), dim3(256), 0, st, n, nmodes, nparts, ta, rm, parts);
     }
 }
+// layout of the partial sums k_tproj_coeffs leaves for a single vector of n doubles: (number of partial sums per mode, stride between modes)
+void tproj_parts_layout(int64_t n, int *nparts, int *pstride)
+{
+    int np = kProjParts;
+    if (n < (int64_t)kProjParts * 4096) { np = (int)((n + 511) / 512); if (np < 1) np = 1; if (np > kProjParts) np = kProjParts; }
+    *nparts = np; *pstride = kProjParts;
+}
 // scratch: nb x 4 x npairs partial sums followed by nb x 4 coefficients
 void launch_template_project_md(const DevPlan &P, int nb, double *t, const double *n_inv, int weighted, const double *pinv, double *scratch,
                                 hipStream_t st)

@@ -932,9 +932,26 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
 
 // reduce partials over ring groups and convert (C, D) -> a_lm (fused hp.almxfl)
 // add / fl_add (optional): alm = fl * (analysis) + fl_add * add, the S^-1 x term of the CG operator folded in
+// lr (optional, one vector per launch): the low-rank template update alm -= rm^t c folded in -- c_k = the sum of the nparts partial sums of mode k
+// (left by k_tproj_coeffs on the operator's input, summed exactly as k_tproj_apply sums them), subtracted from every entry right after it is formed,
+// mode by mode in k_tproj_apply's order: bit-identical to that kernel run afterwards
+struct PostLowRank { int nmodes = 0, nparts = 0, pstride = 0; const double *rm = nullptr, *parts = nullptr; };
+
 __global__ void k_post0(DevPlan P, int RG, const double4 *__restrict__ partial_, const double *__restrict__ fl, double2 *__restrict__ alm_,
-                        const double2 *__restrict__ add_, const double *__restrict__ fl_add)
+                        const double2 *__restrict__ add_, const double *__restrict__ fl_add, PostLowRank lr)
 {
+    __shared__ double lrc[16];
+    if (lr.nmodes > 0) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int k = wave; k < lr.nmodes; k += 4) {
+            double v = 0.0;
+            for (int j = lane; j < lr.nparts; j += 64) v += lr.parts[k * lr.pstride + j];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) lrc[k] = v;
+        }
+        __syncthreads();
+    }
     const int m = blockIdx.y;
     const int nil = (P.lmax - m) / 2 + 1;
     const int64_t base = P.off0[m];
@@ -966,12 +983,20 @@ __global__ void k_post0(DevPlan P, int RG, const double4 *__restrict__ partial_,
         a.y = f0 * c0i + f1 * c1i;
         if (fl) { a.x *= fl[l]; a.y *= fl[l]; }
         if (add) { const double2 t = add[abase + l]; a.x = fma(fl_add[l], t.x, a.x); a.y = fma(fl_add[l], t.y, a.y); }
+        if (lr.nmodes > 0) {
+            const int64_t i = 2 * (abase + l), n2 = 2 * P.nalm;
+            for (int k = 0; k < lr.nmodes; ++k) { a.x = fma(-lr.rm[(int64_t)k * n2 + i], lrc[k], a.x); a.y = fma(-lr.rm[(int64_t)k * n2 + i + 1], lrc[k], a.y); }
+        }
         alm[abase + l] = a;
         if (l + 1 <= P.lmax) {
             double2 b;
             b.x = al * dr; b.y = al * di;
             if (fl) { b.x *= fl[l + 1]; b.y *= fl[l + 1]; }
             if (add) { const double2 t = add[abase + l + 1]; b.x = fma(fl_add[l + 1], t.x, b.x); b.y = fma(fl_add[l + 1], t.y, b.y); }
+            if (lr.nmodes > 0) {
+                const int64_t i = 2 * (abase + l + 1), n2 = 2 * P.nalm;
+                for (int k = 0; k < lr.nmodes; ++k) { b.x = fma(-lr.rm[(int64_t)k * n2 + i], lrc[k], b.x); b.y = fma(-lr.rm[(int64_t)k * n2 + i + 1], lrc[k], b.y); }
+            }
             alm[abase + l + 1] = b;
         }
     }
@@ -1395,28 +1420,30 @@ void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double
 
 template <int R>
 static void launch_anal0_r(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st,
-                           const double *add, const double *fl_add, int nb)
+                           const double *add, const double *fl_add, int nb, const PostLowRank &lr)
 {
     constexpr int RG = 64 * R;
     const int ngroups = (P.npairs + RG - 1) / RG, nmg = own_mgroups(P);
     if (nmg > 0) hipLaunchKernelGGL(k_leg_anal0<R>, dim3(ngroups * nmg, nb), dim3(256), 0, st, P, phase, partial);
     dim3 grid(4, P.mmax + 1, nb);
     hipLaunchKernelGGL(k_post0, grid, dim3(256), 0, st, P, RG, reinterpret_cast<const double4 *>(partial), fl,
-                       reinterpret_cast<double2 *>(alm), reinterpret_cast<const double2 *>(add), fl_add);
+                       reinterpret_cast<double2 *>(alm), reinterpret_cast<const double2 *>(add), fl_add, lr);
 }
 
 void launch_anal0(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st, const double *add,
-                  const double *fl_add, int nb)
+                  const double *fl_add, int nb, int lr_nmodes, int lr_nparts, int lr_pstride, const double *lr_rm, const double *lr_parts)
 {
+    PostLowRank lr;
+    if (lr_nmodes > 0 && nb == 1) { lr.nmodes = lr_nmodes; lr.nparts = lr_nparts; lr.pstride = lr_pstride; lr.rm = lr_rm; lr.parts = lr_parts; }
     switch (r0_anal(P)) {
-    case 1: launch_anal0_r<1>(P, phase, partial, fl, alm, st, add, fl_add, nb); break;
-    case 2: launch_anal0_r<2>(P, phase, partial, fl, alm, st, add, fl_add, nb); break;
-    case 3: launch_anal0_r<3>(P, phase, partial, fl, alm, st, add, fl_add, nb); break;
-    case 5: launch_anal0_r<5>(P, phase, partial, fl, alm, st, add, fl_add, nb); break;
-    case 6: launch_anal0_r<6>(P, phase, partial, fl, alm, st, add, fl_add, nb); break;
-    case 7: launch_anal0_r<7>(P, phase, partial, fl, alm, st, add, fl_add, nb); break;
-    case 8: launch_anal0_r<8>(P, phase, partial, fl, alm, st, add, fl_add, nb); break;
-    default: launch_anal0_r<4>(P, phase, partial, fl, alm, st, add, fl_add, nb); break;
+    case 1: launch_anal0_r<1>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr); break;
+    case 2: launch_anal0_r<2>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr); break;
+    case 3: launch_anal0_r<3>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr); break;
+    case 5: launch_anal0_r<5>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr); break;
+    case 6: launch_anal0_r<6>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr); break;
+    case 7: launch_anal0_r<7>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr); break;
+    case 8: launch_anal0_r<8>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr); break;
+    default: launch_anal0_r<4>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr); break;
     }
 }
 
