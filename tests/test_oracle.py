@@ -198,3 +198,33 @@ def test_c_ring_fft_stage_equals_numpy_stage(oracle, nside, lmax):
     m = rng.standard_normal(12 * nside ** 2)
     a, b = oracle._map2phase(m, nside, lmax, slots), oracle.ring_fft_c(1, nside, lmax, slots, m=m, nthreads=2)
     assert relrms(b[slots >= 0], a[slots >= 0]) < 1e-13
+
+
+def test_preallocated_outputs_of_the_c_stages(oracle):
+    """legendre(..., out=) and ring_fft_c(..., out=) (the preallocated result arrays bench.py's cpu_baseline reuses) give exactly what the
+    allocating calls give, also when the arrays held other data before."""
+    so = oracle
+    nside, lmax = 16, 40
+    rng = np.random.default_rng(3)
+    c, s, pair, slots = so._pair_geometry(nside, True)
+    nalm = so.alm_size(lmax)
+    for spin in (0, 2):
+        nc = 1 if spin == 0 else 2
+        alm = rng.standard_normal((nc, nalm)) + 1j * rng.standard_normal((nc, nalm))
+        alm[:, :lmax + 1] = alm[:, :lmax + 1].real
+        ref = so.legendre(0, 1, spin, lmax, lmax, c, s, pair, alm=alm)
+        buf = np.full(ref.shape, 7. + 3j)
+        assert so.legendre(0, 1, spin, lmax, lmax, c, s, pair, alm=alm, out=buf) is buf and np.array_equal(buf, ref)
+        maps = rng.standard_normal((nc, 12 * nside ** 2))
+        ph = np.zeros((nc, slots.size, lmax + 1), dtype=complex)
+        for i in range(nc):
+            r = so.ring_fft_c(1, nside, lmax, slots, m=maps[i])
+            assert so.ring_fft_c(1, nside, lmax, slots, m=maps[i], out=ph[i]) is not None and np.array_equal(ph[i], r)
+            assert np.allclose(r, so._map2phase(maps[i], nside, lmax, slots), rtol=0, atol=1e-13 * np.abs(r).max())
+        aref = so.legendre(1, 1, spin, lmax, lmax, c, s, pair, phase=ph)
+        abuf = np.full(aref.shape, 1. - 2j)
+        so.legendre(1, 1, spin, lmax, lmax, c, s, pair, phase=ph, out=abuf)
+        assert np.array_equal(abuf, aref)
+        # mode 1 (vectorised, scaled double) against mode 0 (long double) on the same inputs
+        assert np.abs(ref - so.legendre(0, 0, spin, lmax, lmax, c, s, pair, alm=alm)).max() < 1e-12 * np.abs(ref).max()
+        assert np.abs(aref - so.legendre(1, 0, spin, lmax, lmax, c, s, pair, phase=ph)).max() < 1e-12 * np.abs(aref).max()
