@@ -82,3 +82,36 @@ def test_private_right_hand_side_and_refresh_guard():
     with pytest.raises(AssertionError):           # a solve that reaches the residual refresh needs its right-hand side
         cd_solve.cd_solve(np.zeros_like(b), b.copy(), fwd, [pre], _dot_merged(), _stop_after(30), cd_solve.tr_cg, x_is_zero=True,
                           b_scratch=True)
+
+
+def test_pace_rendezvous_of_two_solves():
+    """multigrid.pace: two threads meet once per round; a party that leaves releases the other at once; a party alone is never held
+    (beyond the time-out) -- pacing is an optimisation, not a condition for progress."""
+    import threading
+    import time
+    from plancklens_amd.qcinv import multigrid
+    pc = multigrid.pace(2, timeout=5.0)
+    log = []
+
+    def solve(name, rounds, work):
+        for i in range(rounds):
+            pc.wait()
+            log.append((name, i, time.time()))
+            time.sleep(work)
+        pc.leave()
+    a = threading.Thread(target=solve, args=('a', 6, 0.002))
+    b = threading.Thread(target=solve, args=('b', 3, 0.02))
+    t0 = time.time()
+    a.start(); b.start(); a.join(); b.join()
+    assert time.time() - t0 < 2.0, 'a party was held by one that had left'
+    ta = {i: t for n, i, t in log if n == 'a'}
+    tb = {i: t for n, i, t in log if n == 'b'}
+    for i in range(1, 3):  # rounds both take part in start together: the fast party waited for the slow one
+        assert abs(ta[i] - tb[i]) < 0.015, (i, ta[i] - tb[i])
+        assert ta[i] >= tb[i - 1] + 0.015
+    assert len(ta) == 6 and len(tb) == 3
+    # a single party with a time-out is released by the time-out
+    pc2 = multigrid.pace(2, timeout=0.05)
+    t0 = time.time()
+    pc2.wait()
+    assert 0.04 < time.time() - t0 < 1.0
