@@ -108,6 +108,9 @@ class cmb_maps_nlev(cmb_maps):
         if pix_lib_phas is None:
             assert lib_dir is not None
             from . import phas
+            if mpi.size > 1:
+                print('cmb_maps_nlev: default noise phases are the state-recording pix_lib_phas (the reference\'s semantics: realisations depend on the '
+                      'order of first requests and on each rank\'s generator); a rank-sharded run should pass phas.pix_lib_phas_seeded or _dev')
             pix_lib_phas = phas.pix_lib_phas(lib_dir, 3, (hp.nside2npix(nside),))
         assert pix_lib_phas.shape == (hp.nside2npix(nside),), (pix_lib_phas.shape, (hp.nside2npix(nside),))
         self.pix_lib_phas = pix_lib_phas
