@@ -345,6 +345,16 @@ static int plan_create_impl(int nside, int lmax, int rank, int nranks, pl_plan *
         p->bytes += nd * 8;
         return 0;
     };
+    std::vector<double> ringc((size_t)(nside + 1) * 8, 0.0);
+    for (int q = 1; q <= nside; ++q) {
+        if (clsA[q] < 0) continue;
+        const long double n = 4.0L * q, N = 256 << clsA[q], G = N / 8, pi = 3.14159265358979323846264338327950288L;
+        const long double ang[4] = {pi / n, 2 * pi * G / n, 4 * pi * G / n, 4 * pi * N / n};
+        for (int k = 0; k < 4; ++k) { ringc[(size_t)q * 8 + 2 * k] = (double)cosl(ang[k]); ringc[(size_t)q * 8 + 2 * k + 1] = (double)sinl(ang[k]); }
+    }
+    const double *ringc_dev = nullptr;
+    if (upload(p, ringc, &ringc_dev)) { pl_plan_destroy(p); return 1; }
+    F.ringc = reinterpret_cast<const double2 *>(ringc_dev);
     rc = dalloc(&tw, F.Mtw) || dalloc(&chirp, 2 * nw) || dalloc(&filt, 2 * nc) || dalloc(&filtA, 2 * ncA) ||
          upload(p, Mof, &F.Mof) || upload(p, woff, &F.woff) || upload(p, coff, &F.coff) || upload(p, K2of, &F.K2of) ||
          upload(p, qlist, &qlist_dev) || upload(p, qlistA, &qlistA_dev) ||

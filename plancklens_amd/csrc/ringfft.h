@@ -40,6 +40,8 @@ struct DevFFT {
     const double2 *filt;     // bit-reversed FFT_M of the wrapped conj chirp, times 1 / M
     // register-resident kernels (ringfft.hip, second half): per-direction class lists and Bluestein tables
     int const *K2of;         // [nside + 1] band half-width of the sub-DFT bins of ring length 4 q: |c| <= K2of[q] (analysis)
+    const double2 *ringc;    // [nside + 1][4] wave-uniform phase factors of ring length n = 4 q in its register class of size N (G = N / 8):
+                             // e^{i pi / n}, e^{2 pi i G / n}, e^{4 pi i G / n}, e^{4 pi i N / n} (tables instead of sincos in every thread)
     FftSide A;               // class lists and band-limited Bluestein tables, shared by synthesis and analysis
 };
 

@@ -795,10 +795,10 @@ __global__ __launch_bounds__(N / 8, 2) void k_phase2map_fast(DevPlan P, DevFFT F
     {
         const int tl = fresh(tl0);
         double2 pj = make_double2(1., 0.), pstep = pj, s1 = pj, s2 = pj, s3 = pj, uneg = pj;
-        if (shifted) {
-            pj = cispi(4.0 * tl * inv_n); pstep = cispi(4.0 * G * inv_n);
-            s1 = cispi(inv_n); s2 = cmul(s1, s1); s3 = cmul(s2, s1);
-            uneg = cispi(4.0 * N * inv_n);
+        if (shifted) {  // (the wave-uniform factors come from the plan's per-ring table F.ringc, the per-thread one from sincos)
+            pj = cispi(4.0 * tl * inv_n); pstep = F.ringc[4 * q + 2];
+            s1 = F.ringc[4 * q]; s2 = cmul(s1, s1); s3 = cmul(s2, s1);
+            uneg = F.ringc[4 * q + 3];
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(N / 8, 2) void k_phase2map_fast(DevPlan P, DevFFT F
     const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
     const int tl = fresh(tl0);
     double2 e1 = cispi(2.0 * tl * inv_n);
-    const double2 estep = cispi(2.0 * G * inv_n);
+    const double2 estep = F.ringc[4 * q + 1];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int j1 = tl + G * j;
@@ -932,9 +932,9 @@ __global__ __launch_bounds__(N / 8, 2) void k_map2phase_fast(DevPlan P, DevFFT F
     const bool has_s = os >= 0;
     Tw8<N> tw;
     tw8_load<N>(tw, tl0, F.tw, F.Mtw);
-    const double2 e10 = cispi(2.0 * tl0 * inv_n), e1step = cispi(2.0 * G * inv_n);
+    const double2 e10 = cispi(2.0 * tl0 * inv_n), e1step = F.ringc[4 * q + 1];
     double2 pj0 = make_double2(1., 0.), pstep = pj0, s1 = pj0;
-    if (shifted) { pj0 = cispi(4.0 * tl0 * inv_n); pstep = cispi(4.0 * G * inv_n); s1 = cispi(inv_n); }
+    if (shifted) { pj0 = cispi(4.0 * tl0 * inv_n); pstep = F.ringc[4 * q + 2]; s1 = F.ringc[4 * q]; }
 
     // F_N, F_S of order m = 4 k1 + k2 (+ side owner): a = V_m (own register), vm = V_(n - m) (from the - side owner via LDS)
     auto emit_side = [&](int k2, const double2 (&own)[8], const double2 (&other)[8]) {
@@ -1090,8 +1090,8 @@ __global__ __launch_bounds__(N / 2) void k_phase2map_quad(DevPlan P, DevFFT F, c
         }
         double2 pj = make_double2(1., 0.), pstep = pj, uneg = pj;
         if (shifted) {
-            pj = cispi((4.0 * tl + k2) * inv_n); pstep = cispi(4.0 * G * inv_n);
-            uneg = cispi(4.0 * N * inv_n);
+            pj = cispi((4.0 * tl + k2) * inv_n); pstep = F.ringc[4 * q + 2];
+            uneg = F.ringc[4 * q + 3];
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -1151,7 +1151,8 @@ __global__ __launch_bounds__(N / 2) void k_phase2map_quad(DevPlan P, DevFFT F, c
     const int tl = fresh(tl0);
     {
         double2 ek = cispi(2.0 * k2 * tl * inv_n);
-        const double2 estep = cispi(2.0 * k2 * G * inv_n);
+        const double2 eg = F.ringc[4 * q + 1], eg2 = cmul(eg, eg);  // e^{2 pi i G / n}; this group's step is its k2-th power
+        const double2 estep = k2 == 0 ? make_double2(1., 0.) : k2 == 1 ? eg : k2 == 2 ? eg2 : cmul(eg2, eg);
         __syncthreads();  // every group is done with its exchange buffer
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -1215,6 +1216,7 @@ __global__ __launch_bounds__(N / 2) void k_map2phase_quad(DevPlan P, DevFFT F, c
         const int tl = fresh(tl0);
         const double *mps = has_s ? mp + os : mp + on;
         double vn[2][4], vs[2][4];
+        const double2 e1a = cispi(2.0 * (tl + G * 2 * k2) * inv_n);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {   // all sixteen loads first
             const int j1c = min(tl + G * (2 * k2 + u), q - 1);
@@ -1234,7 +1236,7 @@ __global__ __launch_bounds__(N / 2) void k_map2phase_quad(DevPlan P, DevFFT F, c
             dft_small<4, false>(y);  // y[k2] = sum_j2 i^(j2 k2) conj(z)_(j1 + q j2)
             double2 cw = make_double2(1., 0.);
             if (blue) cw = chirp[j1c];
-            const double2 e1 = cispi(2.0 * j1 * inv_n), e2 = cmul(e1, e1), e3 = cmul(e2, e1);
+            const double2 e1 = u == 0 ? e1a : cmul(e1a, F.ringc[4 * q + 1]), e2 = cmul(e1, e1), e3 = cmul(e2, e1);  // e^{2 pi i j1 / n}
             lds_all[j1] = cmul(y[0], cw);
             lds_all[N + j1] = cmul(y[1], cmul(cw, e1));
             lds_all[2 * N + j1] = cmul(y[2], cmul(cw, e2));
@@ -1303,7 +1305,7 @@ __global__ __launch_bounds__(N / 2) void k_map2phase_quad(DevPlan P, DevFFT F, c
     __syncthreads();
     const double2 *other = lds_all + ((4 - k2) & 3) * N;
     double2 pjj = make_double2(1., 0.), pstep = pjj;
-    if (shifted) { pjj = cispi((4.0 * tl + k2) * inv_n); pstep = cispi(4.0 * G * inv_n); }
+    if (shifted) { pjj = cispi((4.0 * tl + k2) * inv_n); pstep = F.ringc[4 * q + 2]; }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
