@@ -23,13 +23,15 @@ void launch_synths_batch2(const DevPlan &P, const DevSpinTab &S, int spin, const
                           int npairs_b = 1);
 void launch_anal0(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st,
                   const double *add = nullptr, const double *fl_add = nullptr, int nb = 1, int lr_nmodes = 0, int lr_nparts = 0, int lr_pstride = 0,
-                  const double *lr_rm = nullptr, const double *lr_parts = nullptr);
+                  const double *lr_rm = nullptr, const double *lr_parts = nullptr, const PostDots *dots = nullptr, int64_t lr_bstride = 0);
+int post_dots_count(const DevPlan &P);
 void tproj_parts_layout(int64_t n, int *nparts, int *pstride);
+int64_t tproj_parts_bstride();
 void launch_anals(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
                   const double *fl, double *alm, hipStream_t st);
 void launch_anals_gc(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial, const double *fl,
                      double *almG, double *almC, hipStream_t st, const double *addG, const double *addC, const double *flG, const double *flC,
-                     int nb = 1);
+                     int nb = 1, const PostDots *dots = nullptr);
 void launch_preps_gc(const DevPlan &P, const DevSpinTab &S, int spin, const double *almG, const double *almC, const double *fl, double *prep,
                      hipStream_t st, int nb = 1);
 void launch_almxfl(int lmax, const double *in, const double *fl, int nfl, double *out, hipStream_t st, int nb = 1);
@@ -41,6 +43,9 @@ void launch_axpy_dev(int64_t n, const double *num, const double *den, double sig
 void launch_cg_fused(int nf, const int *lmax, int lmin, const double *const *a, const double *const *b1, const double *const *b2, double *parts1,
                      double *parts2, const double *den, double *const *y1, const double *const *x1, double sign1, double *const *y2,
                      const double *const *x2, double sign2, unsigned *bar, hipStream_t st, int nbatch = 1, const double *active = nullptr);
+void launch_cg_axpy_pre(int nf, const int *lmax, int npre, const double *pre1, const double *pre2, const double *den, double *parts1, double *parts2,
+                        double *const *y1, const double *const *x1, double sign1, double *const *y2, const double *const *x2, double sign2, hipStream_t st,
+                        int nbatch, const double *active);
 void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st,
                        const double *fl_hi = nullptr, int nb = 1);
 void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st,
@@ -102,6 +107,8 @@ struct pl_plan {
     double *h_alm = nullptr; int64_t h_alm_cap = 0;   // device staging for host-pointer calls
     double *h_map = nullptr; int64_t h_map_cap = 0;
     double *h_fl = nullptr;
+    // pl_plan_arm_post_dots: scalar products wanted from the next pl_cg_fwd_* call on this plan (one shot)
+    PostDots dots{}; int dots_nf = 0; bool dots_armed = false;
     // optional per-stage timing with HIP events on the caller's stream (pl_profile_*)
     bool profiling = false;
     struct Ev { int kind; hipEvent_t e0, e1; };
@@ -865,6 +872,49 @@ int pl_cg_dot_axpy_b(int nb, int nf, const int *lmax, int lmin, const double *co
     return cg_dot_axpy_impl(nb, nf, lmax, lmin, a, b1, b2, parts1_dev, parts2_dev, den_parts_dev, y1, x1, sign1, y2, x2, sign2, nullptr, active_dev, stream);
 }
 
+int pl_post_dots_count(pl_plan *p)
+{
+    if (!p) return -1;
+    return post_dots_count(p->P);
+}
+
+// One shot: the next pl_cg_fwd_tt* (nf = 1) / pl_cg_fwd_pp* (nf = 2) call on this plan also leaves, per batch entry, pl_post_dots_count(p) partial sums
+// of <d, q> in pre1 and of <d, r> in pre2 (q its result; CG weights, entries l < lmin excluded) -- formed by the kernel that writes q.
+int pl_plan_arm_post_dots(pl_plan *p, int nf, const double *const *d, const double *const *r, int lmin, double *pre1, double *pre2)
+{
+    if (!p) return fail("null plan");
+    if ((nf != 1 && nf != 2) || !d || !r || !pre1 || !pre2) return fail("pl_plan_arm_post_dots: bad arguments");
+    PostDots D;
+    for (int k = 0; k < nf; ++k) {
+        if (!d[k] || !r[k]) return fail("pl_plan_arm_post_dots: null field");
+        D.d[k] = d[k]; D.r[k] = r[k];
+    }
+    D.s1 = pre1; D.s2 = pre2; D.lmin = lmin < 0 ? 0 : lmin;
+    p->dots = D; p->dots_nf = nf; p->dots_armed = true;
+    return 0;
+}
+
+// The vector updates of pl_cg_dot_axpy_b from scalar products that arrive as npre partial sums per batch entry (pl_plan_arm_post_dots, pl_gemv_split_dot,
+// pl_alm_splice_dot): den given: y1 += sign1 sum(pre1) / sum(den) x1; else y1 += sign1 sum(pre2) / sum(pre1) x1 and (optional) y2 += sign2 (same) x2.
+// parts1 / parts2 (optional) receive the totals as PL_DOT_PARTS-entry partial sums.
+int pl_cg_axpy_pre_b(int nb, int nf, const int *lmax, int npre, const double *pre1, const double *pre2, const double *den_parts_dev, double *parts1_dev,
+                     double *parts2_dev, double *const *y1, const double *const *x1, double sign1, double *const *y2, const double *const *x2, double sign2,
+                     const double *active_dev, void *stream)
+{
+    PL_NB_CHECK("pl_cg_axpy_pre_b");
+    if (nf < 1 || nf > 3 || !lmax || npre < 1 || !pre1 || !y1 || !x1) return fail("pl_cg_axpy_pre_b: bad arguments");
+    if (!pre2 && !den_parts_dev) return fail("pl_cg_axpy_pre_b: either a second scalar product (pre2) or a denominator (den_parts_dev) is needed");
+    if (pre2 && den_parts_dev) return fail("pl_cg_axpy_pre_b: pre2 excludes den_parts_dev");
+    if ((y2 == nullptr) != (x2 == nullptr)) return fail("pl_cg_axpy_pre_b: y2 and x2 come together");
+    if ((sign1 != 1.0 && sign1 != -1.0) || (sign2 != 1.0 && sign2 != -1.0)) return fail("pl_cg_axpy_pre_b: signs are +1 or -1");
+    for (int k = 0; k < nf; ++k)
+        if (lmax[k] < 0 || !y1[k] || !x1[k] || (y2 && (!y2[k] || !x2[k]))) return fail("pl_cg_axpy_pre_b: null field");
+    launch_cg_axpy_pre(nf, lmax, npre, pre1, pre2, den_parts_dev, parts1_dev, parts2_dev, y1, x1, sign1, y2, x2, sign2, static_cast<hipStream_t>(stream), nb,
+                       active_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int pl_template_project(int64_t npix, int nmodes, double *tmap, const double *n_inv, const double *pmat, const double *rmat, double *scratch, void *stream)
 {
     if (npix <= 0 || nmodes < 1 || nmodes > PL_TEMPLATE_MAX_MODES || !tmap || !n_inv || !pmat || !rmat || !scratch)
@@ -945,21 +995,27 @@ static int cg_fwd_tt_impl(pl_plan *p, int nb, const double *alm_in, const double
     const int ngroups = (P.npairs + RG - 1) / RG;
     if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * P.nent0 * 4 * nb)) return 1;
     const bool lr_on = lr && lr->nmodes > 0;
+    // scalar products of the result asked for by pl_plan_arm_post_dots (one field)
+    PostDots dots_now;
+    const bool want_dots = p->dots_armed;
+    p->dots_armed = false;
+    if (want_dots) {
+        if (p->dots_nf != 1) return fail("pl_cg_fwd_tt: armed scalar products need one field");
+        dots_now = p->dots;
+    }
+    const PostDots *dots = want_dots ? &dots_now : nullptr;
     if (lr_on && lr_forked) HIPCHK(hipStreamWaitEvent(st, p->fs.join[FftStreams::kN - 1], 0));  // the coefficients are needed from here on
-    if (lr_on && nb == 1) {  // single vector: alm_out -= rm^t c inside the post-processing of the analysis (k_post0)
+    if (lr_on) {  // alm_out -= rm^t c inside the post-processing of the analysis (k_post0), every batch entry from its own coefficients
         int nparts = 0, pstride = 0;
         tproj_parts_layout(2 * P.nalm, &nparts, &pstride);
         ProfScope ps(p, PK_LEG_ANAL0, st);
-        launch_anal0(P, p->phase, p->partial, fl_out, alm_out, st, alm_add, fl_add, nb, lr->nmodes, nparts, pstride, lr->rm, lr->scratch);
+        launch_anal0(P, p->phase, p->partial, fl_out, alm_out, st, alm_add, fl_add, nb, lr->nmodes, nparts, pstride, lr->rm, lr->scratch, dots,
+                     tproj_parts_bstride());
     } else {
         ProfScope ps(p, PK_LEG_ANAL0, st);
-        launch_anal0(P, p->phase, p->partial, fl_out, alm_out, st, alm_add, fl_add, nb);
+        launch_anal0(P, p->phase, p->partial, fl_out, alm_out, st, alm_add, fl_add, nb, 0, 0, 0, nullptr, nullptr, dots);
     }
     HIPCHK(hipGetLastError());
-    if (lr_on && nb > 1) {  // block vectors: the subtraction as its own launch
-        launch_template_project(2 * P.nalm, lr->nmodes, const_cast<double *>(alm_in), nullptr, lr->pm, lr->rm, lr->scratch, st, nb, alm_out, 2);
-        HIPCHK(hipGetLastError());
-    }
     return 0;
 }
 
@@ -1067,8 +1123,15 @@ static int cg_fwd_pp_impl(pl_plan *p, int nb, const double *elm_in, const double
     if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * p->nent[spin] * 4 * nb)) return 1;
     {
         ProfScope ps(p, PK_LEG_ANALS, st);
+        PostDots dots_now;
+        const bool want_dots = p->dots_armed;
+        p->dots_armed = false;
+        if (want_dots) {
+            if (p->dots_nf != 2) return fail("pl_cg_fwd_pp: armed scalar products need two fields");
+            dots_now = p->dots;
+        }
         launch_anals_gc(P, p->S[spin], spin, p->nent[spin], p->phase, p->partial, fl_out, elm_out, blm_out, st, elm_add, blm_add, fl_add_e,
-                        fl_add_b, nb);
+                        fl_add_b, nb, want_dots ? &dots_now : nullptr);
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -14,6 +14,17 @@ struct DevSpinTab {
     const int *gstart;       // [nmgroups] first ring group with any active ring, per group size (see api)
 };
 
+// Scalar products formed by the post-processing kernel of an analysis (k_post0 / k_posts) on its way out: with q the alm it writes (nf = 1: spin 0;
+// nf = 2: gradient and curl), s1[w] = the share of workgroup w of <d, q> and s2[w] that of <d, r>, summed over the fields, in the weights of the CG
+// scalar product (1 on m = 0, 2 elsewhere, 0 below lmin: elementwise.hip alm_dot_weight).  One partial sum per workgroup, batch entry after batch
+// entry (post_dots_count of them each); whoever consumes them adds them in index order (k_cg_axpy_pre).  conjugate-directions step of cd_solve.py:66-84
+// without its own scalar-product launch.
+struct PostDots {
+    const double *d[2] = {nullptr, nullptr}, *r[2] = {nullptr, nullptr};
+    double *s1 = nullptr, *s2 = nullptr;
+    int lmin = 0;
+};
+
 struct DevPlan {
     int nside, lmax, mmax, npairs, mstride;
     int64_t npix, nalm;

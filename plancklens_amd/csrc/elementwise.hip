@@ -353,6 +353,54 @@ __global__ __launch_bounds__(kDotThreads) void k_cg_fused(CgFused f, double *__r
     }
 }
 
+// The updates of k_cg_fused<2> from scalar products that arrive as `npre` per-workgroup partial sums of the kernel that produced the vector (PostDots of
+// k_post0 / k_posts: <d, q> and <d, r> formed while q is written; k_gemv_split / k_alm_splice: <s, q'> formed while s is written) instead of the
+// kDotParts sums of a k_cg_fused<1> launch: every workgroup adds them in a fixed order (thread t takes entries t, t + 1024, ..., then the tree of
+// block_sum_1024).  Same roles as in k_cg_fused: den given: step length = sum(pre1) / sum(den); else sum(pre2) / sum(pre1).  Workgroup 0 leaves the
+// totals behind as canonical kDotParts-entry partial sums {total, 0, ...} (parts1 <- pre1, parts2 <- pre2) for the cache of cd_solve and the monitors.
+__global__ __launch_bounds__(kDotThreads) void k_cg_axpy_pre(CgFused f, int npre, const double *__restrict__ pre1_, const double *__restrict__ pre2_,
+                                                             const double *__restrict__ den_, double *__restrict__ parts1_, double *__restrict__ parts2_,
+                                                             double sign1, double sign2, const double *__restrict__ active)
+{
+    __shared__ double red[2][kDotThreads / 64];
+    const int bq = blockIdx.y;
+    const double *__restrict__ pre1 = pre1_ + (int64_t)bq * npre, *__restrict__ pre2 = pre2_ ? pre2_ + (int64_t)bq * npre : nullptr;
+    const double *__restrict__ den = den_ ? den_ + bq * kDotParts : nullptr;
+    // thread t adds entries t, t + 1024, ...; lanes by shuffles, the 16 wave sums in index order by every thread: one barrier, fixed order
+    double u1 = 0.0, u2 = 0.0;
+    for (int i = threadIdx.x; i < npre; i += kDotThreads) { u1 += pre1[i]; if (pre2) u2 += pre2[i]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { u1 += __shfl_down(u1, off, 64); u2 += __shfl_down(u2, off, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = u1; red[1][threadIdx.x >> 6] = u2; }
+    __syncthreads();
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < kDotThreads / 64; ++w) { t1 += red[0][w]; t2 += red[1][w]; }
+    const double cs = den ? t1 * (1.0 / dot_parts_sum(den)) : t2 * (1.0 / t1);
+    if (blockIdx.x == 0 && threadIdx.x < kDotParts) {
+        if (parts1_) parts1_[bq * kDotParts + threadIdx.x] = threadIdx.x == 0 ? t1 : 0.0;
+        if (parts2_ && pre2) parts2_[bq * kDotParts + threadIdx.x] = threadIdx.x == 0 ? t2 : 0.0;
+    }
+    if (active && active[bq] == 0.0) return;
+    const double c1 = sign1 * cs, c2 = sign2 * cs;
+    for (int k = 0; k < f.nf; ++k) {
+        const int64_t nalm = (int64_t)(f.lmax[k] + 1) * (f.lmax[k] + 2) / 2;
+        const int64_t o = bq * nalm;
+        for (int64_t i = o + (int64_t)blockIdx.x * kDotThreads + threadIdx.x; i < o + nalm; i += (int64_t)gridDim.x * kDotThreads) {
+            const double2 u = f.x1[k][i];
+            double2 v = f.y1[k][i];
+            v.x = fma(c1, u.x, v.x); v.y = fma(c1, u.y, v.y);
+            f.y1[k][i] = v;
+            if (f.y2[0]) {
+                const double2 w2 = f.x2[k][i];
+                double2 w = f.y2[k][i];
+                w.x = fma(c2, w2.x, w.x); w.y = fma(c2, w2.y, w.y);
+                f.y2[k][i] = w;
+            }
+        }
+    }
+}
+
 // ---- N^-1 with template marginalisation in two launches (opfilt_tt.py:196-205) ----------------------------------------
 // t <- N^-1 t - N^-1 P (P^t N^-1 P)^-1 P^t N^-1 t with P (nmodes x n) and R = (P^t N^-1 P)^-1 (P . N^-1) (nmodes x n) given:
 //   pass 1: t <- n_inv t and the per-workgroup partial sums of c_k = sum_i P_ki t_i;  pass 2: t_i -= sum_k R_ki c_k.
@@ -962,6 +1010,27 @@ void launch_cg_fused(int nf, const int *lmax, int lmin, const double *const *a, 
                            sign2, bar, active);
     }
 }
+void launch_cg_axpy_pre(int nf, const int *lmax, int npre, const double *pre1, const double *pre2, const double *den, double *parts1, double *parts2,
+                        double *const *y1, const double *const *x1, double sign1, double *const *y2, const double *const *x2, double sign2, hipStream_t st,
+                        int nbatch, const double *active)
+{
+    CgFused f = {};
+    f.nf = nf;
+    int64_t nmax = 0;
+    for (int k = 0; k < nf; ++k) {
+        f.lmax[k] = lmax[k];
+        f.y1[k] = reinterpret_cast<double2 *>(y1[k]);
+        f.x1[k] = reinterpret_cast<const double2 *>(x1[k]);
+        f.y2[k] = y2 ? reinterpret_cast<double2 *>(y2[k]) : nullptr;
+        f.x2[k] = x2 ? reinterpret_cast<const double2 *>(x2[k]) : nullptr;
+        const int64_t nalm = (int64_t)(lmax[k] + 1) * (lmax[k] + 2) / 2;
+        if (nalm > nmax) nmax = nalm;
+    }
+    const int nb2 = (int)((nmax + kDotThreads - 1) / kDotThreads);  // as the update launch of launch_cg_fused
+    const int cap = npre > 1024 ? 256 : 1024;  // every workgroup adds all npre partial sums: long lists (the fine grids) go to one workgroup per CU
+    hipLaunchKernelGGL(k_cg_axpy_pre, dim3(nb2 < 1 ? 1 : (nb2 > cap ? cap : nb2), nbatch), dim3(kDotThreads), 0, st, f, npre, pre1, pre2, den, parts1,
+                       parts2, sign1, sign2, active);
+}
 // t_apply (optional): the projection is subtracted from this vector instead of t, which is then only read (n_inv null) -- the
 // rank-nmodes update y -= rm^t (pm x) of launch_lowrank_update
 // phase: 0 both launches on st; 1 the coefficient pass only; 2 the subtraction only (the two halves of a low-rank update whose
@@ -1003,6 +1072,7 @@ void tproj_parts_layout(int64_t n, int *nparts, int *pstride)
     if (n < (int64_t)kProjParts * 4096) { np = (int)((n + 511) / 512); if (np < 1) np = 1; if (np > kProjParts) np = kProjParts; }
     *nparts = np; *pstride = kProjParts;
 }
+int64_t tproj_parts_bstride() { return (int64_t)kProjMaxModes * kProjParts; }  // between the partial sums of consecutive batch entries
 // scratch: nb x 4 x npairs partial sums followed by nb x 4 coefficients
 void launch_template_project_md(const DevPlan &P, int nb, double *t, const double *n_inv, int weighted, const double *pinv, double *scratch,
                                 hipStream_t st)

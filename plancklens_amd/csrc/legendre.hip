@@ -932,20 +932,41 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
 
 // reduce partials over ring groups and convert (C, D) -> a_lm (fused hp.almxfl)
 // add / fl_add (optional): alm = fl * (analysis) + fl_add * add, the S^-1 x term of the CG operator folded in
-// lr (optional, one vector per launch): the low-rank template update alm -= rm^t c folded in -- c_k = the sum of the nparts partial sums of mode k
+// lr (optional): the low-rank template update alm -= rm^t c folded in -- c_k = the sum of the nparts partial sums of mode k
 // (left by k_tproj_coeffs on the operator's input, summed exactly as k_tproj_apply sums them), subtracted from every entry right after it is formed,
 // mode by mode in k_tproj_apply's order: bit-identical to that kernel run afterwards
-struct PostLowRank { int nmodes = 0, nparts = 0, pstride = 0; const double *rm = nullptr, *parts = nullptr; };
+// the two partial sums of a workgroup of 256 threads -> PostDots (fixed tree: bit-reproducible)
+__device__ __forceinline__ void post_dots_emit(double t1, double t2, const PostDots &dots, double *red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { t1 += __shfl_down(t1, off, 64); t2 += __shfl_down(t2, off, 64); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave] = t1; red[4 + wave] = t2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t w = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        dots.s1[w] = (red[0] + red[1]) + (red[2] + red[3]);
+        dots.s2[w] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+__device__ __forceinline__ void post_dots_add(double &t1, double &t2, double w, const double2 q, const double2 d, const double2 r)
+{
+    t1 = fma(w, d.x * q.x + d.y * q.y, t1);
+    t2 = fma(w, d.x * r.x + d.y * r.y, t2);
+}
+struct PostLowRank { int nmodes = 0, nparts = 0, pstride = 0; int64_t bstride = 0; const double *rm = nullptr, *parts = nullptr; };  // bstride: between the partial sums of batch entries
 
 __global__ void k_post0(DevPlan P, int RG, const double4 *__restrict__ partial_, const double *__restrict__ fl, double2 *__restrict__ alm_,
-                        const double2 *__restrict__ add_, const double *__restrict__ fl_add, PostLowRank lr)
+                        const double2 *__restrict__ add_, const double *__restrict__ fl_add, PostLowRank lr, PostDots dots)
 {
     __shared__ double lrc[16];
+    __shared__ double dred[8];
+    double t1 = 0., t2 = 0.;
     if (lr.nmodes > 0) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         for (int k = wave; k < lr.nmodes; k += 4) {
             double v = 0.0;
-            for (int j = lane; j < lr.nparts; j += 64) v += lr.parts[k * lr.pstride + j];
+            for (int j = lane; j < lr.nparts; j += 64) v += lr.parts[(int64_t)blockIdx.z * lr.bstride + k * lr.pstride + j];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if (lane == 0) lrc[k] = v;
@@ -963,6 +984,14 @@ __global__ void k_post0(DevPlan P, int RG, const double4 *__restrict__ partial_,
     const int mg4 = 4 * (m / 4);
     for (int il = blockIdx.x * blockDim.x + threadIdx.x; il < nil; il += gridDim.x * blockDim.x) {
         const int64_t e = base + il;
+        // (the vectors of the scalar products are fetched ahead of the partial sums: their latency hides behind that loop)
+        const int l_ = m + 2 * il;
+        const int64_t idot = (int64_t)blockIdx.z * P.nalm + abase + l_;
+        double2 dd0 = make_double2(0., 0.), dd1 = dd0, rr0 = dd0, rr1 = dd0;
+        if (dots.s1) {
+            dd0 = reinterpret_cast<const double2 *>(dots.d[0])[idot]; rr0 = reinterpret_cast<const double2 *>(dots.r[0])[idot];
+            if (l_ + 1 <= P.lmax) { dd1 = reinterpret_cast<const double2 *>(dots.d[0])[idot + 1]; rr1 = reinterpret_cast<const double2 *>(dots.r[0])[idot + 1]; }
+        }
         double c0r = 0., c0i = 0., c1r = 0., c1i = 0., dr = 0., di = 0.;
         for (int g = 0; g < ngroups; ++g) {
             const int last = min(P.npairs - 1, g * RG + RG - 1);
@@ -988,6 +1017,8 @@ __global__ void k_post0(DevPlan P, int RG, const double4 *__restrict__ partial_,
             for (int k = 0; k < lr.nmodes; ++k) { a.x = fma(-lr.rm[(int64_t)k * n2 + i], lrc[k], a.x); a.y = fma(-lr.rm[(int64_t)k * n2 + i + 1], lrc[k], a.y); }
         }
         alm[abase + l] = a;
+        const double wdot = m == 0 ? 1.0 : 2.0;
+        if (dots.s1 && l >= dots.lmin) post_dots_add(t1, t2, wdot, a, dd0, rr0);
         if (l + 1 <= P.lmax) {
             double2 b;
             b.x = al * dr; b.y = al * di;
@@ -998,8 +1029,10 @@ __global__ void k_post0(DevPlan P, int RG, const double4 *__restrict__ partial_,
                 for (int k = 0; k < lr.nmodes; ++k) { b.x = fma(-lr.rm[(int64_t)k * n2 + i], lrc[k], b.x); b.y = fma(-lr.rm[(int64_t)k * n2 + i + 1], lrc[k], b.y); }
             }
             alm[abase + l + 1] = b;
+            if (dots.s1 && l + 1 >= dots.lmin) post_dots_add(t1, t2, wdot, b, dd1, rr1);
         }
     }
+    if (dots.s1) post_dots_emit(t1, t2, dots, dred);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -1230,8 +1263,10 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
 __global__ void k_posts(DevPlan P, DevSpinTab S, int spin, int RG, int64_t nent, const double4 *__restrict__ partial_,
                         const double *__restrict__ fl, double2 *__restrict__ almG_, double2 *__restrict__ almC_,
                         const double2 *__restrict__ addG_, const double2 *__restrict__ addC_, const double *__restrict__ flG,
-                        const double *__restrict__ flC)
+                        const double *__restrict__ flC, PostDots dots)
 {
+    __shared__ double dred[8];
+    double t1 = 0., t2 = 0.;
     const int64_t bz = blockIdx.z;
     const double4 *__restrict__ partial = partial_ + bz * ((P.npairs + RG - 1) / RG) * nent;
     double2 *__restrict__ almG = almG_ + bz * P.nalm, *__restrict__ almC = almC_ + bz * P.nalm;
@@ -1239,6 +1274,7 @@ __global__ void k_posts(DevPlan P, DevSpinTab S, int spin, int RG, int64_t nent,
     const int m = blockIdx.y;
     const int l0 = m > spin ? m : spin;
     const int64_t abase = (int64_t)m * (2 * P.lmax + 1 - m) / 2;
+    const double wdot = m == 0 ? 1.0 : 2.0;
     // entries below the spin are zero
     for (int l = m + blockIdx.x * blockDim.x + threadIdx.x; l < l0 && l <= P.lmax; l += gridDim.x * blockDim.x) {
         double2 g = make_double2(0., 0.), c = g;
@@ -1249,14 +1285,24 @@ __global__ void k_posts(DevPlan P, DevSpinTab S, int spin, int RG, int64_t nent,
         }
         almG[abase + l] = g;
         almC[abase + l] = c;
+        if (dots.s1 && l >= dots.lmin) {
+            const int64_t i = bz * P.nalm + abase + l;
+            post_dots_add(t1, t2, wdot, g, reinterpret_cast<const double2 *>(dots.d[0])[i], reinterpret_cast<const double2 *>(dots.r[0])[i]);
+            post_dots_add(t1, t2, wdot, c, reinterpret_cast<const double2 *>(dots.d[1])[i], reinterpret_cast<const double2 *>(dots.r[1])[i]);
+        }
     }
     const int nl = P.lmax - l0 + 1;
-    if (nl <= 0) return;
     const int64_t base = S.off[m];
     const int ngroups = (P.npairs + RG - 1) / RG;
     const int mg4 = 4 * (m / 4);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nl; i += gridDim.x * blockDim.x) {
         const int64_t e = base + i;
+        const int64_t ii = bz * P.nalm + abase + l0 + i;
+        double2 dg = make_double2(0., 0.), dc = dg, rg = dg, rc = dg;  // fetched ahead of the partial sums (latency)
+        if (dots.s1) {
+            dg = reinterpret_cast<const double2 *>(dots.d[0])[ii]; rg = reinterpret_cast<const double2 *>(dots.r[0])[ii];
+            dc = reinterpret_cast<const double2 *>(dots.d[1])[ii]; rc = reinterpret_cast<const double2 *>(dots.r[1])[ii];
+        }
         double gr = 0., gi = 0., cr = 0., ci = 0.;
         for (int g = 0; g < ngroups; ++g) {
             const int last = min(P.npairs - 1, g * RG + RG - 1);
@@ -1276,7 +1322,12 @@ __global__ void k_posts(DevPlan P, DevSpinTab S, int spin, int RG, int64_t nent,
         }
         almG[abase + l] = g;
         almC[abase + l] = c;
+        if (dots.s1 && l >= dots.lmin) {
+            post_dots_add(t1, t2, wdot, g, dg, rg);
+            post_dots_add(t1, t2, wdot, c, dc, rc);
+        }
     }
+    if (dots.s1) post_dots_emit(t1, t2, dots, dred);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -1312,6 +1363,8 @@ static int rs_synth(const DevPlan &P) { return pick_r("PLSHTS_RS", 2, 4, P); }
 static int r0_anal(const DevPlan &P) { return pick_r("PLSHTS_R0A", P.nside >= 4096 ? 8 : 6, 8, P); }
 static int rs_anal(const DevPlan &P) { return pick_r("PLSHTS_RSA", 4, 4, P); }  // (5, 6, 8 rings per lane -- one wave per SIMD -- measured 5.30 / 6.27 / 10.0 ms against 4.53 ms: round 3)
 
+// partial sums per batch entry that k_post0 / k_posts leave in a PostDots (= their workgroups per entry)
+int post_dots_count(const DevPlan &P) { return 4 * (P.mmax + 1); }
 int rings_per_group(int spin, const DevPlan &P) { return 64 * (spin == 0 ? r0_anal(P) : rs_anal(P)); }
 
 void launch_prep0(const DevPlan &P, const double *alm, const double *fl, double *prep, hipStream_t st, int nb)
@@ -1420,37 +1473,39 @@ void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double
 
 template <int R>
 static void launch_anal0_r(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st,
-                           const double *add, const double *fl_add, int nb, const PostLowRank &lr)
+                           const double *add, const double *fl_add, int nb, const PostLowRank &lr, const PostDots &dots)
 {
     constexpr int RG = 64 * R;
     const int ngroups = (P.npairs + RG - 1) / RG, nmg = own_mgroups(P);
     if (nmg > 0) hipLaunchKernelGGL(k_leg_anal0<R>, dim3(ngroups * nmg, nb), dim3(256), 0, st, P, phase, partial);
     dim3 grid(4, P.mmax + 1, nb);
     hipLaunchKernelGGL(k_post0, grid, dim3(256), 0, st, P, RG, reinterpret_cast<const double4 *>(partial), fl,
-                       reinterpret_cast<double2 *>(alm), reinterpret_cast<const double2 *>(add), fl_add, lr);
+                       reinterpret_cast<double2 *>(alm), reinterpret_cast<const double2 *>(add), fl_add, lr, dots);
 }
 
 void launch_anal0(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st, const double *add,
-                  const double *fl_add, int nb, int lr_nmodes, int lr_nparts, int lr_pstride, const double *lr_rm, const double *lr_parts)
+                  const double *fl_add, int nb, int lr_nmodes, int lr_nparts, int lr_pstride, const double *lr_rm, const double *lr_parts,
+                  const PostDots *dots_, int64_t lr_bstride)
 {
+    const PostDots dots = dots_ ? *dots_ : PostDots();
     PostLowRank lr;
-    if (lr_nmodes > 0 && nb == 1) { lr.nmodes = lr_nmodes; lr.nparts = lr_nparts; lr.pstride = lr_pstride; lr.rm = lr_rm; lr.parts = lr_parts; }
+    if (lr_nmodes > 0) { lr.nmodes = lr_nmodes; lr.nparts = lr_nparts; lr.pstride = lr_pstride; lr.bstride = lr_bstride; lr.rm = lr_rm; lr.parts = lr_parts; }
     switch (r0_anal(P)) {
-    case 1: launch_anal0_r<1>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr); break;
-    case 2: launch_anal0_r<2>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr); break;
-    case 3: launch_anal0_r<3>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr); break;
-    case 5: launch_anal0_r<5>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr); break;
-    case 6: launch_anal0_r<6>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr); break;
-    case 7: launch_anal0_r<7>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr); break;
-    case 8: launch_anal0_r<8>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr); break;
-    default: launch_anal0_r<4>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr); break;
+    case 1: launch_anal0_r<1>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr, dots); break;
+    case 2: launch_anal0_r<2>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr, dots); break;
+    case 3: launch_anal0_r<3>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr, dots); break;
+    case 5: launch_anal0_r<5>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr, dots); break;
+    case 6: launch_anal0_r<6>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr, dots); break;
+    case 7: launch_anal0_r<7>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr, dots); break;
+    case 8: launch_anal0_r<8>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr, dots); break;
+    default: launch_anal0_r<4>(P, phase, partial, fl, alm, st, add, fl_add, nb, lr, dots); break;
     }
 }
 
 template <int R>
 static void launch_anals_r(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
                            const double *fl, double *almG, double *almC, hipStream_t st, const double *addG, const double *addC,
-                           const double *flG, const double *flC, int nb)
+                           const double *flG, const double *flC, int nb, const PostDots &dots)
 {
     constexpr int RG = 64 * R;
     const int ngroups = (P.npairs + RG - 1) / RG, nmg = own_mgroups(P);
@@ -1458,12 +1513,12 @@ static void launch_anals_r(const DevPlan &P, const DevSpinTab &S, int spin, int6
     dim3 grid(4, P.mmax + 1, nb);
     hipLaunchKernelGGL(k_posts, grid, dim3(256), 0, st, P, S, spin, RG, nent, reinterpret_cast<const double4 *>(partial), fl,
                        reinterpret_cast<double2 *>(almG), reinterpret_cast<double2 *>(almC), reinterpret_cast<const double2 *>(addG),
-                       reinterpret_cast<const double2 *>(addC), flG, flC);
+                       reinterpret_cast<const double2 *>(addC), flG, flC, dots);
 }
 
 void launch_anals_gc(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial, const double *fl,
                      double *almG, double *almC, hipStream_t st, const double *addG, const double *addC, const double *flG, const double *flC,
-                     int nb = 1);
+                     int nb = 1, const PostDots *dots = nullptr);
 
 void launch_anals(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial,
                   const double *fl, double *alm, hipStream_t st)
@@ -1474,13 +1529,14 @@ void launch_anals(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent,
 // gradient / curl outputs as two arrays, with the optional add terms of k_posts
 void launch_anals_gc(const DevPlan &P, const DevSpinTab &S, int spin, int64_t nent, const double *phase, double *partial, const double *fl,
                      double *almG, double *almC, hipStream_t st, const double *addG, const double *addC, const double *flG, const double *flC,
-                     int nb)
+                     int nb, const PostDots *dots_)
 {
+    const PostDots dots = dots_ ? *dots_ : PostDots();
     switch (rs_anal(P)) {
-    case 1: launch_anals_r<1>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
-    case 2: launch_anals_r<2>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
-    case 4: launch_anals_r<4>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
-    default: launch_anals_r<3>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb); break;
+    case 1: launch_anals_r<1>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb, dots); break;
+    case 2: launch_anals_r<2>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb, dots); break;
+    case 4: launch_anals_r<4>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb, dots); break;
+    default: launch_anals_r<3>(P, S, spin, nent, phase, partial, fl, almG, almC, st, addG, addC, flG, flC, nb, dots); break;
     }
 }
 

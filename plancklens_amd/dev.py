@@ -359,6 +359,35 @@ def cg_dot_axpy(a, b1, y1, x1, sign1, b2=None, den=None, y2=None, x2=None, sign2
     return parts1, parts2
 
 
+def cg_axpy_pre(pre, y1, x1, sign1, den=None, y2=None, x2=None, sign2=-1.0, active=None):
+    """The updates of cg_dot_axpy from scalar products that the kernel producing the vector left as partial sums (pl_cg_axpy_pre_b):
+    pre = (pre1, pre2) or (pre1, None), [npre] or [nb, npre] each.  den given: c = sum(pre1) / sum(den); else c = sum(pre2) / sum(pre1);
+    y1 += sign1 c x1, y2 += sign2 c x2.  Returns (parts1, parts2): the totals of pre1 / pre2 as DOT_PARTS partial sums (alm_dot's form)."""
+    pre1, pre2 = pre
+    nf = len(y1)
+    for group in (x1, y2, x2):
+        assert group is None or len(group) == nf
+    nb, blk = bshape(y1[0])[0], y1[0].dim() == 2
+    for k in range(nf):
+        for group in (y1, x1, y2, x2):
+            assert group is None or (group[k].dtype == torch.complex128 and group[k].is_contiguous() and group[k].shape == y1[k].shape)
+    assert (pre2 is None) != (den is None) and (den is None or den.numel() == nb * DOT_PARTS)
+    npre = pre1.shape[-1]
+    for t in (pre1, pre2):
+        assert t is None or (t.dtype == torch.float64 and t.is_contiguous() and t.numel() == nb * npre)
+    lmax = (ctypes.c_int * nf)(*[Alm.getlmax(bshape(t)[1]) for t in y1])
+    pshape = (nb, DOT_PARTS) if blk else DOT_PARTS
+    parts1 = torch.empty(pshape, dtype=torch.float64, device=device())
+    parts2 = torch.empty(pshape, dtype=torch.float64, device=device()) if pre2 is not None else None
+    assert active is None or (blk and active.numel() == nb and active.dtype == torch.float64 and active.is_cuda)
+    _lib.check(_lib.lib().pl_cg_axpy_pre_b(nb, nf, lmax, int(npre), pre1.data_ptr(), None if pre2 is None else pre2.data_ptr(),
+                                           None if den is None else den.data_ptr(), parts1.data_ptr(), None if parts2 is None else parts2.data_ptr(),
+                                           _ptr_array(y1), _ptr_array(x1), float(sign1), None if y2 is None else _ptr_array(y2),
+                                           None if x2 is None else _ptr_array(x2), float(sign2), None if active is None else active.data_ptr(),
+                                           stream_ptr()))
+    return parts1, parts2
+
+
 TEMPLATE_MAX_MODES = 16  # PL_TEMPLATE_MAX_MODES of include/plshts.h
 _TPROJ_SCRATCH = {}
 

@@ -91,8 +91,16 @@ def _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_i
     if criterion(it, x, residual):
         return it
     searchdirs = [op(residual) for op in pre_ops]
+    # the two scalar products of a step from the kernel that writes fwd_op's result (fwd_op.with_dots, dot_op.step(pre=...)): one launch
+    # less per iteration (PLENS_CG_POST_DOTS=0: their own launch)
+    post_dots = merged and hasattr(fwd_op, 'with_dots') and os.environ.get('PLENS_CG_POST_DOTS', '1') != '0'
     while True:
-        searchfwds = [fwd_op(d) for d in searchdirs]
+        pre = None
+        if post_dots:
+            q, pre = fwd_op.with_dots(searchdirs[0], residual)
+            searchfwds = [q]
+        else:
+            searchfwds = [fwd_op(d) for d in searchdirs]
         if fused:
             fresh_residual = np.mod(it + 1, roundoff) == 0
             active = getattr(criterion, 'active', None)  # block vectors: 0 / 1 per entry, entries that have converged stand still
@@ -100,7 +108,10 @@ def _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_i
                 assert merged, 'per-entry stopping of a block solve needs dot_op.step'
                 # (a residual refresh recomputes the frozen entries' residuals too: harmless, their solutions no longer move and
                 # the monitor's verdict on them is final)
-                dTAd, delta = dot_op.step(x, searchdirs[0], residual, searchfwds[0], update_r=not fresh_residual, active=active)
+                kw = {} if pre is None else {'pre': pre}
+                dTAd, delta = dot_op.step(x, searchdirs[0], residual, searchfwds[0], update_r=not fresh_residual, active=active, **kw)
+            elif pre is not None:
+                dTAd, delta = dot_op.step(x, searchdirs[0], residual, searchfwds[0], update_r=not fresh_residual, pre=pre)
             elif merged:  # both scalar products in one launch, both updates of all fields in another (or all in one)
                 dTAd, delta = dot_op.step(x, searchdirs[0], residual, searchfwds[0], update_r=not fresh_residual, one_launch=one_launch)
             else:

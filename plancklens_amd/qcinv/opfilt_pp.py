@@ -36,11 +36,14 @@ class dot_op(object):
         dev.axpy_dev(y.blm, x.blm, num, den, sign)
 
     @staticmethod
-    def step(x, d, r, q, update_r=True, one_launch=False, active=None):
+    def step(x, d, r, q, update_r=True, one_launch=False, active=None, pre=None):
         """one conjugate-directions update, all fields in two launches (or one with a grid barrier): dTAd = <d, q>, delta = <d, r>,
         x += (delta / dTAd) d and, if update_r, r -= (delta / dTAd) q; returns (dTAd, delta) as `parts` does.
-        active (block vectors): 0 / 1 per entry, multiplies the step lengths"""
+        active (block vectors): 0 / 1 per entry, multiplies the step lengths.
+        pre: the two scalar products as left by the operator that made q (fwd_op.with_dots): the updates alone, one launch"""
         f = (lambda v: [v.elm, v.blm])
+        if pre is not None:
+            return dev.cg_axpy_pre(pre, f(x), f(d), 1.0, y2=f(r) if update_r else None, x2=f(q) if update_r else None, sign2=-1.0, active=active)
         return dev.cg_dot_axpy(f(d), f(q), f(x), f(d), 1.0, b2=f(r), y2=f(r) if update_r else None, x2=f(q) if update_r else None,
                                sign2=-1.0, lmin=2, one_launch=one_launch, active=active)
 
@@ -66,6 +69,19 @@ class fwd_op(object):
 
     def __call__(self, alm):
         return self.calc(alm)
+
+    def with_dots(self, alm, r):
+        """(fwd_op(alm), pre): pre = the scalar products <alm, result> and <alm, r> as partial sums left by the kernel that writes the
+        result (dot_op.step takes them), or None where the operator is not the one-call form"""
+        f, sl = util.unjit(self.n_inv_filt), self.s_inv_filt.slinv
+        ok = (isinstance(f, alm_filter_ninv) and f.one_call_ok(alm) and not f.wmarg and not np.any(sl[:, 0, 1]) and not np.any(sl[:, 1, 0])
+              and isinstance(r, eblm) and all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.complex128 and t.is_contiguous()
+                                              and t.shape == alm.elm.shape for t in (alm.elm, alm.blm, r.elm, r.blm)))
+        if ok:
+            req = shts.post_dots([r.elm, r.blm], lmin=2)
+            q = f.apply_alm_new(alm, add=alm, fl_add_e=sl[:, 0, 0], fl_add_b=sl[:, 1, 1], dots=req)
+            return q, req.pre
+        return self.calc(alm), None
 
     def calc(self, alm):
         f, sl = util.unjit(self.n_inv_filt), self.s_inv_filt.slinv  # (the filter libraries hand over a lazily built filter)
@@ -257,7 +273,7 @@ class alm_filter_ninv(object):
         z = torch.empty((1, 1), dtype=torch.complex128, device=self.n_inv[0].device)
         return self.one_call_ok(eblm([z, z]))
 
-    def apply_alm_new(self, alm, add=None, fl_add_e=None, fl_add_b=None):
+    def apply_alm_new(self, alm, add=None, fl_add_e=None, fl_add_b=None, dots=None):
         """B^t Y^t N^-1 Y B (E, B) (+ (fl_add_e E', fl_add_b B') for add = (E', B')) as a new eblm (the input is left alone)."""
         self._load_ninv()
         lmax = alm.lmax
@@ -266,13 +282,15 @@ class alm_filter_ninv(object):
             elm, blm = shts.cg_fwd_pp(alm.elm, alm.blm, self.nside, lmax, self.n_inv[0], fl_in=self.b_transf_e,
                                       fl_out=self.b_transf_e * (npix / (4. * np.pi)),
                                       add=None if add is None else (add.elm, add.blm), fl_add_e=fl_add_e, fl_add_b=fl_add_b,
-                                      n_qu=self.n_inv[1] if len(self.n_inv) == 3 else None, n_uu=self.n_inv[2] if len(self.n_inv) == 3 else None)
+                                      n_qu=self.n_inv[1] if len(self.n_inv) == 3 else None, n_uu=self.n_inv[2] if len(self.n_inv) == 3 else None,
+                                      dots=dots)
             if self.wmarg:  # the Q / U templates: y -= V (T^t N^-1 T)^-1 V^t x on the stacked (E, B) vectors (pl_lowrank_update_b)
                 hpm, hrm = self._harm_matrices(lmax)
                 y = torch.stack([elm, blm])
                 dev.lowrank_update(y.view(-1), torch.stack([alm.elm, alm.blm]).to(torch.complex128).view(-1), hpm, hrm)
                 elm, blm = y[0], y[1]
             return eblm([elm, blm])
+        assert dots is None
         ret = self._apply_alm_steps(alm)
         if add is not None:
             dev.almxfl_add(ret.elm, add.elm, fl_add_e, out=ret.elm)

@@ -62,11 +62,14 @@ class dot_op(object):
         dev.axpy_dev(y, x, num, den, sign)
 
     @staticmethod
-    def step(x, d, r, q, update_r=True, one_launch=False, active=None):
+    def step(x, d, r, q, update_r=True, one_launch=False, active=None, pre=None):
         """one conjugate-directions update, all fields in two launches (or one with a grid barrier): dTAd = <d, q>, delta = <d, r>,
         x += (delta / dTAd) d and, if update_r, r -= (delta / dTAd) q; returns (dTAd, delta) as `parts` does.
-        active (block vectors): 0 / 1 per entry, multiplies the step lengths"""
+        active (block vectors): 0 / 1 per entry, multiplies the step lengths.
+        pre: the two scalar products as left by the operator that made q (fwd_op.with_dots): the updates alone, one launch"""
         f = (lambda v: [v])
+        if pre is not None:
+            return dev.cg_axpy_pre(pre, f(x), f(d), 1.0, y2=f(r) if update_r else None, x2=f(q) if update_r else None, sign2=-1.0, active=active)
         return dev.cg_dot_axpy(f(d), f(q), f(x), f(d), 1.0, b2=f(r), y2=f(r) if update_r else None, x2=f(q) if update_r else None,
                                sign2=-1.0, lmin=0, one_launch=one_launch, active=active)
 
@@ -93,6 +96,17 @@ class fwd_op(object):
 
     def __call__(self, talm):
         return self.calc(talm)
+
+    def with_dots(self, talm, r):
+        """(fwd_op(talm), pre): pre = the scalar products <talm, result> and <talm, r> as partial sums left by the kernel that writes the
+        result (dot_op.step takes them), or None where the operator is not the one-call form"""
+        f = util.unjit(self.n_inv_filt)
+        if (isinstance(f, alm_filter_ninv) and f.one_call_ok(talm) and f.one_call_final(talm) and isinstance(r, torch.Tensor) and r.is_cuda
+                and r.dtype == torch.complex128 and talm.dtype == torch.complex128 and r.shape == talm.shape and r.is_contiguous() and talm.is_contiguous()):
+            req = shts.post_dots([r], lmin=0)
+            q = f.apply_alm_new(talm, alm_add=talm, fl_add=self.cltt_inv, dots=req)
+            return q, req.pre
+        return self.calc(talm), None
 
     def calc(self, talm):
         f = util.unjit(self.n_inv_filt)  # (the filter libraries hand over a lazily built filter)
@@ -210,8 +224,15 @@ class alm_filter_ninv(object):
         """True when block vectors [nb, nalm] can go through this filter (they take the one-call operator only: fwd_op.calc)"""
         return self.one_call_ok(torch.empty((1, 1), dtype=torch.complex128, device=self.n_inv.device))
 
-    def apply_alm_new(self, alm, alm_add=None, fl_add=None):
-        """B^t Y^t N^-1 Y B alm (+ fl_add alm_add) as a new array (the input is left alone)."""
+    def one_call_final(self, alm):
+        """True when pl_cg_fwd_tt's result is the operator's (no update applied to it afterwards): scalar products may ride in it"""
+        if len(self.templates) != 0 and os.environ.get('PLENS_TPROJ_HARM', '1') != '0':
+            return sum(t.nmodes for t in self.templates) <= dev.TEMPLATE_MAX_MODES
+        return True
+
+    def apply_alm_new(self, alm, alm_add=None, fl_add=None, dots=None):
+        """B^t Y^t N^-1 Y B alm (+ fl_add alm_add) as a new array (the input is left alone).
+        dots (shts.post_dots, one-call forms only): scalar products of the result formed by the kernel that writes it"""
         lmax = hp.Alm.getlmax(alm.shape[-1] if isinstance(alm, torch.Tensor) else alm.size)
         fl_out = self.b_transf * (self.npix / (4. * np.pi))
         if self.one_call_ok(alm):
@@ -221,17 +242,19 @@ class alm_filter_ninv(object):
                 hpm, hrm = self._harm_matrices(lmax)
                 if hpm.shape[0] <= dev.TEMPLATE_MAX_MODES:  # one call: the coefficient pass of the update runs beside the transforms
                     return shts.cg_fwd_tt(alm, self.nside, lmax, self.n_inv, fl_in=self.b_transf, fl_out=fl_out, alm_add=alm_add, fl_add=fl_add,
-                                          lowrank=(hpm, hrm))
+                                          lowrank=(hpm, hrm), dots=dots)
+                assert dots is None
                 ret = shts.cg_fwd_tt(alm, self.nside, lmax, self.n_inv, fl_in=self.b_transf, fl_out=fl_out, alm_add=alm_add, fl_add=fl_add)
                 return dev.lowrank_update(ret, alm.to(torch.complex128).contiguous(), hpm, hrm)
             if self._md_only() and not shts.plan_all_generic(self.nside, lmax):
                 # monopole + dipole on a grid with register FFT classes: the templates come from the ring geometry, no stored maps
                 return shts.cg_fwd_tt(alm, self.nside, lmax, self.n_inv, fl_in=self.b_transf, fl_out=fl_out, pinv_md=self._pinv_md(),
-                                      alm_add=alm_add, fl_add=fl_add)
+                                      alm_add=alm_add, fl_add=fl_add, dots=dots)
             pmat, rmat = self._proj_matrices()
             nb = alm.shape[0] if alm.dim() == 2 else 1
             return shts.cg_fwd_tt(alm, self.nside, lmax, self.n_inv, fl_in=self.b_transf, fl_out=fl_out, pmat=pmat, rmat=rmat,
-                                  scratch=dev.tproj_scratch(nb) if pmat is not None else None, alm_add=alm_add, fl_add=fl_add)
+                                  scratch=dev.tproj_scratch(nb) if pmat is not None else None, alm_add=alm_add, fl_add=fl_add, dots=dots)
+        assert dots is None
         tmap = alm2map(alm, self.nside, lmax=lmax, fl=self.b_transf)
         self.apply_map(tmap)
         ret = map2alm(tmap, lmax=lmax, iter=0, fl=fl_out)

@@ -309,7 +309,30 @@ def plan_all_generic(nside, lmax):
     return bool(_lib.lib().pl_plan_fft_all_generic(get_plan(nside, lmax).h))
 
 
-def cg_fwd_tt(alm, nside, lmax, n_inv, fl_in=None, fl_out=None, pmat=None, rmat=None, scratch=None, alm_add=None, fl_add=None, pinv_md=None, lowrank=None):
+class post_dots(object):
+    """Request for the scalar products <d, q> and <d, r> of the CG step (cd_solve.py:66-84), handed to cg_fwd_tt / cg_fwd_pp (`dots=`): d is the
+    operator's input, q its result, r the listed fields (laid out as the result).  The kernel that writes q forms them on its way out
+    (pl_plan_arm_post_dots); afterwards `pre` = (pre1, pre2), per batch entry the partial sums of <d, q> and <d, r> that dev.cg_axpy_pre takes."""
+
+    def __init__(self, r, lmin=0):
+        self.r, self.lmin, self.pre = list(r), int(lmin), None
+
+
+def _arm_post_dots(plan, dots, d, nb):
+    assert len(d) == len(dots.r)
+    for t in list(d) + dots.r:
+        assert t.dtype == torch.complex128 and t.is_contiguous() and t.shape == d[0].shape and t.is_cuda, 'post_dots: fields laid out as the operator result'
+    L = _lib.lib()
+    npre = L.pl_post_dots_count(plan.h)
+    pre = torch.empty((2, nb, npre) if d[0].dim() == 2 else (2, npre), dtype=torch.float64, device=d[0].device)
+    nf = len(d)
+    pd = (ctypes.c_void_p * nf)(*[t.data_ptr() for t in d])
+    pr = (ctypes.c_void_p * nf)(*[t.data_ptr() for t in dots.r])
+    _lib.check(L.pl_plan_arm_post_dots(plan.h, nf, pd, pr, dots.lmin, _ptr(pre[0]), _ptr(pre[1])))
+    dots.pre = (pre[0], pre[1])
+
+
+def cg_fwd_tt(alm, nside, lmax, n_inv, fl_in=None, fl_out=None, pmat=None, rmat=None, scratch=None, alm_add=None, fl_add=None, pinv_md=None, lowrank=None, dots=None):
     """fl_out Y^t [N^-1 - N^-1 P (P^t N^-1 P)^-1 P^t N^-1] Y (fl_in alm) + fl_add alm_add on the device, one call (pl_cg_fwd_tt):
     fwd_op.calc of plancklens/qcinv/opfilt_tt.py:67-73.  pmat, rmat: (nmodes, npix) device matrices or None.
     lowrank = (hpm, hrm): plain weighting in pixel space and the template projection as the rank-nmodes update result -= hrm^t (hpm alm)
@@ -332,6 +355,8 @@ def cg_fwd_tt(alm, nside, lmax, n_inv, fl_in=None, fl_out=None, pmat=None, rmat=
     if alm_add is not None:
         alm_add = alm_add.contiguous()
         assert alm_add.shape == a.shape and alm_add.dtype == torch.complex128
+    if dots is not None:  # <alm, result> and <alm, dots.r> from the kernel that writes the result (one shot: consumed by the call below)
+        _arm_post_dots(plan, dots, [a], nb)
     if lowrank is not None:
         hpm, hrm = lowrank
         assert pmat is None and pinv_md is None and hpm.shape == hrm.shape and hpm.shape[1] == 2 * plan.nalm and hpm.is_contiguous() and hrm.is_contiguous()
@@ -351,7 +376,7 @@ def cg_fwd_tt(alm, nside, lmax, n_inv, fl_in=None, fl_out=None, pmat=None, rmat=
     return out
 
 
-def cg_fwd_pp(elm, blm, nside, lmax, n_inv, fl_in=None, fl_out=None, add=None, fl_add_e=None, fl_add_b=None, n_qu=None, n_uu=None):
+def cg_fwd_pp(elm, blm, nside, lmax, n_inv, fl_in=None, fl_out=None, add=None, fl_add_e=None, fl_add_b=None, n_qu=None, n_uu=None, dots=None):
     """fl_out Y2^t [n_inv Y2 (fl_in (E, B))] + (fl_add_e E_add, fl_add_b B_add) on the device, one call (pl_cg_fwd_pp): fwd_op.calc of
     plancklens/qcinv/opfilt_pp.py:69-78 for a single inverse-noise map.  Returns (elm, blm), two views of one (2, nalm) tensor."""
     plan = get_plan(nside, lmax)
@@ -368,6 +393,8 @@ def cg_fwd_pp(elm, blm, nside, lmax, n_inv, fl_in=None, fl_out=None, add=None, f
         ae, ab = add[0].contiguous(), add[1].contiguous()
         assert ae.shape == e.shape and ab.shape == e.shape and ae.dtype == torch.complex128 and ab.dtype == torch.complex128
         fe, fb = _fl_arg(fl_add_e, lmax, True), _fl_arg(fl_add_b, lmax, True)
+    if dots is not None:  # as in cg_fwd_tt, over both fields
+        _arm_post_dots(plan, dots, [e, b], nb)
     if n_qu is not None:
         _lib.check(_lib.lib().pl_cg_fwd_pp_qu_b(plan.h, nb, _ptr(e), _ptr(b), _ptr(fi), _ptr(n_inv), _ptr(n_qu), _ptr(n_uu), _ptr(ae), _ptr(ab),
                                                 _ptr(fe), _ptr(fb), _ptr(out[0]), _ptr(out[1]), _ptr(fo), _stream()))

@@ -247,3 +247,62 @@ def test_split_preconditioner_in_one_launch(lsplit, lmax):
         # block vectors keep the step-by-step route
         blk = torch.stack([multigrid._parts(x)[0]] * 2)
         assert pl.split_apply(blk if nf == 1 else util_alm.eblm([blk, blk]), lsplit, ph) is None
+
+
+@pytest.mark.parametrize('nb', [1, 3])
+def test_step_scalar_products_from_the_operator_kernels(nb):
+    """fwd_op.with_dots: the post-processing kernel of the operator's analysis (k_post0 / k_posts) leaves <d, q> and <d, r> as partial
+    sums (pl_plan_arm_post_dots); they equal the scalar products of pl_alm_dot to rounding, the result q is untouched (bit-identical),
+    and dot_op.step(pre=...) makes the updates of the step from them (pl_cg_axpy_pre_b) -- temperature with monopole + dipole
+    marginalised (the low-rank update folded into k_post0, block vectors too) and polarization."""
+    import torch
+    from plancklens_amd import dev, hp
+    from plancklens_amd.qcinv import opfilt_pp, opfilt_tt
+    from plancklens_amd.qcinv.util_alm import eblm
+    rng = np.random.default_rng(11)
+    nside, lmax = 64, 128
+    npix, nalm = 12 * nside ** 2, hp.Alm.getsize(lmax)
+    ell = np.arange(lmax + 1.)
+    cl = {'tt': np.where(ell >= 1, 1e3 / np.maximum(ell, 1) ** 2, 1.), 'ee': np.where(ell >= 2, 30. / np.maximum(ell, 1) ** 2, 0.),
+          'bb': np.where(ell >= 2, 3. / np.maximum(ell, 1) ** 2, 0.)}
+    transf = hp.gauss_beam(30. / 60 / 180 * np.pi, lmax=lmax)
+    z = hp.pix2vec(nside, np.arange(npix))[2]
+    ninv = (np.abs(z) > 0.3) * (1. + 0.5 * rng.random(npix))
+
+    def vec(shape_nb):
+        v = rng.standard_normal((shape_nb, nalm)) + 1j * rng.standard_normal((shape_nb, nalm))
+        v[:, :lmax + 1].imag = 0.
+        return dev.to_dev(v[0] if nb == 1 else v, torch.complex128).contiguous()
+
+    def tot(parts):
+        return dev.to_host(parts.sum(-1))
+
+    # temperature
+    ft = opfilt_tt.alm_filter_ninv(ninv, transf, marge_monopole=True, marge_dipole=True)
+    op, dot = opfilt_tt.fwd_op(cl, ft), opfilt_tt.dot_op()
+    d, r, x = vec(nb), vec(nb), vec(nb)
+    q_ref = op(d)
+    q, pre = op.with_dots(d, r)
+    assert pre is not None and torch.equal(q, q_ref)
+    np.testing.assert_allclose(tot(pre[0]), tot(dot.parts(d, q)), rtol=1e-12)
+    np.testing.assert_allclose(tot(pre[1]), tot(dot.parts(d, r)), rtol=1e-12, atol=1e-9 * abs(tot(dot.parts(d, d))).max())
+    x1, r1, x2, r2 = x.clone(), r.clone(), x.clone(), r.clone()
+    dtad1, delta1 = dot.step(x1, d, r1, q)
+    dtad2, delta2 = dot.step(x2, d, r2, q, pre=pre)
+    np.testing.assert_allclose(tot(dtad2), tot(dtad1), rtol=1e-12)
+    assert relrms(dev.to_host(x2), dev.to_host(x1)) < 1e-12 and relrms(dev.to_host(r2), dev.to_host(r1)) < 1e-12
+    # polarization
+    fp = opfilt_pp.alm_filter_ninv([ninv], transf)
+    opp, dotp = opfilt_pp.fwd_op(cl, fp), opfilt_pp.dot_op()
+    mk = lambda: eblm([vec(nb), vec(nb)])
+    d, r, x = mk(), mk(), mk()
+    q_ref = opp(d)
+    q, pre = opp.with_dots(d, r)
+    assert pre is not None and torch.equal(q.elm, q_ref.elm) and torch.equal(q.blm, q_ref.blm)
+    np.testing.assert_allclose(tot(pre[0]), tot(dotp.parts(d, q)), rtol=1e-12)
+    np.testing.assert_allclose(tot(pre[1]), tot(dotp.parts(d, r)), rtol=1e-12, atol=1e-9 * abs(tot(dotp.parts(d, d))).max())
+    cp = lambda v: eblm([v.elm.clone(), v.blm.clone()])
+    x1, r1, x2, r2 = cp(x), cp(r), cp(x), cp(r)
+    dotp.step(x1, d, r1, q)
+    dotp.step(x2, d, r2, q, pre=pre)
+    assert relrms(dev.to_host(x2.elm), dev.to_host(x1.elm)) < 1e-12 and relrms(dev.to_host(r2.blm), dev.to_host(r1.blm)) < 1e-12
