@@ -276,6 +276,18 @@ int pl_gemv(int nrows, int ncols, int64_t lda, const double *A, const double *x,
 int pl_gemv_split(int nf, int lmax_lo, int lmax_hi, int64_t lda, const double *A, const double *const *alm_hi, const int *map_dev,
                   const double *const *fl_hi, double *const *alm_out, void *stream);
 
+/* The preconditioner kernels that write the new search direction s of cd_solve.py:93-103 also form <s, q'> (q': the operator applied to the
+ * previous direction), so that the re-orthogonalisation needs no scalar-product launch of its own (pl_cg_axpy_pre_b takes the partial sums):
+ * pl_gemv_split_dot = pl_gemv_split + pl_gemv_split_dot_count(nf, lmax_lo, lmax_hi) partial sums of sum_f <alm_out[f], q[f]> in pre_dev;
+ * pl_alm_splice_dot_b = pl_alm_splice_b (fl_hi may be NULL) + pl_alm_splice_dot_count(lmax_hi) partial sums per batch entry of <out, q>.
+ * Weights of pl_alm_dot, entries l < lmin excluded; q laid out as the output. */
+int pl_gemv_split_dot_count(int nf, int lmax_lo, int lmax_hi);
+int pl_alm_splice_dot_count(int lmax_hi);
+int pl_gemv_split_dot(int nf, int lmax_lo, int lmax_hi, int64_t lda, const double *A, const double *const *alm_hi, const int *map_dev,
+                      const double *const *fl_hi, double *const *alm_out, const double *const *q, int lmin, double *pre_dev, void *stream);
+int pl_alm_splice_dot_b(int lmax_lo, int nb, const double *alm_lo, int lmax_hi, const double *alm_hi, const double *fl_hi, int lsplit, double *out,
+                        const double *q, int lmin, double *pre_dev, void *stream);
+
 /* Copy of ndoubles doubles from device memory to `dst` -- device memory or pinned (device-mapped) host memory -- by a kernel of
  * `nblocks` workgroups on `stream` (16-byte aligned pointers).  Used for the estimator outputs (the reference writes them
  * to disk, qest.py:325-331): a few workgroups saturate PCIe with posted writes and leave the compute units to the kernels of the

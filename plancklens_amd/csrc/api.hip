@@ -47,13 +47,15 @@ void launch_cg_axpy_pre(int nf, const int *lmax, int npre, const double *pre1, c
                         double *const *y1, const double *const *x1, double sign1, double *const *y2, const double *const *x2, double sign2, hipStream_t st,
                         int nbatch, const double *active);
 void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st,
-                       const double *fl_hi = nullptr, int nb = 1);
+                       const double *fl_hi = nullptr, int nb = 1, const double *dot_q = nullptr, int dot_lmin = 0, double *dot_pre = nullptr);
+int alm_splice_dot_count(int lmax_hi);
+int gemv_split_dot_count(int nf, int lmax_lo, int lmax_hi);
 void launch_template_project(int64_t n, int nmodes, double *t, const double *n_inv, const double *pm, const double *rm, double *parts, hipStream_t st,
                              int nb = 1, double *t_apply = nullptr, int phase = 0);
 void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st, int nb = 1);
 void launch_gemv(int nrows, int ncols, int64_t lda, const double *A, const double *x, double *y, hipStream_t st);
 void launch_gemv_split(int nf, int64_t lda, const double *A, const double *const *hi, const int *map, int lmax_lo, int lmax_hi, const double *const *fl_hi,
-                       double *const *out, hipStream_t st);
+                       double *const *out, hipStream_t st, const double *const *dot_q = nullptr, int dot_lmin = 0, double *dot_pre = nullptr);
 void launch_gemv_nb(int nrows, int ncols, int64_t lda, const double *A, int nb, const double *x, double *y, hipStream_t st);
 void launch_copy_slim(const double *src, double *dst, int64_t ndoubles, int nblocks, hipStream_t st);
 void launch_map_mul(int64_t n, const double *a, const double *b, double *out, hipStream_t st);
@@ -1209,6 +1211,38 @@ int pl_gemv_split(int nf, int lmax_lo, int lmax_hi, int64_t lda, const double *A
     const int nrows = nf * (lmax_lo + 1) * (lmax_lo + 2);
     if (lda < nrows || (lda & 1) || (reinterpret_cast<uintptr_t>(A) & 15)) return fail("pl_gemv_split: the matrix must be 16-byte aligned with an even row stride");
     launch_gemv_split(nf, lda, A, alm_hi, map_dev, lmax_lo, lmax_hi, fl_hi, alm_out, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_gemv_split_dot_count(int nf, int lmax_lo, int lmax_hi) { return gemv_split_dot_count(nf, lmax_lo, lmax_hi); }
+int pl_alm_splice_dot_count(int lmax_hi) { return alm_splice_dot_count(lmax_hi); }
+
+// pl_gemv_split that also leaves pl_gemv_split_dot_count(nf, lmax_lo, lmax_hi) partial sums of sum_f <alm_out[f], q[f]> in pre_dev
+int pl_gemv_split_dot(int nf, int lmax_lo, int lmax_hi, int64_t lda, const double *A, const double *const *alm_hi, const int *map_dev,
+                      const double *const *fl_hi, double *const *alm_out, const double *const *q, int lmin, double *pre_dev, void *stream)
+{
+    if (nf < 1 || nf > 2 || lmax_lo < 0 || lmax_hi <= lmax_lo || !A || !alm_hi || !map_dev || !fl_hi || !alm_out || !q || !pre_dev)
+        return fail("pl_gemv_split_dot: bad arguments");
+    for (int f = 0; f < nf; ++f) {
+        if (!alm_hi[f] || !fl_hi[f] || !alm_out[f] || !q[f]) return fail("pl_gemv_split_dot: null field pointer");
+        for (int g = 0; g < nf; ++g) if (alm_out[f] == alm_hi[g]) return fail("pl_gemv_split_dot: output aliases an input");
+    }
+    const int nrows = nf * (lmax_lo + 1) * (lmax_lo + 2);
+    if (lda < nrows || (lda & 1) || (reinterpret_cast<uintptr_t>(A) & 15)) return fail("pl_gemv_split_dot: the matrix must be 16-byte aligned with an even row stride");
+    launch_gemv_split(nf, lda, A, alm_hi, map_dev, lmax_lo, lmax_hi, fl_hi, alm_out, static_cast<hipStream_t>(stream), q, lmin < 0 ? 0 : lmin, pre_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// pl_alm_splice_b (fl_hi may be NULL) that also leaves, per batch entry, pl_alm_splice_dot_count(lmax_hi) partial sums of <out, q> in pre_dev
+int pl_alm_splice_dot_b(int lmax_lo, int nb, const double *alm_lo, int lmax_hi, const double *alm_hi, const double *fl_hi, int lsplit, double *out,
+                        const double *q, int lmin, double *pre_dev, void *stream)
+{
+    PL_NB_CHECK("pl_alm_splice_dot_b");
+    if (lsplit > lmax_lo || lsplit > lmax_hi || lmax_hi < 0) return fail("pl_alm_splice_dot_b: lsplit exceeds a band-limit");
+    if (!q || !pre_dev) return fail("pl_alm_splice_dot_b: null q / pre_dev");
+    launch_alm_splice(lmax_lo, alm_lo, lmax_hi, alm_hi, lsplit, out, static_cast<hipStream_t>(stream), fl_hi, nb, q, lmin < 0 ? 0 : lmin, pre_dev);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -656,6 +656,17 @@ __global__ __launch_bounds__(256) void k_tproj_md_apply(DevPlan P, int nb, doubl
     }
 }
 
+// One partial sum per workgroup of 256 threads, fixed tree (lanes by shuffles, then the four wave sums): the share of this workgroup in a scalar
+// product that the kernel forms about the vector it writes (k_gemv_split, k_alm_splice: <s, q'> of cd_solve.py:96-103 without a launch of its own)
+__device__ __forceinline__ void wg256_sum_store(double t, double *red4, double *dst)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) *dst = (red4[0] + red4[1]) + (red4[2] + red4[3]);
+}
+
 // ---- dense mat-vec y = A x (the dense coarse preconditioner, dense.py:118-119,201-202,284-285) -------------------------
 // A row-major (nrows x ncols, leading dimension lda).  One wavefront per row: every trip the wave reads 1 KiB of the row
 // with 16-byte loads per lane (VEC = 2), four trips in flight; x comes from L2 / L1 (34 KiB at the 4290-column T block).
@@ -715,10 +726,13 @@ __global__ __launch_bounds__(256) void k_gemv(int nrows, int ncols, int64_t lda,
 // of entry e of the lmax_lo layout.  Workgroups [0, ngemv) are those of k_gemv<2> -- same lane partition, chains and tree, so the low
 // part is bit-identical to alm_copy + k_gemv<2> + k_alm_splice -- the others write the high part.
 struct SplitFields { const double2 *hi[2]; double2 *out[2]; const double *fl[2]; };
+// optional: pre[workgroup] = this workgroup's share of sum over the fields of <out, q> (weights of k_alm_dot_parts, l < lmin excluded)
+struct SplitDot { const double2 *q[2] = {nullptr, nullptr}; double *pre = nullptr; int lmin = 0; };
 template <int NF>
 __global__ __launch_bounds__(256) void k_gemv_split(int nrows, int64_t lda, const double *__restrict__ A, SplitFields F, const int *__restrict__ map,
-                                                    int lmax_lo, int lmax_hi, int ngemv)
+                                                    int lmax_lo, int lmax_hi, int ngemv, SplitDot D)
 {
+    __shared__ double red4[4];
     const int lane = threadIdx.x & 63;
     const int nlo = (lmax_lo + 1) * (lmax_lo + 2) / 2;  // complex entries of one field at lmax_lo
     if ((int)blockIdx.x >= ngemv) {  // high multipoles: 4 workgroups per (field, m), as k_alm_splice
@@ -728,15 +742,22 @@ __global__ __launch_bounds__(256) void k_gemv_split(int nrows, int64_t lda, cons
         const double2 *__restrict__ hi = F.hi[f];
         const double *__restrict__ fl = F.fl[f];
         double2 *__restrict__ out = F.out[f];
+        double t = 0.0;
         for (int l = lstart + (bb & 3) * 256 + threadIdx.x; l <= lmax_hi; l += 4 * 256) {
             double2 v = hi[bh + l];
             v.x *= fl[l]; v.y *= fl[l];
             out[bh + l] = v;
+            if (D.pre && l >= D.lmin) { const double2 qv = D.q[f][bh + l]; t = fma(m == 0 ? 1.0 : 2.0, v.x * qv.x + v.y * qv.y, t); }
         }
+        if (D.pre) wg256_sum_store(t, red4, D.pre + blockIdx.x);
         return;
     }
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= nrows) return;
+    const int row_ = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row_ >= nrows) {  // (the last workgroup of the mat-vec part may hold fewer than four rows)
+        if (D.pre) wg256_sum_store(0.0, red4, D.pre + blockIdx.x);
+        return;
+    }
+    const int row = row_;
     const double2 *__restrict__ a2 = reinterpret_cast<const double2 *>(A + (int64_t)row * lda);
     // entry c of the concatenated low-band-limit vector [field 0 | field 1]: read in place from the field's full array
     auto x = [&](int c) -> double2 {
@@ -772,10 +793,14 @@ __global__ __launch_bounds__(256) void k_gemv_split(int nrows, int64_t lda, cons
     double v = (s0 + s1) + (s2 + s3);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    double t = 0.0;
     if (lane == 0) {
         const int f = NF == 1 ? 0 : row / (2 * nlo), r = row - f * 2 * nlo;
-        reinterpret_cast<double *>(F.out[f])[2 * (int64_t)map[r >> 1] + (r & 1)] = v;
+        const int64_t o = 2 * (int64_t)map[r >> 1] + (r & 1);
+        reinterpret_cast<double *>(F.out[f])[o] = v;
+        if (D.pre) t = alm_dot_weight(lmax_lo, D.lmin, r >> 1) * (v * reinterpret_cast<const double *>(D.q[f])[o]);
     }
+    if (D.pre) wg256_sum_store(t, red4, D.pre + blockIdx.x);
 }
 
 // The same for NB right-hand sides at once (Y[b] = A X[b], X: [nb][ncols], Y: [nb][nrows]): the block vectors of a batched
@@ -841,9 +866,13 @@ __global__ __launch_bounds__(256) void k_gemv_nb(int nrows, int ncols, int64_t l
 // out (band-limit lmax_hi) = alm_lo for l <= lsplit, alm_hi above (util_alm.py:8-24)
 // fl_hi (optional, lmax_hi + 1 entries): the high part is fl_hi[l] * alm_hi -- the diagonal preconditioner of pre_op_split's high
 // multipoles (multigrid.py:163-182 with opfilt_tt.py:76-93) applied on the way
+// dot_q / dot_pre (optional): dot_pre[(batch entry, m, workgroup of the m)] = this workgroup's share of <out, dot_q> (weights of k_alm_dot_parts)
 __global__ void k_alm_splice(int lmax_lo, const double2 *__restrict__ lo_, int lmax_hi, const double2 *__restrict__ hi_, int lsplit,
-                             double2 *__restrict__ out_, const double *__restrict__ fl_hi)
+                             double2 *__restrict__ out_, const double *__restrict__ fl_hi, const double2 *__restrict__ dot_q, int dot_lmin,
+                             double *__restrict__ dot_pre)
 {
+    __shared__ double red4[4];
+    double t = 0.0;
     const double2 *__restrict__ lo = lo_ + blockIdx.z * alm_count(lmax_lo), *__restrict__ hi = hi_ + blockIdx.z * alm_count(lmax_hi);
     double2 *__restrict__ out = out_ + blockIdx.z * alm_count(lmax_hi);
     const int m = blockIdx.y;
@@ -857,7 +886,12 @@ __global__ void k_alm_splice(int lmax_lo, const double2 *__restrict__ lo_, int l
             if (fl_hi) { v.x *= fl_hi[l]; v.y *= fl_hi[l]; }
         }
         out[bh + l] = v;
+        if (dot_pre && l >= dot_lmin) {
+            const double2 qv = dot_q[blockIdx.z * alm_count(lmax_hi) + bh + l];
+            t = fma(m == 0 ? 1.0 : 2.0, v.x * qv.x + v.y * qv.y, t);
+        }
     }
+    if (dot_pre) wg256_sum_store(t, red4, dot_pre + ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
 }
 
 // out = a + f_l b (fwd_op: N-part + S^-1 x, opfilt_tt.py:67-73); out may alias a
@@ -1095,16 +1129,19 @@ void launch_gemv(int nrows, int ncols, int64_t lda, const double *A, const doubl
     if (vec) hipLaunchKernelGGL(k_gemv<2>, dim3((nrows + 3) / 4), dim3(256), 0, st, nrows, ncols, lda, A, x, y);
     else hipLaunchKernelGGL(k_gemv<1>, dim3((nrows + 3) / 4), dim3(256), 0, st, nrows, ncols, lda, A, x, y);
 }
+int gemv_split_dot_count(int nf, int lmax_lo, int lmax_hi) { return (nf * (lmax_lo + 1) * (lmax_lo + 2) + 3) / 4 + nf * 4 * (lmax_hi + 1); }
 void launch_gemv_split(int nf, int64_t lda, const double *A, const double *const *hi, const int *map, int lmax_lo, int lmax_hi, const double *const *fl_hi,
-                       double *const *out, hipStream_t st)
+                       double *const *out, hipStream_t st, const double *const *dot_q, int dot_lmin, double *dot_pre)
 {
+    SplitDot D;
+    if (dot_pre) { for (int f = 0; f < nf; ++f) D.q[f] = reinterpret_cast<const double2 *>(dot_q[f]); D.pre = dot_pre; D.lmin = dot_lmin; }
     const int nrows = nf * (lmax_lo + 1) * (lmax_lo + 2);
     const int ngemv = (nrows + 3) / 4;
     SplitFields F = {};
     for (int f = 0; f < nf; ++f) { F.hi[f] = reinterpret_cast<const double2 *>(hi[f]); F.out[f] = reinterpret_cast<double2 *>(out[f]); F.fl[f] = fl_hi[f]; }
     const dim3 grid(ngemv + nf * 4 * (lmax_hi + 1));
-    if (nf == 1) hipLaunchKernelGGL(k_gemv_split<1>, grid, dim3(256), 0, st, nrows, lda, A, F, map, lmax_lo, lmax_hi, ngemv);
-    else hipLaunchKernelGGL(k_gemv_split<2>, grid, dim3(256), 0, st, nrows, lda, A, F, map, lmax_lo, lmax_hi, ngemv);
+    if (nf == 1) hipLaunchKernelGGL(k_gemv_split<1>, grid, dim3(256), 0, st, nrows, lda, A, F, map, lmax_lo, lmax_hi, ngemv, D);
+    else hipLaunchKernelGGL(k_gemv_split<2>, grid, dim3(256), 0, st, nrows, lda, A, F, map, lmax_lo, lmax_hi, ngemv, D);
 }
 // nb right-hand sides: x [nb][ncols] -> y [nb][nrows]
 void launch_gemv_nb(int nrows, int ncols, int64_t lda, const double *A, int nb, const double *x, double *y, hipStream_t st)
@@ -1123,11 +1160,13 @@ void launch_gemv_nb(int nrows, int ncols, int64_t lda, const double *A, int nb, 
         else hipLaunchKernelGGL(k_gemv_nb<8>, dim3((nrows + 3) / 4), dim3(256), 0, st, nrows, ncols, lda, A, n, xb, yb);
     }
 }
+int alm_splice_dot_count(int lmax_hi) { return 4 * (lmax_hi + 1); }
 void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st,
-                       const double *fl_hi, int nb)
+                       const double *fl_hi, int nb, const double *dot_q, int dot_lmin, double *dot_pre)
 {
     hipLaunchKernelGGL(k_alm_splice, dim3(4, lmax_hi + 1, nb), dim3(256), 0, st, lmax_lo, reinterpret_cast<const double2 *>(lo), lmax_hi,
-                       reinterpret_cast<const double2 *>(hi), lsplit, reinterpret_cast<double2 *>(out), fl_hi);
+                       reinterpret_cast<const double2 *>(hi), lsplit, reinterpret_cast<double2 *>(out), fl_hi,
+                       reinterpret_cast<const double2 *>(dot_q), dot_lmin, dot_pre);
 }
 void launch_almxfl_add(int lmax, const double *a, const double *b, const double *fl, int nfl, double *out, hipStream_t st, int nb)
 {

@@ -223,15 +223,28 @@ def alm_splice(alm_lo, alm_hi, lsplit):
     return alm_splice_fl(alm_lo, alm_hi, None, lsplit)
 
 
-def alm_splice_fl(alm_lo, alm_hi, fl_hi, lsplit):
-    """alm_lo for l <= lsplit, fl_hi[l] * alm_hi above (fl_hi None: alm_hi); band-limit of alm_hi (pl_alm_splice / _fl / _b)."""
+def alm_splice_dot_count(lmax_hi):
+    """partial sums per batch entry that alm_splice_fl(dot=...) leaves"""
+    return int(_lib.lib().pl_alm_splice_dot_count(int(lmax_hi)))
+
+
+def alm_splice_fl(alm_lo, alm_hi, fl_hi, lsplit, dot=None):
+    """alm_lo for l <= lsplit, fl_hi[l] * alm_hi above (fl_hi None: alm_hi); band-limit of alm_hi (pl_alm_splice / _fl / _b).
+    dot = (q, lmin, pre): the kernel also leaves the partial sums of <result, q> in the float64 device tensor `pre`
+    ([alm_splice_dot_count] or [nb, ...]; pl_alm_splice_dot_b) -- what cg_axpy_pre takes."""
     nb = _same_block(alm_lo, alm_hi)
     lmax_lo, lmax_hi = Alm.getlmax(bshape(alm_lo)[1]), Alm.getlmax(bshape(alm_hi)[1])
     assert lmax_lo >= lsplit and lmax_hi >= lsplit, (lmax_lo, lmax_hi, lsplit)
     out = torch.empty_like(alm_hi)
     f = None if fl_hi is None else fl_dev(fl_hi, lmax_hi).data_ptr()
     L = _lib.lib()
-    if alm_hi.dim() == 2:
+    if dot is not None:
+        q, lmin, pre = dot
+        assert q.shape == alm_hi.shape and q.dtype == torch.complex128 and q.is_contiguous() and alm_hi.dtype == torch.complex128
+        assert pre.dtype == torch.float64 and pre.is_contiguous() and pre.numel() == nb * alm_splice_dot_count(lmax_hi)
+        _lib.check(L.pl_alm_splice_dot_b(lmax_lo, nb, alm_lo.data_ptr(), lmax_hi, alm_hi.data_ptr(), f, int(lsplit), out.data_ptr(), q.data_ptr(), int(lmin),
+                                         pre.data_ptr(), stream_ptr()))
+    elif alm_hi.dim() == 2:
         _lib.check(L.pl_alm_splice_b(lmax_lo, nb, alm_lo.data_ptr(), lmax_hi, alm_hi.data_ptr(), f, int(lsplit), out.data_ptr(), stream_ptr()))
     elif f is None:
         _lib.check(L.pl_alm_splice(lmax_lo, alm_lo.data_ptr(), lmax_hi, alm_hi.data_ptr(), int(lsplit), out.data_ptr(), stream_ptr()))
@@ -479,10 +492,11 @@ def gemv(amat, x, out=None):
 _SPLIT_MAP = {}
 
 
-def gemv_split(amat, alms_hi, lmax_lo, fls_hi):
+def gemv_split(amat, alms_hi, lmax_lo, fls_hi, dot=None):
     """pre_op_split in one launch (pl_gemv_split) for the fields alms_hi (one tensor, or two: E and B) with their high-l filters fls_hi:
     per field [rows of amat ([fields] truncated to lmax_lo) for l <= lmax_lo | fl_hi alm_hi above], band-limit of the inputs.
-    amat: pre_op_dense's flat matrix for these fields at lmax_lo.  Returns the list of output tensors."""
+    amat: pre_op_dense's flat matrix for these fields at lmax_lo.  Returns the list of output tensors.
+    dot = (qs, lmin): also the partial sums of sum_f <out[f], qs[f]> (pl_gemv_split_dot); returns (outs, pre)."""
     nf = len(alms_hi)
     lmax_hi = Alm.getlmax(alms_hi[0].shape[0])
     n = nf * (lmax_lo + 1) * (lmax_lo + 2)
@@ -498,6 +512,13 @@ def gemv_split(amat, alms_hi, lmax_lo, fls_hi):
         _SPLIT_MAP[key] = torch.from_numpy((m * (2 * lmax_hi + 1 - m) // 2 + l).astype(np.int32)).to(device())
     outs = [torch.empty_like(a) for a in alms_hi]
     fls = [fl_dev(f, lmax_hi) for f in fls_hi]
+    if dot is not None:
+        qs, lmin = dot
+        assert len(qs) == nf and all(q.shape == alms_hi[0].shape and q.dtype == torch.complex128 and q.is_contiguous() for q in qs)
+        pre = torch.empty(_lib.lib().pl_gemv_split_dot_count(nf, int(lmax_lo), int(lmax_hi)), dtype=torch.float64, device=device())
+        _lib.check(_lib.lib().pl_gemv_split_dot(nf, int(lmax_lo), int(lmax_hi), n, amat.data_ptr(), _ptr_array(alms_hi), _SPLIT_MAP[key].data_ptr(),
+                                                _ptr_array(fls), _ptr_array(outs), _ptr_array(qs), int(lmin), pre.data_ptr(), stream_ptr()))
+        return outs, pre
     _lib.check(_lib.lib().pl_gemv_split(nf, int(lmax_lo), int(lmax_hi), n, amat.data_ptr(), _ptr_array(alms_hi), _SPLIT_MAP[key].data_ptr(),
                                         _ptr_array(fls), _ptr_array(outs), stream_ptr()))
     return outs

@@ -128,7 +128,18 @@ def _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_i
             if criterion(it, x, residual):
                 cache.trim(range(tr(it + 1), it))
                 return it
-            searchdirs = [op(residual) for op in pre_ops]
+            # one past direction to orthogonalise against (tr_cg) and a preconditioner whose last kernel can form <s, q'> on its way out:
+            # the re-orthogonalisation is its update alone
+            if post_dots and tr(it) == it - 1 and hasattr(pre_ops[0], 'with_dot') and hasattr(dot_op, 'lmin'):
+                prev_dTAd, prev_dirs, prev_fwds = cache.restore(it - 1)
+                s, opre = pre_ops[0].with_dot(residual, prev_fwds[0], dot_op.lmin)
+                searchdirs = [s]
+                if opre is not None:
+                    dot_op.ortho(s, prev_fwds[0], prev_dirs[0], prev_dTAd, pre=opre)
+                    cache.trim(range(tr(it + 1), it))
+                    continue
+            else:
+                searchdirs = [op(residual) for op in pre_ops]
             for titer in range(tr(it), it):
                 prev_dTAd, prev_dirs, prev_fwds = cache.restore(titer)
                 if merged:

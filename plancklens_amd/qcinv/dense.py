@@ -194,10 +194,11 @@ class _pre_op_dense(object):
     def __call__(self, talm):
         return self.calc(talm)
 
-    def split_apply(self, talm, lsplit, pre_op_hgh):
+    def split_apply(self, talm, lsplit, pre_op_hgh, dot=None):
         """pre_op_split's whole result for a device vector of a higher band-limit -- truncation to lsplit, this dense block, the diagonal
         preconditioner of pre_op_hgh above lsplit and the splice in one launch (pl_gemv_split) -- or None when that form does not apply
-        (block vectors, host vectors, three fields, a high-l preconditioner that couples fields)"""
+        (block vectors, host vectors, three fields, a high-l preconditioner that couples fields).
+        dot = (q, lmin): returns (result, pre) with the partial sums of <result, q> formed by the same launch"""
         parts = _parts(talm)
         if len(parts) == 1 and hasattr(pre_op_hgh, 'filt'):
             fls = [pre_op_hgh.filt]
@@ -215,6 +216,9 @@ class _pre_op_dense(object):
             self._amat = _flat_matrix(self.minv, self.lmax, len(parts))
         if self._amat.shape[0] != len(parts) * (self.lmax + 1) * (self.lmax + 2):
             return None
+        if dot is not None:
+            res, pre = dev.gemv_split(self._amat, parts, lsplit, fls, dot=(_parts(dot[0]), dot[1]))
+            return (res[0] if len(res) == 1 else eblm(res)), pre
         res = dev.gemv_split(self._amat, parts, lsplit, fls)
         return res[0] if len(res) == 1 else eblm(res)
 

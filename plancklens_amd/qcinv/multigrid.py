@@ -141,11 +141,21 @@ class pace(object):
             self.cond.notify_all()
 
 
-def _paced(op, pc):
-    def call(v):
-        pc.wait()
-        return op(v)
-    return call
+class _paced(object):
+    """a preconditioner that meets the other solve at `pc` before it runs"""
+
+    def __init__(self, op, pc):
+        self.op, self.pc = op, pc
+        if hasattr(op, 'with_dot'):
+            self.with_dot = self._with_dot
+
+    def __call__(self, v):
+        self.pc.wait()
+        return self.op(v)
+
+    def _with_dot(self, v, q, lmin):
+        self.pc.wait()
+        return self.op.with_dot(v, q, lmin)
 
 
 def parse_pre_op_descr(pre_op_descr, **kwargs):
@@ -194,6 +204,29 @@ class pre_op_split(object):
 
     def __call__(self, talm):
         return self.calc(talm)
+
+    def with_dot(self, talm, q, lmin):
+        """(calc(talm), pre): pre = the partial sums of <result, q> left by the kernel that writes the result (the one-launch split around
+        the dense block, or the splice with the diagonal high-l part), for dot_op.ortho(pre=...); None where neither form applies"""
+        if _lmax_of(talm) != self.lmax or _lmax_of(q) != self.lmax or _is_block(talm) != _is_block(q):
+            return self.calc(talm), None
+        if hasattr(self.pre_op_low, 'split_apply'):
+            self.iter += 1
+            ret = self.pre_op_low.split_apply(talm, self.lsplit, self.pre_op_hgh, dot=(q, lmin))
+            if ret is not None:
+                return ret
+            self.iter -= 1
+            return self.calc(talm), None
+        if hasattr(self.pre_op_hgh, 'splice_above') and all(isinstance(p, torch.Tensor) and p.is_cuda and p.dtype == torch.complex128 and p.is_contiguous()
+                                                            for p in _parts(talm) + _parts(q)):
+            self.iter += 1
+            talm_low = self.pre_op_low(util_alm.alm_copy(talm, lmax=self.lsplit))
+            ret = self.pre_op_hgh.splice_above(talm_low, talm, self.lsplit, dot=(q, lmin))
+            if ret is not None:
+                return ret
+            talm_hgh = self.pre_op_hgh(talm)
+            return util_alm.alm_splice(talm_low, talm_hgh, self.lsplit), None
+        return self.calc(talm), None
 
     def calc(self, talm):
         self.iter += 1

@@ -18,6 +18,7 @@ alm2map_spin, map2alm_spin = shts.alm2map_spin, shts.map2alm_spin
 
 class dot_op(object):
     """sum_{l >= 2} (2l + 1) (C_l^{EE'} + C_l^{BB'})."""
+    lmin = 2  # first multipole of the sum
 
     def parts(self, alm1, alm2):
         """the scalar product as dev.DOT_PARTS partial sums in device memory (one launch per field, no host synchronisation);
@@ -48,9 +49,13 @@ class dot_op(object):
                                sign2=-1.0, lmin=2, one_launch=one_launch, active=active)
 
     @staticmethod
-    def ortho(s, pq, pd, prev_dtad, one_launch=False):
-        """s -= (<s, pq> / prev_dtad) pd, all fields in two launches (or one with a grid barrier)"""
+    def ortho(s, pq, pd, prev_dtad, one_launch=False, pre=None):
+        """s -= (<s, pq> / prev_dtad) pd, all fields in two launches (or one with a grid barrier).
+        pre: <s, pq> as partial sums left by the preconditioner kernel(s) that wrote s (pre_op.with_dot): the update alone"""
         f = (lambda v: [v.elm, v.blm])
+        if pre is not None:
+            dev.cg_axpy_pre((pre, None), f(s), f(pd), -1.0, den=prev_dtad)
+            return
         dev.cg_dot_axpy(f(s), f(pq), f(s), f(pd), -1.0, den=prev_dtad, lmin=2, one_launch=one_launch)
 
     def __call__(self, alm1, alm2):
@@ -124,12 +129,28 @@ class pre_op_diag(object):
     def calc(self, alm):
         return _apply_2x2(self.flmat, alm)
 
-    def splice_above(self, alm_low, alm, lsplit):
+    def splice_above(self, alm_low, alm, lsplit, dot=None):
         """alm_low for l <= lsplit, this preconditioner applied to alm above: pre_op_split's result in one launch per field
-        (None: not here -- host vectors, or E-B coupling in the spectra)"""
+        (None: not here -- host vectors, or E-B coupling in the spectra).
+        dot = (q, lmin): returns (result, pre), pre the partial sums of <result, q> formed by the same launches (E's, then B's)"""
         fm = self.flmat
         if np.any(fm[:, 0, 1]) or np.any(fm[:, 1, 0]) or not (isinstance(alm.elm, torch.Tensor) and alm.elm.is_cuda):
             return None
+        if dot is not None:
+            q, lmin = dot
+            n = dev.alm_splice_dot_count(alm.lmax)
+            blk = alm.elm.dim() == 2
+            pre = torch.empty((alm.elm.shape[0], 2, n) if blk else (2, n), dtype=torch.float64, device=alm.elm.device)
+            if blk:  # per entry [E partial sums | B partial sums]: each launch fills its half through a contiguous scratch
+                pe, pb = torch.empty((alm.elm.shape[0], n), dtype=torch.float64, device=pre.device), torch.empty((alm.elm.shape[0], n), dtype=torch.float64, device=pre.device)
+            else:
+                pe, pb = pre[0], pre[1]
+            ret = eblm([dev.alm_splice_fl(alm_low.elm, alm.elm, fm[:, 0, 0], lsplit, dot=(q.elm, lmin, pe)),
+                        dev.alm_splice_fl(alm_low.blm, alm.blm, fm[:, 1, 1], lsplit, dot=(q.blm, lmin, pb))])
+            if blk:
+                pre[:, 0].copy_(pe)
+                pre[:, 1].copy_(pb)
+            return ret, pre.reshape(alm.elm.shape[0], 2 * n) if blk else pre.reshape(2 * n)
         return eblm([dev.alm_splice_fl(alm_low.elm, alm.elm, fm[:, 0, 0], lsplit), dev.alm_splice_fl(alm_low.blm, alm.blm, fm[:, 1, 1], lsplit)])
 
 

@@ -45,6 +45,7 @@ def apply_fini(alm, s_cls, n_inv_filt):
 
 class dot_op(object):
     """sum_l (2l + 1) C_l^{ab}: the scalar product of the CG (opfilt_tt.py:43-51)."""
+    lmin = 0  # first multipole of the sum
 
     def parts(self, alm1, alm2):
         """the scalar product as dev.DOT_PARTS partial sums in device memory (one launch per field, no host synchronisation);
@@ -74,9 +75,13 @@ class dot_op(object):
                                sign2=-1.0, lmin=0, one_launch=one_launch, active=active)
 
     @staticmethod
-    def ortho(s, pq, pd, prev_dtad, one_launch=False):
-        """s -= (<s, pq> / prev_dtad) pd, all fields in two launches (or one with a grid barrier)"""
+    def ortho(s, pq, pd, prev_dtad, one_launch=False, pre=None):
+        """s -= (<s, pq> / prev_dtad) pd, all fields in two launches (or one with a grid barrier).
+        pre: <s, pq> as partial sums left by the preconditioner kernel that wrote s (pre_op.with_dot): the update alone"""
         f = (lambda v: [v])
+        if pre is not None:
+            dev.cg_axpy_pre((pre, None), f(s), f(pd), -1.0, den=prev_dtad)
+            return
         dev.cg_dot_axpy(f(s), f(pq), f(s), f(pd), -1.0, den=prev_dtad, lmin=0, one_launch=one_launch)
 
     def __call__(self, alm1, alm2):
@@ -135,10 +140,16 @@ class pre_op_diag(object):
     def calc(self, talm):
         return dev.almxfl(talm, self.filt)
 
-    def splice_above(self, alm_low, talm, lsplit):
-        """alm_low for l <= lsplit, this preconditioner applied to talm above: pre_op_split's result in one launch (None: not here)"""
+    def splice_above(self, alm_low, talm, lsplit, dot=None):
+        """alm_low for l <= lsplit, this preconditioner applied to talm above: pre_op_split's result in one launch (None: not here).
+        dot = (q, lmin): returns (result, pre), pre the partial sums of <result, q> formed by the same launch"""
         if not (isinstance(talm, torch.Tensor) and talm.is_cuda and talm.dtype == torch.complex128 and alm_low.dtype == torch.complex128):
             return None
+        if dot is not None:
+            q, lmin = dot
+            lmax_hi = hp.Alm.getlmax(talm.shape[-1])
+            pre = torch.empty(tuple(talm.shape[:-1]) + (dev.alm_splice_dot_count(lmax_hi),), dtype=torch.float64, device=talm.device)
+            return dev.alm_splice_fl(alm_low, talm, self.filt, lsplit, dot=(q, lmin, pre)), pre
         return dev.alm_splice_fl(alm_low, talm, self.filt, lsplit)
 
 

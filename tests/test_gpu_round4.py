@@ -306,3 +306,56 @@ def test_step_scalar_products_from_the_operator_kernels(nb):
     dotp.step(x1, d, r1, q)
     dotp.step(x2, d, r2, q, pre=pre)
     assert relrms(dev.to_host(x2.elm), dev.to_host(x1.elm)) < 1e-12 and relrms(dev.to_host(r2.blm), dev.to_host(r1.blm)) < 1e-12
+
+
+def test_ortho_scalar_product_from_the_preconditioner_kernels():
+    """pre_op_split.with_dot: the kernel that writes the new search direction (pl_gemv_split_dot around the dense block, pl_alm_splice_dot_b
+    around a nested stage) leaves <s, q'> as partial sums; s is bit-identical to calc's, the sum equals pl_alm_dot's to rounding and
+    dot_op.ortho(pre=...) makes the update of cd_solve.py:96-103 from it -- temperature and polarization."""
+    import torch
+    from plancklens_amd import dev, hp
+    from plancklens_amd.qcinv import multigrid, opfilt_pp, opfilt_tt
+    from plancklens_amd.qcinv.util_alm import eblm
+    rng = np.random.default_rng(12)
+    nside, lmax, lsplit = 32, 64, 12
+    npix, nalm = 12 * nside ** 2, hp.Alm.getsize(lmax)
+    ell = np.arange(lmax + 1.)
+    cl = {'tt': np.where(ell >= 1, 1e3 / np.maximum(ell, 1) ** 2, 1.), 'ee': np.where(ell >= 2, 30. / np.maximum(ell, 1) ** 2, 0.),
+          'bb': np.where(ell >= 2, 3. / np.maximum(ell, 1) ** 2, 0.)}
+    transf = hp.gauss_beam(60. / 60 / 180 * np.pi, lmax=lmax)
+    z = hp.pix2vec(nside, np.arange(npix))[2]
+    ninv = (np.abs(z) > 0.3) * (1. + 0.5 * rng.random(npix))
+
+    def vec():
+        v = rng.standard_normal(nalm) + 1j * rng.standard_normal(nalm)
+        v[:lmax + 1].imag = 0.
+        return dev.to_dev(v, torch.complex128).contiguous()
+
+    tot = lambda parts: float(parts.sum())
+    for opfilt, mk, parts_of in ((opfilt_tt, vec, lambda v: [v]), (opfilt_pp, lambda: eblm([vec(), vec()]), lambda v: [v.elm, v.blm])):
+        filt = opfilt.alm_filter_ninv(ninv, transf) if opfilt is opfilt_tt else opfilt.alm_filter_ninv([ninv], transf)
+        dot = opfilt.dot_op()
+        diag = opfilt.pre_op_diag(cl, filt)
+        dense_op = opfilt.pre_op_dense(lsplit, opfilt.fwd_op(cl, filt.degrade(nside)))
+        # (a) the one-launch split around the dense block; (b) the splice around any other low-l preconditioner (here: the same dense
+        # block without its split form -- stands in for a nested multigrid stage)
+        class plain(object):
+            def __init__(self, op): self.op = op
+            def __call__(self, v): return self.op(v)
+        for low in (dense_op, plain(dense_op)):
+            op = multigrid.pre_op_split(lsplit, lmax, low, diag)
+            r, q, pd = mk(), mk(), mk()
+            s_ref = op(r)
+            s, pre = op.with_dot(r, q, dot.lmin)
+            assert pre is not None
+            for a, b in zip(parts_of(s), parts_of(s_ref)):
+                assert torch.equal(a, b)
+            ref = tot(dot.parts(s, q))
+            assert abs(float(pre.sum()) - ref) <= 1e-12 * abs(tot(dot.parts(s, s))), (float(pre.sum()), ref)
+            dtad = dot.parts(pd, pd)
+            s1 = s_ref if opfilt is opfilt_tt else eblm([s_ref.elm.clone(), s_ref.blm.clone()])
+            s1 = s1.clone() if opfilt is opfilt_tt else s1
+            dot.ortho(s1, q, pd, dtad)
+            dot.ortho(s, q, pd, dtad, pre=pre)
+            for a, b in zip(parts_of(s), parts_of(s1)):
+                assert relrms(dev.to_host(a), dev.to_host(b)) < 1e-12
