@@ -219,12 +219,13 @@ int pl_cg_dot_axpy_b(int nb, int nf, const int *lmax, int lmin, const double *co
  * excluded; d, r: nf device arrays laid out as the operator's output).
  * pl_cg_axpy_pre_b: the updates of pl_cg_dot_axpy_b from such partial sums (npre per batch entry, added in a fixed order by every workgroup):
  * den_parts_dev given: y1 += sign1 sum(pre1) / sum(den) x1; else y1 += sign1 sum(pre2) / sum(pre1) x1 and (y2 non-NULL) y2 += sign2 (the same) x2.
- * parts1_dev / parts2_dev (may be NULL) receive the totals of pre1 / pre2 in the PL_DOT_PARTS-entry form of pl_alm_dot. */
+ * parts1_dev / parts2_dev (may be NULL) receive the totals of pre1 / pre2 in the PL_DOT_PARTS-entry form of pl_alm_dot.  y1_assign != 0: y1 = sign1 (...) x1
+ * (y1 is written, not read: the first step of a solve that starts from zero needs no zero-filled solution vector). */
 int pl_post_dots_count(pl_plan *plan);
 int pl_plan_arm_post_dots(pl_plan *plan, int nf, const double *const *d, const double *const *r, int lmin, double *pre1_dev, double *pre2_dev);
 int pl_cg_axpy_pre_b(int nb, int nf, const int *lmax, int npre, const double *pre1_dev, const double *pre2_dev, const double *den_parts_dev,
                      double *parts1_dev, double *parts2_dev, double *const *y1, const double *const *x1, double sign1, double *const *y2,
-                     const double *const *x2, double sign2, const double *active_dev, void *stream);
+                     const double *const *x2, double sign2, const double *active_dev, int y1_assign, void *stream);
 int pl_template_project_b(int64_t npix, int nmodes, int nb, double *tmap, const double *n_inv, const double *pmat, const double *rmat,
                           double *scratch_dev, void *stream);
 /* y_b -= rmat^t (pmat x_b), b < nb, vectors of n doubles, pmat / rmat (nmodes, n): the template projection of the CG operators applied

@@ -95,7 +95,7 @@ def lib():
     L.pl_cg_dot_axpy_b.argtypes = [i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, dbl, vp, vp, dbl, vp, vp]
     L.pl_post_dots_count.argtypes = [vp]
     L.pl_plan_arm_post_dots.argtypes = [vp, i32, vp, vp, i32, vp, vp]
-    L.pl_cg_axpy_pre_b.argtypes = [i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, dbl, vp, vp, dbl, vp, vp]
+    L.pl_cg_axpy_pre_b.argtypes = [i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, dbl, vp, vp, dbl, vp, i32, vp]
     L.pl_template_project_b.argtypes = [i64, i32, i32, vp, vp, vp, vp, vp, vp]
     L.pl_lowrank_update_b.argtypes = [i64, i32, i32, vp, vp, vp, vp, vp, vp]
     L.pl_cg_fwd_tt_b.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]

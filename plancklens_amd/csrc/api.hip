@@ -45,7 +45,7 @@ void launch_cg_fused(int nf, const int *lmax, int lmin, const double *const *a, 
                      const double *const *x2, double sign2, unsigned *bar, hipStream_t st, int nbatch = 1, const double *active = nullptr);
 void launch_cg_axpy_pre(int nf, const int *lmax, int npre, const double *pre1, const double *pre2, const double *den, double *parts1, double *parts2,
                         double *const *y1, const double *const *x1, double sign1, double *const *y2, const double *const *x2, double sign2, hipStream_t st,
-                        int nbatch, const double *active);
+                        int nbatch, const double *active, int y1_assign);
 void launch_alm_splice(int lmax_lo, const double *lo, int lmax_hi, const double *hi, int lsplit, double *out, hipStream_t st,
                        const double *fl_hi = nullptr, int nb = 1, const double *dot_q = nullptr, int dot_lmin = 0, double *dot_pre = nullptr);
 int alm_splice_dot_count(int lmax_hi);
@@ -898,10 +898,10 @@ int pl_plan_arm_post_dots(pl_plan *p, int nf, const double *const *d, const doub
 
 // The vector updates of pl_cg_dot_axpy_b from scalar products that arrive as npre partial sums per batch entry (pl_plan_arm_post_dots, pl_gemv_split_dot,
 // pl_alm_splice_dot): den given: y1 += sign1 sum(pre1) / sum(den) x1; else y1 += sign1 sum(pre2) / sum(pre1) x1 and (optional) y2 += sign2 (same) x2.
-// parts1 / parts2 (optional) receive the totals as PL_DOT_PARTS-entry partial sums.
+// parts1 / parts2 (optional) receive the totals as PL_DOT_PARTS-entry partial sums.  y1_assign: y1 = ... instead of y1 += ... (y1 is not read).
 int pl_cg_axpy_pre_b(int nb, int nf, const int *lmax, int npre, const double *pre1, const double *pre2, const double *den_parts_dev, double *parts1_dev,
                      double *parts2_dev, double *const *y1, const double *const *x1, double sign1, double *const *y2, const double *const *x2, double sign2,
-                     const double *active_dev, void *stream)
+                     const double *active_dev, int y1_assign, void *stream)
 {
     PL_NB_CHECK("pl_cg_axpy_pre_b");
     if (nf < 1 || nf > 3 || !lmax || npre < 1 || !pre1 || !y1 || !x1) return fail("pl_cg_axpy_pre_b: bad arguments");
@@ -912,7 +912,7 @@ int pl_cg_axpy_pre_b(int nb, int nf, const int *lmax, int npre, const double *pr
     for (int k = 0; k < nf; ++k)
         if (lmax[k] < 0 || !y1[k] || !x1[k] || (y2 && (!y2[k] || !x2[k]))) return fail("pl_cg_axpy_pre_b: null field");
     launch_cg_axpy_pre(nf, lmax, npre, pre1, pre2, den_parts_dev, parts1_dev, parts2_dev, y1, x1, sign1, y2, x2, sign2, static_cast<hipStream_t>(stream), nb,
-                       active_dev);
+                       active_dev, y1_assign);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(kDotThreads) void k_cg_fused(CgFused f, double *__r
 // totals behind as canonical kDotParts-entry partial sums {total, 0, ...} (parts1 <- pre1, parts2 <- pre2) for the cache of cd_solve and the monitors.
 __global__ __launch_bounds__(kDotThreads) void k_cg_axpy_pre(CgFused f, int npre, const double *__restrict__ pre1_, const double *__restrict__ pre2_,
                                                              const double *__restrict__ den_, double *__restrict__ parts1_, double *__restrict__ parts2_,
-                                                             double sign1, double sign2, const double *__restrict__ active)
+                                                             double sign1, double sign2, const double *__restrict__ active, int y1_assign)
 {
     __shared__ double red[2][kDotThreads / 64];
     const int bq = blockIdx.y;
@@ -381,14 +381,18 @@ __global__ __launch_bounds__(kDotThreads) void k_cg_axpy_pre(CgFused f, int npre
         if (parts1_) parts1_[bq * kDotParts + threadIdx.x] = threadIdx.x == 0 ? t1 : 0.0;
         if (parts2_ && pre2) parts2_[bq * kDotParts + threadIdx.x] = threadIdx.x == 0 ? t2 : 0.0;
     }
-    if (active && active[bq] == 0.0) return;
-    const double c1 = sign1 * cs, c2 = sign2 * cs;
+    // y1_assign: y1 = c x1 instead of y1 += c x1 -- the first step of a solve that starts from x = 0 writes its solution vector instead of
+    // reading zeros somebody had to store first (an entry that stands still gets the zeros)
+    const bool still = active && active[bq] == 0.0;
+    if (still && !y1_assign) return;
+    const double c1 = still ? 0.0 : sign1 * cs, c2 = sign2 * cs;
     for (int k = 0; k < f.nf; ++k) {
         const int64_t nalm = (int64_t)(f.lmax[k] + 1) * (f.lmax[k] + 2) / 2;
         const int64_t o = bq * nalm;
         for (int64_t i = o + (int64_t)blockIdx.x * kDotThreads + threadIdx.x; i < o + nalm; i += (int64_t)gridDim.x * kDotThreads) {
             const double2 u = f.x1[k][i];
-            double2 v = f.y1[k][i];
+            double2 v = y1_assign ? make_double2(0., 0.) : f.y1[k][i];
+            if (still) { f.y1[k][i] = v; continue; }
             v.x = fma(c1, u.x, v.x); v.y = fma(c1, u.y, v.y);
             f.y1[k][i] = v;
             if (f.y2[0]) {
@@ -1046,7 +1050,7 @@ void launch_cg_fused(int nf, const int *lmax, int lmin, const double *const *a, 
 }
 void launch_cg_axpy_pre(int nf, const int *lmax, int npre, const double *pre1, const double *pre2, const double *den, double *parts1, double *parts2,
                         double *const *y1, const double *const *x1, double sign1, double *const *y2, const double *const *x2, double sign2, hipStream_t st,
-                        int nbatch, const double *active)
+                        int nbatch, const double *active, int y1_assign)
 {
     CgFused f = {};
     f.nf = nf;
@@ -1063,7 +1067,7 @@ void launch_cg_axpy_pre(int nf, const int *lmax, int npre, const double *pre1, c
     const int nb2 = (int)((nmax + kDotThreads - 1) / kDotThreads);  // as the update launch of launch_cg_fused
     const int cap = npre > 1024 ? 256 : 1024;  // every workgroup adds all npre partial sums: long lists (the fine grids) go to one workgroup per CU
     hipLaunchKernelGGL(k_cg_axpy_pre, dim3(nb2 < 1 ? 1 : (nb2 > cap ? cap : nb2), nbatch), dim3(kDotThreads), 0, st, f, npre, pre1, pre2, den, parts1,
-                       parts2, sign1, sign2, active);
+                       parts2, sign1, sign2, active, y1_assign);
 }
 // t_apply (optional): the projection is subtracted from this vector instead of t, which is then only read (n_inv null) -- the
 // rank-nmodes update y -= rm^t (pm x) of launch_lowrank_update

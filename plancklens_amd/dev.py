@@ -372,10 +372,11 @@ def cg_dot_axpy(a, b1, y1, x1, sign1, b2=None, den=None, y2=None, x2=None, sign2
     return parts1, parts2
 
 
-def cg_axpy_pre(pre, y1, x1, sign1, den=None, y2=None, x2=None, sign2=-1.0, active=None):
+def cg_axpy_pre(pre, y1, x1, sign1, den=None, y2=None, x2=None, sign2=-1.0, active=None, assign_y1=False):
     """The updates of cg_dot_axpy from scalar products that the kernel producing the vector left as partial sums (pl_cg_axpy_pre_b):
     pre = (pre1, pre2) or (pre1, None), [npre] or [nb, npre] each.  den given: c = sum(pre1) / sum(den); else c = sum(pre2) / sum(pre1);
-    y1 += sign1 c x1, y2 += sign2 c x2.  Returns (parts1, parts2): the totals of pre1 / pre2 as DOT_PARTS partial sums (alm_dot's form)."""
+    y1 += sign1 c x1 (assign_y1: y1 = sign1 c x1, y1 is not read), y2 += sign2 c x2.  Returns (parts1, parts2): the totals of pre1 / pre2 as
+    DOT_PARTS partial sums (alm_dot's form)."""
     pre1, pre2 = pre
     nf = len(y1)
     for group in (x1, y2, x2):
@@ -397,7 +398,7 @@ def cg_axpy_pre(pre, y1, x1, sign1, den=None, y2=None, x2=None, sign2=-1.0, acti
                                            None if den is None else den.data_ptr(), parts1.data_ptr(), None if parts2 is None else parts2.data_ptr(),
                                            _ptr_array(y1), _ptr_array(x1), float(sign1), None if y2 is None else _ptr_array(y2),
                                            None if x2 is None else _ptr_array(x2), float(sign2), None if active is None else active.data_ptr(),
-                                           stream_ptr()))
+                                           int(bool(assign_y1)), stream_ptr()))
     return parts1, parts2
 
 

@@ -39,14 +39,16 @@ class cache_mem(dict):
 ROUNDOFF = 25  # iterations between residual refreshes (cd_solve.py:35)
 
 
-def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=ROUNDOFF, x_is_zero=False, b_scratch=False):
+def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=ROUNDOFF, x_is_zero=False, b_scratch=False, x_uninit=False):
     """Solves fwd_op(x) = b in place on x by preconditioned conjugate directions; returns the iteration count.
 
         fwd_op, the pre_ops and dot_op must not modify their arguments.  `tr` selects how many past search
         directions each new one is orthogonalised against (tr_cg: the last one).  The residual is recomputed
         from scratch every `roundoff` iterations.  x_is_zero: the caller guarantees x = 0 on entry (the nested
         multigrid solves), which saves the first fwd_op.  b_scratch (with x_is_zero): b may be overwritten and the solve ends
-        before the first residual refresh -- b itself becomes the residual.
+        before the first residual refresh -- b itself becomes the residual.  x_uninit (with x_is_zero): x stands for zero but its memory
+        holds anything; the first step writes it (dot_op.step(x_init=True)) where it can, else it is zero-filled first -- for callers whose
+        criterion does not look at x before the first step.
 
         With a single preconditioner and a dot_op that offers `dev(a, b)` (a 0-dim device tensor) the step lengths
         stay on the device: no host synchronisation inside an iteration, same arithmetic.  If the dot_op also offers
@@ -66,16 +68,25 @@ def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=
     one_launch = merged and os.environ.get('PLENS_CG_ONE_LAUNCH', '0') == '1'
     if one_launch:  # opt-in experiment: the grid barrier needs every workgroup co-resident; a barrier that gave up invalidates the solve
         try:
-            return _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_is_zero, b_scratch, True)
+            return _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_is_zero, b_scratch, True, x_uninit)
         finally:
             from .. import dev
             if dev.cg_barrier_timed_out(reset=True):
                 raise RuntimeError('PLENS_CG_ONE_LAUNCH: a grid barrier of pl_cg_dot_axpy timed out (workgroups not co-resident: '
                                    'another kernel or process shares the GPU); the solve is invalid -- unset PLENS_CG_ONE_LAUNCH')
-    return _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_is_zero, b_scratch, False)
+    return _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_is_zero, b_scratch, False, x_uninit)
 
 
-def _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_is_zero, b_scratch, one_launch):
+def _zero(x):
+    for name in ('tlm', 'elm', 'blm'):
+        if hasattr(x, name):
+            getattr(x, name).zero_()
+    if not hasattr(x, 'elm'):
+        x.zero_() if hasattr(x, 'zero_') else x.fill(0.)
+
+
+def _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_is_zero, b_scratch, one_launch, x_uninit=False):
+    assert x_is_zero or not x_uninit
     n_pre = len(pre_ops)
     on_dev = n_pre == 1 and hasattr(dot_op, 'dev')
     fused = on_dev and hasattr(dot_op, 'axpy') and hasattr(dot_op, 'parts')
@@ -89,6 +100,8 @@ def _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_i
     # happen are never formed (the reference forms and drops them, cd_solve.py:59,93 -- with nested multigrid stages of three
     # iterations that is a quarter of all coarse work).  Same calls of criterion with the same arguments, same iterates.
     if criterion(it, x, residual):
+        if x_uninit:
+            _zero(x)
         return it
     searchdirs = [op(residual) for op in pre_ops]
     # the two scalar products of a step from the kernel that writes fwd_op's result (fwd_op.with_dots, dot_op.step(pre=...)): one launch
@@ -103,15 +116,21 @@ def _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_i
             searchfwds = [fwd_op(d) for d in searchdirs]
         if fused:
             fresh_residual = np.mod(it + 1, roundoff) == 0
+            kw0 = {}
+            if x_uninit and it == 0:  # the first step writes x (or x is zero-filled now)
+                if pre is not None:
+                    kw0 = {'x_init': True}
+                else:
+                    _zero(x)
             active = getattr(criterion, 'active', None)  # block vectors: 0 / 1 per entry, entries that have converged stand still
             if active is not None:
                 assert merged, 'per-entry stopping of a block solve needs dot_op.step'
                 # (a residual refresh recomputes the frozen entries' residuals too: harmless, their solutions no longer move and
                 # the monitor's verdict on them is final)
                 kw = {} if pre is None else {'pre': pre}
-                dTAd, delta = dot_op.step(x, searchdirs[0], residual, searchfwds[0], update_r=not fresh_residual, active=active, **kw)
+                dTAd, delta = dot_op.step(x, searchdirs[0], residual, searchfwds[0], update_r=not fresh_residual, active=active, **kw, **kw0)
             elif pre is not None:
-                dTAd, delta = dot_op.step(x, searchdirs[0], residual, searchfwds[0], update_r=not fresh_residual, pre=pre)
+                dTAd, delta = dot_op.step(x, searchdirs[0], residual, searchfwds[0], update_r=not fresh_residual, pre=pre, **kw0)
             elif merged:  # both scalar products in one launch, both updates of all fields in another (or all in one)
                 dTAd, delta = dot_op.step(x, searchdirs[0], residual, searchfwds[0], update_r=not fresh_residual, one_launch=one_launch)
             else:
@@ -148,6 +167,8 @@ def _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_i
                     dot_op.axpy(searchdirs[0], prev_dirs[0], dot_op.parts(searchdirs[0], prev_fwds[0]), prev_dTAd, -1.0)
             cache.trim(range(tr(it + 1), it))
             continue
+        if x_uninit and it == 0:
+            _zero(x)
         if on_dev:
             dTAd_inv = 1.0 / dot_op.dev(searchdirs[0], searchfwds[0])
             alphas = [dot_op.dev(searchdirs[0], residual) * dTAd_inv]

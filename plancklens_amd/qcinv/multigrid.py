@@ -205,6 +205,10 @@ class pre_op_split(object):
     def __call__(self, talm):
         return self.calc(talm)
 
+    def _low(self, tmp):
+        """the low-l preconditioner on a temporary it may overwrite"""
+        return self.pre_op_low.calc_owned(tmp) if hasattr(self.pre_op_low, 'calc_owned') else self.pre_op_low(tmp)
+
     def with_dot(self, talm, q, lmin):
         """(calc(talm), pre): pre = the partial sums of <result, q> left by the kernel that writes the result (the one-launch split around
         the dense block, or the splice with the diagonal high-l part), for dot_op.ortho(pre=...); None where neither form applies"""
@@ -220,7 +224,7 @@ class pre_op_split(object):
         if hasattr(self.pre_op_hgh, 'splice_above') and all(isinstance(p, torch.Tensor) and p.is_cuda and p.dtype == torch.complex128 and p.is_contiguous()
                                                             for p in _parts(talm) + _parts(q)):
             self.iter += 1
-            talm_low = self.pre_op_low(util_alm.alm_copy(talm, lmax=self.lsplit))
+            talm_low = self._low(util_alm.alm_copy(talm, lmax=self.lsplit))
             ret = self.pre_op_hgh.splice_above(talm_low, talm, self.lsplit, dot=(q, lmin))
             if ret is not None:
                 return ret
@@ -234,7 +238,7 @@ class pre_op_split(object):
             ret = self.pre_op_low.split_apply(talm, self.lsplit, self.pre_op_hgh)  # dense block + diagonal + splice in one launch
             if ret is not None:
                 return ret
-        talm_low = self.pre_op_low(util_alm.alm_copy(talm, lmax=self.lsplit))
+        talm_low = self._low(util_alm.alm_copy(talm, lmax=self.lsplit))
         if hasattr(self.pre_op_hgh, 'splice_above') and _lmax_of(talm) == self.lmax:
             ret = self.pre_op_hgh.splice_above(talm_low, talm, self.lsplit)  # diagonal high-l part applied inside the splice
             if ret is not None:
@@ -265,6 +269,10 @@ class pre_op_multigrid(object):
     def __call__(self, talm):
         return self.calc(talm)
 
+    def calc_owned(self, talm):
+        """calc for a caller that hands over a temporary: talm may be overwritten (it becomes the residual of the nested solve)"""
+        return self.calc(talm, owned=True)
+
     # A nested solve with a fixed iteration count and nobody reading its log has no host-side data dependence: the same
     # few thousand small kernels (coarse SHTs, dense mat-vec, alm arithmetic) in the same order every time, and at the
     # coarse resolutions they cost less to run than to launch from Python.  After `graph_after` eager calls the outermost
@@ -280,9 +288,9 @@ class pre_op_multigrid(object):
         parts = _parts(talm)
         return all(isinstance(p, torch.Tensor) and p.is_cuda for p in parts) and not torch.cuda.is_current_stream_capturing()
 
-    def calc(self, talm):
+    def calc(self, talm, owned=False):
         if not self._capturable(talm):
-            return self._calc_eager(talm)
+            return self._calc_eager(talm, owned)
         from .. import shts
         # (a graph holds the workspace addresses of the plan context it was recorded in: one graph per context)
         key = tuple((tuple(p.shape), p.dtype) for p in _parts(talm)) + (shts.context(),)
@@ -290,7 +298,7 @@ class pre_op_multigrid(object):
         if st['graph'] is None:
             st['calls'] += 1
             if st['calls'] <= self.graph_after:
-                return self._calc_eager(talm)
+                return self._calc_eager(talm, owned)
             try:
                 st['in'] = [torch.empty_like(p) for p in _parts(talm)]
                 for d, p in zip(st['in'], _parts(talm)):
@@ -305,7 +313,7 @@ class pre_op_multigrid(object):
                 try:
                     # thread_local: another solver of this process may be launching (and allocating) on its own stream meanwhile
                     with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                        out = self._calc_eager(_like(talm, st['in']))
+                        out = self._calc_eager(_like(talm, st['in']), True)  # (the graph's input buffers are refilled before every replay)
                 finally:
                     if gc_was_on:
                         gc.enable()
@@ -317,22 +325,32 @@ class pre_op_multigrid(object):
                     traceback.print_exc()
                 torch.cuda.synchronize()
                 st['graph'] = False
-                return self._calc_eager(talm)
+                return self._calc_eager(talm, owned)
         if st['graph'] is False:
-            return self._calc_eager(talm)
+            return self._calc_eager(talm, owned)
         for d, p in zip(st['in'], _parts(talm)):
             d.copy_(p)
         st['graph'].replay()
         return _like(talm, [o.clone() for o in st['out']])
 
-    def _calc_eager(self, talm):
-        monitor = cd_monitors.monitor_basic(self.opfilt.dot_op(), iter_max=self.iter_max, eps_min=self.eps_min, logger=self.logger,
-                                            quiet=bool(self.quiet is not None and self.quiet()))
-        soltn = _like(talm, [torch.zeros_like(p) for p in _parts(talm)]) if all(isinstance(p, torch.Tensor) for p in _parts(talm)) else talm * 0.0
+    def _calc_eager(self, talm, owned=False):
+        quiet = bool(self.quiet is not None and self.quiet())
+        monitor = cd_monitors.monitor_basic(self.opfilt.dot_op(), iter_max=self.iter_max, eps_min=self.eps_min, logger=self.logger, quiet=quiet)
+        dev_vec = all(isinstance(p, torch.Tensor) for p in _parts(talm))
+        # nobody looks at the solution before the first step (quiet, fixed iteration count): it need not be zero-filled -- the first step
+        # writes it (cd_solve x_uninit)
+        uninit = dev_vec and quiet and self.eps_min == 0. and self.iter_max >= 1
+        if dev_vec:
+            soltn = _like(talm, [torch.empty_like(p) if uninit else torch.zeros_like(p) for p in _parts(talm)])
+        else:
+            soltn = talm * 0.0
         # the right-hand side is a private copy: with fewer iterations than the residual refresh period cd_solve may use it as
-        # its residual (one copy less); a solution at the band-limit of the input needs no splice
-        cd_solve.cd_solve(soltn, util_alm.alm_copy(talm, lmax=self.lmax), self.fwd_op, self.pre_ops, self.opfilt.dot_op(),
-                          monitor, tr=self.tr, cache=self.cache, x_is_zero=True, b_scratch=self.iter_max < cd_solve.ROUNDOFF)
+        # its residual (one copy less); a caller that hands over a temporary of this band-limit (`owned`) has made that copy already;
+        # a solution at the band-limit of the input needs no splice
+        scratch = self.iter_max < cd_solve.ROUNDOFF
+        b = talm if (owned and _lmax_of(talm) == self.lmax) else util_alm.alm_copy(talm, lmax=self.lmax)
+        cd_solve.cd_solve(soltn, b, self.fwd_op, self.pre_ops, self.opfilt.dot_op(), monitor, tr=self.tr, cache=self.cache, x_is_zero=True,
+                          b_scratch=scratch, x_uninit=uninit)
         if _lmax_of(talm) == self.lmax:
             return soltn
         return util_alm.alm_splice(soltn, talm, self.lmax)

@@ -63,14 +63,17 @@ class dot_op(object):
         dev.axpy_dev(y, x, num, den, sign)
 
     @staticmethod
-    def step(x, d, r, q, update_r=True, one_launch=False, active=None, pre=None):
+    def step(x, d, r, q, update_r=True, one_launch=False, active=None, pre=None, x_init=False):
         """one conjugate-directions update, all fields in two launches (or one with a grid barrier): dTAd = <d, q>, delta = <d, r>,
         x += (delta / dTAd) d and, if update_r, r -= (delta / dTAd) q; returns (dTAd, delta) as `parts` does.
         active (block vectors): 0 / 1 per entry, multiplies the step lengths.
-        pre: the two scalar products as left by the operator that made q (fwd_op.with_dots): the updates alone, one launch"""
+        pre: the two scalar products as left by the operator that made q (fwd_op.with_dots): the updates alone, one launch;
+        x_init (with pre): x = (delta / dTAd) d -- x is written, not read (first step of a solve from zero)"""
         f = (lambda v: [v])
         if pre is not None:
-            return dev.cg_axpy_pre(pre, f(x), f(d), 1.0, y2=f(r) if update_r else None, x2=f(q) if update_r else None, sign2=-1.0, active=active)
+            return dev.cg_axpy_pre(pre, f(x), f(d), 1.0, y2=f(r) if update_r else None, x2=f(q) if update_r else None, sign2=-1.0, active=active,
+                                   assign_y1=x_init)
+        assert not x_init
         return dev.cg_dot_axpy(f(d), f(q), f(x), f(d), 1.0, b2=f(r), y2=f(r) if update_r else None, x2=f(q) if update_r else None,
                                sign2=-1.0, lmin=0, one_launch=one_launch, active=active)
 
