@@ -74,7 +74,7 @@ class host_future(object):
                                                    ctypes.c_void_p(cs.cuda_stream)))
             else:
                 h.copy_(t, non_blocking=True)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(blocking=True)  # the helper thread sleeps on it: a spinning waiter takes a core from the launching thread on a busy host
             ev.record(cs)
         t.record_stream(cs)
         if host_future._pool is None:
