@@ -48,7 +48,7 @@ class host_future(object):
     stream goes on with the next reconstruction while the result crosses PCIe.  A helper thread waits for the copy, moves
     the data into an ordinary numpy array (which then owns it) and hands the staging buffer back; result() returns that
     array, waiting for the helper if it has not finished."""
-    MAX_IN_FLIGHT = 4
+    MAX_IN_FLIGHT = 8  # (two results per reconstruction: four reconstructions of slack for the launching thread when the helpers are slow -- a busy host)
     _in_flight = []
     _pool = None
 
