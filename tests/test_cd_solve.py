@@ -115,3 +115,84 @@ def test_pace_rendezvous_of_two_solves():
     t0 = time.time()
     pc2.wait()
     assert 0.04 < time.time() - t0 < 1.0
+
+
+class _dot_pre(_dot_merged):
+    """the merged interface plus the `pre` forms: scalar products handed over by whoever made the vector"""
+    lmin = 0
+    pre_steps = pre_orthos = inits = 0
+
+    def step(self, x, d, r, q, update_r=True, one_launch=False, active=None, pre=None, x_init=False):
+        if pre is None:
+            assert not x_init
+            return _dot_merged.step(self, x, d, r, q, update_r=update_r)
+        _dot_pre.pre_steps += 1
+        dtad, delta = np.array([pre[0].sum()]), np.array([pre[1].sum()])
+        if x_init:
+            _dot_pre.inits += 1
+            x[:] = delta[0] / dtad[0] * d  # written, never read
+        else:
+            x += delta[0] / dtad[0] * d
+        if update_r:
+            r -= delta[0] / dtad[0] * q
+        return dtad, delta
+
+    def ortho(self, s, pq, pd, prev_dtad, one_launch=False, pre=None):
+        if pre is None:
+            return _dot_merged.ortho(self, s, pq, pd, prev_dtad)
+        _dot_pre.pre_orthos += 1
+        s -= pre.sum() / prev_dtad[0] * pd
+
+
+class _fwd_with_dots(object):
+    def __init__(self, amat):
+        self.amat = amat
+
+    def __call__(self, v):
+        return self.amat @ v
+
+    def with_dots(self, d, r):
+        q = self.amat @ d
+        # partial sums, as the kernels leave them: any split whose total is the scalar product
+        return q, (np.array([np.dot(d[:7], q[:7]), np.dot(d[7:], q[7:])]), np.array([np.dot(d[:3], r[:3]), np.dot(d[3:], r[3:])]))
+
+
+class _pre_with_dot(object):
+    def __init__(self, diag, offer=True):
+        self.diag, self.offer = diag, offer
+
+    def __call__(self, v):
+        return v / self.diag
+
+    def with_dot(self, v, q, lmin):
+        s = v / self.diag
+        return s, (np.array([np.dot(s[:11], q[:11]), np.dot(s[11:], q[11:])]) if self.offer else None)
+
+
+@pytest.mark.parametrize('offer', [True, False])
+def test_scalar_products_handed_over_by_the_producing_operators(offer, monkeypatch):
+    """fwd_op.with_dots / pre_op.with_dot / dot_op.step(pre=...) / dot_op.ortho(pre=...): the solver takes the scalar products from the
+    operators that made the vectors (cd_solve.py:66-84,96-103 without scalar-product launches of their own) and lands on the same
+    solution as with its own; a preconditioner that has none to offer falls back per call; x_uninit: the solution vector may hold anything
+    on entry, the first step writes it (or it is zero-filled where no `pre` arrives); PLENS_CG_POST_DOTS=0 switches the protocol off."""
+    amat, b = _system(seed=3)
+    ref = np.zeros_like(b)
+    cd_solve.cd_solve(ref, b.copy(), lambda v: amat @ v, [lambda v: v / np.diag(amat)], _dot_merged(), _stop_after(12), cd_solve.tr_cg, x_is_zero=True)
+    _dot_pre.pre_steps = _dot_pre.pre_orthos = _dot_pre.inits = 0
+    x = np.full_like(b, np.nan)  # uninitialised memory
+    cd_solve.cd_solve(x, b.copy(), _fwd_with_dots(amat), [_pre_with_dot(np.diag(amat), offer)], _dot_pre(), _stop_after(12), cd_solve.tr_cg,
+                      x_is_zero=True, b_scratch=True, x_uninit=True)
+    assert np.allclose(x, ref, rtol=1e-12, atol=1e-14)
+    assert _dot_pre.pre_steps == 12 and _dot_pre.inits == 1 and _dot_pre.pre_orthos == (11 if offer else 0)
+    # a solve that ends before its first step still returns zeros
+    x0 = np.full_like(b, np.nan)
+    assert cd_solve.cd_solve(x0, b.copy(), _fwd_with_dots(amat), [_pre_with_dot(np.diag(amat))], _dot_pre(), _stop_after(0), cd_solve.tr_cg,
+                             x_is_zero=True, x_uninit=True) == 0
+    assert np.array_equal(x0, np.zeros_like(b))
+    # switched off: the solver's own scalar products, the solution vector zero-filled before the first step
+    monkeypatch.setenv('PLENS_CG_POST_DOTS', '0')
+    _dot_pre.pre_steps = _dot_pre.pre_orthos = 0
+    x1 = np.full_like(b, np.nan)
+    cd_solve.cd_solve(x1, b.copy(), _fwd_with_dots(amat), [_pre_with_dot(np.diag(amat))], _dot_pre(), _stop_after(12), cd_solve.tr_cg,
+                      x_is_zero=True, x_uninit=True)
+    assert _dot_pre.pre_steps == 0 and _dot_pre.pre_orthos == 0 and np.allclose(x1, ref, rtol=1e-12, atol=1e-14)
