@@ -216,7 +216,8 @@ int pl_cg_dot_axpy_b(int nb, int nf, const int *lmax, int lmin, const double *co
  * plancklens/qcinv/cd_solve.py:66-84: dTAd = <d, q>, delta = <d, r> with q = fwd_op(d)):
  * pl_plan_arm_post_dots is one shot: the next pl_cg_fwd_tt* (nf = 1) / pl_cg_fwd_pp* (nf = 2) call on this plan also leaves, per batch entry,
  * pl_post_dots_count(plan) partial sums of <d, q> in pre1_dev and of <d, r> in pre2_dev (q its result; weights of pl_alm_dot, entries l < lmin
- * excluded; d, r: nf device arrays laid out as the operator's output).
+ * excluded; d, r: nf device arrays laid out as the operator's output); any other analysis call on the plan (pl_map2alm, pl_legendre_anal) cancels a
+ * pending request.
  * pl_cg_axpy_pre_b: the updates of pl_cg_dot_axpy_b from such partial sums (npre per batch entry, added in a fixed order by every workgroup):
  * den_parts_dev given: y1 += sign1 sum(pre1) / sum(den) x1; else y1 += sign1 sum(pre2) / sum(pre1) x1 and (y2 non-NULL) y2 += sign2 (the same) x2.
  * parts1_dev / parts2_dev (may be NULL) receive the totals of pre1 / pre2 in the PL_DOT_PARTS-entry form of pl_alm_dot.  y1_assign != 0: y1 = sign1 (...) x1

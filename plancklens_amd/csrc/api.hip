@@ -557,6 +557,7 @@ int pl_legendre_synth_grad(pl_plan *p, int spin, const double *almG, const doubl
 int pl_legendre_anal(pl_plan *p, int spin, const double *phase, double *alm, const double *fl, void *stream)
 {
     if (!p) return fail("null plan");
+    p->dots_armed = false;  // (a pending pl_plan_arm_post_dots is for the next pl_cg_fwd_* call only: any other analysis on the plan cancels it)
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int RG = rings_per_group(spin, p->P);
     const int ngroups = (p->P.npairs + RG - 1) / RG;
@@ -682,6 +683,7 @@ int pl_alm2map_batch2(pl_plan *p, int spin, const double *alm_gc_1, const double
 
 int pl_map2alm(pl_plan *p, int spin, const double *map, double *alm, const double *fl, int where, void *stream)
 {
+    if (p) p->dots_armed = false;  // (see pl_legendre_anal)
     if (!p) return fail("null plan");
     if (spin < 0 || spin > kMaxSpin) return fail("spin must be 0..3");
     if (!alm || !map) return fail("null alm / map pointer");
