@@ -94,6 +94,11 @@ int pl_alm2map_grad(pl_plan *plan, int spin, const double *almG, double *map, co
  * Device pointers only, asynchronous on `stream`.  16 + 4 instead of 12 + 4 + 8 + 4 FMAs per recursion step. */
 int pl_alm2map_pair(pl_plan *plan, int spin, const double *alm_gc_dev, const double *fl_dev, const double *alm_g2_dev, const double *fl2_dev,
                     double *maps4_dev, void *stream);
+/* Two gradient-only spin-s syntheses (curl input identically zero: pl_alm2map_grad) on ONE Legendre recursion -- the gradient legs
+ * alm2map_spin([-sqrt(l(l+1)) T^WF_lm, 0], 1) of the temperature estimator (plancklens/qest.py:453-464) for two simulations: 12 instead
+ * of 2 x 8 FMAs per (l, m, ring pair).  maps4: (re1, im1, re2, im2); each pair equals pl_alm2map_grad of its input bit for bit. */
+int pl_alm2map_grad_pair(pl_plan *plan, int spin, const double *alm_g1, const double *fl1, const double *alm_g2, const double *fl2, double *maps4,
+                         void *stream);
 /* The same spin-s synthesis of TWO general inputs (two simulations) on ONE recursion: 4 + 8 + 8 instead of 2 x (4 + 8) FMAs per
  * recursion step (batching independent maps).  alm_gc_k_dev = [G_k | C_k], one filter fl for both;
  * maps4_dev = [Q1 | U1 | Q2 | U2].  Device pointers only, asynchronous on `stream`.  Bit-identical to two pl_alm2map calls. */

@@ -19,6 +19,7 @@ void launch_preps(const DevPlan &P, const DevSpinTab &S, int spin, const double 
 void launch_synth0(const DevPlan &P, const double *prep, double *phase, hipStream_t st, int nb = 1);
 void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st, bool gonly, int nb = 1);
 void launch_synths_pair(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st);
+void launch_synths_gpair(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st);
 void launch_synths_batch2(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st,
                           int npairs_b = 1);
 void launch_anal0(const DevPlan &P, const double *phase, double *partial, const double *fl, double *alm, hipStream_t st,
@@ -652,6 +653,27 @@ int pl_alm2map_pair(pl_plan *p, int spin, const double *alm_gc, const double *fl
     launch_preps(p->P, p->S[spin], spin, alm_gc, fl, p->prep, st, false);
     launch_preps(p->P, p->S[spin], spin, alm_g2, fl2, p->prep2, st, true);
     { ProfScope ps(p, PK_LEG_SYNTHS_PAIR, st); launch_synths_pair(p->P, p->S[spin], spin, p->prep, p->prep2, p->phase, st); }
+    HIPCHK(hipGetLastError());
+    {
+        ProfScope ps(p, PK_FFT_SYNTH, st);
+        HIPCHK(launch_phase2map(p->P, p->F, p->fs, mlim_of(p, spin), 4, p->phase, maps4, st));
+    }
+    return 0;
+}
+
+int pl_alm2map_grad_pair(pl_plan *p, int spin, const double *alm_g1, const double *fl1, const double *alm_g2, const double *fl2, double *maps4, void *stream)
+{
+    if (!p) return fail("null plan");
+    if (spin < 1 || spin > kMaxSpin) return fail("pl_alm2map_grad_pair: spin must be 1..3");
+    if (!alm_g1 || !alm_g2 || !maps4) return fail("pl_alm2map_grad_pair: null alm / map pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ensure_spin(p, spin)) return 1;
+    if (grow(p, &p->prep, &p->prep_cap, p->nent[spin] * 4) || grow(p, &p->prep2, &p->prep2_cap, p->nent[spin] * 4) ||
+        grow(p, &p->phase, &p->phase_cap, 2 * pl_plan_phase_doubles(p, spin)))
+        return 1;
+    launch_preps(p->P, p->S[spin], spin, alm_g1, fl1, p->prep, st, true);
+    launch_preps(p->P, p->S[spin], spin, alm_g2, fl2, p->prep2, st, true);
+    { ProfScope ps(p, PK_LEG_SYNTHS_GRAD, st); launch_synths_gpair(p->P, p->S[spin], spin, p->prep, p->prep2, p->phase, st); }
     HIPCHK(hipGetLastError());
     {
         ProfScope ps(p, PK_FFT_SYNTH, st);

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
     // the same block vector: entries 2 y and 2 y + 1 share the recursion)
     const double4 *__restrict__ prep = prep_ + (int64_t)blockIdx.y * bstride * S.off[P.mmax + 1];
     const double4 *__restrict__ prep2 = prep2_ ? prep2_ + (int64_t)blockIdx.y * bstride * S.off[P.mmax + 1] : nullptr;
-    static_assert(!(GONLY && IN2 != 0), "a second input rides on a general first one");
+    static_assert(!(GONLY && IN2 == 2), "the batch form takes two general inputs");  // GONLY with IN2 = 1: two gradient-only inputs (4 + 4 + 4 FMAs per step)
     constexpr bool PAIR = IN2 == 1, BATCH = IN2 == 2;
     constexpr int EST = IN2 ? 16 : 8;  // 4 doubles x number of components of the phase array
     constexpr int RG = 64 * R;
@@ -1428,6 +1428,20 @@ void launch_synths_pair(const DevPlan &P, const DevSpinTab &S, int spin, const d
                            reinterpret_cast<const double4 *>(prep), phase, reinterpret_cast<const double4 *>(prep2));
     else
         hipLaunchKernelGGL((k_leg_synths<2, false, 1>), dim3(ngroups2 * nmg), dim3(256), 0, st, P, S, spin,
+                           reinterpret_cast<const double4 *>(prep), phase, reinterpret_cast<const double4 *>(prep2));
+}
+
+// two gradient-only inputs (the gradient legs of the temperature estimator of two simulations) on one recursion: 12 FMAs per step for the two
+// transforms instead of 2 x 8; phase entries of 16 doubles as in launch_synths_pair.  Sums formed as by the gradient-only kernel: bit-identical maps.
+void launch_synths_gpair(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st)
+{
+    const int ngroups1 = (P.npairs + 63) / 64, ngroups2 = (P.npairs + 127) / 128, nmg = own_mgroups(P);
+    if (nmg == 0) return;
+    if (rs_synth(P) == 1)
+        hipLaunchKernelGGL((k_leg_synths<1, true, 1>), dim3(ngroups1 * nmg), dim3(256), 0, st, P, S, spin,
+                           reinterpret_cast<const double4 *>(prep), phase, reinterpret_cast<const double4 *>(prep2));
+    else
+        hipLaunchKernelGGL((k_leg_synths<2, true, 1>), dim3(ngroups2 * nmg), dim3(256), 0, st, P, S, spin,
                            reinterpret_cast<const double4 *>(prep), phase, reinterpret_cast<const double4 *>(prep2));
 }
 

@@ -439,15 +439,19 @@ class library(object):
         return out
 
     def _get_sim_Tgclm_pair(self, idx0, idx1, defer=False):
-        """_get_sim_Tgclm of two simulations back to back.  The temperature estimator has no general spin-weighted leg to share a
-        recursion on (its gradient leg is the gradient-only synthesis, 8 of 12 FMAs per step already); what the pair buys is the
-        filter stage of both simulations issued before either estimator, so that no host work sits between the two."""
-        f2map1, _ = self._legs(False)
+        """_get_sim_Tgclm of two simulations: their gradient legs (gradient-only spin-1 syntheses, 8 FMAs per step each) share one
+        Legendre recursion (lib_filt2map.get_gtmap_pair, pl_alm2map_grad_pair: 12 for the two; maps bit-identical to the one-by-one
+        evaluation), and the filter stage of both is issued before either estimator."""
+        f2map1, f2map2 = self._legs(False)
         for i in (idx0, idx1):
             f2map1._alm('tlm', i)
+        gts = f2map2.get_gtmap_pair(idx0, idx1, k='ptt')  # both gradient legs on one recursion (None: one by one)
         out = []
-        for idx in (idx0, idx1):
-            G, C = self._get_sim_Tgclm_dev(idx, 'ptt')
+        for j, idx in enumerate((idx0, idx1)):
+            if gts is None:
+                G, C = self._get_sim_Tgclm_dev(idx, 'ptt')
+            else:
+                G, C = self._gc_from_product(*dev.qe_lens_product((f2map1.get_irestmap(idx), gts[j][0], gts[j][1]), None), 'T')
             if defer and G.numel() >= self._DEFER_MIN_ENTRIES:
                 out.append((dev.host_future(G), dev.host_future(C), G, C))
             else:
@@ -655,6 +659,15 @@ class lib_filt2map(object):
             return self._zeros()
         lmax = self._lmax(mlik)
         return shts.alm2map_spin([mlik, None], self.nside, 1, lmax, fl=_lens_weight(lmax))  # no curl: gradient-only synthesis
+
+    def get_gtmap_pair(self, idx0, idx1, k=None):
+        """get_gtmap of two simulations on one Legendre recursion (pl_alm2map_grad_pair); None where that form does not apply"""
+        m0, m1 = self._gt_alm(idx0, k=k), self._gt_alm(idx1, k=k)
+        if m0 is None or m1 is None or self._lmax(m0) != self._lmax(m1) or shts._lane_active() or os.environ.get('PLENS_BATCH2', '1') == '0' \
+                or not (isinstance(m0, torch.Tensor) and m0.is_cuda and isinstance(m1, torch.Tensor) and m1.is_cuda):
+            return None
+        lmax = self._lmax(m0)
+        return shts.alm2map_spin_grad_pair(m0, m1, self.nside, 1, lmax, fl=_lens_weight(lmax))
 
     def get_gt_gp1maps(self, idx, k=None):
         """(gt, ct), (g1, c1): the two spin-1 legs of the minimum-variance estimator, get_gtmap and get_gpmap(spin 1), on one

@@ -505,6 +505,19 @@ def alm2map_spin_pair(gclm, glm2, nside, spin, lmax, fl=None, fl2=None):
     return [out[0], out[1]], [out[2], out[3]]
 
 
+def alm2map_spin_grad_pair(glm1, glm2, nside, spin, lmax, fl=None, fl2=None):
+    """Two gradient-only spin-s syntheses alm2map_spin([glm, 0], ...) on one Legendre recursion (pl_alm2map_grad_pair, device arrays
+    only): returns ([Q1, U1], [Q2, U2]), bit-identical to the two separate calls at 3/4 of their Legendre work."""
+    assert spin > 0 and _is_dev(glm1) and _is_dev(glm2), 'alm2map_spin_grad_pair works on device arrays'
+    plan = get_plan(nside, lmax)
+    g1, g2 = glm1.to(torch.complex128).contiguous(), glm2.to(torch.complex128).contiguous()
+    assert g1.numel() == plan.nalm and g2.numel() == plan.nalm, (g1.shape, g2.shape, plan.nalm)
+    f, f2 = _fl_arg(fl, lmax, True), _fl_arg(fl if fl2 is None else fl2, lmax, True)
+    out = torch.empty((4, plan.npix), dtype=torch.float64, device=g1.device)
+    _lib.check(_lib.lib().pl_alm2map_grad_pair(plan.h, int(spin), _ptr(g1), _ptr(f), _ptr(g2), _ptr(f2), _ptr(out), _stream()))
+    return [out[0], out[1]], [out[2], out[3]]
+
+
 def alm2map_spin_batch2(gclm1, gclm2, nside, spin, lmax, fl=None):
     """The same spin-s synthesis of two inputs (two simulations) on one Legendre recursion (pl_alm2map_batch2, device arrays
     only): returns ([Q1, U1], [Q2, U2]), bit-identical to two alm2map_spin calls at 5/6 of their Legendre work."""

@@ -359,3 +359,26 @@ def test_ortho_scalar_product_from_the_preconditioner_kernels():
             dot.ortho(s, q, pd, dtad, pre=pre)
             for a, b in zip(parts_of(s), parts_of(s1)):
                 assert relrms(dev.to_host(a), dev.to_host(b)) < 1e-12
+
+
+@pytest.mark.parametrize('nside,lmax,spin', [(32, 64, 1), (128, 200, 1), (64, 95, 3), (512, 512, 1)])
+def test_two_gradient_only_syntheses_on_one_recursion(nside, lmax, spin):
+    """pl_alm2map_grad_pair (k_leg_synths<R, true, 1>: the gradient legs of the temperature estimator of two simulations, 12 instead of
+    2 x 8 FMAs per step) gives the maps of two pl_alm2map_grad calls bit for bit, with one filter or two."""
+    import torch
+    from plancklens_amd import dev, hp, shts
+    rng = np.random.default_rng(nside + lmax)
+    nalm = hp.Alm.getsize(lmax)
+
+    def galm():
+        a = rng.standard_normal(nalm) + 1j * rng.standard_normal(nalm)
+        a[:lmax + 1].imag = 0.
+        return dev.to_dev(a, torch.complex128)
+    g1, g2 = galm(), galm()
+    fl, fl2 = 1. / (1. + np.arange(lmax + 1.)), np.sqrt(np.arange(lmax + 1.))
+    for fa, fb in ((fl, None), (fl, fl2), (None, None)):
+        r1 = shts.alm2map_spin([g1, None], nside, spin, lmax, fl=fa)
+        r2 = shts.alm2map_spin([g2, None], nside, spin, lmax, fl=fa if fb is None else fb)
+        p1, p2 = shts.alm2map_spin_grad_pair(g1, g2, nside, spin, lmax, fl=fa, fl2=fb)
+        for a, b in zip(p1 + p2, r1 + r2):
+            assert torch.equal(a, b)
