@@ -46,16 +46,35 @@ if ROOT not in sys.path:
 FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 vector (= matrix) peak; SURVEY.md 8(d)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6300.0  # MI355X_MICROARCH.md chip table: measured streaming rate
-# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), bytes per launch at nside = lmax = 2048, by profile kind
-# (profiles/*_pmc_traffic.csv; refreshed whenever a kernel changes materially).  FETCH_SIZE on gfx950 counts half of the
-# bytes of 16-B-per-lane streaming reads and is uncalibrated for the scalar table streams of these kernels.
-PMC_TRAFFIC_BYTES = {
-    'leg_anals': (476783 + 887049) * 1024,   # profiles/round3_d_pmc_traffic.csv (k_leg_anals<4>; unchanged since round 1 to 0.2 %)
-    'leg_synths': (431696 + 373984) * 1024,
-    'leg_anal0': (222168 + 311194) * 1024,
-    'leg_synth0': (205126 + 188760) * 1024,
-}
-PMC_TRAFFIC_SOURCE = 'profiles/round3_d_pmc_traffic.csv'
+# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), bytes per launch at nside = lmax = 2048, by profile kind: read from
+# the NEWEST profiles/round*_pmc_traffic.csv (tools/prof_round.sh writes one per evidence set; refreshed whenever a kernel changes
+# materially).  FETCH_SIZE on gfx950 counts half of the bytes of 16-B-per-lane streaming reads and is uncalibrated for the scalar table
+# streams of these kernels.
+PMC_KERNEL_OF_KIND = {'leg_anals': 'k_leg_anals<', 'leg_synths': 'k_leg_synths<', 'leg_anal0': 'k_leg_anal0<', 'leg_synth0': 'k_leg_synth0<'}
+
+
+def pmc_traffic():
+    """({profile kind: FETCH_SIZE + WRITE_SIZE bytes per launch}, source file) from the newest PMC summary under profiles/ (by round and
+    letter in the file name); ({}, None) when there is none."""
+    import csv
+    import glob
+    import re
+    def order(f):  # round number, then the letter of the evidence set
+        m = re.match(r'round(\d+)_([a-z]+)_', os.path.basename(f))
+        return (int(m.group(1)), m.group(2)) if m else (0, '')
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'round*_pmc_traffic.csv')), key=order)
+    if not files:
+        return {}, None
+    out = {}
+    with open(files[-1]) as fh:
+        rows = list(csv.DictReader(line for line in fh if not line.startswith('#')))
+    for kind, pat in PMC_KERNEL_OF_KIND.items():
+        hit = [r for r in rows if pat in r['kernel'] and 'pair' not in r['kernel']]
+        if hit:  # (the first match is the variant with the largest traffic: the file is sorted that way)
+            out[kind] = int((float(hit[0]['FETCH_SIZE_KB']) + float(hit[0]['WRITE_SIZE_KB'])) * 1024)
+    return out, os.path.relpath(files[-1], ROOT)
+
+
 KERNEL_NAMES = {'leg_synth0': 'k_leg_synth0 (scalar Legendre synthesis)', 'leg_synths': 'k_leg_synths (spin-weighted Legendre synthesis)',
                 'leg_anal0': 'k_leg_anal0 (scalar Legendre analysis)', 'leg_anals': 'k_leg_anals (spin-weighted Legendre analysis)',
                 'leg_synths_grad': 'k_leg_synths<GONLY> (gradient-only spin synthesis)',
@@ -359,9 +378,11 @@ def run_rank(args):
     tmp = tempfile.mkdtemp(prefix='plbench_r%d_' % rank)
     mpi.rank = 0  # every rank owns a private scratch directory: all of them create their hash files
     mpi.size = 1
-    ivfs = filt_simple.library_fullsky_sepTP(os.path.join(tmp, 'ivfs'), sims, nside, transf, cl_len, ftl, fel, fbl, cache=False)
-    qlms = qest.library_sepTP(os.path.join(tmp, 'qlms'), ivfs, ivfs, cl_len['te'], nside, lmax_qlm=lmax_qlm, cache=False)
-    mpi.rank, mpi.size = rank, world
+    try:
+        ivfs = filt_simple.library_fullsky_sepTP(os.path.join(tmp, 'ivfs'), sims, nside, transf, cl_len, ftl, fel, fbl, cache=False)
+        qlms = qest.library_sepTP(os.path.join(tmp, 'qlms'), ivfs, ivfs, cl_len['te'], nside, lmax_qlm=lmax_qlm, cache=False)
+    finally:
+        mpi.rank, mpi.size = rank, world
     plan = shts.get_plan(nside, lmax)
 
     def sync_all():
@@ -433,9 +454,11 @@ def run_rank(args):
             skies = cmbs.sims_cmb_unl({k: cl_len[k] for k in ['tt', 'ee', 'bb', 'te']}, sky_ph)
             gsims = sim_maps.cmb_maps_nlev(skies, transf, nlev_t, nlev_p, nside, pix_lib_phas=pix_ph, device_maps=True)
             mpi.rank, mpi.size = 0, 1
-            ivfs_g = filt_simple.library_fullsky_sepTP(os.path.join(tmp, 'ivfs_g'), gsims, nside, transf, cl_len, ftl, fel, fbl, cache=False)
-            qlms_g = qest.library_sepTP(os.path.join(tmp, 'qlms_g'), ivfs_g, ivfs_g, cl_len['te'], nside, lmax_qlm=lmax_qlm, cache=False)
-            mpi.rank, mpi.size = rank, world
+            try:
+                ivfs_g = filt_simple.library_fullsky_sepTP(os.path.join(tmp, 'ivfs_g'), gsims, nside, transf, cl_len, ftl, fel, fbl, cache=False)
+                qlms_g = qest.library_sepTP(os.path.join(tmp, 'qlms_g'), ivfs_g, ivfs_g, cl_len['te'], nside, lmax_qlm=lmax_qlm, cache=False)
+            finally:  # (a constructor that raises must not leave every rank believing it is alone for the rest of the run)
+                mpi.rank, mpi.size = rank, world
             qlms_g.get_sim_qlms(key, [10 ** 6 + world * w + rank for w in range(min(args.warmup, 2))])
             qlms_g._mem.clear()
             sync_all()
@@ -526,8 +549,9 @@ def run_rank(args):
             avg_ms = ms / cnt
             ach = exe[dom] / (avg_ms * 1e-3) / 1e12
             fixed = alg[dom] / (avg_ms * 1e-3) / 1e12
+            pmc_bytes, pmc_source = pmc_traffic()
             res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP64_PEAK_TFLOPS,
-                               'traffic': PMC_TRAFFIC_BYTES.get(dom) if (nside, lmax) == (2048, 2048) else None,
+                               'traffic': pmc_bytes.get(dom) if (nside, lmax) == (2048, 2048) else None, 'traffic_source': pmc_source,
                                'kernel': KERNEL_NAMES.get(dom, dom), 'avg_launch_ms': avg_ms, 'launches': cnt,
                                'share_of_step': ms / (1e3 * dt),
                                'achieved_fixed_denominator': fixed, 'frac_fixed_denominator': fixed / FP64_PEAK_TFLOPS,
@@ -537,7 +561,7 @@ def run_rank(args):
                                        'libsharp-style polar pruning) / mean launch time (HIP events on the launch stream); achieved_fixed_denominator = '
                                        'SURVEY 8(d) count (24 or 8 flop x nalm x 2 nside, pruning not credited). peak = datasheet 78.6 TF; '
                                        'fma_issue_ceiling_measured_tflops is what a pure FMA loop sustains on this GPU by operand mix. '
-                                       'traffic = FETCH_SIZE + WRITE_SIZE bytes per launch (%s: PMC passes of the same kernel)' % PMC_TRAFFIC_SOURCE}
+                                       'traffic = FETCH_SIZE + WRITE_SIZE bytes per launch (%s: PMC passes of the same kernel)' % pmc_source}
         # whole-reconstruction algorithmic traffic (counting rule of SURVEY.md 8(d))
         b_scal = 8.0 * npix + 16.0 * nalm
         b_spin = 2 * b_scal

@@ -47,6 +47,17 @@ int pl_plan_fork(pl_plan *plan, pl_plan **fork);
 /* Plan: HEALPix ring geometry, recursion tables and FFT tables for one (nside, lmax, mmax = lmax).
  * Replaces what healpy / libsharp build internally per call (shts.py:13,18,23,28 build a geometry per call). */
 int pl_plan_create(int nside, int lmax, pl_plan **plan);
+/* Plan options: the ring-FFT routing decisions taken at plan creation, as explicit arguments (the library reads no environment
+ * variable at plan creation; two plans of one process differ only where the caller said so).  -1 = the measured default. */
+typedef struct pl_plan_opts {
+    int fft_legacy;    /* 1: every ring pair through the generic LDS-resident ring-FFT kernel (what the small-size oracle tests pin) */
+    int fft_split_min; /* smallest half-size for split Bluestein rings (default 512); 0: never split */
+    int fft_nyq_min;   /* shortest power-of-two sub-DFT whose order-n/2 rings use the register classes (default 2048); 0: never */
+    int fft_min_fast;  /* a plan whose register classes would hold under 1/d of its ring pairs runs every ring in the generic kernel
+                          (default d = 8); 0: never */
+} pl_plan_opts;
+/* pl_plan_create (rank 0 of 1) / pl_plan_create_shard with options; opts NULL = defaults. */
+int pl_plan_create_opts(int nside, int lmax, int rank, int nranks, const pl_plan_opts *opts, pl_plan **plan);
 int pl_plan_destroy(pl_plan *plan);
 int64_t pl_plan_npix(const pl_plan *plan);
 int64_t pl_plan_nalm(const pl_plan *plan);

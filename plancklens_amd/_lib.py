@@ -10,7 +10,7 @@ from . import _build
 
 _LIB = None
 
-SYMBOLS = ['pl_version', 'pl_last_error', 'pl_device_count', 'pl_plan_create', 'pl_plan_fork', 'pl_plan_destroy', 'pl_plan_npix',
+SYMBOLS = ['pl_version', 'pl_last_error', 'pl_device_count', 'pl_plan_create', 'pl_plan_create_opts', 'pl_plan_fork', 'pl_plan_destroy', 'pl_plan_npix',
            'pl_plan_nalm', 'pl_plan_bytes', 'pl_plan_create_shard', 'pl_phase_pack', 'pl_phase_unpack', 'pl_phase_pack_doubles', 'pl_alm_keep_mgroups', 'pl_map_pack_doubles', 'pl_map_pack_rings', 'pl_map_unpack_rings', 'pl_alm2map', 'pl_alm2map_grad', 'pl_alm2map_pair', 'pl_alm2map_batch2', 'pl_alm2map_grad_pair', 'pl_map2alm', 'pl_plan_phase_doubles', 'pl_legendre_synth', 'pl_legendre_synth_grad',
            'pl_legendre_anal', 'pl_phase2map', 'pl_map2phase', 'pl_almxfl', 'pl_alm2cl', 'pl_alm_copy', 'pl_axpy',
            'pl_alm_dot', 'pl_axpy_dev', 'pl_alm_splice', 'pl_alm_splice_fl', 'pl_cg_dot_axpy', 'pl_almxfl_add', 'pl_template_project', 'pl_cg_fwd_tt', 'pl_cg_fwd_pp', 'pl_gemv', 'pl_gemv_split', 'pl_gemv_split_dot', 'pl_gemv_split_dot_count', 'pl_alm_splice_dot_b', 'pl_alm_splice_dot_count', 'pl_copy_slim',
@@ -19,6 +19,11 @@ SYMBOLS = ['pl_version', 'pl_last_error', 'pl_device_count', 'pl_plan_create', '
            'pl_plan_fft_all_generic', 'pl_cg_fwd_tt_md_b', 'pl_cg_fwd_tt_lr_b', 'pl_gemv_b', 'pl_map_mul', 'pl_map_qu_weight', 'pl_map_cmul', 'pl_qe_lens_product', 'pl_fma64_peak_tflops', 'pl_fma64_rate_tflops', 'pl_profile_enable', 'pl_profile_read']
 
 PL_HOST, PL_DEVICE = 0, 1
+
+
+class PlanOpts(ctypes.Structure):
+    """pl_plan_opts of include/plshts.h (-1: the library's default)"""
+    _fields_ = [('fft_legacy', ctypes.c_int), ('fft_split_min', ctypes.c_int), ('fft_nyq_min', ctypes.c_int), ('fft_min_fast', ctypes.c_int)]
 
 
 class PlshtsError(AssertionError):
@@ -39,6 +44,7 @@ def lib():
     L.pl_last_error.restype = ctypes.c_char_p
     L.pl_device_count.restype = i32
     L.pl_plan_create.argtypes = [i32, i32, ctypes.POINTER(vp)]
+    L.pl_plan_create_opts.argtypes = [i32, i32, i32, i32, ctypes.POINTER(PlanOpts), ctypes.POINTER(vp)]
     L.pl_plan_fork.argtypes = [vp, ctypes.POINTER(vp)]
     L.pl_plan_create_shard.argtypes = [i32, i32, i32, i32, ctypes.POINTER(vp)]
     L.pl_phase_pack.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, vp]

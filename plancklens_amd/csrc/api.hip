@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -165,12 +167,30 @@ static int grow(pl_plan *p, double **buf, int64_t *cap, int64_t ndoubles)
     return 0;
 }
 
+// The spin tables of a plan are built on first use and shared with its forks, which other host threads may be launching on (two solvers
+// of one process, filt_cinv.run_tp): building and publishing them is serialised by one process-wide lock (taken only until a plan has
+// the tables of that spin, a few times per process).
+static std::recursive_mutex g_spin_mutex;
+
+static int ensure_spin_locked(pl_plan *p, int spin);
+
 static int ensure_spin(pl_plan *p, int spin)
 {
     if (spin < 1 || spin > kMaxSpin) return fail("spin must be 1, 2 or 3");
     if (p->have_spin[spin]) return 0;
+    std::lock_guard<std::recursive_mutex> lock(g_spin_mutex);
+    try {
+        return ensure_spin_locked(p, spin);
+    } catch (const std::exception &e) {
+        return fail(std::string("spin tables: ") + e.what());
+    }
+}
+
+static int ensure_spin_locked(pl_plan *p, int spin)
+{
+    if (p->have_spin[spin]) return 0;
     if (p->parent) {  // tables live in the parent
-        if (ensure_spin(p->parent, spin)) return 1;
+        if (ensure_spin_locked(p->parent, spin)) return 1;
         p->S[spin] = p->parent->S[spin];
         p->nent[spin] = p->parent->nent[spin];
         p->have_spin[spin] = true;
@@ -211,9 +231,15 @@ int pl_device_count(void)
     return n;
 }
 
-static int plan_create_impl(int nside, int lmax, int rank, int nranks, pl_plan **out);
+static int plan_create_impl(int nside, int lmax, int rank, int nranks, const pl_plan_opts *opts, pl_plan **out);
 
-int pl_plan_create(int nside, int lmax, pl_plan **out) { return plan_create_impl(nside, lmax, 0, 1, out); }
+int pl_plan_create(int nside, int lmax, pl_plan **out) { return plan_create_impl(nside, lmax, 0, 1, nullptr, out); }
+
+int pl_plan_create_opts(int nside, int lmax, int rank, int nranks, const pl_plan_opts *opts, pl_plan **out)
+{
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail("pl_plan_create_opts: rank out of range");
+    return plan_create_impl(nside, lmax, rank, nranks, opts, out);
+}
 
 // A plan for one of `nranks` shards of a single transform (north_star: "m-blocks shard across the GPUs"; SURVEY.md 8(e), secondary):
 // its Legendre launches cover the m-groups rank, rank + nranks, ... (4 consecutive orders each), its ring-FFT launches the ring
@@ -222,17 +248,35 @@ int pl_plan_create(int nside, int lmax, pl_plan **out) { return plan_create_impl
 int pl_plan_create_shard(int nside, int lmax, int rank, int nranks, pl_plan **out)
 {
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail("pl_plan_create_shard: rank out of range");
-    return plan_create_impl(nside, lmax, rank, nranks, out);
+    return plan_create_impl(nside, lmax, rank, nranks, nullptr, out);
 }
 
-static int plan_create_impl(int nside, int lmax, int rank, int nranks, pl_plan **out)
+static int plan_create_body(int nside, int lmax, int rank, int nranks, const pl_plan_opts &opts, pl_plan *&p, pl_plan **out);
+
+// The tables of a plan are built on the host (std::vector, long double) before they are uploaded -- about 1 GB at nside 4096: a host
+// allocation failure must come back as an error code like every other failure, not end the calling process (include/plshts.h).
+static int plan_create_impl(int nside, int lmax, int rank, int nranks, const pl_plan_opts *opts_in, pl_plan **out)
 {
     if (!out) return fail("null plan pointer");
     *out = nullptr;
     if (nside < 1 || nside > 8192) return fail("nside out of range [1, 8192]");
     if (lmax < 0 || lmax > 4 * nside) return fail("lmax out of range [0, 4 nside]");
-    pl_plan *p = new pl_plan();
-    if (hipGetDevice(&p->device) != hipSuccess) { delete p; return fail("no HIP device (hipGetDevice failed)"); }
+    pl_plan_opts opts = {0, -1, -1, -1};
+    if (opts_in) opts = *opts_in;
+    pl_plan *p = nullptr;
+    try {
+        return plan_create_body(nside, lmax, rank, nranks, opts, p, out);
+    } catch (const std::exception &e) {
+        *out = nullptr;
+        if (p) pl_plan_destroy(p);
+        return fail(std::string("pl_plan_create: ") + e.what());
+    }
+}
+
+static int plan_create_body(int nside, int lmax, int rank, int nranks, const pl_plan_opts &opts, pl_plan *&p, pl_plan **out)
+{
+    p = new pl_plan();
+    if (hipGetDevice(&p->device) != hipSuccess) { delete p; p = nullptr; return fail("no HIP device (hipGetDevice failed)"); }
     DevPlan &P = p->P;
     P.nside = nside; P.lmax = lmax; P.mmax = lmax;
     P.npix = 12LL * nside * nside;
@@ -254,17 +298,18 @@ static int plan_create_impl(int nside, int lmax, int rank, int nranks, pl_plan *
     std::vector<int> mlim(g.npairs);
     for (int i = 0; i < g.npairs; ++i) mlim[i] = mlim_ring(lmax, 0, g.sth[i], g.cth[i]);
     rc = rc || upload(p, mlim, &P.mlim0);
-    if (rc) { pl_plan_destroy(p); return 1; }
+    if (rc) { pl_plan_destroy(p); p = nullptr; return 1; }
 
     // FFT tables: ring lengths 4 q, q = 1 .. nside.  Every ring pair is served either by a register-resident kernel of
     // transform size N = 256 << c (ringfft.hip; synthesis and analysis share the class lists and the band-limited
     // Bluestein tables) or, for the short polar rings, aliased rings and anything unusual, by the LDS-resident generic
-    // kernel.  PLSHTS_FFT_LEGACY=1 sends every pair to the generic kernel.
+    // kernel.  opts.fft_legacy sends every pair to the generic kernel.  (Plan options are arguments of pl_plan_create_opts, not
+    // environment variables: two plans of one process differ only where the caller said so.)
     DevFFT &F = p->F;
-    const bool all_legacy = getenv("PLSHTS_FFT_LEGACY") && atoi(getenv("PLSHTS_FFT_LEGACY")) != 0;
+    const bool all_legacy = opts.fft_legacy != 0;
     std::vector<int> K2of(nside + 1, 0), MofA(nside + 1, 0), clsA(nside + 1, -1), splitA(nside + 1, 0);
-    // smallest half-size for which a Bluestein ring is split into two half-size convolutions (PLSHTS_FFT_SPLIT: 0 = never)
-    const int split_min = getenv("PLSHTS_FFT_SPLIT") ? atoi(getenv("PLSHTS_FFT_SPLIT")) : 512;
+    // smallest half-size for which a Bluestein ring is split into two half-size convolutions (opts.fft_split_min: 0 = never)
+    const int split_min = opts.fft_split_min >= 0 ? opts.fft_split_min : 512;
     {
         std::vector<int> mlmax(nside + 1, 0);
         for (int i = 0; i < g.npairs; ++i) {
@@ -282,9 +327,9 @@ static int plan_create_impl(int nside, int lmax, int rank, int nranks, pl_plan *
             if (all_legacy) continue;
             // the ring's own sub-DFT length: no band limit needed, only one order per bin (mlim <= n / 2; the kernels know the bin n / 2 --
             // the belt of a grid with lmax = 2 nside, which every coarse level of the CG chains is)
-            // (PLSHTS_FFT_NYQ = shortest sub-DFT routed this way, 0 = never: measured 17 % / 7 % faster stages (synthesis / analysis) at
+            // (opts.fft_nyq_min = shortest sub-DFT routed this way, 0 = never: measured 17 % / 7 % faster stages (synthesis / analysis) at
             // q = 2048, even at q <= 512, a slower analysis at q = 1024 -- the generic kernel runs those belts as well)
-            const int nyq_min = getenv("PLSHTS_FFT_NYQ") ? atoi(getenv("PLSHTS_FFT_NYQ")) : 2048;
+            const int nyq_min = opts.fft_nyq_min >= 0 ? opts.fft_nyq_min : 2048;
             if ((q & (q - 1)) == 0) { if ((nyq_min > 0 && q >= nyq_min) ? mlmax[q] <= 2 * q : 2 * K + 1 < q) clsA[q] = cls_of(q); continue; }
             if (2 * K + 1 >= q) continue;                               // aliased ring (mlim >= n / 2 - 5): generic kernel
             int Na = 256;
@@ -302,8 +347,8 @@ static int plan_create_impl(int nside, int lmax, int rank, int nranks, pl_plan *
     }
     {   // A plan whose register classes would hold only a few ring pairs (nside 256 at lmax = 2 nside: 25 of 512) runs every ring in the
         // generic kernel: the stage is then one launch without a fork / join of side streams, and the CG operators can take the whole
-        // pixel-space part in one (k_ring_roundtrip).  PLSHTS_FFT_MIN_FAST = d: below 1 / d of the pairs (default 8; 0: never).
-        const int min_fast = getenv("PLSHTS_FFT_MIN_FAST") ? atoi(getenv("PLSHTS_FFT_MIN_FAST")) : 8;
+        // pixel-space part in one (k_ring_roundtrip).  opts.fft_min_fast = d: below 1 / d of the pairs (default 8; 0: never).
+        const int min_fast = opts.fft_min_fast >= 0 ? opts.fft_min_fast : 8;
         int64_t nfast = 0;
         for (int i = 0; i < g.npairs; ++i) nfast += clsA[g.nphi[i] / 4] >= 0;
         if (min_fast > 0 && nfast > 0 && nfast * min_fast < g.npairs)
@@ -338,7 +383,7 @@ static int plan_create_impl(int nside, int lmax, int rank, int nranks, pl_plan *
     F.Mtw = Lmax < 2 ? 2 : Lmax;
     if (F.Mtw < M2max) F.Mtw = M2max;
     for (int c = 0; c < kFftClasses; ++c) if ((!listA[c].empty() || !dirA[c].empty() || !splA[c].empty()) && F.Mtw < (256 << c)) F.Mtw = 256 << c;
-    if ((size_t)Lmax * 16 > 160 * 1024 - 256) { pl_plan_destroy(p); return fail("ring FFT workspace exceeds the 160 KiB LDS of a CU"); }
+    if ((size_t)Lmax * 16 > 160 * 1024 - 256) { pl_plan_destroy(p); p = nullptr; return fail("ring FFT workspace exceeds the 160 KiB LDS of a CU"); }
     {   // LDS twiddle tables of the largest generic transform (radix-8 passes + one radix-4/2 tail), if they fit beside it
         int k = 0; while ((1 << k) < Lmax) ++k;
         const int rt = (k % 3 == 0) ? 8 : (k % 3 == 2 ? 4 : 2);
@@ -363,7 +408,7 @@ static int plan_create_impl(int nside, int lmax, int rank, int nranks, pl_plan *
         for (int k = 0; k < 4; ++k) { ringc[(size_t)q * 8 + 2 * k] = (double)cosl(ang[k]); ringc[(size_t)q * 8 + 2 * k + 1] = (double)sinl(ang[k]); }
     }
     const double *ringc_dev = nullptr;
-    if (upload(p, ringc, &ringc_dev)) { pl_plan_destroy(p); return 1; }
+    if (upload(p, ringc, &ringc_dev)) { pl_plan_destroy(p); p = nullptr; return 1; }
     F.ringc = reinterpret_cast<const double2 *>(ringc_dev);
     rc = dalloc(&tw, F.Mtw) || dalloc(&chirp, 2 * nw) || dalloc(&filt, 2 * nc) || dalloc(&filtA, 2 * ncA) ||
          upload(p, Mof, &F.Mof) || upload(p, woff, &F.woff) || upload(p, coff, &F.coff) || upload(p, K2of, &F.K2of) ||
@@ -378,7 +423,7 @@ static int plan_create_impl(int nside, int lmax, int rank, int nranks, pl_plan *
         F.A.dir_n[c] = (int)dirA[c].size();
         F.A.split_n[c] = (int)splA[c].size();
     }
-    if (rc) { pl_plan_destroy(p); return 1; }
+    if (rc) { pl_plan_destroy(p); p = nullptr; return 1; }
     F.tw = reinterpret_cast<const double2 *>(tw);
     F.chirp = reinterpret_cast<const double2 *>(chirp);
     F.filt = reinterpret_cast<const double2 *>(filt);
@@ -388,7 +433,7 @@ static int plan_create_impl(int nside, int lmax, int rank, int nranks, pl_plan *
     if (e == hipSuccess) e = launch_bluestein_setup2(F, qlistA_dev, (int)qlistA.size(), M2max, filtA, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = fft_streams_create(p->fs);
-    if (e != hipSuccess) { pl_plan_destroy(p); return fail(std::string("FFT table setup: ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) { pl_plan_destroy(p); p = nullptr; return fail(std::string("FFT table setup: ") + hipGetErrorString(e)); }
     *out = p;
     return 0;
 }
@@ -398,7 +443,8 @@ int pl_plan_fork(pl_plan *parent, pl_plan **out)
     if (!parent || !out) return fail("null plan pointer");
     *out = nullptr;
     if (parent->parent) return fail("fork the original plan, not a fork");
-    pl_plan *p = new pl_plan();
+    pl_plan *p = nullptr;
+    try { p = new pl_plan(); } catch (const std::exception &e) { return fail(std::string("pl_plan_fork: ") + e.what()); }
     p->device = parent->device;
     p->P = parent->P;
     p->F = parent->F;
@@ -956,7 +1002,7 @@ int pl_template_project(int64_t npix, int nmodes, double *tmap, const double *n_
 // ride in the two FFT launches (NinvProj); on the finer grids they are the two pl_template_project launches between the transforms.
 static bool cg_roundtrip_enabled()
 {
-    static const bool on = !(getenv("PLSHTS_CG_ROUNDTRIP") && atoi(getenv("PLSHTS_CG_ROUNDTRIP")) == 0);
+    static const bool on = dbg_env_int("PLSHTS_CG_ROUNDTRIP", 1) != 0;  // (PLSHTS_DEBUG=1 PLSHTS_CG_ROUNDTRIP=0: the two-launch form, tests)
     return on;
 }
 
@@ -967,6 +1013,14 @@ static int cg_fwd_tt_impl(pl_plan *p, int nb, const double *alm_in, const double
                           void *stream, const double *pinv_md = nullptr, const LowRank *lr = nullptr)
 {
     if (!p) return fail("null plan");
+    // scalar products of the result asked for by pl_plan_arm_post_dots (one field): the request is consumed HERE, before any early
+    // return -- a call that fails must not leave the plan armed for a later one (whose `pre` buffers may be gone by then)
+    PostDots dots_now;
+    const bool want_dots = p->dots_armed;
+    const int dots_nf = p->dots_nf;
+    p->dots_armed = false;
+    if (want_dots) dots_now = p->dots;
+    if (want_dots && dots_nf != 1) return fail("pl_cg_fwd_tt: armed scalar products need one field");
     if (!alm_in || !alm_out || !n_inv) return fail("pl_cg_fwd_tt: null alm / n_inv pointer");
     // pinv_md: the templates are exactly (monopole, dipole) and evaluated from the ring geometry (k_tproj_md_*): nmodes = 4, no matrices
     if (pinv_md && (nmodes != 4 || !scratch)) return fail("pl_cg_fwd_tt_md: nmodes = 4 and a scratch buffer are required");
@@ -978,6 +1032,12 @@ static int cg_fwd_tt_impl(pl_plan *p, int nb, const double *alm_in, const double
     // low-rank template update of the result (lr): its coefficient pass c = pm x reads the input only, so it runs beside the transforms
     // on a side stream of the plan (a parallel branch when the solve is replayed as a HIP graph) and leaves the critical path
     bool lr_forked = false;
+    // every exit after the fork joins the side stream again (eager: nothing of this call is left running unordered with the caller's
+    // stream; under graph capture: no unjoined branch, which would fail the capture with an unrelated message)
+    struct JoinGuard {
+        bool *forked; hipStream_t st; hipEvent_t ev;
+        ~JoinGuard() { if (*forked) (void)hipStreamWaitEvent(st, ev, 0); }
+    } join_guard{&lr_forked, st, p->fs.join[FftStreams::kN - 1]};
     if (lr && lr->nmodes > 0) {
         hipStream_t side = p->fs.ok ? p->fs.s[FftStreams::kN - 1] : nullptr;
         if (side && hipEventRecord(p->fs.fork, st) == hipSuccess && hipStreamWaitEvent(side, p->fs.fork, 0) == hipSuccess) {
@@ -1021,16 +1081,11 @@ static int cg_fwd_tt_impl(pl_plan *p, int nb, const double *alm_in, const double
     const int ngroups = (P.npairs + RG - 1) / RG;
     if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * P.nent0 * 4 * nb)) return 1;
     const bool lr_on = lr && lr->nmodes > 0;
-    // scalar products of the result asked for by pl_plan_arm_post_dots (one field)
-    PostDots dots_now;
-    const bool want_dots = p->dots_armed;
-    p->dots_armed = false;
-    if (want_dots) {
-        if (p->dots_nf != 1) return fail("pl_cg_fwd_tt: armed scalar products need one field");
-        dots_now = p->dots;
-    }
     const PostDots *dots = want_dots ? &dots_now : nullptr;
-    if (lr_on && lr_forked) HIPCHK(hipStreamWaitEvent(st, p->fs.join[FftStreams::kN - 1], 0));  // the coefficients are needed from here on
+    if (lr_on && lr_forked) {  // the coefficients are needed from here on
+        lr_forked = false;     // (joined here: the guard has nothing left to do)
+        HIPCHK(hipStreamWaitEvent(st, p->fs.join[FftStreams::kN - 1], 0));
+    }
     if (lr_on) {  // alm_out -= rm^t c inside the post-processing of the analysis (k_post0), every batch entry from its own coefficients
         int nparts = 0, pstride = 0;
         tproj_parts_layout(2 * P.nalm, &nparts, &pstride);
@@ -1101,8 +1156,15 @@ static int cg_fwd_pp_impl(pl_plan *p, int nb, const double *elm_in, const double
 {
     // n_qu / n_uu given: n_inv is the QQ map of a (QQ, QU, UU) noise model -- the weighting is then one pass of k_map_qu_weight between
     // the two ring-FFT stages instead of riding in the synthesis-side kernels
-    if ((n_qu == nullptr) != (n_uu == nullptr)) return fail("pl_cg_fwd_pp: n_qu and n_uu come together");
     if (!p) return fail("null plan");
+    // armed scalar products (pl_plan_arm_post_dots, two fields): consumed before any early return, as in cg_fwd_tt_impl
+    PostDots dots_now;
+    const bool want_dots = p->dots_armed;
+    const int dots_nf = p->dots_nf;
+    p->dots_armed = false;
+    if (want_dots) dots_now = p->dots;
+    if (want_dots && dots_nf != 2) return fail("pl_cg_fwd_pp: armed scalar products need two fields");
+    if ((n_qu == nullptr) != (n_uu == nullptr)) return fail("pl_cg_fwd_pp: n_qu and n_uu come together");
     if (!elm_in || !blm_in || !elm_out || !blm_out || !n_inv) return fail("pl_cg_fwd_pp: null alm / n_inv pointer");
     if ((elm_add == nullptr) != (blm_add == nullptr) || (elm_add && (!fl_add_e || !fl_add_b)))
         return fail("pl_cg_fwd_pp: elm_add, blm_add, fl_add_e and fl_add_b come together");
@@ -1117,7 +1179,7 @@ static int cg_fwd_pp_impl(pl_plan *p, int nb, const double *elm_in, const double
     // Block vectors on the grids where the kernel is bound by FMA issue: the entries go through the synthesis two at a time on one
     // recursion (k_leg_synths<R, false, 2>: 20 instead of 24 FMAs per step and pair, bit-identical maps); odd block sizes go unpaired.
     // On the coarse grids (launch latency, not FMA issue) every entry is a workgroup row of the ordinary kernel.
-    static const int pair_min_nside = getenv("PLSHTS_CG_PAIR_NSIDE") ? atoi(getenv("PLSHTS_CG_PAIR_NSIDE")) : 1024;
+    static const int pair_min_nside = dbg_env_int("PLSHTS_CG_PAIR_NSIDE", 1024);
     if (nb >= 2 && (nb & 1) == 0 && P.nside >= pair_min_nside) {  // (odd block sizes take the unpaired route)
         ProfScope ps(p, PK_LEG_SYNTHS_BATCH2, st);
         launch_synths_batch2(P, p->S[spin], spin, p->prep, p->prep + p->nent[spin] * 4, p->phase, st, nb / 2);
@@ -1149,13 +1211,6 @@ static int cg_fwd_pp_impl(pl_plan *p, int nb, const double *elm_in, const double
     if (grow(p, &p->partial, &p->partial_cap, (int64_t)ngroups * p->nent[spin] * 4 * nb)) return 1;
     {
         ProfScope ps(p, PK_LEG_ANALS, st);
-        PostDots dots_now;
-        const bool want_dots = p->dots_armed;
-        p->dots_armed = false;
-        if (want_dots) {
-            if (p->dots_nf != 2) return fail("pl_cg_fwd_pp: armed scalar products need two fields");
-            dots_now = p->dots;
-        }
         launch_anals_gc(P, p->S[spin], spin, p->nent[spin], p->phase, p->partial, fl_out, elm_out, blm_out, st, elm_add, blm_add, fl_add_e,
                         fl_add_b, nb, want_dots ? &dots_now : nullptr);
     }

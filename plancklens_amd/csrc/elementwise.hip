@@ -756,53 +756,53 @@ __global__ __launch_bounds__(256) void k_gemv_split(int nrows, int64_t lda, cons
         if (D.pre) wg256_sum_store(t, red4, D.pre + blockIdx.x);
         return;
     }
-    const int row_ = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row_ >= nrows) {  // (the last workgroup of the mat-vec part may hold fewer than four rows)
-        if (D.pre) wg256_sum_store(0.0, red4, D.pre + blockIdx.x);
-        return;
-    }
-    const int row = row_;
-    const double2 *__restrict__ a2 = reinterpret_cast<const double2 *>(A + (int64_t)row * lda);
-    // entry c of the concatenated low-band-limit vector [field 0 | field 1]: read in place from the field's full array
-    auto x = [&](int c) -> double2 {
-        if constexpr (NF == 1) return F.hi[0][map[c]];
-        else return c < nlo ? F.hi[0][map[c]] : F.hi[1][map[c - nlo]];
-    };
-    double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
-    const int n2 = NF * nlo;
-    int c = lane;
-    for (; c + 448 < n2; c += 512) {
-        const double2 u0 = a2[c], u1 = a2[c + 64], u2 = a2[c + 128], u3 = a2[c + 192];
-        const double2 u4 = a2[c + 256], u5 = a2[c + 320], u6 = a2[c + 384], u7 = a2[c + 448];
-        const double2 v0 = x(c), v1 = x(c + 64), v2 = x(c + 128), v3 = x(c + 192);
-        const double2 v4 = x(c + 256), v5 = x(c + 320), v6 = x(c + 384), v7 = x(c + 448);
-        s0 = fma(u0.x, v0.x, s0); s0 = fma(u0.y, v0.y, s0);
-        s1 = fma(u1.x, v1.x, s1); s1 = fma(u1.y, v1.y, s1);
-        s2 = fma(u2.x, v2.x, s2); s2 = fma(u2.y, v2.y, s2);
-        s3 = fma(u3.x, v3.x, s3); s3 = fma(u3.y, v3.y, s3);
-        s0 = fma(u4.x, v4.x, s0); s0 = fma(u4.y, v4.y, s0);
-        s1 = fma(u5.x, v5.x, s1); s1 = fma(u5.y, v5.y, s1);
-        s2 = fma(u6.x, v6.x, s2); s2 = fma(u6.y, v6.y, s2);
-        s3 = fma(u7.x, v7.x, s3); s3 = fma(u7.y, v7.y, s3);
-    }
-    for (; c + 192 < n2; c += 256) {
-        const double2 u0 = a2[c], u1 = a2[c + 64], u2 = a2[c + 128], u3 = a2[c + 192];
-        const double2 v0 = x(c), v1 = x(c + 64), v2 = x(c + 128), v3 = x(c + 192);
-        s0 = fma(u0.x, v0.x, s0); s0 = fma(u0.y, v0.y, s0);
-        s1 = fma(u1.x, v1.x, s1); s1 = fma(u1.y, v1.y, s1);
-        s2 = fma(u2.x, v2.x, s2); s2 = fma(u2.y, v2.y, s2);
-        s3 = fma(u3.x, v3.x, s3); s3 = fma(u3.y, v3.y, s3);
-    }
-    for (; c < n2; c += 64) { const double2 u = a2[c], v = x(c); s0 = fma(u.x, v.x, s0); s0 = fma(u.y, v.y, s0); }
-    double v = (s0 + s1) + (s2 + s3);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    // (the last workgroup of the mat-vec part may hold fewer than four rows: its idle waves skip the row and fall through with t = 0 to
+    // the ONE wg256_sum_store every wave of the workgroup executes -- a barrier is never reached from two program points)
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool valid = row < nrows;
     double t = 0.0;
-    if (lane == 0) {
-        const int f = NF == 1 ? 0 : row / (2 * nlo), r = row - f * 2 * nlo;
-        const int64_t o = 2 * (int64_t)map[r >> 1] + (r & 1);
-        reinterpret_cast<double *>(F.out[f])[o] = v;
-        if (D.pre) t = alm_dot_weight(lmax_lo, D.lmin, r >> 1) * (v * reinterpret_cast<const double *>(D.q[f])[o]);
+    if (valid) {
+        const double2 *__restrict__ a2 = reinterpret_cast<const double2 *>(A + (int64_t)row * lda);
+        // entry c of the concatenated low-band-limit vector [field 0 | field 1]: read in place from the field's full array
+        auto x = [&](int c) -> double2 {
+            if constexpr (NF == 1) return F.hi[0][map[c]];
+            else return c < nlo ? F.hi[0][map[c]] : F.hi[1][map[c - nlo]];
+        };
+        double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
+        const int n2 = NF * nlo;
+        int c = lane;
+        for (; c + 448 < n2; c += 512) {
+            const double2 u0 = a2[c], u1 = a2[c + 64], u2 = a2[c + 128], u3 = a2[c + 192];
+            const double2 u4 = a2[c + 256], u5 = a2[c + 320], u6 = a2[c + 384], u7 = a2[c + 448];
+            const double2 v0 = x(c), v1 = x(c + 64), v2 = x(c + 128), v3 = x(c + 192);
+            const double2 v4 = x(c + 256), v5 = x(c + 320), v6 = x(c + 384), v7 = x(c + 448);
+            s0 = fma(u0.x, v0.x, s0); s0 = fma(u0.y, v0.y, s0);
+            s1 = fma(u1.x, v1.x, s1); s1 = fma(u1.y, v1.y, s1);
+            s2 = fma(u2.x, v2.x, s2); s2 = fma(u2.y, v2.y, s2);
+            s3 = fma(u3.x, v3.x, s3); s3 = fma(u3.y, v3.y, s3);
+            s0 = fma(u4.x, v4.x, s0); s0 = fma(u4.y, v4.y, s0);
+            s1 = fma(u5.x, v5.x, s1); s1 = fma(u5.y, v5.y, s1);
+            s2 = fma(u6.x, v6.x, s2); s2 = fma(u6.y, v6.y, s2);
+            s3 = fma(u7.x, v7.x, s3); s3 = fma(u7.y, v7.y, s3);
+        }
+        for (; c + 192 < n2; c += 256) {
+            const double2 u0 = a2[c], u1 = a2[c + 64], u2 = a2[c + 128], u3 = a2[c + 192];
+            const double2 v0 = x(c), v1 = x(c + 64), v2 = x(c + 128), v3 = x(c + 192);
+            s0 = fma(u0.x, v0.x, s0); s0 = fma(u0.y, v0.y, s0);
+            s1 = fma(u1.x, v1.x, s1); s1 = fma(u1.y, v1.y, s1);
+            s2 = fma(u2.x, v2.x, s2); s2 = fma(u2.y, v2.y, s2);
+            s3 = fma(u3.x, v3.x, s3); s3 = fma(u3.y, v3.y, s3);
+        }
+        for (; c < n2; c += 64) { const double2 u = a2[c], v = x(c); s0 = fma(u.x, v.x, s0); s0 = fma(u.y, v.y, s0); }
+        double v = (s0 + s1) + (s2 + s3);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) {
+            const int f = NF == 1 ? 0 : row / (2 * nlo), r = row - f * 2 * nlo;
+            const int64_t o = 2 * (int64_t)map[r >> 1] + (r & 1);
+            reinterpret_cast<double *>(F.out[f])[o] = v;
+            if (D.pre) t = alm_dot_weight(lmax_lo, D.lmin, r >> 1) * (v * reinterpret_cast<const double *>(D.q[f])[o]);
+        }
     }
     if (D.pre) wg256_sum_store(t, red4, D.pre + blockIdx.x);
 }

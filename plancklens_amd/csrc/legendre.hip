@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "device_plan.h"
+#include "plshts_internal.h"
 #include "legendre_math.h"
 
 
@@ -1333,12 +1334,8 @@ __global__ void k_posts(DevPlan P, DevSpinTab S, int spin, int RG, int64_t nent,
 // -----------------------------------------------------------------------------------------------------
 // host launchers
 // -----------------------------------------------------------------------------------------------------
-// ring pairs per lane (tunable at run time for experiments: PLSHTS_R0 / PLSHTS_RS in the environment)
-static int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
+// ring pairs per lane (tunable at run time for experiments, under PLSHTS_DEBUG=1: PLSHTS_R0 / PLSHTS_RS in the environment)
+static int env_int(const char *name, int dflt) { return dbg_env_int(name, dflt); }
 // Ring pairs per lane (R): more rings per lane amortise the per-l overhead (coefficient fetch, cross-lane reduce) but
 // coarsen the polar pruning and shrink the grid.  The defaults are the measured optima at nside = lmax = 2048; smaller
 // transforms step R down until the grid has at least ~4 workgroups per CU.  PLSHTS_R0 / RS / R0A / RSA override.

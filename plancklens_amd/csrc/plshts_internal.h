@@ -7,6 +7,11 @@ namespace plshts {
 
 constexpr int kMaxSpin = 3;
 
+// Development knobs of the launchers (kernel-variant fallbacks, stream counts, rings per lane: INTEGRATION.md section 4) are read from the
+// environment ONLY when PLSHTS_DEBUG is set to a non-zero value; a production process has none of them.  Returns NULL otherwise.
+const char *dbg_env(const char *name);
+int dbg_env_int(const char *name, int dflt);
+
 // ---- host-side tables (tables.cpp), built in long double and rounded once ---------------------------
 struct Spin0Tables {
     // Two-step recursion of the spin-0 Legendre functions for every m (see DESIGN.md "Legendre kernels"):

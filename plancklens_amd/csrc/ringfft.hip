@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "device_plan.h"
+#include "plshts_internal.h"
 #include "ringfft.h"
 
 namespace plshts {
@@ -1377,8 +1378,8 @@ static int current_device()
 
 // dynamic LDS ceiling of the generic kernels: the CU's 160 KiB less their static allocations (k_map2phase keeps the template coefficients there)
 static constexpr int kGenericMaxLds = 160 * 1024 - 256;
-// largest LDS footprint for which the generic kernel transforms the four sub-DFTs of a ring side by side (PLSHTS_FFT_B4_KB overrides)
-static const size_t kB4MaxLds = getenv("PLSHTS_FFT_B4_KB") ? (size_t)atoi(getenv("PLSHTS_FFT_B4_KB")) * 1024 : (size_t)kGenericMaxLds;
+// largest LDS footprint for which the generic kernel transforms the four sub-DFTs of a ring side by side
+static constexpr size_t kB4MaxLds = (size_t)kGenericMaxLds;
 static size_t fft_lds_bytes(const DevFFT &F) { return (size_t)(F.Lmax + F.twl_cap) * sizeof(double2); }
 
 template <int NT, int QMAX>
@@ -1386,9 +1387,8 @@ static hipError_t launch_p2m(const DevPlan &P, const DevFFT &F, const int *mlim,
                              hipStream_t st, const NinvProj &W)
 {
     if (F.A.legacy_n == 0) return hipSuccess;
-    static const bool no_b4 = getenv("PLSHTS_FFT_NOB4") && atoi(getenv("PLSHTS_FFT_NOB4")) != 0;
     const size_t lds4 = (size_t)(4 * F.Lmax + F.twl_cap) * sizeof(double2);
-    if (!no_b4 && lds4 <= kB4MaxLds) {  // short transforms (coarse grids, short cap rings): the four sub-DFTs side by side
+    if (lds4 <= kB4MaxLds) {  // short transforms (coarse grids, short cap rings): the four sub-DFTs side by side
         static bool attr4_done[kMaxDevices] = {};
         const int dv4 = current_device();
         if (!attr4_done[dv4] && lds4 > 48 * 1024) {
@@ -1420,9 +1420,8 @@ static hipError_t launch_m2p(const DevPlan &P, const DevFFT &F, const int *mlim,
                              hipStream_t st, const NinvProj &W)
 {
     if (F.A.legacy_n == 0) return hipSuccess;
-    static const bool no_b4 = getenv("PLSHTS_FFT_NOB4") && atoi(getenv("PLSHTS_FFT_NOB4")) != 0;
     const size_t lds4 = (size_t)(4 * F.Lmax + F.twl_cap) * sizeof(double2);
-    if (!no_b4 && lds4 <= kB4MaxLds) {  // short transforms (coarse grids, short cap rings): the four sub-DFTs side by side
+    if (lds4 <= kB4MaxLds) {  // short transforms (coarse grids, short cap rings): the four sub-DFTs side by side
         static bool attr4_done[kMaxDevices] = {};
         const int dv4 = current_device();
         if (!attr4_done[dv4] && lds4 > 48 * 1024) {
@@ -1465,9 +1464,8 @@ template <int NT, int QMAX>
 static hipError_t launch_rt(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, double *phase, hipStream_t st, const double *n_inv)
 {
     if (F.A.legacy_n == 0) return hipSuccess;
-    static const bool no_b4 = getenv("PLSHTS_FFT_NOB4") && atoi(getenv("PLSHTS_FFT_NOB4")) != 0;
     const size_t lds4 = (size_t)(4 * F.Lmax + F.twl_cap) * sizeof(double2);
-    if (!no_b4 && lds4 <= kB4MaxLds) {
+    if (lds4 <= kB4MaxLds) {
         static bool attr4_done[kMaxDevices] = {};
         const int dv4 = current_device();
         if (!attr4_done[dv4] && lds4 > 48 * 1024) {
@@ -1516,16 +1514,15 @@ static hipError_t launch_map2phase_legacy(const DevPlan &P, const DevFFT &F, con
 // (tools/fft_kernel_stats.sh, profiles/round4_b_fft_kernel_stats.txt): N = 512 classes 2.0x faster, N = 1024 1.2-1.8x, N = 2048 analysis
 // of the direct rings 1.07x; the N = 2048 syntheses and Bluestein analyses are equal or slower (one 1024-thread workgroup per CU:
 // no second workgroup to overlap its memory phases with, and the per-thread phase-factor set-up is paid by four times the threads).
-// PLSHTS_FFT_QUAD: 0 = never, 2 = every class N <= 2048 (development).
+// (PLSHTS_DEBUG=1 PLSHTS_FFT_QUAD=0: the one-group kernels everywhere, for the per-kernel comparison of tools/fft_kernel_stats.sh.)
 // In a synthesis stage of a grid that has N = 2048 classes the quad kernels of the small classes (512- and 1024-thread workgroups with
 // 64-128 KB of LDS) get in the way of the dominant one-group kernel running beside them (stage 0.66 -> 0.70 ms): syntheses use them
 // on grids up to nside 1024 only (the coarse and middle levels of the CG chains), analyses everywhere.
 template <int N, bool BLUE, bool SPLIT>
 static bool fft_quad_enabled(bool synth, int nside)
 {
-    static const int mode = getenv("PLSHTS_FFT_QUAD") ? atoi(getenv("PLSHTS_FFT_QUAD")) : 1;
+    static const int mode = dbg_env_int("PLSHTS_FFT_QUAD", 1);
     if (mode == 0 || N < 512 || N > 2048) return false;
-    if (mode == 2) return true;
     if (synth) return nside <= 1024 && N <= 1024;
     return N <= 1024 || !BLUE;  // N = 2048: the analysis of the direct (equatorial) rings only
 }
@@ -1634,8 +1631,9 @@ static hipError_t launch_split_class(const DevPlan &P, const DevFFT &F, int cls,
 static hipError_t launch_stage(const DevPlan &P, const DevFFT &F, const FftStreams &fs, bool synth, const int *mlim, int ncomp,
                                const double *in, double *out, hipStream_t st, const NinvProj &W)
 {
-    // PLSHTS_FFT_SERIAL=1: every class on the caller's stream (profiling with PMC counters: one kernel at a time)
-    const bool par = fs.ok && !(getenv("PLSHTS_FFT_SERIAL") && atoi(getenv("PLSHTS_FFT_SERIAL")) != 0);
+    // PLSHTS_DEBUG=1 PLSHTS_FFT_SERIAL=1: every class on the caller's stream (profiling with PMC counters: one kernel at a time)
+    static const bool serial = dbg_env_int("PLSHTS_FFT_SERIAL", 0) != 0;
+    const bool par = fs.ok && !serial;
     // Work items: w = 3 c + kind of class c (kind 0: direct, 1: Bluestein, 2: split Bluestein) and the generic list (w = nw).  Cost
     // model: ring pairs x transform size x transforms per sub-DFT, plus a fixed latency (the short-ring kernels are latency-bound).
     // The costliest item stays on the caller's stream; the others go, costliest first, to the side stream with the least work
@@ -1680,8 +1678,8 @@ static hipError_t launch_stage(const DevPlan &P, const DevFFT &F, const FftStrea
     };
     // items of a handful of ring pairs (the single power-of-two cap rings) are pure latency: they go first, one after the other, on
     // the last side stream, which takes nothing else -- at the end of a queue they were the tail of every stage (45-50 us)
-    static const int nside_streams = [] { const char *v = getenv("PLSHTS_FFT_STREAMS"); const int n = v ? atoi(v) : 3; return n < 2 ? 2 : (n > FftStreams::kN ? FftStreams::kN : n); }();
-    // PLSHTS_FFT_STREAMS: side streams in use, 2 ... 5.  Every one costs a join on the caller's stream (the idle gap at the end of a stage
+    static const int nside_streams = [] { const int n = dbg_env_int("PLSHTS_FFT_STREAMS", 3); return n < 2 ? 2 : (n > FftStreams::kN ? FftStreams::kN : n); }();
+    // (PLSHTS_DEBUG=1) PLSHTS_FFT_STREAMS: side streams in use, 2 ... 5.  Every one costs a join on the caller's stream (the idle gap at the end of a stage
     // grows by ~10 us per joined stream); measured 26.54 ms per reconstruction with 3, 26.64 with 5, 26.89 with 2
     const int kTinyStream = nside_streams - 1;
     auto tiny = [&](int w) { return w != nw && count(w) < 8; };

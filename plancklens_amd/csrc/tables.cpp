@@ -3,6 +3,7 @@
 #include "plshts_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace plshts {
 
@@ -131,6 +132,18 @@ void build_spin_tables(int spin, int lmax, int mmax, SpinTables &t)
             else         { t.seedfac_p[m] = fac; t.usecos_p[m] = k > 0; }
         }
     }
+}
+
+const char *dbg_env(const char *name)
+{
+    static const bool on = [] { const char *v = getenv("PLSHTS_DEBUG"); return v && atoi(v) != 0; }();
+    return on ? getenv(name) : nullptr;
+}
+
+int dbg_env_int(const char *name, int dflt)
+{
+    const char *v = dbg_env(name);
+    return v ? atoi(v) : dflt;
 }
 
 }  // namespace plshts

@@ -213,14 +213,20 @@ class library_jTP(object):
                         hp.write_alm(self._fn(f, idx), dev.to_host(ent[f]), overwrite=True)
         return ent[a]
 
+    def _get_alms(self, a, idx):
+        """inverse-variance filtered alm of field a in 'teb' (the reference's private getter, filt_simple.py:266-342, kept by name: one
+        joint filter application serves all three fields, here through the device cache of get_sim_alm_dev)"""
+        assert a in ['t', 'e', 'b'], a
+        return dev.to_host(self.get_sim_alm_dev(a + 'lm', idx))
+
     def get_sim_tlm(self, idx):
-        return dev.to_host(self.get_sim_alm_dev('tlm', idx))
+        return self._get_alms('t', idx)
 
     def get_sim_elm(self, idx):
-        return dev.to_host(self.get_sim_alm_dev('elm', idx))
+        return self._get_alms('e', idx)
 
     def get_sim_blm(self, idx):
-        return dev.to_host(self.get_sim_alm_dev('blm', idx))
+        return self._get_alms('b', idx)
 
     def get_sim_tmliklm(self, idx):
         return dev.to_host(self.get_sim_alm_dev('tmliklm', idx))

@@ -123,6 +123,10 @@ class library(object):
     def hashdict(self):
         return {'f2map1': self.f2map1.hashdict(), 'f2map2': self.f2map2.hashdict()}
 
+    # ring-FFT stages of the leg syntheses of the single-simulation MV route on side lanes (shts.lane); a measured non-gain kept as a
+    # tested code path of the lane mechanism, switched per instance, never from the environment
+    pipeline_lanes = False
+
     def get_fundkeys(self, k_list):
         """Fundamental estimators needed to build the (possibly derived) keys of k_list (qest.py:122-141)."""
         ret = []
@@ -373,7 +377,7 @@ class library(object):
         # The five leg syntheses are independent: inside a lane the FFT stage of a synthesis runs on a side stream (own plan
         # fork and phase buffer) while the current stream goes on with the Legendre stage of the next one; joined before
         # the pixel product.
-        lanes = os.environ.get('PLENS_LANES', '0') == '1'  # measured +-2 % at nside 2048: off by default
+        lanes = self.pipeline_lanes  # measured +-2 % at nside 2048: off
         ln = (lambda i: shts.lane(i if lanes else 0))
         with ln(1):
             tmap = f2map1.get_irestmap(idx)

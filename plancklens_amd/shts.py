@@ -28,17 +28,21 @@ _PLANS = {}
 class Plan(object):
     """One (nside, lmax) plan of the HIP engine (ring geometry, recursion and FFT tables, workspaces)."""
 
-    def __init__(self, nside, lmax, shard=None):
-        """shard = (rank, nranks): the plan of one rank of a transform sharded by m-group / ring pair (pl_plan_create_shard)"""
+    def __init__(self, nside, lmax, shard=None, opts=()):
+        """shard = (rank, nranks): the plan of one rank of a transform sharded by m-group / ring pair (pl_plan_create_shard).
+        opts: ((name, value), ...) of pl_plan_opts fields (see `plan_options`); empty = the library's defaults."""
         L = _lib.lib()
         if _lib.device_count() < 1:
             raise RuntimeError('no HIP device visible: plancklens_amd.shts has no CPU path')
         h = ctypes.c_void_p()
-        if shard is None:
-            _lib.check(L.pl_plan_create(int(nside), int(lmax), ctypes.byref(h)))
-        else:
-            _lib.check(L.pl_plan_create_shard(int(nside), int(lmax), int(shard[0]), int(shard[1]), ctypes.byref(h)))
+        o = _lib.PlanOpts(0, -1, -1, -1)
+        for k, v in dict(opts).items():
+            assert hasattr(o, k), 'unknown plan option %s' % k
+            setattr(o, k, int(v))
+        rank, nranks = (0, 1) if shard is None else (int(shard[0]), int(shard[1]))
+        _lib.check(L.pl_plan_create_opts(int(nside), int(lmax), rank, nranks, ctypes.byref(o), ctypes.byref(h)))
         self.shard = shard
+        self.opts = tuple(sorted(dict(opts).items()))
         self.h = h
         self.nside, self.lmax = int(nside), int(lmax)
         self.npix = int(L.pl_plan_npix(h))
@@ -107,6 +111,31 @@ def _plan_key(nside, lmax):
     return (int(nside), int(lmax), dev_id)
 
 
+# ---- plan options: the ring-FFT routing of the plans created inside a `plan_options` block --------------------------------
+_OPTS = ()
+
+
+class plan_options(object):
+    """`with shts.plan_options(fft_legacy=1):` -- transforms issued inside use plans created with these pl_plan_opts fields
+    (fft_legacy, fft_split_min, fft_nyq_min, fft_min_fast; include/plshts.h).  Plans are cached per option set, so the default plans of
+    the process are untouched: the fast-vs-generic tests compare two plans of one grid this way.  Options are explicit arguments of
+    pl_plan_create_opts -- the library reads no environment variable at plan creation."""
+
+    def __init__(self, **opts):
+        self.opts = tuple(sorted((k, int(v)) for k, v in opts.items()))
+
+    def __enter__(self):
+        global _OPTS
+        self.prev = _OPTS
+        _OPTS = self.opts
+        return self
+
+    def __exit__(self, *exc):
+        global _OPTS
+        _OPTS = self.prev
+        return False
+
+
 # ---- plan contexts: independent solvers of one process on different streams ---------------------------------------------
 _CTX = threading.local()
 _PLANS_LOCK = threading.RLock()
@@ -140,9 +169,11 @@ class plan_context(object):
 
 def get_plan(nside, lmax):
     key = _plan_key(nside, lmax)
+    if _OPTS:
+        key = key + (('opts',) + _OPTS,)
     with _PLANS_LOCK:
         if key not in _PLANS:
-            _PLANS[key] = Plan(key[0], key[1])
+            _PLANS[key] = Plan(key[0], key[1], opts=_OPTS)
         c = context()
         return _PLANS[key] if c == 0 else _PLANS[key].fork(('ctx', c))
 
@@ -154,7 +185,7 @@ def geometry_plan(nside, lmax):
     when the grid has no plan yet."""
     dev_id = _plan_key(nside, lmax)[2]
     with _PLANS_LOCK:
-        have = [k for k in _PLANS if len(k) == 3 and k[0] == int(nside) and k[2] == dev_id]
+        have = [k for k in _PLANS if len(k) == 3 and k[0] == int(nside) and k[2] == dev_id] if not _OPTS else []
     if have:
         return get_plan(nside, max(k[1] for k in have))
     return get_plan(nside, lmax)
@@ -355,14 +386,19 @@ def cg_fwd_tt(alm, nside, lmax, n_inv, fl_in=None, fl_out=None, pmat=None, rmat=
     if alm_add is not None:
         alm_add = alm_add.contiguous()
         assert alm_add.shape == a.shape and alm_add.dtype == torch.complex128
-    if dots is not None:  # <alm, result> and <alm, dots.r> from the kernel that writes the result (one shot: consumed by the call below)
-        _arm_post_dots(plan, dots, [a], nb)
+    lr_scratch = None
     if lowrank is not None:
         hpm, hrm = lowrank
         assert pmat is None and pinv_md is None and hpm.shape == hrm.shape and hpm.shape[1] == 2 * plan.nalm and hpm.is_contiguous() and hrm.is_contiguous()
         assert hpm.dtype == torch.float64 and hrm.dtype == torch.float64
         from . import dev as _dev
-        _lib.check(_lib.lib().pl_cg_fwd_tt_lr_b(plan.h, nb, _ptr(a), _ptr(fi), _ptr(n_inv), int(hpm.shape[0]), _ptr(hpm), _ptr(hrm), _ptr(_dev.tproj_scratch(nb)),
+        lr_scratch = _dev.tproj_scratch(nb)  # (raises inside a graph capture when it would have to allocate)
+    # <alm, result> and <alm, dots.r> from the kernel that writes the result.  One shot: armed only now that every check above has
+    # passed, and consumed by the call below at its very top (the library disarms before any of its own early returns)
+    if dots is not None:
+        _arm_post_dots(plan, dots, [a], nb)
+    if lowrank is not None:
+        _lib.check(_lib.lib().pl_cg_fwd_tt_lr_b(plan.h, nb, _ptr(a), _ptr(fi), _ptr(n_inv), int(hpm.shape[0]), _ptr(hpm), _ptr(hrm), _ptr(lr_scratch),
                                                 _ptr(alm_add), _ptr(fa), _ptr(out), _ptr(fo), _stream()))
     elif pinv_md is not None:
         _lib.check(_lib.lib().pl_cg_fwd_tt_md_b(plan.h, nb, _ptr(a), _ptr(fi), _ptr(n_inv), _ptr(pinv_md), _ptr(scratch), _ptr(alm_add), _ptr(fa),

@@ -352,7 +352,7 @@ def test_ring_roundtrip_kernel_is_bit_identical_to_the_two_launches():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sums = []
     for v in ('0', '1'):
-        env = dict(os.environ, PLSHTS_CG_ROUNDTRIP=v)
+        env = dict(os.environ, PLSHTS_DEBUG='1', PLSHTS_CG_ROUNDTRIP=v)  # (development knobs are read under PLSHTS_DEBUG only)
         out = subprocess.run([sys.executable, os.path.join(root, 'tests', 'workers', 'roundtrip_check.py')], cwd=root, env=env,
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]

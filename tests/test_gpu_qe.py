@@ -197,15 +197,15 @@ def test_qe_power_of_gaussian_skies_matches_analytic_n0(tmp_path):
             assert abs(np.sum(pc[sl]) / np.sum(CC[sl]) - 1.) < 0.12, (key, 'C', lo, np.sum(pc[sl]) / np.sum(CC[sl]))
 
 
-def test_mv_estimator_with_pipelined_lanes(setup, monkeypatch):
-    """PLENS_LANES=1: the FFT stage of each leg synthesis runs on a side stream with a fork of the plan (pl_plan_fork, own
+def test_mv_estimator_with_pipelined_lanes(setup):
+    """library.pipeline_lanes: the FFT stage of each leg synthesis runs on a side stream with a fork of the plan (pl_plan_fork, own
     phase buffer) while the current stream continues with the next Legendre stage -- same numbers as the plain path."""
     from plancklens_amd import qest
     g, ivfs, cl, tmp = setup[0], setup[1], setup[4], setup[5]
     q = qest.library_sepTP(os.path.join(tmp, 'qdd_lanes'), ivfs, ivfs, cl['te'], int(g['nside']), lmax_qlm=int(g['lmax_qlm']), cache=False)
     ref = q.get_sim_qlm('p', 0)
     q._mem.clear()
-    monkeypatch.setenv('PLENS_LANES', '1')
+    q.pipeline_lanes = True
     out = q.get_sim_qlm('p', 0)
     assert out is not ref and relrms(out, ref) < 1e-14 and relrms(out, g['dd_p_0']) < TOL
 

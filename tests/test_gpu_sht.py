@@ -166,20 +166,11 @@ def _run_with_plan(shts, plan, fn):
 @pytest.mark.parametrize('nside,lmax', [(256, 300), (256, 512), (512, 512), (512, 1024), (768, 1000), (1024, 1400), (1024, 2048), (2048, 1024), (2048, 2048)])
 def test_register_fft_kernels_match_generic_kernel(shts, nside, lmax):
     """The long rings go through the register-resident ring-FFT kernels (sizes 256 .. 4096, direct and band-limited
-    Bluestein); PLSHTS_FFT_LEGACY=1 at plan creation sends every ring through the generic LDS kernel, which the
+    Bluestein); the plan option fft_legacy (pl_plan_opts) sends every ring through the generic LDS kernel, which the
     small-nside tests above pin against the oracle.  Same inputs, both plans: maps and alm must agree to rounding.
     lmax = 2 nside (every coarse grid of the CG chains): the belt rings carry the order n / 2, which the direct classes treat on its own."""
-    import os
-    os.environ['PLSHTS_FFT_LEGACY'] = '1'
-    try:
-        generic = shts.Plan(nside, lmax)
-    finally:
-        del os.environ['PLSHTS_FFT_LEGACY']
-    os.environ['PLSHTS_FFT_NYQ'] = '256'  # lmax = 2 nside: the belt in the direct classes at every size (default: sub-DFTs >= 2048 only)
-    try:
-        fast = shts.Plan(nside, lmax)
-    finally:
-        del os.environ['PLSHTS_FFT_NYQ']
+    generic = shts.Plan(nside, lmax, opts={'fft_legacy': 1})
+    fast = shts.Plan(nside, lmax, opts={'fft_nyq_min': 256})  # lmax = 2 nside: the belt in the direct classes at every size (default: sub-DFTs >= 2048 only)
     rng = np.random.default_rng(nside + lmax)
     a = random_alm(rng, lmax)
     g, c = random_alm(rng, lmax, 2), random_alm(rng, lmax, 2)

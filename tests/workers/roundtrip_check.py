@@ -1,4 +1,4 @@
-"""Prints a checksum of the CG operators on all-generic grids; run with PLSHTS_CG_ROUNDTRIP=0 and =1: the sums must be equal
+"""Prints a checksum of the CG operators on all-generic grids; run with PLSHTS_DEBUG=1 PLSHTS_CG_ROUNDTRIP=0 and =1: the sums must be equal
 (k_ring_roundtrip is bit-identical to k_phase2map + k_map2phase)."""
 import hashlib
 import sys

@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT"
 NS=${1:-2048}; LM=${2:-2048}; SP=${3:-2}
 for Q in 0 1; do
   rm -rf gpurun_out/fks_$Q
-  PLSHTS_FFT_QUAD=$Q PLSHTS_FFT_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fks_$Q -o t -- python3 tools/kernel_bench.py $NS $LM 5 ps,pa $SP > gpurun_out/fks_$Q.log 2>&1
+  PLSHTS_DEBUG=1 PLSHTS_FFT_QUAD=$Q PLSHTS_FFT_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fks_$Q -o t -- python3 tools/kernel_bench.py $NS $LM 5 ps,pa $SP > gpurun_out/fks_$Q.log 2>&1
   python3 - $Q <<'PY'
 import csv, glob, sys, collections
 q = sys.argv[1]

@@ -2,7 +2,7 @@
 # SQ counters and isolated durations of the ring-FFT kernels (classes serialised on one stream) -- run on the GPU box
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-export PLSHTS_FFT_SERIAL=1
+export PLSHTS_DEBUG=1 PLSHTS_FFT_SERIAL=1
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
 rm -rf gpurun_out/pmc_fft
@@ -22,6 +22,6 @@ PY
 done
 rm -rf gpurun_out/pmc_fft
 unset PLSHTS_FFT_SERIAL
-PLSHTS_FFT_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc_fft -o v -- python3 tools/kernel_bench.py 2048 2048 3 ps,pa 2 > gpurun_out/pmc_fft.log 2>&1
+PLSHTS_DEBUG=1 PLSHTS_FFT_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc_fft -o v -- python3 tools/kernel_bench.py 2048 2048 3 ps,pa 2 > gpurun_out/pmc_fft.log 2>&1
 f=$(find gpurun_out/pmc_fft -name "*kernel_stats.csv" | head -1); echo "== isolated durations (classes serialised), 2 components per launch"; cut -d, -f1-4,6 "$f" | grep phase | head -24
 rm -rf gpurun_out/pmc_fft
