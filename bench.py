@@ -424,6 +424,16 @@ def run_rank(args):
     prof = plan.profile_read()
     plan.profile(False)
     assert len(gathered) == world and mf.size == hp.Alm.getsize(lmax_qlm)
+    # self-check, outside the timed region: the last gradient alm of the timed (paired / replayed) route against a fresh evaluation of the
+    # same simulation through the SINGLE-simulation eager route -- the one tests/test_gpu_fullsize.py compares with the oracle at this
+    # size.  The two routes form every sum in the same order: the difference must be exactly zero.
+    selfcheck = None
+    single = {'p': lambda i: qlms._get_sim_MVgclm(i, 'p'), 'p_p': lambda i: qlms._get_sim_Pgclm(i, 'p_p'), 'ptt': lambda i: qlms._get_sim_Tgclm(i, 'ptt')}
+    if key in single and qlms._last_dev_key is not None and not args.qe_only:
+        g_timed = dev.to_host(qlms._last_dev[0])
+        idx_last = qlms._last_dev_key[1]
+        g_single = np.asarray(dev.resolve(single[key](idx_last)[0]))
+        selfcheck = float(np.max(np.abs(g_single - g_timed)))
     nrec = sum(1 for (k_, i_) in qlms._mem if k_ == key and isinstance(i_, (int, np.integer)))
     assert nrec == K, 'timed region ran %d reconstructions on rank %d, expected %d' % (nrec, rank, K)
     ranks_seen = world
@@ -501,6 +511,7 @@ def run_rank(args):
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / K, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic', 'ranks_seen': ranks_seen,
             'ms_per_step_by_rank': [1e3 * x / K for x in dt_ranks],
+            'selfcheck_max_abs_diff': selfcheck,  # timed route vs single-simulation eager route, same simulation (rank 0); must be 0.0
             'config': {'workload': "'%s' MV quadratic estimator from T,Q,U maps: isotropic filter + qest.library_sepTP, "
                                    "nside=%d lmax_ivf=%d lmax_qlm=%d, 9 SHTs (2 scalar + 7 spin pairs) per reconstruction (BASELINE.json headline config); "
                                    "timed region = qest.library.get_sim_qlm_mf over %d simulations (%d per GPU) + all-gather of the last qlm"

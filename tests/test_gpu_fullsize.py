@@ -327,11 +327,14 @@ def test_cg_operators_at_baseline_size():
     assert max(et, eb, ee, ebb) < 1e-11, (et, eb, ee, ebb)
 
 
-def _estimators_vs_oracle(tmp_path, nside, keys, seed=11):
+def _estimators_vs_oracle(tmp_path, nside, keys, seed=11, pair_check=()):
     """T, Q, U maps at `nside` -> isotropic filter -> the quadratic estimators `keys` at lmax = lmax_qlm = nside, gradient and curl,
     through the product's own classes (filt_simple / qest.library_sepTP) on the GPU and through oracle/qe_oracle.py on the host
     (its transforms routed to the threaded C stages of the oracle: Legendre stage and ring FFTs, every ring pair).
-    Returns {key: (gradient rel rms, curl rel rms)}."""
+    Returns {key: (gradient rel rms, curl rel rms)}.
+    pair_check: keys for which the route the benchmark times -- get_sim_qlm_mf over two simulations, served as a PAIR on shared Legendre
+    recursions (qest._get_sim_*gclm_pair) -- is also run, on a fresh library, and must give the single-route estimates of both simulations
+    bit for bit: the oracle comparison of the single route then covers the timed route."""
     import sys
     import time
     import torch
@@ -359,6 +362,7 @@ def _estimators_vs_oracle(tmp_path, nside, keys, seed=11):
     fbl = 1. / (cls['bb'] + 2e-3 / transf ** 2)
     fbl[:2] = 0.
     maps = rng.standard_normal((3, 12 * nside ** 2))
+    maps1 = rng.standard_normal((3, 12 * nside ** 2)) if pair_check else None  # simulation 1 of the pair check
     saved = {k: getattr(so, k) for k in fast}
     t0 = time.time()
     ref = {}
@@ -378,10 +382,11 @@ def _estimators_vs_oracle(tmp_path, nside, keys, seed=11):
             return {'fullsize': seed}
 
         def get_sim_tmap(self, idx):
-            return maps[0]
+            return (maps if idx == 0 else maps1)[0]
 
         def get_sim_pmap(self, idx):
-            return maps[1], maps[2]
+            m = maps if idx == 0 else maps1
+            return m[1], m[2]
     ivfs = filt_simple.library_fullsky_sepTP(str(tmp_path / 'ivfs'), sims(), nside, transf, cls, fl, fel, fbl, cache=False)
     ql = qest.library_sepTP(str(tmp_path / 'ql'), ivfs, ivfs, cls['te'], nside, lmax_qlm=lmax, cache=False)
     out = {}
@@ -392,6 +397,19 @@ def _estimators_vs_oracle(tmp_path, nside, keys, seed=11):
         out[key] = (relrms(G, ref[key][0]), relrms(C, ref[key][1]))
         _note("'%s' end to end at nside = lmax = lmax_qlm = %d vs oracle: gradient rel rms %.2e, curl %.2e" % ((key, nside) + out[key]))
     _note("   (oracle: filter + %s in %.0f s on %d threads)" % (', '.join(keys), t_oracle, nt))
+    for key in pair_check:
+        kx = 'x' + key[1:]
+        single = [ql.get_sim_qlm(k_, i) for i in (0, 1) for k_ in (key, kx)]
+        ivfs2 = filt_simple.library_fullsky_sepTP(str(tmp_path / ('ivfs2' + key)), sims(), nside, transf, cls, fl, fel, fbl, cache=False)
+        ql2 = qest.library_sepTP(str(tmp_path / ('ql2' + key)), ivfs2, ivfs2, cls['te'], nside, lmax_qlm=lmax, cache=False)
+        assert ql2._pair_getter(key, lmax) is not None, 'the paired route is not taken for %s' % key
+        mf = ql2.get_sim_qlm_mf(key, np.array([0, 1]), collective=True)  # the call bench.py times
+        paired = [ql2.get_sim_qlm(k_, i) for i in (0, 1) for k_ in (key, kx)]
+        for a, b in zip(paired, single):
+            assert np.array_equal(a, b), "paired route differs from the single route for '%s'" % key
+        assert relrms(mf, 0.5 * (single[0] + single[2])) < 1e-15
+        _note("'%s' at nside %d: the paired route of get_sim_qlm_mf (what bench.py times) equals the single route bit for bit (2 simulations, "
+              "gradient and curl)" % (key, nside))
     return out
 
 
@@ -399,7 +417,7 @@ def test_estimators_end_to_end_at_baseline_size(tmp_path):
     """BASELINE.json's configurations 2, 3 and the headline one by name, end to end against the oracle at nside = lmax = lmax_qlm =
     2048: 'ptt' (the gradient-only spin-1 synthesis k_leg_synths<R, true>), 'p_p' (spin-2 / spin-3 legs) and the MV 'p' (paired
     spin-1 synthesis, the nine-map product).  north_star asks for qlm rms agreement < 1e-8; observed ~1e-13."""
-    out = _estimators_vs_oracle(tmp_path, 2048, ['p', 'ptt', 'p_p'])
+    out = _estimators_vs_oracle(tmp_path, 2048, ['p', 'ptt', 'p_p'], pair_check=['p'])
     for key, (eg, ec) in out.items():
         assert eg < 1e-8 and ec < 1e-8, (key, eg, ec)
         assert eg < 1e-11 and ec < 1e-11, (key, eg, ec)  # what the arithmetic delivers; the line above is north_star's bar
@@ -409,7 +427,7 @@ def test_ptt_end_to_end_at_config1_size(tmp_path):
     """BASELINE config 1's exact workload -- the temperature-only 'ptt' estimator at nside = lmax = lmax_qlm = 512 (the reference's own
     CPU-runnable case, idealized_example.py on a small grid) -- end to end against the oracle: the 512 plan picks other rings-per-lane
     and ring-FFT classes than the 2048 one.  The polarization and MV keys ride along (the oracle does this size in seconds)."""
-    out = _estimators_vs_oracle(tmp_path, 512, ['ptt', 'p_p', 'p'], seed=13)
+    out = _estimators_vs_oracle(tmp_path, 512, ['ptt', 'p_p', 'p'], seed=13, pair_check=['ptt', 'p_p', 'p'])
     for key, (eg, ec) in out.items():
         assert eg < 1e-8 and ec < 1e-8, (key, eg, ec)
         assert eg < 1e-11 and ec < 1e-11, (key, eg, ec)

@@ -361,7 +361,7 @@ def test_ortho_scalar_product_from_the_preconditioner_kernels():
                 assert relrms(dev.to_host(a), dev.to_host(b)) < 1e-12
 
 
-@pytest.mark.parametrize('nside,lmax,spin', [(32, 64, 1), (128, 200, 1), (64, 95, 3), (512, 512, 1)])
+@pytest.mark.parametrize('nside,lmax,spin', [(32, 64, 1), (128, 200, 1), (64, 95, 3), (512, 512, 1), (2048, 2048, 1)])
 def test_two_gradient_only_syntheses_on_one_recursion(nside, lmax, spin):
     """pl_alm2map_grad_pair (k_leg_synths<R, true, 1>: the gradient legs of the temperature estimator of two simulations, 12 instead of
     2 x 8 FMAs per step) gives the maps of two pl_alm2map_grad calls bit for bit, with one filter or two."""

@@ -192,3 +192,28 @@ def test_spectral_matrix_and_statistics_helpers():
     alm = rng.standard_normal(10) + 1j * rng.standard_normal(10)
     alm[:4] = alm[:4].real
     assert np.allclose(utils.rlm2alm(utils.alm2rlm(alm)), alm) and utils.alm2rlm(alm).size == 16
+
+
+def test_sql_tables_follow_the_reference_schema(tmp_path):
+    """helpers.sql.npdb / fldb (plancklens/helpers/sql.py:28-106): same table and column names (files interchangeable with the reference's),
+    add refuses duplicates without raising, get returns None for a missing id, remove deletes."""
+    import sqlite3
+    from plancklens_amd.helpers import sql
+    db = sql.npdb(str(tmp_path / 'cl.db'))
+    v = np.arange(5.) * 0.5
+    assert db.get('a') is None
+    db.add('a', v)
+    db.add('a', 2 * v)  # refused ("npdb add failed!"), the first entry stays
+    assert np.array_equal(db.get('a'), v) and db.get('a').ndim == 1
+    db.remove('a')
+    assert db.get('a') is None
+    fl = sql.fldb(str(tmp_path / 'fl.db'), idtype='INTEGER')
+    fl.add(3, 0.25)
+    fl.add(3, 0.5)
+    assert fl.get(3) == 0.25 and fl.get(4) is None
+    fl.remove(3)
+    assert fl.get(3) is None
+    for fn, table, cols in (('cl.db', 'npdb', ['id', 'arr']), ('fl.db', 'fldb', ['id', 'fl'])):
+        con = sqlite3.connect(str(tmp_path / fn))
+        assert [r[1] for r in con.execute('PRAGMA table_info(%s)' % table)] == cols
+        con.close()
