@@ -1,6 +1,8 @@
 """Generates tests/golden/*.npz by running the REFERENCE's own Python (imported from /root/reference, in this
 container only) on seeded inputs, with its `healpy` dependency (absent here) stood in by the CPU oracle's SHTs
-(oracle/sht_oracle.py) and the healpy-compatible host helpers (plancklens_amd/hp.py).
+(oracle/sht_oracle.py) and the oracle's own restatement of the healpy host helpers (oracle/hp_oracle.py: Alm, almxfl, alm2cl,
+gauss_beam, ud_grade, ... -- independent of the product's plancklens_amd/hp.py, which only lends the FITS readers / writers (the
+file formats are pinned by tests/test_host.py) and the pixel angles used to draw the input masks).
 
 What the fixtures pin: everything the reference does ABOVE the SHT seam -- isotropic filtering
 (filt_simple.library_fullsky_sepTP), the specialised QE route (qest.library_sepTP.get_sim_qlm), the generic
@@ -8,7 +10,9 @@ route (qest.eval_qe), index shuffling / leg symmetrisation (filt_util.library_sh
 evaluated with SHTs that are themselves pinned by tests/test_oracle.py.  Only data (inputs and the
 reference's outputs) is stored; no reference source is copied.
 
-Run:  python tests/golden/make_golden.py      (needs /root/reference; not needed on the GPU box)
+Run:  python tests/golden/make_golden.py      (needs /root/reference; not needed on the GPU box; `... cinv` separately: 20 minutes)
+The generator is reproducible to rounding only: the oracle's threaded stages and the reference's OpenMP Fortran sum in an order that
+depends on the thread count and, for the Fortran reductions, on the run (two runs of `resp` differ in 26 of 80 arrays at <= 2e-15).
 """
 import os
 import shutil
@@ -24,15 +28,17 @@ sys.path.insert(0, ROOT)
 REF = '/root/reference'
 
 from oracle import sht_oracle as so  # noqa: E402
-from plancklens_amd import hp as myhp  # noqa: E402
+from oracle import hp_oracle as oh  # noqa: E402
+from plancklens_amd import hp as myhp  # noqa: E402  (FITS IO and the angles of the input masks only)
 
 
 def install_healpy_standin():
     """A module object named `healpy` built from the oracle SHTs + host helpers (never written to disk)."""
     m = types.ModuleType('healpy')
-    for name in ['Alm', 'almxfl', 'alm2cl', 'gauss_beam', 'nside2npix', 'npix2nside', 'nside2pixarea', 'ud_grade',
-                 'read_alm', 'write_alm', 'read_map', 'write_map', 'pix2ang', 'pix2vec', 'UNSEEN']:
-        setattr(m, name, getattr(myhp, name))
+    for name in ['Alm', 'almxfl', 'alm2cl', 'gauss_beam', 'nside2npix', 'npix2nside', 'nside2pixarea', 'ud_grade', 'pix2ang', 'pix2vec', 'UNSEEN']:
+        setattr(m, name, getattr(oh, name))     # arithmetic the reference's results depend on: the oracle's own
+    for name in ['read_alm', 'write_alm', 'read_map', 'write_map']:
+        setattr(m, name, getattr(myhp, name))   # file formats (tests/test_host.py)
     def alm2map(alm, nside, lmax=None, mmax=None, pol=False, **kw):
         if pol and not isinstance(alm, np.ndarray) and len(alm) == 3:  # (T, E, B) -> (T, Q, U), as healpy's pol=True
             q, u = so.alm2map_spin([np.asarray(alm[1]), np.asarray(alm[2])], nside, 2, so.alm_lmax(len(alm[1])))
@@ -73,24 +79,24 @@ class tiny_sims(object):
             return a
         u1, u2, u3 = unit(), unit(), unit()
         tt, ee, bb, te = (self.cls[k][:self.lmax + 1] for k in ['tt', 'ee', 'bb', 'te'])
-        tlm = myhp.almxfl(u1, np.sqrt(tt))
+        tlm = oh.almxfl(u1, np.sqrt(tt))
         r = te * np.where(tt > 0, 1. / np.sqrt(np.where(tt > 0, tt, 1.)), 0.)
-        elm = myhp.almxfl(u1, r) + myhp.almxfl(u2, np.sqrt(np.maximum(ee - r ** 2, 0.)))
-        blm = myhp.almxfl(u3, np.sqrt(bb))
+        elm = oh.almxfl(u1, r) + oh.almxfl(u2, np.sqrt(np.maximum(ee - r ** 2, 0.)))
+        blm = oh.almxfl(u3, np.sqrt(bb))
         return tlm, elm, blm
 
     def _noise(self, idx, f):
         rng = np.random.default_rng(2000 + 3 * idx + f)
-        vamin = np.sqrt(myhp.nside2pixarea(self.nside, degrees=True)) * 60
+        vamin = np.sqrt(oh.nside2pixarea(self.nside, degrees=True)) * 60
         return (self.nlev_t if f == 0 else self.nlev_p) / vamin * rng.standard_normal(12 * self.nside ** 2)
 
     def get_sim_tmap(self, idx):
         tlm, _, _ = self._alms(idx)
-        return so.alm2map(myhp.almxfl(tlm, self.transf), self.nside, lmax=self.lmax) + self._noise(idx, 0)
+        return so.alm2map(oh.almxfl(tlm, self.transf), self.nside, lmax=self.lmax) + self._noise(idx, 0)
 
     def get_sim_pmap(self, idx):
         _, elm, blm = self._alms(idx)
-        q, u = so.alm2map_spin([myhp.almxfl(elm, self.transf), myhp.almxfl(blm, self.transf)], self.nside, 2, self.lmax)
+        q, u = so.alm2map_spin([oh.almxfl(elm, self.transf), oh.almxfl(blm, self.transf)], self.nside, 2, self.lmax)
         return q + self._noise(idx, 1), u + self._noise(idx, 2)
 
 
@@ -106,7 +112,7 @@ def main():
     cl_len = utils.camb_clfile(cls_path, lmax=lmax_ivf)
     # bring the spectra to O(1) signal-to-noise at these tiny multipoles
     nlev_t, nlev_p = 1200., 35.
-    transf = myhp.gauss_beam(4. / 180. * np.pi, lmax=lmax_ivf)
+    transf = oh.gauss_beam(4. / 180. * np.pi, lmax=lmax_ivf)
     sims = tiny_sims(nside, lmax_ivf, cl_len, transf, nlev_t, nlev_p)
     arcmin = np.pi / 180. / 60.
     ftl = utils.cli(cl_len['tt'][:lmax_ivf + 1] + (nlev_t * arcmin) ** 2 * utils.cli(transf ** 2))
@@ -148,9 +154,6 @@ def main():
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     np.savez_compressed(os.path.join(HERE, 'qe_golden.npz'), **out)
-    make_cg_golden()
-    make_resp_golden()
-    make_lib_golden()
     print('wrote qe_golden.npz with %d arrays' % len(out))
     for k in ['ptt', 'p_p', 'p']:
         d = np.abs(out['gen_%s_G' % k] - out['dd_%s_0' % k]).max() / np.abs(out['dd_%s_0' % k]).max()
@@ -167,14 +170,14 @@ def make_cg_golden():
     ell = np.arange(lmax + 1.)
     cl = {'tt': np.where(ell >= 2, 3e3 / np.maximum(ell, 1.) ** 2.2, 0.), 'ee': np.where(ell >= 2, 60. / np.maximum(ell, 1.) ** 1.8, 0.),
           'bb': np.where(ell >= 2, 2. / np.maximum(ell, 1.) ** 1.5, 0.)}
-    transf = myhp.gauss_beam(6. / 180. * np.pi, lmax=lmax)
+    transf = oh.gauss_beam(6. / 180. * np.pi, lmax=lmax)
     th, ph = myhp.pix2ang(nside)
     mask = (np.abs(np.cos(th)) > 0.25).astype(float)                         # galactic-like band removed
     ninv_t = mask * (0.5 + 0.4 * np.sin(3 * ph) * np.sin(th)) / 40. ** 2 * (npix / (4 * np.pi)) * 1e-4
     ninv_p = mask * (0.6 + 0.3 * np.cos(2 * ph)) / 10. ** 2 * (npix / (4 * np.pi)) * 1e-4
-    tmap = so.alm2map(myhp.almxfl(myhp.synalm(cl['tt'], lmax, rng), transf), nside) + rng.standard_normal(npix) * 40.
-    e, b = myhp.synalm(cl['ee'], lmax, rng), myhp.synalm(cl['bb'], lmax, rng)
-    q, u = so.alm2map_spin([myhp.almxfl(e, transf), myhp.almxfl(b, transf)], nside, 2, lmax)
+    tmap = so.alm2map(oh.almxfl(oh.synalm(cl['tt'], lmax, rng), transf), nside) + rng.standard_normal(npix) * 40.
+    e, b = oh.synalm(cl['ee'], lmax, rng), oh.synalm(cl['bb'], lmax, rng)
+    q, u = so.alm2map_spin([oh.almxfl(e, transf), oh.almxfl(b, transf)], nside, 2, lmax)
     qmap, umap = q + rng.standard_normal(npix) * 10., u + rng.standard_normal(npix) * 10.
     out = {'nside': nside, 'lmax': lmax, 'transf': transf, 'ninv_t': ninv_t, 'ninv_p': ninv_p, 'tmap': tmap, 'qmap': qmap,
            'umap': umap, 'cl_tt': cl['tt'], 'cl_ee': cl['ee'], 'cl_bb': cl['bb']}
@@ -194,7 +197,7 @@ def make_cg_golden():
     out['cg_tlm'] = talm
     out['cg_t_trace'] = np.array([t[2] for t in trace if t[0] == 0])
     out['cg_t_prep'] = opfilt_tt.calc_prep(tmap, cl, n_inv_filt)
-    x = myhp.synalm(cl['tt'], lmax, rng)
+    x = oh.synalm(cl['tt'], lmax, rng)
     out['cg_t_x'] = x
     out['cg_t_fwd'] = opfilt_tt.fwd_op(cl, n_inv_filt)(x)
     out['cg_t_diag'] = opfilt_tt.pre_op_diag(cl, n_inv_filt)(x)
@@ -208,7 +211,7 @@ def make_cg_golden():
     chain_p.solve(palm, [qmap, umap])
     out['cg_elm'], out['cg_blm'] = palm.elm, palm.blm
     out['cg_p_trace'] = np.array([t[2] for t in trace if t[0] == 0])
-    xe = util_alm.eblm([myhp.synalm(cl['ee'], lmax, rng), myhp.synalm(cl['bb'], lmax, rng)])
+    xe = util_alm.eblm([oh.synalm(cl['ee'], lmax, rng), oh.synalm(cl['bb'], lmax, rng)])
     out['cg_p_xe'], out['cg_p_xb'] = xe.elm, xe.blm
     f = opfilt_pp.fwd_op(cl, n_inv_filt_p)(xe)
     out['cg_p_fwd_e'], out['cg_p_fwd_b'] = f.elm, f.blm
@@ -218,7 +221,7 @@ def make_cg_golden():
     cl_tp = dict(cl)
     cl_tp['te'] = 0.6 * np.sqrt(cl['tt'] * cl['ee'])
     out['cl_te'] = cl_tp['te']
-    transf_e = myhp.gauss_beam(7. / 180. * np.pi, lmax=lmax)   # different beam for polarization
+    transf_e = oh.gauss_beam(7. / 180. * np.pi, lmax=lmax)   # different beam for polarization
     out['transf_e'] = transf_e
     n_inv_filt_tp = opfilt_tp.alm_filter_ninv([ninv_t, ninv_p], transf, b_transf_e=transf_e, b_transf_b=transf_e,
                                               marge_monopole=True, marge_dipole=True)
@@ -230,7 +233,7 @@ def make_cg_golden():
     chain_tp.solve(tpalm, [tmap, qmap, umap])
     out['cg_tp_tlm'], out['cg_tp_elm'], out['cg_tp_blm'] = tpalm.tlm, tpalm.elm, tpalm.blm
     out['cg_tp_trace'] = np.array([t[2] for t in trace if t[0] == 0])
-    xt = util_alm.teblm([myhp.synalm(cl['tt'], lmax, rng), myhp.synalm(cl['ee'], lmax, rng), myhp.synalm(cl['bb'], lmax, rng)])
+    xt = util_alm.teblm([oh.synalm(cl['tt'], lmax, rng), oh.synalm(cl['ee'], lmax, rng), oh.synalm(cl['bb'], lmax, rng)])
     out['cg_tp_xt'], out['cg_tp_xe'], out['cg_tp_xb'] = xt.tlm, xt.elm, xt.blm
     f = opfilt_tp.fwd_op(cl_tp, n_inv_filt_tp)(xt)
     out['cg_tp_fwd_t'], out['cg_tp_fwd_e'], out['cg_tp_fwd_b'] = f.tlm, f.elm, f.blm
@@ -288,7 +291,7 @@ def make_resp_golden():
     lmax_ivf, lmax_qlm, lmin_ivf = 40, 47, 4
     cls_path = os.path.join(ROOT, 'plancklens_amd', 'data', 'cls', 'FFP10_wdipole_lensedCls.dat')
     cl_len = utils.camb_clfile(cls_path, lmax=lmax_ivf)
-    transf = myhp.gauss_beam(4. / 180. * np.pi, lmax=lmax_ivf)
+    transf = oh.gauss_beam(4. / 180. * np.pi, lmax=lmax_ivf)
     arcmin = np.pi / 180. / 60.
     fal = {'tt': utils.cli(cl_len['tt'][:lmax_ivf + 1] + (1200. * arcmin) ** 2 * utils.cli(transf ** 2)),
            'ee': utils.cli(cl_len['ee'][:lmax_ivf + 1] + (35. * arcmin) ** 2 * utils.cli(transf ** 2)),
@@ -341,7 +344,7 @@ def make_lib_golden():
     cls_path = os.path.join(ROOT, 'plancklens_amd', 'data', 'cls', 'FFP10_wdipole_lensedCls.dat')
     cl_len = utils.camb_clfile(cls_path, lmax=lmax_ivf)
     nlev_t, nlev_p = 1200., 35.
-    transf = myhp.gauss_beam(4. / 180. * np.pi, lmax=lmax_ivf)
+    transf = oh.gauss_beam(4. / 180. * np.pi, lmax=lmax_ivf)
     sims = tiny_sims(nside, lmax_ivf, cl_len, transf, nlev_t, nlev_p)
     arcmin = np.pi / 180. / 60.
     ftl = utils.cli(cl_len['tt'][:lmax_ivf + 1] + (nlev_t * arcmin) ** 2 * utils.cli(transf ** 2))
@@ -447,7 +450,7 @@ def make_sims_golden():
             out['sky_%slm_1' % f] = sky.get_sim_alm(1, f)
         fixed = cmbs.sims_cmb_unl_fixed_phi(cls, lp)
         out['fixed_plm_1'], out['fixed_tlm_1'] = fixed.get_sim_plm(1), fixed.get_sim_tlm(1)
-        transf = myhp.gauss_beam(8. / 180. * np.pi, lmax=lmax)
+        transf = oh.gauss_beam(8. / 180. * np.pi, lmax=lmax)
         out['transf'] = transf
         nl = maps.cmb_maps_nlev(sky, transf, 50., 70., nside, pix_lib_phas=pp)
         out['nlev_tmap_0'] = nl.get_sim_tmap(0)
@@ -516,7 +519,7 @@ def make_sims_golden():
         cls_path = os.path.join(ROOT, 'plancklens_amd', 'data', 'cls', 'FFP10_wdipole_lensedCls.dat')
         cl_len = utils.camb_clfile(cls_path, lmax=lmax_ivf)
         nlev_t, nlev_p = 1200., 35.
-        transf_q = myhp.gauss_beam(4. / 180. * np.pi, lmax=lmax_ivf)
+        transf_q = oh.gauss_beam(4. / 180. * np.pi, lmax=lmax_ivf)
         sims = tiny_sims(nside_q, lmax_ivf, cl_len, transf_q, nlev_t, nlev_p)
         arcmin = np.pi / 180. / 60.
         ftl = utils.cli(cl_len['tt'][:lmax_ivf + 1] + (nlev_t * arcmin) ** 2 * utils.cli(transf_q ** 2))
@@ -554,7 +557,7 @@ def make_cg2_golden():
     cl = {'tt': np.where(ell >= 2, 3e3 / np.maximum(ell, 1.) ** 2.2, 0.), 'ee': np.where(ell >= 2, 60. / np.maximum(ell, 1.) ** 1.8, 0.),
           'bb': np.where(ell >= 2, 2. / np.maximum(ell, 1.) ** 1.5, 0.)}
     cl['te'] = 0.6 * np.sqrt(cl['tt'] * cl['ee'])
-    transf = myhp.gauss_beam(6. / 180. * np.pi, lmax=lmax)
+    transf = oh.gauss_beam(6. / 180. * np.pi, lmax=lmax)
     th, ph = myhp.pix2ang(nside)
     mask = (np.abs(np.cos(th)) > 0.25).astype(float)
     sc = (npix / (4 * np.pi)) * 1e-4
@@ -569,7 +572,7 @@ def make_cg2_golden():
            'tmap': tmap, 'tq0': tq[0], 'tq1': tq[1], 'tu0': tu[0]}
     for k in cl:
         out['cl_' + k] = cl[k]
-    x = util_alm.eblm([myhp.synalm(cl['ee'], lmax, rng), myhp.synalm(cl['bb'], lmax, rng)])
+    x = util_alm.eblm([oh.synalm(cl['ee'], lmax, rng), oh.synalm(cl['bb'], lmax, rng)])
     out['xe'], out['xb'] = x.elm, x.blm
     # (QQ, QU, UU)
     f3 = opfilt_pp.alm_filter_ninv([nqq, nqu, nuu], transf)
@@ -585,7 +588,7 @@ def make_cg2_golden():
     out['ppm_prep_e'], out['ppm_prep_b'] = pr.elm, pr.blm
     # joint filter, four maps
     f4 = opfilt_tp.alm_filter_ninv([ntt, nqq, nqu, nuu], transf, marge_monopole=True, marge_dipole=True)
-    xt = util_alm.teblm([myhp.synalm(cl['tt'], lmax, rng), myhp.synalm(cl['ee'], lmax, rng), myhp.synalm(cl['bb'], lmax, rng)])
+    xt = util_alm.teblm([oh.synalm(cl['tt'], lmax, rng), oh.synalm(cl['ee'], lmax, rng), oh.synalm(cl['bb'], lmax, rng)])
     out['tp4_xt'], out['tp4_xe'], out['tp4_xb'] = xt.tlm, xt.elm, xt.blm
     r = opfilt_tp.fwd_op(cl, f4)(xt)
     out['tp4_fwd_t'], out['tp4_fwd_e'], out['tp4_fwd_b'] = r.tlm, r.elm, r.blm
@@ -640,7 +643,7 @@ def make_cinv_golden():
                 names = ['elm', 'blm']
             out['trace_' + kind] = np.array([t[2] for t in trace if t[0] == 0])
             for nm, a in zip(names, sol):
-                out[nm + '_cl'] = myhp.alm2cl(a)
+                out[nm + '_cl'] = oh.alm2cl(a)
                 out[nm + '_sub'] = a[sub]
                 out[nm + '_low'] = a[out['low']]
             print('cinv_%s: %d top-level iterations in %.0f s, last eps %.3e' % (kind, len(out['trace_' + kind]), time.time() - t0,
@@ -659,7 +662,7 @@ def make_mfresp_golden():
     lmax_qe, lmax_out, lmin = 40, 47, 4
     cls_path = os.path.join(ROOT, 'plancklens_amd', 'data', 'cls', 'FFP10_wdipole_lensedCls.dat')
     cl_len = utils.camb_clfile(cls_path, lmax=lmax_qe + 20)   # the CMB spectra reach beyond the filtered range, as in an analysis
-    transf = myhp.gauss_beam(4. / 180. * np.pi, lmax=lmax_qe)
+    transf = oh.gauss_beam(4. / 180. * np.pi, lmax=lmax_qe)
     arcmin = np.pi / 180. / 60.
     ivf = {'tt': utils.cli(cl_len['tt'][:lmax_qe + 1] + (1200. * arcmin) ** 2 * utils.cli(transf ** 2)),
            'ee': utils.cli(cl_len['ee'][:lmax_qe + 1] + (35. * arcmin) ** 2 * utils.cli(transf ** 2)),
@@ -703,3 +706,8 @@ if __name__ == '__main__':
         make_cg_golden()
     else:
         main()
+        # every other fixture set in a process of its own (the response fixtures install the Fortran Wigner stand-in BEFORE the reference's
+        # modules are imported; 'cinv' -- the reference's own cinv_t / cinv_p solves at nside 512 -- takes ~20 minutes of CPU and is run by name)
+        import subprocess
+        for part in ('cg', 'resp', 'lib', 'sims', 'cg2', 'mfresp'):
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), part])

@@ -228,3 +228,42 @@ def test_preallocated_outputs_of_the_c_stages(oracle):
         # mode 1 (vectorised, scaled double) against mode 0 (long double) on the same inputs
         assert np.abs(ref - so.legendre(0, 0, spin, lmax, lmax, c, s, pair, alm=alm)).max() < 1e-12 * np.abs(ref).max()
         assert np.abs(aref - so.legendre(1, 0, spin, lmax, lmax, c, s, pair, phase=ph)).max() < 1e-12 * np.abs(aref).max()
+
+
+def test_oracle_host_helpers_agree_with_the_products():
+    """oracle/hp_oracle.py (what the golden generator hands the reference as `healpy`) and plancklens_amd/hp.py (the product's host
+    helpers) are written independently; on random inputs they must agree -- bit for bit where the arithmetic is a fixed sequence
+    (index maps, almxfl, alm2cl, gauss_beam, synalm), to a few ulp for the degrade (different summation order) and the pixel angles."""
+    from oracle import hp_oracle as oh
+    from plancklens_amd import hp
+    rng = np.random.default_rng(77)
+    for lmax in (0, 1, 7, 40, 129):
+        n = oh.Alm.getsize(lmax)
+        assert n == hp.Alm.getsize(lmax) and oh.Alm.getlmax(n) == lmax == hp.Alm.getlmax(n) and oh.Alm.getlmax(n + 1) == -1
+        l1, m1 = oh.Alm.getlm(lmax)
+        l2, m2 = hp.Alm.getlm(lmax)
+        assert np.array_equal(l1, l2) and np.array_equal(m1, m2) and np.array_equal(oh.Alm.getidx(lmax, l1, m1), np.arange(n))
+        a = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        for fl in (rng.standard_normal(lmax + 1), rng.standard_normal(max(1, lmax // 2)), rng.standard_normal(lmax + 9)):
+            assert np.array_equal(oh.almxfl(a, fl), hp.almxfl(a, fl))
+        assert np.array_equal(oh.alm2cl(a), hp.alm2cl(a)) and np.array_equal(oh.alm2cl(a, b), hp.alm2cl(a, b))
+        assert np.array_equal(oh.alm2cl(a, b, lmax_out=lmax + 3), hp.alm2cl(a, b, lmax_out=lmax + 3))
+        cl = rng.uniform(0.1, 2., lmax + 1)
+        assert np.array_equal(oh.synalm(cl, lmax, np.random.default_rng(5)), hp.synalm(cl, lmax, np.random.default_rng(5)))
+    for fwhm in (0.01, 0.1):
+        assert np.array_equal(oh.gauss_beam(fwhm, lmax=300), hp.gauss_beam(fwhm, lmax=300))
+    for nside in (1, 2, 8, 32):
+        assert oh.nside2npix(nside) == hp.nside2npix(nside) and oh.npix2nside(12 * nside ** 2) == nside
+        assert oh.nside2pixarea(nside, degrees=True) == hp.nside2pixarea(nside, degrees=True)
+        t1, p1 = oh.pix2ang(nside)
+        t2, p2 = hp.pix2ang(nside)
+        assert np.max(np.abs(t1 - t2)) < 1e-14 and np.max(np.abs(p1 - p2)) < 1e-14
+        assert np.array_equal(oh.ang2pix(nside, t2, p2), np.arange(12 * nside ** 2))  # every centre lies in its own pixel
+        m = rng.standard_normal(12 * nside ** 2)
+        nout = nside
+        while nout >= 1:
+            for power in (None, -2):
+                x, y = oh.ud_grade(m, nout, power=power), hp.ud_grade(m, nout, power=power)
+                assert np.max(np.abs(x - y)) <= 1e-14 * np.max(np.abs(y))
+            nout //= 2
