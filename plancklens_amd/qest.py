@@ -401,10 +401,12 @@ class library(object):
             return dev.host_future(G), dev.host_future(C)
         return dev.to_host(G), dev.to_host(C)
 
-    def _get_sim_MVgclm_pair(self, idx0, idx1, defer=False):
+    # ---- two simulations at a time: the leg syntheses of a pair share Legendre recursions ---------------------------------------------
+    # Each family has a device part (`_pair_dev_*`: filtered alms resident -> device (G, C) of both simulations, no host interaction:
+    # what `_pair_graph` captures) and the common host part (`_pair_out`).
+    def _pair_dev_p(self, idx0, idx1):
         """_get_sim_MVgclm of two simulations whose spin-2 and spin-3 leg syntheses share their Legendre recursions
-        (lib_filt2map.get_irespmap_batch2 / get_gpmap_batch2; same legs on both sides only).  Returns, per simulation,
-        (G host, C host, G device, C device); the host entries are dev.host_future objects when `defer`."""
+        (lib_filt2map.get_irespmap_batch2 / get_gpmap_batch2; same legs on both sides only)."""
         f2map1, f2map2 = self._legs(False)
         idxs = (idx0, idx1)
         tmaps = [f2map1.get_irestmap(i) for i in idxs]
@@ -415,18 +417,13 @@ class library(object):
             (gt, ct), (g1, c1) = f2map2.get_gt_gp1maps(idx, k='p')
             dre, dim = dev.qe_lens_product((tmaps[j], gt, ct), (resp[j][0], resp[j][1], gp3[j][0], gp3[j][1], g1, c1))
             del gt, ct, g1, c1
-            G, C = self._gc_from_product(dre, dim, 'P')
-            if defer and G.numel() >= self._DEFER_MIN_ENTRIES:
-                out.append((dev.host_future(G), dev.host_future(C), G, C))
-            else:
-                out.append((dev.to_host(G), dev.to_host(C), G, C))
-        self._last_dev, self._last_dev_key = (out[1][2], out[1][3]), ('p', idx1, False)
+            out.append(tuple(self._gc_from_product(dre, dim, 'P')))
         return out
 
-    def _get_sim_Pgclm_pair(self, idx0, idx1, defer=False):
+    def _pair_dev_p_p(self, idx0, idx1):
         """_get_sim_Pgclm of two simulations: the spin-2, spin-3 and spin-1 leg syntheses each serve both on one Legendre recursion
         (lib_filt2map.get_irespmap_batch2 / get_gpmap_batch2; same legs on both sides only); maps bit-identical to the one-by-one
-        evaluation.  Returns, per simulation, (G host, C host, G device, C device) like _get_sim_MVgclm_pair."""
+        evaluation."""
         f2map1, f2map2 = self._legs(False)
         resp = f2map1.get_irespmap_batch2(idx0, idx1)
         gp3 = f2map2.get_gpmap_batch2(idx0, idx1, 3, k='p_p')
@@ -434,15 +431,10 @@ class library(object):
         out = []
         for j in (0, 1):
             dre, dim = dev.qe_lens_product(None, (resp[j][0], resp[j][1], gp3[j][0], gp3[j][1], gp1[j][0], gp1[j][1]))
-            G, C = self._gc_from_product(dre, dim, 'P')
-            if defer and G.numel() >= self._DEFER_MIN_ENTRIES:
-                out.append((dev.host_future(G), dev.host_future(C), G, C))
-            else:
-                out.append((dev.to_host(G), dev.to_host(C), G, C))
-        self._last_dev, self._last_dev_key = (out[1][2], out[1][3]), ('p_p', idx1, False)
+            out.append(tuple(self._gc_from_product(dre, dim, 'P')))
         return out
 
-    def _get_sim_Tgclm_pair(self, idx0, idx1, defer=False):
+    def _pair_dev_ptt(self, idx0, idx1):
         """_get_sim_Tgclm of two simulations: their gradient legs (gradient-only spin-1 syntheses, 8 FMAs per step each) share one
         Legendre recursion (lib_filt2map.get_gtmap_pair, pl_alm2map_grad_pair: 12 for the two; maps bit-identical to the one-by-one
         evaluation), and the filter stage of both is issued before either estimator."""
@@ -453,14 +445,203 @@ class library(object):
         out = []
         for j, idx in enumerate((idx0, idx1)):
             if gts is None:
-                G, C = self._get_sim_Tgclm_dev(idx, 'ptt')
+                out.append(tuple(self._get_sim_Tgclm_dev(idx, 'ptt')))
             else:
-                G, C = self._gc_from_product(*dev.qe_lens_product((f2map1.get_irestmap(idx), gts[j][0], gts[j][1]), None), 'T')
+                out.append(tuple(self._gc_from_product(*dev.qe_lens_product((f2map1.get_irestmap(idx), gts[j][0], gts[j][1]), None), 'T')))
+        return out
+
+    def _pair_out(self, fam, idx1, gcs, defer):
+        """per simulation (G host, C host, G device, C device); the host entries are dev.host_future objects when `defer`"""
+        out = []
+        for G, C in gcs:
             if defer and G.numel() >= self._DEFER_MIN_ENTRIES:
                 out.append((dev.host_future(G), dev.host_future(C), G, C))
             else:
                 out.append((dev.to_host(G), dev.to_host(C), G, C))
-        self._last_dev, self._last_dev_key = (out[1][2], out[1][3]), ('ptt', idx1, False)
+        self._last_dev, self._last_dev_key = (out[1][2], out[1][3]), (fam, idx1, False)
+        return out
+
+    def _pair(self, fam, idx0, idx1, defer):
+        gcs = self._pair_graph(fam, idx0, idx1)  # one replayed HIP graph where the libraries allow it (None: not here)
+        if gcs is None:
+            gcs = getattr(self, '_pair_dev_' + fam)(idx0, idx1)
+        return self._pair_out(fam, idx1, gcs, defer)
+
+    def _get_sim_MVgclm_pair(self, idx0, idx1, defer=False):
+        return self._pair('p', idx0, idx1, defer)
+
+    def _get_sim_Pgclm_pair(self, idx0, idx1, defer=False):
+        return self._pair('p_p', idx0, idx1, defer)
+
+    def _get_sim_Tgclm_pair(self, idx0, idx1, defer=False):
+        return self._pair('ptt', idx0, idx1, defer)
+
+    # ---- a pair of reconstructions as ONE replayed HIP graph ---------------------------------------------------------------------------
+    # From the input maps to the device (G, C) of both simulations a pair is ~400 kernel launches (two filters, five leg syntheses with
+    # their ring-FFT classes on side streams, the products, two analyses) with no host-side data dependence: launched from one Python
+    # thread they make the rate depend on how quiet the host is (8 ranks share one host), and at small sizes (nside 512: 1.7 ms per
+    # reconstruction for 0.1 ms of arithmetic) the launches ARE the cost.  After `graph_after` eager evaluations the sequence is captured
+    # once (torch.cuda.CUDAGraph: libplshts launches on torch's current stream, its side-stream forks / joins are captured with it)
+    # and replayed; per pair the host then copies / adopts the input maps, replays, and starts the device -> host copies.  The captured
+    # code is the eager code (`_pair_body`), so the results are the eager ones bit for bit (tests/test_gpu_qe.py, test_gpu_fullsize.py).
+    # The reference has no counterpart: its loop (qest.py:238-244, examples/run_qlms.py:66-74) is CPU code.
+    use_graph = True   # per instance; PLENS_QE_GRAPH=0 switches the route off for the process
+    graph_after = 2    # eager pair evaluations before the capture (workspaces grown, filters uploaded, code objects loaded)
+
+    _PAIR_FIELDS = {'p': 'tqu', 'p_p': 'qu', 'ptt': 't'}
+
+    def _pair_graph_ok(self, fam, idx0, idx1):
+        ivfs = self.f2map1.ivfs
+        if not self.use_graph or os.environ.get('PLENS_QE_GRAPH', '1') == '0' or self.pipeline_lanes or shts.lane_active():
+            return False
+        if torch.cuda.is_current_stream_capturing() or not self._same_legs() or self.cache:
+            return False
+        # the filter must be a pure device function of the maps: isotropic filter classes without a file cache or a starting-point library
+        if not (hasattr(ivfs, '_apply_ivf_t') and hasattr(ivfs, '_apply_ivf_p') and hasattr(ivfs, '_dev_entry') and hasattr(ivfs, 'nside')):
+            return False
+        if getattr(ivfs, 'cache', True) or getattr(ivfs, 'soltn_lib', None) is not None or not hasattr(ivfs, 'sim_lib'):
+            return False
+        if type(self.f2map1) not in (lib_filt2map, lib_filt2map_sepTP):
+            return False
+        for idx in (idx0, idx1):  # filtered alms already resident (another key ran first): the eager route reuses them
+            if idx in ivfs._dev_cache and not ivfs._dev_cache[idx].get('_graph_static', False):
+                return False
+        # per-stage HIP-event timing (pl_profile_enable) records events on the launch stream: not inside a captured region
+        return not any(getattr(pl, '_profiling', False) for pl in shts._PLANS.values())
+
+    def _pair_inputs(self, fam, idxs):
+        """the input maps of the pair in slot order: per simulation T (if used), then Q, U (if used)"""
+        sim_lib = self.f2map1.ivfs.sim_lib
+        maps = []
+        for idx in idxs:
+            if 't' in self._PAIR_FIELDS[fam]:
+                maps.append(sim_lib.get_sim_tmap(idx))
+            if 'q' in self._PAIR_FIELDS[fam]:
+                maps += list(sim_lib.get_sim_pmap(idx))
+        return maps
+
+    def _pair_body(self, fam, idx0, idx1, maps):
+        """filter of both simulations (entries of the filter library's device cache, as get_sim_alm_dev makes them), then the paired
+        estimator: device work only.  maps: device tensors in slot order (Q, U the two rows of one array)."""
+        ivfs = self.f2map1.ivfs
+        it = iter(maps)
+        ents = []
+        for idx in (idx0, idx1):
+            ent = ivfs._dev_entry(idx)
+            ent.clear()
+            if 't' in self._PAIR_FIELDS[fam]:
+                ent['t'] = dev.to_dev(ivfs._apply_ivf_t(next(it), soltn=None))
+            if 'q' in self._PAIR_FIELDS[fam]:
+                e, b = ivfs._apply_ivf_p([next(it), next(it)], soltn=None)
+                ent['e'], ent['b'] = dev.to_dev(e), dev.to_dev(b)
+            ents.append(ent)
+        return getattr(self, '_pair_dev_' + fam)(idx0, idx1), ents
+
+    def _pair_graph(self, fam, idx0, idx1):
+        if not self._pair_graph_ok(fam, idx0, idx1):
+            return None
+        import gc
+        ivfs = self.f2map1.ivfs
+        npix = hp.nside2npix(ivfs.nside)
+        nslots = 2 * len(self._PAIR_FIELDS[fam])
+        maps = self._pair_inputs(fam, (idx0, idx1))
+        if len(maps) != nslots or any((m.numel() if isinstance(m, torch.Tensor) else np.size(m)) != npix for m in maps):
+            return None
+        st = self.__dict__.setdefault('_pair_graphs', {}).setdefault((fam, shts.context(), torch.cuda.current_device()),
+                                                                    {'calls': 0, 'graph': None, 'held': None})
+
+        def evict():  # cache entries of the filter library that alias the graph's static alms: stale once the inputs change
+            for idx in [i for i, ent in ivfs._dev_cache.items() if ent.get('_graph_static', False)]:
+                ivfs._dev_cache.pop(idx)
+
+        def fill(slots):
+            """input maps into the static slots.  A device tensor that a `stable_maps` simulation library hands out again (same
+            storage, shape and version: maps resident in HBM) is already there from the last replay; host arrays are uploaded straight
+            into their slot."""
+            stable = getattr(ivfs.sim_lib, 'stable_maps', False)
+            for k, (slot, m) in enumerate(zip(slots, maps)):
+                if isinstance(m, torch.Tensor):
+                    tag = (m.data_ptr(), m._version, tuple(m.shape), m.dtype) if stable else None
+                    if tag is not None and st['tags'][k] == tag:
+                        continue
+                    slot.copy_(m.reshape(-1), non_blocking=True)
+                    st['tags'][k] = tag
+                else:
+                    slot.copy_(torch.from_numpy(np.ascontiguousarray(m, dtype=np.float64).reshape(-1)))
+                    st['tags'][k] = None
+
+        if st['graph'] is None or st['graph'] is False:
+            st['calls'] += 1
+            if st['graph'] is False or st['calls'] <= self.graph_after:
+                evict()
+                dmaps = self._pair_dev_maps(fam, maps)
+                return self._pair_body(fam, idx0, idx1, dmaps)[0]
+            try:
+                evict()
+                # static input slots: per simulation [T] and / or the two rows of one (2, npix) array for (Q, U)
+                st['in'], st['tags'] = [], [None] * nslots
+                for _ in range(2):
+                    if 't' in self._PAIR_FIELDS[fam]:
+                        st['in'].append(torch.empty(npix, dtype=torch.float64, device=dev.device()))
+                    if 'q' in self._PAIR_FIELDS[fam]:
+                        qu = torch.empty((2, npix), dtype=torch.float64, device=dev.device())
+                        st['in'] += [qu[0], qu[1]]
+                fill(st['in'])
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                gc_was_on = gc.isenabled()
+                gc.disable()  # (finalisers of unrelated garbage make HIP calls that are illegal while capturing: qcinv.multigrid)
+                try:
+                    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                        gcs, ents = self._pair_body(fam, -(10 ** 9) - 1, -(10 ** 9) - 2, st['in'])
+                finally:
+                    if gc_was_on:
+                        gc.enable()
+                for i in (-(10 ** 9) - 1, -(10 ** 9) - 2):
+                    ivfs._dev_cache.pop(i, None)
+                st['out'] = gcs
+                st['ents'] = [dict(ent, _graph_static=True) for ent in ents]
+                st['graph'] = g
+                st['first'] = True
+            except Exception as e:  # capture is an optimisation: stay eager for good
+                print('qest.library: graph capture of the %s pair failed (%s); staying eager' % (fam, str(e).split('\n')[0]))
+                if os.environ.get('PLENS_QE_GRAPH_DEBUG'):
+                    import traceback
+                    traceback.print_exc()
+                torch.cuda.synchronize()
+                for i in (-(10 ** 9) - 1, -(10 ** 9) - 2):
+                    ivfs._dev_cache.pop(i, None)
+                st['graph'] = False
+                return self._pair_body(fam, idx0, idx1, self._pair_dev_maps(fam, maps))[0]
+        evict()
+        # device -> host copies of the previous pair read the static outputs on the copy stream: they come first
+        torch.cuda.current_stream().wait_stream(dev._copy_stream())
+        if st.pop('first', False):
+            pass  # (the slots were filled for the capture)
+        else:
+            fill(st['in'])
+        st['graph'].replay()
+        for idx, ent in zip((idx0, idx1), st['ents']):
+            ivfs._dev_entry(idx).update(ent)  # the filtered alms of the pair stay available (until the next replay) to further keys
+        return st['out']
+
+    def _pair_dev_maps(self, fam, maps):
+        """input maps as device tensors for the eager body: (Q, U) as the two rows of one array (what the spin transform takes)"""
+        out, k = [], 0
+        for _ in range(2):
+            if 't' in self._PAIR_FIELDS[fam]:
+                out.append(dev.to_dev(maps[k], torch.float64).reshape(-1))
+                k += 1
+            if 'q' in self._PAIR_FIELDS[fam]:
+                q, u = maps[k], maps[k + 1]
+                k += 2
+                if isinstance(q, torch.Tensor) and isinstance(u, torch.Tensor):
+                    out += [dev.to_dev(q, torch.float64).reshape(-1), dev.to_dev(u, torch.float64).reshape(-1)]
+                else:
+                    buf = torch.empty((2, np.size(q)), dtype=torch.float64, device=dev.device())
+                    buf[0].copy_(torch.from_numpy(np.ascontiguousarray(q, dtype=np.float64).reshape(-1)))
+                    buf[1].copy_(torch.from_numpy(np.ascontiguousarray(u, dtype=np.float64).reshape(-1)))
+                    out += [buf[0], buf[1]]
         return out
 
     def _scalar_from_product(self, prod, fac, lmax_key):

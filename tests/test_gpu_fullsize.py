@@ -403,13 +403,20 @@ def _estimators_vs_oracle(tmp_path, nside, keys, seed=11, pair_check=()):
         ivfs2 = filt_simple.library_fullsky_sepTP(str(tmp_path / ('ivfs2' + key)), sims(), nside, transf, cls, fl, fel, fbl, cache=False)
         ql2 = qest.library_sepTP(str(tmp_path / ('ql2' + key)), ivfs2, ivfs2, cls['te'], nside, lmax_qlm=lmax, cache=False)
         assert ql2._pair_getter(key, lmax) is not None, 'the paired route is not taken for %s' % key
-        mf = ql2.get_sim_qlm_mf(key, np.array([0, 1]), collective=True)  # the call bench.py times
-        paired = [ql2.get_sim_qlm(k_, i) for i in (0, 1) for k_ in (key, kx)]
-        for a, b in zip(paired, single):
-            assert np.array_equal(a, b), "paired route differs from the single route for '%s'" % key
-        assert relrms(mf, 0.5 * (single[0] + single[2])) < 1e-15
-        _note("'%s' at nside %d: the paired route of get_sim_qlm_mf (what bench.py times) equals the single route bit for bit (2 simulations, "
-              "gradient and curl)" % (key, nside))
+        # the call bench.py times, `graph_after` times eagerly, then captured into a HIP graph and replayed (qest.library._pair_graph)
+        for rep in range(ql2.graph_after + 2):
+            ql2._mem.clear()
+            mf = ql2.get_sim_qlm_mf(key, np.array([0, 1]), collective=True)
+            paired = [ql2.get_sim_qlm(k_, i) for i in (0, 1) for k_ in (key, kx)]
+            for a, b in zip(paired, single):
+                assert np.array_equal(a, b), "paired route (call %d) differs from the single route for '%s'" % (rep, key)
+            assert relrms(mf, 0.5 * (single[0] + single[2])) < 1e-15
+        graphs = [v['graph'] for (f_, _, _), v in getattr(ql2, '_pair_graphs', {}).items() if f_ == key]
+        assert len(graphs) == 1 and isinstance(graphs[0], torch.cuda.CUDAGraph), 'the pair was not captured into a graph: %s' % graphs
+        del ql2, ivfs2, graphs
+        torch.cuda.empty_cache()
+        _note("'%s' at nside %d: the paired route of get_sim_qlm_mf (what bench.py times) -- eager, the capturing call and graph replays -- equals "
+              "the single route bit for bit (2 simulations, gradient and curl)" % (key, nside))
     return out
 
 

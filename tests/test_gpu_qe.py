@@ -236,3 +236,51 @@ def test_paired_simulations_equal_single_evaluations(setup, tmp_path):
         assert np.array_equal(a, b)
     assert relrms(res['pair'][0], g['dd_mf_p']) < TOL and relrms(res['pair'][2], g['dd_p_1']) < TOL
     assert relrms(res['pair'][5], g['dd_p_p_0']) < TOL and relrms(res['pair'][9], g['dd_ptt_0']) < TOL and relrms(res['pair'][11], g['dd_xtt_0']) < TOL
+
+
+def test_pair_graph_replay_equals_eager(setup, tmp_path):
+    """qest.library._pair_graph: a pair of reconstructions (filter -> legs -> product -> analysis) captured into one HIP graph after
+    `graph_after` eager evaluations and replayed from then on.  Eager evaluations, the capturing call and pure replays must give the
+    same gradient / curl / mean field bit for bit, for all three paired families, with inputs that change between replays; the
+    filtered alms of a replayed pair stay available to further keys (filter-library device cache) until the next replay."""
+    import torch
+    from plancklens_amd import qest
+    from plancklens_amd.filt import filt_simple
+    g, cl = setup[0], setup[4]
+    nside, lmax_qlm = int(g['nside']), int(g['lmax_qlm'])
+
+    class sims(_gold_sims):  # more simulations out of the two golden ones (2, 3, ...: fields of either, rescaled)
+        def get_sim_tmap(self, idx):
+            return self.g['tmap_%d' % (idx % 2)] * (1. + 0.25 * (idx // 2))
+
+        def get_sim_pmap(self, idx):
+            return self.g['qmap_%d' % ((idx + idx // 2) % 2)], self.g['umap_%d' % (idx % 2)] * (1. - 0.125 * (idx // 2))
+
+    def make(tag, use_graph):
+        ivfs = filt_simple.library_fullsky_sepTP(str(tmp_path / ('ivfs_' + tag)), sims(g), nside, g['transf'], cl, g['ftl'], g['fel'], g['fbl'], cache=False)
+        q = qest.library_sepTP(str(tmp_path / ('q_' + tag)), ivfs, ivfs, cl['te'], nside, lmax_qlm=lmax_qlm, cache=False)
+        q.use_graph, q.graph_after = use_graph, 1
+        return ivfs, q
+    ivfs_e, qe = make('eager', False)
+    ivfs_g, qg = make('graph', True)
+    for fam, kx in (('p', 'x'), ('p_p', 'x_p'), ('ptt', 'xtt')):
+        ref = {}
+        pairs = ((0, 1), (2, 3), (4, 5), (6, 7), (6, 7))
+        for pair in pairs[:-1]:
+            qe._mem.clear()
+            mf = qe.get_sim_qlm_mf(fam, np.array(pair))
+            ref[pair] = [mf] + [qe.get_sim_qlm(k_, i) for i in pair for k_ in (fam, kx)]
+        # 1 eager evaluation, the capture (+ first replay), then replays with new inputs and once more with the same
+        for rep, pair in enumerate(pairs):
+            qg._mem.clear()
+            mf = qg.get_sim_qlm_mf(fam, np.array(pair))
+            out = [mf] + [qg.get_sim_qlm(k_, i) for i in pair for k_ in (fam, kx)]
+            for a, b in zip(out, ref[pair]):
+                assert np.array_equal(a, b), (fam, rep, pair)
+        st = [v for (f_, _, _), v in qg._pair_graphs.items() if f_ == fam]
+        assert len(st) == 1 and isinstance(st[0]['graph'], torch.cuda.CUDAGraph) and st[0]['calls'] == 2, (fam, st)
+    # after the last replay of ('ptt', (6, 7)) the filtered T alms of 6 and 7 are cache entries of the filter library (static buffers of the
+    # graph): a further key for those simulations reuses them, and its result is the eager library's
+    assert ivfs_g._dev_cache[7].get('_graph_static') and 't' in ivfs_g._dev_cache[7]
+    assert np.array_equal(qg.get_sim_qlm('stt', 7), qe.get_sim_qlm('stt', 7))
+    assert relrms(qg.get_sim_qlm('p', 0), g['dd_p_0']) < TOL
