@@ -331,6 +331,16 @@ int pl_qe_lens_product(int64_t n, const double *tmap, const double *gt, const do
                        const double *g3, const double *c3, const double *g1, const double *c1, double *out_re, double *out_im,
                        void *stream);
 
+/* Simulation inputs generated on the device (replaces numpy's standard_normal in plancklens/sims/phas.py:125-195 and
+ * the noise adds of sims/maps.py:46-77,136-173).  Standard normal deviates are a pure function of (key, position): Philox4x32-10 on the
+ * counter (position / 2, tag), 2 x 53-bit uniforms, Box-Muller; position 2 p takes the cosine deviate, 2 p + 1 the sine one.
+ *   pl_map_add_normal : map_out[i] = (map_in ? map_in[i] : 0) + sigma n_i, i < n (tag 0); map_out may be map_in; device pointers,
+ *                       16-byte aligned.  One pass over the map, no array of deviates.
+ *   pl_alm_unit_phases: unit-variance alm (healpy layout, mmax = lmax) under `key` (tag 1): entries of m > 0 are (n_2i, n_2i+1) / sqrt 2,
+ *                       the m = 0 column is real with unit variance (the convention of phas.py:162-168). */
+int pl_map_add_normal(int64_t n, const double *map_in, double *map_out, double sigma, uint64_t key, void *stream);
+int pl_alm_unit_phases(int lmax, double *alm_out, uint64_t key, void *stream);
+
 /* FP64 FMA-rate microbenchmarks (16 independent chains per lane, no memory traffic): achieved TFLOP/s.
  * pl_fma64_rate_tflops: mode 0 = one vector + one scalar source besides the accumulator, 1 = two scalar (wave-uniform)
  * sources -- the operand mix of the synthesis kernels --, 2 = three vector sources -- the analysis kernels.

@@ -16,7 +16,7 @@ SYMBOLS = ['pl_version', 'pl_last_error', 'pl_device_count', 'pl_plan_create', '
            'pl_alm_dot', 'pl_axpy_dev', 'pl_alm_splice', 'pl_alm_splice_fl', 'pl_cg_dot_axpy', 'pl_almxfl_add', 'pl_template_project', 'pl_cg_fwd_tt', 'pl_cg_fwd_pp', 'pl_gemv', 'pl_gemv_split', 'pl_gemv_split_dot', 'pl_gemv_split_dot_count', 'pl_alm_splice_dot_b', 'pl_alm_splice_dot_count', 'pl_copy_slim',
            'pl_almxfl_b', 'pl_alm_copy_b', 'pl_alm_splice_b', 'pl_almxfl_add_b', 'pl_alm_dot_b', 'pl_axpy_dev_b', 'pl_cg_dot_axpy_b', 'pl_post_dots_count', 'pl_plan_arm_post_dots', 'pl_cg_axpy_pre_b', 'pl_template_project_b', 'pl_lowrank_update_b',
            'pl_cg_fwd_tt_b', 'pl_cg_fwd_pp_b', 'pl_cg_fwd_pp_qu_b', 'pl_template_project_md_b', 'pl_template_md_scratch_doubles',
-           'pl_plan_fft_all_generic', 'pl_cg_fwd_tt_md_b', 'pl_cg_fwd_tt_lr_b', 'pl_gemv_b', 'pl_map_mul', 'pl_map_qu_weight', 'pl_map_cmul', 'pl_qe_lens_product', 'pl_fma64_peak_tflops', 'pl_fma64_rate_tflops', 'pl_profile_enable', 'pl_profile_read']
+           'pl_plan_fft_all_generic', 'pl_cg_fwd_tt_md_b', 'pl_cg_fwd_tt_lr_b', 'pl_gemv_b', 'pl_map_mul', 'pl_map_qu_weight', 'pl_map_cmul', 'pl_qe_lens_product', 'pl_map_add_normal', 'pl_alm_unit_phases', 'pl_fma64_peak_tflops', 'pl_fma64_rate_tflops', 'pl_profile_enable', 'pl_profile_read']
 
 PL_HOST, PL_DEVICE = 0, 1
 
@@ -119,6 +119,8 @@ def lib():
     L.pl_map_qu_weight.argtypes = [i64, vp, vp, vp, vp, vp, vp]
     L.pl_map_cmul.argtypes = [i64, vp, vp, dbl, vp, vp, dbl, dbl, vp, vp, i32, vp]
     L.pl_qe_lens_product.argtypes = [i64] + [vp] * 12
+    L.pl_map_add_normal.argtypes = [i64, vp, vp, dbl, ctypes.c_uint64, vp]
+    L.pl_alm_unit_phases.argtypes = [i32, vp, ctypes.c_uint64, vp]
     L.pl_fma64_rate_tflops.argtypes = [i32, i32, vp]
     L.pl_fma64_rate_tflops.restype = dbl
     L.pl_profile_enable.argtypes = [vp, i32]

@@ -69,6 +69,8 @@ void launch_qe_lens_product(int64_t n, const double *tmap, const double *gt, con
 void launch_map_cmul(int64_t n, const double *ar, const double *ai, double s1, const double *br, const double *bi, double s2,
                      double sign, double *outr, double *outi, int accumulate, hipStream_t st);
 void launch_fma_peak(int mode, int iters, double *out, int nblk, hipStream_t st);
+void launch_map_add_normal(int64_t n, const double *in, double *out, double sigma, uint64_t key, hipStream_t st);
+void launch_alm_unit_phases(int lmax, double *out, uint64_t key, hipStream_t st);
 void launch_template_project_md(const DevPlan &P, int nb, double *t, const double *n_inv, int weighted, const double *pinv, double *scratch,
                                 hipStream_t st);
 void launch_phase_pack(const DevPlan &P, int ncomp, double *phase, double *buf, int pair0, int pstride, int mg0, int mgstride, bool unpack, hipStream_t st);
@@ -1367,6 +1369,24 @@ int pl_qe_lens_product(int64_t n, const double *tmap, const double *gt, const do
     if (!tmap && !rep) return fail("neither the temperature nor the polarization part given");
     if ((tmap && (!gt || !ct)) || (rep && (!imp || !g3 || !c3 || !g1 || !c1))) return fail("incomplete set of leg maps");
     launch_qe_lens_product(n, tmap, gt, ct, rep, imp, g3, c3, g1, c1, out_re, out_im, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_map_add_normal(int64_t n, const double *map_in, double *map_out, double sigma, uint64_t key, void *stream)
+{
+    if (n < 0 || !map_out) return fail("pl_map_add_normal: bad arguments");
+    if (((reinterpret_cast<uintptr_t>(map_in) | reinterpret_cast<uintptr_t>(map_out)) & 15) != 0) return fail("pl_map_add_normal: pointers must be 16-byte aligned");
+    if (n == 0) return 0;
+    launch_map_add_normal(n, map_in, map_out, sigma, key, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_alm_unit_phases(int lmax, double *alm_out, uint64_t key, void *stream)
+{
+    if (lmax < 0 || !alm_out) return fail("pl_alm_unit_phases: bad arguments");
+    launch_alm_unit_phases(lmax, alm_out, key, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return 0;
 }

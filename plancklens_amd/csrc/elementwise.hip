@@ -967,6 +967,62 @@ __global__ void k_alm_keep_mgroups(int lmax, double2 *__restrict__ alm_, int mg0
     for (int l = m + blockIdx.x * blockDim.x + threadIdx.x; l <= lmax; l += gridDim.x * blockDim.x) alm[base + l] = make_double2(0., 0.);
 }
 
+// ---- simulation inputs on the device (plancklens/sims/phas.py:125-195, sims/maps.py:46-77,136-173) -------------------
+// Standard normal deviates as a pure function of (key, position): Philox4x32-10 (Salmon et al. 2011, the public counter-based
+// generator; known-answer vectors in tests/test_sims.py) on the counter (pair index, tag), its 128 bits -> two 53-bit uniforms ->
+// Box-Muller -> the deviates of positions 2 p and 2 p + 1.  No state, no tensor of deviates: a map receives sigma n(0, 1) in the one
+// pass that reads and writes it, and any (seed, field, simulation, position) can be regenerated anywhere (on any rank) at will.
+__device__ __forceinline__ void philox4x32_10(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t k0, uint32_t k1)
+{
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0, hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += W0; k1 += W1;
+    }
+}
+
+__device__ __forceinline__ double2 normal_pair(uint64_t key, uint64_t p, uint32_t tag)
+{
+    uint32_t c0 = (uint32_t)p, c1 = (uint32_t)(p >> 32), c2 = tag, c3 = 0u;
+    philox4x32_10(c0, c1, c2, c3, (uint32_t)key, (uint32_t)(key >> 32));
+    const uint64_t a = ((uint64_t)c0 | ((uint64_t)c1 << 32)) >> 11, b = ((uint64_t)c2 | ((uint64_t)c3 << 32)) >> 11;
+    const double u1 = (double)(a + 1) * 0x1.0p-53;  // (0, 1]
+    const double u2 = (double)b * 0x1.0p-53;        // [0, 1)
+    const double rad = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincospi(2.0 * u2, &s, &c);
+    return make_double2(rad * c, rad * s);
+}
+
+// out[i] = (in ? in[i] : 0) + sigma n_i, n_i the deviate of position i under `key` (tag 0); two positions per thread, 16-byte accesses
+__global__ __launch_bounds__(256) void k_map_add_normal(int64_t n, const double *in, double *out, double sigma, uint64_t key)
+{
+    const int64_t np = (n + 1) >> 1, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += stride) {
+        const double2 g = normal_pair(key, (uint64_t)p, 0u);
+        if (2 * p + 1 < n) {
+            double2 v = in ? *reinterpret_cast<const double2 *>(in + 2 * p) : make_double2(0., 0.);
+            v.x = fma(sigma, g.x, v.x); v.y = fma(sigma, g.y, v.y);
+            *reinterpret_cast<double2 *>(out + 2 * p) = v;
+        } else {
+            out[2 * p] = fma(sigma, g.x, in ? in[2 * p] : 0.0);
+        }
+    }
+}
+
+// unit-variance harmonic coefficients (healpy layout, mmax = lmax): entry i > lmax gets (n_2i, n_2i+1) / sqrt 2, the real m = 0 column
+// (i <= lmax) gets (n_2i, 0) -- the convention of phas.lib_phas.get_sim (phas.py:162-168); tag 1
+__global__ __launch_bounds__(256) void k_alm_unit_phases(int lmax, int64_t nalm, double2 *out, uint64_t key)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nalm; i += stride) {
+        const double2 g = normal_pair(key, (uint64_t)i, 1u);
+        out[i] = i <= lmax ? make_double2(g.x, 0.0) : make_double2(g.x * 0.70710678118654752440, g.y * 0.70710678118654752440);
+    }
+}
+
 static inline int nblocks(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
 void launch_phase_pack(const DevPlan &P, int ncomp, double *phase, double *buf, int pair0, int pstride, int mg0, int mgstride, bool unpack, hipStream_t st)
@@ -1211,6 +1267,16 @@ void launch_fma_peak(int mode, int iters, double *out, int nblk, hipStream_t st)
     if (mode == 1) hipLaunchKernelGGL(k_fma_peak<1>, dim3(nblk), dim3(256), 0, st, iters, xs, ys, out);
     else if (mode == 2) hipLaunchKernelGGL(k_fma_peak<2>, dim3(nblk), dim3(256), 0, st, iters, xs, ys, out);
     else hipLaunchKernelGGL(k_fma_peak<0>, dim3(nblk), dim3(256), 0, st, iters, xs, ys, out);
+}
+
+void launch_map_add_normal(int64_t n, const double *in, double *out, double sigma, uint64_t key, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_map_add_normal, dim3(nblocks((n + 1) / 2)), dim3(256), 0, st, n, in, out, sigma, key);
+}
+void launch_alm_unit_phases(int lmax, double *out, uint64_t key, hipStream_t st)
+{
+    const int64_t nalm = (int64_t)(lmax + 1) * (lmax + 2) / 2;
+    hipLaunchKernelGGL(k_alm_unit_phases, dim3(nblocks(nalm)), dim3(256), 0, st, lmax, nalm, reinterpret_cast<double2 *>(out), key);
 }
 
 }  // namespace plshts

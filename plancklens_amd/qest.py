@@ -544,11 +544,18 @@ class library(object):
         ivfs = self.f2map1.ivfs
         npix = hp.nside2npix(ivfs.nside)
         nslots = 2 * len(self._PAIR_FIELDS[fam])
-        maps = self._pair_inputs(fam, (idx0, idx1))
-        if len(maps) != nslots or any((m.numel() if isinstance(m, torch.Tensor) else np.size(m)) != npix for m in maps):
-            return None
         st = self.__dict__.setdefault('_pair_graphs', {}).setdefault((fam, shts.context(), torch.cuda.current_device()),
                                                                     {'calls': 0, 'graph': None, 'held': None})
+        sim_lib = ivfs.sim_lib
+        # a simulation library that writes its maps into buffers of the caller (sims.maps.cmb_maps with device maps) fills the static
+        # input slots itself: the pass that adds the noise is the one that writes the slot
+        into = (isinstance(st['graph'], torch.cuda.CUDAGraph) and getattr(sim_lib, 'device_maps', False)
+                and hasattr(sim_lib, 'get_sim_tmap_into') and hasattr(sim_lib, 'get_sim_pmap_into'))
+        maps = None
+        if not into:
+            maps = self._pair_inputs(fam, (idx0, idx1))
+            if len(maps) != nslots or any((m.numel() if isinstance(m, torch.Tensor) else np.size(m)) != npix for m in maps):
+                return None
 
         def evict():  # cache entries of the filter library that alias the graph's static alms: stale once the inputs change
             for idx in [i for i, ent in ivfs._dev_cache.items() if ent.get('_graph_static', False)]:
@@ -558,7 +565,16 @@ class library(object):
             """input maps into the static slots.  A device tensor that a `stable_maps` simulation library hands out again (same
             storage, shape and version: maps resident in HBM) is already there from the last replay; host arrays are uploaded straight
             into their slot."""
-            stable = getattr(ivfs.sim_lib, 'stable_maps', False)
+            if into:
+                it = iter(slots)
+                for idx in (idx0, idx1):
+                    if 't' in self._PAIR_FIELDS[fam]:
+                        sim_lib.get_sim_tmap_into(idx, next(it))
+                    if 'q' in self._PAIR_FIELDS[fam]:
+                        sim_lib.get_sim_pmap_into(idx, next(it), next(it))
+                st['tags'] = [None] * nslots
+                return
+            stable = getattr(sim_lib, 'stable_maps', False)
             for k, (slot, m) in enumerate(zip(slots, maps)):
                 if isinstance(m, torch.Tensor):
                     tag = (m.data_ptr(), m._version, tuple(m.shape), m.dtype) if stable else None

@@ -38,36 +38,49 @@ class cmb_maps(object):
     def _out(self, t):
         return t if self.device_maps else dev.to_host(t)
 
-    def _add_noise(self, m, noise):
-        """m + noise; a (scale, unit-variance device tensor) pair is added in place in one pass (device noise, see cmb_maps_nlev)"""
-        if isinstance(noise, tuple):
-            return m.add_(noise[1], alpha=float(noise[0]))
-        return m + dev.to_dev(noise)
+    def _add_noise(self, m, idx, idf, out=None):
+        """sky map m (device tensor, may be overwritten) + the noise of field idf -> device tensor; `out`: written there instead"""
+        res = m + dev.to_dev(self._noise_term(idx, idf))
+        return res if out is None else out.copy_(res)
 
-    def get_sim_tmap(self, idx):
+    def _tsky(self, idx):
         tlm = dev.to_dev(self.sims_cmb_len.get_sim_tlm(idx))
-        tmap = shts.alm2map(tlm, self.nside, fl=self.cl_transf_T)
-        return self._out(self._add_noise(tmap, self._noise_term(idx, 0)))
+        return shts.alm2map(tlm, self.nside, fl=self.cl_transf_T)
 
-    def get_sim_pmap(self, idx):
+    def _psky(self, idx):
         held = self.__dict__.get('_pair_held')
         if held is not None and held[0] == idx:  # made together with the previous simulation (hint_pair)
             self._pair_held = None
-            Q, U = held[1]
-        else:
-            elm = dev.to_dev(self.sims_cmb_len.get_sim_elm(idx))
-            blm = dev.to_dev(self.sims_cmb_len.get_sim_blm(idx))
-            lmax = hp.Alm.getlmax(elm.numel())
-            nxt = self.__dict__.get('_pair_next')
-            self._pair_next = None
-            if nxt is not None and nxt[0] == idx and self.device_maps:
-                # the sky of the announced next simulation on the same Legendre recursion (pl_alm2map_batch2: bit-identical maps)
-                e2, b2 = dev.to_dev(self.sims_cmb_len.get_sim_elm(nxt[1])), dev.to_dev(self.sims_cmb_len.get_sim_blm(nxt[1]))
-                (Q, U), (Q2, U2) = shts.alm2map_spin_batch2([elm, blm], [e2, b2], self.nside, 2, lmax, fl=self.cl_transf_P)
-                self._pair_held = (nxt[1], (Q2, U2))
-            else:
-                Q, U = shts.alm2map_spin([elm, blm], self.nside, 2, lmax, fl=self.cl_transf_P)
-        return self._out(self._add_noise(Q, self._noise_term(idx, 1))), self._out(self._add_noise(U, self._noise_term(idx, 2)))
+            return held[1]
+        elm = dev.to_dev(self.sims_cmb_len.get_sim_elm(idx))
+        blm = dev.to_dev(self.sims_cmb_len.get_sim_blm(idx))
+        lmax = hp.Alm.getlmax(elm.numel())
+        nxt = self.__dict__.get('_pair_next')
+        self._pair_next = None
+        if nxt is not None and nxt[0] == idx and self.device_maps:
+            # the sky of the announced next simulation on the same Legendre recursion (pl_alm2map_batch2: bit-identical maps)
+            e2, b2 = dev.to_dev(self.sims_cmb_len.get_sim_elm(nxt[1])), dev.to_dev(self.sims_cmb_len.get_sim_blm(nxt[1]))
+            (Q, U), (Q2, U2) = shts.alm2map_spin_batch2([elm, blm], [e2, b2], self.nside, 2, lmax, fl=self.cl_transf_P)
+            self._pair_held = (nxt[1], (Q2, U2))
+            return Q, U
+        return shts.alm2map_spin([elm, blm], self.nside, 2, lmax, fl=self.cl_transf_P)
+
+    def get_sim_tmap(self, idx):
+        return self._out(self._add_noise(self._tsky(idx), idx, 0))
+
+    def get_sim_pmap(self, idx):
+        Q, U = self._psky(idx)
+        return self._out(self._add_noise(Q, idx, 1)), self._out(self._add_noise(U, idx, 2))
+
+    # the same maps written into buffers of the caller (device float64 [npix]; an extension for consumers with fixed input slots --
+    # the replayed graph of qest.library._pair_graph): with device noise the pass that adds the noise is the one that fills the slot
+    def get_sim_tmap_into(self, idx, out):
+        self._add_noise(self._tsky(idx), idx, 0, out=out)
+
+    def get_sim_pmap_into(self, idx, outq, outu):
+        Q, U = self._psky(idx)
+        self._add_noise(Q, idx, 1, out=outq)
+        self._add_noise(U, idx, 2, out=outu)
 
     def hint_pair(self, idx0, idx1):
         """The caller is about to ask for the polarization maps of idx0 and then idx1 (a mean-field loop serving simulations in
@@ -128,14 +141,16 @@ class cmb_maps_nlev(cmb_maps):
     def _vamin(self):
         return np.sqrt(hp.nside2pixarea(self.nside, degrees=True)) * 60
 
-    def _noise_term(self, idx, idf):
-        """device phases: (scale, unit-variance tensor) for an in-place scaled add -- two passes over a map less than scaling the
-        noise and adding it out of place; host phases: the noise map"""
-        pha = self.pix_lib_phas.get_sim(idx, idf=idf)
-        scale = (self.nlev_t if idf == 0 else self.nlev_p) / self._vamin()
-        if isinstance(pha, np.ndarray):
-            return scale * pha
-        return (scale, pha)
+    def _scale(self, idf):
+        return (self.nlev_t if idf == 0 else self.nlev_p) / self._vamin()
+
+    def _add_noise(self, m, idx, idf, out=None):
+        """device phase library with `add_scaled` (phas.pix_lib_phas_dev): sigma n(0, 1) is added by the generator kernel in the one pass
+        that reads the sky map and writes the result (pl_map_add_normal) -- in place, or into `out`; host phases: the noise map is added"""
+        if hasattr(self.pix_lib_phas, 'add_scaled'):
+            return self.pix_lib_phas.add_scaled(m.contiguous(), idx, idf, self._scale(idf), out=out)
+        res = m + dev.to_dev(self._scale(idf) * self.pix_lib_phas.get_sim(idx, idf=idf))
+        return res if out is None else out.copy_(res)
 
     def get_sim_tnoise(self, idx):
         return self.nlev_t / self._vamin() * self.pix_lib_phas.get_sim(idx, idf=0)

@@ -261,52 +261,77 @@ class lib_phas_seeded(_seeded_lib):
         return {'nfields': self.nfields, 'lmax': self.lmax, 'seed': self.seed}
 
 
-def _dev_generator(seed, idf, idx):
-    import torch
-    g = torch.Generator(device='cuda')
-    # SplitMix-style mix of the three integers into one 63-bit seed (distinct streams for distinct (seed, idf, idx))
+def _dev_key(seed, idf, idx):
+    """64-bit Philox key of (library seed, field, simulation): a SplitMix-style mix, distinct streams for distinct triples"""
     z = (int(seed) * 0x9E3779B97F4A7C15 + int(idf) * 0xBF58476D1CE4E5B9 + int(idx) * 0x94D049BB133111EB + 0x2545F4914F6CDD1D) & (2 ** 64 - 1)
     z ^= z >> 31
-    g.manual_seed(z & (2 ** 63 - 1))
-    return g
+    z = (z * 0xD6E8FEB86659FD93) & (2 ** 64 - 1)
+    z ^= z >> 32
+    return z
 
 
 class pix_lib_phas_dev(pix_lib_phas_seeded):
-    """pix_lib_phas drawn on the device: get_sim returns float64 CUDA tensors."""
+    """pix_lib_phas drawn on the device by the library's own counter-based generator (pl_map_add_normal: Philox4x32-10 + Box-Muller, a pure
+    function of (seed, field, index, pixel)): get_sim returns float64 CUDA tensors; `add_scaled` adds scale x that realisation to a map in
+    the one pass that reads and writes it -- no tensor of deviates, no second pass (sims/maps.py:46-77,136-173 of the reference add a
+    host array)."""
+
+    def _key(self, idx, idf):
+        assert idf < self.nfields, (idf, self.nfields)
+        if self.nmax is not None:
+            assert idx < self.nmax
+        return _dev_key(self.seed, idf, idx)
+
+    def add_scaled(self, m, idx, idf, scale, out=None):
+        """out = m + scale x (realisation idx of field idf); out defaults to m (in place); m None: out = scale x realisation"""
+        import ctypes
+        import torch
+        from .. import _lib, dev
+        n = int(np.prod(self.shape))
+        out = m if out is None else out
+        assert out is not None and out.is_cuda and out.dtype == torch.float64 and out.is_contiguous() and out.numel() == n, 'float64 device map of the library shape'
+        assert m is None or (m.is_cuda and m.dtype == torch.float64 and m.is_contiguous() and m.numel() == n)
+        _lib.check(_lib.lib().pl_map_add_normal(n, None if m is None else m.data_ptr(), out.data_ptr(), float(scale), ctypes.c_uint64(self._key(idx, idf)),
+                                               dev.stream_ptr()))
+        return out
 
     def get_sim(self, idx, idf=None, phas_only=False):
         import torch
         if idf is not None:
-            assert idf < self.nfields, (idf, self.nfields)
-            if self.nmax is not None:
-                assert idx < self.nmax
+            key = self._key(idx, idf)
             if phas_only:
                 return None
-            return torch.randn(self.shape, generator=_dev_generator(self.seed, idf, idx), dtype=torch.float64, device='cuda')
+            del key
+            return self.add_scaled(None, idx, idf, 1.0, out=torch.empty(self.shape, dtype=torch.float64, device='cuda'))
         return torch.stack([self.get_sim(idx, idf=i) for i in range(self.nfields)])
 
     def hashdict(self):
-        return {'nfields': self.nfields, 'shape': self.shape, 'seed': self.seed, 'rng': 'torch-philox-cuda'}
+        return {'nfields': self.nfields, 'shape': self.shape, 'seed': self.seed, 'rng': 'plshts-philox4x32-10-boxmuller'}
 
 
 class lib_phas_dev(lib_phas_seeded):
-    """lib_phas drawn on the device: get_sim returns complex128 CUDA tensors (unit variance, real m = 0 column)."""
+    """lib_phas drawn on the device (pl_alm_unit_phases): get_sim returns complex128 CUDA tensors (unit variance, real m = 0 column).  The
+    fields of the most recent simulation are kept: a sky library asks for each of them once per correlated field."""
 
     def get_sim(self, idx, idf=None, phas_only=False):
+        import ctypes
         import torch
+        from .. import _lib, dev
         if idf is not None:
             assert idf < self.nfields, (idf, self.nfields)
             if self.nmax is not None:
                 assert idx < self.nmax
             if phas_only:
                 return None
-            n = hp.Alm.getsize(self.lmax)
-            ri = torch.randn((n, 2), generator=_dev_generator(self.seed, idf, idx), dtype=torch.float64, device='cuda')
-            ri *= np.sqrt(0.5)
-            ri[:self.lmax + 1, 0] *= np.sqrt(2.)
-            ri[:self.lmax + 1, 1] = 0.
-            return torch.view_as_complex(ri)
+            memo = self.__dict__.setdefault('_memo', {})
+            if (idx, idf) not in memo:
+                for k in [k for k in memo if k[0] != idx]:
+                    del memo[k]
+                out = torch.empty(hp.Alm.getsize(self.lmax), dtype=torch.complex128, device='cuda')
+                _lib.check(_lib.lib().pl_alm_unit_phases(int(self.lmax), out.data_ptr(), ctypes.c_uint64(_dev_key(self.seed, idf, idx)), dev.stream_ptr()))
+                memo[(idx, idf)] = out
+            return memo[(idx, idf)]  # (read-only by convention: the sky libraries combine the fields out of place)
         return torch.stack([self.get_sim(idx, idf=i) for i in range(self.nfields)])
 
     def hashdict(self):
-        return {'nfields': self.nfields, 'lmax': self.lmax, 'seed': self.seed, 'rng': 'torch-philox-cuda'}
+        return {'nfields': self.nfields, 'lmax': self.lmax, 'seed': self.seed, 'rng': 'plshts-philox4x32-10-boxmuller'}

@@ -158,3 +158,40 @@ def test_run_qlms_masked_sky_cg_filters(tmp_path):
     finally:
         for k in ('PLENS', 'PLENS_NSIDE', 'PLENS_LMAX', 'PLENS_NSIMS'):
             os.environ.pop(k, None)
+
+
+def test_device_generator_matches_its_restatement(tmp_path):
+    """pl_map_add_normal / pl_alm_unit_phases against oracle/philox_oracle.py (Philox4x32-10 pinned by the published known-answer vectors,
+    tests/test_sims.py): same deviates to rounding (the integer part is exact; log / sincospi differ in the last bits), in place, out of
+    place and with an odd length; the phase libraries built on them are pure functions of (seed, field, index)."""
+    import ctypes
+    import numpy as np
+    import torch
+    from oracle import philox_oracle as po
+    from plancklens_amd import _lib, dev, hp
+    from plancklens_amd.sims import phas
+    L = _lib.lib()
+    key = 0x9E3779B97F4A7C15
+    for n in (2, 1001, 12 * 64 ** 2):
+        base = torch.linspace(-1., 1., n, dtype=torch.float64, device='cuda')
+        out = torch.empty_like(base)
+        _lib.check(L.pl_map_add_normal(n, base.data_ptr(), out.data_ptr(), 2.5, ctypes.c_uint64(key), dev.stream_ptr()))
+        ref = base.cpu().numpy() + 2.5 * po.normals(key, n)
+        assert np.max(np.abs(out.cpu().numpy() - ref)) < 1e-13
+        inpl = base.clone()
+        _lib.check(L.pl_map_add_normal(n, inpl.data_ptr(), inpl.data_ptr(), 2.5, ctypes.c_uint64(key), dev.stream_ptr()))
+        assert torch.equal(inpl, out)
+        _lib.check(L.pl_map_add_normal(n, None, out.data_ptr(), 1.0, ctypes.c_uint64(key), dev.stream_ptr()))
+        assert np.max(np.abs(out.cpu().numpy() - po.normals(key, n))) < 1e-13
+    lmax = 37
+    alm = torch.empty(hp.Alm.getsize(lmax), dtype=torch.complex128, device='cuda')
+    _lib.check(L.pl_alm_unit_phases(lmax, alm.data_ptr(), ctypes.c_uint64(key), dev.stream_ptr()))
+    assert np.max(np.abs(alm.cpu().numpy() - po.unit_phases(key, lmax))) < 1e-13
+    lib = phas.pix_lib_phas_dev(str(tmp_path / 'pix'), 3, (12 * 16 ** 2,), seed=5)
+    k = phas._dev_key(5, 2, 7)
+    assert np.max(np.abs(lib.get_sim(7, idf=2).cpu().numpy() - po.normals(k, 12 * 16 ** 2))) < 1e-13
+    m = torch.ones(12 * 16 ** 2, dtype=torch.float64, device='cuda')
+    o = torch.empty_like(m)
+    lib.add_scaled(m, 7, 2, 0.5, out=o)
+    assert torch.equal(o, lib.add_scaled(m.clone(), 7, 2, 0.5)) and bool((m == 1.).all())
+    assert phas._dev_key(5, 2, 7) != phas._dev_key(5, 1, 7) != phas._dev_key(5, 1, 8)

@@ -382,10 +382,10 @@ def _estimators_vs_oracle(tmp_path, nside, keys, seed=11, pair_check=()):
             return {'fullsize': seed}
 
         def get_sim_tmap(self, idx):
-            return (maps if idx == 0 else maps1)[0]
+            return (maps if idx % 2 == 0 else maps1)[0]
 
         def get_sim_pmap(self, idx):
-            m = maps if idx == 0 else maps1
+            m = maps if idx % 2 == 0 else maps1
             return m[1], m[2]
     ivfs = filt_simple.library_fullsky_sepTP(str(tmp_path / 'ivfs'), sims(), nside, transf, cls, fl, fel, fbl, cache=False)
     ql = qest.library_sepTP(str(tmp_path / 'ql'), ivfs, ivfs, cls['te'], nside, lmax_qlm=lmax, cache=False)
@@ -404,10 +404,10 @@ def _estimators_vs_oracle(tmp_path, nside, keys, seed=11, pair_check=()):
         ql2 = qest.library_sepTP(str(tmp_path / ('ql2' + key)), ivfs2, ivfs2, cls['te'], nside, lmax_qlm=lmax, cache=False)
         assert ql2._pair_getter(key, lmax) is not None, 'the paired route is not taken for %s' % key
         # the call bench.py times, `graph_after` times eagerly, then captured into a HIP graph and replayed (qest.library._pair_graph)
-        for rep in range(ql2.graph_after + 2):
+        for rep in range(ql2.graph_after + 2):  # (simulations 2 r and 2 r + 1 are simulations 0 and 1 again, under indices not seen before)
             ql2._mem.clear()
-            mf = ql2.get_sim_qlm_mf(key, np.array([0, 1]), collective=True)
-            paired = [ql2.get_sim_qlm(k_, i) for i in (0, 1) for k_ in (key, kx)]
+            mf = ql2.get_sim_qlm_mf(key, np.array([2 * rep, 2 * rep + 1]), collective=True)
+            paired = [ql2.get_sim_qlm(k_, i) for i in (2 * rep, 2 * rep + 1) for k_ in (key, kx)]
             for a, b in zip(paired, single):
                 assert np.array_equal(a, b), "paired route (call %d) differs from the single route for '%s'" % (rep, key)
             assert relrms(mf, 0.5 * (single[0] + single[2])) < 1e-15

@@ -178,3 +178,23 @@ def test_sim_lib_add_sim_and_add_dat():
             for idx in (-1, 0, 2):
                 assert np.allclose(ours.get_sim_tmap(idx), theirs.get_sim_tmap(idx), rtol=1e-15, atol=1e-15)
                 assert all(np.allclose(x, y, rtol=1e-15, atol=1e-15) for x, y in zip(ours.get_sim_pmap(idx), theirs.get_sim_pmap(idx)))
+
+
+def test_philox_restatement_against_the_published_known_answers():
+    """oracle/philox_oracle.py (the definition of the device-side generator pl_map_add_normal / pl_alm_unit_phases) reproduces the
+    known-answer vectors of Philox4x32-10 published with the Random123 library (Salmon et al. 2011: kat_vectors), and its deviates
+    have the right moments; distinct keys / tags / positions give distinct streams."""
+    from oracle import philox_oracle as po
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, out in kat:
+        assert tuple(int(x) for x in po.philox4x32_10(ctr, key)) == out
+    n = po.normals(0x1234567890ABCDEF, 200001)
+    assert n.size == 200001 and abs(n.mean()) < 0.01 and abs(n.std() - 1.) < 0.01 and abs(np.mean(n ** 4) - 3.) < 0.1
+    assert abs(np.mean(n[0::2] * n[1::2][:100000])) < 0.01  # the two deviates of a pair are uncorrelated
+    assert not np.array_equal(n[:100], po.normals(0x1234567890ABCDEE, 100))
+    a = po.unit_phases(99, 40)
+    assert a.size == 41 * 42 // 2 and np.all(a[:41].imag == 0) and abs(np.mean(np.abs(a[41:]) ** 2) - 1.) < 0.1
+    c, s = po.normal_pairs(99, 41, 1)
+    assert np.array_equal(a[:41].real, c) and not np.array_equal(po.normal_pairs(99, 41, 0)[0], c)
