@@ -522,7 +522,13 @@ def run_rank(args):
             # generation alone (maps of K further simulations made and dropped)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for idx in range(K):
+            for idx in range(0, K - K % 2, 2):  # in pairs, as the estimator's loop asks for them (the two polarization skies on one recursion)
+                i0, i1 = 2 * 10 ** 6 + idx, 2 * 10 ** 6 + idx + 1
+                gsims.hint_pair(i0, i1)
+                for i_ in (i0, i1):
+                    gsims.get_sim_tmap(i_)
+                    gsims.get_sim_pmap(i_)
+            for idx in range(K - K % 2, K):
                 gsims.get_sim_tmap(2 * 10 ** 6 + idx)
                 gsims.get_sim_pmap(2 * 10 ** 6 + idx)
             torch.cuda.synchronize()

@@ -178,6 +178,10 @@ int pl_cg_dot_axpy(int nf, const int *lmax, int lmin, const double *const *a, co
                    double *parts1_dev, double *parts2_dev, const double *den_parts_dev, double *const *y1, const double *const *x1,
                    double sign1, double *const *y2, const double *const *x2, double sign2, unsigned *barrier_dev, void *stream);
 
+/* out[k] = fl[2k] alm[2k] (+ fl[2k+1] alm[2k+1]), k < nout <= 2 outputs of nterm[k] = 1 or 2 terms each, all of band-limit lmax with filters of
+ * lmax + 1 entries: the Wiener-filtered legs X^WF = C^XX Xb (+ C^TE Yb) of the quadratic estimators (plancklens/qest.py:566-638, where they
+ * are three hp.almxfl calls and an addition) for both components of a spin transform in one launch; rounded as pl_almxfl then pl_almxfl_add. */
+int pl_alm_lincomb(int lmax, int nout, const int *nterm, const double *const *alm, const double *const *fl, double *const *out, void *stream);
 /* Inverse-noise weighting with template marginalisation (alm_filter_ninv.apply_map, opfilt_tt.py:196-205) in two
  * launches: tmap <- n_inv tmap - sum_k rmat[k] c_k, c_k = sum_i pmat[k][i] n_inv[i] tmap[i], with pmat (nmodes x npix,
  * the template modes) and rmat = (P^t N^-1 P)^-1 (pmat . n_inv) (nmodes x npix), all device arrays; scratch_dev:

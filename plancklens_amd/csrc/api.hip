@@ -71,6 +71,7 @@ void launch_map_cmul(int64_t n, const double *ar, const double *ai, double s1, c
 void launch_fma_peak(int mode, int iters, double *out, int nblk, hipStream_t st);
 void launch_map_add_normal(int64_t n, const double *in, double *out, double sigma, uint64_t key, hipStream_t st);
 void launch_alm_unit_phases(int lmax, double *out, uint64_t key, hipStream_t st);
+void launch_alm_lincomb(int lmax, int nout, const int *nterm, const double *const *alm, const double *const *fl, double *const *out, hipStream_t st);
 void launch_template_project_md(const DevPlan &P, int nb, double *t, const double *n_inv, int weighted, const double *pinv, double *scratch,
                                 hipStream_t st);
 void launch_phase_pack(const DevPlan &P, int ncomp, double *phase, double *buf, int pair0, int pstride, int mg0, int mgstride, bool unpack, hipStream_t st);
@@ -1264,6 +1265,21 @@ int pl_almxfl_add(int lmax, const double *a, const double *b, const double *fl, 
 {
     if (lmax < 0 || !a || !b || !fl || !out) return fail("pl_almxfl_add: bad arguments");
     launch_almxfl_add(lmax, a, b, fl, nfl, out, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int pl_alm_lincomb(int lmax, int nout, const int *nterm, const double *const *alm, const double *const *fl, double *const *out, void *stream)
+{
+    if (lmax < 0 || nout < 1 || nout > 2 || !nterm || !alm || !fl || !out) return fail("pl_alm_lincomb: bad arguments");
+    for (int k = 0; k < nout; ++k) {
+        if (nterm[k] < 1 || nterm[k] > 2 || !out[k]) return fail("pl_alm_lincomb: one or two terms per output");
+        for (int t = 0; t < nterm[k]; ++t) {
+            if (!alm[2 * k + t] || !fl[2 * k + t]) return fail("pl_alm_lincomb: null term");
+            if (alm[2 * k + t] == out[k] && t > 0) return fail("pl_alm_lincomb: an output may alias its first term only");
+        }
+    }
+    launch_alm_lincomb(lmax, nout, nterm, alm, fl, out, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -1023,6 +1023,30 @@ __global__ __launch_bounds__(256) void k_alm_unit_phases(int lmax, int64_t nalm,
     }
 }
 
+// out[k] = f[k][0] a[k][0] (+ f[k][1] a[k][1]), k < nout <= 2: the Wiener-filtered legs of the estimators (X^WF = C^XX Xb + C^TE Yb,
+// qest.py:566-638) for both components of a spin transform in ONE launch.  Rounded exactly as k_almxfl followed by k_almxfl_add.
+struct LinComb { const double2 *a[2][2]; const double *f[2][2]; double2 *out[2]; int nterm[2]; };
+__global__ void k_alm_lincomb(int lmax, LinComb C)
+{
+    const int m = blockIdx.y, k = blockIdx.z;
+    const int64_t base = (int64_t)m * (2 * lmax + 1 - m) / 2;
+    const double2 *__restrict__ a0 = C.a[k][0], *__restrict__ a1 = C.a[k][1];
+    const double *__restrict__ f0 = C.f[k][0], *__restrict__ f1 = C.f[k][1];
+    double2 *__restrict__ out = C.out[k];
+    const bool two = C.nterm[k] == 2;
+    for (int l = m + blockIdx.x * blockDim.x + threadIdx.x; l <= lmax; l += gridDim.x * blockDim.x) {
+        const double2 x = a0[base + l];
+        const double g = f0[l];
+        double2 v = make_double2(x.x * g, x.y * g);
+        if (two) {
+            const double2 y = a1[base + l];
+            const double h = f1[l];
+            v = make_double2(fma(h, y.x, v.x), fma(h, y.y, v.y));
+        }
+        out[base + l] = v;
+    }
+}
+
 static inline int nblocks(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
 void launch_phase_pack(const DevPlan &P, int ncomp, double *phase, double *buf, int pair0, int pstride, int mg0, int mgstride, bool unpack, hipStream_t st)
@@ -1277,6 +1301,17 @@ void launch_alm_unit_phases(int lmax, double *out, uint64_t key, hipStream_t st)
 {
     const int64_t nalm = (int64_t)(lmax + 1) * (lmax + 2) / 2;
     hipLaunchKernelGGL(k_alm_unit_phases, dim3(nblocks(nalm)), dim3(256), 0, st, lmax, nalm, reinterpret_cast<double2 *>(out), key);
+}
+
+void launch_alm_lincomb(int lmax, int nout, const int *nterm, const double *const *alm, const double *const *fl, double *const *out, hipStream_t st)
+{
+    LinComb C{};
+    for (int k = 0; k < nout; ++k) {
+        C.nterm[k] = nterm[k];
+        C.out[k] = reinterpret_cast<double2 *>(out[k]);
+        for (int t = 0; t < nterm[k]; ++t) { C.a[k][t] = reinterpret_cast<const double2 *>(alm[2 * k + t]); C.f[k][t] = fl[2 * k + t]; }
+    }
+    hipLaunchKernelGGL(k_alm_lincomb, dim3(4, lmax + 1, nout), dim3(256), 0, st, lmax, C);
 }
 
 }  // namespace plshts

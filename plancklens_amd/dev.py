@@ -43,27 +43,38 @@ def _copy_stream():
 
 
 class host_future(object):
-    """A device -> host copy in flight: issued on a copy stream into a pinned staging buffer from a small recycled pool
-    (hipHostMalloc of a 33 MB alm costs milliseconds and synchronises: never on the per-result path), so the caller's
-    stream goes on with the next reconstruction while the result crosses PCIe.  A helper thread waits for the copy, moves
-    the data into an ordinary numpy array (which then owns it) and hands the staging buffer back; result() returns that
-    array, waiting for the helper if it has not finished."""
+    """A device -> host copy in flight into a pinned staging buffer from a small recycled pool (hipHostMalloc of a 33 MB alm costs
+    milliseconds and synchronises: never on the per-result path), so the caller's stream goes on with the next reconstruction while
+    the result crosses PCIe.  result() returns an ordinary numpy array that owns the data.  Two forms:
+      threaded (large results): the copy runs on a copy stream; a helper thread waits for it, moves the data out of the staging
+        buffer and hands the buffer back -- the 33 MB host copies stay off the launching thread;
+      lazy (threaded=False; small results, where a thread hand-off costs more than the copy): the copy is issued on the caller's
+        stream and nobody waits for it until result() is called or its staging buffer is needed again (oldest first)."""
     MAX_IN_FLIGHT = 8  # (two results per reconstruction: four reconstructions of slack for the launching thread when the helpers are slow -- a busy host)
     _in_flight = []
     _pool = None
 
-    def __init__(self, t):
+    def __init__(self, t, threaded=True):
         from . import shts
         shts.join_lanes()  # results of transforms still running on side lanes
         t = t.detach().contiguous()
-        host_future._in_flight[:] = [f for f in host_future._in_flight if not f._job.done()]
+        host_future._in_flight[:] = [f for f in host_future._in_flight if not f.done()]
         while len(host_future._in_flight) >= host_future.MAX_IN_FLIGHT:  # staging buffers all busy: wait for the oldest copy
-            host_future._in_flight.pop(0)._job.result()
+            host_future._in_flight.pop(0).result()
         key = (tuple(t.shape), t.dtype)
         if key not in _PINNED_FREE:  # the whole staging pool of this shape at once, on first use (i.e. during warm-up)
             _PINNED_FREE[key] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for _ in range(host_future.MAX_IN_FLIGHT)]
         free = _PINNED_FREE[key]
         h = free.pop() if free else torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        self._arr = None
+        self._job = None
+        if not threaded:
+            h.copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._lazy = (ev, h, free, t)  # (t: the source stays alive until the copy has been waited for)
+            host_future._in_flight.append(self)
+            return
         cs = _copy_stream()
         cs.wait_stream(torch.cuda.current_stream())
         nblk = int(os.environ.get('PLENS_D2H_BLOCKS', '64'))
@@ -87,12 +98,21 @@ class host_future(object):
             free.append(h)
             return arr
         self._job = host_future._pool.submit(finish)
-        self._arr = None
         host_future._in_flight.append(self)
+
+    def done(self):
+        return self._arr is not None or (self._job is not None and self._job.done())
 
     def result(self):
         if self._arr is None:
-            self._arr = self._job.result()
+            if self._job is not None:
+                self._arr = self._job.result()
+            else:
+                ev, h, free, _ = self._lazy
+                ev.synchronize()
+                self._arr = h.numpy().copy()
+                free.append(h)
+                self._lazy = None
         return self._arr
 
 
@@ -100,7 +120,7 @@ def _release_staging():
     """pending copies, pinned buffers and copy streams go before the interpreter (and the HIP runtime) shut down"""
     try:
         for f in list(host_future._in_flight):
-            f._job.result()
+            f.result()
         del host_future._in_flight[:]
         if host_future._pool is not None:
             host_future._pool.shutdown(wait=True)
@@ -265,6 +285,30 @@ def almxfl_add(a, b, fl, out=None):
     else:
         _lib.check(_lib.lib().pl_almxfl_add_b(lmax, nb, a.data_ptr(), b.data_ptr(), f.data_ptr(), lmax + 1, out.data_ptr(), stream_ptr()))
     return out
+
+
+def alm_lincomb(outputs):
+    """[sum_t fl_t alm_t for the (alm, fl) terms of an output] for one or two outputs of one or two terms each, in ONE launch
+    (pl_alm_lincomb); returns the rows of one (nout, nalm) tensor -- (G, C) of a spin transform as its synthesis takes them, no stacking
+    copy.  Rounded exactly as almxfl of the first term followed by almxfl_add of the second."""
+    nout = len(outputs)
+    assert 1 <= nout <= 2 and all(1 <= len(o) <= 2 for o in outputs)
+    a0 = outputs[0][0][0]
+    n = a0.numel()
+    lmax = Alm.getlmax(n)
+    out = torch.empty((nout, n), dtype=torch.complex128, device=a0.device)
+    alms, fls, keep = [None] * (2 * nout), [None] * (2 * nout), []
+    for k, terms in enumerate(outputs):
+        for t, (alm, fl) in enumerate(terms):
+            assert alm.dim() == 1 and alm.numel() == n and alm.dtype == torch.complex128 and alm.is_cuda
+            alm = alm.contiguous()
+            keep.append(alm)
+            alms[2 * k + t], fls[2 * k + t] = alm.data_ptr(), fl_dev(fl, lmax).data_ptr()
+    nterm = (ctypes.c_int * nout)(*[len(o) for o in outputs])
+    pa, pf = (ctypes.c_void_p * (2 * nout))(*alms), (ctypes.c_void_p * (2 * nout))(*fls)
+    po = (ctypes.c_void_p * nout)(*[out[k].data_ptr() for k in range(nout)])
+    _lib.check(_lib.lib().pl_alm_lincomb(lmax, nout, nterm, pa, pf, po, stream_ptr()))
+    return [out[k] for k in range(nout)]
 
 
 DOT_PARTS = 64  # PL_DOT_PARTS of include/plshts.h

@@ -454,8 +454,9 @@ class library(object):
         """per simulation (G host, C host, G device, C device); the host entries are dev.host_future objects when `defer`"""
         out = []
         for G, C in gcs:
-            if defer and G.numel() >= self._DEFER_MIN_ENTRIES:
-                out.append((dev.host_future(G), dev.host_future(C), G, C))
+            if defer:  # (small results: copies nobody waits for until they are read -- no helper thread, see dev.host_future)
+                big = G.numel() >= self._DEFER_MIN_ENTRIES
+                out.append((dev.host_future(G, threaded=big), dev.host_future(C, threaded=big), G, C))
             else:
                 out.append((dev.to_host(G), dev.to_host(C), G, C))
         self._last_dev, self._last_dev_key = (out[1][2], out[1][3]), (fam, idx1, False)
@@ -963,9 +964,32 @@ class lib_filt2map_sepTP(lib_filt2map):
             G = G + dev.almxfl(self._alm('tlm', idx), self.clte)
         return shts.alm2map_spin([G, C], self.nside, 2, self._lmax(G))
 
+    # ---- the Wiener-filtered legs in one launch each -------------------------------------------------------------------------------------
+    # For a filter library whose Wiener-filtered fields are C^XX_l Xb_lm (filt_simple.library_sepTP and its subclasses) the legs
+    # T^WF (+ C^TE Eb) and (E^WF (+ C^TE Tb), B^WF) are linear combinations of the filtered alms: one pl_alm_lincomb launch instead of
+    # hp.almxfl per field plus an addition (qest.py:582-589,613-618), rounded the same way.  The polarization pair serves the spin-3 and
+    # the spin-1 leg: it is kept for the two most recent simulations.
+    def _wf_direct(self):
+        from .filt import filt_simple
+        return (isinstance(self.ivfs, filt_simple.library_sepTP) and type(self.ivfs).get_sim_alm_dev is filt_simple.library_sepTP.get_sim_alm_dev
+                and all(kk in self.ivfs.cl for kk in ('tt', 'ee', 'bb')))
+
+    def _memo_leg(self, key, make):
+        memo = self.__dict__.setdefault('_leg_memo', collections.OrderedDict())
+        if key not in memo:
+            while len(memo) >= 4:
+                memo.popitem(last=False)
+            memo[key] = make()
+        return memo[key]
+
     def _gt_alm(self, idx, k=None, xfilt=None):
         """Gradient alm of the spin-1 leg of T^WF (+ C^TE Eb for k = 'p'), with optional 0/1 field selectors (qest.py:566-595)."""
         assert k in ['ptt', 'p'], k
+        if xfilt is None and self._wf_direct():
+            t = self._alm('tlm', idx)
+            terms = [(t, self.ivfs.cl['tt'])] + ([(self._alm('elm', idx), self.clte)] if k == 'p' else [])
+            if all(isinstance(a, torch.Tensor) and a.is_cuda and a.numel() == t.numel() for a, _ in terms):
+                return self._memo_leg(('gt', k, idx, t.data_ptr()), lambda: dev.alm_lincomb([terms])[0])
         if xfilt is not None:
             assert isinstance(xfilt, dict) and 't' in xfilt.keys()
             if k == 'p':
@@ -989,6 +1013,11 @@ class lib_filt2map_sepTP(lib_filt2map):
     def _gp_alms(self, idx, k=None, xfilt=None):
         """(G, C) of the spin-1 / spin-3 legs of (E^WF (+ C^TE Tb for k = 'p'), B^WF) (qest.py:597-638)."""
         assert k in ['p_p', 'p'], k
+        if xfilt is None and self._wf_direct():
+            e, b = self._alm('elm', idx), self._alm('blm', idx)
+            gterms = [(e, self.ivfs.cl['ee'])] + ([(self._alm('tlm', idx), self.clte)] if k == 'p' else [])
+            if all(isinstance(a, torch.Tensor) and a.is_cuda and a.numel() == e.numel() for a, _ in gterms + [(b, None)]):
+                return self._memo_leg(('gp', k, idx, e.data_ptr()), lambda: tuple(dev.alm_lincomb([gterms, [(b, self.ivfs.cl['bb'])]])))
         if xfilt is not None:
             assert isinstance(xfilt, dict) and all(f in xfilt.keys() for f in 'teb')
         need_p = xfilt is None or np.any(xfilt['e']) or np.any(xfilt['b'])
