@@ -127,6 +127,8 @@ def parse(argv=None):
     ap.add_argument('--no-cg', action='store_true', help='skip the CG block (BASELINE config 4)')
     ap.add_argument('--cg-iters', type=int, default=100)
     ap.add_argument('--cg-batches', type=str, default='2,4,8', help='block sizes B > 1 of the CG block (simulations filtered together); empty: none')
+    ap.add_argument('--sims-seed', type=int, default=None, help='seed of the resident input maps (default 1000 + rank: every rank its own sky)')
+    ap.add_argument('--no-plan-stats', action='store_true', help='skip the nside-4096 plan-creation measurement (time and host memory of the table build)')
     return ap.parse_args(argv)
 
 
@@ -352,14 +354,18 @@ def run_rank(args):
     import torch
     import torch.distributed as dist
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (no CPU path)'
-    if local_rank >= torch.cuda.device_count():  # (device_count does not initialise the GPU)
-        sys.stderr.write('bench.py: rank %d of %d has no GPU of its own (%d visible): one rank per GPU\n' % (rank, world, torch.cuda.device_count()))
+    # PLENS_DIST_BACKEND=gloo (tests): the ranks may share a GPU, collectives are staged through the host (plancklens_amd.parallel);
+    # the default -- and the only form a number is quoted from -- is nccl = RCCL with one GPU per rank
+    backend = os.environ.get('PLENS_DIST_BACKEND') or 'nccl'
+    ndev = torch.cuda.device_count()  # (device_count does not initialise the GPU)
+    if local_rank >= ndev and backend == 'nccl':
+        sys.stderr.write('bench.py: rank %d of %d has no GPU of its own (%d visible): one rank per GPU\n' % (rank, world, ndev))
         return 2
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(1, ndev))
     use_dist = world > 1 or ('RANK' in os.environ and os.environ.get('PLENS_DIST_FORCE', '0') == '1')
     if use_dist:  # (PLENS_DIST_FORCE=1 under a launcher: RCCL collectives with a single rank, tests/test_gpu_bench.py)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl')
+        dist.init_process_group(backend=backend)
     from plancklens_amd.helpers import mpi
     mpi.rank, mpi.size = rank, world
 
@@ -378,7 +384,10 @@ def run_rank(args):
     for f in (ftl, fel, fbl):
         f[:min(lmin_ivf, lmax // 4)] = 0.
 
-    sims = resident_sims(nside, lmax, cl_len, transf, nlev_t, nlev_p, seed=1000 + rank)
+    t_plan0 = time.perf_counter()
+    shts.get_plan(nside, lmax)  # geometry, recursion and ring-FFT tables of the benchmarked grid (built on the host, uploaded once)
+    plan_create_s = time.perf_counter() - t_plan0
+    sims = resident_sims(nside, lmax, cl_len, transf, nlev_t, nlev_p, seed=(1000 + rank) if args.sims_seed is None else args.sims_seed)
     tmp = tempfile.mkdtemp(prefix='plbench_r%d_' % rank)
     mpi.rank = 0  # every rank owns a private scratch directory: all of them create their hash files
     mpi.size = 1
@@ -394,6 +403,12 @@ def run_rank(args):
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
+
+    def reduce_max(vals):
+        """max over ranks of a few floats (device tensors on nccl, host tensors on a CPU backend)"""
+        tt = torch.tensor(list(vals), dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return [float(x) for x in tt.tolist()]
 
     K = args.steps
     # set-up, not a step: the paired-simulation transforms are run once on zeros so that their workspaces (four-component phase
@@ -482,14 +497,12 @@ def run_rank(args):
     if use_dist:
         # per-rank times of the timed region (before the closing barrier a slow rank shows up as a long time of its own, after it as
         # everybody's): gathered so that imbalance between GPUs is visible in the line; `value` uses the maximum
-        mine = torch.zeros(world, dtype=torch.float64, device='cuda')
+        mine = torch.zeros(world, dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
         mine[rank] = dt_local
         dist.all_reduce(mine)
         dt_ranks = [float(x) for x in mine.tolist()]
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        one = torch.ones(1, device='cuda')
+        dt, = reduce_max([dt])
+        one = torch.ones(1, device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(one)
         ranks_seen = int(one.item())
 
@@ -534,9 +547,7 @@ def run_rank(args):
             torch.cuda.synchronize()
             dgen = time.perf_counter() - t0
             if use_dist:
-                tt = torch.tensor([dtg, dgen], dtype=torch.float64, device='cuda')
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dtg, dgen = float(tt[0]), float(tt[1])
+                dtg, dgen = reduce_max([dtg, dgen])
             from_sims = {'value': world * K / dtg, 'unit': 'reconstructions/s', 'ms_per_step': 1e3 * dtg / K,
                          'generation_ms_per_simulation': 1e3 * dgen / K, 'generation_share_of_step': dgen / dtg,
                          'note': "same estimator, inputs NOT resident: every simulation's T, Q, U maps are generated on the device inside the "
@@ -560,6 +571,9 @@ def run_rank(args):
             'ms_per_step_by_rank': [1e3 * x / K for x in dt_ranks],
             'selfcheck_max_abs_diff': selfcheck,  # timed route vs single-simulation eager route, same simulation (rank 0); must be 0.0
             'graph_replay': graphed,  # timed region = replayed HIP graphs of reconstruction pairs (qest.library._pair_graph)
+            # sum |mf_lm|^2 of the mean field the timed region produced (all ranks' simulations: after the all-reduce every rank holds it)
+            'mean_field_checksum': float(np.sum(np.abs(mf) ** 2)),
+            'plan_create': {'nside': nside, 'lmax': lmax, 'seconds': plan_create_s},
             'config': {'workload': "'%s' MV quadratic estimator from T,Q,U maps: isotropic filter + qest.library_sepTP, "
                                    "nside=%d lmax_ivf=%d lmax_qlm=%d, 9 SHTs (2 scalar + 7 spin pairs) per reconstruction (BASELINE.json headline config); "
                                    "timed region = qest.library.get_sim_qlm_mf over %d simulations (%d per GPU) + all-gather of the last qlm"
@@ -635,6 +649,24 @@ def run_rank(args):
         res['from_sims'] = from_sims
     # release the QE working set before the CG block
     del sims, ivfs, qlms, gathered
+    if world == 1 and rank == 0 and not args.no_plan_stats and nside == 2048:
+        # BASELINE config 5 starts 8 ranks at once, each building the tables of an nside-4096 plan on the host (long double, ~1 GB of
+        # vectors) before uploading them: the first thing that can time out or run a host out of memory.  Measured here, outside every
+        # timed region: wall time of pl_plan_create, growth of the process's peak resident set, device bytes of the plan.
+        try:
+            import resource
+            rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+            t0p = time.perf_counter()
+            p4 = shts.Plan(4096, 4096)
+            t4 = time.perf_counter() - t0p
+            rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+            res['plan_create']['nside_4096'] = {'seconds': t4, 'host_peak_rss_growth_mb': (rss1 - rss0) / 1024., 'host_peak_rss_mb': rss1 / 1024.,
+                                                'device_mb': p4.bytes() / 2. ** 20,
+                                                'note': 'pl_plan_create(4096, 4096) in this process after the 2048 run: geometry + spin-0 recursion + ring-FFT '
+                                                        'tables (spin tables are built on first use of a spin: +1 table set each)'}
+            del p4
+        except Exception as e:
+            res['plan_create']['nside_4096'] = {'error': repr(e)}
     if world == 1 and rank == 0:
         if not args.no_cg:
             try:

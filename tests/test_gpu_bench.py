@@ -52,3 +52,33 @@ def test_bench_under_launcher_with_rccl_collectives():
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
     assert d['n_gpus'] == 1 and d['ranks_seen'] == 1 and d['value'] > 0 and len(d['ms_per_step_by_rank']) == 1 and 'error' not in d['from_sims']
+
+
+def _bench_line(args, env=None, nranks=1, timeout=900):
+    import socket
+    if nranks == 1:
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py')] + args
+    else:
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nranks), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(nranks)] + args
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+
+
+def test_bench_two_ranks_on_one_gpu_give_the_one_rank_mean_field():
+    """The N > 1 path of bench.py for real (no stub) on the one GPU of the box: two rank processes under the driver's launcher sharing
+    device 0, process group on gloo (PLENS_DIST_BACKEND=gloo: collectives staged through the host).  Both ranks are seen, each
+    reports its own time, and the mean field over world x K simulations -- sharded jobs[rank::size], summed by the all-reduce --
+    equals the one computed by a single rank over the same simulations (all ranks on the same input maps: --sims-seed)."""
+    common = ['--nside', '64', '--lmax', '64', '--warmup', '2', '--no-cg', '--no-cpu-baseline', '--no-from-sims', '--sims-seed', '7']
+    one = _bench_line(common + ['--steps', '4'])
+    two = _bench_line(common + ['--steps', '2'], env={'PLENS_DIST_BACKEND': 'gloo'}, nranks=2)
+    assert one['ranks_seen'] == 1 and two['ranks_seen'] == 2 and two['n_gpus'] == 2
+    assert len(two['ms_per_step_by_rank']) == 2 and all(t > 0 for t in two['ms_per_step_by_rank'])
+    assert two['steps'] == 2 and abs(two['value'] * two['ms_per_step'] / 1e3 - 2.) < 1e-6  # whole-job rate: world x K reconstructions / time
+    assert one['mean_field_checksum'] > 0
+    assert abs(two['mean_field_checksum'] / one['mean_field_checksum'] - 1.) < 1e-12
+    assert one['selfcheck_max_abs_diff'] == 0.0 and two['selfcheck_max_abs_diff'] == 0.0
+    assert one['plan_create']['seconds'] > 0
