@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "device_plan.h"
 #include "plshts_internal.h"
@@ -1047,6 +1048,236 @@ __global__ __launch_bounds__(N / 8, 2) void k_map2phase_fast(DevPlan P, DevFFT F
 }
 
 // =====================================================================================================
+// Wavefront-private transforms for the direct rings of sub-DFT length q = N = 2048 (the belt of an nside-2048 grid: half its pixels)
+// =====================================================================================================
+// The register kernels above run a size-N transform as three or four radix-8 passes with the whole workgroup exchanging its points
+// through LDS between passes: 24 barrier pairs per ring pair, and a wave that spends half its cycles waiting at them.  Here ONE
+// wavefront owns a whole sub-DFT: 32 points per lane, N = 32 x 64 --
+//   (1) DFT-32 over the lane's own points (registers only),  (2) twiddle W_N^(b L),  (3) a 64 x 32 transpose through a strip of LDS
+//   that belongs to the wave (no barrier: a wave's LDS operations execute in order),  (4) DFT-32 again,  (5) one radix-2 step across
+//   lane pairs (DPP) --
+// so the four sub-DFTs of a ring pair proceed on the four waves of a workgroup without ever synchronising; only the radix-4 step on
+// the pixel side, which needs all four, goes through LDS between waves (four barriers per ring pair).  LDS operations per point
+// fall from 3 writes + 3 reads to 2 + 2.  Index algebra (inverse transform, W = e^{+2 pi i / N}): input k1 = L + 64 j (lane L, register
+// j), output j1 = 32 a + b:  W^(j1 k1) = W_64^(a L) W_N^(b L) W_32^(b j);  a = a' + 32 s:  y[32 a + b] = E_0[a'] + (-1)^s W_64^(a') E_1[a'],
+// E_h[a'] = sum_i v[2 i + h][b] W_32^(a' i).
+__device__ constexpr double kC64[33] = {1.0, 0.9951847266721969, 0.9807852804032304, 0.9569403357322088, 0.9238795325112867, 0.881921264348355, 0.8314696123025452, 0.773010453362737, 0.7071067811865476, 0.6343932841636455, 0.5555702330196022, 0.47139673682599764, 0.3826834323650898, 0.2902846772544624, 0.19509032201612828, 0.0980171403295606, 0.0, -0.0980171403295606, -0.19509032201612828, -0.2902846772544624, -0.3826834323650898, -0.47139673682599764, -0.5555702330196022, -0.6343932841636455, -0.7071067811865476, -0.773010453362737, -0.8314696123025452, -0.881921264348355, -0.9238795325112867, -0.9569403357322088, -0.9807852804032304, -0.9951847266721969, -1.0};
+__device__ constexpr double kS64[33] = {0.0, 0.0980171403295606, 0.19509032201612828, 0.2902846772544624, 0.3826834323650898, 0.47139673682599764, 0.5555702330196022, 0.6343932841636455, 0.7071067811865476, 0.773010453362737, 0.8314696123025452, 0.881921264348355, 0.9238795325112867, 0.9569403357322088, 0.9807852804032304, 0.9951847266721969, 1.0, 0.9951847266721969, 0.9807852804032304, 0.9569403357322088, 0.9238795325112867, 0.881921264348355, 0.8314696123025452, 0.773010453362737, 0.7071067811865476, 0.6343932841636455, 0.5555702330196022, 0.47139673682599764, 0.3826834323650898, 0.2902846772544624, 0.19509032201612828, 0.0980171403295606, 0.0};
+
+__device__ constexpr int kBrev5[32] = {0, 16, 8, 24, 4, 20, 12, 28, 2, 18, 10, 26, 6, 22, 14, 30, 1, 17, 9, 25, 5, 21, 13, 29, 3, 19, 11, 27, 7, 23, 15, 31};
+
+// d * e^{-+ 2 pi i t / 64} (FWD: -), t a compile-time index in [0, 32]
+template <bool FWD>
+__device__ __forceinline__ double2 rot64(double2 d, int t)
+{
+    if (t == 0) return d;
+    if (t == 16) return mul_i<FWD>(d);
+    if (t == 32) return make_double2(-d.x, -d.y);
+    const double c = kC64[t], s = FWD ? -kS64[t] : kS64[t];
+    return make_double2(d.x * c - d.y * s, d.x * s + d.y * c);
+}
+
+// In-register DFT-32, decimation in frequency: natural order in, x[i] = X[kBrev5[i]] out (the register index is a compile-time
+// constant everywhere, so the permutation costs nothing).  FWD: e^{-2 pi i jk/32}, else e^{+2 pi i jk/32}; unnormalised.
+template <bool FWD>
+__device__ __forceinline__ void dft32(double2 (&x)[32])
+{
+#pragma unroll
+    for (int len = 32; len >= 2; len >>= 1) {
+        const int half = len >> 1, step = 64 / len;  // twiddle W_len^k = W_64^(k step)
+#pragma unroll
+        for (int blk = 0; blk < 32; blk += len) {
+#pragma unroll
+            for (int k = 0; k < half; ++k) {
+                const double2 a = x[blk + k], b = x[blk + k + half];
+                x[blk + k] = cadd(a, b);
+                x[blk + k + half] = rot64<FWD>(csub(a, b), k * step);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ double dpp_xor1(double v)  // the value of lane ^ 1 (quad_perm [1, 0, 3, 2])
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// orders a wave's own LDS traffic for the compiler (the hardware executes one wave's DS instructions in order)
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kWaveN = 2048, kWaveRow = 66, kWaveReg = 16 * kWaveRow;  // LDS strip of a wave in double2 units: 32 rows of 64 + 2 (pad) doubles = 16.5 KB
+constexpr int kWaveLds = 4 * kWaveReg * (int)sizeof(double2);
+
+// synthesis of the direct rings, q = N = 2048: workgroup = 4 waves = the four sub-DFTs k2 of one ring pair and component
+template <bool WGT>
+__global__ __launch_bounds__(256, 2) void k_phase2map_wave(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim,
+                                                           int ncomp, const double *__restrict__ phase, double *__restrict__ map,
+                                                           const double *__restrict__ wgt)
+{
+    extern __shared__ double2 lds[];
+    constexpr int N = kWaveN;
+    const int tl = threadIdx.x, L = tl & 63, k2 = tl >> 6, h = L & 1, bl = L >> 1;
+    const int ip = pairs[blockIdx.x], comp = blockIdx.y;
+    const int n = P.nphi[ip], q = n >> 2;  // q == N (the launcher's list holds those rings only)
+    const int ml = min(mlim[ip], P.mmax);
+    const bool shifted = P.phi0[ip] != 0.0;
+    const double inv_n = 1.0 / n;
+    constexpr int estride = 4;
+    const double *__restrict__ ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * estride;
+    double2 *reg = lds + k2 * kWaveReg;
+
+    // ---- gather: x[j] = z of bin k = 4 k1 + k2, k1 = L + 64 j (first half of the sub-DFT: order +k; second half: order n - k) --------
+    // Two regimes, chosen per ring (wave-uniform): with mlim < 2304 (every ring of a grid with lmax <= nside + 255) only the register slots
+    // j <= 8 (orders +k) and j >= 23 (orders n - k) can hold in-band bins -- 18 loads, all in flight at once, the other slots are zero;
+    // otherwise all 32 slots, 16 loads in flight at a time.
+    double2 x[32];
+    auto gather = [&](auto shifted_c, auto narrow_c) {
+        constexpr bool SH = decltype(shifted_c)::value, NARROW = decltype(narrow_c)::value;
+        double2 p0 = make_double2(1., 0.);
+        if constexpr (SH) p0 = cispi((4.0 * L + k2) * inv_n);  // e^{i pi (4 L + k2) / n}; the step to the next j is e^{i pi 256 / n} = e^{2 pi i / 64}
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {  // batch g: slots j = 16 g .. 16 g + 15 (narrow: the in-band ones of both halves in batch 0)
+            double4 f[18];
+            bool hv[18];
+#pragma unroll
+            for (int t = 0; t < (NARROW ? 18 : 16); ++t) {
+                const int j = NARROW ? (t < 9 ? t : 14 + t) : 16 * g + t;
+                if (NARROW && g == 1) continue;
+                const int k = 4 * (L + 64 * j) + k2;
+                const int mm = j < 16 ? k : n - k;
+                hv[t] = mm <= ml;
+                f[t] = *reinterpret_cast<const double4 *>(ph + (int64_t)(hv[t] ? mm : 0) * estride);  // branch-free: out-of-band bins read order 0, zeroed below
+            }
+            phase_fence();
+#pragma unroll
+            for (int t = 0; t < (NARROW ? 18 : 16); ++t) {
+                const int j = NARROW ? (t < 9 ? t : 14 + t) : 16 * g + t;
+                if (NARROW && g == 1) continue;
+                const bool plus = j < 16, have = hv[t];
+                double2 fn = make_double2(f[t].x, f[t].y), fs = make_double2(f[t].z, f[t].w);
+                if constexpr (SH) {
+                    const double2 pk = rot64<false>(p0, j);                            // e^{i pi k / n}
+                    const double2 pm = plus ? pk : make_double2(-pk.x, pk.y);          // order n - k: e^{i pi} conj
+                    fn = cmul(fn, pm); fs = cmul(fs, pm);
+                }
+                double2 z;
+                z.x = have ? (plus ? fn.x - fs.y : fn.x + fs.y) : 0.0;
+                z.y = have ? (plus ? fn.y + fs.x : -fn.y + fs.x) : 0.0;
+                if (j == 16) {  // bin n / 2 (k2 = 0, k1 = q / 2) of a ring with mlim = n / 2 holds that order from both sides
+                    const bool nyq = have && k2 == 0 && L == 0;
+                    z.x = nyq ? 2.0 * fn.x : z.x;
+                    z.y = nyq ? 2.0 * fs.x : z.y;
+                }
+                x[j] = z;
+            }
+            phase_fence();
+        }
+        if constexpr (NARROW) {
+#pragma unroll
+            for (int j = 9; j < 23; ++j) x[j] = make_double2(0., 0.);
+        }
+    };
+    if (ml < 2304) { if (shifted) gather(std::true_type{}, std::true_type{}); else gather(std::false_type{}, std::true_type{}); }
+    else { if (shifted) gather(std::true_type{}, std::false_type{}); else gather(std::false_type{}, std::false_type{}); }
+    // ---- (1) DFT-32 over j, (2) twiddle W_N^(b L) ----------------------------------------------------------------------------------
+    __builtin_amdgcn_sched_barrier(0);  // (phases stay apart: hipcc otherwise hoists the table / LDS accesses of later phases into earlier ones)
+    dft32<false>(x);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const int ts = F.Mtw / N;  // F.tw[t] = e^{-2 pi i t / Mtw}, t < Mtw / 2: every index below is < Mtw / 2 (16 L <= 1008 < N / 2)
+        double2 lo[8], hi[4];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) lo[1 << s] = cconj(F.tw[(L << s) * ts]);
+        hi[1] = cconj(F.tw[(L << 3) * ts]); hi[2] = cconj(F.tw[(L << 4) * ts]);
+        lo[3] = cmul(lo[1], lo[2]); lo[5] = cmul(lo[1], lo[4]); lo[6] = cmul(lo[2], lo[4]); lo[7] = cmul(lo[3], lo[4]);
+        hi[3] = cmul(hi[1], hi[2]);
+#pragma unroll
+        for (int b = 1; b < 32; ++b) {
+            const double2 w = (b & 7) == 0 ? hi[b >> 3] : ((b >> 3) == 0 ? lo[b & 7] : cmul(lo[b & 7], hi[b >> 3]));
+            x[kBrev5[b]] = cmul(x[kBrev5[b]], w);
+        }
+    }
+    // ---- (3) transpose through the wave's own strip, real parts then imaginary parts (a strip holds 32 rows of 64 doubles): lane
+    // (b = L / 2, h = L % 2) receives v[2 i + h][b], i < 32.  Every lane takes part in both rounds; after a round's stores the x of
+    // that part are dead, so the live set stays near 128 registers.  Row stride 66 doubles: the 16 rows met by a group of 32 lanes of a
+    // ds_read_b64 start 4 banks apart (conflict-free), the stores are contiguous.
+    __builtin_amdgcn_sched_barrier(0);
+    double2 u[32];
+    {
+        double *regd = reinterpret_cast<double *>(reg);
+        const double *row = regd + bl * kWaveRow + h;
+#pragma unroll
+        for (int b = 0; b < 32; ++b) regd[b * kWaveRow + L] = x[kBrev5[b]].x;
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < 32; ++i) u[i].x = row[2 * i];
+        wave_lds_fence();
+#pragma unroll
+        for (int b = 0; b < 32; ++b) regd[b * kWaveRow + L] = x[kBrev5[b]].y;
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < 32; ++i) u[i].y = row[2 * i];
+        wave_lds_fence();
+    }
+    // ---- (4) DFT-32 over i, (5) radix-2 across the lane pair: lane h keeps a = a' + 32 h -------------------------------------------------
+    __builtin_amdgcn_sched_barrier(0);
+    dft32<false>(u);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const double hd = (double)h, sg = 1.0 - 2.0 * hd;
+#pragma unroll
+        for (int a = 0; a < 32; ++a) {
+            const double2 own = u[kBrev5[a]];
+            // lane 0 sends E_0, lane 1 sends W_64^(a') E_1: the factor is 1 or W by lane, formed without a select
+            const double2 f = make_double2(fma(hd, kC64[a] - 1.0, 1.0), hd * kS64[a]);
+            const double2 t = (a == 0) ? own : cmul(own, f);
+            const double2 r = make_double2(dpp_xor1(t.x), dpp_xor1(t.y));
+            u[kBrev5[a]] = make_double2(fma(sg, t.x, r.x), fma(sg, t.y, r.y));  // lane 0: E_0 + W E_1; lane 1: E_0 - W E_1
+        }
+    }
+    // ---- radix-4 over k2 on the pixel side: the sub-DFT values of 512 pixels at a time meet in LDS (double-buffered, own strips) --------
+    // lane (b, h), register a' holds pixel j1 = 1024 h + 32 a' + b of sub-DFT k2; thread tl combines pixels j1 = 1024 uu + 256 c + tl
+    __builtin_amdgcn_sched_barrier(0);
+    double *__restrict__ mp = map + (int64_t)comp * P.npix;
+    const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
+    const double2 e0 = cispi(2.0 * tl * inv_n);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        double2 *wb = reg + (c & 1) * 520 + h * 260 + bl;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) wb[32 * a] = u[kBrev5[8 * c + a]];
+        __syncthreads();
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+            const int j1 = 1024 * uu + 256 * c + tl;
+            const double2 *rb = lds + (c & 1) * 520 + uu * 260 + tl;
+            const double2 d0 = rb[0], d1 = rb[kWaveReg], d2 = rb[2 * kWaveReg], d3 = rb[3 * kWaveReg];
+            const double2 e1 = rot64<false>(e0, 2 * (4 * uu + c));  // e^{2 pi i j1 / n}
+            const double2 e2 = cmul(e1, e1), e3 = cmul(e2, e1);
+            double2 y[4] = {d0, cmul(d1, e1), cmul(d2, e2), cmul(d3, e3)};
+            dft_small<4, false>(y);  // y[j2] = sum_k2 i^(j2 k2) y_k2
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                if constexpr (WGT) {
+                    mp[on + j1 + q * j2] = y[j2].x * wgt[on + j1 + q * j2];
+                    if (os >= 0) mp[os + j1 + q * j2] = y[j2].y * wgt[os + j1 + q * j2];
+                } else {
+                    mp[on + j1 + q * j2] = y[j2].x;
+                    if (os >= 0) mp[os + j1 + q * j2] = y[j2].y;
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================
 // "Quad" variants of the register-resident kernels: one workgroup of 4 G = N / 2 threads per ring pair and component, thread group
 // k2 = threadIdx / G owning sub-DFT k2 -- 8 points per thread instead of 4 x 8.  The four sub-DFTs of a ring then go through their
 // LDS exchanges at the same time (4 exchange buffers, 6 instead of 24 barrier pairs per ring), every gather or store round is
@@ -1557,6 +1788,23 @@ static hipError_t launch_fast_class(const DevPlan &P, const DevFFT &F, int cls, 
     const int n = BLUE ? sd.cls_n[cls] : sd.dir_n[cls];
     const int *pairs = BLUE ? sd.cls_pairs[cls] : sd.dir_pairs[cls];
     if (n == 0) return hipSuccess;
+    if constexpr (N == kWaveN && !BLUE) {
+        // the direct rings of length 4 N: wavefront-private sub-DFTs (k_phase2map_wave); PLSHTS_DEBUG=1 PLSHTS_FFT_WAVE=0: the one-group kernel
+        static const bool wave = dbg_env_int("PLSHTS_FFT_WAVE", 1) != 0;
+        if (synth && wave) {
+            static bool wattr_done[kMaxDevices] = {};
+            const int dv = current_device();
+            if (!wattr_done[dv]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map_wave<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kWaveLds);
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map_wave<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kWaveLds);
+                if (e != hipSuccess) return e;
+                wattr_done[dv] = true;
+            }
+            if (wgt) hipLaunchKernelGGL((k_phase2map_wave<true>), dim3(n, ncomp), dim3(256), kWaveLds, st, P, F, pairs, mlim, ncomp, in, out, wgt);
+            else hipLaunchKernelGGL((k_phase2map_wave<false>), dim3(n, ncomp), dim3(256), kWaveLds, st, P, F, pairs, mlim, ncomp, in, out, wgt);
+            return hipGetLastError();
+        }
+    }
     if constexpr (N <= 2048 && N >= 512) {
         if (fft_quad_enabled<N, BLUE, false>(synth, P.nside)) return launch_quad_class<N, BLUE, false>(P, F, n, pairs, synth, mlim, ncomp, in, out, st, wgt);
     }
