@@ -1277,6 +1277,168 @@ __global__ __launch_bounds__(256, 2) void k_phase2map_wave(DevPlan P, DevFFT F, 
     }
 }
 
+// analysis of the direct rings, q = N = 2048: the mirror image of k_phase2map_wave.  All 256 threads first work as pixel columns (load the
+// 4 + 4 pixels j1 + q j2 of both rings, radix-4 over j2, twiddle e^{2 pi i j1 k2 / n}) and hand sub-DFT k2's input to wave k2 through that
+// wave's LDS strip (512 columns at a time, double-buffered: four barriers); every wave then transforms its sub-DFT on its own
+// (wave_fft: no barrier) and ends with bin k1 = 32 (a' + 32 h) + b in lane (b, h), register a'.  The lanes h = 1 hold the upper half of the
+// bins -- the negative-frequency side -- and publish it in their strip (one barrier); the lanes h = 0 own the orders m = 4 k1 + k2 <= mlim
+// and combine V_m with V_(n - m), which lives in sub-DFT (4 - k2) mod 4.
+__global__ __launch_bounds__(256, 2) void k_map2phase_wave(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim,
+                                                           int ncomp, const double *map, double *phase)
+{
+    extern __shared__ double2 lds[];
+    constexpr int N = kWaveN;
+    const int tl = threadIdx.x, L = tl & 63, k2 = tl >> 6, h = L & 1, bl = L >> 1;
+    const int ip = pairs[blockIdx.x], comp = blockIdx.y;
+    const int n = P.nphi[ip], q = n >> 2;  // q == N
+    const int ml = min(mlim[ip], P.mmax);
+    const bool shifted = P.phi0[ip] != 0.0;
+    const double inv_n = 1.0 / n;
+    constexpr int estride = 4;
+    double *ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * estride;
+    const double wgt = 0.5 * 4.0 * 3.14159265358979323846 / (double)P.npix;  // includes the 1/2 of the N/S split
+    const double *mp = map + (int64_t)comp * P.npix;
+    const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
+    const bool has_s = os >= 0;
+    const double *mps = has_s ? mp + os : mp + on;
+    double2 *reg = lds + k2 * kWaveReg;
+
+    // ---- pixel columns -> sub-DFT inputs: thread tl makes columns j1 = 1024 uu + 256 c + tl; wave k2, lane L takes j1 = L + 64 j -------------
+    double2 x[32];
+    {
+        const double2 e0 = cispi(2.0 * tl * inv_n);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            double2 yk[2][4];
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) {
+                const int j1 = 1024 * uu + 256 * c + tl;
+                double2 y[4];
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) {
+                    const double vn = mp[on + j1 + q * j2], vs = mps[j1 + q * j2];
+                    y[j2] = make_double2(vn, has_s ? -vs : 0.0);
+                }
+                dft_small<4, false>(y);  // y[k2] = sum_j2 i^(j2 k2) conj(z)_(j1 + q j2)
+                const double2 e1 = rot64<false>(e0, 2 * (4 * uu + c));  // e^{2 pi i j1 / n}
+                const double2 e2 = cmul(e1, e1), e3 = cmul(e2, e1);
+                yk[uu][0] = y[0]; yk[uu][1] = cmul(y[1], e1); yk[uu][2] = cmul(y[2], e2); yk[uu][3] = cmul(y[3], e3);
+            }
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) {
+                double2 *wb = lds + (c & 1) * 520 + uu * 260 + tl;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wb[k * kWaveReg] = yk[uu][k];
+            }
+            __syncthreads();
+            const double2 *rb = reg + (c & 1) * 520 + L;
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) x[16 * uu + 4 * c + w] = rb[uu * 260 + 64 * w];
+            }
+        }
+    }
+    // ---- the sub-DFT (inverse sign, as in the synthesis): DFT-32, twiddle, transpose, DFT-32, radix-2 across the lane pair ----------------------
+    __builtin_amdgcn_sched_barrier(0);
+    dft32<false>(x);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const int ts = F.Mtw / N;
+        double2 lo[8], hi[4];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) lo[1 << s] = cconj(F.tw[(L << s) * ts]);
+        hi[1] = cconj(F.tw[(L << 3) * ts]); hi[2] = cconj(F.tw[(L << 4) * ts]);
+        lo[3] = cmul(lo[1], lo[2]); lo[5] = cmul(lo[1], lo[4]); lo[6] = cmul(lo[2], lo[4]); lo[7] = cmul(lo[3], lo[4]);
+        hi[3] = cmul(hi[1], hi[2]);
+#pragma unroll
+        for (int b = 1; b < 32; ++b) {
+            const double2 w = (b & 7) == 0 ? hi[b >> 3] : ((b >> 3) == 0 ? lo[b & 7] : cmul(lo[b & 7], hi[b >> 3]));
+            x[kBrev5[b]] = cmul(x[kBrev5[b]], w);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double2 u[32];
+    {
+        double *regd = reinterpret_cast<double *>(reg);
+        const double *row = regd + bl * kWaveRow + h;
+#pragma unroll
+        for (int b = 0; b < 32; ++b) regd[b * kWaveRow + L] = x[kBrev5[b]].x;
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < 32; ++i) u[i].x = row[2 * i];
+        wave_lds_fence();
+#pragma unroll
+        for (int b = 0; b < 32; ++b) regd[b * kWaveRow + L] = x[kBrev5[b]].y;
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < 32; ++i) u[i].y = row[2 * i];
+        wave_lds_fence();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    dft32<false>(u);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const double hd = (double)h, sg = 1.0 - 2.0 * hd;
+#pragma unroll
+        for (int a = 0; a < 32; ++a) {
+            const double2 own = u[kBrev5[a]];
+            const double2 f = make_double2(fma(hd, kC64[a] - 1.0, 1.0), hd * kS64[a]);
+            const double2 t = (a == 0) ? own : cmul(own, f);
+            const double2 r = make_double2(dpp_xor1(t.x), dpp_xor1(t.y));
+            u[kBrev5[a]] = make_double2(fma(sg, t.x, r.x), fma(sg, t.y, r.y));
+        }
+    }
+    // ---- orders: lane (b, h = 0), register a' owns V_m, m = 4 k1 + k2, k1 = 32 a' + b < q / 2; V_(n - m) = bin k1m of sub-DFT (4 - k2) mod 4,
+    // k1m = q - 1 - k1 (k2 = 0: q - k1), in the upper half: published by the lanes h = 1 of that wave at entry k1m - q / 2 of its strip
+    __builtin_amdgcn_sched_barrier(0);
+    if (h == 1) {
+#pragma unroll
+        for (int a = 0; a < 32; ++a) reg[32 * a + bl] = u[kBrev5[a]];
+    }
+    __syncthreads();
+    {
+        const double2 *mir = lds + ((4 - k2) & 3) * kWaveReg;
+        double2 p0 = make_double2(1., 0.), p1 = p0;
+        if (shifted) {
+            p0 = cispi((4.0 * bl + k2) * inv_n);                                         // e^{i pi (4 b + k2) / n}; step per a': e^{i pi 128 / n} = e^{2 pi i / 128}
+            p1 = cmul(p0, make_double2(0.9987954562051724, 0.049067674327418015));   // x e^{2 pi i / 128}
+        }
+#pragma unroll
+        for (int a = 0; a < 32; ++a) {
+            if (128 * a + k2 > ml) break;  // (wave-uniform: the smallest order of this register, at b = 0, is already out of band)
+            const int k1 = 32 * a + bl, m = 4 * k1 + k2;
+            if (h == 0 && m <= ml) {
+                const double2 own = u[kBrev5[a]];
+                const int k1m = k2 == 0 ? 1024 - k1 : 1023 - k1;          // k1m - q / 2 (k2 = 0, k1 = 0: the order 0 mirrors into itself)
+                const double2 vm = (k2 == 0 && k1 == 0) ? own : mir[k1m];
+                const double2 av = cconj(own);
+                double2 fn = cadd(av, vm);
+                const double2 dd = csub(av, vm);
+                double2 fs = make_double2(dd.y, -dd.x);   // (conj(V_m) - V_(n-m)) / i
+                if (shifted) { const double2 pk = rot64<false>((a & 1) ? p1 : p0, a >> 1); fn = cmulc(fn, pk); fs = cmulc(fs, pk); }  // e^{-i pi m / n}
+                double4 o;
+                o.x = fn.x * wgt; o.y = fn.y * wgt;
+                o.z = has_s ? fs.x * wgt : 0.0; o.w = has_s ? fs.y * wgt : 0.0;
+                *reinterpret_cast<double4 *>(ph + (int64_t)m * estride) = o;
+            }
+        }
+        // the order n / 2 of a ring with mlim = n / 2: bin q / 2 of sub-DFT 0 (lane b = 0, h = 1, register a' = 0) mirrors into itself
+        if (k2 == 0 && L == 1 && 2 * q <= ml) {
+            const double2 own = u[kBrev5[0]];
+            const double2 av = cconj(own);
+            double2 fn = cadd(av, own);
+            const double2 dd = csub(av, own);
+            double2 fs = make_double2(dd.y, -dd.x);
+            if (shifted) { const double2 pk = cispi(2.0 * q * inv_n); fn = cmulc(fn, pk); fs = cmulc(fs, pk); }
+            double4 o;
+            o.x = fn.x * wgt; o.y = fn.y * wgt;
+            o.z = has_s ? fs.x * wgt : 0.0; o.w = has_s ? fs.y * wgt : 0.0;
+            *reinterpret_cast<double4 *>(ph + (int64_t)(2 * q) * estride) = o;
+        }
+    }
+}
+
 // =====================================================================================================
 // "Quad" variants of the register-resident kernels: one workgroup of 4 G = N / 2 threads per ring pair and component, thread group
 // k2 = threadIdx / G owning sub-DFT k2 -- 8 points per thread instead of 4 x 8.  The four sub-DFTs of a ring then go through their
@@ -1802,6 +1964,17 @@ static hipError_t launch_fast_class(const DevPlan &P, const DevFFT &F, int cls, 
             }
             if (wgt) hipLaunchKernelGGL((k_phase2map_wave<true>), dim3(n, ncomp), dim3(256), kWaveLds, st, P, F, pairs, mlim, ncomp, in, out, wgt);
             else hipLaunchKernelGGL((k_phase2map_wave<false>), dim3(n, ncomp), dim3(256), kWaveLds, st, P, F, pairs, mlim, ncomp, in, out, wgt);
+            return hipGetLastError();
+        }
+        if (!synth && wave) {
+            static bool wattr_a_done[kMaxDevices] = {};
+            const int dv = current_device();
+            if (!wattr_a_done[dv]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_map2phase_wave), hipFuncAttributeMaxDynamicSharedMemorySize, kWaveLds);
+                if (e != hipSuccess) return e;
+                wattr_a_done[dv] = true;
+            }
+            hipLaunchKernelGGL(k_map2phase_wave, dim3(n, ncomp), dim3(256), kWaveLds, st, P, F, pairs, mlim, ncomp, in, out);
             return hipGetLastError();
         }
     }

@@ -328,19 +328,6 @@ class pre_op_multigrid(object):
                 return self._calc_eager(talm, owned)
         if st['graph'] is False:
             return self._calc_eager(talm, owned)
-        ms = _coarse_mask_stream(shts.context())
-        if ms is not None:  # experiment (cu_mask_cus): the coarse chain of this solver context on its own set of CUs
-            cur = torch.cuda.current_stream()
-            ms.wait_stream(cur)
-            with torch.cuda.stream(ms):
-                for d, p in zip(st['in'], _parts(talm)):
-                    d.copy_(p)
-                st['graph'].replay()
-                outs = [o.clone() for o in st['out']]
-            cur.wait_stream(ms)
-            for o in outs:
-                o.record_stream(cur)
-            return _like(talm, outs)
         for d, p in zip(st['in'], _parts(talm)):
             d.copy_(p)
         st['graph'].replay()
@@ -367,31 +354,6 @@ class pre_op_multigrid(object):
         if _lmax_of(talm) == self.lmax:
             return soltn
         return util_alm.alm_splice(soltn, talm, self.lmax)
-
-
-# ---- measured and NOT adopted: the two coarse chains of a T || P pair on disjoint sets of CUs ----------------
-# cu_mask_cus = n > 0: the graph of a nested stage is replayed on a stream created with hipExtStreamCreateWithCUMask -- CUs [0, n) for
-# plan context 0 (the temperature solve of filt_cinv.run_tp), CUs [256 - n, 256) for any other context (the polarization solve).
-cu_mask_cus = 0
-_MASK_STREAMS = {}
-
-
-def _coarse_mask_stream(ctx):
-    if cu_mask_cus <= 0:
-        return None
-    key = (torch.cuda.current_device(), ctx != 0, cu_mask_cus)
-    if key not in _MASK_STREAMS:
-        import ctypes
-        hip = ctypes.CDLL('libamdhip64.so')
-        words = (ctypes.c_uint32 * 8)(*[0] * 8)
-        for i in (range(cu_mask_cus) if ctx == 0 else range(256 - cu_mask_cus, 256)):
-            words[i // 32] |= (1 << (i % 32))
-        sp = ctypes.c_void_p()
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(sp), 8, words)
-        if rc != 0:
-            raise RuntimeError('hipExtStreamCreateWithCUMask failed: %d' % rc)
-        _MASK_STREAMS[key] = torch.cuda.ExternalStream(sp.value)
-    return _MASK_STREAMS[key]
 
 
 def _lmax_of(v):

@@ -188,24 +188,6 @@ def _run(nside, lmax, iters, kinds, joint, verbose, peak_tflops, batches=()):
                                     'speedup_vs_one_after_the_other': (res['t']['seconds'] + res['p']['seconds']) / dtc}
             if nside == 2048 and lmax == 2048:
                 res['tp_concurrent']['frac_of_fp64_floor'] = (FLOP_PER_ITER_2048['t'] + FLOP_PER_ITER_2048['p']) / peak_tflops / 1e12 / (dtc / iters)
-            # experiment (CG_BENCH_CU_MASKS=128,160,...): the coarse chains of the two solves replayed on CU-masked streams, T on the first n
-            # CUs and P on the last n (qcinv.multigrid.cu_mask_cus); alternating with the unmasked form on the same box
-            if os.environ.get('CG_BENCH_CU_MASKS'):
-                from plancklens_amd.qcinv import multigrid as _mg
-                sweep = {}
-                for ncu in [0] + [int(x) for x in os.environ['CG_BENCH_CU_MASKS'].split(',')] + [0]:
-                    _mg.cu_mask_cus = ncu
-                    ts_ = []
-                    for rep in range(REPS):
-                        t0 = time.time()
-                        filt_cinv.apply_ivf_tp(ft, dmaps_of['t'], fp, dmaps_of['p'])
-                        torch.cuda.synchronize()
-                        ts_.append(time.time() - t0)
-                    sweep.setdefault(str(ncu), []).append(iters / float(np.median(ts_)))
-                _mg.cu_mask_cus = 0
-                res['tp_concurrent']['cu_mask_sweep_iters_per_s'] = sweep
-                if verbose:
-                    print('cu_mask_sweep', json.dumps(sweep), flush=True)
             # block solves of B simulations, T block and P block at the same time (what filter_sims runs with its default batch)
             for B in batches:
                 if B < 4:  # (B = 2 adds little to the picture and 8 s to the run)
