@@ -2103,12 +2103,10 @@ static hipError_t launch_stage(const DevPlan &P, const DevFFT &F, const FftStrea
     // (PLSHTS_DEBUG=1) PLSHTS_FFT_STREAMS: side streams in use, 2 ... 5.  Every one costs a join on the caller's stream (the idle gap at the end of a stage
     // grows by ~10 us per joined stream); measured 26.54 ms per reconstruction with 3, 26.64 with 5, 26.89 with 2
     const int kTinyStream = nside_streams - 1;
-    // ... and so do the items that hold under a tenth of the stage's work (round 5): launched costliest-first behind the big classes they
-    // were the stage's tail -- ~70 us in which three or four short-ring kernels ran one after the other on an otherwise idle chip
-    // (tools/fft_timeline.sh) -- while at the head of the stage they run beside the big kernels and cost nothing
-    int64_t total = 0;
-    for (int a = 0; a < nitems; ++a) total += cost[order[a]];
-    auto tiny = [&](int w) { return (w != nw && count(w) < 8) || cost[w] * 10 < total; };
+    // (round 5, measured and dropped: also sending every item under a tenth of the stage's work to that stream, so that the short kernels
+    // run at the head of the stage beside the big ones instead of forming its ~70 us tail -- in series on one stream they became the
+    // critical path instead: analysis stage 0.57 -> 0.62 ms, spin-0 synthesis 0.37 -> 0.44 ms)
+    auto tiny = [&](int w) { return w != nw && count(w) < 8; };
     auto on_side = [&](int i, int w) -> hipStream_t {
         if (joined[i] || hipStreamWaitEvent(fs.s[i], fs.fork, 0) == hipSuccess) {
             joined[i] = true;
