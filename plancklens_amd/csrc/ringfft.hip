@@ -2118,17 +2118,33 @@ static hipError_t launch_stage(const DevPlan &P, const DevFFT &F, const FftStrea
     if (par && nitems > 1)
         for (int a = 1; a < nitems && e == hipSuccess; ++a)
             if (tiny(order[a])) e = run(order[a], on_side(kTinyStream, order[a]));
-    for (int a = 0; a < nitems && e == hipSuccess; ++a) {
+    // assignment: costliest first to the least-loaded side stream (LPT); launch order on a side stream: per `side_small_first` cheapest first,
+    // so that a stream's short latency-bound kernels run at the head of the stage, beside the big classes, instead of alone at its end
+    static const bool side_small_first = dbg_env_int("PLSHTS_FFT_SMALL_FIRST", 1) != 0;
+    int assign[nw + 1];
+    for (int a = 0; a < nitems; ++a) {
         const int w = order[a];
-        hipStream_t s = st;
+        assign[a] = -1;  // the caller's stream
         if (par && a > 0) {
-            if (tiny(w)) continue;  // launched above
+            if (tiny(w)) { assign[a] = -2; continue; }  // launched above
             int best = 0;
             for (int i = 1; i < kTinyStream; ++i) if (load[i] < load[best]) best = i;
-            s = on_side(best, w);
+            assign[a] = best;
+            load[best] += cost[w];
         }
-        e = run(w, s);
     }
+    if (nitems > 0 && e == hipSuccess) e = run(order[0], st);
+    for (int i = 0; i < kTinyStream && e == hipSuccess; ++i) {
+        for (int a0 = 1; a0 < nitems && e == hipSuccess; ++a0) {
+            const int a = side_small_first ? nitems - a0 : a0;  // (order[] is sorted costliest first)
+            if (assign[a] != i) continue;
+            const int64_t keep = load[i];
+            e = run(order[a], on_side(i, order[a]));
+            load[i] = keep;  // (on_side adds the cost again: the loads were final after the assignment)
+        }
+    }
+    for (int a = 1; a < nitems && e == hipSuccess; ++a)
+        if (assign[a] == -1) e = run(order[a], st);  // (no side streams: everything on the caller's stream)
     for (int i = 0; i < FftStreams::kN; ++i) {
         if (!joined[i]) continue;
         hipError_t e2 = hipEventRecord(fs.join[i], fs.s[i]);
