@@ -403,8 +403,8 @@ class library(object):
 
     # ---- two simulations at a time: the leg syntheses of a pair share Legendre recursions ---------------------------------------------
     # Each family has a device part (`_pair_dev_*`: filtered alms resident -> device (G, C) of both simulations, no host interaction:
-    # what `_pair_graph` captures) and the common host part (`_pair_out`).
-    def _pair_dev_p(self, idx0, idx1):
+    # what `_pair_graph` captures) and the common host part (`_host_pair`).
+    def _pair_dev_p(self, idx0, idx1, emit=None):
         """_get_sim_MVgclm of two simulations whose spin-2 and spin-3 leg syntheses share their Legendre recursions
         (lib_filt2map.get_irespmap_batch2 / get_gpmap_batch2; same legs on both sides only)."""
         f2map1, f2map2 = self._legs(False)
@@ -418,9 +418,11 @@ class library(object):
             dre, dim = dev.qe_lens_product((tmaps[j], gt, ct), (resp[j][0], resp[j][1], gp3[j][0], gp3[j][1], g1, c1))
             del gt, ct, g1, c1
             out.append(tuple(self._gc_from_product(dre, dim, 'P')))
+            if emit is not None:
+                emit(*out[-1])
         return out
 
-    def _pair_dev_p_p(self, idx0, idx1):
+    def _pair_dev_p_p(self, idx0, idx1, emit=None):
         """_get_sim_Pgclm of two simulations: the spin-2, spin-3 and spin-1 leg syntheses each serve both on one Legendre recursion
         (lib_filt2map.get_irespmap_batch2 / get_gpmap_batch2; same legs on both sides only); maps bit-identical to the one-by-one
         evaluation."""
@@ -432,9 +434,11 @@ class library(object):
         for j in (0, 1):
             dre, dim = dev.qe_lens_product(None, (resp[j][0], resp[j][1], gp3[j][0], gp3[j][1], gp1[j][0], gp1[j][1]))
             out.append(tuple(self._gc_from_product(dre, dim, 'P')))
+            if emit is not None:
+                emit(*out[-1])
         return out
 
-    def _pair_dev_ptt(self, idx0, idx1):
+    def _pair_dev_ptt(self, idx0, idx1, emit=None):
         """_get_sim_Tgclm of two simulations: their gradient legs (gradient-only spin-1 syntheses, 8 FMAs per step each) share one
         Legendre recursion (lib_filt2map.get_gtmap_pair, pl_alm2map_grad_pair: 12 for the two; maps bit-identical to the one-by-one
         evaluation), and the filter stage of both is issued before either estimator."""
@@ -448,25 +452,27 @@ class library(object):
                 out.append(tuple(self._get_sim_Tgclm_dev(idx, 'ptt')))
             else:
                 out.append(tuple(self._gc_from_product(*dev.qe_lens_product((f2map1.get_irestmap(idx), gts[j][0], gts[j][1]), None), 'T')))
+            if emit is not None:
+                emit(*out[-1])
         return out
 
-    def _pair_out(self, fam, idx1, gcs, defer):
-        """per simulation (G host, C host, G device, C device); the host entries are dev.host_future objects when `defer`"""
-        out = []
-        for G, C in gcs:
-            if defer:  # (small results: copies nobody waits for until they are read -- no helper thread, see dev.host_future)
-                big = G.numel() >= self._DEFER_MIN_ENTRIES
-                out.append((dev.host_future(G, threaded=big), dev.host_future(C, threaded=big), G, C))
-            else:
-                out.append((dev.to_host(G), dev.to_host(C), G, C))
-        self._last_dev, self._last_dev_key = (out[1][2], out[1][3]), (fam, idx1, False)
-        return out
+    def _host_pair(self, G, C, defer):
+        """(G host, C host, G device, C device); the host entries are dev.host_future objects when `defer`"""
+        if defer:  # (small results: copies nobody waits for until they are read -- no helper thread, see dev.host_future)
+            big = G.numel() >= self._DEFER_MIN_ENTRIES
+            return (dev.host_future(G, threaded=big), dev.host_future(C, threaded=big), G, C)
+        return (dev.to_host(G), dev.to_host(C), G, C)
 
     def _pair(self, fam, idx0, idx1, defer):
+        """per simulation (G host, C host, G device, C device)"""
         gcs = self._pair_graph(fam, idx0, idx1)  # one replayed HIP graph where the libraries allow it (None: not here)
-        if gcs is None:
-            gcs = getattr(self, '_pair_dev_' + fam)(idx0, idx1)
-        return self._pair_out(fam, idx1, gcs, defer)
+        if gcs is not None:
+            out = [self._host_pair(G, C, defer) for G, C in gcs]
+        else:  # eager: a simulation's results start for the host as soon as they exist -- the copies of the first run beside the (FMA-bound)
+            out = []  # Legendre kernels of the second instead of beside the bandwidth-bound first stages of the next pair
+            getattr(self, '_pair_dev_' + fam)(idx0, idx1, emit=lambda G, C: out.append(self._host_pair(G, C, defer)))
+        self._last_dev, self._last_dev_key = (out[1][2], out[1][3]), (fam, idx1, False)
+        return out
 
     def _get_sim_MVgclm_pair(self, idx0, idx1, defer=False):
         return self._pair('p', idx0, idx1, defer)
