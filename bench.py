@@ -128,6 +128,8 @@ def parse(argv=None):
     ap.add_argument('--cg-iters', type=int, default=100)
     ap.add_argument('--cg-batches', type=str, default='2,4,8', help='block sizes B > 1 of the CG block (simulations filtered together); empty: none')
     ap.add_argument('--sims-seed', type=int, default=None, help='seed of the resident input maps (default 1000 + rank: every rank its own sky)')
+    ap.add_argument('--plan-opt', action='append', default=[], metavar='NAME=VALUE',
+                    help='pl_plan_opts field for every plan of the run (shts.plan_options), e.g. fft_legacy=1: a development aid, not a number to quote')
     ap.add_argument('--no-plan-stats', action='store_true', help='skip the nside-4096 plan-creation measurement (time and host memory of the table build)')
     return ap.parse_args(argv)
 
@@ -374,6 +376,8 @@ def run_rank(args):
 
     nside, lmax, key = args.nside, args.lmax, args.key
     lmax_qlm = lmax if args.lmax_qlm is None else args.lmax_qlm
+    if args.plan_opt:
+        shts.plan_options(**{kv.split('=')[0]: int(kv.split('=')[1]) for kv in args.plan_opt}).__enter__()  # (for the life of the process)
     cl_len = utils.camb_clfile(os.path.join(ROOT, 'plancklens_amd', 'data', 'cls', 'FFP10_wdipole_lensedCls.dat'), lmax=lmax)
     transf = hp.gauss_beam(5. / 60. / 180. * np.pi, lmax=lmax)
     nlev_t, nlev_p, lmin_ivf = 35., 55., 100

@@ -55,6 +55,9 @@ typedef struct pl_plan_opts {
     int fft_nyq_min;   /* shortest power-of-two sub-DFT whose order-n/2 rings use the register classes (default 2048); 0: never */
     int fft_min_fast;  /* a plan whose register classes would hold under 1/d of its ring pairs runs every ring in the generic kernel
                           (default d = 8); 0: never */
+    int fft_generic_nside; /* grids up to this nside run every ring in the generic kernel: one launch per stage instead of a dozen
+                          latency-bound class kernels on side streams (default 512: measured 1.2-4x faster stages at nside 256 / 512,
+                          1.5-2x slower at 1024); 0: never */
 } pl_plan_opts;
 /* pl_plan_create (rank 0 of 1) / pl_plan_create_shard with options; opts NULL = defaults. */
 int pl_plan_create_opts(int nside, int lmax, int rank, int nranks, const pl_plan_opts *opts, pl_plan **plan);

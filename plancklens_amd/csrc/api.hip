@@ -264,7 +264,7 @@ static int plan_create_impl(int nside, int lmax, int rank, int nranks, const pl_
     *out = nullptr;
     if (nside < 1 || nside > 8192) return fail("nside out of range [1, 8192]");
     if (lmax < 0 || lmax > 4 * nside) return fail("lmax out of range [0, 4 nside]");
-    pl_plan_opts opts = {0, -1, -1, -1};
+    pl_plan_opts opts = {0, -1, -1, -1, -1};
     if (opts_in) opts = *opts_in;
     pl_plan *p = nullptr;
     try {
@@ -352,9 +352,13 @@ static int plan_create_body(int nside, int lmax, int rank, int nranks, const pl_
         // generic kernel: the stage is then one launch without a fork / join of side streams, and the CG operators can take the whole
         // pixel-space part in one (k_ring_roundtrip).  opts.fft_min_fast = d: below 1 / d of the pairs (default 8; 0: never).
         const int min_fast = opts.fft_min_fast >= 0 ? opts.fft_min_fast : 8;
+        // ... and so does every small grid (opts.fft_generic_nside, default 512): there a stage of ~10 class kernels is ~10 launch
+        // latencies on three streams for microseconds of work each (round 5, tools/kernel_bench.py with plan options: nside 256 stages
+        // 0.072 -> 0.017-0.031 ms, nside 512 0.099-0.108 -> 0.044-0.084 ms; at nside 1024 the classes win 1.5-2x)
+        const int generic_nside = opts.fft_generic_nside >= 0 ? opts.fft_generic_nside : 512;
         int64_t nfast = 0;
         for (int i = 0; i < g.npairs; ++i) nfast += clsA[g.nphi[i] / 4] >= 0;
-        if (min_fast > 0 && nfast > 0 && nfast * min_fast < g.npairs)
+        if ((min_fast > 0 && nfast > 0 && nfast * min_fast < g.npairs) || (nfast > 0 && nside <= generic_nside))
             for (int q = 1; q <= nside; ++q) { clsA[q] = -1; MofA[q] = 0; splitA[q] = 0; }
     }
     // (A power-of-two ring length below nside is met by a single ring pair per hemisphere pair; it still gets the launch of its

@@ -170,7 +170,9 @@ def test_register_fft_kernels_match_generic_kernel(shts, nside, lmax):
     small-nside tests above pin against the oracle.  Same inputs, both plans: maps and alm must agree to rounding.
     lmax = 2 nside (every coarse grid of the CG chains): the belt rings carry the order n / 2, which the direct classes treat on its own."""
     generic = shts.Plan(nside, lmax, opts={'fft_legacy': 1})
-    fast = shts.Plan(nside, lmax, opts={'fft_nyq_min': 256})  # lmax = 2 nside: the belt in the direct classes at every size (default: sub-DFTs >= 2048 only)
+    # lmax = 2 nside: the belt in the direct classes at every size (default: sub-DFTs >= 2048 only); fft_generic_nside = 0: the register
+    # classes on the small grids too (by default every ring of a grid up to nside 512 runs in the generic kernel)
+    fast = shts.Plan(nside, lmax, opts={'fft_nyq_min': 256, 'fft_generic_nside': 0})
     rng = np.random.default_rng(nside + lmax)
     a = random_alm(rng, lmax)
     g, c = random_alm(rng, lmax, 2), random_alm(rng, lmax, 2)
@@ -187,16 +189,21 @@ def test_register_fft_kernels_match_generic_kernel(shts, nside, lmax):
 
 @pytest.mark.parametrize('nside,lmax', [(256, 383), (512, 512)])
 def test_mid_size_vs_oracle(shts, oracle, nside, lmax):
-    """sizes whose rings use the register-resident FFT classes, against the oracle (spin 0 and 2, both directions)"""
+    """mid sizes against the oracle (spin 0 and 2, both directions): with the default plan (grids up to nside 512: every ring in the generic
+    ring-FFT kernel) and with the register-resident FFT classes switched on for these grids (plan option fft_generic_nside = 0)"""
     rng = np.random.default_rng(7 * nside + lmax)
     a = random_alm(rng, lmax)
-    assert relrms(shts.alm2map(a, nside, lmax=lmax), oracle.alm2map(a, nside, lmax=lmax)) < TOL
     m = rng.standard_normal(12 * nside ** 2)
-    assert relrms(shts.map2alm(m, lmax=lmax, iter=0), oracle.map2alm(m, lmax=lmax)) < TOL
     g, c = random_alm(rng, lmax, 2), random_alm(rng, lmax, 2)
-    assert relrms(np.stack(shts.alm2map_spin([g, c], nside, 2, lmax)), np.stack(oracle.alm2map_spin([g, c], nside, 2, lmax))) < TOL
     qu = rng.standard_normal((2, 12 * nside ** 2))
-    assert relrms(np.stack(shts.map2alm_spin(qu, 2, lmax)), np.stack(oracle.map2alm_spin(qu, 2, lmax))) < TOL
+    ref = (oracle.alm2map(a, nside, lmax=lmax), oracle.map2alm(m, lmax=lmax), np.stack(oracle.alm2map_spin([g, c], nside, 2, lmax)),
+           np.stack(oracle.map2alm_spin(qu, 2, lmax)))
+    for opts in ({}, {'fft_generic_nside': 0}):
+        with shts.plan_options(**opts):
+            out = (shts.alm2map(a, nside, lmax=lmax), shts.map2alm(m, lmax=lmax, iter=0), np.stack(shts.alm2map_spin([g, c], nside, 2, lmax)),
+                   np.stack(shts.map2alm_spin(qu, 2, lmax)))
+        for x, y in zip(out, ref):
+            assert relrms(x, y) < TOL, opts
 
 
 @pytest.mark.parametrize('spin', [1, 2, 3])

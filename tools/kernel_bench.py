@@ -1,5 +1,5 @@
 """Stage-level timing of the SHT kernels at one (nside, lmax) -- development aid for profiling runs.
-usage: python3 tools/kernel_bench.py [nside] [lmax] [reps] [stages: ls,la,ps,pa]"""
+usage: python3 tools/kernel_bench.py [nside] [lmax] [reps] [stages: ls,la,ps,pa] [spins: 0,2] [plan options: fft_legacy=1,...]"""
 import ctypes
 import sys
 
@@ -14,8 +14,10 @@ lmax = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 stages = sys.argv[4].split(',') if len(sys.argv) > 4 else ['ls', 'la', 'ps', 'pa']
 spins = [int(s) for s in sys.argv[5].split(',')] if len(sys.argv) > 5 else [0, 2]
+opts = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in sys.argv[6].split(',')} if len(sys.argv) > 6 else {}  # pl_plan_opts, e.g. fft_legacy=1
 L = _lib.lib()
-plan = shts.get_plan(nside, lmax)
+with shts.plan_options(**opts):
+    plan = shts.get_plan(nside, lmax)
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 rng = np.random.default_rng(1)
 nalm = (lmax + 1) * (lmax + 2) // 2
