@@ -994,24 +994,14 @@ __global__ void k_post0(DevPlan P, int RG, const double4 *__restrict__ partial_,
             if (l_ + 1 <= P.lmax) { dd1 = reinterpret_cast<const double2 *>(dots.d[0])[idot + 1]; rr1 = reinterpret_cast<const double2 *>(dots.r[0])[idot + 1]; }
         }
         double c0r = 0., c0i = 0., c1r = 0., c1i = 0., dr = 0., di = 0.;
-        // the ring groups' partial sums, four groups (eight loads) in flight at a time; pruned groups are read and discarded (see k_posts)
-        for (int g0 = 0; g0 < ngroups; g0 += 4) {
-            double4 v[4], w[4];
-            bool ok[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int g = g0 + u, gc = g < ngroups ? g : ngroups - 1;
-                const int last = min(P.npairs - 1, gc * RG + RG - 1);
-                ok[u] = g < ngroups && P.mlim0[last] >= mg4;
-                v[u] = partial[(int64_t)gc * P.nent0 + e];
-                w[u] = partial[(int64_t)gc * P.nent0 + e - (il > 0 ? 1 : 0)];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (ok[u]) {
-                    c0r += v[u].x; c0i += v[u].y; dr += v[u].z; di += v[u].w;
-                    if (il > 0) { c1r += w[u].x; c1i += w[u].y; }
-                }
+        for (int g = 0; g < ngroups; ++g) {
+            const int last = min(P.npairs - 1, g * RG + RG - 1);
+            if (P.mlim0[last] < mg4) continue;
+            const double4 v = partial[(int64_t)g * P.nent0 + e];
+            c0r += v.x; c0i += v.y; dr += v.z; di += v.w;
+            if (il > 0) {
+                const double4 w = partial[(int64_t)g * P.nent0 + e - 1];
+                c1r += w.x; c1i += w.y;
             }
         }
         const int l = m + 2 * il;
@@ -1314,23 +1304,12 @@ __global__ void k_posts(DevPlan P, DevSpinTab S, int spin, int RG, int64_t nent,
             dg = reinterpret_cast<const double2 *>(dots.d[0])[ii]; rg = reinterpret_cast<const double2 *>(dots.r[0])[ii];
             dc = reinterpret_cast<const double2 *>(dots.d[1])[ii]; rc = reinterpret_cast<const double2 *>(dots.r[1])[ii];
         }
-        // the ring groups' partial sums, eight loads in flight at a time (round 5: one dependent load per trip ran at 2.2 TB/s); groups
-        // whose rings are all pruned for this m were never written: their slots are read (any valid address) and discarded by a select.
-        // Same terms in the same order as before: bit-identical results.
         double gr = 0., gi = 0., cr = 0., ci = 0.;
-        for (int g0 = 0; g0 < ngroups; g0 += 8) {
-            double4 v[8];
-            bool ok[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int g = g0 + u, gc = g < ngroups ? g : ngroups - 1;
-                const int last = min(P.npairs - 1, gc * RG + RG - 1);
-                ok[u] = g < ngroups && S.mlim[last] >= mg4;
-                v[u] = partial[(int64_t)gc * nent + e];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (ok[u]) { gr += v[u].x; gi += v[u].y; cr += v[u].z; ci += v[u].w; }
+        for (int g = 0; g < ngroups; ++g) {
+            const int last = min(P.npairs - 1, g * RG + RG - 1);
+            if (S.mlim[last] < mg4) continue;
+            const double4 v = partial[(int64_t)g * nent + e];
+            gr += v.x; gi += v.y; cr += v.z; ci += v.w;
         }
         const int l = l0 + i;
         double f = 0.5 * S.beta[e];
