@@ -427,9 +427,6 @@ static int plan_create_body(int nside, int lmax, int rank, int nranks, const pl_
     for (int c = 0; c < kFftClasses && !rc; ++c) {
         rc = upload(p, listA[c], &F.A.cls_pairs[c]) || upload(p, dirA[c], &F.A.dir_pairs[c]) || upload(p, splA[c], &F.A.split_pairs[c]);
         F.A.cls_n[c] = (int)listA[c].size();
-        F.A.cls_kmax[c] = F.A.split_kmax[c] = 0;
-        for (int i : listA[c]) if (K2of[g.nphi[i] / 4] > F.A.cls_kmax[c]) F.A.cls_kmax[c] = K2of[g.nphi[i] / 4];
-        for (int i : splA[c]) if (K2of[g.nphi[i] / 4] > F.A.split_kmax[c]) F.A.split_kmax[c] = K2of[g.nphi[i] / 4];
         F.A.dir_n[c] = (int)dirA[c].size();
         F.A.split_n[c] = (int)splA[c].size();
     }

@@ -16,8 +16,6 @@ struct FftSide {
     int legacy_qmax;         // longest quarter-ring of the generic list: sizes its workgroups (threads x points per thread >= qmax)
     const int *cls_pairs[kFftClasses]; // register-resident kernels, transform size N = 256 << c: Bluestein rings (q != N)
     int cls_n[kFftClasses];
-    int cls_kmax[kFftClasses];         // largest band half-width K2of[q] among the rings of the list (wave kernels: narrow bands only)
-    int split_kmax[kFftClasses];
     const int *dir_pairs[kFftClasses]; // ... and the rings whose own sub-DFT length is N (q == N, a power of two)
     int dir_n[kFftClasses];
     // split Bluestein rings: the convolution of size 2 N runs as two halves of size N = 256 << c sharing one transform -- synthesis

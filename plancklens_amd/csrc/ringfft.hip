@@ -1114,7 +1114,6 @@ __device__ __forceinline__ void wave_lds_fence()
 
 constexpr int kWaveN = 2048, kWaveRow = 66, kWaveReg = 16 * kWaveRow;  // LDS strip of a wave in double2 units: 32 rows of 64 + 2 (pad) doubles = 16.5 KB
 constexpr int kWaveLds = 4 * kWaveReg * (int)sizeof(double2);
-constexpr int kWaveKmax = 575;  // narrow band: the in-band Bluestein slots |c| <= K lie in the register slots j <= 8 and j >= 23 of the A layout
 
 // synthesis of the direct rings, q = N = 2048: workgroup = 4 waves = the four sub-DFTs k2 of one ring pair and component
 template <bool WGT>
@@ -1274,233 +1273,6 @@ __global__ __launch_bounds__(256, 2) void k_phase2map_wave(DevPlan P, DevFFT F, 
                     if (os >= 0) mp[os + j1 + q * j2] = y[j2].y;
                 }
             }
-        }
-    }
-}
-
-// ---- the wave transform as two primitives (round 5): A layout = point L + 64 j in lane L, register j; B layout = point 32 (a' + 32 h) + b in
-// lane (b = L / 2, h = L % 2), register a'.  wave_fft_ab: x (A, natural j) -> u with u[kBrev5[a']] = bin a' (B); wave_fft_ba: t with
-// t[kBrev5[a']] = bin a' (B; i.e. the array wave_fft_ab leaves) -> x with x[kBrev5[j]] = point j (A).  FWD: e^{-2 pi i nk / N}.  `reg`: the
-// wave's own LDS strip (kWaveReg double2).  Used by the Bluestein kernels: forward A -> B, filter in the B layout, inverse B -> A.
-template <bool FWD>
-__device__ __forceinline__ void wave_twiddle(double2 (&x)[32], int L, const DevFFT &F, bool brev)
-{
-    // x[b] (brev: x[kBrev5[b]]) *= W_N^(-+ b L): five table entries (F.tw[t] = e^{-2 pi i t / Mtw}, t < Mtw / 2; 16 L <= 1008 < N / 2) and products
-    const int ts = F.Mtw / kWaveN;
-    double2 lo[8], hi[4];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) { const double2 w = F.tw[(L << s) * ts]; lo[1 << s] = FWD ? w : cconj(w); }
-    { const double2 w = F.tw[(L << 3) * ts]; hi[1] = FWD ? w : cconj(w); }
-    { const double2 w = F.tw[(L << 4) * ts]; hi[2] = FWD ? w : cconj(w); }
-    lo[3] = cmul(lo[1], lo[2]); lo[5] = cmul(lo[1], lo[4]); lo[6] = cmul(lo[2], lo[4]); lo[7] = cmul(lo[3], lo[4]);
-    hi[3] = cmul(hi[1], hi[2]);
-#pragma unroll
-    for (int b = 1; b < 32; ++b) {
-        const double2 w = (b & 7) == 0 ? hi[b >> 3] : ((b >> 3) == 0 ? lo[b & 7] : cmul(lo[b & 7], hi[b >> 3]));
-        const int i = brev ? kBrev5[b] : b;
-        x[i] = cmul(x[i], w);
-    }
-}
-
-// lane L's values v[b] (array index kBrev5[b] if `brev`) -> lane (b, h)'s u[i] = v of lane 2 i + h, through the strip (real, then imaginary parts)
-__device__ __forceinline__ void wave_transpose_ab(const double2 (&x)[32], double2 (&u)[32], double2 *reg, int L)
-{
-    double *regd = reinterpret_cast<double *>(reg);
-    const double *row = regd + (L >> 1) * kWaveRow + (L & 1);
-#pragma unroll
-    for (int b = 0; b < 32; ++b) regd[b * kWaveRow + L] = x[kBrev5[b]].x;
-    wave_lds_fence();
-#pragma unroll
-    for (int i = 0; i < 32; ++i) u[i].x = row[2 * i];
-    wave_lds_fence();
-#pragma unroll
-    for (int b = 0; b < 32; ++b) regd[b * kWaveRow + L] = x[kBrev5[b]].y;
-    wave_lds_fence();
-#pragma unroll
-    for (int i = 0; i < 32; ++i) u[i].y = row[2 * i];
-    wave_lds_fence();
-}
-
-// the reverse: lane (b, h)'s g[i] (array index kBrev5[i]) becomes entry 2 i + h of row b; lane L collects x[b] = entry L of row b
-__device__ __forceinline__ void wave_transpose_ba(const double2 (&g)[32], double2 (&x)[32], double2 *reg, int L)
-{
-    double *regd = reinterpret_cast<double *>(reg);
-    double *row = regd + (L >> 1) * kWaveRow + (L & 1);
-#pragma unroll
-    for (int i = 0; i < 32; ++i) row[2 * i] = g[kBrev5[i]].x;
-    wave_lds_fence();
-#pragma unroll
-    for (int b = 0; b < 32; ++b) x[b].x = regd[b * kWaveRow + L];
-    wave_lds_fence();
-#pragma unroll
-    for (int i = 0; i < 32; ++i) row[2 * i] = g[kBrev5[i]].y;
-    wave_lds_fence();
-#pragma unroll
-    for (int b = 0; b < 32; ++b) x[b].y = regd[b * kWaveRow + L];
-    wave_lds_fence();
-}
-
-template <bool FWD>
-__device__ __forceinline__ void wave_fft_ab(double2 (&x)[32], double2 (&u)[32], double2 *reg, int L, const DevFFT &F)
-{
-    __builtin_amdgcn_sched_barrier(0);
-    dft32<FWD>(x);
-    __builtin_amdgcn_sched_barrier(0);
-    wave_twiddle<FWD>(x, L, F, true);
-    __builtin_amdgcn_sched_barrier(0);
-    wave_transpose_ab(x, u, reg, L);
-    __builtin_amdgcn_sched_barrier(0);
-    dft32<FWD>(u);
-    __builtin_amdgcn_sched_barrier(0);
-    const double hd = (double)(L & 1), sg = 1.0 - 2.0 * hd;
-#pragma unroll
-    for (int a = 0; a < 32; ++a) {  // y[a' + 32 s] = E_0[a'] + (-1)^s W_64^(-+ a') E_1[a']: lane h keeps s = h
-        const double2 own = u[kBrev5[a]];
-        const double2 f = make_double2(fma(hd, kC64[a] - 1.0, 1.0), hd * (FWD ? -kS64[a] : kS64[a]));
-        const double2 t = (a == 0) ? own : cmul(own, f);
-        const double2 r = make_double2(dpp_xor1(t.x), dpp_xor1(t.y));
-        u[kBrev5[a]] = make_double2(fma(sg, t.x, r.x), fma(sg, t.y, r.y));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-template <bool FWD>
-__device__ __forceinline__ void wave_fft_ba(double2 (&t)[32], double2 (&x)[32], double2 *reg, int L, const DevFFT &F)
-{
-    __builtin_amdgcn_sched_barrier(0);
-    {   // radix-2 over the lane pair first: lane 0 takes S[a'] = A[a'] + A[a' + 32], lane 1 D[a'] = (A[a'] - A[a' + 32]) W_64^(-+ a')
-        const double hd = (double)(L & 1), sg = 1.0 - 2.0 * hd;
-#pragma unroll
-        for (int a = 0; a < 32; ++a) {
-            const double2 own = t[kBrev5[a]];
-            const double2 r = make_double2(dpp_xor1(own.x), dpp_xor1(own.y));
-            const double2 v = make_double2(fma(sg, own.x, r.x), fma(sg, own.y, r.y));  // lane 0: own + recv; lane 1: recv - own
-            const double2 f = make_double2(fma(hd, kC64[a] - 1.0, 1.0), hd * (FWD ? -kS64[a] : kS64[a]));
-            t[kBrev5[a]] = (a == 0) ? v : cmul(v, f);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {   // DFT-32 over a': natural-order input = the array read through kBrev5
-        double2 v[32];
-#pragma unroll
-        for (int a = 0; a < 32; ++a) v[a] = t[kBrev5[a]];
-        dft32<FWD>(v);
-        __builtin_amdgcn_sched_barrier(0);
-        wave_transpose_ba(v, x, reg, L);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    wave_twiddle<FWD>(x, L, F, false);
-    __builtin_amdgcn_sched_barrier(0);
-    dft32<FWD>(x);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// synthesis of the Bluestein rings of convolution size N = 2048 whose band fits the narrow regime (K <= 575: the in-band sub-DFT bins c in
-// [-K, K] sit in the register slots j <= 8 and j >= 23): per sub-DFT (= per wave) forward transform A -> B, filter spectrum in the B layout,
-// inverse transform B -> A, then chirp, twiddle and the radix-4 step of the pixel side as in k_phase2map_wave
-template <bool WGT>
-__global__ __launch_bounds__(256, 2) void k_phase2map_wave_blue(DevPlan P, DevFFT F, const int *__restrict__ pairs, const int *__restrict__ mlim,
-                                                                int ncomp, const double *__restrict__ phase, double *__restrict__ map,
-                                                                const double *__restrict__ wgt)
-{
-    extern __shared__ double2 lds[];
-    constexpr int N = kWaveN;
-    const int tl = threadIdx.x, L = tl & 63, k2 = tl >> 6;
-    const int ip = pairs[blockIdx.x], comp = blockIdx.y;
-    const int n = P.nphi[ip], q = n >> 2;
-    const int K = F.K2of[q];
-    const double2 *__restrict__ chirp = F.chirp + F.woff[q];
-    const double2 *__restrict__ filt = F.A.filt + F.A.coff[q];
-    const int ml = min(mlim[ip], P.mmax);
-    const bool shifted = P.phi0[ip] != 0.0;
-    const double inv_n = 1.0 / n;
-    constexpr int estride = 4;
-    const double *__restrict__ ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * estride;
-    double2 *reg = lds + k2 * kWaveReg;
-
-    // ---- gather: slot idx = L + 64 j; idx <= K: bin c = idx >= 0 (order +k, k = 4 idx + k2); idx >= N - K: c = idx - N < 0, k1 = q + c (order n - k)
-    double2 x[32];
-    {
-        double2 pp = make_double2(1., 0.), pm = pp, st = pp;
-        if (shifted) {  // e^{i pi m / n}: + side m = 4 (L + 64 j) + k2; - side (j' = 31 - j) m = 4 (64 (j' + 1) - L) - k2; step e^{i pi 256 / n}
-            pp = cispi((4.0 * L + k2) * inv_n);
-            pm = cispi((4.0 * (64 - L) - k2) * inv_n);
-            st = cispi(256.0 * inv_n);
-        }
-        double4 f[18];
-        bool hv[18];
-#pragma unroll
-        for (int t = 0; t < 18; ++t) {
-            const bool plus = t < 9;
-            const int cabs = plus ? L + 64 * t : 64 * (t - 8) - L;        // |c|: + side idx, - side N - idx (t - 9 = j' = 31 - j)
-            const int m = plus ? 4 * cabs + k2 : 4 * cabs - k2;            // the order: k on the + side, n - k = 4 (N - idx) - k2 on the - side
-            hv[t] = cabs <= K && (plus || cabs >= 1) && m <= ml && m >= 0;
-            f[t] = *reinterpret_cast<const double4 *>(ph + (int64_t)(hv[t] ? m : 0) * estride);
-        }
-        phase_fence();
-#pragma unroll
-        for (int t = 0; t < 18; ++t) {
-            const bool plus = t < 9;
-            const int cabs = plus ? L + 64 * t : 64 * (t - 8) - L;
-            double2 fn = make_double2(f[t].x, f[t].y), fs = make_double2(f[t].z, f[t].w);
-            if (shifted) {
-                double2 &pc = plus ? pp : pm;
-                fn = cmul(fn, pc); fs = cmul(fs, pc);
-                if (t != 8 && t != 17) pc = cmul(pc, st);
-            }
-            const double2 cw = chirp[min(cabs, q - 1)];
-            double2 z;
-            z.x = hv[t] ? (plus ? fn.x - fs.y : fn.x + fs.y) : 0.0;
-            z.y = hv[t] ? (plus ? fn.y + fs.x : -fn.y + fs.x) : 0.0;
-            x[plus ? t : 40 - t] = cmul(z, cw);  // - side: j = 31 - (t - 9)
-        }
-#pragma unroll
-        for (int j = 9; j < 23; ++j) x[j] = make_double2(0., 0.);
-    }
-    // ---- forward transform, filter (frequency 32 (a' + 32 h) + b), inverse transform ---------------------------------------------------------
-    double2 u[32];
-    wave_fft_ab<true>(x, u, reg, L, F);
-    {
-        const double2 *fb = filt + 1024 * (L & 1) + (L >> 1);
-#pragma unroll
-        for (int a = 0; a < 32; ++a) u[kBrev5[a]] = cmul(u[kBrev5[a]], fb[32 * a]);
-    }
-    wave_fft_ba<false>(u, x, reg, L, F);  // x[kBrev5[j]] = pixel-side value of slot j1 = L + 64 j
-    // ---- chirp, twiddle e^{2 pi i j1 k2 / n}, radix-4 over k2: 512 columns at a time through the strips (double-buffered) ------------------------
-    __builtin_amdgcn_sched_barrier(0);
-    double *__restrict__ mp = map + (int64_t)comp * P.npix;
-    const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
-    double2 e1 = cispi(2.0 * tl * inv_n);
-    const double2 estep = F.ringc[4 * q + 1];  // e^{2 pi i 256 / n}
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        if (512 * c >= q) break;  // (wave-uniform: no column of this round is a pixel)
-        double2 *wb = reg + (c & 1) * 512 + L;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) wb[64 * jj] = x[kBrev5[8 * c + jj]];
-        __syncthreads();
-#pragma unroll
-        for (int uu = 0; uu < 2; ++uu) {
-            const int j1 = 512 * c + 256 * uu + tl;
-            const double2 *rb = lds + (c & 1) * 512 + uu * 256 + tl;
-            const double2 d0 = rb[0], d1 = rb[kWaveReg], d2 = rb[2 * kWaveReg], d3 = rb[3 * kWaveReg];
-            const double2 cw = chirp[min(j1, q - 1)];
-            if (j1 < q) {
-                const double2 e2 = cmul(e1, e1), e3 = cmul(e2, e1);
-                double2 y[4] = {cmul(d0, cw), cmul(d1, cmul(cw, e1)), cmul(d2, cmul(cw, e2)), cmul(d3, cmul(cw, e3))};
-                dft_small<4, false>(y);
-#pragma unroll
-                for (int j2 = 0; j2 < 4; ++j2) {
-                    if constexpr (WGT) {
-                        mp[on + j1 + q * j2] = y[j2].x * wgt[on + j1 + q * j2];
-                        if (os >= 0) mp[os + j1 + q * j2] = y[j2].y * wgt[os + j1 + q * j2];
-                    } else {
-                        mp[on + j1 + q * j2] = y[j2].x;
-                        if (os >= 0) mp[os + j1 + q * j2] = y[j2].y;
-                    }
-                }
-            }
-            e1 = cmul(e1, estep);
         }
     }
 }
@@ -2203,24 +1975,6 @@ static hipError_t launch_fast_class(const DevPlan &P, const DevFFT &F, int cls, 
                 wattr_a_done[dv] = true;
             }
             hipLaunchKernelGGL(k_map2phase_wave, dim3(n, ncomp), dim3(256), kWaveLds, st, P, F, pairs, mlim, ncomp, in, out);
-            return hipGetLastError();
-        }
-    }
-    if constexpr (N == kWaveN && BLUE) {
-        // Bluestein rings of convolution size N whose bands are narrow (K <= kWaveKmax for every ring of the list): wave transforms A -> B,
-        // filter, B -> A (k_phase2map_wave_blue); PLSHTS_DEBUG=1 PLSHTS_FFT_WAVE_BLUE=0: the one-group kernel
-        static const bool waveb = dbg_env_int("PLSHTS_FFT_WAVE_BLUE", 1) != 0;
-        if (synth && waveb && sd.cls_kmax[cls] <= kWaveKmax) {
-            static bool wattr_b_done[kMaxDevices] = {};
-            const int dv = current_device();
-            if (!wattr_b_done[dv]) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map_wave_blue<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kWaveLds);
-                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_phase2map_wave_blue<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kWaveLds);
-                if (e != hipSuccess) return e;
-                wattr_b_done[dv] = true;
-            }
-            if (wgt) hipLaunchKernelGGL((k_phase2map_wave_blue<true>), dim3(n, ncomp), dim3(256), kWaveLds, st, P, F, pairs, mlim, ncomp, in, out, wgt);
-            else hipLaunchKernelGGL((k_phase2map_wave_blue<false>), dim3(n, ncomp), dim3(256), kWaveLds, st, P, F, pairs, mlim, ncomp, in, out, wgt);
             return hipGetLastError();
         }
     }
