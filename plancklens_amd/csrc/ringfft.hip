@@ -804,6 +804,17 @@ __global__ __launch_bounds__(N / 8, 2) void k_phase2map_fast(DevPlan P, DevFFT F
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            // Round 5: a block of G slots that holds no in-band bin for any thread of the workgroup is skipped outright (a workgroup-uniform
+            // branch per j: no loads, no chirp, no selects).  With a band of K ~ 300-410 bins (the cap rings of nside 2048 at lmax = nside)
+            // only j = 0, 1 (orders +k) and j = 6, 7 (orders n - k) survive: 16 of the 32 loads of a thread.
+            const bool band_j = blue ? (G * j <= K || G * (j + 1) - 1 >= N - K)
+                                     : (4 * G * j <= ml || n - 4 * (G * (j + 1) - 1) - 3 <= ml);
+            if (!band_j) {
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) d[k2][j] = make_double2(0., 0.);
+                pj = cmul(pj, pstep);
+                continue;
+            }
             const FastBin b = fast_bin(blue, tl + G * j, N, q, K);
             double2 cw = make_double2(1., 0.);
             if (blue) cw = chirp[b.cabs];
