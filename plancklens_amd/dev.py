@@ -569,6 +569,15 @@ def gemv_split(amat, alms_hi, lmax_lo, fls_hi, dot=None):
     return outs
 
 
+def add_(y, x):
+    """y += x in place for two same-shape float64 / complex128 device tensors, one launch of pl_axpy (y = 1.0 x + y: exact); the running
+    sums of the mean-field loop -- the framework's element-wise complex128 add runs at a quarter of the streaming rate"""
+    assert y.shape == x.shape and y.dtype == x.dtype and y.is_contiguous() and x.is_contiguous() and y.dtype in (torch.float64, torch.complex128)
+    n = y.numel() * (2 if y.is_complex() else 1)
+    _lib.check(_lib.lib().pl_axpy(n, 1.0, x.data_ptr(), y.data_ptr(), y.data_ptr(), stream_ptr()))
+    return y
+
+
 def alm2cl(a, b=None):
     lmax = Alm.getlmax(a.numel())
     out = torch.empty(lmax + 1, dtype=torch.float64, device=a.device)

@@ -79,7 +79,12 @@ def mean_field(get_qlm, idxs, like, get_pair=None, collective=True):
     mine = shard(idxs) if collective else idxs
 
     def add(q):
-        acc.add_(q if isinstance(q, torch.Tensor) else torch.as_tensor(q).to(acc.device))
+        q = q if isinstance(q, torch.Tensor) else torch.as_tensor(q).to(acc.device)
+        if acc.is_cuda and q.is_cuda and q.dtype == acc.dtype and q.shape == acc.shape and q.is_contiguous() and acc.dtype in (torch.float64, torch.complex128):
+            from . import dev
+            dev.add_(acc, q)  # pl_axpy: one streaming pass
+        else:
+            acc.add_(q)
     n2 = len(mine) - len(mine) % 2 if get_pair is not None else 0
     for i in range(0, n2, 2):
         q0, q1 = get_pair(mine[i], mine[i + 1])
