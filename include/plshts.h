@@ -65,6 +65,9 @@ int pl_plan_destroy(pl_plan *plan);
 int64_t pl_plan_npix(const pl_plan *plan);
 int64_t pl_plan_nalm(const pl_plan *plan);
 int64_t pl_plan_bytes(const pl_plan *plan); /* device bytes held by the plan */
+/* The plan's i-th side stream (a hipStream_t; NULL when i is out of range): the streams the classes of a ring-FFT stage are spread over
+ * between a fork and a join on the caller's stream.  For tools that look at how streams fall onto the hardware queues. */
+void *pl_plan_side_stream(const pl_plan *plan, int i);
 
 /* One transform over several GPUs ("m-blocks shard across the GPUs", BASELINE.json north_star; the reference's only parallelism
  * inside a transform is the third-party library's threads, shts.py:10).  Shard `rank` of `nranks`:

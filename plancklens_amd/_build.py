@@ -5,7 +5,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 SOURCES = ['api.hip', 'legendre.hip', 'ringfft.hip', 'elementwise.hip', 'tables.cpp']
-HEADERS = ['device_plan.h', 'legendre_math.h', 'plshts_internal.h', 'ringfft.h', os.path.join('..', '..', 'include', 'plshts.h')]
+HEADERS = ['device_plan.h', 'legendre_math.h', 'plshts_internal.h', 'ringfft.h', 'tproj_device.h', os.path.join('..', '..', 'include', 'plshts.h')]
 LIBNAME = 'libplshts.so'
 
 

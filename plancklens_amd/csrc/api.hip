@@ -17,6 +17,8 @@
 namespace plshts {
 int rings_per_group(int spin, const DevPlan &P);
 void launch_prep0(const DevPlan &P, const double *alm, const double *fl, double *prep, hipStream_t st, int nb = 1);
+bool launch_prep0_lowrank(const DevPlan &P, const double *alm, const double *fl, double *prep, hipStream_t st, int nb, int nmodes, const double *pm,
+                          double *parts);
 void launch_preps(const DevPlan &P, const DevSpinTab &S, int spin, const double *alm, const double *fl, double *prep, hipStream_t st, bool gonly);
 void launch_synth0(const DevPlan &P, const double *prep, double *phase, hipStream_t st, int nb = 1);
 void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st, bool gonly, int nb = 1);
@@ -572,6 +574,7 @@ int pl_profile_read(pl_plan *p, double *ms_sum, int64_t *counts)
 int64_t pl_plan_npix(const pl_plan *p) { return p ? p->P.npix : 0; }
 int64_t pl_plan_nalm(const pl_plan *p) { return p ? p->P.nalm : 0; }
 int64_t pl_plan_bytes(const pl_plan *p) { return p ? p->bytes : 0; }
+void *pl_plan_side_stream(const pl_plan *p, int i) { return (p && p->fs.ok && i >= 0 && i < FftStreams::kN) ? (void *)p->fs.s[i] : nullptr; }
 
 int64_t pl_plan_phase_doubles(const pl_plan *p, int spin)
 {
@@ -579,13 +582,18 @@ int64_t pl_plan_phase_doubles(const pl_plan *p, int spin)
     return (int64_t)p->P.npairs * p->P.mstride * 4 * ncomp_of(spin);
 }
 
-static int legendre_synth_impl(pl_plan *p, int spin, const double *alm, const double *fl, double *phase, void *stream, bool gonly, int nb = 1)
+// lr_* (spin 0): the coefficient pass of a low-rank update on the same input (c = lr_pm alm, partial sums into lr_parts) asked to ride in the
+// prologue launch; *lr_done tells whether it did (coarse grids) -- if not the caller launches it
+static int legendre_synth_impl(pl_plan *p, int spin, const double *alm, const double *fl, double *phase, void *stream, bool gonly, int nb = 1,
+                               int lr_nmodes = 0, const double *lr_pm = nullptr, double *lr_parts = nullptr, bool *lr_done = nullptr)
 {
     if (!p) return fail("null plan");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (spin == 0) {  // nb > 1: nb consecutive alm arrays -> phase array of nb components (spin 0 only)
         if (grow(p, &p->prep, &p->prep_cap, p->P.nent0 * 4 * nb)) return 1;
-        launch_prep0(p->P, alm, fl, p->prep, st, nb);
+        const bool fused = lr_done && lr_nmodes > 0 && launch_prep0_lowrank(p->P, alm, fl, p->prep, st, nb, lr_nmodes, lr_pm, lr_parts);
+        if (lr_done) *lr_done = fused;
+        if (!fused) launch_prep0(p->P, alm, fl, p->prep, st, nb);
         { ProfScope ps(p, PK_LEG_SYNTH0, st); launch_synth0(p->P, p->prep, phase, st, nb); }
     } else {
         if (ensure_spin(p, spin)) return 1;
@@ -1013,6 +1021,21 @@ static bool cg_roundtrip_enabled()
     return on;
 }
 
+// (PLSHTS_DEBUG=1 PLSHTS_LR_PROLOGUE=0: the coefficient pass of a low-rank update always as its own launch on a side stream, tests)
+static bool lr_prologue_enabled()
+{
+    static const bool on = dbg_env_int("PLSHTS_LR_PROLOGUE", 1) != 0;
+    return on;
+}
+// launch shape of the coefficient pass (elementwise.hip / tproj_device.h: 1024-thread workgroups on fine grids, 256-thread ones below)
+static void tproj_coeffs_shape_host(int64_t n, int *nt, int *nparts)
+{
+    int np = 0, ps = 0;
+    tproj_parts_layout(n, &np, &ps);
+    *nparts = np;
+    *nt = n >= (int64_t)ps * 4096 ? 1024 : 256;
+}
+
 struct LowRank { int nmodes = 0; const double *pm = nullptr, *rm = nullptr; double *scratch = nullptr; };
 
 static int cg_fwd_tt_impl(pl_plan *p, int nb, const double *alm_in, const double *fl_in, const double *n_inv, int nmodes, const double *pmat,
@@ -1045,7 +1068,11 @@ static int cg_fwd_tt_impl(pl_plan *p, int nb, const double *alm_in, const double
         bool *forked; hipStream_t st; hipEvent_t ev;
         ~JoinGuard() { if (*forked) (void)hipStreamWaitEvent(st, ev, 0); }
     } join_guard{&lr_forked, st, p->fs.join[FftStreams::kN - 1]};
-    if (lr && lr->nmodes > 0) {
+    // (coarse grids: the pass rides in the prologue launch of the synthesis instead -- no fork, the replayed solve stays one chain of kernels)
+    int lr_nt = 0, lr_np = 0;
+    tproj_coeffs_shape_host(2 * P.nalm, &lr_nt, &lr_np);
+    const bool lr_in_prologue = lr && lr->nmodes > 0 && lr_nt == 256 && lr_prologue_enabled();
+    if (lr && lr->nmodes > 0 && !lr_in_prologue) {
         hipStream_t side = p->fs.ok ? p->fs.s[FftStreams::kN - 1] : nullptr;
         if (side && hipEventRecord(p->fs.fork, st) == hipSuccess && hipStreamWaitEvent(side, p->fs.fork, 0) == hipSuccess) {
             launch_template_project(2 * P.nalm, lr->nmodes, const_cast<double *>(alm_in), nullptr, lr->pm, lr->rm, lr->scratch, side, nb, alm_out, 1);
@@ -1056,7 +1083,14 @@ static int cg_fwd_tt_impl(pl_plan *p, int nb, const double *alm_in, const double
         }
         HIPCHK(hipGetLastError());
     }
-    if (legendre_synth_impl(p, 0, alm_in, fl_in, p->phase, stream, false, nb)) return 1;
+    if (lr_in_prologue) {
+        bool done = false;
+        if (legendre_synth_impl(p, 0, alm_in, fl_in, p->phase, stream, false, nb, lr->nmodes, lr->pm, lr->scratch, &done)) return 1;
+        if (!done) {  // (cannot happen while the two shape rules agree; kept correct anyway)
+            launch_template_project(2 * P.nalm, lr->nmodes, const_cast<double *>(alm_in), nullptr, lr->pm, lr->rm, lr->scratch, st, nb, alm_out, 1);
+            HIPCHK(hipGetLastError());
+        }
+    } else if (legendre_synth_impl(p, 0, alm_in, fl_in, p->phase, stream, false, nb)) return 1;
     // the weighting always rides in the synthesis-side FFT kernels; the projection too where every ring runs in the generic kernel
     const bool fused = nmodes == 0 || (!pinv_md && fft_all_generic(P, p->F) && nmodes <= kFuseModes);
     NinvProj W;

@@ -7,6 +7,7 @@
 #include <cstdint>
 
 #include "device_plan.h"
+#include "tproj_device.h"
 
 namespace plshts {
 
@@ -409,61 +410,17 @@ __global__ __launch_bounds__(kDotThreads) void k_cg_axpy_pre(CgFused f, int npre
 // t <- N^-1 t - N^-1 P (P^t N^-1 P)^-1 P^t N^-1 t with P (nmodes x n) and R = (P^t N^-1 P)^-1 (P . N^-1) (nmodes x n) given:
 //   pass 1: t <- n_inv t and the per-workgroup partial sums of c_k = sum_i P_ki t_i;  pass 2: t_i -= sum_k R_ki c_k.
 // The partial sums are added in index order by every workgroup of pass 2: bit-reproducible, no atomics.
-constexpr int kProjParts = 256, kProjMaxModes = 16;
-constexpr int kFuseModesB = 4;  // block-vector kernels below: monopole + dipole (more modes: one launch set per map)
+// (kProjParts, kProjMaxModes, kFuseModesB, kProjChunk and the workgroup bodies of the coefficient pass: tproj_device.h)
 // NT threads per workgroup, gridDim.x = nparts <= kProjParts workgroups: one partial sum per workgroup and mode.  Small maps (the
 // coarse multigrid levels, where this pair of kernels runs dozens of times per CG iteration) take fewer, smaller workgroups:
 // the work is a few microseconds and the cost is the launch and the reduction tail.
 // Block vectors: up to kProjChunk maps per workgroup pass -- the template rows (shared by the batch) are read once for all of them.
 // Every map's sums are formed exactly as the one-map kernel forms them (same pixels per thread, same order): bit-identical.
-constexpr int kProjChunk = 4;
 template <int NT>
 __global__ __launch_bounds__(NT) void k_tproj_coeffs_b(int64_t n, int nmodes, int nb, double *__restrict__ t_, const double *__restrict__ n_inv,
                                                        const double *__restrict__ pm, double *__restrict__ parts_)
 {
-    __shared__ double red[kProjChunk][kFuseModesB][NT / 64];
-    const int b0 = blockIdx.y * kProjChunk, nbc = min(kProjChunk, nb - b0);
-    double acc[kProjChunk][kFuseModesB];
-#pragma unroll
-    for (int b = 0; b < kProjChunk; ++b)
-#pragma unroll
-        for (int k = 0; k < kFuseModesB; ++k) acc[b][k] = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
-        double p[kFuseModesB];
-#pragma unroll
-        for (int k = 0; k < kFuseModesB; ++k) p[k] = k < nmodes ? pm[(int64_t)k * n + i] : 0.0;
-        const double w = n_inv ? n_inv[i] : 1.0;
-#pragma unroll
-        for (int b = 0; b < kProjChunk; ++b) {
-            if (b < nbc) {
-                double *tb = t_ + (int64_t)(b0 + b) * n;
-                double u = tb[i];
-                if (n_inv) { u *= w; tb[i] = u; }
-#pragma unroll
-                for (int k = 0; k < kFuseModesB; ++k)
-                    if (k < nmodes) acc[b][k] = fma(p[k], u, acc[b][k]);
-            }
-        }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int b = 0; b < kProjChunk; ++b)
-#pragma unroll
-        for (int k = 0; k < kFuseModesB; ++k) {
-            if (b < nbc && k < nmodes) {  // wave-uniform
-                double v = acc[b][k];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-                if (lane == 0) red[b][k][wave] = v;
-            }
-        }
-    __syncthreads();
-    if ((int)threadIdx.x < nmodes * nbc) {
-        const int b = threadIdx.x / nmodes, k = threadIdx.x % nmodes;
-        double v = 0.0;
-        for (int w = 0; w < NT / 64; ++w) v += red[b][k][w];
-        parts_[(int64_t)(b0 + b) * (kProjMaxModes * kProjParts) + k * kProjParts + blockIdx.x] = v;
-    }
+    tproj_coeffs_b_wg<NT>(n, nmodes, nb, t_, n_inv, pm, parts_, blockIdx.x, gridDim.x, blockIdx.y);
 }
 __global__ __launch_bounds__(256) void k_tproj_apply_b(int64_t n, int nmodes, int nparts, int nb, double *__restrict__ t_, const double *__restrict__ rm,
                                                        const double *__restrict__ parts_)
@@ -503,35 +460,8 @@ template <int NT>
 __global__ __launch_bounds__(NT) void k_tproj_coeffs(int64_t n, int nmodes, double *__restrict__ t_, const double *__restrict__ n_inv,
                                                      const double *__restrict__ pm, double *__restrict__ parts_)
 {
-    double *__restrict__ t = t_ + blockIdx.y * n;  // batch entry blockIdx.y: its own map and partial sums, shared n_inv and modes
-    double *__restrict__ parts = parts_ + blockIdx.y * (kProjMaxModes * kProjParts);
-    __shared__ double red[kProjMaxModes][NT / 64];
-    double acc[kProjMaxModes];
-#pragma unroll
-    for (int k = 0; k < kProjMaxModes; ++k) acc[k] = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
-        double u = t[i];
-        if (n_inv) { u *= n_inv[i]; t[i] = u; }  // n_inv null: t arrives weighted (the ring-FFT kernels did it), nothing to store
-#pragma unroll
-        for (int k = 0; k < kProjMaxModes; ++k)
-            if (k < nmodes) acc[k] = fma(pm[(int64_t)k * n + i], u, acc[k]);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < kProjMaxModes; ++k) {
-        if (k < nmodes) {  // wave-uniform
-            double v = acc[k];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0) red[k][wave] = v;
-        }
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < nmodes) {
-        double v = 0.0;
-        for (int w = 0; w < NT / 64; ++w) v += red[threadIdx.x][w];
-        parts[threadIdx.x * kProjParts + blockIdx.x] = v;
-    }
+    // batch entry blockIdx.y: its own map and partial sums, shared n_inv and modes
+    tproj_coeffs_wg<NT>(n, nmodes, t_ + blockIdx.y * n, n_inv, pm, parts_ + blockIdx.y * (kProjMaxModes * kProjParts), blockIdx.x, gridDim.x);
 }
 // c_k = sum of the nparts partial sums of mode k, by one wavefront per mode in a fixed order (lane j takes parts j, j + 64, ...,
 // then a fixed shuffle tree): one barrier instead of a shared-memory tree per mode

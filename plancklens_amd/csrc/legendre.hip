@@ -23,6 +23,7 @@
 #include "device_plan.h"
 #include "plshts_internal.h"
 #include "legendre_math.h"
+#include "tproj_device.h"
 
 
 namespace plshts {
@@ -98,7 +99,7 @@ struct StreamPrefetch {
 // alm -> recursion-basis coefficients (fused hp.almxfl)
 // -----------------------------------------------------------------------------------------------------
 // spin 0: prep[e] = {c_re, c_im, d_re, d_im}
-__global__ void k_prep0(DevPlan P, const double2 *__restrict__ alm_, const double *__restrict__ fl, double4 *__restrict__ prep_)
+__device__ __forceinline__ void prep0_wg(const DevPlan &P, const double2 *__restrict__ alm_, const double *__restrict__ fl, double4 *__restrict__ prep_)
 {
     const double2 *__restrict__ alm = alm_ + (int64_t)blockIdx.z * P.nalm;
     double4 *__restrict__ prep = prep_ + (int64_t)blockIdx.z * P.nent0;
@@ -124,6 +125,31 @@ __global__ void k_prep0(DevPlan P, const double2 *__restrict__ alm_, const doubl
         o.z = al * a1.x;
         o.w = al * a1.y;
         prep[e] = o;
+    }
+}
+__global__ void k_prep0(DevPlan P, const double2 *__restrict__ alm_, const double *__restrict__ fl, double4 *__restrict__ prep_)
+{
+    prep0_wg(P, alm_, fl, prep_);
+}
+// The same launch with the coefficient pass of a low-rank update on the SAME input riding along (the temperature CG operator with its template
+// projection in harmonic space, pl_cg_fwd_tt_lr_b: c = pm alm_in reads the input only): workgroups y <= mmax are k_prep0's, the workgroups
+// behind them are those of k_tproj_coeffs<256> / k_tproj_coeffs_b<256> on the 2 nalm doubles of the input (tproj_device.h: identical partial sums).
+// On the coarse multigrid levels this replaces a forked side-stream launch: the replayed solve stays one chain of kernels on one hardware queue.
+struct PrepLowRank { int nmodes, nparts, nb; const double *pm; double *parts; };
+template <bool BATCH>
+__global__ __launch_bounds__(256) void k_prep0_lr(DevPlan P, const double2 *__restrict__ alm_, const double *__restrict__ fl, double4 *__restrict__ prep_,
+                                                  PrepLowRank L)
+{
+    if ((int)blockIdx.y <= P.mmax) { prep0_wg(P, alm_, fl, prep_); return; }
+    const int part = ((int)blockIdx.y - (P.mmax + 1)) * (int)gridDim.x + (int)blockIdx.x;
+    if (part >= L.nparts) return;
+    double *t = const_cast<double *>(reinterpret_cast<const double *>(alm_));  // (read only: n_inv null)
+    if constexpr (BATCH) {
+        if ((int)blockIdx.z * kProjChunk >= L.nb) return;
+        tproj_coeffs_b_wg<256>(2 * P.nalm, L.nmodes, L.nb, t, nullptr, L.pm, L.parts, part, L.nparts, blockIdx.z);
+    } else {
+        tproj_coeffs_wg<256>(2 * P.nalm, L.nmodes, t + (int64_t)blockIdx.z * 2 * P.nalm, nullptr, L.pm,
+                             L.parts + (int64_t)blockIdx.z * (kProjMaxModes * kProjParts), part, L.nparts);
     }
 }
 
@@ -1369,6 +1395,23 @@ void launch_prep0(const DevPlan &P, const double *alm, const double *fl, double 
     dim3 grid(4, P.mmax + 1, nb);
     hipLaunchKernelGGL(k_prep0, grid, dim3(256), 0, st, P, reinterpret_cast<const double2 *>(alm), fl,
                        reinterpret_cast<double4 *>(prep));
+}
+
+// launch_prep0 + the coefficient pass c = pm x of launch_template_project(2 nalm, nmodes, alm, null, pm, ., parts, ., nb, ., phase 1) in one launch;
+// false (nothing launched) where that pass would not run in 256-thread workgroups (fine grids): the caller launches the two separately
+bool launch_prep0_lowrank(const DevPlan &P, const double *alm, const double *fl, double *prep, hipStream_t st, int nb, int nmodes, const double *pm,
+                          double *parts)
+{
+    int nt = 0, nparts = 0;
+    tproj_coeffs_shape(2 * P.nalm, &nt, &nparts);
+    if (nt != 256 || nmodes < 1 || nmodes > kProjMaxModes) return false;
+    PrepLowRank L = {nmodes, nparts, nb, pm, parts};
+    dim3 grid(4, P.mmax + 1 + (nparts + 3) / 4, nb);
+    if (nb > 1 && nmodes <= kFuseModesB)
+        hipLaunchKernelGGL(k_prep0_lr<true>, grid, dim3(256), 0, st, P, reinterpret_cast<const double2 *>(alm), fl, reinterpret_cast<double4 *>(prep), L);
+    else
+        hipLaunchKernelGGL(k_prep0_lr<false>, grid, dim3(256), 0, st, P, reinterpret_cast<const double2 *>(alm), fl, reinterpret_cast<double4 *>(prep), L);
+    return true;
 }
 
 // gradient and curl coefficients as two arrays (almC null: gradient only)

@@ -33,12 +33,79 @@ def to_dev(x, dtype=None):
 
 _PINNED_FREE = {}
 _COPY_STREAMS = {}
+_SPIN = {}
+
+
+def streams_overlap(a, b):
+    """True when kernels launched on streams a and b run at the same time.  The HIP runtime spreads its streams over a few hardware
+    queues (four by default); two streams that fell onto one queue run their kernels one after the other however independent they are.
+    Measured, not assumed: one spin kernel alone on a, then one on each stream started together -- the pair takes as long as one
+    kernel (different queues) or as two (same queue).  Synchronises the device: set-up time only, never during a graph capture."""
+    if a.cuda_stream == b.cuda_stream:
+        return False
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    done = torch.cuda.Event()
+    d = torch.cuda.current_device()
+
+    def alone(cycles):
+        torch.cuda.synchronize()
+        with torch.cuda.stream(a):
+            ev[0].record()
+            torch.cuda._sleep(cycles)
+            ev[1].record()
+        torch.cuda.synchronize()
+        return ev[0].elapsed_time(ev[1])
+    if d not in _SPIN:  # a spin of ~1 ms: long against launch latencies and event granularity
+        cycles = 1 << 18
+        alone(cycles)  # (first launch of the spin kernel: not timed)
+        for _ in range(10):
+            if alone(cycles) >= 0.8:
+                break
+            cycles *= 2
+        _SPIN[d] = cycles
+    cycles = _SPIN[d]
+    t1 = min(alone(cycles), alone(cycles))
+    with torch.cuda.stream(a):
+        ev[2].record()
+    b.wait_event(ev[2])
+    with torch.cuda.stream(b):
+        torch.cuda._sleep(cycles)
+        done.record()
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(cycles)
+        a.wait_event(done)
+        ev[3].record()
+    torch.cuda.synchronize()
+    return ev[2].elapsed_time(ev[3]) < 1.5 * t1
+
+
+def concurrent_stream(beside=(), tries=8):
+    """A torch stream whose kernels overlap those of every stream in `beside` (default: the current stream): up to `tries` streams of
+    torch's pool are tried (streams_overlap); the first one if none qualifies -- a stream that does not overlap is still correct."""
+    beside = list(beside) or [torch.cuda.current_stream()]
+    first = None
+    dbg = os.environ.get('PLENS_STREAM_DEBUG')
+    for i in range(tries):
+        s = torch.cuda.Stream()
+        first = first or s
+        try:
+            if all(streams_overlap(o, s) for o in beside):
+                if dbg:
+                    print('concurrent_stream: candidate %d overlaps' % i, flush=True)
+                return s
+        except RuntimeError as e:  # (e.g. called while a capture is under way: no probing then)
+            if dbg:
+                print('concurrent_stream: probe failed: %r' % (e,), flush=True)
+            break
+    if dbg:
+        print('concurrent_stream: none of %d candidates overlaps' % tries, flush=True)
+    return first
 
 
 def _copy_stream():
     d = torch.cuda.current_device()
     if d not in _COPY_STREAMS:
-        _COPY_STREAMS[d] = torch.cuda.Stream()
+        _COPY_STREAMS[d] = concurrent_stream() if not torch.cuda.is_current_stream_capturing() else torch.cuda.Stream()
     return _COPY_STREAMS[d]
 
 

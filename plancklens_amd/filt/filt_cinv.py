@@ -48,10 +48,11 @@ _TP_SIDE_STREAMS = {}
 
 
 def _tp_side_stream():
-    """the stream of the polarization solve, one per device"""
+    """the stream of the polarization solve, one per device: one whose kernels do run beside those of the caller's stream
+    (dev.concurrent_stream: two streams that the runtime put on one hardware queue would run the two solves one after the other)"""
     d = torch.cuda.current_device()
     if d not in _TP_SIDE_STREAMS:
-        _TP_SIDE_STREAMS[d] = torch.cuda.Stream()
+        _TP_SIDE_STREAMS[d] = dev.concurrent_stream()
     return _TP_SIDE_STREAMS[d]
 
 

@@ -358,3 +358,22 @@ def test_ring_roundtrip_kernel_is_bit_identical_to_the_two_launches():
         assert out.returncode == 0, out.stderr[-2000:]
         sums.append(out.stdout.strip().splitlines()[-1])
     assert len(sums[0]) == 64 and sums[0] == sums[1]
+
+
+def test_lowrank_coefficient_pass_in_the_prologue_launch_is_bit_identical_to_its_own_launch():
+    """pl_cg_fwd_tt_lr_b on coarse grids: the coefficient pass c = hpm x of the low-rank template update rides in extra workgroups of the
+    synthesis prologue (k_prep0_lr) instead of a forked side-stream launch (k_tproj_coeffs).  Same workgroup bodies (tproj_device.h), so the
+    operators (monopole + dipole marginalised; single vectors and blocks of 2 ... 4) must agree bit for bit: two child processes (the switch
+    is read once per process, under PLSHTS_DEBUG) print a checksum of their results."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sums = []
+    for v in ('0', '1'):
+        env = dict(os.environ, PLSHTS_DEBUG='1', PLSHTS_LR_PROLOGUE=v)
+        out = subprocess.run([sys.executable, os.path.join(root, 'tests', 'workers', 'roundtrip_check.py')], cwd=root, env=env,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        sums.append(out.stdout.strip().splitlines()[-1])
+    assert len(sums[0]) == 64 and sums[0] == sums[1]

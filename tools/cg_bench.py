@@ -67,6 +67,8 @@ def _run(nside, lmax, iters, kinds, joint, verbose, peak_tflops, batches=()):
     import torch
     from plancklens_amd import dev, hp, shts, utils
     from plancklens_amd.filt import filt_cinv
+    if os.environ.get('CG_BENCH_PLAN_OPTS'):  # development aid: pl_plan_opts for every plan of the run, e.g. fft_generic_nside=0
+        shts.plan_options(**{kv.split('=')[0]: int(kv.split('=')[1]) for kv in os.environ['CG_BENCH_PLAN_OPTS'].split(',')}).__enter__()
     rng = np.random.default_rng(7)
     npix = hp.nside2npix(nside)
     cl = utils.camb_clfile(os.path.join(ROOT, 'plancklens_amd', 'data', 'cls', 'FFP10_wdipole_lensedCls.dat'), lmax=lmax)
@@ -188,6 +190,13 @@ def _run(nside, lmax, iters, kinds, joint, verbose, peak_tflops, batches=()):
                                     'speedup_vs_one_after_the_other': (res['t']['seconds'] + res['p']['seconds']) / dtc}
             if nside == 2048 and lmax == 2048:
                 res['tp_concurrent']['frac_of_fp64_floor'] = (FLOP_PER_ITER_2048['t'] + FLOP_PER_ITER_2048['p']) / peak_tflops / 1e12 / (dtc / iters)
+            # the two solves' streams on different hardware queues (measured: dev.streams_overlap)?  On one queue they run one after the other
+            res['tp_concurrent']['streams_overlap'] = bool(dev.streams_overlap(torch.cuda.current_stream(), filt_cinv._tp_side_stream()))
+            if os.environ.get('CG_BENCH_QUEUE_DIAG'):  # which streams run beside which, here and now (stderr)
+                names = ['current', 'tp_side'] + ['new%d' % i for i in range(8)]
+                strs = [torch.cuda.current_stream(), filt_cinv._tp_side_stream()] + [torch.cuda.Stream() for _ in range(8)]
+                for i in range(len(strs)):
+                    sys.stderr.write('%-8s %s\n' % (names[i], ' '.join('.' if j == i else ('1' if dev.streams_overlap(strs[i], strs[j]) else '0') for j in range(len(strs)))))
             # block solves of B simulations, T block and P block at the same time (what filter_sims runs with its default batch)
             for B in batches:
                 if B < 4:  # (B = 2 adds little to the picture and 8 s to the run)

@@ -7,7 +7,7 @@ cd "$GRAFT_REPO_ROOT"
 IT=${1:-12}
 TAG=${2:-tp_overlap}
 rm -rf gpurun_out/$TAG
-CG_BENCH_REPS=1 CG_BENCH_BATCHES= rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$TAG -o t -- python3 tools/cg_bench.py 2048 2048 $IT > gpurun_out/$TAG.log 2>&1
+CG_BENCH_REPS=1 CG_BENCH_BATCHES=${BATCHES-} rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$TAG -o t -- python3 tools/cg_bench.py 2048 2048 $IT > gpurun_out/$TAG.log 2>&1
 python3 - "$TAG" <<'PY'
 import csv, glob, json, sys, collections
 tag = sys.argv[1]
