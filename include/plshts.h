@@ -58,6 +58,11 @@ typedef struct pl_plan_opts {
     int fft_generic_nside; /* grids up to this nside run every ring in the generic kernel: one launch per stage instead of a dozen
                           latency-bound class kernels on side streams (default 512: measured 1.2-4x faster stages at nside 256 / 512,
                           1.5-2x slower at 1024); 0: never */
+    int seed_tables;   /* 1 (default): the plan keeps, per kernel family, the Legendre recursion state of every (m, ring pair) at the step
+                          where the family's kernels would stop recursing without accumulating (no ring of the wavefront has reached the
+                          activation threshold yet: ~10 % of all recursion steps, at the latency of their dependent FMA chains), made once
+                          by the same arithmetic -- transforms start from it, results bit-identical; ~40 B per (m, ring pair) and spin
+                          (1.2 GB at nside = lmax = 2048 with spins 0-3).  0: none, every launch recurses from l = m */
 } pl_plan_opts;
 /* pl_plan_create (rank 0 of 1) / pl_plan_create_shard with options; opts NULL = defaults. */
 int pl_plan_create_opts(int nside, int lmax, int rank, int nranks, const pl_plan_opts *opts, pl_plan **plan);

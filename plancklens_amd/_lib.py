@@ -24,7 +24,7 @@ PL_HOST, PL_DEVICE = 0, 1
 class PlanOpts(ctypes.Structure):
     """pl_plan_opts of include/plshts.h (-1: the library's default)"""
     _fields_ = [('fft_legacy', ctypes.c_int), ('fft_split_min', ctypes.c_int), ('fft_nyq_min', ctypes.c_int), ('fft_min_fast', ctypes.c_int),
-                ('fft_generic_nside', ctypes.c_int)]
+                ('fft_generic_nside', ctypes.c_int), ('seed_tables', ctypes.c_int)]
 
 
 class PlshtsError(AssertionError):

@@ -17,6 +17,8 @@
 namespace plshts {
 int rings_per_group(int spin, const DevPlan &P);
 void launch_prep0(const DevPlan &P, const double *alm, const double *fl, double *prep, hipStream_t st, int nb = 1);
+int seed_family_rg(const DevPlan &P, int spin, int fam);
+bool launch_seed_gen(const DevPlan &P, const DevSpinTab *S, int spin, int fam, int rg, int *il, double *st, int *sc, hipStream_t s);
 bool launch_prep0_lowrank(const DevPlan &P, const double *alm, const double *fl, double *prep, hipStream_t st, int nb, int nmodes, const double *pm,
                           double *parts);
 void launch_preps(const DevPlan &P, const DevSpinTab &S, int spin, const double *alm, const double *fl, double *prep, hipStream_t st, bool gonly);
@@ -105,6 +107,7 @@ struct pl_plan {
     bool have_spin[kMaxSpin + 1] = {false, false, false, false};
     int64_t nent[kMaxSpin + 1] = {0, 0, 0, 0};
     std::vector<void *> allocs;
+    bool seed_tables = true;    // pl_plan_opts.seed_tables
     pl_plan *parent = nullptr;  // forked plan: geometry / recursion / FFT tables belong to (and are freed by) the parent
     int64_t bytes = 0;
     // workspaces (grown on demand)
@@ -177,6 +180,39 @@ static int grow(pl_plan *p, double **buf, int64_t *cap, int64_t ndoubles)
 // the tables of that spin, a few times per process).
 static std::recursive_mutex g_spin_mutex;
 
+// The seed tables of one spin (device_plan.h DevSeedTab; both kernel families), built on the device by the families' own phase A.
+// A failed allocation leaves the plan without that table (the kernels then recurse from l = m): never an error.
+static void build_seed_tables(pl_plan *p, int spin)
+{
+    if (!p->seed_tables || p->parent) return;
+    const DevPlan &P = p->P;
+    for (int fam = 0; fam < 2; ++fam) {
+        DevSeedTab &T = spin == 0 ? (fam == 0 ? p->P.seed_syn0 : p->P.seed_ana0) : (fam == 0 ? p->S[spin].seed_syn : p->S[spin].seed_ana);
+        T = DevSeedTab{};
+        const int rg = seed_family_rg(P, spin, fam);
+        const int ngroups = (P.npairs + rg - 1) / rg, npad = ngroups * rg, w = spin == 0 ? 1 : 2;
+        const size_t n_il = (size_t)(P.mmax + 1) * ngroups, n_e = (size_t)(P.mmax + 1) * npad;
+        int *il = nullptr, *sc = nullptr;
+        double *st = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&il), n_il * sizeof(int)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&st), n_e * 2 * w * sizeof(double)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&sc), n_e * w * sizeof(int)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (il) (void)hipFree(il);
+            if (st) (void)hipFree(st);
+            if (sc) (void)hipFree(sc);
+            continue;
+        }
+        const DevPlan Pc = p->P;  // (by value: the table under construction is not part of what the generator reads)
+        const bool ok = launch_seed_gen(Pc, spin == 0 ? nullptr : &p->S[spin], spin, fam, rg, il, st, sc, nullptr) && hipGetLastError() == hipSuccess &&
+                        hipDeviceSynchronize() == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); (void)hipFree(il); (void)hipFree(st); (void)hipFree(sc); continue; }
+        p->allocs.push_back(il); p->allocs.push_back(st); p->allocs.push_back(sc);
+        p->bytes += (int64_t)(n_il * sizeof(int) + n_e * 2 * w * sizeof(double) + n_e * w * sizeof(int));
+        T.il = il; T.st = st; T.sc = sc; T.rg = rg; T.npad = npad;
+    }
+}
+
 static int ensure_spin_locked(pl_plan *p, int spin);
 
 static int ensure_spin(pl_plan *p, int spin)
@@ -216,6 +252,7 @@ static int ensure_spin_locked(pl_plan *p, int spin)
     if (upload(p, mlim, &S.mlim)) return 1;
     S.gstart = nullptr;
     p->nent[spin] = t.off.back();
+    build_seed_tables(p, spin);
     p->have_spin[spin] = true;
     return 0;
 }
@@ -266,7 +303,7 @@ static int plan_create_impl(int nside, int lmax, int rank, int nranks, const pl_
     *out = nullptr;
     if (nside < 1 || nside > 8192) return fail("nside out of range [1, 8192]");
     if (lmax < 0 || lmax > 4 * nside) return fail("lmax out of range [0, 4 nside]");
-    pl_plan_opts opts = {0, -1, -1, -1, -1};
+    pl_plan_opts opts = {0, -1, -1, -1, -1, -1};
     if (opts_in) opts = *opts_in;
     pl_plan *p = nullptr;
     try {
@@ -443,6 +480,8 @@ static int plan_create_body(int nside, int lmax, int rank, int nranks, const pl_
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = fft_streams_create(p->fs);
     if (e != hipSuccess) { pl_plan_destroy(p); p = nullptr; return fail(std::string("FFT table setup: ") + hipGetErrorString(e)); }
+    p->seed_tables = opts.seed_tables != 0;
+    build_seed_tables(p, 0);
     *out = p;
     return 0;
 }

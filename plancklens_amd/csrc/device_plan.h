@@ -4,6 +4,18 @@
 
 namespace plshts {
 
+// Recursion state of every (m, ring pair) at the step where phase A (recursion only: no ring of the wave counts yet, legendre_math.h) of
+// its wave ends, made once per plan by the same arithmetic (legendre.hip: k_seed_gen0 / k_seed_gens) for one kernel family: a grouping of
+// `rg` ring pairs per wave, an activation threshold and a check interval.  A Legendre kernel whose grouping matches starts from the table
+// (bit-identical state) instead of recursing from l = m: phase A is ~10 % of all recursion steps and runs at the latency of its dependent
+// FMA chains.  rg = 0: no table.
+struct DevSeedTab {
+    const int *il;      // [mmax + 1][ngroups]: first recursion step of (m, ring group) that is not skipped (a multiple of the check interval)
+    const double *st;   // [mmax + 1][npad][2] (spin 0: p0, p1) or [mmax + 1][npad][4] (spin s: n0, n1, p0, p1)
+    const int *sc;      // [mmax + 1][npad] (spin 0) or [mmax + 1][npad][2] (spin s: scn, scp)
+    int rg, npad;       // npad = ngroups * rg
+};
+
 struct DevSpinTab {
     const int64_t *off;      // [mmax + 2]
     const double *ab;        // 2 per entry
@@ -12,6 +24,7 @@ struct DevSpinTab {
     const int *psin, *phalf, *usecos_n, *usecos_p;
     const int *mlim;         // [npairs]
     const int *gstart;       // [nmgroups] first ring group with any active ring, per group size (see api)
+    DevSeedTab seed_syn, seed_ana;  // synthesis / analysis kernel family of this spin
 };
 
 // Scalar products formed by the post-processing kernel of an analysis (k_post0 / k_posts) on its way out: with q the alm it writes (nf = 1: spin 0;
@@ -43,6 +56,7 @@ struct DevPlan {
     // m-block shard (pl_plan_create_shard): the Legendre launches of this plan cover the m-groups mg0, mg0 + mgstride, ... only
     // (an m-group = 4 consecutive orders, the unit of a workgroup); 0 / 1 on an ordinary plan
     int mg0, mgstride;
+    DevSeedTab seed_syn0, seed_ana0;  // spin-0 synthesis / analysis kernel family
 };
 
 }  // namespace plshts

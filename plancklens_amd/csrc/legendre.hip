@@ -184,6 +184,124 @@ __global__ void k_preps(DevPlan P, DevSpinTab S, int spin, const double2 *__rest
 }
 
 // -----------------------------------------------------------------------------------------------------
+// seed tables (device_plan.h DevSeedTab): phase A of a kernel family run once per plan
+// -----------------------------------------------------------------------------------------------------
+// One wave = (m, ring group of 64 R pairs) as in the Legendre kernels; the loop below is their phase A -- the same steps on the same
+// coefficients in the same order, so the stored state is the state they would have computed -- with the family's activation threshold
+// `thr` and check interval `gran` (8: the synthesis kernels' blocks; 16: the analysis kernels' tiles, two blocks each).
+template <int R>
+__global__ __launch_bounds__(256) void k_seed_gen0(DevPlan P, double thr, int gran, int *__restrict__ il_out, double2 *__restrict__ st_out,
+                                                   int *__restrict__ sc_out)
+{
+    constexpr int RG = 64 * R;
+    const int wave = wave_id(), lane = threadIdx.x & 63;
+    const int ngroups = (P.npairs + RG - 1) / RG;
+    const int g = blockIdx.x % ngroups, m = 4 * (blockIdx.x / ngroups) + wave;
+    if (m > P.mmax) return;
+    Rec0 r[R];
+    const double seed = P.seed0[m];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int ip = g * RG + k * 64 + lane;
+        const int ipc = min(ip, P.npairs - 1);
+        rec0_init(r[k], seed, m, P.cth[ipc], P.sth[ipc], ip < P.npairs && m <= P.mlim0[ipc]);
+    }
+    const int nil = (P.lmax - m) / 2 + 1;
+    const double2 *__restrict__ ab = reinterpret_cast<const double2 *>(P.ab0) + P.off0[m];
+    int il = 0;
+    while (il + gran <= nil) {
+        bool act = false;
+#pragma unroll
+        for (int k = 0; k < R; ++k) act = act || rec0_counts(r[k], thr);
+        if (wave_any(act)) break;
+        for (int b = 0; b < gran; b += 8) {
+            for (int t = 0; t < 8; ++t) {
+                const double2 c = ab[il + b + t];
+#pragma unroll
+                for (int k = 0; k < R; ++k) rec0_step_fast(r[k], c.x, c.y);
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) rec0_renorm_up(r[k]);
+        }
+        il += gran;
+    }
+    if (lane == 0) il_out[m * ngroups + g] = il;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int64_t e = (int64_t)m * (ngroups * RG) + g * RG + k * 64 + lane;
+        st_out[e] = make_double2(r[k].p0, r[k].p1);
+        sc_out[e] = r[k].sc;
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_seed_gens(DevPlan P, DevSpinTab S, int spin, double thr, int gran, int *__restrict__ il_out,
+                                                   double4 *__restrict__ st_out, int2 *__restrict__ sc_out)
+{
+    constexpr int RG = 64 * R;
+    const int wave = wave_id(), lane = threadIdx.x & 63;
+    const int ngroups = (P.npairs + RG - 1) / RG;
+    const int g = blockIdx.x % ngroups, m = 4 * (blockIdx.x / ngroups) + wave;
+    if (m > P.mmax) return;
+    const int l0 = m > spin ? m : spin;
+    RecS r[R];
+    int i = 0;
+    if (l0 <= P.lmax) {
+        const double fn = S.seedfac_n[m], fp = S.seedfac_p[m];
+        const int psin = S.psin[m], phalf = S.phalf[m], ucn = S.usecos_n[m], ucp = S.usecos_p[m];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int ip = g * RG + k * 64 + lane;
+            const int ipc = min(ip, P.npairs - 1);
+            recs_init(r[k], fn, fp, psin, phalf, ucn, ucp, P.cth[ipc], P.sth[ipc], P.chalf[ipc], P.shalf[ipc], ip < P.npairs && m <= S.mlim[ipc]);
+        }
+        const int nl = P.lmax - l0 + 1;
+        const double2 *__restrict__ ab = reinterpret_cast<const double2 *>(S.ab) + S.off[m];
+        while (i + gran <= nl) {
+            bool act = false;
+#pragma unroll
+            for (int k = 0; k < R; ++k) act = act || recs_counts(r[k], thr);
+            if (wave_any(act)) break;
+            for (int b = 0; b < gran; b += 8) {
+                for (int t = 0; t < 8; ++t) {
+                    const double2 c = ab[i + b + t];
+#pragma unroll
+                    for (int k = 0; k < R; ++k) recs_step_fast(r[k], c.x, c.y);
+                }
+#pragma unroll
+                for (int k = 0; k < R; ++k) recs_renorm_up(r[k]);
+            }
+            i += gran;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) { r[k].n0 = r[k].n1 = r[k].p0 = r[k].p1 = 0.0; r[k].x = 0.0; r[k].scn = r[k].scp = kNeverActive; }
+    }
+    if (lane == 0) il_out[m * ngroups + g] = i;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int64_t e = (int64_t)m * (ngroups * RG) + g * RG + k * 64 + lane;
+        st_out[e] = make_double4(r[k].n0, r[k].n1, r[k].p0, r[k].p1);
+        sc_out[e] = make_int2(r[k].scn, r[k].scp);
+    }
+}
+
+// state of ring k of this lane from the table of its family (T.rg == 64 R checked by the caller)
+__device__ __forceinline__ void seed_load0(const DevSeedTab &T, int m, int ip, double x, Rec0 &r)
+{
+    const int64_t e = (int64_t)m * T.npad + ip;
+    const double2 v = reinterpret_cast<const double2 *>(T.st)[e];
+    r.x2 = x * x; r.p0 = v.x; r.p1 = v.y; r.sc = T.sc[e];
+}
+__device__ __forceinline__ void seed_loads(const DevSeedTab &T, int m, int ip, double x, RecS &r)
+{
+    const int64_t e = (int64_t)m * T.npad + ip;
+    const double4 v = reinterpret_cast<const double4 *>(T.st)[e];
+    const int2 c = reinterpret_cast<const int2 *>(T.sc)[e];
+    r.x = x; r.n0 = v.x; r.n1 = v.y; r.p0 = v.z; r.p1 = v.w; r.scn = c.x; r.scp = c.y;
+}
+
+// -----------------------------------------------------------------------------------------------------
 // synthesis, spin 0
 // -----------------------------------------------------------------------------------------------------
 template <int R>
@@ -209,12 +327,14 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
     if (m <= P.mmax) {
         Rec0 r[R];
         const double seed = P.seed0[m];
+        const bool seeded = P.seed_syn0.rg == RG;  // the plan's table of states at the end of phase A (device_plan.h DevSeedTab)
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int ip = g * RG + k * 64 + lane;
             const bool ok = ip < P.npairs && m <= P.mlim0[min(ip, P.npairs - 1)];
             const int ipc = min(ip, P.npairs - 1);
-            rec0_init(r[k], seed, m, P.cth[ipc], P.sth[ipc], ok);
+            if (seeded) seed_load0(P.seed_syn0, m, ip, P.cth[ipc], r[k]);
+            else rec0_init(r[k], seed, m, P.cth[ipc], P.sth[ipc], ok);
         }
         const int nil = (P.lmax - m) / 2 + 1;
         const int64_t base = P.off0[m];
@@ -222,7 +342,7 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
         const double4 *__restrict__ cd = prep + base;
         const d2v_t *__restrict__ abv = reinterpret_cast<const d2v_t *>(ab);
         const d4v_t *__restrict__ cdv = reinterpret_cast<const d4v_t *>(cd);
-        int il = 0;
+        int il = seeded ? __builtin_amdgcn_readfirstlane(P.seed_syn0.il[m * ngroups + g]) : 0;
         bool all_done = false;
         {
             bool live = false;
@@ -237,7 +357,7 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
         while (il + 8 <= nil) {
             bool act = false;
 #pragma unroll
-            for (int k = 0; k < R; ++k) act = act || (r[k].sc == 0);
+            for (int k = 0; k < R; ++k) act = act || rec0_counts(r[k], kActSynth0);
             if (wave_any(act)) break;
             pf.step<32, 16>(cd, ab, il, nil, lane);
             const d8v_t c0 = ld8(ab + il), c1 = ld8(ab + il + 4);
@@ -411,12 +531,14 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
         sig0 = ((l0 + m) & 1) ? -1.0 : 1.0;
         const double fn = S.seedfac_n[m], fp = S.seedfac_p[m];
         const int psin = S.psin[m], phalf = S.phalf[m], ucn = S.usecos_n[m], ucp = S.usecos_p[m];
+        const bool seeded = S.seed_syn.rg == RG;  // the table of states at the end of phase A (device_plan.h DevSeedTab)
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int ip = g * RG + k * 64 + lane;
             const int ipc = min(ip, P.npairs - 1);
             const bool ok = ip < P.npairs && m <= S.mlim[ipc];
-            recs_init(r[k], fn, fp, psin, phalf, ucn, ucp, P.cth[ipc], P.sth[ipc], P.chalf[ipc], P.shalf[ipc], ok);
+            if (seeded) seed_loads(S.seed_syn, m, ip, P.cth[ipc], r[k]);
+            else recs_init(r[k], fn, fp, psin, phalf, ucn, ucp, P.cth[ipc], P.sth[ipc], P.chalf[ipc], P.shalf[ipc], ok);
         }
         const int nl = P.lmax - l0 + 1;
         const int64_t base = S.off[m];
@@ -426,7 +548,7 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
         const d4v_t *__restrict__ aav = reinterpret_cast<const d4v_t *>(aa);
         const double4 *__restrict__ aa2 = IN2 ? prep2 + base : nullptr;  // pair: gradient-only prep {sg Ap2, Ap2}, only Ap2 is read; batch: {An2, Ap2}
         const d4v_t *__restrict__ aav2 = reinterpret_cast<const d4v_t *>(aa2);
-        int i = 0;
+        int i = seeded ? __builtin_amdgcn_readfirstlane(S.seed_syn.il[m * ngroups + g]) : 0;
         bool all_done = false;
         {
             bool live = false;
@@ -491,7 +613,7 @@ __global__ __launch_bounds__(256) void k_leg_synths(DevPlan P, DevSpinTab S, int
         while (i + 8 <= nl) {
             bool act = false;
 #pragma unroll
-            for (int k = 0; k < R; ++k) act = act || r[k].scn == 0 || r[k].scp == 0;
+            for (int k = 0; k < R; ++k) act = act || recs_counts(r[k], kActSynthS);
             if (wave_any(act)) break;
             pf.step<32, 16>(aa, ab, i, nl, lane);
             const d8v_t c0 = ld8(ab + i), c1 = ld8(ab + i + 4);
@@ -803,6 +925,7 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
     Rec0 r[R];
     double er[R], ei[R], orr[R], oi[R];
     const double seed = P.seed0[m];
+    const bool seeded = P.seed_ana0.rg == RG;  // the plan's table of states at the end of phase A (device_plan.h DevSeedTab)
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int rl = k * 64 + lane;
@@ -810,7 +933,8 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
         const int ipc = min(ip, P.npairs - 1);
         const bool ok = ip < P.npairs && m <= P.mlim0[ipc];
         const double x = P.cth[ipc];
-        rec0_init(r[k], seed, m, x, P.sth[ipc], ok);
+        if (seeded) seed_load0(P.seed_ana0, m, ip, x, r[k]);
+        else rec0_init(r[k], seed, m, x, P.sth[ipc], ok);
         const double *t = tile + rl * 16 + wave * 4;
         const double nr = ok ? t[0] : 0., ni = ok ? t[1] : 0., sr = ok ? t[2] : 0., si = ok ? t[3] : 0.;
         er[k] = nr + sr; ei[k] = ni + si;
@@ -897,14 +1021,18 @@ __global__ __launch_bounds__(256) void k_leg_anal0(DevPlan P, const double *__re
             return;
         }
     }
-    for (int il0 = 0; il0 < nil; il0 += T) {
+    // tiles that the seed table skips (recursion only, no ring of the wave counted yet): their partial sums are zero
+    const int il_start = seeded ? __builtin_amdgcn_readfirstlane(P.seed_ana0.il[m * ngroups + g]) : 0;
+    for (int il0 = 0; il0 < il_start; il0 += T)
+        if (il0 + (lane >> 2) < nil) out[(int64_t)il0 * 4 + lane] = 0.0;
+    for (int il0 = il_start; il0 < nil; il0 += T) {
         if (!any_active) {
             // no lane has reached the IEEE range: recursion only.  A lane that activates inside this tile is
             // at 2^-256 then and cannot grow past ~2^-70 within the tile, so the tile's sums are exactly
             // representable as zero at double precision.
             bool act = false;
 #pragma unroll
-            for (int k = 0; k < R; ++k) act = act || (r[k].sc == 0);
+            for (int k = 0; k < R; ++k) act = act || rec0_counts(r[k], kActAnal0);
             any_active = wave_any(act);
             if (!any_active) {
                 const int nt = min(T, nil - il0);
@@ -1106,13 +1234,15 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
     const double sg = (spin & 1) ? -1.0 : 1.0;
     const double fn = S.seedfac_n[m], fp = S.seedfac_p[m];
     const int psin = S.psin[m], phalf = S.phalf[m], ucn = S.usecos_n[m], ucp = S.usecos_p[m];
+    const bool seeded = S.seed_ana.rg == RG;  // the table of states at the end of phase A (device_plan.h DevSeedTab)
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int rl = k * 64 + lane;
         const int ip = g * RG + rl;
         const int ipc = min(ip, P.npairs - 1);
         const bool ok = ip < P.npairs && m <= S.mlim[ipc];
-        recs_init(r[k], fn, fp, psin, phalf, ucn, ucp, P.cth[ipc], P.sth[ipc], P.chalf[ipc], P.shalf[ipc], ok);
+        if (seeded) seed_loads(S.seed_ana, m, ip, P.cth[ipc], r[k]);
+        else recs_init(r[k], fn, fp, psin, phalf, ucn, ucp, P.cth[ipc], P.sth[ipc], P.chalf[ipc], P.shalf[ipc], ok);
         const double *t = tile + rl * 32 + wave * 8;
         // select, not multiply: entries of pruned (m, ring) are never written by the FFT stage and may hold anything
         const double qnr = ok ? t[0] : 0., qni = ok ? t[1] : 0., qsr = ok ? t[2] : 0., qsi = ok ? t[3] : 0.;
@@ -1216,11 +1346,15 @@ __global__ __launch_bounds__(256) void k_leg_anals(DevPlan P, DevSpinTab S, int 
             return;
         }
     }
-    for (int i0 = 0; i0 < nl; i0 += T) {
+    // tiles that the seed table skips (recursion only, no ring of the wave counted yet): their partial sums are zero
+    const int i_start = seeded ? __builtin_amdgcn_readfirstlane(S.seed_ana.il[m * ngroups + g]) : 0;
+    for (int i0 = 0; i0 < i_start; i0 += T)
+        if (i0 + (lane >> 2) < nl) out[(int64_t)i0 * 4 + lane] = 0.0;
+    for (int i0 = i_start; i0 < nl; i0 += T) {
         if (!any_active) {
             bool act = false;
 #pragma unroll
-            for (int k = 0; k < R; ++k) act = act || r[k].scn == 0 || r[k].scp == 0;
+            for (int k = 0; k < R; ++k) act = act || recs_counts(r[k], kActAnalS);
             any_active = wave_any(act);
             if (!any_active) {
                 const int nt = min(T, nl - i0);
@@ -1389,6 +1523,55 @@ static int rs_anal(const DevPlan &P) { return pick_r("PLSHTS_RSA", 4, 4, P); }  
 // partial sums per batch entry that k_post0 / k_posts leave in a PostDots (= their workgroups per entry)
 int post_dots_count(const DevPlan &P) { return 4 * (P.mmax + 1); }
 int rings_per_group(int spin, const DevPlan &P) { return 64 * (spin == 0 ? r0_anal(P) : rs_anal(P)); }
+
+// ---- seed tables (device_plan.h DevSeedTab) of a kernel family: fam 0 = synthesis, 1 = analysis ------------------------------------------
+// ring pairs per wave of the family on this plan (what its launcher will pick)
+int seed_family_rg(const DevPlan &P, int spin, int fam)
+{
+    return 64 * (spin == 0 ? (fam == 0 ? r0_synth(P) : r0_anal(P)) : (fam == 0 ? rs_synth(P) : rs_anal(P)));
+}
+template <int R>
+static void seed_gen0_r(const DevPlan &P, double thr, int gran, int *il, double *st, int *sc, hipStream_t s)
+{
+    const int ngroups = (P.npairs + 64 * R - 1) / (64 * R), nmg = (P.mmax + 4) / 4;
+    hipLaunchKernelGGL(k_seed_gen0<R>, dim3(ngroups * nmg), dim3(256), 0, s, P, thr, gran, il, reinterpret_cast<double2 *>(st), sc);
+}
+template <int R>
+static void seed_gens_r(const DevPlan &P, const DevSpinTab &S, int spin, double thr, int gran, int *il, double *st, int *sc, hipStream_t s)
+{
+    const int ngroups = (P.npairs + 64 * R - 1) / (64 * R), nmg = (P.mmax + 4) / 4;
+    hipLaunchKernelGGL(k_seed_gens<R>, dim3(ngroups * nmg), dim3(256), 0, s, P, S, spin, thr, gran, il, reinterpret_cast<double4 *>(st),
+                       reinterpret_cast<int2 *>(sc));
+}
+// il: (mmax + 1) x ngroups ints; st: (mmax + 1) x npad x (2 | 4) doubles; sc: (mmax + 1) x npad x (1 | 2) ints, npad = ngroups x rg
+bool launch_seed_gen(const DevPlan &P, const DevSpinTab *S, int spin, int fam, int rg, int *il, double *st, int *sc, hipStream_t s)
+{
+    const int gran = fam == 0 ? 8 : 16;  // check interval of the family's kernels, in recursion steps
+    const double thr = spin == 0 ? (fam == 0 ? kActSynth0 : kActAnal0) : (fam == 0 ? kActSynthS : kActAnalS);
+    const int R = rg / 64;
+    if (spin == 0) {
+        switch (R) {
+        case 1: seed_gen0_r<1>(P, thr, gran, il, st, sc, s); break;
+        case 2: seed_gen0_r<2>(P, thr, gran, il, st, sc, s); break;
+        case 3: seed_gen0_r<3>(P, thr, gran, il, st, sc, s); break;
+        case 4: seed_gen0_r<4>(P, thr, gran, il, st, sc, s); break;
+        case 5: seed_gen0_r<5>(P, thr, gran, il, st, sc, s); break;
+        case 6: seed_gen0_r<6>(P, thr, gran, il, st, sc, s); break;
+        case 7: seed_gen0_r<7>(P, thr, gran, il, st, sc, s); break;
+        case 8: seed_gen0_r<8>(P, thr, gran, il, st, sc, s); break;
+        default: return false;
+        }
+    } else {
+        switch (R) {
+        case 1: seed_gens_r<1>(P, *S, spin, thr, gran, il, st, sc, s); break;
+        case 2: seed_gens_r<2>(P, *S, spin, thr, gran, il, st, sc, s); break;
+        case 3: seed_gens_r<3>(P, *S, spin, thr, gran, il, st, sc, s); break;
+        case 4: seed_gens_r<4>(P, *S, spin, thr, gran, il, st, sc, s); break;
+        default: return false;
+        }
+    }
+    return true;
+}
 
 void launch_prep0(const DevPlan &P, const double *alm, const double *fl, double *prep, hipStream_t st, int nb)
 {

@@ -17,6 +17,17 @@ namespace plshts {
 // any sum is < 1e-77 of an O(1) term and is dropped, exactly as libsharp does below its own threshold.
 constexpr double kFBig = 0x1p+512, kFSmall = 0x1p-512, kTBig = 0x1p+256, kTSmall = 0x1p-256;
 constexpr int kNeverActive = -(1 << 28);
+// When does a wave start to accumulate?  The kernels run three phases per wave: (A) recursion only while no ring of the wave counts,
+// (B) masked accumulation while some rings are still scaled, (C) the pure FMA stream once every ring is in the double range.  A ring
+// *counts* once it is active AND its value has reached an activation threshold 2^-k: the rings of a wave become O(1) at different l, and
+// until round 5 a wave left phase A as soon as its first ring entered the double range (2^-256) -- 2-3 % of all recursion steps ran their
+// accumulation FMAs on terms below 1e-30 of an O(1) term.  (libsharp drops what lies below 2^-60.)  The check is made once per block of
+// recursion steps, so a ring that crosses the threshold inside a block is noticed at the block's end; the thresholds are set per kernel
+// family from the largest value that is left out of a sum that way, measured over all (m, ring) of an nside = lmax = 2048 grid:
+//   synthesis spin s (blocks of  8 l): 2^-112 -> at most 2^-89      synthesis spin 0 (8 two-l steps = 16 l): 2^-128 -> 2^-85
+//   analysis  spin s (tiles of  16 l): 2^-128 -> at most 2^-85      analysis  spin 0 (16 two-l steps = 32 l): 2^-160 -> 2^-82
+// i.e. below 1e-24 of an O(1) term.  Phases B and C are unchanged (a ring in the double range is summed from there on, however small).
+constexpr double kActSynthS = 0x1p-112, kActSynth0 = 0x1p-128, kActAnalS = 0x1p-128, kActAnal0 = 0x1p-160;
 
 PL_HD void renorm(double &v, int &s)
 {
@@ -89,6 +100,9 @@ PL_HD void rec0_renorm_up(Rec0 &r)
     if (r.sc < 0 && fabs(r.p1) > kTBig) { r.p0 *= kFSmall; r.p1 *= kFSmall; r.sc += 1; }
 }
 
+// does this ring end phase A of its wave?
+PL_HD bool rec0_counts(const Rec0 &r, double thr) { return r.sc == 0 && fabs(r.p1) >= thr; }
+
 // value usable in sums for the current il (0 while still scaled)
 PL_HD double rec0_value(const Rec0 &r) { return r.sc == 0 ? r.p1 : 0.0; }
 
@@ -138,6 +152,8 @@ PL_HD void recs_renorm_up(RecS &r)  // see rec0_renorm_up
     if (r.scn < 0 && fabs(r.n1) > kTBig) { r.n0 *= kFSmall; r.n1 *= kFSmall; r.scn += 1; }
     if (r.scp < 0 && fabs(r.p1) > kTBig) { r.p0 *= kFSmall; r.p1 *= kFSmall; r.scp += 1; }
 }
+
+PL_HD bool recs_counts(const RecS &r, double thr) { return (r.scn == 0 && fabs(r.n1) >= thr) || (r.scp == 0 && fabs(r.p1) >= thr); }
 
 PL_HD double recs_value_n(const RecS &r) { return r.scn == 0 ? r.n1 : 0.0; }
 PL_HD double recs_value_p(const RecS &r) { return r.scp == 0 ? r.p1 : 0.0; }

@@ -35,7 +35,7 @@ class Plan(object):
         if _lib.device_count() < 1:
             raise RuntimeError('no HIP device visible: plancklens_amd.shts has no CPU path')
         h = ctypes.c_void_p()
-        o = _lib.PlanOpts(0, -1, -1, -1, -1)
+        o = _lib.PlanOpts(0, -1, -1, -1, -1, -1)
         for k, v in dict(opts).items():
             assert hasattr(o, k), 'unknown plan option %s' % k
             setattr(o, k, int(v))
@@ -117,7 +117,7 @@ _OPTS = ()
 
 class plan_options(object):
     """`with shts.plan_options(fft_legacy=1):` -- transforms issued inside use plans created with these pl_plan_opts fields
-    (fft_legacy, fft_split_min, fft_nyq_min, fft_min_fast, fft_generic_nside; include/plshts.h).  Plans are cached per option set, so the default plans of
+    (fft_legacy, fft_split_min, fft_nyq_min, fft_min_fast, fft_generic_nside, seed_tables; include/plshts.h).  Plans are cached per option set, so the default plans of
     the process are untouched: the fast-vs-generic tests compare two plans of one grid this way.  Options are explicit arguments of
     pl_plan_create_opts -- the library reads no environment variable at plan creation."""
 

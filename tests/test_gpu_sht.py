@@ -287,3 +287,41 @@ def test_batched_synthesis_is_bit_identical_to_two_calls(shts, spin, nside, lmax
     r2 = shts.alm2map_spin([g2, c2], nside, spin, lmax, fl=fl)
     for a, b in ((q1, r1[0]), (u1, r1[1]), (q2, r2[0]), (u2, r2[1])):
         assert bool((a == b).all()), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize('nside,lmax', [(16, 40), (64, 128), (128, 300), (512, 512), (1024, 1500), (2048, 2048)])
+def test_seed_tables_start_the_recursions_where_they_would_have_arrived(shts, nside, lmax):
+    """A plan keeps, per kernel family, the recursion state of every (m, ring pair) at the step where the family's kernels stop recursing
+    without accumulating (pl_plan_opts.seed_tables, DevSeedTab), made by the same arithmetic: every transform of a plan with the tables
+    equals that of a plan without them (seed_tables = 0: every launch recurses from l = m) bit for bit -- all spins, both directions,
+    the gradient-only, paired and two-simulation syntheses, a filter on the way."""
+    import torch
+    from plancklens_amd import dev
+    rng = np.random.default_rng(11 * nside + lmax)
+    plain = shts.Plan(nside, lmax, opts={'seed_tables': 0})
+    seeded = shts.Plan(nside, lmax)
+    assert seeded.bytes() > plain.bytes()
+    npix = 12 * nside ** 2
+    fl = 1. / (1. + np.arange(lmax + 1.)) ** .5
+    a = dev.to_dev(random_alm(rng, lmax))
+    gc = [[dev.to_dev(random_alm(rng, lmax, s)) for _ in range(2)] for s in (1, 2, 3)]
+    gc2 = [dev.to_dev(random_alm(rng, lmax, 2)) for _ in range(2)]
+    m = dev.to_dev(rng.standard_normal(npix))
+    qu = dev.to_dev(rng.standard_normal((2, npix)))
+
+    def everything():
+        out = [shts.alm2map(a, nside, lmax=lmax), shts.alm2map(a, nside, lmax=lmax, fl=fl), shts.map2alm(m, lmax=lmax, iter=0)]
+        for s in (1, 2, 3):
+            g, c = gc[s - 1]
+            out += shts.alm2map_spin([g, c], nside, s, lmax) + shts.alm2map_spin([g, None], nside, s, lmax, fl=fl)
+            out += shts.map2alm_spin([qu[0], qu[1]], s, lmax) + shts.map2alm_spin([qu[1], qu[0]], s, lmax, fl=fl)
+        g, c = gc[1]
+        for pair in (shts.alm2map_spin_pair([g, c], gc2[0], nside, 2, lmax, fl=fl), shts.alm2map_spin_grad_pair(g, gc2[0], nside, 2, lmax),
+                     shts.alm2map_spin_batch2([g, c], gc2, nside, 2, lmax)):
+            out += pair[0] + pair[1]
+        return [dev.to_host(x) if isinstance(x, torch.Tensor) else np.asarray(x) for x in out]
+    r0 = _run_with_plan(shts, plain, everything)
+    r1 = _run_with_plan(shts, seeded, everything)
+    assert len(r0) == len(r1)
+    for i, (x, y) in enumerate(zip(r0, r1)):
+        assert x.shape == y.shape and np.array_equal(x, y), (i, float(np.max(np.abs(x - y))))
