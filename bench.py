@@ -21,8 +21,8 @@ Prints ONE JSON line (rank 0).
  * `roofline`: the Legendre kernel with the largest summed time inside the timed region (HIP events on the launch
    stream, pl_profile_*).  The binding ceiling is FP64 vector-FMA issue, reported under the "mfma" (TFLOP/s) arm of the
    schema: gfx950's FP64 MFMA peak equals its FP64 vector peak and no MFMA is used (a recurrence, not a contraction).
-   `achieved` counts EXECUTED flops (the (l, m, ring pair) steps left after libsharp-style polar pruning); the
-   fixed-denominator count of SURVEY.md 8(d) (no pruning credit) is reported beside it as `achieved_fixed_denominator`.
+   `achieved` counts EXECUTED flops (the (l, m, ring pair) steps the kernel runs: what is left after libsharp-style polar pruning,
+   from the step at which the plan's seed table starts each wavefront -- pl_plan_executed_steps); the fixed-denominator count of SURVEY.md 8(d) (no pruning credit) is reported beside it as `achieved_fixed_denominator`.
  * `kernels`: every timed stage (per launch; ring-FFT GB/s per component).
  * `cg`: BASELINE config 4 (cinv_t + cinv_p, masked sky, 100 top-level iterations, dense preconditioner cached outside
    the timed region), rank 0 at N = 1 only.
@@ -572,6 +572,18 @@ def run_rank(args):
         steps_leg = nalm * 2 * nside                      # (l, m, ring pair) recursion steps per transform
         flops_spin, flops_scal = 24.0 * steps_leg, 8.0 * steps_leg
         exec_spin, exec_scal = executed_flops(nside, lmax, 2), executed_flops(nside, lmax, 0)
+        # what the kernels run since round 5: the plan's seed tables start every wave where its recursion-only phase would have ended
+        # (pl_plan_executed_steps: steps from there on, every ring-pair slot of a running wave counted), by kernel family
+        exec_by_family = {}
+        try:
+            from plancklens_amd import _lib as _plib
+            hpl = shts.get_plan(nside, lmax).h
+            for nm, sp, fam, fl_ in (('leg_synth0', 0, 0, 12.), ('leg_anal0', 0, 1, 12.), ('leg_synths', 2, 0, 24.), ('leg_anals', 2, 1, 24.)):
+                st_ = int(_plib.lib().pl_plan_executed_steps(hpl, sp, fam))
+                if st_ >= 0:
+                    exec_by_family[nm] = st_ * fl_
+        except Exception:
+            exec_by_family = {}
         npix = hp.nside2npix(nside)
         res = {
             'metric': "QE reconstructions/sec at nside=%d lmax=%d ('%s' MV); CG-iter/sec" % (nside, lmax, key),
@@ -599,8 +611,10 @@ def run_rank(args):
         # step for TWO maps (the fixed count of the two transforms it replaces is 48)
         alg = {'leg_synth0': flops_scal, 'leg_synths': flops_spin, 'leg_anal0': flops_scal, 'leg_anals': flops_spin,
                'leg_synths_grad': flops_spin * 16. / 24., 'leg_synths_pair': flops_spin * 32. / 24., 'leg_synths_batch2': flops_spin * 40. / 24.}
-        exe = {'leg_synth0': exec_scal, 'leg_synths': exec_spin, 'leg_anal0': exec_scal, 'leg_anals': exec_spin,
-               'leg_synths_grad': exec_spin * 16. / 24., 'leg_synths_pair': exec_spin * 32. / 24., 'leg_synths_batch2': exec_spin * 40. / 24.}
+        e_s0, e_a0 = exec_by_family.get('leg_synth0', exec_scal), exec_by_family.get('leg_anal0', exec_scal)
+        e_ss, e_as = exec_by_family.get('leg_synths', exec_spin), exec_by_family.get('leg_anals', exec_spin)
+        exe = {'leg_synth0': e_s0, 'leg_synths': e_ss, 'leg_anal0': e_a0, 'leg_anals': e_as,
+               'leg_synths_grad': e_ss * 16. / 24., 'leg_synths_pair': e_ss * 32. / 24., 'leg_synths_batch2': e_ss * 40. / 24.}
         # components per ring-FFT stage launch are not recorded by the profile; both directions move, per component,
         # 8 npix + 32 npairs (mmax + 1) algorithmic bytes.  Launch mix of one 'p' reconstruction (qest._get_sim_MVgclm):
         # synthesis stages of 1 + 2 + 2 + 4 components in 4 launches, analysis stages of 1 + 2 + 2 in 3 launches.
@@ -642,8 +656,8 @@ def run_rank(args):
                                'achieved_fixed_denominator': fixed, 'frac_fixed_denominator': fixed / FP64_PEAK_TFLOPS,
                                'fma_issue_ceiling_measured_tflops': fma_ceilings(),
                                'note': 'dominant kernel = largest summed time in the timed region. FP64 vector-FMA issue bound (v_fma_f64); gfx950 FP64 MFMA '
-                                       'peak = FP64 vector peak; no MFMA used. achieved = EXECUTED flops (the (l, m, ring pair) steps the kernel runs after '
-                                       'libsharp-style polar pruning) / mean launch time (HIP events on the launch stream); achieved_fixed_denominator = '
+                                       'peak = FP64 vector peak; no MFMA used. achieved = EXECUTED flops (the (l, m, ring pair) steps the kernel runs: after '
+                                       'libsharp-style polar pruning and from the step its seed table starts each wavefront at, pl_plan_executed_steps) / mean launch time (HIP events on the launch stream); achieved_fixed_denominator = '
                                        'SURVEY 8(d) count (24 or 8 flop x nalm x 2 nside, pruning not credited). peak = datasheet 78.6 TF; '
                                        'fma_issue_ceiling_measured_tflops is what a pure FMA loop sustains on this GPU by operand mix. '
                                        'traffic = FETCH_SIZE + WRITE_SIZE bytes per launch (%s: PMC passes of the same kernel)' % pmc_source}

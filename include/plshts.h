@@ -73,6 +73,10 @@ int64_t pl_plan_bytes(const pl_plan *plan); /* device bytes held by the plan */
 /* The plan's i-th side stream (a hipStream_t; NULL when i is out of range): the streams the classes of a ring-FFT stage are spread over
  * between a fork and a join on the caller's stream.  For tools that look at how streams fall onto the hardware queues. */
 void *pl_plan_side_stream(const pl_plan *plan, int i);
+/* Recursion steps the Legendre kernels of one family (fam 0: synthesis, 1: analysis) of the plan execute per launch and input, read from
+ * the plan's seed table (pl_plan_opts.seed_tables): (l, ring pair) steps for spin >= 1 (12 FMA each), two-l steps for spin 0 (6 FMA each);
+ * every ring-pair slot of a wavefront that runs is counted.  -1 without a table.  For measurement tools (bench.py's executed flops). */
+int64_t pl_plan_executed_steps(pl_plan *plan, int spin, int fam);
 
 /* One transform over several GPUs ("m-blocks shard across the GPUs", BASELINE.json north_star; the reference's only parallelism
  * inside a transform is the third-party library's threads, shts.py:10).  Shard `rank` of `nranks`:

@@ -1,6 +1,7 @@
 // C ABI (include/plshts.h): plan management and the stream-ordered transform entry points.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -613,6 +614,36 @@ int pl_profile_read(pl_plan *p, double *ms_sum, int64_t *counts)
 int64_t pl_plan_npix(const pl_plan *p) { return p ? p->P.npix : 0; }
 int64_t pl_plan_nalm(const pl_plan *p) { return p ? p->P.nalm : 0; }
 int64_t pl_plan_bytes(const pl_plan *p) { return p ? p->bytes : 0; }
+// Recursion steps the Legendre kernels of a family (fam 0: synthesis, 1: analysis) of this plan execute per launch, from the plan's seed
+// table: sum over the live (m, ring group) waves of (steps of m - first step of the wave) x ring-pair slots of the wave (pruned and padded slots of
+// a live wave run along).  Units: (l, ring pair) steps for spin >= 1, two-l steps for spin 0.  -1: no table (every launch recurses from l = m).
+int64_t pl_plan_executed_steps(pl_plan *p, int spin, int fam)
+{
+    if (!p || spin < 0 || spin > kMaxSpin || fam < 0 || fam > 1) return -1;
+    if (spin > 0 && ensure_spin(p, spin)) return -1;
+    const DevPlan &P = p->P;
+    const DevSeedTab &T = spin == 0 ? (fam == 0 ? P.seed_syn0 : P.seed_ana0) : (fam == 0 ? p->S[spin].seed_syn : p->S[spin].seed_ana);
+    if (T.rg <= 0) return -1;
+    try {
+        const int ngroups = T.npad / T.rg;
+        std::vector<int> il((size_t)(P.mmax + 1) * ngroups), mlim(P.npairs);
+        if (hipMemcpy(il.data(), T.il, il.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(mlim.data(), spin == 0 ? P.mlim0 : p->S[spin].mlim, mlim.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+            return -1;
+        int64_t steps = 0;
+        for (int g = 0; g < ngroups; ++g) {
+            int gl = -1;  // largest order any ring of the group keeps
+            for (int ip = g * T.rg; ip < std::min(P.npairs, (g + 1) * T.rg); ++ip) gl = std::max(gl, mlim[ip]);
+            for (int m = 0; m <= std::min(P.mmax, gl); ++m) {
+                const int n = spin == 0 ? (P.lmax - m) / 2 + 1 : P.lmax - std::max(m, spin) + 1;
+                if (n > 0) steps += (int64_t)std::max(0, n - il[(size_t)m * ngroups + g]) * T.rg;
+            }
+        }
+        return steps;
+    } catch (const std::exception &) {
+        return -1;
+    }
+}
 void *pl_plan_side_stream(const pl_plan *p, int i) { return (p && p->fs.ok && i >= 0 && i < FftStreams::kN) ? (void *)p->fs.s[i] : nullptr; }
 
 int64_t pl_plan_phase_doubles(const pl_plan *p, int spin)
