@@ -1516,8 +1516,9 @@ static int pick_r(const char *env, int dflt, int rmax, const DevPlan &P)
 }
 static int r0_synth(const DevPlan &P) { return pick_r("PLSHTS_R0", 3, 6, P); }
 static int rs_synth(const DevPlan &P) { return pick_r("PLSHTS_RS", 2, 4, P); }
-// (spin-0 analysis: 8 rings per lane at nside >= 4096 -- 8.31 against 8.99 ms at nside = lmax = 4096; at 2048 6 and 8 are equal, 7 is slower)
-static int r0_anal(const DevPlan &P) { return pick_r("PLSHTS_R0A", P.nside >= 4096 ? 8 : 6, 8, P); }
+// (spin-0 analysis: 6 rings per lane.  Before the seed tables 8 won at nside >= 4096 (8.31 against 8.99 ms at nside = lmax = 4096); with them every ring of a
+// wave still runs from the wave's first step, and the wider group of R = 8 pays more for that than it saves: 10.3 against 8.8 ms, tools/r_sweep.sh)
+static int r0_anal(const DevPlan &P) { return pick_r("PLSHTS_R0A", 6, 8, P); }
 static int rs_anal(const DevPlan &P) { return pick_r("PLSHTS_RSA", 4, 4, P); }  // (5, 6, 8 rings per lane -- one wave per SIMD -- measured 5.30 / 6.27 / 10.0 ms against 4.53 ms: round 3)
 
 // partial sums per batch entry that k_post0 / k_posts leave in a PostDots (= their workgroups per entry)
