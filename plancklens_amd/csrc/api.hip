@@ -250,6 +250,7 @@ static int ensure_spin_locked(pl_plan *p, int spin)
     build_geometry(p->P.nside, g);
     std::vector<int> mlim(g.npairs);
     for (int i = 0; i < g.npairs; ++i) mlim[i] = mlim_ring(p->P.lmax, spin, g.sth[i], g.cth[i]);
+    for (int i = 1; i < g.npairs; ++i) mlim[i] = std::max(mlim[i], mlim[i - 1]);  // non-decreasing towards the equator (it is; k_posts relies on it: the ring groups an order keeps are the last ones)
     if (upload(p, mlim, &S.mlim)) return 1;
     S.gstart = nullptr;
     p->nent[spin] = t.off.back();
@@ -340,6 +341,7 @@ static int plan_create_body(int nside, int lmax, int rank, int nranks, const pl_
     p->nent[0] = P.nent0;
     std::vector<int> mlim(g.npairs);
     for (int i = 0; i < g.npairs; ++i) mlim[i] = mlim_ring(lmax, 0, g.sth[i], g.cth[i]);
+    for (int i = 1; i < g.npairs; ++i) mlim[i] = std::max(mlim[i], mlim[i - 1]);  // non-decreasing towards the equator (it is; k_post0 relies on it: the ring groups an order keeps are the last ones)
     rc = rc || upload(p, mlim, &P.mlim0);
     if (rc) { pl_plan_destroy(p); p = nullptr; return 1; }
 

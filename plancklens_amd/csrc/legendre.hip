@@ -1137,6 +1137,10 @@ __global__ void k_post0(DevPlan P, int RG, const double4 *__restrict__ partial_,
     double2 *__restrict__ alm = alm_ + (int64_t)blockIdx.z * P.nalm;
     const double2 *__restrict__ add = add_ ? add_ + (int64_t)blockIdx.z * P.nalm : nullptr;
     const int mg4 = 4 * (m / 4);
+    // the ring groups this m-group keeps (the analysis kernel wrote partial sums for exactly these): mlim does not decrease towards the equator, so they
+    // are the groups from the first kept one on
+    int g0 = 0;
+    while (g0 < ngroups && P.mlim0[min(P.npairs - 1, g0 * RG + RG - 1)] < mg4) ++g0;
     for (int il = blockIdx.x * blockDim.x + threadIdx.x; il < nil; il += gridDim.x * blockDim.x) {
         const int64_t e = base + il;
         // (the vectors of the scalar products are fetched ahead of the partial sums: their latency hides behind that loop)
@@ -1148,9 +1152,8 @@ __global__ void k_post0(DevPlan P, int RG, const double4 *__restrict__ partial_,
             if (l_ + 1 <= P.lmax) { dd1 = reinterpret_cast<const double2 *>(dots.d[0])[idot + 1]; rr1 = reinterpret_cast<const double2 *>(dots.r[0])[idot + 1]; }
         }
         double c0r = 0., c0i = 0., c1r = 0., c1i = 0., dr = 0., di = 0.;
-        for (int g = 0; g < ngroups; ++g) {
-            const int last = min(P.npairs - 1, g * RG + RG - 1);
-            if (P.mlim0[last] < mg4) continue;
+#pragma unroll 4
+        for (int g = g0; g < ngroups; ++g) {  // (loads of four groups in flight; added in group order as before)
             const double4 v = partial[(int64_t)g * P.nent0 + e];
             c0r += v.x; c0i += v.y; dr += v.z; di += v.w;
             if (il > 0) {
@@ -1456,6 +1459,10 @@ __global__ void k_posts(DevPlan P, DevSpinTab S, int spin, int RG, int64_t nent,
     const int64_t base = S.off[m];
     const int ngroups = (P.npairs + RG - 1) / RG;
     const int mg4 = 4 * (m / 4);
+    // the ring groups this m-group keeps (the analysis kernel wrote partial sums for exactly these): mlim does not decrease towards the equator, so they
+    // are the groups from the first kept one on
+    int g0 = 0;
+    while (g0 < ngroups && S.mlim[min(P.npairs - 1, g0 * RG + RG - 1)] < mg4) ++g0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nl; i += gridDim.x * blockDim.x) {
         const int64_t e = base + i;
         const int64_t ii = bz * P.nalm + abase + l0 + i;
@@ -1465,9 +1472,8 @@ __global__ void k_posts(DevPlan P, DevSpinTab S, int spin, int RG, int64_t nent,
             dc = reinterpret_cast<const double2 *>(dots.d[1])[ii]; rc = reinterpret_cast<const double2 *>(dots.r[1])[ii];
         }
         double gr = 0., gi = 0., cr = 0., ci = 0.;
-        for (int g = 0; g < ngroups; ++g) {
-            const int last = min(P.npairs - 1, g * RG + RG - 1);
-            if (S.mlim[last] < mg4) continue;
+#pragma unroll 4
+        for (int g = g0; g < ngroups; ++g) {  // (loads of four groups in flight; added in group order as before)
             const double4 v = partial[(int64_t)g * nent + e];
             gr += v.x; gi += v.y; cr += v.z; ci += v.w;
         }
