@@ -62,7 +62,7 @@ typedef struct pl_plan_opts {
                           where the family's kernels would stop recursing without accumulating (no ring of the wavefront has reached the
                           activation threshold yet: ~10 % of all recursion steps, at the latency of their dependent FMA chains), made once
                           by the same arithmetic -- transforms start from it, results bit-identical; ~40 B per (m, ring pair) and spin
-                          (1.2 GB at nside = lmax = 2048 with spins 0-3).  0: none, every launch recurses from l = m */
+                          (0.34 GB for spin 0 + 0.67 GB per spin s at nside = lmax = 2048; x 4 at 4096).  0: none, every launch recurses from l = m */
 } pl_plan_opts;
 /* pl_plan_create (rank 0 of 1) / pl_plan_create_shard with options; opts NULL = defaults. */
 int pl_plan_create_opts(int nside, int lmax, int rank, int nranks, const pl_plan_opts *opts, pl_plan **plan);
