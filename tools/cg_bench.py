@@ -193,8 +193,17 @@ def _run(nside, lmax, iters, kinds, joint, verbose, peak_tflops, batches=()):
             # the two solves' streams on different hardware queues (measured: dev.streams_overlap)?  On one queue they run one after the other
             res['tp_concurrent']['streams_overlap'] = bool(dev.streams_overlap(torch.cuda.current_stream(), filt_cinv._tp_side_stream()))
             if os.environ.get('CG_BENCH_QUEUE_DIAG'):  # which streams run beside which, here and now (stderr)
-                names = ['current', 'tp_side'] + ['new%d' % i for i in range(8)]
-                strs = [torch.cuda.current_stream(), filt_cinv._tp_side_stream()] + [torch.cuda.Stream() for _ in range(8)]
+                names = ['current', 'tp_side'] + ['new%d' % i for i in range(4)]
+                strs = [torch.cuda.current_stream(), filt_cinv._tp_side_stream()] + [torch.cuda.Stream() for _ in range(4)]
+                from plancklens_amd import _lib as _l
+                for ctx, tag in ((0, 'T'), (filt_cinv.P_CONTEXT, 'P')):  # the ring-FFT side streams of the fine-level plans of the two solves
+                    with shts.plan_context(ctx):
+                        ph = shts.get_plan(nside, lmax).h
+                    for i in range(3):
+                        ptr = _l.lib().pl_plan_side_stream(ph, i)
+                        if ptr:
+                            names.append('%s.s%d' % (tag, i))
+                            strs.append(torch.cuda.ExternalStream(ptr))
                 for i in range(len(strs)):
                     sys.stderr.write('%-8s %s\n' % (names[i], ' '.join('.' if j == i else ('1' if dev.streams_overlap(strs[i], strs[j]) else '0') for j in range(len(strs)))))
             # block solves of B simulations, T block and P block at the same time (what filter_sims runs with its default batch)
