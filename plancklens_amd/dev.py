@@ -116,7 +116,7 @@ class host_future(object):
       threaded (large results): the copy runs on a copy stream; a helper thread waits for it, moves the data out of the staging
         buffer and hands the buffer back -- the 33 MB host copies stay off the launching thread;
       lazy (threaded=False; small results, where a thread hand-off costs more than the copy): the copy is issued on the caller's
-        stream and nobody waits for it until result() is called or its staging buffer is needed again (oldest first)."""
+        stream into a pinned tensor of its own and nobody waits for it until result() is called, which returns that memory."""
     MAX_IN_FLIGHT = 8  # (two results per reconstruction: four reconstructions of slack for the launching thread when the helpers are slow -- a busy host)
     _in_flight = []
     _pool = None
@@ -126,8 +126,22 @@ class host_future(object):
         shts.join_lanes()  # results of transforms still running on side lanes
         t = t.detach().contiguous()
         host_future._in_flight[:] = [f for f in host_future._in_flight if not f.done()]
-        while len(host_future._in_flight) >= host_future.MAX_IN_FLIGHT:  # staging buffers all busy: wait for the oldest copy
-            host_future._in_flight.pop(0).result()
+        if not threaded:
+            # small result: a pinned tensor of its own from torch's caching host allocator (after warm-up the block of a result the caller has
+            # dropped: no hipHostMalloc), filled by an asynchronous copy on the caller's stream; result() hands out that tensor's memory as the
+            # numpy array -- no second pass over the data on the launching thread, no staging buffer to give back
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._arr = None
+            self._job = None
+            self._lazy = (ev, h, t)  # (t: the source stays alive until the copy has been waited for)
+            host_future._in_flight.append(self)
+            return
+        while len([f for f in host_future._in_flight if f._job is not None]) >= host_future.MAX_IN_FLIGHT:  # staging buffers all busy: wait for the oldest copy
+            next(f for f in host_future._in_flight if f._job is not None).result()
+            host_future._in_flight[:] = [f for f in host_future._in_flight if not f.done()]
         key = (tuple(t.shape), t.dtype)
         if key not in _PINNED_FREE:  # the whole staging pool of this shape at once, on first use (i.e. during warm-up)
             _PINNED_FREE[key] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for _ in range(host_future.MAX_IN_FLIGHT)]
@@ -135,13 +149,6 @@ class host_future(object):
         h = free.pop() if free else torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         self._arr = None
         self._job = None
-        if not threaded:
-            h.copy_(t, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._lazy = (ev, h, free, t)  # (t: the source stays alive until the copy has been waited for)
-            host_future._in_flight.append(self)
-            return
         cs = _copy_stream()
         cs.wait_stream(torch.cuda.current_stream())
         nblk = int(os.environ.get('PLENS_D2H_BLOCKS', '64'))
@@ -168,17 +175,20 @@ class host_future(object):
         host_future._in_flight.append(self)
 
     def done(self):
-        return self._arr is not None or (self._job is not None and self._job.done())
+        if self._arr is not None:
+            return True
+        if self._job is not None:
+            return self._job.done()
+        return self._lazy is not None and self._lazy[0].query()  # lazy: the copy has landed (result() then costs nothing)
 
     def result(self):
         if self._arr is None:
             if self._job is not None:
                 self._arr = self._job.result()
             else:
-                ev, h, free, _ = self._lazy
+                ev, h, _ = self._lazy
                 ev.synchronize()
-                self._arr = h.numpy().copy()
-                free.append(h)
+                self._arr = h.numpy()  # (a view: the array keeps the pinned tensor alive and torch recycles its block afterwards)
                 self._lazy = None
         return self._arr
 
