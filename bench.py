@@ -15,14 +15,15 @@ qest.library.get_sim_qlm_mf: every rank reconstructs its share jobs[rank::size] 
 scaling, run_qlms.py:72), the running sum stays on the device and one RCCL all-reduce completes it
 (plancklens_amd/parallel.py); then the last gradient alm of every rank is all-gathered over xGMI.  The library serves
 its share two simulations at a time (the spin-2 and spin-3 leg syntheses of a pair share one Legendre recursion each,
-pl_alm2map_batch2; PLENS_BATCH2=0 evaluates them one by one): a step is still one reconstruction.
+pl_alm2map_batch2; PLENS_OPTIONS=batch2=0 evaluates them one by one): a step is still one reconstruction.
 
 Prints ONE JSON line (rank 0).
  * `roofline`: the Legendre kernel with the largest summed time inside the timed region (HIP events on the launch
    stream, pl_profile_*).  The binding ceiling is FP64 vector-FMA issue, reported under the "mfma" (TFLOP/s) arm of the
    schema: gfx950's FP64 MFMA peak equals its FP64 vector peak and no MFMA is used (a recurrence, not a contraction).
-   `achieved` counts EXECUTED flops (the (l, m, ring pair) steps the kernel runs: what is left after libsharp-style polar pruning,
-   from the step at which the plan's seed table starts each wavefront -- pl_plan_executed_steps); the fixed-denominator count of SURVEY.md 8(d) (no pruning credit) is reported beside it as `achieved_fixed_denominator`.
+   `achieved` / `frac` follow SURVEY.md 8(d): the ALGORITHMIC flop count of a launch (no credit for pruned rings or skipped steps) / its mean
+   duration; `achieved_executed` / `frac_executed` count the flops the kernel really issues (pl_plan_executed_steps), `frac_of_measured_issue_ceiling`
+   relates those to the FMA rate a pure loop of the same operand mix sustains on this GPU in this process.
  * `kernels`: every timed stage (per launch; ring-FFT GB/s per component).
  * `cg`: BASELINE config 4 (cinv_t + cinv_p, masked sky, 100 top-level iterations, dense preconditioner cached outside
    the timed region), rank 0 at N = 1 only.
@@ -113,7 +114,11 @@ def executed_flops(nside, lmax, spin):
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=None, help='timed reconstructions per GPU (default 10; 32 with --config 5: 256 simulations over 8 GPUs)')
+    ap.add_argument('--config', type=int, default=None, choices=[1, 2, 3, 4, 5],
+                    help="a BASELINE.json configuration by number: 1 = 'ptt' nside=lmax=512; 2 = 'ptt' 2048; 3 = 'p_p' 2048; 4 = the default line (MV 'p' at 2048 "
+                         "with its CG block: config 4 is the `cg` object); 5 = MV 'p' nside=lmax=4096, 32 simulations per GPU (256 over 8 GPUs, sim-sharded + "
+                         "RCCL all-reduce / all-gather), no CG / CPU legs.  Sets --nside / --lmax / --key (and --steps unless given)")
     ap.add_argument('--warmup', type=int, default=4, help='untimed reconstructions (the GPU needs ~0.1 s of work to reach its sustained clocks)')
     ap.add_argument('--nside', type=int, default=2048)
     ap.add_argument('--lmax', type=int, default=2048)
@@ -131,7 +136,18 @@ def parse(argv=None):
     ap.add_argument('--plan-opt', action='append', default=[], metavar='NAME=VALUE',
                     help='pl_plan_opts field for every plan of the run (shts.plan_options), e.g. fft_legacy=1: a development aid, not a number to quote')
     ap.add_argument('--no-plan-stats', action='store_true', help='skip the nside-4096 plan-creation measurement (time and host memory of the table build)')
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.config is not None:
+        nside, key = {1: (512, 'ptt'), 2: (2048, 'ptt'), 3: (2048, 'p_p'), 4: (2048, 'p'), 5: (4096, 'p')}[args.config]
+        args.nside = args.lmax = nside
+        args.key = key
+        if args.config == 5:
+            args.no_cg = args.no_cpu_baseline = args.no_plan_stats = True
+            if args.steps is None:
+                args.steps = 32
+    if args.steps is None:
+        args.steps = 10
+    return args
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -321,6 +337,96 @@ def cpu_baseline(nside, lmax, budget_seconds, reps=3):
                       % (sample, nside, lmax, ncores, os.cpu_count() or 1, nrep, t, ts[0], ts[-1], flop_rec / sec_per_rec / ncores / 1e9, flop_rec)}
 
 
+def _healpy_sequence(hp, nside, lmax):
+    """(seconds, (G, C)) of one 'p' reconstruction as the reference runs it, on the module `hp` (healpy, or a stand-in with its signatures): the
+    hp.* calls in the reference's order with numpy between them -- isotropic filter (filt_simple.py:397-407), the polarization and temperature
+    estimators (qest.py:248-285 over lib_filt2map_sepTP.get_irespmap / get_gpmap(3) / get_gpmap(1) / get_irestmap / get_gtmap, :506-530,
+    :566-638) and their sum (:318-322).  Inputs: seeded random maps, unit filters above l = 1, C^TE = 0.1 (the cost does not depend on the values)."""
+    rng = np.random.default_rng(5)
+    npix = 12 * nside ** 2
+    tmap, qmap, umap = rng.standard_normal((3, npix))
+    fl = np.ones(lmax + 1)
+    fl[:2] = 0.
+    clte = 0.1 * fl
+    lw = -np.sqrt(np.arange(lmax + 1, dtype=float) * np.arange(1, lmax + 2))  # qest.py:260,282
+
+    def gp_fl(spin):  # qest.py:494-501
+        f = (np.arange(2, lmax + 3, dtype=float) * np.arange(-1, lmax)) if spin == 1 else (np.arange(-2, lmax - 1, dtype=float) * np.arange(3, lmax + 4))
+        f[:spin] *= 0.
+        return np.sqrt(f)
+
+    t0 = time.perf_counter()
+    tlm = hp.almxfl(hp.map2alm(tmap, lmax=lmax, iter=0), fl)                                  # filt_simple.py:397-401
+    elm, blm = hp.map2alm_spin([qmap, umap], 2, lmax=lmax)                                    # :403-407
+    elm, blm = hp.almxfl(elm, fl), hp.almxfl(blm, fl)
+    # polarization estimator (qest.py:265-285)
+    repmap, impmap = hp.alm2map_spin([elm * 0.5, blm * 0.5], nside, 2, lmax)                      # get_irespmap, qest.py:521-530
+    ewf, bwf = hp.almxfl(elm, fl) + hp.almxfl(tlm, clte), hp.almxfl(blm, fl)                  # Wiener-filtered E (with C^TE T), B
+    Gs, Cs = hp.alm2map_spin([hp.almxfl(ewf, gp_fl(3)), hp.almxfl(bwf, gp_fl(3))], nside, 3, lmax)  # get_gpmap(idx, 3), :597-638
+    GC = (repmap - 1j * impmap) * (Gs + 1j * Cs)
+    Gs, Cs = hp.alm2map_spin([hp.almxfl(ewf, gp_fl(1)), hp.almxfl(bwf, gp_fl(1))], nside, 1, lmax)  # get_gpmap(idx, 1)
+    GC -= (repmap + 1j * impmap) * (Gs - 1j * Cs)
+    del repmap, impmap, Gs, Cs
+    GP, CP = hp.map2alm_spin([GC.real, GC.imag], 1, lmax=lmax)
+    del GC
+    hp.almxfl(GP, lw, inplace=True)
+    hp.almxfl(CP, lw, inplace=True)
+    # temperature estimator (qest.py:248-263)
+    tb = hp.alm2map(tlm, nside, lmax=lmax)                                                    # get_irestmap, :506-514
+    twf = hp.almxfl(tlm, fl) + hp.almxfl(elm, clte)
+    G, C = hp.alm2map_spin([hp.almxfl(twf, lw), np.zeros_like(twf)], nside, 1, lmax)        # get_gtmap, :566-593
+    G *= tb
+    C *= tb
+    GT, CT = hp.map2alm_spin([G, C], 1, lmax=lmax)
+    hp.almxfl(GT, lw, inplace=True)
+    hp.almxfl(CT, lw, inplace=True)
+    out = GP + GT, CP + CT                                                                    # :318-322
+    return time.perf_counter() - t0, out
+
+
+def _cpu_baseline_healpy_estimate(hp, nside, lmax):
+    return _healpy_sequence(hp, nside, lmax)[1]
+
+
+def cpu_baseline_healpy(hp, nside, lmax, budget_seconds, reps=3):
+    """BASELINE.md section 2 / SURVEY.md 8(d), first choice: if `import healpy` succeeds on the box, the reference path itself (_healpy_sequence)
+    timed on the host cores.  OpenMP threads of healpy's libsharp: OMP_NUM_THREADS as found, reported."""
+    ncores = usable_cpus()
+
+    def one():
+        return _healpy_sequence(hp, nside, lmax)
+
+    t_first, _ = one()  # warm-up (also the cost estimate)
+    nrep = int(max(1, min(reps, budget_seconds // max(t_first, 1e-9) - 1)))
+    ts = sorted(one()[0] for _ in range(nrep))
+    t = ts[len(ts) // 2]
+    nalm = (lmax + 1) * (lmax + 2) // 2
+    flop_rec = (2 * 8 + 7 * 24) * float(nalm) * 2 * nside
+    return {'value': 1.0 / t, 'unit': 'reconstructions/s', 'cores': ncores, 'kind': 'healpy', 'repetitions': nrep, 'seconds_per_reconstruction': t,
+            'gflops_per_core': flop_rec / t / ncores / 1e9, 'healpy_version': getattr(hp, '__version__', None),
+            'omp_num_threads': os.environ.get('OMP_NUM_THREADS'),
+            'sample': "the reference's own call sequence for one 'p' reconstruction on healpy %s (filt_simple.py:397-407 + qest.py:248-285,318-322: 2 scalar + "
+                      "7 spin-weighted transforms, every ring, numpy between them) at nside=%d lmax=%d; 1 warm-up + %d repetition(s), median %.2f s "
+                      "(min %.2f, max %.2f); %d usable CPUs, OMP_NUM_THREADS=%s" % (getattr(hp, '__version__', '?'), nside, lmax, nrep, t, ts[0], ts[-1], ncores,
+                                                                                  os.environ.get('OMP_NUM_THREADS'))}
+
+
+def cpu_baseline_any(nside, lmax, budget_seconds):
+    """healpy if it can be imported on this box (the reference path itself, kind 'healpy'), the in-repo restatement otherwise (kind 'port')"""
+    try:
+        import healpy
+    except Exception:
+        healpy = None
+    if healpy is not None:
+        try:
+            return cpu_baseline_healpy(healpy, nside, lmax, budget_seconds)
+        except Exception as e:  # a healpy that imports but cannot run the sequence: say so, fall back
+            res = cpu_baseline(nside, lmax, budget_seconds)
+            res['healpy_error'] = repr(e)
+            return res
+    return cpu_baseline(nside, lmax, budget_seconds)
+
+
 def stub_rank(args, rank, world):
     """Launcher self-test (PLBENCH_STUB=1, tests/test_bench_launcher.py): gloo on CPU, no GPU work, no number."""
     import torch
@@ -371,7 +477,7 @@ def run_rank(args):
     from plancklens_amd.helpers import mpi
     mpi.rank, mpi.size = rank, world
 
-    from plancklens_amd import dev, hp, parallel, qest, shts, utils
+    from plancklens_amd import dev, hp, options, parallel, qest, shts, utils
     from plancklens_amd.filt import filt_simple
 
     nside, lmax, key = args.nside, args.lmax, args.key
@@ -417,7 +523,7 @@ def run_rank(args):
     K = args.steps
     # set-up, not a step: the paired-simulation transforms are run once on zeros so that their workspaces (four-component phase
     # array, second coefficient array) exist and their code objects are loaded before anything is timed
-    if key == 'p' and os.environ.get('PLENS_BATCH2', '1') != '0':
+    if key == 'p' and options.opts.batch2:
         z = torch.zeros((2, hp.Alm.getsize(lmax)), dtype=torch.complex128, device='cuda')
         for spin in (2, 3):
             shts.alm2map_spin_batch2([z[0], z[1]], [z[0], z[1]], nside, spin, lmax)
@@ -427,7 +533,7 @@ def run_rank(args):
     # set-up, not steps: the library captures a pair of reconstructions into a HIP graph after `graph_after` eager pairs (qest.library.
     # _pair_graph); whatever the warm-up count, the capture and a first replay happen here, before anything is timed
     graphed = False
-    if not args.qe_only and qlms._pair_getter(key, lmax_qlm) is not None and os.environ.get('PLENS_QE_GRAPH', '1') != '0':
+    if not args.qe_only and qlms._pair_getter(key, lmax_qlm) is not None and options.opts.qe_graph:
         for rep in range(qlms.graph_after + 3):
             if any(isinstance(g.get('graph'), torch.cuda.CUDAGraph) and not g.get('first', False) for g in getattr(qlms, '_pair_graphs', {}).values()):
                 graphed = True
@@ -496,6 +602,15 @@ def run_rank(args):
         idx_last = last_dev_key[1]
         g_single = np.asarray(dev.resolve(single[key](idx_last)[0]))
         selfcheck = float(np.max(np.abs(g_single - g_timed)))
+    # device memory: the plan of the benchmarked grid with the tables of every spin the key used (geometry, recursion coefficients, ring-FFT tables,
+    # seed tables per kernel family: pl_plan_bytes; hipMalloc, not the framework's allocator), the framework allocator's peak, and what the
+    # driver reports as used (everything, this process's share of the GPU)
+    free_b, total_b = torch.cuda.mem_get_info()
+    mem_stats = {'plan_device_mb': plan.bytes() / 2. ** 20, 'torch_peak_allocated_mb': torch.cuda.max_memory_allocated() / 2. ** 20,
+                 'torch_peak_reserved_mb': torch.cuda.max_memory_reserved() / 2. ** 20, 'device_used_mb': (total_b - free_b) / 2. ** 20,
+                 'device_total_mb': total_b / 2. ** 20,
+                 'note': 'after the timed region; plan_device_mb = pl_plan_bytes of the (nside, lmax) plan incl. the seed tables of every spin used so far; '
+                         'device_used_mb = total - free of hipMemGetInfo (all plans, workspaces, the caching allocator, captured graphs)'}
     ranks_seen = world
     dt_ranks = [dt]
     if use_dist:
@@ -574,7 +689,7 @@ def run_rank(args):
         exec_spin, exec_scal = executed_flops(nside, lmax, 2), executed_flops(nside, lmax, 0)
         # what the kernels run since round 5: the plan's seed tables start every wave where its recursion-only phase would have ended
         # (pl_plan_executed_steps: steps from there on, every ring-pair slot of a running wave counted), by kernel family
-        exec_by_family = {}
+        exec_by_family, exe_useful = {}, {}
         try:
             from plancklens_amd import _lib as _plib
             hpl = shts.get_plan(nside, lmax).h
@@ -582,6 +697,9 @@ def run_rank(args):
                 st_ = int(_plib.lib().pl_plan_executed_steps(hpl, sp, fam))
                 if st_ >= 0:
                     exec_by_family[nm] = st_ * fl_
+                su_ = int(_plib.lib().pl_plan_useful_steps(hpl, sp, fam))
+                if su_ >= 0:
+                    exe_useful[nm] = su_ * fl_
         except Exception:
             exec_by_family = {}
         npix = hp.nside2npix(nside)
@@ -593,9 +711,11 @@ def run_rank(args):
             'ms_per_step_by_rank': [1e3 * x / K for x in dt_ranks],
             'selfcheck_max_abs_diff': selfcheck,  # timed route vs single-simulation eager route, same simulation (rank 0); must be 0.0
             'graph_replay': graphed,  # timed region = replayed HIP graphs of reconstruction pairs (qest.library._pair_graph)
+            'options': options.opts.as_dict(),  # the host layer's run-time options (plancklens_amd/options.py; PLENS_OPTIONS)
             # sum |mf_lm|^2 of the mean field the timed region produced (all ranks' simulations: after the all-reduce every rank holds it)
             'mean_field_checksum': float(np.sum(np.abs(mf) ** 2)),
             'plan_create': {'nside': nside, 'lmax': lmax, 'seconds': plan_create_s},
+            'memory': mem_stats,
             'config': {'workload': "'%s' MV quadratic estimator from T,Q,U maps: isotropic filter + qest.library_sepTP, "
                                    "nside=%d lmax_ivf=%d lmax_qlm=%d, 9 SHTs (2 scalar + 7 spin pairs) per reconstruction (BASELINE.json headline config); "
                                    "timed region = qest.library.get_sim_qlm_mf over %d simulations (%d per GPU) + all-gather of the last qlm"
@@ -631,6 +751,8 @@ def run_rank(args):
             ent = {'avg_ms': m_ / c_, 'launches': c_, 'share_of_step': m_ / (1e3 * dt_prof)}
             if k in alg:
                 ent['executed_tflops'] = exe[k] / (m_ / c_ * 1e-3) / 1e12
+                if k in exe_useful:
+                    ent['executed_useful_tflops'] = exe_useful[k] / (m_ / c_ * 1e-3) / 1e12
                 ent['fixed_denominator_tflops'] = alg[k] / (m_ / c_ * 1e-3) / 1e12
             elif k in comps_per_launch:
                 ent['components_per_launch'] = comps_per_launch[k]
@@ -648,19 +770,30 @@ def run_rank(args):
             avg_ms = ms / cnt
             ach = exe[dom] / (avg_ms * 1e-3) / 1e12
             fixed = alg[dom] / (avg_ms * 1e-3) / 1e12
+            useful = exe_useful.get(dom)
             pmc_bytes, pmc_source = pmc_traffic()
-            res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP64_PEAK_TFLOPS,
+            ceil = fma_ceilings()
+            # the FMA mix of the dominant kernel: analysis accumulates with three vector sources, synthesis with a scalar coefficient operand
+            mix = 'three_vector_sources (analysis mix)' if 'anal' in dom else 'two_scalar_sources (synthesis mix)'
+            res['roofline'] = {'bound': 'mfma', 'achieved': fixed, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': fixed / FP64_PEAK_TFLOPS,
                                'traffic': pmc_bytes.get(dom) if (nside, lmax) == (2048, 2048) else None, 'traffic_source': pmc_source,
                                'kernel': KERNEL_NAMES.get(dom, dom), 'avg_launch_ms': avg_ms, 'launches': cnt,
                                'share_of_step': ms / (1e3 * dt_prof),
-                               'achieved_fixed_denominator': fixed, 'frac_fixed_denominator': fixed / FP64_PEAK_TFLOPS,
-                               'fma_issue_ceiling_measured_tflops': fma_ceilings(),
-                               'note': 'dominant kernel = largest summed time in the timed region. FP64 vector-FMA issue bound (v_fma_f64); gfx950 FP64 MFMA '
-                                       'peak = FP64 vector peak; no MFMA used. achieved = EXECUTED flops (the (l, m, ring pair) steps the kernel runs: after '
-                                       'libsharp-style polar pruning and from the step its seed table starts each wavefront at, pl_plan_executed_steps) / mean launch time (HIP events on the launch stream); achieved_fixed_denominator = '
-                                       'SURVEY 8(d) count (24 or 8 flop x nalm x 2 nside, pruning not credited). peak = datasheet 78.6 TF; '
-                                       'fma_issue_ceiling_measured_tflops is what a pure FMA loop sustains on this GPU by operand mix. '
-                                       'traffic = FETCH_SIZE + WRITE_SIZE bytes per launch (%s: PMC passes of the same kernel)' % pmc_source}
+                               'achieved_executed': ach, 'frac_executed': ach / FP64_PEAK_TFLOPS,
+                               'achieved_executed_useful': None if useful is None else useful / (avg_ms * 1e-3) / 1e12,
+                               'frac_of_measured_issue_ceiling': ach / ceil[mix] if ceil.get(mix) else None,
+                               'issue_ceiling_mix': mix,
+                               'fma_issue_ceiling_measured_tflops': ceil,
+                               'note': 'dominant kernel = largest summed time in the timed region. FP64 vector-FMA issue bound (v_fma_f64), reported under the "mfma" '
+                                       '(TFLOP/s) arm of the schema: gfx950 FP64 MFMA peak = FP64 vector peak, and NO MFMA instruction is used (a recurrence, not a '
+                                       'contraction). achieved / frac = SURVEY 8(d) ALGORITHMIC count (24 or 8 flop x nalm x 2 nside per launch, no credit for pruned '
+                                       'rings or for the steps the seed tables skip -- so it is no ceiling: it can exceed what is executed) / mean launch time (HIP '
+                                       'events on the launch stream) against the datasheet 78.6 TF. achieved_executed / frac_executed = the flops the kernel really '
+                                       'issues (every ring-pair slot of every running wavefront from the step its seed table starts it at, pl_plan_executed_steps); '
+                                       'achieved_executed_useful counts only slots holding an unpruned ring (pl_plan_useful_steps). frac_of_measured_issue_ceiling = '
+                                       'achieved_executed / the rate a pure FMA loop of the same operand mix sustains on this GPU in this process '
+                                       '(fma_issue_ceiling_measured_tflops). traffic = FETCH_SIZE + WRITE_SIZE bytes per launch (%s: PMC passes of the same kernel)'
+                                       % pmc_source}
         # whole-reconstruction algorithmic traffic (counting rule of SURVEY.md 8(d))
         b_scal = 8.0 * npix + 16.0 * nalm
         b_spin = 2 * b_scal
@@ -683,11 +816,22 @@ def run_rank(args):
             t0p = time.perf_counter()
             p4 = shts.Plan(4096, 4096)
             t4 = time.perf_counter() - t0p
+            mb0 = p4.bytes() / 2. ** 20
+            t0s = time.perf_counter()
+            from plancklens_amd import _lib as _plib4
+            by_spin = {}
+            for sp in (1, 2, 3):  # first use of a spin builds its recursion tables (host) and seed tables (device): the MV estimator uses all three
+                b_before = p4.bytes()
+                assert _plib4.lib().pl_plan_executed_steps(p4.h, sp, 0) != 0
+                by_spin[str(sp)] = (p4.bytes() - b_before) / 2. ** 20
+            t4s = time.perf_counter() - t0s
             rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
-            res['plan_create']['nside_4096'] = {'seconds': t4, 'host_peak_rss_growth_mb': (rss1 - rss0) / 1024., 'host_peak_rss_mb': rss1 / 1024.,
+            res['plan_create']['nside_4096'] = {'seconds': t4, 'spin_tables_seconds': t4s, 'host_peak_rss_growth_mb': (rss1 - rss0) / 1024.,
+                                                'host_peak_rss_mb': rss1 / 1024., 'device_mb_spin0': mb0, 'device_mb_by_spin': by_spin,
                                                 'device_mb': p4.bytes() / 2. ** 20,
-                                                'note': 'pl_plan_create(4096, 4096) in this process after the 2048 run: geometry + spin-0 recursion + ring-FFT '
-                                                        'tables (spin tables are built on first use of a spin: +1 table set each)'}
+                                                'note': 'pl_plan_create(4096, 4096) in this process after the 2048 run, then the tables of spins 1, 2, 3 (built on '
+                                                        "first use; the MV estimator of BASELINE config 5 uses all of them): device_mb = the plan's whole footprint "
+                                                        'incl. the seed tables of both kernel families of every spin'}
             del p4
         except Exception as e:
             res['plan_create']['nside_4096'] = {'error': repr(e)}
@@ -723,11 +867,12 @@ def run_rank(args):
                 res['cg'] = {'error': repr(e)}
         if not args.no_cpu_baseline:
             try:
-                res['cpu_baseline'] = cpu_baseline(nside, lmax, args.cpu_seconds)
+                res['cpu_baseline'] = cpu_baseline_any(nside, lmax, args.cpu_seconds)
             except Exception as e:
                 res['cpu_baseline'] = {'value': None, 'unit': 'reconstructions/s', 'cores': usable_cpus(), 'kind': 'port',
                                        'sample': 'failed: %r' % (e,)}
     if rank == 0:
+        res['graphs'] = dict(options.stats)  # HIP-graph captures of this process and the ones that failed and fell back to eager launches
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()

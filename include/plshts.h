@@ -77,6 +77,9 @@ void *pl_plan_side_stream(const pl_plan *plan, int i);
  * the plan's seed table (pl_plan_opts.seed_tables): (l, ring pair) steps for spin >= 1 (12 FMA each), two-l steps for spin 0 (6 FMA each);
  * every ring-pair slot of a wavefront that runs is counted.  -1 without a table.  For measurement tools (bench.py's executed flops). */
 int64_t pl_plan_executed_steps(pl_plan *plan, int spin, int fam);
+/* The same count restricted to the slots that hold a ring which keeps the order (ring pair < npairs, m <= its pruning limit): the steps
+ * whose results are used -- the difference is lanes of running wavefronts that ride along on pruned rings or padding. */
+int64_t pl_plan_useful_steps(pl_plan *plan, int spin, int fam);
 
 /* One transform over several GPUs ("m-blocks shard across the GPUs", BASELINE.json north_star; the reference's only parallelism
  * inside a transform is the third-party library's threads, shts.py:10).  Shard `rank` of `nranks`:

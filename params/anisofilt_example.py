@@ -8,7 +8,7 @@ mask live on NERSC, and hp.pixwin needs a data file packaged inside healpy; here
 fiducial lensed spectra, the transfer function is the 5' beam alone and the mask is synthetic (a |b| < 20 deg band plus 200
 one-degree discs, fsky ~ 0.65: the mask of BASELINE config 4, tools/cg_bench.py).  The N1 library (n1f Fortran) is not provided.
 The driver (examples/run_qlms.py -ivt -ivp) filters each rank's simulations several at a time in block solves of the CG
-(library_cinv_sepTP.filter_sims, $PLENS_CG_BATCH right-hand sides per solve, default 4).
+(library_cinv_sepTP.filter_sims, options.opts.cg_batch right-hand sides per solve, default 4; PLENS_OPTIONS=cg_batch=N).
 Sizes can be reduced through the environment for quick runs: PLENS_NSIDE (>= 512), PLENS_LMAX (>= 1024), PLENS_NSIMS.
 """
 import os

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -105,7 +106,8 @@ struct pl_plan {
     DevFFT F{};
     FftStreams fs{};
     DevSpinTab S[kMaxSpin + 1]{};
-    bool have_spin[kMaxSpin + 1] = {false, false, false, false};
+    // published with a release store once S / nent / the seed tables of the spin are complete, read with an acquire load on the lock-free fast path
+    std::atomic<bool> have_spin[kMaxSpin + 1] = {};
     int64_t nent[kMaxSpin + 1] = {0, 0, 0, 0};
     std::vector<void *> allocs;
     bool seed_tables = true;    // pl_plan_opts.seed_tables
@@ -219,7 +221,7 @@ static int ensure_spin_locked(pl_plan *p, int spin);
 static int ensure_spin(pl_plan *p, int spin)
 {
     if (spin < 1 || spin > kMaxSpin) return fail("spin must be 1, 2 or 3");
-    if (p->have_spin[spin]) return 0;
+    if (p->have_spin[spin].load(std::memory_order_acquire)) return 0;
     std::lock_guard<std::recursive_mutex> lock(g_spin_mutex);
     try {
         return ensure_spin_locked(p, spin);
@@ -230,12 +232,12 @@ static int ensure_spin(pl_plan *p, int spin)
 
 static int ensure_spin_locked(pl_plan *p, int spin)
 {
-    if (p->have_spin[spin]) return 0;
+    if (p->have_spin[spin].load(std::memory_order_acquire)) return 0;
     if (p->parent) {  // tables live in the parent
         if (ensure_spin_locked(p->parent, spin)) return 1;
         p->S[spin] = p->parent->S[spin];
         p->nent[spin] = p->parent->nent[spin];
-        p->have_spin[spin] = true;
+        p->have_spin[spin].store(true, std::memory_order_release);
         return 0;
     }
     SpinTables t;
@@ -255,7 +257,7 @@ static int ensure_spin_locked(pl_plan *p, int spin)
     S.gstart = nullptr;
     p->nent[spin] = t.off.back();
     build_seed_tables(p, spin);
-    p->have_spin[spin] = true;
+    p->have_spin[spin].store(true, std::memory_order_release);
     return 0;
 }
 
@@ -351,7 +353,7 @@ static int plan_create_body(int nside, int lmax, int rank, int nranks, const pl_
     // kernel.  opts.fft_legacy sends every pair to the generic kernel.  (Plan options are arguments of pl_plan_create_opts, not
     // environment variables: two plans of one process differ only where the caller said so.)
     DevFFT &F = p->F;
-    const bool all_legacy = opts.fft_legacy != 0;
+    const bool all_legacy = opts.fft_legacy > 0;  // (negative = "the measured default" like every other field: off)
     std::vector<int> K2of(nside + 1, 0), MofA(nside + 1, 0), clsA(nside + 1, -1), splitA(nside + 1, 0);
     // smallest half-size for which a Bluestein ring is split into two half-size convolutions (opts.fft_split_min: 0 = never)
     const int split_min = opts.fft_split_min >= 0 ? opts.fft_split_min : 512;
@@ -619,7 +621,7 @@ int64_t pl_plan_bytes(const pl_plan *p) { return p ? p->bytes : 0; }
 // Recursion steps the Legendre kernels of a family (fam 0: synthesis, 1: analysis) of this plan execute per launch, from the plan's seed
 // table: sum over the live (m, ring group) waves of (steps of m - first step of the wave) x ring-pair slots of the wave (pruned and padded slots of
 // a live wave run along).  Units: (l, ring pair) steps for spin >= 1, two-l steps for spin 0.  -1: no table (every launch recurses from l = m).
-int64_t pl_plan_executed_steps(pl_plan *p, int spin, int fam)
+static int64_t executed_steps_impl(pl_plan *p, int spin, int fam, bool useful_only)
 {
     if (!p || spin < 0 || spin > kMaxSpin || fam < 0 || fam > 1) return -1;
     if (spin > 0 && ensure_spin(p, spin)) return -1;
@@ -634,11 +636,18 @@ int64_t pl_plan_executed_steps(pl_plan *p, int spin, int fam)
             return -1;
         int64_t steps = 0;
         for (int g = 0; g < ngroups; ++g) {
+            const int ip0 = g * T.rg, ip1 = std::min(P.npairs, (g + 1) * T.rg);
             int gl = -1;  // largest order any ring of the group keeps
-            for (int ip = g * T.rg; ip < std::min(P.npairs, (g + 1) * T.rg); ++ip) gl = std::max(gl, mlim[ip]);
+            for (int ip = ip0; ip < ip1; ++ip) gl = std::max(gl, mlim[ip]);
             for (int m = 0; m <= std::min(P.mmax, gl); ++m) {
                 const int n = spin == 0 ? (P.lmax - m) / 2 + 1 : P.lmax - std::max(m, spin) + 1;
-                if (n > 0) steps += (int64_t)std::max(0, n - il[(size_t)m * ngroups + g]) * T.rg;
+                if (n <= 0) continue;
+                int64_t slots = T.rg;
+                if (useful_only) {  // mlim is non-decreasing towards the equator: the rings of the group that keep order m are its last ones
+                    slots = 0;
+                    for (int ip = ip0; ip < ip1; ++ip) slots += mlim[ip] >= m;
+                }
+                steps += (int64_t)std::max(0, n - il[(size_t)m * ngroups + g]) * slots;
             }
         }
         return steps;
@@ -646,6 +655,10 @@ int64_t pl_plan_executed_steps(pl_plan *p, int spin, int fam)
         return -1;
     }
 }
+int64_t pl_plan_executed_steps(pl_plan *p, int spin, int fam) { return executed_steps_impl(p, spin, fam, false); }
+// The same count over the ring-pair slots that hold a ring which keeps the order (ip < npairs and m <= mlim[ip]): the steps whose results are
+// used.  pl_plan_executed_steps - pl_plan_useful_steps = lanes of live waves that run along on pruned rings or padding.
+int64_t pl_plan_useful_steps(pl_plan *p, int spin, int fam) { return executed_steps_impl(p, spin, fam, true); }
 void *pl_plan_side_stream(const pl_plan *p, int i) { return (p && p->fs.ok && i >= 0 && i < FftStreams::kN) ? (void *)p->fs.s[i] : nullptr; }
 
 int64_t pl_plan_phase_doubles(const pl_plan *p, int spin)

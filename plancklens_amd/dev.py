@@ -84,7 +84,8 @@ def concurrent_stream(beside=(), tries=8):
     torch's pool are tried (streams_overlap); the first one if none qualifies -- a stream that does not overlap is still correct."""
     beside = list(beside) or [torch.cuda.current_stream()]
     first = None
-    dbg = os.environ.get('PLENS_STREAM_DEBUG')
+    from . import options
+    dbg = options.opts.debug
     for i in range(tries):
         s = torch.cuda.Stream()
         first = first or s
@@ -151,7 +152,8 @@ class host_future(object):
         self._job = None
         cs = _copy_stream()
         cs.wait_stream(torch.cuda.current_stream())
-        nblk = int(os.environ.get('PLENS_D2H_BLOCKS', '64'))
+        from . import options
+        nblk = int(options.opts.d2h_blocks)
         with torch.cuda.stream(cs):
             if nblk > 0 and t.element_size() * t.numel() % 8 == 0 and t.data_ptr() % 16 == 0:
                 # pl_copy_slim: a few workgroups writing straight into the pinned (device-mapped) buffer
@@ -379,12 +381,14 @@ def alm_lincomb(outputs):
         for t, (alm, fl) in enumerate(terms):
             assert alm.dim() == 1 and alm.numel() == n and alm.dtype == torch.complex128 and alm.is_cuda
             alm = alm.contiguous()
-            keep.append(alm)
-            alms[2 * k + t], fls[2 * k + t] = alm.data_ptr(), fl_dev(fl, lmax).data_ptr()
+            f = fl_dev(fl, lmax)  # a tensor `fl` yields a fresh temporary: it must outlive the launch like the alms do
+            keep += [alm, f]
+            alms[2 * k + t], fls[2 * k + t] = alm.data_ptr(), f.data_ptr()
     nterm = (ctypes.c_int * nout)(*[len(o) for o in outputs])
     pa, pf = (ctypes.c_void_p * (2 * nout))(*alms), (ctypes.c_void_p * (2 * nout))(*fls)
     po = (ctypes.c_void_p * nout)(*[out[k].data_ptr() for k in range(nout)])
     _lib.check(_lib.lib().pl_alm_lincomb(lmax, nout, nterm, pa, pf, po, stream_ptr()))
+    del keep  # (alive until here: the caching allocator may hand a dropped block to the next fl_dev of the loop above)
     return [out[k] for k in range(nout)]
 
 

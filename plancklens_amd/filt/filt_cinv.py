@@ -12,7 +12,7 @@ import pickle as pk
 import numpy as np
 import torch
 
-from .. import dev, hp, utils
+from .. import dev, hp, options, utils
 from ..helpers import mpi
 from ..qcinv import cd_solve, multigrid, opfilt_pp, opfilt_tp, opfilt_tt, util, util_alm
 from . import filt_simple
@@ -57,9 +57,9 @@ def _tp_side_stream():
 
 
 def _p_context():
-    """the plan context of this library's polarization solves: P_CONTEXT unless $PLENS_TP_CONCURRENT = 0"""
+    """the plan context of this library's polarization solves: P_CONTEXT unless options.opts.tp_concurrent is off"""
     from .. import shts
-    return shts.plan_context(P_CONTEXT if os.environ.get('PLENS_TP_CONCURRENT', '1') != '0' else 0)
+    return shts.plan_context(P_CONTEXT if options.opts.tp_concurrent else 0)
 
 
 def run_tp(job_t, job_p, warm=True):
@@ -72,7 +72,7 @@ def run_tp(job_t, job_p, warm=True):
     warm=False: the same two jobs in the same contexts, one after the other on the calling thread -- used for the first solve of a
     shape, which allocates workspaces and captures the nested stages into HIP graphs.  Results are identical either way."""
     from .. import shts
-    if not warm or os.environ.get('PLENS_TP_CONCURRENT', '1') == '0':
+    if not warm or not options.opts.tp_concurrent:
         rt = job_t()
         with _p_context():
             rp = job_p()
@@ -122,7 +122,7 @@ def apply_ivf_tp(cinv_t, tmap, cinv_p, pmap, soltn_t=None, soltn_p=None):
     job_t = (lambda: cinv_t.apply_ivf_batch(tmap, soltns=soltn_t)) if blk_t else (lambda: cinv_t.apply_ivf(tmap, soltn=soltn_t))
     job_p = (lambda: cinv_p.apply_ivf_batch(pmap, soltns=soltn_p)) if blk_p else (lambda: cinv_p.apply_ivf(pmap, soltn=soltn_p))
     warm = key in warm_t and key in warm_p
-    paced = warm and os.environ.get('PLENS_TP_CONCURRENT', '1') != '0' and os.environ.get('PLENS_TP_PACE', '1') != '0'
+    paced = warm and options.opts.tp_concurrent and options.opts.tp_pace
     if paced:  # the two solves meet before every top-level preconditioner call (multigrid.pace)
         pc = multigrid.pace(2)
         util.unjit(cinv_t.chain).pace = util.unjit(cinv_p.chain).pace = pc
@@ -585,17 +585,17 @@ class library_cinv_sepTP(filt_simple.library_sepTP):
         """Filters (and caches) the simulations `idxs` that are not cached yet, `batch` at a time in block solves of the CG
         (cinv_t / cinv_p.apply_ivf_batch: every launch of a solve carries the whole block) -- what the driver's filtering phase
         calls instead of looping over get_sim_tlm / get_sim_elm one simulation at a time (run_qlms.py:57-62).  Same cache files, same
-        alms.  batch: block size (default $PLENS_CG_BATCH or 4; 1 = one solve per simulation); a filter that cannot take block
-        vectors (supports_block) is served one simulation at a time.  concurrent (default $PLENS_TP_CONCURRENT != 0): when both 't'
+        alms.  batch: block size (default options.opts.cg_batch = 4; 1 = one solve per simulation); a filter that cannot take block
+        vectors (supports_block) is served one simulation at a time.  concurrent (default options.opts.tp_concurrent): when both 't'
         and 'p' are asked for, the temperature and polarization solves of a block run at the same time on two streams of this
         process (apply_ivf_tp) instead of one after the other.  With cache=False the results only live in the device cache of
         _dev_slots simulations, which grows to the block size; more indices than that per call are solved again when asked for.
         Returns True (the wrappers of filt_util forward the call and report whether the library underneath took it)."""
         if batch is None:
-            batch = int(os.environ.get('PLENS_CG_BATCH', '4'))
+            batch = int(options.opts.cg_batch)
         batch = max(1, batch)
         if concurrent is None:
-            concurrent = os.environ.get('PLENS_TP_CONCURRENT', '1') != '0'
+            concurrent = bool(options.opts.tp_concurrent)
         for a in fields:
             assert a in 'tp', a
         fields = [a for a in 'tp' if a in fields]

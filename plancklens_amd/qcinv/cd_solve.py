@@ -1,7 +1,7 @@
 """Flexible conjugate-directions solver, API and algorithm of plancklens/qcinv/cd_solve.py (`cd_solve` :35-107,
 `cache_mem` :15-32, `tr_cg` / `tr_cd` / `PTR` :7-12).  The vectors are opaque objects supporting + - * += -=
 (numpy arrays, device tensors, eblm / teblm); all arithmetic on them happens wherever they live."""
-import os
+from .. import options
 
 import numpy as np
 
@@ -55,26 +55,16 @@ def cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache=None, roundoff=
         `parts(a, b)` (the scalar product in whatever device-resident form `axpy` accepts) and `axpy(y, x, num, den, sign)`
         (y += sign num / den x in place) every scalar product and vector update is one launch and the cache holds
         d^t A d instead of its inverse; with `step` and `ortho` as well the two scalar products of an iteration are one launch for
-        all fields and its two updates another (pl_cg_dot_axpy; PLENS_CG_MERGED=0 keeps them apart), likewise the
-        re-orthogonalisation.  PLENS_CG_ONE_LAUNCH=1 joins each pair with a grid-wide barrier: measured on MI355X that barrier costs
-        what the kernel boundary costs, so it is off by default.
+        all fields and its two updates another (pl_cg_dot_axpy; options.opts.cg_merged = False keeps them apart), likewise the
+        re-orthogonalisation.  (Joining each pair into one launch with a grid-wide barrier was measured on MI355X to cost what the
+        kernel boundary costs -- DESIGN.md sections 5 and 9 -- and is no longer a solver option; the C entry keeps the form.)
     """
     if cache is None:
         cache = cache_mem()
     n_pre = len(pre_ops)
     on_dev = n_pre == 1 and hasattr(dot_op, 'dev')
     fused = on_dev and hasattr(dot_op, 'axpy') and hasattr(dot_op, 'parts')
-    merged = fused and hasattr(dot_op, 'step') and hasattr(dot_op, 'ortho') and os.environ.get('PLENS_CG_MERGED', '1') != '0'
-    one_launch = merged and os.environ.get('PLENS_CG_ONE_LAUNCH', '0') == '1'
-    if one_launch:  # opt-in experiment: the grid barrier needs every workgroup co-resident; a barrier that gave up invalidates the solve
-        try:
-            return _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_is_zero, b_scratch, True, x_uninit)
-        finally:
-            from .. import dev
-            if dev.cg_barrier_timed_out(reset=True):
-                raise RuntimeError('PLENS_CG_ONE_LAUNCH: a grid barrier of pl_cg_dot_axpy timed out (workgroups not co-resident: '
-                                   'another kernel or process shares the GPU); the solve is invalid -- unset PLENS_CG_ONE_LAUNCH')
-    return _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_is_zero, b_scratch, False, x_uninit)
+    return _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_is_zero, b_scratch, x_uninit)
 
 
 def _zero(x):
@@ -85,12 +75,12 @@ def _zero(x):
         x.zero_() if hasattr(x, 'zero_') else x.fill(0.)
 
 
-def _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_is_zero, b_scratch, one_launch, x_uninit=False):
+def _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_is_zero, b_scratch, x_uninit=False):
     assert x_is_zero or not x_uninit
     n_pre = len(pre_ops)
     on_dev = n_pre == 1 and hasattr(dot_op, 'dev')
     fused = on_dev and hasattr(dot_op, 'axpy') and hasattr(dot_op, 'parts')
-    merged = fused and hasattr(dot_op, 'step') and hasattr(dot_op, 'ortho') and os.environ.get('PLENS_CG_MERGED', '1') != '0'
+    merged = fused and hasattr(dot_op, 'step') and hasattr(dot_op, 'ortho') and options.opts.cg_merged
     if x_is_zero and b_scratch:
         residual, b = b, None
     else:
@@ -105,8 +95,8 @@ def _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_i
         return it
     searchdirs = [op(residual) for op in pre_ops]
     # the two scalar products of a step from the kernel that writes fwd_op's result (fwd_op.with_dots, dot_op.step(pre=...)): one launch
-    # less per iteration (PLENS_CG_POST_DOTS=0: their own launch)
-    post_dots = merged and hasattr(fwd_op, 'with_dots') and os.environ.get('PLENS_CG_POST_DOTS', '1') != '0'
+    # less per iteration (options.opts.cg_post_dots = False: their own launch)
+    post_dots = merged and hasattr(fwd_op, 'with_dots') and options.opts.cg_post_dots
     while True:
         pre = None
         if post_dots:
@@ -132,7 +122,7 @@ def _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_i
             elif pre is not None:
                 dTAd, delta = dot_op.step(x, searchdirs[0], residual, searchfwds[0], update_r=not fresh_residual, pre=pre, **kw0)
             elif merged:  # both scalar products in one launch, both updates of all fields in another (or all in one)
-                dTAd, delta = dot_op.step(x, searchdirs[0], residual, searchfwds[0], update_r=not fresh_residual, one_launch=one_launch)
+                dTAd, delta = dot_op.step(x, searchdirs[0], residual, searchfwds[0], update_r=not fresh_residual)
             else:
                 dTAd = dot_op.parts(searchdirs[0], searchfwds[0])
                 delta = dot_op.parts(searchdirs[0], residual)
@@ -162,7 +152,7 @@ def _cd_solve(x, b, fwd_op, pre_ops, dot_op, criterion, tr, cache, roundoff, x_i
             for titer in range(tr(it), it):
                 prev_dTAd, prev_dirs, prev_fwds = cache.restore(titer)
                 if merged:
-                    dot_op.ortho(searchdirs[0], prev_fwds[0], prev_dirs[0], prev_dTAd, one_launch=one_launch)
+                    dot_op.ortho(searchdirs[0], prev_fwds[0], prev_dirs[0], prev_dTAd)
                 else:
                     dot_op.axpy(searchdirs[0], prev_dirs[0], dot_op.parts(searchdirs[0], prev_fwds[0]), prev_dTAd, -1.0)
             cache.trim(range(tr(it + 1), it))

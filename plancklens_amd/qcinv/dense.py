@@ -10,7 +10,7 @@ import pickle as pk
 import numpy as np
 import torch
 
-from .. import dev
+from .. import dev, options
 from ..hp import Alm
 from .util_alm import eblm, teblm
 
@@ -161,7 +161,7 @@ class _pre_op_dense(object):
         # The columns are fwd_op of the unit vectors (dense.py:77-84 applies it to one vector at a time: thousands of launch-bound
         # coarse operators).  Here nbk unit vectors go through the operator as one block vector -- every launch carries all of them,
         # each column bit-identical to the one-at-a-time result; an operator that does not take blocks gets them one by one.
-        nbk = max(1, min(int(os.environ.get('PLENS_DENSE_BLOCK', '32')), 64))
+        nbk = max(1, min(int(options.opts.dense_block), 64))
         i0 = 0
         while i0 < nrlm:
             n_ = min(nbk, nrlm - i0)

@@ -8,13 +8,13 @@ from __future__ import print_function
 
 import copy
 import gc
-import os
 import re
 import sys
 
 import numpy as np
 import torch
 
+from .. import options
 from . import cd_monitors, cd_solve, util, util_alm
 
 
@@ -279,9 +279,10 @@ class pre_op_multigrid(object):
     # such preconditioner is captured into a HIP graph (torch.cuda.CUDAGraph; the kernels of libplshts are launched on
     # torch's current stream, so they are captured with everything else) and replayed from then on.
     graph_after = 2
+    graph_fallbacks = 0  # captures of this stage that failed (it then stays eager)
 
     def _capturable(self, talm):
-        if os.environ.get('PLENS_CG_GRAPH', '1') == '0' or self.iter_max == np.inf or self.eps_min != 0.:
+        if not options.opts.cg_graph or self.iter_max == np.inf or self.eps_min != 0.:
             return False
         if self.quiet is None or not self.quiet():
             return False
@@ -318,9 +319,11 @@ class pre_op_multigrid(object):
                     if gc_was_on:
                         gc.enable()
                 st['out'], st['graph'] = _parts(out), g
-            except Exception as e:  # capture is an optimisation: fall back to the eager path for good
-                print('pre_op_multigrid: graph capture failed (%s); staying eager' % str(e).split('\n')[0])
-                if os.environ.get('PLENS_CG_GRAPH_DEBUG'):
+                options.count('cg_graph_captures')
+            except Exception as e:  # capture is an optimisation: fall back to the eager path for good -- counted (options.stats), not printed
+                self.graph_fallbacks += 1
+                options.count('cg_graph_fallbacks', 'pre_op_multigrid depth %s: %s' % (getattr(self, 'depth', '?'), str(e).split('\n')[0]))
+                if options.opts.debug:
                     import traceback
                     traceback.print_exc()
                 torch.cuda.synchronize()

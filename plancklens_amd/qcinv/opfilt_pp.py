@@ -3,12 +3,11 @@
 `calc_prep` :306-317, `apply_fini` :320-324).  Vectors are util_alm.eblm pairs of device tensors."""
 from __future__ import print_function
 
-import os
 
 import numpy as np
 import torch
 
-from .. import dev, hp, shts
+from .. import dev, hp, options, shts
 from ..utils import clhash
 from . import dense, template_removal, util
 from .util_alm import eblm
@@ -37,7 +36,7 @@ class dot_op(object):
         dev.axpy_dev(y.blm, x.blm, num, den, sign)
 
     @staticmethod
-    def step(x, d, r, q, update_r=True, one_launch=False, active=None, pre=None, x_init=False):
+    def step(x, d, r, q, update_r=True, active=None, pre=None, x_init=False):
         """one conjugate-directions update, all fields in two launches (or one with a grid barrier): dTAd = <d, q>, delta = <d, r>,
         x += (delta / dTAd) d and, if update_r, r -= (delta / dTAd) q; returns (dTAd, delta) as `parts` does.
         active (block vectors): 0 / 1 per entry, multiplies the step lengths.
@@ -49,17 +48,17 @@ class dot_op(object):
                                    assign_y1=x_init)
         assert not x_init
         return dev.cg_dot_axpy(f(d), f(q), f(x), f(d), 1.0, b2=f(r), y2=f(r) if update_r else None, x2=f(q) if update_r else None,
-                               sign2=-1.0, lmin=2, one_launch=one_launch, active=active)
+                               sign2=-1.0, lmin=2, active=active)
 
     @staticmethod
-    def ortho(s, pq, pd, prev_dtad, one_launch=False, pre=None):
+    def ortho(s, pq, pd, prev_dtad, pre=None):
         """s -= (<s, pq> / prev_dtad) pd, all fields in two launches (or one with a grid barrier).
         pre: <s, pq> as partial sums left by the preconditioner kernel(s) that wrote s (pre_op.with_dot): the update alone"""
         f = (lambda v: [v.elm, v.blm])
         if pre is not None:
             dev.cg_axpy_pre((pre, None), f(s), f(pd), -1.0, den=prev_dtad)
             return
-        dev.cg_dot_axpy(f(s), f(pq), f(s), f(pd), -1.0, den=prev_dtad, lmin=2, one_launch=one_launch)
+        dev.cg_dot_axpy(f(s), f(pq), f(s), f(pd), -1.0, den=prev_dtad, lmin=2)
 
     def __call__(self, alm1, alm2):
         p = self.parts(alm1, alm2)
@@ -284,7 +283,7 @@ class alm_filter_ninv(object):
         self._load_ninv()
         same_b = self.b_transf_b is self.b_transf_e or np.array_equal(self.b_transf_e, self.b_transf_b)
         # (templates: as a rank-nmodes update in harmonic space, single vectors only -- the (E, B) pair of a block entry is not contiguous)
-        harm = (self.wmarg and os.environ.get('PLENS_TPROJ_HARM', '1') != '0' and isinstance(alm.elm, torch.Tensor) and alm.elm.dim() == 1
+        harm = (self.wmarg and options.opts.tproj_harm and isinstance(alm.elm, torch.Tensor) and alm.elm.dim() == 1
                 and len(self.n_inv) == 1 and len(self.marge_qmaps) + len(self.marge_umaps) <= dev.TEMPLATE_MAX_MODES)
         return (isinstance(alm.elm, torch.Tensor) and alm.elm.is_cuda and len(self.n_inv) in (1, 3) and (not self.wmarg or harm) and same_b
                 and alm2map_spin is shts.alm2map_spin and map2alm_spin is shts.map2alm_spin and not shts.lane_active()

@@ -6,12 +6,11 @@ Y = (alm2map, alm2map_spin 2) and Y^t = npix / 4 pi (map2alm, map2alm_spin 2) ru
 the transforms; the inverse-noise maps, the T template projector and every CG vector live in HBM."""
 from __future__ import print_function
 
-import os
 
 import numpy as np
 import torch
 
-from .. import dev, hp, shts
+from .. import dev, hp, options, shts
 from ..utils import clhash
 from . import dense, template_removal, util
 from .util_alm import teblm
@@ -75,19 +74,19 @@ class dot_op(object):
         dev.axpy_dev(y.blm, x.blm, num, den, sign)
 
     @staticmethod
-    def step(x, d, r, q, update_r=True, one_launch=False, active=None):
+    def step(x, d, r, q, update_r=True, active=None):
         """one conjugate-directions update, all fields in two launches (or one with a grid barrier): dTAd = <d, q>, delta = <d, r>,
         x += (delta / dTAd) d and, if update_r, r -= (delta / dTAd) q; returns (dTAd, delta) as `parts` does.
         active (block vectors): 0 / 1 per entry, an entry with 0 stands still"""
         f = (lambda v: [v.tlm, v.elm, v.blm])
         return dev.cg_dot_axpy(f(d), f(q), f(x), f(d), 1.0, b2=f(r), y2=f(r) if update_r else None, x2=f(q) if update_r else None,
-                               sign2=-1.0, lmin=0, one_launch=one_launch, active=active)
+                               sign2=-1.0, lmin=0, active=active)
 
     @staticmethod
-    def ortho(s, pq, pd, prev_dtad, one_launch=False):
+    def ortho(s, pq, pd, prev_dtad):
         """s -= (<s, pq> / prev_dtad) pd, all fields in two launches (or one with a grid barrier)"""
         f = (lambda v: [v.tlm, v.elm, v.blm])
-        dev.cg_dot_axpy(f(s), f(pq), f(s), f(pd), -1.0, den=prev_dtad, lmin=0, one_launch=one_launch)
+        dev.cg_dot_axpy(f(s), f(pq), f(s), f(pd), -1.0, den=prev_dtad, lmin=0)
 
     def __call__(self, alm1, alm2):
         p = self.parts(alm1, alm2)
@@ -311,9 +310,9 @@ class alm_filter_ninv(object):
             fac = self.npix / (4. * np.pi)
             nb = alm.tlm.shape[0] if alm.tlm.dim() == 2 else 1
             md = (len(self.templates_t) == 2 and isinstance(self.templates_t[0], template_removal.template_monopole)
-                  and isinstance(self.templates_t[1], template_removal.template_dipole) and os.environ.get('PLENS_TPROJ_MD', '1') != '0'
+                  and isinstance(self.templates_t[1], template_removal.template_dipole) and options.opts.tproj_md
                   and not shts.plan_all_generic(self.nside, lmax))
-            if len(self.templates_t) != 0 and os.environ.get('PLENS_TPROJ_HARM', '1') != '0':
+            if len(self.templates_t) != 0 and options.opts.tproj_harm:
                 # the temperature templates as a rank-nmodes update in harmonic space, as in opfilt_tt (pl_lowrank_update_b)
                 hpm, hrm = self._harm_matrices(lmax)
                 ttlm = shts.cg_fwd_tt(alm.tlm, self.nside, lmax, self.n_inv[0], fl_in=self.b_transf_t, fl_out=self.b_transf_t * fac, lowrank=(hpm, hrm))

@@ -7,12 +7,11 @@ transforms; the inverse-noise map, the template projector and every CG vector li
 from __future__ import print_function
 
 import hashlib
-import os
 
 import numpy as np
 import torch
 
-from .. import dev, hp, shts
+from .. import dev, hp, options, shts
 from ..utils import clhash, enumerate_progress
 from . import dense, template_removal, util
 
@@ -63,7 +62,7 @@ class dot_op(object):
         dev.axpy_dev(y, x, num, den, sign)
 
     @staticmethod
-    def step(x, d, r, q, update_r=True, one_launch=False, active=None, pre=None, x_init=False):
+    def step(x, d, r, q, update_r=True, active=None, pre=None, x_init=False):
         """one conjugate-directions update, all fields in two launches (or one with a grid barrier): dTAd = <d, q>, delta = <d, r>,
         x += (delta / dTAd) d and, if update_r, r -= (delta / dTAd) q; returns (dTAd, delta) as `parts` does.
         active (block vectors): 0 / 1 per entry, multiplies the step lengths.
@@ -75,17 +74,17 @@ class dot_op(object):
                                    assign_y1=x_init)
         assert not x_init
         return dev.cg_dot_axpy(f(d), f(q), f(x), f(d), 1.0, b2=f(r), y2=f(r) if update_r else None, x2=f(q) if update_r else None,
-                               sign2=-1.0, lmin=0, one_launch=one_launch, active=active)
+                               sign2=-1.0, lmin=0, active=active)
 
     @staticmethod
-    def ortho(s, pq, pd, prev_dtad, one_launch=False, pre=None):
+    def ortho(s, pq, pd, prev_dtad, pre=None):
         """s -= (<s, pq> / prev_dtad) pd, all fields in two launches (or one with a grid barrier).
         pre: <s, pq> as partial sums left by the preconditioner kernel that wrote s (pre_op.with_dot): the update alone"""
         f = (lambda v: [v])
         if pre is not None:
             dev.cg_axpy_pre((pre, None), f(s), f(pd), -1.0, den=prev_dtad)
             return
-        dev.cg_dot_axpy(f(s), f(pq), f(s), f(pd), -1.0, den=prev_dtad, lmin=0, one_launch=one_launch)
+        dev.cg_dot_axpy(f(s), f(pq), f(s), f(pd), -1.0, den=prev_dtad, lmin=0)
 
     def __call__(self, alm1, alm2):
         p = self.parts(alm1, alm2)
@@ -240,7 +239,7 @@ class alm_filter_ninv(object):
 
     def one_call_final(self, alm):
         """True when pl_cg_fwd_tt's result is the operator's (no update applied to it afterwards): scalar products may ride in it"""
-        if len(self.templates) != 0 and os.environ.get('PLENS_TPROJ_HARM', '1') != '0':
+        if len(self.templates) != 0 and options.opts.tproj_harm:
             return sum(t.nmodes for t in self.templates) <= dev.TEMPLATE_MAX_MODES
         return True
 
@@ -250,7 +249,7 @@ class alm_filter_ninv(object):
         lmax = hp.Alm.getlmax(alm.shape[-1] if isinstance(alm, torch.Tensor) else alm.size)
         fl_out = self.b_transf * (self.npix / (4. * np.pi))
         if self.one_call_ok(alm):
-            if len(self.templates) != 0 and os.environ.get('PLENS_TPROJ_HARM', '1') != '0':
+            if len(self.templates) != 0 and options.opts.tproj_harm:
                 # the projection in harmonic space: the transforms carry the plain N^-1 weighting (inside the ring-FFT launches),
                 # the templates are a rank-nmodes update of the result (pl_lowrank_update_b)
                 hpm, hrm = self._harm_matrices(lmax)
@@ -284,7 +283,7 @@ class alm_filter_ninv(object):
 
     def _md_only(self):
         """the templates are exactly (monopole, dipole): (1, x, y, z) of the pixel centres, which the kernels can evaluate themselves"""
-        if os.environ.get('PLENS_TPROJ_MD', '1') == '0' or len(self.templates) != 2:
+        if not options.opts.tproj_md or len(self.templates) != 2:
             return False
         return isinstance(self.templates[0], template_removal.template_monopole) and isinstance(self.templates[1], template_removal.template_dipole)
 

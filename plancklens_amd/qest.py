@@ -23,7 +23,7 @@ import pickle as pk
 import numpy as np
 import torch
 
-from . import dev, hp, shts
+from . import dev, hp, options, shts
 from . import utils as ut
 from .helpers import mpi
 
@@ -280,11 +280,11 @@ class library(object):
         """(idx0, idx1) -> the two device estimates, evaluated together (the leg syntheses of the two simulations share their Legendre
         recursions, pl_alm2map_batch2), or None when this key / library does not pair: 'p' / 'x' (minimum variance), 'p_p' / 'x_p'
         (polarization) and 'ptt' / 'xtt' (temperature: the filter stage only) of a same-legs library at its full band-limit.
-        PLENS_BATCH2=0 disables."""
+        options.opts.batch2 = False disables."""
         k = self.keys_remaps.get(k, k)
         fam = self._GC_FAMILY.get(k)
         if (fam is None or k not in self.keys_fund or lmax != self.get_lmax_qlm(k) or not self._same_legs()
-                or os.environ.get('PLENS_BATCH2', '1') == '0'):
+                or not options.opts.batch2):
             return None
         build = {'p': self._build_sim_MVgclm_pair, 'p_p': self._build_sim_Pgclm_pair, 'ptt': self._build_sim_Tgclm_pair}[fam[0]]
         which = fam[1]
@@ -492,14 +492,15 @@ class library(object):
     # and replayed; per pair the host then copies / adopts the input maps, replays, and starts the device -> host copies.  The captured
     # code is the eager code (`_pair_body`), so the results are the eager ones bit for bit (tests/test_gpu_qe.py, test_gpu_fullsize.py).
     # The reference has no counterpart: its loop (qest.py:238-244, examples/run_qlms.py:66-74) is CPU code.
-    use_graph = True   # per instance; PLENS_QE_GRAPH=0 switches the route off for the process
+    use_graph = True   # per instance; options.opts.qe_graph = False switches the route off for the process
+    graph_fallbacks = 0  # captures of this library that failed and fell back to eager launches for good (process totals: options.stats)
     graph_after = 2    # eager pair evaluations before the capture (workspaces grown, filters uploaded, code objects loaded)
 
     _PAIR_FIELDS = {'p': 'tqu', 'p_p': 'qu', 'ptt': 't'}
 
     def _pair_graph_ok(self, fam, idx0, idx1):
         ivfs = self.f2map1.ivfs
-        if not self.use_graph or os.environ.get('PLENS_QE_GRAPH', '1') == '0' or self.pipeline_lanes or shts.lane_active():
+        if not self.use_graph or not options.opts.qe_graph or self.pipeline_lanes or shts.lane_active():
             return False
         if torch.cuda.is_current_stream_capturing() or not self._same_legs() or self.cache:
             return False
@@ -626,9 +627,11 @@ class library(object):
                 st['ents'] = [dict(ent, _graph_static=True) for ent in ents]
                 st['graph'] = g
                 st['first'] = True
-            except Exception as e:  # capture is an optimisation: stay eager for good
-                print('qest.library: graph capture of the %s pair failed (%s); staying eager' % (fam, str(e).split('\n')[0]))
-                if os.environ.get('PLENS_QE_GRAPH_DEBUG'):
+                options.count('qe_graph_captures')
+            except Exception as e:  # capture is an optimisation: stay eager for good -- counted, and the reason kept, for whoever asks
+                self.graph_fallbacks += 1
+                options.count('qe_graph_fallbacks', 'qest.library %s pair: %s' % (fam, str(e).split('\n')[0]))
+                if options.opts.debug:
                     import traceback
                     traceback.print_exc()
                 torch.cuda.synchronize()
@@ -637,16 +640,20 @@ class library(object):
                 st['graph'] = False
                 return self._pair_body(fam, idx0, idx1, self._pair_dev_maps(fam, maps))[0]
         evict()
-        # device -> host copies of the previous pair read the static outputs on the copy stream: they come first
-        torch.cuda.current_stream().wait_stream(dev._copy_stream())
         if st.pop('first', False):
             pass  # (the slots were filled for the capture)
         else:
             fill(st['in'])
         st['graph'].replay()
         for idx, ent in zip((idx0, idx1), st['ents']):
-            ivfs._dev_entry(idx).update(ent)  # the filtered alms of the pair stay available (until the next replay) to further keys
-        return st['out']
+            # the filtered alms of the pair stay available to further keys UNTIL THE NEXT REPLAY of this graph (they alias its static buffers:
+            # entries marked _graph_static; a caller that keeps one across pairs must clone it)
+            ivfs._dev_entry(idx).update(ent)
+        # The results leave the graph's static outputs at once (4 x 33.6 MB at lmax 2048: ~0.1 ms of copies per pair): what the caller holds --
+        # the device (G, C) it sums or keeps as _last_dev, and the source of the device -> host copies on the copy stream -- is its own
+        # memory, valid for as long as it is referenced, and the next replay need not wait for the previous pair's results to have crossed
+        # PCIe (it used to: the copy stream read the static outputs, 4 x 0.6 ms per pair with the launch stream idle behind them).
+        return [(G.clone(), C.clone()) for G, C in st['out']]
 
     def _pair_dev_maps(self, fam, maps):
         """input maps as device tensors for the eager body: (Q, U) as the two rows of one array (what the spin transform takes)"""
@@ -720,8 +727,8 @@ class library(object):
 
     def _defer_ok(self):
         """in-memory results of a same-legs library may be stored while still crossing PCIe (resolved by _load);
-        PLENS_ASYNC_D2H=0: blocking copies"""
-        return self._same_legs() and not self.cache and os.environ.get('PLENS_ASYNC_D2H', '1') != '0'
+        options.opts.async_d2h = False: blocking copies"""
+        return self._same_legs() and not self.cache and options.opts.async_d2h
 
     def _build_sim_Tgclm(self, idx):
         G, C = self._get_sim_Tgclm(idx, 'ptt', defer=True) if self._defer_ok() else self._sym_gc(self._get_sim_Tgclm, idx, 'ptt')
@@ -871,7 +878,7 @@ class lib_filt2map(object):
     def get_gtmap_pair(self, idx0, idx1, k=None):
         """get_gtmap of two simulations on one Legendre recursion (pl_alm2map_grad_pair); None where that form does not apply"""
         m0, m1 = self._gt_alm(idx0, k=k), self._gt_alm(idx1, k=k)
-        if m0 is None or m1 is None or self._lmax(m0) != self._lmax(m1) or shts._lane_active() or os.environ.get('PLENS_BATCH2', '1') == '0' \
+        if m0 is None or m1 is None or self._lmax(m0) != self._lmax(m1) or shts._lane_active() or not options.opts.batch2 \
                 or not (isinstance(m0, torch.Tensor) and m0.is_cuda and isinstance(m1, torch.Tensor) and m1.is_cuda):
             return None
         lmax = self._lmax(m0)

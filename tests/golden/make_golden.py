@@ -10,7 +10,8 @@ route (qest.eval_qe), index shuffling / leg symmetrisation (filt_util.library_sh
 evaluated with SHTs that are themselves pinned by tests/test_oracle.py.  Only data (inputs and the
 reference's outputs) is stored; no reference source is copied.
 
-Run:  python tests/golden/make_golden.py      (needs /root/reference; not needed on the GPU box; `... cinv` separately: 20 minutes)
+Run:  python tests/golden/make_golden.py      (needs /root/reference; not needed on the GPU box; `... cinv` separately: 20 minutes; `... cinv2048`
+      separately: BASELINE config 4 at nside = lmax = 2048, 3 top-level iterations of the reference's cinv_t / cinv_p)
 The generator is reproducible to rounding only: the oracle's threaded stages and the reference's OpenMP Fortran sum in an order that
 depends on the thread count and, for the Fortran reductions, on the run (two runs of `resp` differ in 26 of 80 arrays at <= 2e-15).
 """
@@ -654,6 +655,62 @@ def make_cinv_golden():
     print('wrote cinv_golden.npz with %d arrays' % len(out))
 
 
+def make_cinv2048_golden():
+    """BASELINE config 4 at its own size (nside = lmax = 2048): the reference's own filt_cinv.cinv_t and cinv_p (filt_cinv.py:56-338) with the
+    default chains (:112-116, :236-239), the benchmark's mask / noise model / data maps (tools/cg_bench.py::inputs, here on the oracle's
+    transforms), the top level cut to 3 iterations (iter_max = 3, eps_min = 0: two to three fine operators and the full nested coarse solves
+    per iteration), solver cd_solve.py:35-107.  Stored: checksums of the inputs, the top-level residual trace, C_l and <x, x> of each
+    solution, 4096 seeded entries + every entry with l <= 8."""
+    import time
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import cg_bench
+    from plancklens.filt import filt_cinv
+    from plancklens.qcinv import cd_solve as ref_cd_solve
+    nside = lmax = 2048
+    niter = 3
+    t0 = time.time()
+    d = cg_bench.inputs(nside, lmax, lambda a, ns: so.alm2map(a, ns, lmax=lmax), so.alm2map_spin)
+    print('inputs: %.0f s' % (time.time() - t0), flush=True)
+    out = {'nside': nside, 'lmax': lmax, 'niter': niter}
+    for k in ['mask', 'tmap', 'qmap', 'umap']:
+        out['chk_' + k] = np.array([d[k].sum(), (d[k] ** 2).sum(), d[k][::9973].sum()])
+    l_of = np.concatenate([np.arange(m, lmax + 1) for m in range(lmax + 1)])
+    sub = np.sort(np.random.default_rng(2048).choice(l_of.size, 4096, replace=False))
+    out['subset'] = sub
+    out['low'] = np.nonzero(l_of <= 8)[0]
+    w = np.full(l_of.size, 2.)
+    w[:lmax + 1] = 1.
+    tmp = tempfile.mkdtemp(prefix='plgolden_cinv2048_')
+    try:
+        for kind in ('t', 'p'):
+            trace = []
+            t0 = time.time()
+            pcf = os.path.join(tmp, 'dense_%s.pk' % kind)
+            descr = cg_bench.chain(kind, niter, lmax, nside, pcf, cd_solve=ref_cd_solve)
+            if kind == 't':
+                filt = filt_cinv.cinv_t(os.path.join(tmp, 'cinv_t'), lmax, nside, d['cl'], d['transf'], d['ninv_t'], chain_descr=descr)
+            else:
+                filt = filt_cinv.cinv_p(os.path.join(tmp, 'cinv_p'), lmax, nside, d['cl'], d['transf'], d['ninv_p'], chain_descr=descr)
+            log0 = filt.chain.log
+            filt.chain.log = lambda stage, it, eps, **kw: (trace.append((stage.depth, it, eps)), log0(stage, it, eps, **kw))
+            if kind == 't':
+                sol, names = [filt.apply_ivf(d['tmap'])], ['tlm']
+            else:
+                sol, names = list(filt.apply_ivf([d['qmap'], d['umap']])), ['elm', 'blm']
+            out['trace_' + kind] = np.array([t[2] for t in trace if t[0] == 0])
+            for nm, a in zip(names, sol):
+                out[nm + '_cl'] = oh.alm2cl(a)
+                out[nm + '_sub'] = a[sub]
+                out[nm + '_low'] = a[out['low']]
+                out[nm + '_xx'] = np.array(float(np.sum(w * (a.real ** 2 + a.imag ** 2))))
+            print('cinv_%s at 2048: %d top-level iterations in %.0f s, eps %s' % (kind, len(out['trace_' + kind]), time.time() - t0,
+                                                                                 out['trace_' + kind]), flush=True)
+            np.savez_compressed(os.path.join(HERE, 'cinv2048_golden.npz'), **out)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    print('wrote cinv2048_golden.npz with %d arrays' % len(out))
+
+
 def make_mfresp_golden():
     """Reference qresp.get_mf_resp (qresp.py:421-500; its Python on its own Fortran Wigner module) for 'ptt' and 'p_p' on the tiny
     configuration of the response fixtures, with the three pieces of the gradient response (retterms)."""
@@ -694,11 +751,11 @@ if __name__ == '__main__':
         install_healpy_standin()
         sys.path.insert(0, REF)
         make_lib_golden()
-    elif len(sys.argv) > 1 and sys.argv[1] in ('sims', 'cg2', 'cinv', 'mfresp'):   # simulation inputs / small wrapper classes; further noise models of the CG
+    elif len(sys.argv) > 1 and sys.argv[1] in ('sims', 'cg2', 'cinv', 'cinv2048', 'mfresp'):   # simulation inputs / small wrapper classes; further noise models of the CG
         assert os.path.isdir(REF), 'the reference is only present in the build container'
         install_healpy_standin()
         sys.path.insert(0, REF)
-        {'sims': make_sims_golden, 'cg2': make_cg2_golden, 'cinv': make_cinv_golden, 'mfresp': make_mfresp_golden}[sys.argv[1]]()
+        {'sims': make_sims_golden, 'cg2': make_cg2_golden, 'cinv': make_cinv_golden, 'cinv2048': make_cinv2048_golden, 'mfresp': make_mfresp_golden}[sys.argv[1]]()
     elif len(sys.argv) > 1 and sys.argv[1] == 'cg':   # only the CG fixtures
         assert os.path.isdir(REF), 'the reference is only present in the build container'
         install_healpy_standin()

@@ -35,7 +35,7 @@ class _dot_parts(_dot_host):
 
 
 class _dot_merged(_dot_parts):
-    def step(self, x, d, r, q, update_r=True, one_launch=False):
+    def step(self, x, d, r, q, update_r=True):
         _dot_merged.calls += 1
         dtad, delta = self.parts(d, q), self.parts(d, r)
         x += delta[0] / dtad[0] * d
@@ -43,7 +43,7 @@ class _dot_merged(_dot_parts):
             r -= delta[0] / dtad[0] * q
         return dtad, delta
 
-    def ortho(self, s, pq, pd, prev_dtad, one_launch=False):
+    def ortho(self, s, pq, pd, prev_dtad):
         s -= np.dot(s, pq) / prev_dtad[0] * pd
 
 
@@ -122,7 +122,7 @@ class _dot_pre(_dot_merged):
     lmin = 0
     pre_steps = pre_orthos = inits = 0
 
-    def step(self, x, d, r, q, update_r=True, one_launch=False, active=None, pre=None, x_init=False):
+    def step(self, x, d, r, q, update_r=True, active=None, pre=None, x_init=False):
         if pre is None:
             assert not x_init
             return _dot_merged.step(self, x, d, r, q, update_r=update_r)
@@ -137,7 +137,7 @@ class _dot_pre(_dot_merged):
             r -= delta[0] / dtad[0] * q
         return dtad, delta
 
-    def ortho(self, s, pq, pd, prev_dtad, one_launch=False, pre=None):
+    def ortho(self, s, pq, pd, prev_dtad, pre=None):
         if pre is None:
             return _dot_merged.ortho(self, s, pq, pd, prev_dtad)
         _dot_pre.pre_orthos += 1
@@ -174,7 +174,7 @@ def test_scalar_products_handed_over_by_the_producing_operators(offer, monkeypat
     """fwd_op.with_dots / pre_op.with_dot / dot_op.step(pre=...) / dot_op.ortho(pre=...): the solver takes the scalar products from the
     operators that made the vectors (cd_solve.py:66-84,96-103 without scalar-product launches of their own) and lands on the same
     solution as with its own; a preconditioner that has none to offer falls back per call; x_uninit: the solution vector may hold anything
-    on entry, the first step writes it (or it is zero-filled where no `pre` arrives); PLENS_CG_POST_DOTS=0 switches the protocol off."""
+    on entry, the first step writes it (or it is zero-filled where no `pre` arrives); options.opts.cg_post_dots = False switches the protocol off."""
     amat, b = _system(seed=3)
     ref = np.zeros_like(b)
     cd_solve.cd_solve(ref, b.copy(), lambda v: amat @ v, [lambda v: v / np.diag(amat)], _dot_merged(), _stop_after(12), cd_solve.tr_cg, x_is_zero=True)
@@ -190,7 +190,8 @@ def test_scalar_products_handed_over_by_the_producing_operators(offer, monkeypat
                              x_is_zero=True, x_uninit=True) == 0
     assert np.array_equal(x0, np.zeros_like(b))
     # switched off: the solver's own scalar products, the solution vector zero-filled before the first step
-    monkeypatch.setenv('PLENS_CG_POST_DOTS', '0')
+    from plancklens_amd import options
+    monkeypatch.setattr(options.opts, 'cg_post_dots', False)
     _dot_pre.pre_steps = _dot_pre.pre_orthos = 0
     x1 = np.full_like(b, np.nan)
     cd_solve.cd_solve(x1, b.copy(), _fwd_with_dots(amat), [_pre_with_dot(np.diag(amat))], _dot_pre(), _stop_after(12), cd_solve.tr_cg,

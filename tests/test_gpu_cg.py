@@ -229,13 +229,16 @@ trace = []
 log0 = f.chain.log
 f.chain.log = lambda stage, it, eps, **kw: (trace.append(float(eps)) if stage.depth == 0 else None, log0(stage, it, eps, **kw))
 out = dev.to_host(dev.to_dev(f.apply_ivf(dev.to_dev(tmap))))
-np.save(os.path.join(tmp, 'sol_%%s.npy' %% os.environ.get('PLENS_CG_GRAPH', '1')), out)
-np.save(os.path.join(tmp, 'eps_%%s.npy' %% os.environ.get('PLENS_CG_GRAPH', '1')), np.array(trace))
+from plancklens_amd import options
+tag = '1' if options.opts.cg_graph else '0'
+assert options.stats['cg_graph_fallbacks'] == 0 and (options.stats['cg_graph_captures'] > 0) == options.opts.cg_graph, options.stats
+np.save(os.path.join(tmp, 'sol_%%s.npy' %% tag), out)
+np.save(os.path.join(tmp, 'eps_%%s.npy' %% tag), np.array(trace))
 ''' % (ROOT, ROOT, ROOT)
     script = tmp_path / 'cg_full.py'
     script.write_text(code)
     for graph in ('0', '1'):  # the second run reads the dense block cached by the first
-        out = subprocess.run([sys.executable, str(script), str(tmp_path)], env=dict(os.environ, PLENS_CG_GRAPH=graph), stdout=subprocess.PIPE,
+        out = subprocess.run([sys.executable, str(script), str(tmp_path)], env=dict(os.environ, PLENS_OPTIONS='cg_graph=' + graph), stdout=subprocess.PIPE,
                              stderr=subprocess.STDOUT, timeout=1500)
         assert out.returncode == 0, out.stdout.decode()[-3000:]
     a, b = np.load(tmp_path / 'sol_0.npy'), np.load(tmp_path / 'sol_1.npy')

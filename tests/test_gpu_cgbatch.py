@@ -299,9 +299,10 @@ def test_dense_preconditioner_built_through_block_vectors(monkeypatch):
            (dense.pre_op_dense_pp, opfilt_pp.fwd_op(cl, opfilt_pp.alm_filter_ninv([npol], g['transf'][:17])), 5),
            (dense.pre_op_dense_tp, opfilt_tp.fwd_op(cl, opfilt_tp.alm_filter_ninv([nt, npol], g['transf'][:17], marge_monopole=True, marge_dipole=True)), 4)]
     for cls_, op, lmax in ops:
-        monkeypatch.setenv('PLENS_DENSE_BLOCK', '1')
+        from plancklens_amd import options
+        monkeypatch.setattr(options.opts, 'dense_block', 1)
         one = cls_(lmax, op).minv
-        monkeypatch.setenv('PLENS_DENSE_BLOCK', '32')
+        monkeypatch.setattr(options.opts, 'dense_block', 32)
         blk = cls_(lmax, op).minv
         assert bool((one == blk).all()), cls_.__name__
 
@@ -325,9 +326,10 @@ def test_template_projection_in_harmonic_space_equals_the_pixel_space_one(nside,
     nf = opfilt_tt.alm_filter_ninv(ninv, bl, marge_monopole=True, marge_dipole=True, marge_maps=marge_maps)
     op = opfilt_tt.fwd_op(cl, nf)
     xt = _ralm(rng, lmax, nb) if nb > 1 else _ralm(rng, lmax, 2)[0].contiguous()
-    monkeypatch.setenv('PLENS_TPROJ_HARM', '0')
+    from plancklens_amd import options
+    monkeypatch.setattr(options.opts, 'tproj_harm', False)
     ref = op(xt)
-    monkeypatch.setenv('PLENS_TPROJ_HARM', '1')
+    monkeypatch.setattr(options.opts, 'tproj_harm', True)
     got = op(xt)
     assert got.shape == ref.shape
     assert relrms(dev.to_host(got), dev.to_host(ref)) < 1e-12

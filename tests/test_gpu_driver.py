@@ -127,7 +127,7 @@ def test_run_qlms_masked_sky_cg_filters(tmp_path):
     cinv_t + cinv_p with the default multigrid chains and dense coarse preconditioners, library_ftl on top) at nside 512, lmax 1024:
     the filtering phase runs in block solves (library_cinv_sepTP.filter_sims through the library_ftl wrapper), the estimators are
     built from the cached filtered alms, and a one-by-one filtering of the same simulation gives the same alm."""
-    env = dict(os.environ, PLENS=str(tmp_path), PLENS_NSIDE='512', PLENS_LMAX='1024', PLENS_NSIMS='10', PLENS_CG_BATCH='3')
+    env = dict(os.environ, PLENS=str(tmp_path), PLENS_NSIDE='512', PLENS_LMAX='1024', PLENS_NSIMS='10', PLENS_OPTIONS='cg_batch=3')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, 'examples', 'run_qlms.py'), os.path.join(ROOT, 'params', 'anisofilt_example.py'),

@@ -213,15 +213,13 @@ def test_mv_estimator_with_pipelined_lanes(setup):
 def test_paired_simulations_equal_single_evaluations(setup, tmp_path):
     """The mean-field loop serves a same-legs library two simulations at a time (their spin-2 and spin-3 leg syntheses share
     Legendre recursions, pl_alm2map_batch2): estimates and mean field must equal the one-at-a-time evaluation bit for bit."""
-    import os
-    from plancklens_amd import qest
+    from plancklens_amd import options, qest
     from plancklens_amd.filt import filt_simple
     g, cl = setup[0], setup[4]
     nside, lmax_qlm = int(g['nside']), int(g['lmax_qlm'])
     res = {}
-    for tag, env in (('pair', '1'), ('single', '0')):
-        os.environ['PLENS_BATCH2'] = env
-        try:
+    for tag, pairing in (('pair', True), ('single', False)):
+        with options.override(batch2=pairing):
             ivfs = filt_simple.library_fullsky_sepTP(str(tmp_path / ('ivfs_' + tag)), _gold_sims(g), nside, g['transf'], cl, g['ftl'], g['fel'],
                                                      g['fbl'], cache=False)
             q = qest.library_sepTP(str(tmp_path / ('q_' + tag)), ivfs, ivfs, cl['te'], nside, lmax_qlm=lmax_qlm, cache=False)
@@ -230,8 +228,6 @@ def test_paired_simulations_equal_single_evaluations(setup, tmp_path):
             # round 4: the polarization-only and temperature-only keys pair as well ('p_p': all three leg syntheses on shared recursions)
             for k, kx in (('p_p', 'x_p'), ('ptt', 'xtt')):
                 res[tag] += (q.get_sim_qlm_mf(k, np.array([0, 1])), q.get_sim_qlm(k, 0), q.get_sim_qlm(k, 1), q.get_sim_qlm(kx, 0))
-        finally:
-            del os.environ['PLENS_BATCH2']
     for a, b in zip(res['pair'], res['single']):
         assert np.array_equal(a, b)
     assert relrms(res['pair'][0], g['dd_mf_p']) < TOL and relrms(res['pair'][2], g['dd_p_1']) < TOL

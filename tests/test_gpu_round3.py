@@ -115,13 +115,10 @@ def test_polarization_operators_with_qu_noise_and_templates(g2):
     r = opfilt_pp.fwd_op(cl, fm)(x)
     assert relrms(dev.to_host(r.elm), g['ppm_fwd_e']) < 1e-11 and relrms(dev.to_host(r.blm), g['ppm_fwd_b']) < 1e-11
     # (that was the projection as a rank-3 update in harmonic space, pl_lowrank_update_b on the stacked (E, B) vectors; the pixel-space form:)
-    import os
-    os.environ['PLENS_TPROJ_HARM'] = '0'
-    try:
+    from plancklens_amd import options
+    with options.override(tproj_harm=False):
         assert not fm.one_call_ok(x)
         r0 = opfilt_pp.fwd_op(cl, fm)(x)
-    finally:
-        del os.environ['PLENS_TPROJ_HARM']
     assert fm.one_call_ok(x)
     assert relrms(dev.to_host(r0.elm), g['ppm_fwd_e']) < 1e-11 and relrms(dev.to_host(r0.blm), g['ppm_fwd_b']) < 1e-11
     assert relrms(dev.to_host(r.elm), dev.to_host(r0.elm)) < 1e-12 and relrms(dev.to_host(r.blm), dev.to_host(r0.blm)) < 1e-12

@@ -1,0 +1,177 @@
+"""Round 6: the whole-solve reference point of BASELINE config 4 at its own size, the 8-rank dress rehearsal of the sharded drivers on one
+GPU, and the run-time options object."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import relrms
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _note(name, lines):
+    d = os.path.join(os.environ.get('GRAFT_REPO_ROOT', ROOT), 'gpurun_out')
+    if os.path.isdir(d):
+        with open(os.path.join(d, name), 'w') as f:
+            f.write('\n'.join(lines) + '\n')
+
+
+def test_cinv_t_and_cinv_p_at_2048_vs_the_reference_classes(tmp_path):
+    """BASELINE config 4 at nside = lmax = 2048 -- the workload bench.py's `cg` block times (tools/cg_bench.py::inputs: the benchmark's mask,
+    noise model and data maps; default chains of filt_cinv.py:112-116, 236-239) -- against the REFERENCE's own cinv_t / cinv_p
+    (filt_cinv.py:56-338 -> multigrid.py:45-69 -> cd_solve.py:35-107) run over the oracle's transforms with the top level cut to 3
+    iterations (tests/golden/make_golden.py cinv2048 -> cinv2048_golden.npz).  Compared at 1e-10: the top-level residual trace, <x, x>,
+    C_l, 4096 seeded entries and every entry with l <= 8 of each solution.  The inputs are re-made here with the product's transforms
+    (they differ from the generator's by rounding: checksums compared at 1e-9)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import cg_bench
+    from plancklens_amd import dev, hp, options, shts
+    from plancklens_amd.filt import filt_cinv
+    g = np.load(os.path.join(HERE, 'golden', 'cinv2048_golden.npz'))
+    nside, lmax, niter = int(g['nside']), int(g['lmax']), int(g['niter'])
+    assert nside == 2048 and lmax == 2048
+    d = cg_bench.inputs(nside, lmax, shts.alm2map, shts.alm2map_spin)
+    for k in ['mask', 'tmap', 'qmap', 'umap']:
+        chk = np.array([d[k].sum(), (d[k] ** 2).sum(), d[k][::9973].sum()])
+        assert np.allclose(chk, g['chk_' + k], rtol=1e-9, atol=1e-9 * np.sqrt(chk[1])), (k, chk, g['chk_' + k])
+    sub, low = g['subset'], g['low']
+    w = np.full(hp.Alm.getsize(lmax), 2.)
+    w[:lmax + 1] = 1.
+    report = []
+    for kind in ('t', 'p'):
+        pcf = str(tmp_path / ('dense_%s.pk' % kind))
+        descr = cg_bench.chain(kind, niter, lmax, nside, pcf)
+        trace = []
+        if kind == 't':
+            filt = filt_cinv.cinv_t(str(tmp_path / 'cinv_t'), lmax, nside, d['cl'], d['transf'], d['ninv_t'], chain_descr=descr)
+        else:
+            filt = filt_cinv.cinv_p(str(tmp_path / 'cinv_p'), lmax, nside, d['cl'], d['transf'], d['ninv_p'], chain_descr=descr)
+        log0 = filt.chain.log
+        filt.chain.log = lambda stage, it, eps, **kw: (trace.append((stage.depth, it, float(eps))), log0(stage, it, eps, **kw))
+        if kind == 't':
+            sols = {'tlm': np.asarray(dev.to_host(dev.to_dev(filt.apply_ivf(dev.to_dev(d['tmap'])))))}
+        else:
+            e, b = filt.apply_ivf([dev.to_dev(d['qmap']), dev.to_dev(d['umap'])])
+            sols = {'elm': np.asarray(dev.to_host(dev.to_dev(e))), 'blm': np.asarray(dev.to_host(dev.to_dev(b)))}
+        tr = np.array([t[2] for t in trace if t[0] == 0])
+        ref = g['trace_' + kind]
+        assert len(tr) == len(ref) == niter + 1, (kind, tr, ref)
+        e_tr = float(np.max(np.abs(tr / ref - 1)))
+        for nm, a in sols.items():
+            e_sub, e_low = relrms(a[sub], g[nm + '_sub']), relrms(a[low], g[nm + '_low'])
+            cl_ref = g[nm + '_cl']
+            ok = cl_ref[2:] > 0
+            e_cl = float(np.max(np.abs(hp.alm2cl(a)[2:][ok] / cl_ref[2:][ok] - 1)))
+            e_xx = abs(float(np.sum(w * (a.real ** 2 + a.imag ** 2))) / float(g[nm + '_xx']) - 1.)
+            report.append('%s at nside = lmax = 2048, %d top-level iterations: 4096-entry subset %.1e, l <= 8 %.1e, C_l %.1e, <x, x> %.1e, residual trace %.1e'
+                          % (nm, niter, e_sub, e_low, e_cl, e_xx, e_tr))
+            assert e_sub < 1e-10 and e_low < 1e-10 and e_cl < 1e-10 and e_xx < 1e-10 and e_tr < 1e-8, report[-1]
+    assert options.stats['cg_graph_fallbacks'] == 0, options.stats
+    _note('cinv2048_reference_parity.txt', report)
+    print('\n'.join(report))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _bench_line(args, env=None, nranks=1, timeout=1500):
+    if nranks == 1:
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py')] + args
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nranks), '--master-addr', '127.0.0.1',
+               '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', str(nranks)] + args
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+
+
+def test_bench_eight_ranks_on_one_gpu_give_the_one_rank_mean_field():
+    """Dress rehearsal of the driver's 8-GPU line on the one GPU of the box: `bench.py --gpus 8` for real (no stub) under
+    torch.distributed.run, eight rank processes sharing device 0, process group on gloo (collectives staged through the host; RCCL needs a
+    GPU per rank).  All eight ranks are seen, each reports its own time, the whole-job rate is world x K / time, and the mean field over the
+    16 simulations -- sharded jobs[rank::size] (run_qlms.py:57,72), summed by the all-reduce -- equals the one a single rank computes over
+    the same simulations."""
+    common = ['--nside', '64', '--lmax', '64', '--warmup', '2', '--no-cg', '--no-cpu-baseline', '--no-from-sims', '--sims-seed', '7']
+    one = _bench_line(common + ['--steps', '16'])
+    eight = _bench_line(common + ['--steps', '2'], env={'PLENS_DIST_BACKEND': 'gloo'}, nranks=8)
+    assert one['ranks_seen'] == 1 and eight['ranks_seen'] == 8 and eight['n_gpus'] == 8
+    assert len(eight['ms_per_step_by_rank']) == 8 and all(t > 0 for t in eight['ms_per_step_by_rank'])
+    assert eight['steps'] == 2 and abs(eight['value'] * eight['ms_per_step'] / 1e3 - 8.) < 1e-6
+    assert one['mean_field_checksum'] > 0 and abs(eight['mean_field_checksum'] / one['mean_field_checksum'] - 1.) < 1e-12
+    assert one['selfcheck_max_abs_diff'] == 0.0 and eight['selfcheck_max_abs_diff'] == 0.0
+    assert eight['config']['parallelism'] == 'sim-sharded x8'
+    assert eight['memory']['plan_device_mb'] > 0 and eight['graphs']['qe_graph_fallbacks'] == 0
+
+
+def test_bench_config_switch():
+    """`--config 5` names BASELINE config 5 (MV 'p', nside = lmax = 4096, 32 simulations per GPU, no CG / CPU legs) so that the driver need
+    not guess flags; checked through the stub launcher (argument handling only: no GPU work)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse(['--config', '5', '--gpus', '8'])
+    assert (a.nside, a.lmax, a.key, a.steps, a.no_cg, a.no_cpu_baseline) == (4096, 4096, 'p', 32, True, True)
+    a = bench.parse(['--config', '5', '--steps', '4'])
+    assert a.steps == 4
+    a = bench.parse(['--config', '1'])
+    assert (a.nside, a.lmax, a.key, a.steps) == (512, 512, 'ptt', 10)
+    assert bench.parse([]).steps == 10 and bench.parse([]).nside == 2048
+
+
+def test_run_qlms_mean_field_over_eight_ranks(tmp_path):
+    """examples/run_qlms.py -mfdd with eight ranks on one GPU (gloo): every simulation reconstructed by exactly one rank
+    (jobs[rank::size], run_qlms.py:72; helpers/mpi.py:19-53), the mean fields equal to the single-process ones."""
+    args = [os.path.join(ROOT, 'examples', 'run_qlms.py'), os.path.join(ROOT, 'params', 'idealized_example.py'),
+            '-imin', '0', '-imax', '15', '-k', 'p', '-ivt', '-ivp', '-dd', '-mfdd']
+    base = dict(os.environ, PLENS_NSIDE='32', PLENS_LMAX='64', PLENS_NSIMS='64')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        base.pop(k, None)
+    one = subprocess.run([sys.executable] + args, env=dict(base, PLENS=str(tmp_path / 'one')), cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=1500)
+    assert one.returncode == 0, one.stdout.decode()[-3000:]
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable] + args, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              env=dict(base, PLENS=str(tmp_path / 'eight'), RANK=str(r), WORLD_SIZE='8', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
+                                       MASTER_PORT=str(port), PLENS_DIST_BACKEND='gloo')) for r in range(8)]
+    outs = [p.communicate(timeout=1500)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    for r, o in enumerate(outs):
+        line = [l for l in o.splitlines() if 'doing QE sims' in l][0]
+        mine = [int(x) for x in line.split('QE sims [')[1].split(']')[0].split(',') if x.strip()]
+        assert mine == list(range(0, 16))[r::8], (r, mine)
+    from plancklens_amd import hp
+    d1 = os.path.join(str(tmp_path), 'one', 'temp', 'idealized_example', 'qlms_dd')
+    d2 = os.path.join(str(tmp_path), 'eight', 'temp', 'idealized_example', 'qlms_dd')
+    mfs = sorted(f for f in os.listdir(d1) if f.startswith('simMF_'))
+    assert len(mfs) == 2 and mfs == sorted(f for f in os.listdir(d2) if f.startswith('simMF_'))
+    for f in mfs + ['sim_p_0011.fits']:
+        a, b = hp.read_alm(os.path.join(d1, f)), hp.read_alm(os.path.join(d2, f))
+        assert np.abs(a).max() > 0 and np.abs(a - b).max() < 1e-12 * np.abs(a).max(), f
+
+
+def test_options_object_and_graph_counters(tmp_path):
+    """plancklens_amd.options: one object instead of one environment variable per switch; unknown names raise; a failed graph capture is
+    counted (options.stats, library.graph_fallbacks) instead of printed."""
+    from plancklens_amd import options
+    assert options.opts.qe_graph and options.opts.cg_graph and options.opts.cg_batch == 4
+    with options.override(cg_batch=2, qe_graph=False):
+        assert options.opts.cg_batch == 2 and not options.opts.qe_graph
+    assert options.opts.cg_batch == 4 and options.opts.qe_graph
+    with pytest.raises(KeyError):
+        options.opts.set(no_such_option=1)
+    out = subprocess.run([sys.executable, '-c', 'import sys; sys.path.insert(0, %r); from plancklens_amd import options; '
+                          'print(options.opts.cg_graph, options.opts.dense_block)' % ROOT],
+                         env=dict(os.environ, PLENS_OPTIONS='cg_graph=0,dense_block=8'), capture_output=True, text=True)
+    assert out.stdout.split() == ['False', '8'], (out.stdout, out.stderr)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # How much does the reconstruction rate depend on the host's launch thread?  The bench's QE leg on a quiet host and beside NSPIN busy-loop
 # processes (default 32: twice the CPU quota of a GPU slot), with the replayed-graph route (default) and with eager launches
-# (PLENS_QE_GRAPH=0).  Run on the GPU box; prints one line per arm.
+# (PLENS_OPTIONS=qe_graph=0).  Run on the GPU box; prints one line per arm.
 cd "$GRAFT_REPO_ROOT"
 NSPIN=${1:-32}
 STEPS=${2:-20}
@@ -17,10 +17,10 @@ spin_start() { PIDS=""; for i in $(seq $NSPIN); do python3 -c "
 while True: pass" & PIDS="$PIDS $!"; done; sleep 1; }
 spin_stop() { for p in $PIDS; do kill $p 2>/dev/null; done; wait 2>/dev/null; }
 for rep in 1 2; do
-  one "quiet host, graph replay" "PLENS_QE_GRAPH=1"
-  one "quiet host, eager launches" "PLENS_QE_GRAPH=0"
+  one "quiet host, graph replay" "PLENS_OPTIONS=qe_graph=1"
+  one "quiet host, eager launches" "PLENS_OPTIONS=qe_graph=0"
   spin_start
-  one "$NSPIN spinners, graph replay" "PLENS_QE_GRAPH=1"
-  one "$NSPIN spinners, eager launches" "PLENS_QE_GRAPH=0"
+  one "$NSPIN spinners, graph replay" "PLENS_OPTIONS=qe_graph=1"
+  one "$NSPIN spinners, eager launches" "PLENS_OPTIONS=qe_graph=0"
   spin_stop
 done

@@ -35,8 +35,33 @@ def make_mask(nside, rng):
     return mask
 
 
-def chain(kind, n, lmax, nside, pcf):
-    from plancklens_amd.qcinv import cd_solve
+def inputs(nside, lmax, alm2map, alm2map_spin):
+    """The workload of BASELINE config 4 as a recipe with the transforms as arguments: this benchmark makes it with the product's SHTs, the
+    golden generator (tests/golden/make_golden.py cinv2048, the reference's own cinv_t / cinv_p at this size) with the oracle's.  One seeded
+    stream: mask discs, T sky, T noise, E sky, B sky, Q noise, U noise."""
+    from plancklens_amd import hp, utils
+    rng = np.random.default_rng(7)
+    npix = hp.nside2npix(nside)
+    cl = utils.camb_clfile(os.path.join(ROOT, 'plancklens_amd', 'data', 'cls', 'FFP10_wdipole_lensedCls.dat'), lmax=lmax)
+    transf = hp.gauss_beam(5. / 60. / 180. * np.pi, lmax=lmax)
+    nlev_t, nlev_p = 35., 55.
+    mask = make_mask(nside, rng)
+    vamin = np.sqrt(hp.nside2pixarea(nside, degrees=True)) * 60
+    tmap = np.asarray(alm2map(hp.almxfl(hp.synalm(cl['tt'], lmax, rng), transf), nside)) + nlev_t / vamin * rng.standard_normal(npix)
+    elm = hp.almxfl(hp.synalm(cl['ee'], lmax, rng), transf)
+    blm = hp.almxfl(hp.synalm(cl['bb'], lmax, rng), transf)
+    q, u = (np.asarray(x) for x in alm2map_spin([elm, blm], nside, 2, lmax))
+    q = q + nlev_p / vamin * rng.standard_normal(npix)
+    u = u + nlev_p / vamin * rng.standard_normal(npix)
+    return {'cl': cl, 'transf': transf, 'mask': mask, 'tmap': tmap, 'qmap': q, 'umap': u, 'nlev_t': nlev_t, 'nlev_p': nlev_p, 'vamin': vamin,
+            'ninv_t': [np.array([3. / nlev_t ** 2]) * mask], 'ninv_p': [[np.array([3. / nlev_p ** 2]) * mask]]}
+
+
+def chain(kind, n, lmax, nside, pcf, cd_solve=None):
+    """default chains of filt_cinv.py:112-116 (T) / :236-239 (P) with the stage-0 iteration count n and eps_min = 0; cd_solve: the module whose
+    tr_cg / cache_mem the entries carry (the golden generator passes the reference's)"""
+    if cd_solve is None:
+        from plancklens_amd.qcinv import cd_solve
     if kind in ('t', 'tp'):
         return [[3, ["split(dense(" + pcf + "), 64, diag_cl)"], 256, 128, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
                 [2, ["split(stage(3),  256, diag_cl)"], 512, 256, 3, 0.0, cd_solve.tr_cg, cd_solve.cache_mem()],
@@ -69,21 +94,12 @@ def _run(nside, lmax, iters, kinds, joint, verbose, peak_tflops, batches=()):
     from plancklens_amd.filt import filt_cinv
     if os.environ.get('CG_BENCH_PLAN_OPTS'):  # development aid: pl_plan_opts for every plan of the run, e.g. fft_generic_nside=0
         shts.plan_options(**{kv.split('=')[0]: int(kv.split('=')[1]) for kv in os.environ['CG_BENCH_PLAN_OPTS'].split(',')}).__enter__()
-    rng = np.random.default_rng(7)
-    npix = hp.nside2npix(nside)
-    cl = utils.camb_clfile(os.path.join(ROOT, 'plancklens_amd', 'data', 'cls', 'FFP10_wdipole_lensedCls.dat'), lmax=lmax)
-    transf = hp.gauss_beam(5. / 60. / 180. * np.pi, lmax=lmax)
-    nlev_t, nlev_p = 35., 55.
-    mask = make_mask(nside, rng)
+    d = inputs(nside, lmax, shts.alm2map, shts.alm2map_spin)
+    cl, transf, mask, tmap, q, u = d['cl'], d['transf'], d['mask'], d['tmap'], d['qmap'], d['umap']
+    nlev_t, nlev_p, vamin = d['nlev_t'], d['nlev_p'], d['vamin']
     fsky = float(mask.mean())
-    vamin = np.sqrt(hp.nside2pixarea(nside, degrees=True)) * 60
-    tmap = shts.alm2map(hp.almxfl(hp.synalm(cl['tt'], lmax, rng), transf), nside) + nlev_t / vamin * rng.standard_normal(npix)
-    q, u = shts.alm2map_spin([hp.almxfl(hp.synalm(cl['ee'], lmax, rng), transf), hp.almxfl(hp.synalm(cl['bb'], lmax, rng), transf)], nside, 2, lmax)
-    q += nlev_p / vamin * rng.standard_normal(npix)
-    u += nlev_p / vamin * rng.standard_normal(npix)
     tmp = tempfile.mkdtemp(prefix='cgbench_')
-    ninv_t = [np.array([3. / nlev_t ** 2]) * mask]
-    ninv_p = [[np.array([3. / nlev_p ** 2]) * mask]]
+    ninv_t, ninv_p = d['ninv_t'], d['ninv_p']
     res = {'fsky': fsky, 'iters': iters}
 
     def timed(f, dmap):
