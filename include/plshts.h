@@ -130,7 +130,9 @@ int pl_alm2map_grad_pair(pl_plan *plan, int spin, const double *alm_g1, const do
                          void *stream);
 /* The same spin-s synthesis of TWO general inputs (two simulations) on ONE recursion: 4 + 8 + 8 instead of 2 x (4 + 8) FMAs per
  * recursion step (batching independent maps).  alm_gc_k_dev = [G_k | C_k], one filter fl for both;
- * maps4_dev = [Q1 | U1 | Q2 | U2].  Device pointers only, asynchronous on `stream`.  Bit-identical to two pl_alm2map calls. */
+ * maps4_dev = [Q1 | U1 | Q2 | U2].  Device pointers only, asynchronous on `stream`.  Bit-identical to two pl_alm2map calls.
+ * spin 0 (round 6): alm_gc_k_dev = one scalar alm array each, maps4_dev = [T1 | T2] (two rows); on grids of nside >= 1024 the two inputs share the
+ * recursion (10 instead of 2 x 6 FMAs per two-l step and ring pair), elsewhere they are two workgroup sets of one launch; bit-identical to two pl_alm2map calls. */
 int pl_alm2map_batch2(pl_plan *plan, int spin, const double *alm_gc_1_dev, const double *alm_gc_2_dev, const double *fl_dev, double *maps4_dev,
                       void *stream);
 int pl_map2alm(pl_plan *plan, int spin, const double *map, double *alm, const double *fl, int where, void *stream);
@@ -151,9 +153,10 @@ int pl_map2phase(pl_plan *plan, int spin, const double *map_dev, double *phase_d
  * 2 Legendre analysis spin 0 (+ reduction), 3 Legendre analysis spin s (+ reduction), 4 ring FFT synthesis,
  * 5 ring FFT analysis, 6 gradient-only Legendre synthesis spin s (pl_legendre_synth_grad: 16 instead of 24 flop
  * per recursion step, kept apart so that kind 1 prices full launches only), 7 paired Legendre synthesis (pl_alm2map_pair:
- * 32 flop per step for two transforms), 8 batched Legendre synthesis (pl_alm2map_batch2: 40 flop per step for two maps).  pl_profile_read synchronises the recorded events, returns summed milliseconds and
+ * 32 flop per step for two transforms), 8 batched Legendre synthesis (pl_alm2map_batch2: 40 flop per step for two maps), 9 two scalar
+ * syntheses on one recursion (pl_alm2map_batch2 with spin 0 / an even block of pl_cg_fwd_tt_b on a fine grid: 20 instead of 2 x 12 flop per two-l step).  pl_profile_read synchronises the recorded events, returns summed milliseconds and
  * launch counts per kind (arrays of PL_PROFILE_KINDS entries) and resets the record. */
-#define PL_PROFILE_KINDS 9
+#define PL_PROFILE_KINDS 10
 int pl_profile_enable(pl_plan *plan, int on);
 int pl_profile_read(pl_plan *plan, double *ms_sum, int64_t *counts);
 

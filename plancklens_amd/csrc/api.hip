@@ -25,6 +25,7 @@ bool launch_prep0_lowrank(const DevPlan &P, const double *alm, const double *fl,
                           double *parts);
 void launch_preps(const DevPlan &P, const DevSpinTab &S, int spin, const double *alm, const double *fl, double *prep, hipStream_t st, bool gonly);
 void launch_synth0(const DevPlan &P, const double *prep, double *phase, hipStream_t st, int nb = 1);
+bool synth0_pairs(const DevPlan &P, int nb);
 void launch_synths(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, double *phase, hipStream_t st, bool gonly, int nb = 1);
 void launch_synths_pair(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st);
 void launch_synths_gpair(const DevPlan &P, const DevSpinTab &S, int spin, const double *prep, const double *prep2, double *phase, hipStream_t st);
@@ -131,7 +132,7 @@ struct pl_plan {
     std::vector<Ev> events;
 };
 
-enum { PK_LEG_SYNTH0 = 0, PK_LEG_SYNTHS, PK_LEG_ANAL0, PK_LEG_ANALS, PK_FFT_SYNTH, PK_FFT_ANAL, PK_LEG_SYNTHS_GRAD, PK_LEG_SYNTHS_PAIR, PK_LEG_SYNTHS_BATCH2, PK_NKINDS };
+enum { PK_LEG_SYNTH0 = 0, PK_LEG_SYNTHS, PK_LEG_ANAL0, PK_LEG_ANALS, PK_FFT_SYNTH, PK_FFT_ANAL, PK_LEG_SYNTHS_GRAD, PK_LEG_SYNTHS_PAIR, PK_LEG_SYNTHS_BATCH2, PK_LEG_SYNTH0_PAIR, PK_NKINDS };
 static_assert(PK_NKINDS == PL_PROFILE_KINDS, "include/plshts.h PL_PROFILE_KINDS out of date");
 
 struct ProfScope {
@@ -679,7 +680,7 @@ static int legendre_synth_impl(pl_plan *p, int spin, const double *alm, const do
         const bool fused = lr_done && lr_nmodes > 0 && launch_prep0_lowrank(p->P, alm, fl, p->prep, st, nb, lr_nmodes, lr_pm, lr_parts);
         if (lr_done) *lr_done = fused;
         if (!fused) launch_prep0(p->P, alm, fl, p->prep, st, nb);
-        { ProfScope ps(p, PK_LEG_SYNTH0, st); launch_synth0(p->P, p->prep, phase, st, nb); }
+        { ProfScope ps(p, synth0_pairs(p->P, nb) ? PK_LEG_SYNTH0_PAIR : PK_LEG_SYNTH0, st); launch_synth0(p->P, p->prep, phase, st, nb); }
     } else {
         if (ensure_spin(p, spin)) return 1;
         if (grow(p, &p->prep, &p->prep_cap, p->nent[spin] * 4)) return 1;
@@ -831,9 +832,21 @@ int pl_alm2map_grad_pair(pl_plan *p, int spin, const double *alm_g1, const doubl
 int pl_alm2map_batch2(pl_plan *p, int spin, const double *alm_gc_1, const double *alm_gc_2, const double *fl, double *maps4, void *stream)
 {
     if (!p) return fail("null plan");
-    if (spin < 1 || spin > kMaxSpin) return fail("pl_alm2map_batch2: spin must be 1..3");
+    if (spin < 0 || spin > kMaxSpin) return fail("pl_alm2map_batch2: spin must be 0..3");
     if (!alm_gc_1 || !alm_gc_2 || !maps4) return fail("pl_alm2map_batch2: null alm / map pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (spin == 0) {  // two scalar inputs (one alm array each) -> the two rows of maps4; fine grids: one recursion for both (k_leg_synth0<R, true>)
+        if (grow(p, &p->prep, &p->prep_cap, p->P.nent0 * 4 * 2) || grow(p, &p->phase, &p->phase_cap, 2 * pl_plan_phase_doubles(p, 0))) return 1;
+        launch_prep0(p->P, alm_gc_1, fl, p->prep, st, 1);
+        launch_prep0(p->P, alm_gc_2, fl, p->prep + p->P.nent0 * 4, st, 1);
+        { ProfScope ps(p, synth0_pairs(p->P, 2) ? PK_LEG_SYNTH0_PAIR : PK_LEG_SYNTH0, st); launch_synth0(p->P, p->prep, p->phase, st, 2); }
+        HIPCHK(hipGetLastError());
+        {
+            ProfScope ps(p, PK_FFT_SYNTH, st);
+            HIPCHK(launch_phase2map(p->P, p->F, p->fs, mlim_of(p, 0), 2, p->phase, maps4, st));
+        }
+        return 0;
+    }
     if (ensure_spin(p, spin)) return 1;
     if (grow(p, &p->prep, &p->prep_cap, p->nent[spin] * 4) || grow(p, &p->prep2, &p->prep2_cap, p->nent[spin] * 4) ||
         grow(p, &p->phase, &p->phase_cap, 2 * pl_plan_phase_doubles(p, spin)))

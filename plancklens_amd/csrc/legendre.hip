@@ -304,12 +304,16 @@ __device__ __forceinline__ void seed_loads(const DevSeedTab &T, int m, int ip, d
 // -----------------------------------------------------------------------------------------------------
 // synthesis, spin 0
 // -----------------------------------------------------------------------------------------------------
-template <int R>
+// IN2 (round 6): two inputs on one recursion -- batch entries (2 y, 2 y + 1) of the prep block share every recursion value (it depends on m and the
+// ring only): 2 + 2 x 4 = 10 FMAs per two-l step and ring for two maps instead of 2 x (2 + 4) = 12.  The sums of each input are formed in the same
+// order from the same values as by the single-input kernel: bit-identical phase values.  Phase components 2 y and 2 y + 1 of 2 gridDim.y.
+template <int R, bool IN2 = false>
 __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__restrict__ prep_, double *__restrict__ phase)
 {
-    const double4 *__restrict__ prep = prep_ + (int64_t)blockIdx.y * P.nent0;
+    constexpr int NI = IN2 ? 2 : 1;
+    const double4 *__restrict__ prep = prep_ + (int64_t)(NI * blockIdx.y) * P.nent0;
     constexpr int RG = 64 * R;
-    __shared__ double tile[RG * 16];  // [ring][m_local 4][4]
+    __shared__ double tile[NI * RG * 16];  // [input][ring][m_local 4][4]
     const int wave = wave_id();
     const int lane = threadIdx.x & 63;
     const int ngroups = (P.npairs + RG - 1) / RG;
@@ -320,9 +324,11 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
     if (P.mlim0[last] < 4 * mg) return;  // every ring of the group is pruned for every m of the group
     const int m = 4 * mg + wave;
 
-    double cr[R], ci[R], dr[R], di[R];
+    double cr[NI][R], ci[NI][R], dr[NI][R], di[NI][R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) cr[k] = ci[k] = dr[k] = di[k] = 0.0;
+    for (int n = 0; n < NI; ++n)
+#pragma unroll
+        for (int k = 0; k < R; ++k) cr[n][k] = ci[n][k] = dr[n][k] = di[n][k] = 0.0;
 
     if (m <= P.mmax) {
         Rec0 r[R];
@@ -340,8 +346,10 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
         const int64_t base = P.off0[m];
         const double2 *__restrict__ ab = reinterpret_cast<const double2 *>(P.ab0) + base;
         const double4 *__restrict__ cd = prep + base;
+        const double4 *__restrict__ cd2 = cd + (IN2 ? P.nent0 : 0);
         const d2v_t *__restrict__ abv = reinterpret_cast<const d2v_t *>(ab);
         const d4v_t *__restrict__ cdv = reinterpret_cast<const d4v_t *>(cd);
+        const d4v_t *__restrict__ cdv2 = reinterpret_cast<const d4v_t *>(cd2);
         int il = seeded ? __builtin_amdgcn_readfirstlane(P.seed_syn0.il[m * ngroups + g]) : 0;
         bool all_done = false;
         {
@@ -350,8 +358,9 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
             for (int k = 0; k < R; ++k) live = live || (r[k].sc != kNeverActive);
             if (!wave_any(live)) il = nil;  // every ring of this wave is pruned for this m
         }
-        StreamPrefetch pf;
+        StreamPrefetch pf, pf2;
         pf.start<32, 16>(cd, ab, il, nil, lane);
+        if constexpr (IN2) pf2.start<32, 16>(cd2, ab, il, nil, lane);
         // phase A: no lane of the wave has reached the IEEE range yet -- recursion only; the rescale check is deferred
         // to the end of each block of 8 il (see rec0_renorm_up)
         while (il + 8 <= nil) {
@@ -360,6 +369,7 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
             for (int k = 0; k < R; ++k) act = act || rec0_counts(r[k], kActSynth0);
             if (wave_any(act)) break;
             pf.step<32, 16>(cd, ab, il, nil, lane);
+            if constexpr (IN2) pf2.step<32, 16>(cd2, ab, il, nil, lane);
             const d8v_t c0 = ld8(ab + il), c1 = ld8(ab + il + 4);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -382,20 +392,29 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
 #pragma unroll
             for (int k = 0; k < R; ++k) mk[k] = r[k].sc == 0 ? 1.0 : 0.0;
             pf.step<32, 16>(cd, ab, il, nil, lane);
+            if constexpr (IN2) pf2.step<32, 16>(cd2, ab, il, nil, lane);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const d8v_t c = ld8(ab + il + 4 * h);
                 const d8v_t q0 = ldc<d8v_t>(cdv + il + 4 * h), q1 = ldc<d8v_t>(cdv + il + 4 * h + 2);
+                d8v_t p0 = q0, p1 = q1;
+                if constexpr (IN2) { p0 = ldc<d8v_t>(cdv2 + il + 4 * h); p1 = ldc<d8v_t>(cdv2 + il + 4 * h + 2); }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int o = 4 * (t & 1);
                     const double qx = t < 2 ? q0[o] : q1[o], qy = t < 2 ? q0[o + 1] : q1[o + 1];
                     const double qz = t < 2 ? q0[o + 2] : q1[o + 2], qw = t < 2 ? q0[o + 3] : q1[o + 3];
+                    const double px = t < 2 ? p0[o] : p1[o], py = t < 2 ? p0[o + 1] : p1[o + 1];
+                    const double pz = t < 2 ? p0[o + 2] : p1[o + 2], pw = t < 2 ? p0[o + 3] : p1[o + 3];
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
                         const double v = r[k].p1 * mk[k];
-                        cr[k] = fma(v, qx, cr[k]); ci[k] = fma(v, qy, ci[k]);
-                        dr[k] = fma(v, qz, dr[k]); di[k] = fma(v, qw, di[k]);
+                        cr[0][k] = fma(v, qx, cr[0][k]); ci[0][k] = fma(v, qy, ci[0][k]);
+                        dr[0][k] = fma(v, qz, dr[0][k]); di[0][k] = fma(v, qw, di[0][k]);
+                        if constexpr (IN2) {
+                            cr[1][k] = fma(v, px, cr[1][k]); ci[1][k] = fma(v, py, ci[1][k]);
+                            dr[1][k] = fma(v, pz, dr[1][k]); di[1][k] = fma(v, pw, di[1][k]);
+                        }
                         rec0_step_fast(r[k], c[2 * t], c[2 * t + 1]);
                     }
                 }
@@ -406,67 +425,87 @@ __global__ __launch_bounds__(256) void k_leg_synth0(DevPlan P, const double4 *__
         }
         // phase C: every live lane is in the IEEE range -- pure FMA stream, coefficient loads one trip ahead
         if (all_done) {
-            auto one_step = [&](const d2v_t &c_ab, const d4v_t &c) {
+            auto one_step = [&](const d2v_t &c_ab, const d4v_t &c, const d4v_t &c2) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     const double v = r[k].p1;
-                    cr[k] = fma(v, c.x, cr[k]); ci[k] = fma(v, c.y, ci[k]);
-                    dr[k] = fma(v, c.z, dr[k]); di[k] = fma(v, c.w, di[k]);
+                    cr[0][k] = fma(v, c.x, cr[0][k]); ci[0][k] = fma(v, c.y, ci[0][k]);
+                    dr[0][k] = fma(v, c.z, dr[0][k]); di[0][k] = fma(v, c.w, di[0][k]);
+                    if constexpr (IN2) {
+                        cr[1][k] = fma(v, c2.x, cr[1][k]); ci[1][k] = fma(v, c2.y, ci[1][k]);
+                        dr[1][k] = fma(v, c2.z, dr[1][k]); di[1][k] = fma(v, c2.w, di[1][k]);
+                    }
                     rec0_step_fast(r[k], c_ab.x, c_ab.y);
                 }
             };
             // two coefficient sets of two steps each, loaded one set ahead (see k_leg_synths)
             d2v_t A0 = ldc<d2v_t>(abv + il), A1 = ldc<d2v_t>(abv + min(il + 1, nil - 1));
             d4v_t Ac0 = ldc<d4v_t>(cdv + il), Ac1 = ldc<d4v_t>(cdv + min(il + 1, nil - 1));
+            d4v_t Ad0 = Ac0, Ad1 = Ac1;
+            if constexpr (IN2) { Ad0 = ldc<d4v_t>(cdv2 + il); Ad1 = ldc<d4v_t>(cdv2 + min(il + 1, nil - 1)); }
             while (il + 3 < nil) {
                 pf.step<32, 16>(cd, ab, il, nil, lane);
+                if constexpr (IN2) pf2.step<32, 16>(cd2, ab, il, nil, lane);
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 const d2v_t B0 = ldc<d2v_t>(abv + il + 2), B1 = ldc<d2v_t>(abv + il + 3);
                 const d4v_t Bc0 = ldc<d4v_t>(cdv + il + 2), Bc1 = ldc<d4v_t>(cdv + il + 3);
+                d4v_t Bd0 = Bc0, Bd1 = Bc1;
+                if constexpr (IN2) { Bd0 = ldc<d4v_t>(cdv2 + il + 2); Bd1 = ldc<d4v_t>(cdv2 + il + 3); }
                 __builtin_amdgcn_sched_barrier(0);
-                one_step(A0, Ac0); one_step(A1, Ac1);
+                one_step(A0, Ac0, Ad0); one_step(A1, Ac1, Ad1);
                 __builtin_amdgcn_sched_barrier(0);
                 const int ip = min(il + 4, nil - 2);
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 A0 = ldc<d2v_t>(abv + ip); A1 = ldc<d2v_t>(abv + ip + 1); Ac0 = ldc<d4v_t>(cdv + ip); Ac1 = ldc<d4v_t>(cdv + ip + 1);
+                if constexpr (IN2) { Ad0 = ldc<d4v_t>(cdv2 + ip); Ad1 = ldc<d4v_t>(cdv2 + ip + 1); }
                 __builtin_amdgcn_sched_barrier(0);
-                one_step(B0, Bc0); one_step(B1, Bc1);
+                one_step(B0, Bc0, Bd0); one_step(B1, Bc1, Bd1);
                 __builtin_amdgcn_sched_barrier(0);
                 il += 4;
             }
-            if (il + 1 < nil) { one_step(A0, Ac0); one_step(A1, Ac1); il += 2; }
+            if (il + 1 < nil) { one_step(A0, Ac0, Ad0); one_step(A1, Ac1, Ad1); il += 2; }
         }
         // tail (at most 7 il, any mix of active and scaled lanes): one careful step at a time
         for (; il < nil; ++il) {
             const double2 c_ab = ab[il];
             const double4 c = cd[il];
+            const double4 c2 = cd2[il];
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const double v = rec0_value(r[k]);
-                cr[k] = fma(v, c.x, cr[k]); ci[k] = fma(v, c.y, ci[k]);
-                dr[k] = fma(v, c.z, dr[k]); di[k] = fma(v, c.w, di[k]);
+                cr[0][k] = fma(v, c.x, cr[0][k]); ci[0][k] = fma(v, c.y, ci[0][k]);
+                dr[0][k] = fma(v, c.z, dr[0][k]); di[0][k] = fma(v, c.w, di[0][k]);
+                if constexpr (IN2) {
+                    cr[1][k] = fma(v, c2.x, cr[1][k]); ci[1][k] = fma(v, c2.y, ci[1][k]);
+                    dr[1][k] = fma(v, c2.z, dr[1][k]); di[1][k] = fma(v, c2.w, di[1][k]);
+                }
                 rec0_step_careful(r[k], c_ab.x, c_ab.y);
             }
         }
         pf.drain();
+        if constexpr (IN2) pf2.drain();
     }
     // F_north = C + x D, F_south = C - x D  -> LDS tile -> ring-major global phase array
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const int rl = k * 64 + lane;
-        const int ip = min(g * RG + rl, P.npairs - 1);
-        const double x = P.cth[ip];
-        double *t = tile + rl * 16 + wave * 4;
-        t[0] = fma(x, dr[k], cr[k]); t[1] = fma(x, di[k], ci[k]);
-        t[2] = fma(-x, dr[k], cr[k]); t[3] = fma(-x, di[k], ci[k]);
-    }
+    for (int n = 0; n < NI; ++n)
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int rl = k * 64 + lane;
+            const int ip = min(g * RG + rl, P.npairs - 1);
+            const double x = P.cth[ip];
+            double *t = tile + n * (RG * 16) + rl * 16 + wave * 4;
+            t[0] = fma(x, dr[n][k], cr[n][k]); t[1] = fma(x, di[n][k], ci[n][k]);
+            t[2] = fma(-x, dr[n][k], cr[n][k]); t[3] = fma(-x, di[n][k], ci[n][k]);
+        }
     __syncthreads();
-    for (int c = threadIdx.x; c < RG * 8; c += 256) {
-        const int rl = c >> 3, part = c & 7;
+    const int ncomp = NI * (int)gridDim.y;
+    for (int c = threadIdx.x; c < NI * RG * 8; c += 256) {
+        const int n = c / (RG * 8), cc = c - n * (RG * 8);
+        const int rl = cc >> 3, part = cc & 7;
         const int ip = g * RG + rl;
         if (ip < P.npairs) {
-            double2 v = *reinterpret_cast<const double2 *>(tile + rl * 16 + part * 2);
-            *reinterpret_cast<double2 *>(phase + (((int64_t)ip * gridDim.y + blockIdx.y) * P.mstride + 4 * mg) * 4 + part * 2) = v;
+            double2 v = *reinterpret_cast<const double2 *>(tile + n * (RG * 16) + rl * 16 + part * 2);
+            *reinterpret_cast<double2 *>(phase + (((int64_t)ip * ncomp + NI * blockIdx.y + n) * P.mstride + 4 * mg) * 4 + part * 2) = v;
         }
     }
 }
@@ -1619,23 +1658,34 @@ void launch_preps(const DevPlan &P, const DevSpinTab &S, int spin, const double 
 }
 
 template <int R>
-static void launch_synth0_r(const DevPlan &P, const double *prep, double *phase, hipStream_t st, int nb)
+static void launch_synth0_r(const DevPlan &P, const double *prep, double *phase, hipStream_t st, int nb, bool pair)
 {
     constexpr int RG = 64 * R;
     const int ngroups = (P.npairs + RG - 1) / RG, nmg = own_mgroups(P);
     if (nmg == 0) return;
-    hipLaunchKernelGGL(k_leg_synth0<R>, dim3(ngroups * nmg, nb), dim3(256), 0, st, P, reinterpret_cast<const double4 *>(prep), phase);
+    if (pair) hipLaunchKernelGGL((k_leg_synth0<R, true>), dim3(ngroups * nmg, nb / 2), dim3(256), 0, st, P, reinterpret_cast<const double4 *>(prep), phase);
+    else hipLaunchKernelGGL((k_leg_synth0<R, false>), dim3(ngroups * nmg, nb), dim3(256), 0, st, P, reinterpret_cast<const double4 *>(prep), phase);
+}
+
+// An even block of inputs on fine grids goes through the recursion two at a time (k_leg_synth0<R, true>: bit-identical phase values, 10 instead of
+// 12 FMAs per two-l step for two maps).  PLSHTS_DEBUG=1 PLSHTS_S0_PAIR_NSIDE: smallest nside (default 1024; a large value switches it off).
+bool synth0_pairs(const DevPlan &P, int nb)
+{
+    static const int nside_min = env_int("PLSHTS_S0_PAIR_NSIDE", 1024);
+    const int r = r0_synth(P);
+    return nb >= 2 && nb % 2 == 0 && P.nside >= nside_min && (r == 3 || r == 4);
 }
 
 void launch_synth0(const DevPlan &P, const double *prep, double *phase, hipStream_t st, int nb)
 {
+    const bool pair = synth0_pairs(P, nb);
     switch (r0_synth(P)) {
-    case 1: launch_synth0_r<1>(P, prep, phase, st, nb); break;
-    case 2: launch_synth0_r<2>(P, prep, phase, st, nb); break;
-    case 5: launch_synth0_r<5>(P, prep, phase, st, nb); break;
-    case 6: launch_synth0_r<6>(P, prep, phase, st, nb); break;
-    case 4: launch_synth0_r<4>(P, prep, phase, st, nb); break;
-    default: launch_synth0_r<3>(P, prep, phase, st, nb); break;
+    case 1: launch_synth0_r<1>(P, prep, phase, st, nb, false); break;
+    case 2: launch_synth0_r<2>(P, prep, phase, st, nb, false); break;
+    case 5: launch_synth0_r<5>(P, prep, phase, st, nb, false); break;
+    case 6: launch_synth0_r<6>(P, prep, phase, st, nb, false); break;
+    case 4: launch_synth0_r<4>(P, prep, phase, st, nb, pair); break;
+    default: launch_synth0_r<3>(P, prep, phase, st, nb, pair); break;
     }
 }
 

@@ -409,7 +409,7 @@ class library(object):
         (lib_filt2map.get_irespmap_batch2 / get_gpmap_batch2; same legs on both sides only)."""
         f2map1, f2map2 = self._legs(False)
         idxs = (idx0, idx1)
-        tmaps = [f2map1.get_irestmap(i) for i in idxs]
+        tmaps = f2map1.get_irestmap_batch2(idx0, idx1)  # (the two inverse-variance filtered T maps on one Legendre recursion)
         resp = f2map1.get_irespmap_batch2(idx0, idx1)
         gp3 = f2map2.get_gpmap_batch2(idx0, idx1, 3, k='p')
         out = []
@@ -451,7 +451,9 @@ class library(object):
             if gts is None:
                 out.append(tuple(self._get_sim_Tgclm_dev(idx, 'ptt')))
             else:
-                out.append(tuple(self._gc_from_product(*dev.qe_lens_product((f2map1.get_irestmap(idx), gts[j][0], gts[j][1]), None), 'T')))
+                if j == 0:
+                    tmaps = f2map1.get_irestmap_batch2(idx0, idx1)
+                out.append(tuple(self._gc_from_product(*dev.qe_lens_product((tmaps[j], gts[j][0], gts[j][1]), None), 'T')))
             if emit is not None:
                 emit(*out[-1])
         return out
@@ -935,6 +937,16 @@ class lib_filt2map(object):
             assert isinstance(xfilt, dict) and 'e' in xfilt.keys() and 'b' in xfilt.keys()
             e, b = dev.almxfl(e, xfilt['e']), dev.almxfl(b, xfilt['b'])
         return shts.alm2map_spin([e, b], self.nside, 2, lmax, fl=0.5 * np.ones(lmax + 1))
+
+    def get_irestmap_batch2(self, idx0, idx1):
+        """get_irestmap of two simulations: their scalar syntheses in one call (pl_alm2map_batch2 with spin 0: one Legendre recursion for both on
+        fine grids); maps bit-identical to the one-by-one evaluation, which serves every case the pair form does not."""
+        t0, t1 = self._alm('tlm', idx0), self._alm('tlm', idx1)
+        if (not options.opts.batch2 or shts._lane_active() or not (isinstance(t0, torch.Tensor) and t0.is_cuda and isinstance(t1, torch.Tensor) and t1.is_cuda)
+                or t0.numel() != t1.numel()):
+            return [self.get_irestmap(idx0), self.get_irestmap(idx1)]
+        out = shts.alm2map_batch2(t0, t1, self.nside, lmax=self._lmax(t0))
+        return [out[0], out[1]]
 
     # ---- two simulations on one Legendre recursion (pl_alm2map_batch2): same maps, bit for bit, at 0.8 of the time -----------
     def get_irespmap_batch2(self, idx0, idx1):

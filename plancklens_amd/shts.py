@@ -85,7 +85,7 @@ class Plan(object):
         return int(_lib.lib().pl_plan_phase_doubles(self.h, int(spin)))
 
     PROFILE_KINDS = ('leg_synth0', 'leg_synths', 'leg_anal0', 'leg_anals', 'fft_synth', 'fft_anal', 'leg_synths_grad', 'leg_synths_pair',
-                     'leg_synths_batch2')
+                     'leg_synths_batch2', 'leg_synth0_pair')
 
     def profile(self, on=True):
         self._profiling = bool(on)
@@ -567,6 +567,22 @@ def alm2map_spin_batch2(gclm1, gclm2, nside, spin, lmax, fl=None):
     out = torch.empty((4, plan.npix), dtype=torch.float64, device=a1.device)
     _lib.check(_lib.lib().pl_alm2map_batch2(plan.h, int(spin), _ptr(a1), _ptr(a2), _ptr(f), _ptr(out), _stream()))
     return [out[0], out[1]], [out[2], out[3]]
+
+
+def alm2map_batch2(alm1, alm2, nside, lmax=None, fl=None):
+    """The scalar synthesis of two inputs (two simulations) in one call (pl_alm2map_batch2 with spin 0, device arrays only): returns the two
+    maps as the rows of one (2, npix) tensor, bit-identical to two alm2map calls.  On grids of nside >= 1024 the two inputs share one Legendre
+    recursion (k_leg_synth0<R, true>: 10 instead of 12 FMAs per two-l step and ring pair for the two maps)."""
+    assert _is_dev(alm1) and _is_dev(alm2), 'alm2map_batch2 works on device arrays'
+    a1, a2 = alm1.to(torch.complex128).contiguous(), alm2.to(torch.complex128).contiguous()
+    if lmax is None:
+        lmax = Alm.getlmax(a1.numel())
+    plan = get_plan(nside, lmax)
+    assert a1.numel() == plan.nalm and a2.numel() == plan.nalm, (a1.shape, a2.shape, plan.nalm)
+    f = _fl_arg(fl, lmax, True)
+    out = torch.empty((2, plan.npix), dtype=torch.float64, device=a1.device)
+    _lib.check(_lib.lib().pl_alm2map_batch2(plan.h, 0, _ptr(a1), _ptr(a2), _ptr(f), _ptr(out), _stream()))
+    return out
 
 
 def map2alm_spin(maps, spin, lmax=None, mmax=None, fl=None):

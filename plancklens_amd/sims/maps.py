@@ -44,7 +44,20 @@ class cmb_maps(object):
         return res if out is None else out.copy_(res)
 
     def _tsky(self, idx):
+        held = self.__dict__.get('_pair_held_t')
+        if held is not None and held[0] == idx:  # made together with the previous simulation (hint_pair)
+            self._pair_held_t = None
+            return held[1]
         tlm = dev.to_dev(self.sims_cmb_len.get_sim_tlm(idx))
+        nxt = self.__dict__.get('_pair_next_t')
+        self._pair_next_t = None
+        if nxt is not None and nxt[0] == idx and self.device_maps:
+            # the temperature sky of the announced next simulation in the same call (pl_alm2map_batch2 with spin 0: one Legendre recursion for
+            # both on fine grids; bit-identical maps)
+            t2 = dev.to_dev(self.sims_cmb_len.get_sim_tlm(nxt[1]))
+            both = shts.alm2map_batch2(tlm, t2, self.nside, fl=self.cl_transf_T)
+            self._pair_held_t = (nxt[1], both[1])
+            return both[0]
         return shts.alm2map(tlm, self.nside, fl=self.cl_transf_T)
 
     def _psky(self, idx):
@@ -83,10 +96,11 @@ class cmb_maps(object):
         self._add_noise(U, idx, 2, out=outu)
 
     def hint_pair(self, idx0, idx1):
-        """The caller is about to ask for the polarization maps of idx0 and then idx1 (a mean-field loop serving simulations in
-        pairs): with device maps the two sky syntheses then share one Legendre recursion.  A hint only: any other order of calls
+        """The caller is about to ask for the maps of idx0 and then idx1 (a mean-field loop serving simulations in pairs): with device
+        maps the polarization sky syntheses of the two then share one Legendre recursion, and so do the temperature ones.  A hint only: any other order of calls
         gives the same maps one by one."""
         self._pair_next = (idx0, idx1)
+        self._pair_next_t = (idx0, idx1)
 
     def _noise_term(self, idx, idf):
         return (self.get_sim_tnoise, self.get_sim_qnoise, self.get_sim_unoise)[idf](idx)

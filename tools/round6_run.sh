@@ -14,3 +14,9 @@ fi
 if [[ $WHAT == *tests* ]]; then
   timeout ${TEST_TIMEOUT:-3000} python3 -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-} > gpurun_out/$TAG/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -15 gpurun_out/$TAG/pytest_gpu.log
 fi
+if [[ $WHAT == *s0pair* ]]; then
+  for sz in "2048 2048" "1024 1024" "4096 4096"; do timeout 300 python3 tools/s0_pair_ab.py $sz 10; done > gpurun_out/$TAG/s0_pair_ab.txt 2>&1; cat gpurun_out/$TAG/s0_pair_ab.txt
+fi
+if [[ $WHAT == *config5* ]]; then
+  timeout 900 python3 bench.py --config 5 --steps 8 > gpurun_out/$TAG/bench_config5.json 2> gpurun_out/$TAG/bench_config5.err; echo "config5 rc $?"; head -c 700 gpurun_out/$TAG/bench_config5.json; echo
+fi
