@@ -132,6 +132,7 @@ __global__ __launch_bounds__(kThreads) void k_persistent(int nphase, int work, d
 int main(int argc, char **argv)
 {
     const int nphase = argc > 1 ? atoi(argv[1]) : 7 * 27;  // seams of the nside-128 level of one temperature iteration
+    const char *order = argc > 2 ? argv[2] : "012";        // the order in which the three forms are timed at each phase length (0 graph, 1 xcd barrier, 2 flat barrier)
     const int reps = 20;
     CHK(hipSetDevice(0));
     hipStream_t st;
@@ -142,8 +143,8 @@ int main(int argc, char **argv)
     CHK(hipMalloc(&A, nb)); CHK(hipMalloc(&B, nb)); CHK(hipMalloc(&A2, nb)); CHK(hipMalloc(&B2, nb)); CHK(hipMalloc(&bar, sizeof(Bar)));
     std::vector<double> h0((size_t)kWG * kStrip), fin_h[3] = {h0, h0, h0};
     for (size_t i = 0; i < h0.size(); ++i) h0[i] = 1.0 + 1e-3 * (double)(i % 977);
-    printf("seam probe: %d workgroups x %d threads, %d phases (%d seams), 8 KB strip per workgroup and phase, every read crosses workgroups\n", kWG,
-           kThreads, nphase, nphase - 1);
+    printf("seam probe: %d workgroups x %d threads, %d phases (%d seams), 8 KB strip per workgroup and phase, every read crosses workgroups; forms timed in the order %s\n", kWG,
+           kThreads, nphase, nphase - 1, order);
     printf("%8s %14s %14s %14s | %12s %12s %12s | %s\n", "work", "graph us/phase", "xcd-bar", "flat-bar", "seam(graph)", "seam(xcd)", "seam(flat)", "check");
     double base[3] = {0, 0, 0};
     for (int work : {0, 200, 800, 2000, 4000}) {
@@ -155,7 +156,8 @@ int main(int argc, char **argv)
         CHK(hipStreamEndCapture(st, &g));
         CHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         double t[3];
-        for (int form = 0; form < 3; ++form) {
+        for (int fi = 0; fi < 3; ++fi) {
+            const int form = order[fi] - '0';
             double best = 1e30;
             for (int r = 0; r < reps + 2; ++r) {
                 double *a = form == 0 ? A : A2, *bb = form == 0 ? B : B2;

@@ -20,3 +20,6 @@ fi
 if [[ $WHAT == *config5* ]]; then
   timeout 900 python3 bench.py --config 5 --steps 8 > gpurun_out/$TAG/bench_config5.json 2> gpurun_out/$TAG/bench_config5.err; echo "config5 rc $?"; head -c 700 gpurun_out/$TAG/bench_config5.json; echo
 fi
+if [[ $WHAT == *probe2* ]]; then
+  for o in 210 102 012; do timeout 300 tools/probes/seam_probe 189 $o; done > gpurun_out/$TAG/seam_probe_orders.txt 2>&1; cat gpurun_out/$TAG/seam_probe_orders.txt
+fi
