@@ -134,6 +134,7 @@ def parse(argv=None):
     ap.add_argument('--cg-iters', type=int, default=100)
     ap.add_argument('--cg-batches', type=str, default='2,4,8', help='block sizes B > 1 of the CG block (simulations filtered together); empty: none')
     ap.add_argument('--sims-seed', type=int, default=None, help='seed of the resident input maps (default 1000 + rank: every rank its own sky)')
+    ap.add_argument('--resident-sets', type=int, default=2, help='distinct T, Q, U realisations resident in HBM; consecutive pairs of simulations are served different ones')
     ap.add_argument('--plan-opt', action='append', default=[], metavar='NAME=VALUE',
                     help='pl_plan_opts field for every plan of the run (shts.plan_options), e.g. fft_legacy=1: a development aid, not a number to quote')
     ap.add_argument('--no-plan-stats', action='store_true', help='skip the nside-4096 plan-creation measurement (time and host memory of the table build)')
@@ -193,9 +194,17 @@ def launch_ranks(n, argv):
 
 class resident_sims(object):
     """Synthetic T, Q, U maps held in HBM: Gaussian T/E/B sky with TE correlation (FFP10 lensed spectra) x 5'
-    beam + white noise (35 / 55 muK-arcmin), SURVEY.md 8(d).  The same maps serve every simulation index."""
+    beam + white noise (35 / 55 muK-arcmin), SURVEY.md 8(d).  `nsets` distinct realisations (seed, seed + 7919, ...) are resident; simulation
+    idx is served set (idx // 2) % nsets, so that consecutive PAIRS of a mean-field loop -- the unit the estimator evaluates -- see different
+    maps (round 6: a replayed pair reads its inputs through a table of device addresses, so this costs 8 bytes per map, not a copy)."""
 
-    def __init__(self, nside, lmax, cls, transf, nlev_t, nlev_p, seed):
+    def __init__(self, nside, lmax, cls, transf, nlev_t, nlev_p, seed, nsets=2):
+        self.seed, self.nsets = seed, max(1, int(nsets))
+        self.sets = [self._make(nside, lmax, cls, transf, nlev_t, nlev_p, seed + 7919 * k) for k in range(self.nsets)]
+        self.tmap, self.qmap, self.umap = self.sets[0]
+
+    @staticmethod
+    def _make(nside, lmax, cls, transf, nlev_t, nlev_p, seed):
         import torch
         from plancklens_amd import dev, hp, shts
         rng = np.random.default_rng(seed)
@@ -215,26 +224,29 @@ class resident_sims(object):
         gen.manual_seed(seed)
         vamin = np.sqrt(hp.nside2pixarea(nside, degrees=True)) * 60
         npix = hp.nside2npix(nside)
-        self.tmap = shts.alm2map(dev.to_dev(tlm), nside, fl=transf) + nlev_t / vamin * torch.randn(npix, generator=gen, dtype=torch.float64, device='cuda')
+        tmap = shts.alm2map(dev.to_dev(tlm), nside, fl=transf) + nlev_t / vamin * torch.randn(npix, generator=gen, dtype=torch.float64, device='cuda')
         q, u = shts.alm2map_spin([dev.to_dev(elm), dev.to_dev(blm)], nside, 2, lmax, fl=transf)
         qu = torch.empty((2, npix), dtype=torch.float64, device='cuda')  # (Q, U) as the two rows of one array: what map2alm_spin takes
         qu[0] = q + nlev_p / vamin * torch.randn(npix, generator=gen, dtype=torch.float64, device='cuda')
         qu[1] = u + nlev_p / vamin * torch.randn(npix, generator=gen, dtype=torch.float64, device='cuda')
-        self.qmap, self.umap = qu[0], qu[1]
-        self.seed = seed
+        return tmap, qu[0], qu[1]
 
     # the tensors handed out are never modified: a consumer that keeps a copy of one (the static input slots of the estimator's replayed
-    # graph, qest.library._pair_graph) need not copy it again while storage, shape and version are unchanged -- inputs resident in HBM
+    # graph on its slot route, options.opts.qe_indirect off) need not copy it again while storage, shape and version are unchanged
     stable_maps = True
 
     def hashdict(self):
-        return {'resident_sims': self.seed}
+        return {'resident_sims': self.seed, 'nsets': self.nsets}
+
+    def _set(self, idx):
+        return self.sets[(int(idx) // 2) % self.nsets]
 
     def get_sim_tmap(self, idx):
-        return self.tmap
+        return self._set(idx)[0]
 
     def get_sim_pmap(self, idx):
-        return self.qmap, self.umap
+        s_ = self._set(idx)
+        return s_[1], s_[2]
 
 
 def usable_cpus():
@@ -498,7 +510,7 @@ def run_rank(args):
     t_plan0 = time.perf_counter()
     shts.get_plan(nside, lmax)  # geometry, recursion and ring-FFT tables of the benchmarked grid (built on the host, uploaded once)
     plan_create_s = time.perf_counter() - t_plan0
-    sims = resident_sims(nside, lmax, cl_len, transf, nlev_t, nlev_p, seed=(1000 + rank) if args.sims_seed is None else args.sims_seed)
+    sims = resident_sims(nside, lmax, cl_len, transf, nlev_t, nlev_p, seed=(1000 + rank) if args.sims_seed is None else args.sims_seed, nsets=args.resident_sets)
     tmp = tempfile.mkdtemp(prefix='plbench_r%d_' % rank)
     mpi.rank = 0  # every rank owns a private scratch directory: all of them create their hash files
     mpi.size = 1
@@ -568,31 +580,6 @@ def run_rank(args):
     assert nrec == K, 'timed region ran %d reconstructions on rank %d, expected %d' % (nrec, rank, K)
     last_dev, last_dev_key = qlms._last_dev, qlms._last_dev_key
     eager_pass = None
-    fresh_inputs = None
-    if graphed and not args.qe_only:
-        # The timed region above serves the SAME resident maps to every index, so the replayed graph's input slots are filled once
-        # (`stable_maps`).  A run over distinct resident maps copies 3 x 8 npix bytes per reconstruction into the slots first: the same K
-        # reconstructions once more with that copy forced on every replay (reported beside `value`, never instead of it).
-        g_keep, key_keep = (last_dev[0].clone(), None), last_dev_key
-        qlms._mem.clear()
-        sims.stable_maps = False
-        try:
-            sync_all()
-            t0f = time.perf_counter()
-            qlms.get_sim_qlm_mf(key, np.arange(3 * world * K, 4 * world * K), collective=True)
-            for f_ in list(dev.host_future._in_flight):
-                f_.result()
-            torch.cuda.synchronize()
-            sync_all()
-            dtf = time.perf_counter() - t0f
-        finally:
-            sims.stable_maps = True
-        if use_dist:
-            dtf, = reduce_max([dtf])
-        fresh_inputs = {'value': world * K / dtf, 'ms_per_step': 1e3 * dtf / K,
-                        'note': 'same reconstructions with the 3 x 8 npix B of every simulation copied into the replayed graph\'s input slots before each '
-                                'replay (what distinct HBM-resident maps cost; `value` replays one resident set, whose slots are filled once)'}
-        last_dev, last_dev_key = g_keep, key_keep
     if graphed:
         # Per-kernel durations: HIP events cannot be recorded inside a replayed graph, so the SAME K reconstructions per rank run once
         # more right here, launched eagerly (use_graph off, same paired kernels in the same order) with the per-stage events on the launch
@@ -748,6 +735,7 @@ def run_rank(args):
                                    % (key, nside, lmax, lmax_qlm, world * K, K) +
                                    (' -- QE-ONLY variant: filtered alms already resident, the filter transforms are not timed' if args.qe_only else ''),
                        'nside': nside, 'lmax': lmax, 'lmax_qlm': lmax_qlm, 'key': key, 'sims_per_gpu': K,
+                       'resident_map_sets': sims.nsets,  # distinct T, Q, U realisations in HBM: consecutive pairs of simulations read different ones
                        'parallelism': 'sim-sharded x%d' % world},
         }
         # gradient-only synthesis (curl alm = 0, shts.alm2map_spin([G, None])): 8 recurrence + 8 accumulation flop per step;
@@ -792,8 +780,6 @@ def run_rank(args):
         res['kernels'] = per_kernel
         if eager_pass is not None:
             res['eager_pass'] = eager_pass
-        if fresh_inputs is not None:
-            res['fresh_inputs'] = fresh_inputs
         leg = [k for k in per_kernel if k in alg]
         if leg:
             dom = max(leg, key=lambda k: prof[k][0])  # largest summed time in the timed region

@@ -136,6 +136,11 @@ int pl_alm2map_grad_pair(pl_plan *plan, int spin, const double *alm_g1, const do
 int pl_alm2map_batch2(pl_plan *plan, int spin, const double *alm_gc_1_dev, const double *alm_gc_2_dev, const double *fl_dev, double *maps4_dev,
                       void *stream);
 int pl_map2alm(pl_plan *plan, int spin, const double *map, double *alm, const double *fl, int where, void *stream);
+/* pl_map2alm on device maps whose ADDRESSES are read, when the kernels run, from a table in device memory (one entry per component: 1 for spin 0, 2 for
+ * spin s; each an npix map anywhere in device memory).  A launch captured into a HIP graph can be replayed on other input maps by rewriting the table --
+ * no copy into fixed input slots (qest.library._pair_graph) -- and (Q, U) need not be the rows of one array.  Device pointers only; same kernels and
+ * arithmetic as pl_map2alm (hp.map2alm(_spin)(..., iter=0), shts.py:16-30), bit-identical results. */
+int pl_map2alm_ind(pl_plan *plan, int spin, const double *const *maps_ind_dev, double *alm_dev, const double *fl_dev, void *stream);
 
 /* Stage-level entry points: tests, stage timings, and callers that pipeline independent transforms (the Legendre stage of
  * one on the caller's stream while the ring FFTs of another run on a second stream and a fork of the plan).

@@ -739,6 +739,25 @@ int pl_map2phase(pl_plan *p, int spin, const double *map, double *phase, void *s
     return 0;
 }
 
+// pl_map2alm on device arrays whose addresses are read from a table in DEVICE memory when the kernels run (ncomp entries: one per component, each
+// an npix map anywhere in device memory).  A captured launch (HIP graph) can then be replayed on other inputs by rewriting the table -- no copy of the
+// maps into fixed slots -- and the components of a spin transform need not be the rows of one array.  Same kernels, same arithmetic as pl_map2alm.
+int pl_map2alm_ind(pl_plan *p, int spin, const double *const *maps_ind_dev, double *alm_dev, const double *fl_dev, void *stream)
+{
+    if (p) p->dots_armed = false;  // (see pl_legendre_anal)
+    if (!p) return fail("null plan");
+    if (spin < 0 || spin > kMaxSpin) return fail("spin must be 0..3");
+    if (!maps_ind_dev || !alm_dev) return fail("pl_map2alm_ind: null pointer table / alm pointer");
+    if (spin && ensure_spin(p, spin)) return 1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (grow(p, &p->phase, &p->phase_cap, pl_plan_phase_doubles(p, spin))) return 1;
+    {
+        ProfScope ps(p, PK_FFT_ANAL, st);
+        HIPCHK(launch_map2phase(p->P, p->F, p->fs, mlim_of(p, spin), ncomp_of(spin), nullptr, p->phase, st, nullptr, maps_ind_dev));
+    }
+    return pl_legendre_anal(p, spin, p->phase, alm_dev, fl_dev, stream);
+}
+
 static int stage_fl(pl_plan *p, const double *fl, int where, hipStream_t st, const double **fl_dev)
 {
     *fl_dev = nullptr;

@@ -43,7 +43,14 @@ struct DevFFT {
     const double2 *ringc;    // [nside + 1][4] wave-uniform phase factors of ring length n = 4 q in its register class of size N (G = N / 8):
                              // e^{i pi / n}, e^{2 pi i G / n}, e^{4 pi i G / n}, e^{4 pi i N / n} (tables instead of sincos in every thread)
     FftSide A;               // class lists and band-limited Bluestein tables, shared by synthesis and analysis
+    // analysis stage only, set per launch (launch_map2phase): component c of the input is read at map_ind[c] instead of map + c npix -- a table of
+    // device pointers in device memory, dereferenced when the kernel runs: a captured launch can be replayed on other inputs (pl_map2alm_ind)
+    const double *const *map_ind = nullptr;
 };
+__device__ __forceinline__ const double *fft_input_map(const DevFFT &F, const DevPlan &P, const double *map, int comp)
+{
+    return F.map_ind ? F.map_ind[comp] : map + (int64_t)comp * P.npix;
+}
 
 // Optional inverse-noise weighting with template marginalisation folded into the generic ring-FFT kernels (the CG operator of
 // opfilt_tt.py:196-205 on the coarse multigrid grids, where every ring runs in the generic kernel):
@@ -72,7 +79,7 @@ void fft_streams_destroy(FftStreams &fs);
 hipError_t launch_phase2map(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *phase, double *map, hipStream_t st,
                             const NinvProj *W = nullptr);
 hipError_t launch_map2phase(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *map, double *phase, hipStream_t st,
-                            const NinvProj *W = nullptr);
+                            const NinvProj *W = nullptr, const double *const *map_ind = nullptr);
 // phase -> pixels -> n_inv x pixels -> phase in one launch and in place (k_ring_roundtrip): plans with fft_all_generic only
 hipError_t launch_ring_roundtrip(const DevPlan &P, const DevFFT &F, const int *mlim, int ncomp, double *phase, const double *n_inv, hipStream_t st);
 bool fft_all_generic(const DevPlan &P, const DevFFT &F);  // every ring pair runs in the generic kernel: NinvProj can be fused

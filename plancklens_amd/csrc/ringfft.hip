@@ -569,7 +569,7 @@ __global__ __launch_bounds__(NT) void k_map2phase(DevPlan P, DevFFT F, const int
     const int q = c.q;
     double *__restrict__ ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * 4;
     const double wgt = 0.5 * 4.0 * 3.14159265358979323846 / (double)P.npix;  // includes the 1/2 of the N/S split
-    const double *__restrict__ mp = map + (int64_t)comp * P.npix;
+    const double *__restrict__ mp = fft_input_map(F, P, map, comp);
     const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
     const bool has_s = os >= 0;
 
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(N / 8, 2) void k_map2phase_fast(DevPlan P, DevFFT F
     constexpr int estride = 4;  // phase array [ring pair][component][m][N re, N im, S re, S im]
     double *ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * estride;
     const double wgt = 0.5 * 4.0 * 3.14159265358979323846 / (double)P.npix;  // includes the 1/2 of the N/S split
-    const double *mp = map + (int64_t)comp * P.npix;  // no __restrict__: see k_phase2map_fast
+    const double *mp = fft_input_map(F, P, map, comp);  // no __restrict__: see k_phase2map_fast
     const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
     const bool has_s = os >= 0;
     Tw8<N> tw;
@@ -1308,7 +1308,7 @@ __global__ __launch_bounds__(256, 2) void k_map2phase_wave(DevPlan P, DevFFT F, 
     constexpr int estride = 4;
     double *ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * estride;
     const double wgt = 0.5 * 4.0 * 3.14159265358979323846 / (double)P.npix;  // includes the 1/2 of the N/S split
-    const double *mp = map + (int64_t)comp * P.npix;
+    const double *mp = fft_input_map(F, P, map, comp);
     const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
     const bool has_s = os >= 0;
     const double *mps = has_s ? mp + os : mp + on;
@@ -1611,7 +1611,7 @@ __global__ __launch_bounds__(N / 2) void k_map2phase_quad(DevPlan P, DevFFT F, c
     constexpr int estride = 4;
     double *ph = phase + ((int64_t)ip * ncomp + comp) * P.mstride * estride;
     const double wgt = 0.5 * 4.0 * 3.14159265358979323846 / (double)P.npix;  // includes the 1/2 of the N/S split
-    const double *mp = map + (int64_t)comp * P.npix;
+    const double *mp = fft_input_map(F, P, map, comp);
     const int64_t on = P.ofs_n[ip], os = P.ofs_s[ip];
     const bool has_s = os >= 0;
     Tw8<N> tw;
@@ -2178,9 +2178,15 @@ hipError_t launch_phase2map(const DevPlan &P, const DevFFT &F, const FftStreams 
 }
 
 hipError_t launch_map2phase(const DevPlan &P, const DevFFT &F, const FftStreams &fs, const int *mlim, int ncomp, const double *map,
-                            double *phase, hipStream_t st, const NinvProj *W)
+                            double *phase, hipStream_t st, const NinvProj *W, const double *const *map_ind)
 {
     if (W && W->rm && !(fft_all_generic(P, F) && W->nmodes <= kFuseModes && W->nparts >= F.A.legacy_n)) return hipErrorInvalidValue;
+    if (map_ind) {  // inputs through a pointer table in device memory (one entry per component)
+        if (W && (W->rm || W->n_inv)) return hipErrorInvalidValue;
+        DevFFT Fi = F;
+        Fi.map_ind = map_ind;
+        return launch_stage(P, Fi, fs, false, mlim, ncomp, map, phase, st, NinvProj());
+    }
     return launch_stage(P, F, fs, false, mlim, ncomp, map, phase, st, W ? *W : NinvProj());
 }
 

@@ -571,6 +571,61 @@ class library(object):
             for idx in [i for i, ent in ivfs._dev_cache.items() if ent.get('_graph_static', False)]:
                 ivfs._dev_cache.pop(idx)
 
+        # Inputs of the captured launches.  Indirect (default): the graph's analyses read their maps through a table of device addresses
+        # (shts.MapRef, pl_map2alm_ind) -- a replay on other device-resident maps rewrites 8 bytes per map instead of copying 8 npix; only host
+        # arrays (uploaded) and simulation libraries that write into buffers of the caller get slots of the graph's own.  Otherwise (filters
+        # that touch the maps before the transform, options.opts.qe_indirect off): static slots, device inputs copied into them.
+        from .filt import filt_simple as _fs
+        indirect = bool(options.opts.qe_indirect) and getattr(type(ivfs), '_mask', None) is getattr(_fs._iso_filter_mixin, '_mask', False)
+        if isinstance(st['graph'], torch.cuda.CUDAGraph):
+            indirect = st.get('indirect', False)  # (as captured)
+
+        def own_slot(k):
+            own = st.setdefault('own', {})
+            if k not in own:
+                own[k] = torch.empty(npix, dtype=torch.float64, device=dev.device())
+            return own[k]
+
+        def fill_indirect():
+            addrs, hold = list(st['addr']), []
+            if into:
+                k = 0
+                for idx in (idx0, idx1):
+                    if 't' in self._PAIR_FIELDS[fam]:
+                        sim_lib.get_sim_tmap_into(idx, own_slot(k))
+                        addrs[k] = own_slot(k).data_ptr()
+                        k += 1
+                    if 'q' in self._PAIR_FIELDS[fam]:
+                        sim_lib.get_sim_pmap_into(idx, own_slot(k), own_slot(k + 1))
+                        addrs[k], addrs[k + 1] = own_slot(k).data_ptr(), own_slot(k + 1).data_ptr()
+                        k += 2
+            else:
+                for k, m in enumerate(maps):
+                    if isinstance(m, torch.Tensor) and m.is_cuda and m.dtype == torch.float64 and m.is_contiguous() and m.data_ptr() % 16 == 0:
+                        t = m.reshape(-1)
+                        addrs[k] = t.data_ptr()
+                        hold.append(t)  # alive until the next pair's inputs are in place: the replay that reads it is enqueued by then
+                    elif isinstance(m, torch.Tensor):
+                        own_slot(k).copy_(m.reshape(-1), non_blocking=True)
+                        addrs[k] = own_slot(k).data_ptr()
+                    else:
+                        own_slot(k).copy_(torch.from_numpy(np.ascontiguousarray(m, dtype=np.float64).reshape(-1)))
+                        addrs[k] = own_slot(k).data_ptr()
+            if addrs != st['addr']:
+                ring = st.setdefault('ptab_host', [])
+                j = st['ptab_next'] = (st.get('ptab_next', -1) + 1) % 4
+                if len(ring) <= j:
+                    ring.append([torch.empty(nslots, dtype=torch.int64, pin_memory=True), None])
+                h, ev = ring[j]
+                if ev is not None:
+                    ev.synchronize()  # (four pairs ago: long done)
+                h.copy_(torch.tensor(addrs, dtype=torch.int64))
+                st['ptab'].copy_(h, non_blocking=True)
+                ring[j][1] = torch.cuda.Event()
+                ring[j][1].record()
+                st['addr'] = addrs
+            st['held'] = hold
+
         def fill(slots):
             """input maps into the static slots.  A device tensor that a `stable_maps` simulation library hands out again (same
             storage, shape and version: maps resident in HBM) is already there from the last replay; host arrays are uploaded straight
@@ -604,15 +659,22 @@ class library(object):
                 return self._pair_body(fam, idx0, idx1, dmaps)[0]
             try:
                 evict()
-                # static input slots: per simulation [T] and / or the two rows of one (2, npix) array for (Q, U)
-                st['in'], st['tags'] = [], [None] * nslots
-                for _ in range(2):
-                    if 't' in self._PAIR_FIELDS[fam]:
-                        st['in'].append(torch.empty(npix, dtype=torch.float64, device=dev.device()))
-                    if 'q' in self._PAIR_FIELDS[fam]:
-                        qu = torch.empty((2, npix), dtype=torch.float64, device=dev.device())
-                        st['in'] += [qu[0], qu[1]]
-                fill(st['in'])
+                st['indirect'] = indirect
+                if indirect:  # inputs through a pointer table: entries = the slot order of _pair_inputs
+                    st['ptab'] = torch.zeros(nslots, dtype=torch.int64, device=dev.device())
+                    st['addr'] = [0] * nslots
+                    st['in'] = [shts.MapRef(st['ptab'], k, npix) for k in range(nslots)]
+                    fill_indirect()
+                else:
+                    # static input slots: per simulation [T] and / or the two rows of one (2, npix) array for (Q, U)
+                    st['in'], st['tags'] = [], [None] * nslots
+                    for _ in range(2):
+                        if 't' in self._PAIR_FIELDS[fam]:
+                            st['in'].append(torch.empty(npix, dtype=torch.float64, device=dev.device()))
+                        if 'q' in self._PAIR_FIELDS[fam]:
+                            qu = torch.empty((2, npix), dtype=torch.float64, device=dev.device())
+                            st['in'] += [qu[0], qu[1]]
+                    fill(st['in'])
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 gc_was_on = gc.isenabled()
@@ -643,7 +705,9 @@ class library(object):
                 return self._pair_body(fam, idx0, idx1, self._pair_dev_maps(fam, maps))[0]
         evict()
         if st.pop('first', False):
-            pass  # (the slots were filled for the capture)
+            pass  # (the inputs were put in place for the capture)
+        elif st.get('indirect', False):
+            fill_indirect()
         else:
             fill(st['in'])
         st['graph'].replay()

@@ -464,6 +464,38 @@ def _anal(spin, maps, lmax, fl=None):
     return out
 
 
+class MapRef(object):
+    """An input map of an analysis that is read THROUGH a table of device addresses (pl_map2alm_ind): entry `k` of `table` (a device int64
+    tensor) holds the address of an npix float64 map when the kernels run.  What a captured HIP graph takes as its input so that a replay can
+    serve other maps without copying them into fixed slots (qest.library._pair_graph); map2alm / map2alm_spin accept it in place of a tensor
+    ((Q, U) as two consecutive entries of one table)."""
+
+    def __init__(self, table, k, npix):
+        assert isinstance(table, torch.Tensor) and table.is_cuda and table.dtype == torch.int64 and table.is_contiguous() and 0 <= k < table.numel()
+        self.table, self.k, self.npix = table, int(k), int(npix)
+
+    def __len__(self):
+        return self.npix
+
+    def numel(self):
+        return self.npix
+
+    def ptr(self):
+        """address of the table entry (what pl_map2alm_ind takes)"""
+        return ctypes.c_void_p(self.table.data_ptr() + 8 * self.k)
+
+
+def _anal_ind(spin, refs, lmax, fl=None):
+    ncomp = 1 if spin == 0 else 2
+    assert len(refs) == ncomp and all(isinstance(r, MapRef) for r in refs)
+    assert ncomp == 1 or (refs[1].table is refs[0].table and refs[1].k == refs[0].k + 1 and refs[1].npix == refs[0].npix), 'the components of a spin transform are consecutive entries of one table'
+    plan = get_plan(npix2nside(refs[0].npix), lmax)
+    f = _fl_arg(fl, lmax, True)
+    out = torch.empty((ncomp, plan.nalm) if ncomp == 2 else (plan.nalm,), dtype=torch.complex128, device=refs[0].table.device)
+    _lib.check(_lib.lib().pl_map2alm_ind(plan.h, int(spin), refs[0].ptr(), _ptr(out), _ptr(f), _stream()))
+    return out
+
+
 def _stack(pair):
     if _is_dev(pair):
         return pair
@@ -499,6 +531,10 @@ def map2alm(m, lmax=None, mmax=None, iter=0, pol=False, use_weights=False, fl=No
     pol=True takes [T, Q, U] (opfilt_tp.py:281)."""
     assert iter == 0, 'only iter=0 is implemented: every reference call passes iter=0 (SURVEY.md Appendix A.2)'
     assert not use_weights
+    if isinstance(m, MapRef):
+        lmax = 3 * npix2nside(m.npix) - 1 if lmax is None else lmax
+        assert mmax is None or mmax == lmax
+        return _anal_ind(0, [m], lmax, fl=fl)
     if pol or (not _is_dev(m) and np.ndim(m) == 2 and len(m) == 3) or (_is_dev(m) and m.dim() == 2 and m.shape[0] == 3):
         t = map2alm(m[0], lmax=lmax, iter=0)
         lm = Alm.getlmax(t.numel() if _is_dev(t) else t.size)
@@ -589,6 +625,11 @@ def map2alm_spin(maps, spin, lmax=None, mmax=None, fl=None):
     """hp.map2alm_spin (shts.py:26-30): the 4 pi / npix weighted adjoint of alm2map_spin; returns [G, C]."""
     assert spin > 0, spin
     assert len(maps) == 2
+    if isinstance(maps[0], MapRef):
+        lmax = 3 * npix2nside(maps[0].npix) - 1 if lmax is None else lmax
+        assert mmax is None or mmax == lmax
+        out = _anal_ind(int(spin), list(maps), lmax, fl=fl)
+        return [out[0], out[1]]
     m = _stack(maps)
     npix = m.shape[1]
     if lmax is None:

@@ -234,23 +234,29 @@ def test_paired_simulations_equal_single_evaluations(setup, tmp_path):
     assert relrms(res['pair'][5], g['dd_p_p_0']) < TOL and relrms(res['pair'][9], g['dd_ptt_0']) < TOL and relrms(res['pair'][11], g['dd_xtt_0']) < TOL
 
 
-def test_pair_graph_replay_equals_eager(setup, tmp_path):
+@pytest.mark.parametrize('route', ['indirect_host', 'indirect_device', 'slots_device'])
+def test_pair_graph_replay_equals_eager(setup, tmp_path, route, monkeypatch):
     """qest.library._pair_graph: a pair of reconstructions (filter -> legs -> product -> analysis) captured into one HIP graph after
     `graph_after` eager evaluations and replayed from then on.  Eager evaluations, the capturing call and pure replays must give the
     same gradient / curl / mean field bit for bit, for all three paired families, with inputs that change between replays; the
-    filtered alms of a replayed pair stay available to further keys (filter-library device cache) until the next replay."""
+    filtered alms of a replayed pair stay available to further keys (filter-library device cache) until the next replay.
+    Routes of the inputs into the captured launches (round 6): through a table of device addresses (pl_map2alm_ind, the default) with host
+    arrays (uploaded into slots of the graph's own) or with device tensors that are new objects at new addresses on every call (the table is
+    rewritten, nothing is copied); and the static-slot route (options.opts.qe_indirect off: device tensors copied into fixed slots)."""
     import torch
-    from plancklens_amd import qest
+    from plancklens_amd import dev, options, qest
     from plancklens_amd.filt import filt_simple
     g, cl = setup[0], setup[4]
     nside, lmax_qlm = int(g['nside']), int(g['lmax_qlm'])
+    monkeypatch.setattr(options.opts, 'qe_indirect', route != 'slots_device')
+    on_dev = (lambda a: dev.to_dev(np.ascontiguousarray(a))) if route != 'indirect_host' else (lambda a: a)
 
     class sims(_gold_sims):  # more simulations out of the two golden ones (2, 3, ...: fields of either, rescaled)
         def get_sim_tmap(self, idx):
-            return self.g['tmap_%d' % (idx % 2)] * (1. + 0.25 * (idx // 2))
+            return on_dev(self.g['tmap_%d' % (idx % 2)] * (1. + 0.25 * (idx // 2)))
 
         def get_sim_pmap(self, idx):
-            return self.g['qmap_%d' % ((idx + idx // 2) % 2)], self.g['umap_%d' % (idx % 2)] * (1. - 0.125 * (idx // 2))
+            return on_dev(self.g['qmap_%d' % ((idx + idx // 2) % 2)]), on_dev(self.g['umap_%d' % (idx % 2)] * (1. - 0.125 * (idx // 2)))
 
     def make(tag, use_graph):
         ivfs = filt_simple.library_fullsky_sepTP(str(tmp_path / ('ivfs_' + tag)), sims(g), nside, g['transf'], cl, g['ftl'], g['fel'], g['fbl'], cache=False)
@@ -275,6 +281,9 @@ def test_pair_graph_replay_equals_eager(setup, tmp_path):
                 assert np.array_equal(a, b), (fam, rep, pair)
         st = [v for (f_, _, _), v in qg._pair_graphs.items() if f_ == fam]
         assert len(st) == 1 and isinstance(st[0]['graph'], torch.cuda.CUDAGraph) and st[0]['calls'] == 2, (fam, st)
+        assert st[0]['indirect'] == (route != 'slots_device')
+        if route == 'indirect_device':
+            assert not st[0].get('own'), 'device-resident inputs are read in place: no slot of the graph\'s own'
     # after the last replay of ('ptt', (6, 7)) the filtered T alms of 6 and 7 are cache entries of the filter library (static buffers of the
     # graph): a further key for those simulations reuses them, and its result is the eager library's
     assert ivfs_g._dev_cache[7].get('_graph_static') and 't' in ivfs_g._dev_cache[7]

@@ -188,3 +188,35 @@ def test_scalar_synthesis_of_two_inputs_equals_the_single_transforms(nside, lmax
         for i in range(2):
             one = shts.alm2map(a[i].contiguous(), nside, lmax=lmax, fl=f)
             assert both[i].shape == one.shape and bool((both[i] == one).all()), (nside, lmax, i, f is None)
+
+
+@pytest.mark.parametrize('nside,lmax', [(16, 32), (256, 512), (1024, 1024), (2048, 2048)])
+def test_analysis_through_a_table_of_device_addresses(nside, lmax):
+    """pl_map2alm_ind / shts.MapRef: the analysis kernels read component c of their input at table[c] (a device address, dereferenced when
+    the kernel runs) instead of map + c npix.  Same kernels: alm bit-identical to map2alm / map2alm_spin on the same maps, for every
+    ring-FFT kernel family (generic, register, quad, wavefront-private); (Q, U) need not be rows of one array; rewriting the table
+    re-points an already recorded call at other maps."""
+    import torch
+    from plancklens_amd import shts
+    rng = np.random.default_rng(nside)
+    npix = 12 * nside ** 2
+    maps = [torch.from_numpy(rng.standard_normal(npix)).cuda() for _ in range(4)]  # four separate allocations
+    table = torch.zeros(3, dtype=torch.int64, device='cuda')
+    refs = [shts.MapRef(table, k, npix) for k in range(3)]
+    assert len(refs[0]) == npix and refs[1].numel() == npix
+
+    def point(ms):
+        table.copy_(torch.tensor([m.data_ptr() for m in ms], dtype=torch.int64))
+    point(maps[:3])
+    t = shts.map2alm(refs[0], lmax=lmax, iter=0)
+    assert bool((t == shts.map2alm(maps[0], lmax=lmax, iter=0)).all())
+    fl = 1. / (1. + np.arange(lmax + 1.))
+    for spin in (1, 2):
+        g, c = shts.map2alm_spin([refs[1], refs[2]], spin, lmax, fl=fl)
+        g0, c0 = shts.map2alm_spin([maps[1], maps[2]], spin, lmax, fl=fl)
+        assert bool((g == g0).all()) and bool((c == c0).all()), (nside, spin)
+    point([maps[3], maps[0], maps[3]])  # the same recorded references, other maps
+    assert bool((shts.map2alm(refs[0], lmax=lmax, iter=0) == shts.map2alm(maps[3], lmax=lmax, iter=0)).all())
+    g, c = shts.map2alm_spin([refs[1], refs[2]], 2, lmax)
+    g0, c0 = shts.map2alm_spin([maps[0], maps[3]], 2, lmax)
+    assert bool((g == g0).all()) and bool((c == c0).all())

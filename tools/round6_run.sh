@@ -23,3 +23,12 @@ fi
 if [[ $WHAT == *probe2* ]]; then
   for o in 210 102 012; do timeout 300 tools/probes/seam_probe 189 $o; done > gpurun_out/$TAG/seam_probe_orders.txt 2>&1; cat gpurun_out/$TAG/seam_probe_orders.txt
 fi
+if [[ $WHAT == *benchslots* ]]; then
+  # the headline with its inputs copied into static slots (the route of rounds 5 / 6a-d) against the address-table route, same box, QE leg only
+  for rep in 1 2; do for o in 1 0; do
+    PLENS_OPTIONS=qe_indirect=$o timeout 600 python3 bench.py --no-cg --no-cpu-baseline --no-from-sims --no-plan-stats --steps 20 --warmup 4 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][0])
+print('qe_indirect=$o: %.3f ms/step = %.2f rec/s (eager pass %.3f ms), resident map sets %d, selfcheck %s' % (d['ms_per_step'], d['value'], d['eager_pass']['ms_per_step'], d['config']['resident_map_sets'], d['selfcheck_max_abs_diff']))"
+  done; done > gpurun_out/$TAG/bench_indirect_ab.txt 2>&1; cat gpurun_out/$TAG/bench_indirect_ab.txt
+fi
