@@ -576,7 +576,7 @@ class library(object):
         # arrays (uploaded) and simulation libraries that write into buffers of the caller get slots of the graph's own.  Otherwise (filters
         # that touch the maps before the transform, options.opts.qe_indirect off): static slots, device inputs copied into them.
         from .filt import filt_simple as _fs
-        indirect = bool(options.opts.qe_indirect) and getattr(type(ivfs), '_mask', None) is getattr(_fs._iso_filter_mixin, '_mask', False)
+        indirect = bool(options.opts.qe_indirect) and getattr(type(ivfs), '_mask', None) is _fs.library_fullsky_sepTP._mask  # (the maps go straight into the transforms)
         if isinstance(st['graph'], torch.cuda.CUDAGraph):
             indirect = st.get('indirect', False)  # (as captured)
 
