@@ -2,7 +2,8 @@
 nside = lmax = lmax_qlm = 2048 on MI355X, and CG iterations per second of the qcinv Wiener filter (BASELINE.json metric;
 SURVEY.md 8(d)).
 
-One step = one reconstruction = T, Q, U maps (resident in HBM) -> isotropic inverse-variance filter
+One step = one reconstruction = T, Q, U maps (resident in HBM: `--resident-sets` distinct realisations, default 2, consecutive pairs of
+simulations are served different ones) -> isotropic inverse-variance filter
 (filt_simple.py:397-407) -> qest.library_sepTP.get_sim_qlm('p') -> gradient + curl alm copied to host memory.
 9 spherical harmonic transforms per step (2 scalar + 7 spin-weighted pairs), all FP64.
 
