@@ -32,3 +32,6 @@ d=json.loads([l for l in sys.stdin if l.startswith('{')][0])
 print('qe_indirect=$o: %.3f ms/step = %.2f rec/s (eager pass %.3f ms), resident map sets %d, selfcheck %s' % (d['ms_per_step'], d['value'], d['eager_pass']['ms_per_step'], d['config']['resident_map_sets'], d['selfcheck_max_abs_diff']))"
   done; done > gpurun_out/$TAG/bench_indirect_ab.txt 2>&1; cat gpurun_out/$TAG/bench_indirect_ab.txt
 fi
+if [[ $WHAT == *configs* ]]; then
+  timeout 1200 bash tools/bench_configs.sh > gpurun_out/$TAG/bench_configs.log 2>&1; cat gpurun_out/$TAG/bench_configs.log
+fi
