@@ -22,12 +22,13 @@ import threading
 
 
 class Options(object):
-    __slots__ = ('batch2', 'qe_graph', 'qe_indirect', 'async_d2h', 'd2h_blocks', 'cg_graph', 'cg_merged', 'cg_post_dots', 'tp_concurrent', 'tp_pace', 'cg_batch',
+    __slots__ = ('batch2', 'qe_graph', 'qe_graph_min_nside', 'qe_indirect', 'async_d2h', 'd2h_blocks', 'cg_graph', 'cg_merged', 'cg_post_dots', 'tp_concurrent', 'tp_pace', 'cg_batch',
                  'tproj_harm', 'tproj_md', 'dense_block', 'debug')
 
     def __init__(self):
         self.batch2 = True        # estimator: the same spin synthesis of two simulations on one recursion (pl_alm2map_batch2 / _grad_pair)
         self.qe_graph = True      # estimator: a pair of reconstructions as one replayed HIP graph (qest.library._pair_graph)
+        self.qe_graph_min_nside = 1024  # ... on grids of at least this nside: below, a pair's ~400 launches cost the host less eagerly than one hipGraphLaunch of as many nodes
         self.qe_indirect = True   # ... its input maps read through a table of device addresses (pl_map2alm_ind) instead of copied into static slots
         self.async_d2h = True     # estimator: results cross PCIe on a copy stream, handed out as futures
         self.d2h_blocks = 64      # workgroups of the device -> pinned-host copy kernel

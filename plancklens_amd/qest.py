@@ -495,6 +495,7 @@ class library(object):
     # code is the eager code (`_pair_body`), so the results are the eager ones bit for bit (tests/test_gpu_qe.py, test_gpu_fullsize.py).
     # The reference has no counterpart: its loop (qest.py:238-244, examples/run_qlms.py:66-74) is CPU code.
     use_graph = True   # per instance; options.opts.qe_graph = False switches the route off for the process
+    graph_min_nside = None  # smallest grid served through the replayed graph (None: options.opts.qe_graph_min_nside); see _pair_graph_ok
     graph_fallbacks = 0  # captures of this library that failed and fell back to eager launches for good (process totals: options.stats)
     graph_after = 2    # eager pair evaluations before the capture (workspaces grown, filters uploaded, code objects loaded)
 
@@ -508,6 +509,12 @@ class library(object):
             return False
         # the filter must be a pure device function of the maps: isotropic filter classes without a file cache or a starting-point library
         if not (hasattr(ivfs, '_apply_ivf_t') and hasattr(ivfs, '_apply_ivf_p') and hasattr(ivfs, '_dev_entry') and hasattr(ivfs, 'nside')):
+            return False
+        # Small grids stay eager: one hipGraphLaunch of a pair's ~400 nodes costs the host about what 400 launches cost, and at nside 512 the
+        # host, not the GPU, is what a pair waits for (BASELINE config 1: 0.72 ms per reconstruction eager, 0.79-0.93 replayed; from nside
+        # 1024 on the GPU work of a pair is >= 6 ms and the replay's immunity to a busy host is what counts).
+        min_nside = options.opts.qe_graph_min_nside if self.graph_min_nside is None else self.graph_min_nside
+        if ivfs.nside < min_nside:
             return False
         if getattr(ivfs, 'cache', True) or getattr(ivfs, 'soltn_lib', None) is not None or not hasattr(ivfs, 'sim_lib'):
             return False

@@ -403,6 +403,7 @@ def _estimators_vs_oracle(tmp_path, nside, keys, seed=11, pair_check=()):
         ivfs2 = filt_simple.library_fullsky_sepTP(str(tmp_path / ('ivfs2' + key)), sims(), nside, transf, cls, fl, fel, fbl, cache=False)
         ql2 = qest.library_sepTP(str(tmp_path / ('ql2' + key)), ivfs2, ivfs2, cls['te'], nside, lmax_qlm=lmax, cache=False)
         assert ql2._pair_getter(key, lmax) is not None, 'the paired route is not taken for %s' % key
+        ql2.graph_min_nside = 0  # (config 1's size is below the default threshold of the replayed route: exercised here all the same)
         # the call bench.py times, `graph_after` times eagerly, then captured into a HIP graph and replayed (qest.library._pair_graph)
         for rep in range(ql2.graph_after + 2):  # (simulations 2 r and 2 r + 1 are simulations 0 and 1 again, under indices not seen before)
             ql2._mem.clear()

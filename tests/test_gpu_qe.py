@@ -261,7 +261,7 @@ def test_pair_graph_replay_equals_eager(setup, tmp_path, route, monkeypatch):
     def make(tag, use_graph):
         ivfs = filt_simple.library_fullsky_sepTP(str(tmp_path / ('ivfs_' + tag)), sims(g), nside, g['transf'], cl, g['ftl'], g['fel'], g['fbl'], cache=False)
         q = qest.library_sepTP(str(tmp_path / ('q_' + tag)), ivfs, ivfs, cl['te'], nside, lmax_qlm=lmax_qlm, cache=False)
-        q.use_graph, q.graph_after = use_graph, 1
+        q.use_graph, q.graph_after, q.graph_min_nside = use_graph, 1, 0  # (the graph route also on this small grid)
         return ivfs, q
     ivfs_e, qe = make('eager', False)
     ivfs_g, qg = make('graph', True)

@@ -145,7 +145,7 @@ int main(int argc, char **argv)
     for (size_t i = 0; i < h0.size(); ++i) h0[i] = 1.0 + 1e-3 * (double)(i % 977);
     printf("seam probe: %d workgroups x %d threads, %d phases (%d seams), 8 KB strip per workgroup and phase, every read crosses workgroups; forms timed in the order %s\n", kWG,
            kThreads, nphase, nphase - 1, order);
-    printf("%8s %14s %14s %14s | %12s %12s %12s | %s\n", "work", "graph us/phase", "xcd-bar", "flat-bar", "seam(graph)", "seam(xcd)", "seam(flat)", "check");
+    printf("%8s %14s %14s %14s %14s | %12s %12s %12s | %s\n", "work", "graph us/phase", "xcd-bar", "flat-bar", "eager launches", "seam(graph)", "seam(xcd)", "seam(flat)", "check");
     double base[3] = {0, 0, 0};
     for (int work : {0, 200, 800, 2000, 4000}) {
         // (a) one kernel per phase, captured and replayed
@@ -155,17 +155,18 @@ int main(int argc, char **argv)
             hipLaunchKernelGGL(k_phase, dim3(kWG), dim3(kThreads), 0, st, p, work, (p & 1) ? B : A, (p & 1) ? A : B);
         CHK(hipStreamEndCapture(st, &g));
         CHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        double t[3];
-        for (int fi = 0; fi < 3; ++fi) {
-            const int form = order[fi] - '0';
+        double t[4];
+        for (int fi = 0; fi < 4; ++fi) {
+            const int form = fi < 3 ? order[fi] - '0' : 3;  // 3: the same kernels launched eagerly on the stream (no graph), timed last
             double best = 1e30;
             for (int r = 0; r < reps + 2; ++r) {
-                double *a = form == 0 ? A : A2, *bb = form == 0 ? B : B2;
+                double *a = (form == 0 || form == 3) ? A : A2, *bb = (form == 0 || form == 3) ? B : B2;
                 CHK(hipMemcpyAsync(a, h0.data(), nb, hipMemcpyHostToDevice, st));
                 CHK(hipMemsetAsync(bar, 0, sizeof(Bar), st));
                 CHK(hipStreamSynchronize(st));
                 auto t0 = std::chrono::steady_clock::now();
                 if (form == 0) CHK(hipGraphLaunch(ge, st));
+                else if (form == 3) { for (int p = 0; p < nphase; ++p) hipLaunchKernelGGL(k_phase, dim3(kWG), dim3(kThreads), 0, st, p, work, (p & 1) ? B : A, (p & 1) ? A : B); }
                 else if (form == 1) hipLaunchKernelGGL(k_persistent<0>, dim3(kWG), dim3(kThreads), 0, st, nphase, work, a, bb, bar);
                 else hipLaunchKernelGGL(k_persistent<1>, dim3(kWG), dim3(kThreads), 0, st, nphase, work, a, bb, bar);
                 CHK(hipStreamSynchronize(st));
@@ -173,7 +174,7 @@ int main(int argc, char **argv)
                 if (r >= 2 && us < best) best = us;
             }
             t[form] = best / nphase;
-            CHK(hipMemcpy(fin_h[form].data(), (nphase & 1) ? (form == 0 ? B : B2) : (form == 0 ? A : A2), nb, hipMemcpyDeviceToHost));
+            if (form < 3) CHK(hipMemcpy(fin_h[form].data(), (nphase & 1) ? (form == 0 ? B : B2) : (form == 0 ? A : A2), nb, hipMemcpyDeviceToHost));
         }
         // word-for-word check of the three forms' final buffers
         size_t bad = 0;
@@ -181,7 +182,7 @@ int main(int argc, char **argv)
         unsigned tmo = 0;
         CHK(hipMemcpy(&tmo, bar->timeout, sizeof(unsigned), hipMemcpyDeviceToHost));
         if (work == 0) { base[0] = t[0]; base[1] = t[1]; base[2] = t[2]; }
-        printf("%8d %14.2f %14.2f %14.2f | %12.2f %12.2f %12.2f | %s%s\n", work, t[0], t[1], t[2], base[0], base[1], base[2],
+        printf("%8d %14.2f %14.2f %14.2f %14.2f | %12.2f %12.2f %12.2f | %s%s\n", work, t[0], t[1], t[2], t[3], base[0], base[1], base[2],
                bad ? "MISMATCH (a barrier form vs graph)" : "both barrier forms == graph", tmo ? " TIMEOUT" : "");
         CHK(hipGraphExecDestroy(ge)); CHK(hipGraphDestroy(g));
     }
