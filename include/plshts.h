@@ -141,6 +141,9 @@ int pl_map2alm(pl_plan *plan, int spin, const double *map, double *alm, const do
  * no copy into fixed input slots (qest.library._pair_graph) -- and (Q, U) need not be the rows of one array.  Device pointers only; same kernels and
  * arithmetic as pl_map2alm (hp.map2alm(_spin)(..., iter=0), shts.py:16-30), bit-identical results. */
 int pl_map2alm_ind(pl_plan *plan, int spin, const double *const *maps_ind_dev, double *alm_dev, const double *fl_dev, void *stream);
+/* Writes n <= 8 device addresses (a HOST array, read before the call returns: passed to the kernel by value) into the table `table_dev` that
+ * pl_map2alm_ind reads, by a one-workgroup kernel on `stream` (ordered like any other launch; no host buffer to keep alive). */
+int pl_store_addresses(int n, const unsigned long long *addrs, unsigned long long *table_dev, void *stream);
 
 /* Stage-level entry points: tests, stage timings, and callers that pipeline independent transforms (the Legendre stage of
  * one on the caller's stream while the ring FFTs of another run on a second stream and a fork of the plan).

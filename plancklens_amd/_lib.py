@@ -11,7 +11,7 @@ from . import _build
 _LIB = None
 
 SYMBOLS = ['pl_version', 'pl_last_error', 'pl_device_count', 'pl_plan_create', 'pl_plan_create_opts', 'pl_plan_fork', 'pl_plan_destroy', 'pl_plan_npix',
-           'pl_plan_nalm', 'pl_plan_bytes', 'pl_plan_side_stream', 'pl_plan_executed_steps', 'pl_plan_useful_steps', 'pl_plan_create_shard', 'pl_phase_pack', 'pl_phase_unpack', 'pl_phase_pack_doubles', 'pl_alm_keep_mgroups', 'pl_map_pack_doubles', 'pl_map_pack_rings', 'pl_map_unpack_rings', 'pl_alm2map', 'pl_alm2map_grad', 'pl_alm2map_pair', 'pl_alm2map_batch2', 'pl_alm2map_grad_pair', 'pl_map2alm', 'pl_map2alm_ind', 'pl_plan_phase_doubles', 'pl_legendre_synth', 'pl_legendre_synth_grad',
+           'pl_plan_nalm', 'pl_plan_bytes', 'pl_plan_side_stream', 'pl_plan_executed_steps', 'pl_plan_useful_steps', 'pl_plan_create_shard', 'pl_phase_pack', 'pl_phase_unpack', 'pl_phase_pack_doubles', 'pl_alm_keep_mgroups', 'pl_map_pack_doubles', 'pl_map_pack_rings', 'pl_map_unpack_rings', 'pl_alm2map', 'pl_alm2map_grad', 'pl_alm2map_pair', 'pl_alm2map_batch2', 'pl_alm2map_grad_pair', 'pl_map2alm', 'pl_map2alm_ind', 'pl_store_addresses', 'pl_plan_phase_doubles', 'pl_legendre_synth', 'pl_legendre_synth_grad',
            'pl_legendre_anal', 'pl_phase2map', 'pl_map2phase', 'pl_almxfl', 'pl_alm2cl', 'pl_alm_copy', 'pl_axpy',
            'pl_alm_dot', 'pl_axpy_dev', 'pl_alm_splice', 'pl_alm_splice_fl', 'pl_cg_dot_axpy', 'pl_almxfl_add', 'pl_alm_lincomb', 'pl_template_project', 'pl_cg_fwd_tt', 'pl_cg_fwd_pp', 'pl_gemv', 'pl_gemv_split', 'pl_gemv_split_dot', 'pl_gemv_split_dot_count', 'pl_alm_splice_dot_b', 'pl_alm_splice_dot_count', 'pl_copy_slim',
            'pl_almxfl_b', 'pl_alm_copy_b', 'pl_alm_splice_b', 'pl_almxfl_add_b', 'pl_alm_dot_b', 'pl_axpy_dev_b', 'pl_cg_dot_axpy_b', 'pl_post_dots_count', 'pl_plan_arm_post_dots', 'pl_cg_axpy_pre_b', 'pl_template_project_b', 'pl_lowrank_update_b',
@@ -77,6 +77,7 @@ def lib():
     L.pl_legendre_synth_grad.argtypes = [vp, i32, vp, vp, vp, vp]
     L.pl_map2alm.argtypes = [vp, i32, vp, vp, vp, i32, vp]
     L.pl_map2alm_ind.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.pl_store_addresses.argtypes = [i32, ctypes.POINTER(ctypes.c_uint64), vp, vp]
     L.pl_legendre_synth.argtypes = [vp, i32, vp, vp, vp, vp]
     L.pl_legendre_anal.argtypes = [vp, i32, vp, vp, vp, vp]
     L.pl_phase2map.argtypes = [vp, i32, vp, vp, vp]

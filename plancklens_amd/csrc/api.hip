@@ -68,6 +68,7 @@ void launch_gemv_split(int nf, int64_t lda, const double *A, const double *const
                        double *const *out, hipStream_t st, const double *const *dot_q = nullptr, int dot_lmin = 0, double *dot_pre = nullptr);
 void launch_gemv_nb(int nrows, int ncols, int64_t lda, const double *A, int nb, const double *x, double *y, hipStream_t st);
 void launch_copy_slim(const double *src, double *dst, int64_t ndoubles, int nblocks, hipStream_t st);
+void launch_store_addresses(int n, const unsigned long long *vals, unsigned long long *dst, hipStream_t st);
 void launch_map_mul(int64_t n, const double *a, const double *b, double *out, hipStream_t st);
 void launch_map_qu_weight(int64_t n, double *q, double *u, const double *nqq, const double *nqu, const double *nuu, hipStream_t st, int nb = 1,
                           int64_t bstride = 0);
@@ -1505,6 +1506,16 @@ int pl_copy_slim(const double *src_dev, double *dst, int64_t ndoubles, int nbloc
     if (((reinterpret_cast<uintptr_t>(src_dev) | reinterpret_cast<uintptr_t>(dst)) & 15) != 0) return fail("pl_copy_slim: pointers must be 16-byte aligned");
     if (ndoubles == 0) return 0;
     launch_copy_slim(src_dev, dst, ndoubles, nblocks, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// The table of pl_map2alm_ind: n <= 8 device addresses (given by value: `addrs` is a host array read before the call returns) stored to table_dev by a
+// one-workgroup kernel on `stream` -- ordered after whatever still reads the old entries, before whatever reads the new ones.
+int pl_store_addresses(int n, const unsigned long long *addrs, unsigned long long *table_dev, void *stream)
+{
+    if (n < 1 || n > 8 || !addrs || !table_dev) return fail("pl_store_addresses: 1 <= n <= 8 addresses, non-null pointers");
+    launch_store_addresses(n, addrs, table_dev, static_cast<hipStream_t>(stream));
     HIPCHK(hipGetLastError());
     return 0;
 }

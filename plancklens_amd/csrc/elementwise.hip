@@ -1131,6 +1131,19 @@ void launch_template_project_md(const DevPlan &P, int nb, double *t, const doubl
     hipLaunchKernelGGL(k_tproj_md_reduce, dim3(nb), dim3(256), 0, st, P.npairs, scratch, pinv, d);
     hipLaunchKernelGGL(k_tproj_md_apply, dim3(P.npairs, nchunk), dim3(256), 0, st, P, nb, t, n_inv, d);
 }
+// up to 8 device addresses, passed BY VALUE in the kernel arguments, written to a table in device memory (pl_store_addresses): stream-ordered like any
+// kernel, no host buffer whose lifetime the caller would have to manage
+struct AddrList { unsigned long long a[8]; };
+__global__ void k_store_addresses(AddrList v, int n, unsigned long long *__restrict__ dst)
+{
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = v.a[threadIdx.x];
+}
+void launch_store_addresses(int n, const unsigned long long *vals, unsigned long long *dst, hipStream_t st)
+{
+    AddrList v = {};
+    for (int i = 0; i < n && i < 8; ++i) v.a[i] = vals[i];
+    hipLaunchKernelGGL(k_store_addresses, dim3(1), dim3(64), 0, st, v, n, dst);
+}
 void launch_copy_slim(const double *src, double *dst, int64_t ndoubles, int nblocks, hipStream_t st)
 {
     const int64_t n2 = ndoubles / 2;

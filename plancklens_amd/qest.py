@@ -619,17 +619,8 @@ class library(object):
                         own_slot(k).copy_(torch.from_numpy(np.ascontiguousarray(m, dtype=np.float64).reshape(-1)))
                         addrs[k] = own_slot(k).data_ptr()
             if addrs != st['addr']:
-                ring = st.setdefault('ptab_host', [])
-                j = st['ptab_next'] = (st.get('ptab_next', -1) + 1) % 4
-                if len(ring) <= j:
-                    ring.append([torch.empty(nslots, dtype=torch.int64, pin_memory=True), None])
-                h, ev = ring[j]
-                if ev is not None:
-                    ev.synchronize()  # (four pairs ago: long done)
-                h.copy_(torch.tensor(addrs, dtype=torch.int64))
-                st['ptab'].copy_(h, non_blocking=True)
-                ring[j][1] = torch.cuda.Event()
-                ring[j][1].record()
+                # (by a one-workgroup kernel that takes the addresses by value: stream-ordered behind the previous replay, nothing on the host to keep alive)
+                shts.store_addresses(addrs, st['ptab'])
                 st['addr'] = addrs
             st['held'] = hold
 

@@ -485,6 +485,14 @@ class MapRef(object):
         return ctypes.c_void_p(self.table.data_ptr() + 8 * self.k)
 
 
+def store_addresses(addrs, table):
+    """device addresses (python ints, at most 8) -> the first entries of `table` (device int64) on the current stream (pl_store_addresses)"""
+    n = len(addrs)
+    assert 1 <= n <= 8 and table.numel() >= n and table.dtype == torch.int64 and table.is_cuda
+    arr = (ctypes.c_uint64 * n)(*[int(a) for a in addrs])
+    _lib.check(_lib.lib().pl_store_addresses(n, arr, ctypes.c_void_p(table.data_ptr()), _stream()))
+
+
 def _anal_ind(spin, refs, lmax, fl=None):
     ncomp = 1 if spin == 0 else 2
     assert len(refs) == ncomp and all(isinstance(r, MapRef) for r in refs)

@@ -206,7 +206,7 @@ def test_analysis_through_a_table_of_device_addresses(nside, lmax):
     assert len(refs[0]) == npix and refs[1].numel() == npix
 
     def point(ms):
-        table.copy_(torch.tensor([m.data_ptr() for m in ms], dtype=torch.int64))
+        shts.store_addresses([m.data_ptr() for m in ms], table)  # (pl_store_addresses: a kernel on the stream, addresses by value)
     point(maps[:3])
     t = shts.map2alm(refs[0], lmax=lmax, iter=0)
     assert bool((t == shts.map2alm(maps[0], lmax=lmax, iter=0)).all())

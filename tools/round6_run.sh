@@ -12,7 +12,7 @@ if [[ $WHAT == *bench* ]]; then
   timeout 900 python3 bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err; echo "bench rc $?"; head -c 1500 gpurun_out/$TAG/bench.json; echo
 fi
 if [[ $WHAT == *tests* ]]; then
-  timeout ${TEST_TIMEOUT:-3000} python3 -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-} > gpurun_out/$TAG/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -15 gpurun_out/$TAG/pytest_gpu.log
+  timeout ${TEST_TIMEOUT:-3000} python3 -m pytest ${PYTEST_PATHS:-tests} -m gpu -x -q ${PYTEST_ARGS:-} > gpurun_out/$TAG/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -15 gpurun_out/$TAG/pytest_gpu.log
 fi
 if [[ $WHAT == *s0pair* ]]; then
   for sz in "2048 2048" "1024 1024" "4096 4096"; do timeout 300 python3 tools/s0_pair_ab.py $sz 10; done > gpurun_out/$TAG/s0_pair_ab.txt 2>&1; cat gpurun_out/$TAG/s0_pair_ab.txt
