@@ -28,7 +28,7 @@ class Options(object):
     def __init__(self):
         self.batch2 = True        # estimator: the same spin synthesis of two simulations on one recursion (pl_alm2map_batch2 / _grad_pair)
         self.qe_graph = True      # estimator: a pair of reconstructions as one replayed HIP graph (qest.library._pair_graph)
-        self.qe_graph_min_nside = 1024  # ... on grids of at least this nside: below, a pair's ~400 launches cost the host less eagerly than one hipGraphLaunch of as many nodes
+        self.qe_graph_min_nside = 0   # ... on grids of at least this nside (0: every grid; at nside 512 eager launches and the replay are equal within the noise of a shared host)
         self.qe_indirect = True   # ... its input maps read through a table of device addresses (pl_map2alm_ind) instead of copied into static slots
         self.async_d2h = True     # estimator: results cross PCIe on a copy stream, handed out as futures
         self.d2h_blocks = 64      # workgroups of the device -> pinned-host copy kernel

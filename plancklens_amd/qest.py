@@ -510,9 +510,9 @@ class library(object):
         # the filter must be a pure device function of the maps: isotropic filter classes without a file cache or a starting-point library
         if not (hasattr(ivfs, '_apply_ivf_t') and hasattr(ivfs, '_apply_ivf_p') and hasattr(ivfs, '_dev_entry') and hasattr(ivfs, 'nside')):
             return False
-        # Small grids stay eager: one hipGraphLaunch of a pair's ~400 nodes costs the host about what 400 launches cost, and at nside 512 the
-        # host, not the GPU, is what a pair waits for (BASELINE config 1: 0.72 ms per reconstruction eager, 0.79-0.93 replayed; from nside
-        # 1024 on the GPU work of a pair is >= 6 ms and the replay's immunity to a busy host is what counts).
+        # A size threshold for the replayed route (default 0: none).  One hipGraphLaunch of a pair's ~400 nodes costs the host about what 400
+        # launches cost, so at nside 512 (1.4 ms of GPU work per pair) the two routes are equal within the noise of a shared host: 0.90-0.94 ms per
+        # reconstruction eager, 0.77-1.29 replayed (profiles/round6_h_small_inputs_ab.txt); from nside 1024 on the replay's immunity to a busy host counts.
         min_nside = options.opts.qe_graph_min_nside if self.graph_min_nside is None else self.graph_min_nside
         if ivfs.nside < min_nside:
             return False
