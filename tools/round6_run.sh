@@ -35,3 +35,6 @@ fi
 if [[ $WHAT == *configs* ]]; then
   timeout 1200 bash tools/bench_configs.sh > gpurun_out/$TAG/bench_configs.log 2>&1; cat gpurun_out/$TAG/bench_configs.log
 fi
+if [[ $WHAT == *twostreams* ]]; then
+  timeout 900 python3 tools/qe_two_streams.py 2048 5 > gpurun_out/$TAG/qe_two_streams.txt 2>&1; tail -5 gpurun_out/$TAG/qe_two_streams.txt
+fi
