@@ -2,7 +2,6 @@
 (complex128) in HBM; the arithmetic is done by the HIP kernels of plancklens_amd/csrc (through shts /
 _lib), torch only allocates, copies and launches trivial element-wise glue on its current stream."""
 import ctypes
-import os
 
 import numpy as np
 import torch
